@@ -1,0 +1,233 @@
+/*
+ * metrpo.h -- C ABI of libmetrpo.so: the MI355X (gfx950) implementation of the ME-TRPO
+ * policy-optimisation inner loop (imagined rollout -> GAE -> TRPO CG/FVP update).
+ *
+ * The reference (thanard/me-trpo) is pure Python on TF1.4 + rllab and has NO FFI of its own
+ * (SURVEY.md section 2); this header therefore declares the entry points a binding for that path
+ * would need, one per reference operation, each citing the reference interface it replaces
+ * (file:line under the reference tree).  `[rllab]` marks arithmetic that lives in the reference's
+ * third-party dependency rllab (not vendored, no version pinned) and is reached at the cited
+ * call site.  INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - every pointer named `d_*` is DEVICE memory owned by the caller (e.g. torch `data_ptr()`);
+ *    the library never frees or retains it past the call, except the `set_*` calls which COPY.
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, calls return
+ *    without synchronising unless documented.  One ctx per GPU, one host thread per ctx.
+ *  - all functions return 0 (METRPO_OK) or a negative metrpo_status; no exception or abort
+ *    crosses the ABI; metrpo_last_error() gives the message for the last failure on a ctx.
+ *  - arithmetic is float32 on device (TF graph dtype of the reference); CG vectors, reductions
+ *    and advantage statistics are float64, as the reference's host-side NumPy is.
+ *  - trajectory tensors are TIME-MAJOR: element (t, b) of a [T][B][w] tensor is at
+ *    ((t*B)+b)*w.  B = parallel imagined envs (the reference's n_envs), T = steps executed.
+ */
+#ifndef METRPO_H
+#define METRPO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define METRPO_ABI_VERSION 1
+#define METRPO_MAX_LAYERS 6      /* hidden layers per MLP */
+
+typedef struct metrpo_ctx metrpo_ctx;
+
+typedef enum {
+    METRPO_OK = 0,
+    METRPO_EINVAL = -1,          /* bad dimension / argument */
+    METRPO_ENULL = -2,           /* required pointer is NULL */
+    METRPO_EHIP = -3,            /* HIP runtime error, see metrpo_last_error */
+    METRPO_EUNSUPPORTED = -4,    /* configuration exceeds this build's limits (e.g. LDS) */
+    METRPO_ESTATE = -5           /* set_dynamics / set_policy not called yet */
+} metrpo_status;
+
+/* analytic reward / termination of the env families the reference ships (envs/com_*_env.py) */
+typedef enum {
+    METRPO_ENV_SWIMMER = 0,      /* envs/com_swimmer_env.py:112-114        */
+    METRPO_ENV_HALF_CHEETAH = 1, /* envs/com_half_cheetah_env.py:72-75     */
+    METRPO_ENV_ANT = 2,          /* envs/com_ant_env.py:77-83, is_done :88-101 */
+    METRPO_ENV_HUMANOID = 3,     /* envs/com_simple_humanoid_env.py:105-109 */
+    METRPO_ENV_HOPPER = 4,       /* envs/com_hopper_env.py:94-104          */
+    METRPO_ENV_SNAKE = 5         /* envs/com_snake_env.py:81-84            */
+} metrpo_env;
+
+/* VecSimpleEnv.get_next_observation sampling modes, env_helpers.py:617-634 */
+typedef enum {
+    METRPO_SAM_STEP_RAND = 0, METRPO_SAM_EPS_RAND = 1, METRPO_SAM_MODEL_MEAN_STD = 2,
+    METRPO_SAM_MODEL_MEAN = 3, METRPO_SAM_MODEL_MED = 4, METRPO_SAM_ONE_MODEL = 5
+} metrpo_sam_mode;
+
+typedef enum { METRPO_ACT_IDENTITY = 0, METRPO_ACT_RELU = 1, METRPO_ACT_TANH = 2 } metrpo_act;
+
+/* Static shape of the problem (params/params-<env>.json keys in brackets). */
+typedef struct {
+    int32_t env;                              /* metrpo_env                                   */
+    int32_t ns, na;                           /* state / action dims                          */
+    int32_t n_models;                         /* K  [n_models]                                */
+    int32_t dyn_n_hidden;                     /* [dynamics_model.hidden_layers]               */
+    int32_t dyn_hidden[METRPO_MAX_LAYERS];
+    int32_t dyn_act[METRPO_MAX_LAYERS];       /* metrpo_act per hidden layer [.nonlinearity]  */
+    int32_t n_drop;                           /* 2: ignore_xy_input, 1: ignore_x_input, 0     */
+    int32_t pol_n_hidden;                     /* [policy.hidden_layers], tanh, identity out   */
+    int32_t pol_hidden[METRPO_MAX_LAYERS];
+} metrpo_dims;
+
+int32_t metrpo_abi_version(void);
+const char* metrpo_status_string(int32_t status);
+
+/* ---- context ------------------------------------------------------------------------------ */
+int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_dims* dims);
+int32_t metrpo_destroy(metrpo_ctx* ctx);
+const char* metrpo_last_error(const metrpo_ctx* ctx);
+/* floats per dynamics model: [W0 (n_in x h0, row-major), b0, W1, b1, ..., Wout, bout]          */
+int32_t metrpo_dyn_param_count(const metrpo_ctx* ctx);
+/* floats in the flat policy vector, [rllab] get_param_values order: W0,b0,...,Wout,bout,log_std */
+int32_t metrpo_policy_param_count(const metrpo_ctx* ctx);
+
+/* Replaces the K `dynamics_model` graph copies + RunningMeanStd read-outs the reference builds at
+ * model_based_rl.py:91-97 from training.py:218-269 / running_mean_std.py:22-27.
+ * d_params [K][dyn_param_count]; d_in_mean,d_in_std [ns+na]; d_diff_mean,d_diff_std [ns]. COPIES. */
+int32_t metrpo_set_dynamics(metrpo_ctx* ctx, const float* d_params, const float* d_in_mean,
+                            const float* d_in_std, const float* d_diff_mean, const float* d_diff_std,
+                            void* stream);
+/* [rllab] policy.set_param_values / get_param_values (used by ConjugateGradientOptimizer and by
+ * the snapshot/restore at model_based_rl.py:1127-1129,1291-1293,1400).  d_theta [P]. COPIES. */
+int32_t metrpo_set_policy(metrpo_ctx* ctx, const float* d_theta, void* stream);
+int32_t metrpo_get_policy(metrpo_ctx* ctx, float* d_theta_out, void* stream);
+
+/* ---- single step API (drop-in granularity of the reference's sampler loop) ---------------- */
+/* [rllab] GaussianMLPPolicy.get_actions, called at samplers/vectorized_sampler.py:63.
+ * d_obs [B][ns]; d_eps [B][na] N(0,1) draws or NULL (actions = mean, the determ=True path :64-65);
+ * outputs d_actions [B][na] (unclipped), d_mean [B][na].  log_std is theta's tail. */
+int32_t metrpo_policy_actions(metrpo_ctx* ctx, const float* d_obs, const float* d_eps, int32_t B,
+                              float* d_actions, float* d_mean, void* stream);
+/* VecSimpleEnv.step minus the horizon/reset bookkeeping: env_helpers.py:599-603 + 609-635.
+ * d_s [B][ns]; d_a [B][na] UNCLIPPED (clipped inside, :599); d_model_idx [B] int32 (step_rand:
+ * fresh draw, eps_rand: cur_model_idx; ignored otherwise, may be NULL); d_noise [B][ns] for
+ * model_mean_std else NULL.  Outputs: d_s_next [B][ns], d_reward [B] (= -cost_np_vec, :601),
+ * d_done [B] uint8 (= is_done(s',s'), :603), optional d_next_all [K][B][ns] (all heads, :612). */
+int32_t metrpo_step(metrpo_ctx* ctx, const float* d_s, const float* d_a, int32_t B, int32_t sam_mode,
+                    const int32_t* d_model_idx, const float* d_noise, float* d_s_next, float* d_reward,
+                    uint8_t* d_done, float* d_next_all, void* stream);
+
+/* ---- fused rollout: VectorizedSampler.obtain_samples (samplers/vectorized_sampler.py:45-116)
+ *      driving VecSimpleEnv.reset/step (env_helpers.py:585-607) and policy.get_actions ---------- */
+typedef struct {
+    int32_t B, T, H;             /* envs, steps to execute, max_path_length                      */
+    int32_t sam_mode;            /* metrpo_sam_mode                                              */
+    int32_t determ;              /* 1: actions = mean (obtain_samples(determ=True), :64-65)      */
+    int32_t eval_all_heads;      /* 1: evaluate all K heads every step as the reference does
+                                    (env_helpers.py:612); 0: only the selected head where the
+                                    mode allows (step_rand/eps_rand/one_model)                   */
+    const float* d_pool;         /* [n_pool][ns] initial-state pool standing in for the real
+                                    simulator's env.reset() (env_helpers.py:552-555)             */
+    int32_t n_pool;
+    uint64_t seed;               /* Philox seed for every draw not supplied below                */
+    uint64_t stream_offset;      /* added to the Philox counter: rank*B for sharded runs         */
+    /* parity mode: explicit draws (any may be NULL -> Philox)                                   */
+    const float* d_eps;          /* [T][B][na]  policy noise (np.random.normal in get_actions)   */
+    const int32_t* d_model_idx;  /* [T][B]      step_rand index (env_helpers.py:619)             */
+    const float* d_sel_noise;    /* [T][B][ns]  model_mean_std noise (:626)                      */
+    const int32_t* d_reset_idx;  /* [T+1][B]    pool row used when env b resets AFTER step t-1
+                                                (row 0 = the initial reset(), :49/:585-595)      */
+    const int32_t* d_reset_model;/* [T+1][B]    cur_model_idx drawn at that reset (:593)         */
+    /* outputs, time-major                                                                      */
+    float* d_obs;                /* [T][B][ns]  observation BEFORE the step (:91)                */
+    float* d_act;                /* [T][B][na]  UNCLIPPED action (:92)                           */
+    float* d_rew;                /* [T][B]                                                       */
+    float* d_mean;               /* [T][B][na]  agent_infos['mean'] (log_std = theta tail)       */
+    uint8_t* d_done;             /* [T][B]      done flag returned by step (incl. ts>=H, :604)   */
+    int32_t* d_tpath;            /* [T][B]      0-based step index inside its path               */
+    float* d_last_obs;           /* [B][ns]     state after the last step (optional, may be NULL) */
+} metrpo_rollout_args;
+int32_t metrpo_rollout(metrpo_ctx* ctx, const metrpo_rollout_args* args, void* stream);
+
+/* build_policy_graph forward (model_based_rl.py:106-151): per model i, deterministic clipped
+ * policy, model i for the whole trajectory, cost_i = sum_t gamma^t mean_b cost (Ant: masked by the
+ * running dones, :134-137).  d_s0 [Bv][ns] -> d_costs [K] (float64). */
+int32_t metrpo_validation_cost(metrpo_ctx* ctx, const float* d_s0, int32_t Bv, int32_t T, double gamma,
+                               double* d_costs, void* stream);
+
+/* ---- BaseSampler.process_samples (samplers/base.py:48-104) -------------------------------- */
+/* Per env column reverse scan: V = [rllab] LinearFeatureBaseline.predict (zeros if d_coeffs NULL),
+ * delta = r + g*V' - V, adv = discount_cumsum(delta, g*lam), ret = discount_cumsum(r, g) (:57-64),
+ * restarting at every done; samples of a trailing unfinished path get valid=0 (the reference
+ * drops such paths, vectorized_sampler.py:60,104).  d_coeffs [2*ns+4] float64 or NULL.
+ * d_stats [3] float64 is ACCUMULATED (caller zeroes): sum(adv), sum(adv^2), count over valid. */
+int32_t metrpo_gae(metrpo_ctx* ctx, const float* d_obs, const float* d_rew, const uint8_t* d_done,
+                   const int32_t* d_tpath, int32_t T, int32_t B, const double* d_coeffs, double gamma,
+                   double lam, float* d_adv, float* d_ret, uint8_t* d_valid, double* d_stats, void* stream);
+/* [rllab] util.center_advantages (base.py:82-83): adv <- (adv-mean)/(std+1e-8) over valid samples,
+ * mean/std from d_stats (after the caller all-reduced it across ranks). */
+int32_t metrpo_center_advantages(metrpo_ctx* ctx, float* d_adv, const uint8_t* d_valid, int64_t N,
+                                 const double* d_stats, void* stream);
+/* [rllab] LinearFeatureBaseline.fit normal equations (base.py:164-167): ACCUMULATES
+ * d_AtA [F][F] += F^T F and d_Aty [F] += F^T ret over valid samples, F = 2*ns+4 features
+ * [o, o^2, t/100, (t/100)^2, (t/100)^3, 1], o = clip(obs,-10,10).  float64. The F x F solve stays
+ * with the caller (after its all-reduce). */
+int32_t metrpo_baseline_gram(metrpo_ctx* ctx, const float* d_obs, const float* d_ret, const int32_t* d_tpath,
+                             const uint8_t* d_valid, int64_t N, double* d_AtA, double* d_Aty, void* stream);
+
+/* ---- NPO/TRPO update (algos/npo.py:68-111, algos/trpo.py:18-20; [rllab] ConjugateGradientOptimizer) */
+typedef struct {
+    const float* d_obs;          /* [N][ns]                                                      */
+    const float* d_act;          /* [N][na] unclipped actions                                    */
+    const float* d_adv;          /* [N]                                                          */
+    const float* d_old_mean;     /* [N][na] agent_infos['mean']                                  */
+    const float* d_old_log_std;  /* [N][na] (stride na) or [na] broadcast (stride 0)             */
+    int32_t old_log_std_stride;
+    const uint8_t* d_valid;      /* [N] or NULL (= all valid)                                    */
+    int64_t N;                   /* local samples                                                */
+    double inv_n_global;         /* 1 / (valid samples over ALL ranks): partial results are
+                                    pre-scaled so that a sum all-reduce yields the global mean   */
+} metrpo_batch;
+
+/* f_loss + f_grad of the surrogate (npo.py:75): d_out[0] = loss partial, d_out[1..P] = gradient
+ * partial (float64, this rank's share).  theta = the ctx policy. */
+int32_t metrpo_loss_grad(metrpo_ctx* ctx, const metrpo_batch* batch, double* d_out, void* stream);
+/* [rllab] PerlmutterHvp f_Hx_plain: Hessian(mean_kl) . v WITHOUT the reg_coeff*v term (added by the
+ * caller after its all-reduce).  d_v [P] float64 in, d_hv [P] float64 out (this rank's share). */
+int32_t metrpo_fvp(metrpo_ctx* ctx, const metrpo_batch* batch, const double* d_v, double* d_hv, void* stream);
+/* f_loss_constraint at d_theta (float32 [P], or NULL = ctx policy): d_out[0]=loss, d_out[1]=mean_kl
+ * partials (float64). */
+int32_t metrpo_loss_kl(metrpo_ctx* ctx, const metrpo_batch* batch, const float* d_theta, double* d_out,
+                       void* stream);
+
+/* all-reduce(sum) hook for sharded runs: called on the host while enqueuing, must reduce `count`
+ * float64 values at device pointer d_buf in place across ranks, ordered after prior work on
+ * `stream` and before later work on it.  NULL = single rank. */
+typedef int32_t (*metrpo_allreduce_fn)(void* user, double* d_buf, int64_t count, void* stream);
+
+typedef struct {
+    double max_kl;               /* step_size (params trpo.step_size, npo.py:22,88)              */
+    int32_t cg_iters;            /* 10                                                           */
+    double reg_coeff;            /* 1e-5                                                         */
+    double backtrack_ratio;      /* 0.8                                                          */
+    int32_t max_backtracks;      /* 15                                                           */
+    int32_t accept_violation;    /* 0                                                            */
+    double residual_tol;         /* 1e-10 ([rllab] krylov.cg)                                    */
+    metrpo_allreduce_fn allreduce;
+    void* allreduce_user;
+} metrpo_trpo_params;
+
+typedef struct {                 /* host-side diagnostics of one optimize() call                 */
+    double loss_before, loss, kl, beta;
+    int32_t n_backtrack, accepted, cg_iters_run;
+} metrpo_trpo_diag;
+
+/* One [rllab] ConjugateGradientOptimizer.optimize call (reached from algos/npo.py:111): loss_before,
+ * flat gradient, cg_iters x FVP in krylov.cg, step scale, backtracking line search; on return the
+ * ctx policy holds theta_new (or theta_prev if rejected).  SYNCHRONISES the stream once per
+ * line-search trial (the accept test is a host decision in the reference too).
+ * Optional parity outputs (may be NULL): d_g_out, d_dir_out [P] float64 (gradient, CG direction). */
+int32_t metrpo_trpo_update(metrpo_ctx* ctx, const metrpo_batch* batch, const metrpo_trpo_params* params,
+                           metrpo_trpo_diag* diag, double* d_g_out, double* d_dir_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* METRPO_H */

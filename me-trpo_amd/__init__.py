@@ -1,0 +1,12 @@
+"""metrpo_amd -- MI355X-native ME-TRPO policy-optimisation inner loop.
+
+The package directory is `me-trpo_amd/`; import it as `metrpo_amd` (repo-root alias module).
+Host code mirrors the reference's operator interface for this one path
+(NeuralNetEnv / vec_env_executor / VectorizedSampler / BatchPolopt / NPO / TRPO /
+ConjugateGradientOptimizer / LinearFeatureBaseline); all arithmetic runs in libmetrpo.so
+(hand-written HIP for gfx950) through the C ABI of include/metrpo.h.  No CPU fallback exists.
+"""
+from . import _lib                      # raises ImportError if libmetrpo.so is missing
+from .engine import Engine, Trajectory, xavier_policy_theta
+
+__all__ = ['Engine', 'Trajectory', 'xavier_policy_theta']

@@ -1,0 +1,401 @@
+// C-ABI entry points of libmetrpo.so (include/metrpo.h): context management, argument checking,
+// dispatch to the kernels, and the host driver of one TRPO update.
+#include "metrpo_internal.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+int set_err(metrpo_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+extern "C" int32_t metrpo_abi_version(void) { return METRPO_ABI_VERSION; }
+
+extern "C" const char* metrpo_status_string(int32_t s) {
+    switch (s) {
+    case METRPO_OK: return "ok";
+    case METRPO_EINVAL: return "invalid argument";
+    case METRPO_ENULL: return "null pointer";
+    case METRPO_EHIP: return "HIP runtime error";
+    case METRPO_EUNSUPPORTED: return "unsupported configuration";
+    case METRPO_ESTATE: return "dynamics/policy not set";
+    }
+    return "unknown status";
+}
+
+static bool build_net(NetDesc* n, int n_in, const int32_t* hidden, const int32_t* acts, int n_hidden, int n_out,
+                      int default_act) {
+    if (n_hidden < 0 || n_hidden > METRPO_MAX_LAYERS || n_in <= 0 || n_out <= 0) return false;
+    n->n_layers = n_hidden + 1;
+    n->dims[0] = n_in;
+    for (int l = 0; l < n_hidden; ++l) {
+        if (hidden[l] <= 0) return false;
+        n->dims[l + 1] = hidden[l];
+        n->act[l] = acts ? acts[l] : default_act;
+        if (n->act[l] < METRPO_ACT_IDENTITY || n->act[l] > METRPO_ACT_TANH) return false;
+    }
+    n->dims[n_hidden + 1] = n_out;
+    n->act[n_hidden] = METRPO_ACT_IDENTITY;
+    int off = 0, mw = 0;
+    for (int l = 0; l < n->n_layers; ++l) {
+        n->w_off[l] = off; off += n->dims[l] * n->dims[l + 1];
+        n->b_off[l] = off; off += n->dims[l + 1];
+    }
+    for (int l = 0; l <= n->n_layers; ++l) mw = std::max(mw, n->dims[l]);
+    n->n_params = off;
+    n->max_width = mw;
+    return true;
+}
+
+// CG workspace layout (doubles): gout[1+P] | x[P] | r[P] | p[P] | z[P] | step[P] | scal[8] | lk[2]
+struct CgView { double *gout, *x, *r, *p, *z, *step, *scal, *lk; };
+static CgView cg_view(metrpo_ctx* c) {
+    const int P = c->pd.P;
+    CgView v;
+    v.gout = c->d_cg; v.x = v.gout + 1 + P; v.r = v.x + P; v.p = v.r + P; v.z = v.p + P; v.step = v.z + P;
+    v.scal = v.step + P; v.lk = v.scal + 8;
+    return v;
+}
+enum { S_RDOTR = 0, S_DONE = 1, S_BETA = 2, S_XHX = 3, S_ITERS = 4 };
+
+extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_dims* d) {
+    if (!out || !d) return METRPO_ENULL;
+    *out = nullptr;
+    if (d->ns <= 0 || d->na <= 0 || d->n_models <= 0 || d->n_drop < 0 || d->n_drop >= d->ns) return METRPO_EINVAL;
+    if (d->env < METRPO_ENV_SWIMMER || d->env > METRPO_ENV_SNAKE) return METRPO_EINVAL;
+    // the analytic rewards index fixed state columns (see metrpo_env)
+    const int min_ns[] = {6, 10, 16, 1, 6, 8};
+    if (d->ns < min_ns[d->env]) return METRPO_EINVAL;
+    metrpo_ctx* c = new (std::nothrow) metrpo_ctx();
+    if (!c) return METRPO_EINVAL;
+    c->device = device; c->dims = *d;
+    c->d_dyn = c->d_norm = c->d_theta = nullptr; c->have_dyn = c->have_pol = false;
+    c->d_dyn_img = c->d_pol_img = nullptr; c->mfma_cfg = -1;
+    c->d_partials = nullptr; c->partials_cap = 0; c->d_cg = nullptr; c->d_vf = nullptr; c->d_theta_try = nullptr;
+    c->d_valbuf = nullptr; c->h_pinned = nullptr; c->n_sm = 256;
+    ProblemDesc& pd = c->pd;
+    pd.env = d->env; pd.ns = d->ns; pd.na = d->na; pd.K = d->n_models; pd.n_drop = d->n_drop;
+    pd.nin = d->ns + d->na - d->n_drop;
+    if (!build_net(&pd.dyn, pd.nin, d->dyn_hidden, d->dyn_act, d->dyn_n_hidden, d->ns, METRPO_ACT_RELU) ||
+        !build_net(&pd.pol, d->ns, d->pol_hidden, nullptr, d->pol_n_hidden, d->na, METRPO_ACT_TANH)) {
+        delete c;
+        return METRPO_EINVAL;
+    }
+    pd.P = pd.pol.n_params + d->na;
+    *out = c;
+    if (hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return METRPO_EHIP; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_sm = prop.multiProcessorCount;
+    const size_t ncg = (size_t)(1 + pd.P) + 5 * (size_t)pd.P + 8 + 2;
+    if (hipMalloc(&c->d_dyn, sizeof(float) * (size_t)pd.K * pd.dyn.n_params) != hipSuccess ||
+        hipMalloc(&c->d_norm, sizeof(float) * (2 * (pd.ns + pd.na) + 2 * pd.ns)) != hipSuccess ||
+        hipMalloc(&c->d_theta, sizeof(float) * pd.P) != hipSuccess ||
+        hipMalloc(&c->d_vf, sizeof(float) * pd.P) != hipSuccess ||
+        hipMalloc(&c->d_theta_try, sizeof(float) * pd.P) != hipSuccess ||
+        hipMalloc(&c->d_cg, sizeof(double) * ncg) != hipSuccess ||
+        hipMalloc(&c->d_valbuf, sizeof(double) * pd.K) != hipSuccess ||
+        hipHostMalloc(&c->h_pinned, sizeof(double) * 16) != hipSuccess) {
+        c->err = "device allocation failed";
+        return METRPO_EHIP;
+    }
+    c->mfma_cfg = mfma_select_config(c);
+    return METRPO_OK;
+}
+
+extern "C" int32_t metrpo_destroy(metrpo_ctx* c) {
+    if (!c) return METRPO_ENULL;
+    void* bufs[] = {c->d_dyn, c->d_norm, c->d_theta, c->d_vf, c->d_theta_try, c->d_cg, c->d_valbuf, c->d_partials,
+                    c->d_dyn_img, c->d_pol_img};
+    for (void* p : bufs) if (p) (void)hipFree(p);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    delete c;
+    return METRPO_OK;
+}
+
+extern "C" const char* metrpo_last_error(const metrpo_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+extern "C" int32_t metrpo_dyn_param_count(const metrpo_ctx* c) { return c ? c->pd.dyn.n_params : METRPO_ENULL; }
+extern "C" int32_t metrpo_policy_param_count(const metrpo_ctx* c) { return c ? c->pd.P : METRPO_ENULL; }
+
+extern "C" int32_t metrpo_set_dynamics(metrpo_ctx* c, const float* p, const float* in_mean, const float* in_std,
+                                       const float* diff_mean, const float* diff_std, void* stream) {
+    if (!c) return METRPO_ENULL;
+    if (!p || !in_mean || !in_std || !diff_mean || !diff_std) return set_err(c, METRPO_ENULL, "set_dynamics: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const ProblemDesc& pd = c->pd;
+    const int nx = pd.ns + pd.na;
+    HIP_TRY(c, hipMemcpyAsync(c->d_dyn, p, sizeof(float) * (size_t)pd.K * pd.dyn.n_params, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_norm, in_mean, sizeof(float) * nx, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_norm + nx, in_std, sizeof(float) * nx, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_norm + 2 * nx, diff_mean, sizeof(float) * pd.ns, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_norm + 2 * nx + pd.ns, diff_std, sizeof(float) * pd.ns, hipMemcpyDeviceToDevice, st));
+    c->have_dyn = true;
+    if (c->mfma_cfg >= 0) return mfma_prepare_dynamics(c, st);
+    return METRPO_OK;
+}
+
+extern "C" int32_t metrpo_set_policy(metrpo_ctx* c, const float* theta, void* stream) {
+    if (!c) return METRPO_ENULL;
+    if (!theta) return set_err(c, METRPO_ENULL, "set_policy: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(c, hipMemcpyAsync(c->d_theta, theta, sizeof(float) * c->pd.P, hipMemcpyDeviceToDevice, st));
+    c->have_pol = true;
+    if (c->mfma_cfg >= 0) return mfma_prepare_policy(c, st);
+    return METRPO_OK;
+}
+
+extern "C" int32_t metrpo_get_policy(metrpo_ctx* c, float* out, void* stream) {
+    if (!c) return METRPO_ENULL;
+    if (!out) return set_err(c, METRPO_ENULL, "get_policy: NULL pointer");
+    if (!c->have_pol) return set_err(c, METRPO_ESTATE, "policy not set");
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_theta, sizeof(float) * c->pd.P, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return METRPO_OK;
+}
+
+#define NEED_POL(c) if (!(c)->have_pol) return set_err((c), METRPO_ESTATE, "metrpo_set_policy has not been called")
+#define NEED_DYN(c) if (!(c)->have_dyn) return set_err((c), METRPO_ESTATE, "metrpo_set_dynamics has not been called")
+
+extern "C" int32_t metrpo_policy_actions(metrpo_ctx* c, const float* obs, const float* eps, int32_t B, float* actions,
+                                         float* mean, void* stream) {
+    if (!c) return METRPO_ENULL;
+    NEED_POL(c);
+    if (!obs || !actions || !mean) return set_err(c, METRPO_ENULL, "policy_actions: NULL pointer");
+    if (B < 0) return set_err(c, METRPO_EINVAL, "policy_actions: B < 0");
+    if (B == 0) return METRPO_OK;
+    return launch_policy_actions(c, obs, eps, B, actions, mean, (hipStream_t)stream);
+}
+
+static bool sam_ok(int m) { return m >= METRPO_SAM_STEP_RAND && m <= METRPO_SAM_ONE_MODEL; }
+
+extern "C" int32_t metrpo_step(metrpo_ctx* c, const float* s, const float* a, int32_t B, int32_t sam_mode,
+                               const int32_t* model_idx, const float* noise, float* s_next, float* reward,
+                               uint8_t* done, float* next_all, void* stream) {
+    if (!c) return METRPO_ENULL;
+    NEED_DYN(c);
+    if (!s || !a || !s_next || !reward || !done) return set_err(c, METRPO_ENULL, "step: NULL pointer");
+    if (!sam_ok(sam_mode)) return set_err(c, METRPO_EINVAL, "sam mode is not defined");      // env_helpers.py:634
+    if ((sam_mode == METRPO_SAM_STEP_RAND || sam_mode == METRPO_SAM_EPS_RAND) && !model_idx)
+        return set_err(c, METRPO_ENULL, "step: model_idx required for step_rand/eps_rand");
+    if (sam_mode == METRPO_SAM_MODEL_MEAN_STD && !noise) return set_err(c, METRPO_ENULL, "step: noise required for model_mean_std");
+    if (B < 0) return set_err(c, METRPO_EINVAL, "step: B < 0");
+    if (B == 0) return METRPO_OK;
+    return launch_step(c, s, a, B, sam_mode, model_idx, noise, s_next, reward, done, next_all, (hipStream_t)stream);
+}
+
+extern "C" int32_t metrpo_rollout(metrpo_ctx* c, const metrpo_rollout_args* a, void* stream) {
+    if (!c) return METRPO_ENULL;
+    if (!a) return set_err(c, METRPO_ENULL, "rollout: args NULL");
+    NEED_DYN(c); NEED_POL(c);
+    if (!sam_ok(a->sam_mode)) return set_err(c, METRPO_EINVAL, "sam mode is not defined");
+    if (a->B < 0 || a->T < 0 || a->H <= 0 || a->n_pool <= 0) return set_err(c, METRPO_EINVAL, "rollout: bad B/T/H/n_pool");
+    if (!a->d_pool || !a->d_obs || !a->d_act || !a->d_rew || !a->d_mean || !a->d_done || !a->d_tpath)
+        return set_err(c, METRPO_ENULL, "rollout: required pointer is NULL");
+    if (a->B == 0 || a->T == 0) return METRPO_OK;
+    if (c->mfma_cfg >= 0) {
+        const int rc = launch_rollout_mfma(c, a, (hipStream_t)stream);
+        if (rc != METRPO_EUNSUPPORTED) return rc;
+    }
+    return launch_rollout_generic(c, a, (hipStream_t)stream);
+}
+
+// test/diagnostic hook: force the generic kernel regardless of the MFMA table
+extern "C" int32_t metrpo_rollout_generic(metrpo_ctx* c, const metrpo_rollout_args* a, void* stream) {
+    if (!c) return METRPO_ENULL;
+    if (!a) return set_err(c, METRPO_ENULL, "rollout: args NULL");
+    NEED_DYN(c); NEED_POL(c);
+    if (!sam_ok(a->sam_mode)) return set_err(c, METRPO_EINVAL, "sam mode is not defined");
+    if (a->B <= 0 || a->T <= 0 || a->H <= 0 || a->n_pool <= 0) return set_err(c, METRPO_EINVAL, "rollout: bad B/T/H/n_pool");
+    if (!a->d_pool || !a->d_obs || !a->d_act || !a->d_rew || !a->d_mean || !a->d_done || !a->d_tpath)
+        return set_err(c, METRPO_ENULL, "rollout: required pointer is NULL");
+    return launch_rollout_generic(c, a, (hipStream_t)stream);
+}
+extern "C" int32_t metrpo_has_mfma_path(const metrpo_ctx* c) { return (c && c->mfma_cfg >= 0) ? 1 : 0; }
+
+extern "C" int32_t metrpo_validation_cost(metrpo_ctx* c, const float* s0, int32_t Bv, int32_t T, double gamma,
+                                          double* costs, void* stream) {
+    if (!c) return METRPO_ENULL;
+    NEED_DYN(c); NEED_POL(c);
+    if (!s0 || !costs) return set_err(c, METRPO_ENULL, "validation_cost: NULL pointer");
+    if (Bv <= 0 || T < 0) return set_err(c, METRPO_EINVAL, "validation_cost: bad Bv/T");
+    return launch_validation_cost(c, s0, Bv, T, gamma, costs, (hipStream_t)stream);
+}
+
+extern "C" int32_t metrpo_gae(metrpo_ctx* c, const float* obs, const float* rew, const uint8_t* done,
+                              const int32_t* tpath, int32_t T, int32_t B, const double* coeffs, double gamma, double lam,
+                              float* adv, float* ret, uint8_t* valid, double* stats, void* stream) {
+    if (!c) return METRPO_ENULL;
+    if (!obs || !rew || !done || !tpath || !adv || !ret || !valid || !stats) return set_err(c, METRPO_ENULL, "gae: NULL pointer");
+    if (T < 0 || B < 0) return set_err(c, METRPO_EINVAL, "gae: bad T/B");
+    if (T == 0 || B == 0) return METRPO_OK;
+    return launch_gae(c, obs, rew, done, tpath, T, B, coeffs, gamma, lam, adv, ret, valid, stats, (hipStream_t)stream);
+}
+
+extern "C" int32_t metrpo_center_advantages(metrpo_ctx* c, float* adv, const uint8_t* valid, int64_t N,
+                                            const double* stats, void* stream) {
+    if (!c) return METRPO_ENULL;
+    if (!adv || !stats) return set_err(c, METRPO_ENULL, "center: NULL pointer");
+    if (N <= 0) return METRPO_OK;
+    return launch_center(c, adv, valid, N, stats, (hipStream_t)stream);
+}
+
+extern "C" int32_t metrpo_baseline_gram(metrpo_ctx* c, const float* obs, const float* ret, const int32_t* tpath,
+                                        const uint8_t* valid, int64_t N, double* AtA, double* Aty, void* stream) {
+    if (!c) return METRPO_ENULL;
+    if (!obs || !ret || !tpath || !AtA || !Aty) return set_err(c, METRPO_ENULL, "gram: NULL pointer");
+    if (N <= 0) return METRPO_OK;
+    return launch_gram(c, obs, ret, tpath, valid, N, AtA, Aty, (hipStream_t)stream);
+}
+
+extern "C" int32_t metrpo_loss_grad(metrpo_ctx* c, const metrpo_batch* b, double* out, void* stream) {
+    if (!c) return METRPO_ENULL;
+    NEED_POL(c);
+    if (!out) return set_err(c, METRPO_ENULL, "loss_grad: out NULL");
+    return launch_loss_grad(c, b, out, (hipStream_t)stream);
+}
+extern "C" int32_t metrpo_fvp(metrpo_ctx* c, const metrpo_batch* b, const double* v, double* hv, void* stream) {
+    if (!c) return METRPO_ENULL;
+    NEED_POL(c);
+    return launch_fvp(c, b, v, hv, (hipStream_t)stream);
+}
+extern "C" int32_t metrpo_loss_kl(metrpo_ctx* c, const metrpo_batch* b, const float* theta, double* out, void* stream) {
+    if (!c) return METRPO_ENULL;
+    NEED_POL(c);
+    if (!out) return set_err(c, METRPO_ENULL, "loss_kl: out NULL");
+    return launch_loss_kl(c, b, theta, out, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// TRPO update driver: [rllab] ConjugateGradientOptimizer.optimize + krylov.cg, vectors resident on
+// the device in float64 (the reference keeps them in host NumPy float64), one block per vector op.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double blk_sum(double v, double* sh) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) sh[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) r += sh[i];     // every thread sums the same values in the same order
+    return r;
+}
+
+__global__ void k_cg_init(int P, const double* __restrict__ gout, double* x, double* r, double* p, double* scal) {
+    __shared__ double sh[16];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        const double g = gout[1 + i];
+        x[i] = 0.0; r[i] = g; p[i] = g;
+        acc += g * g;
+    }
+    const double rdotr = blk_sum(acc, sh);
+    if (threadIdx.x == 0) { scal[S_RDOTR] = rdotr; scal[S_DONE] = 0.0; scal[S_ITERS] = 0.0; }
+}
+
+// one krylov.cg iteration after z = f_Ax(p) has been formed (z lacks the reg term: added here)
+__global__ void k_cg_step(int P, double reg, double tol, double* x, double* r, double* p, double* z, double* scal) {
+    __shared__ double sh[16];
+    if (scal[S_DONE] != 0.0) return;
+    const double rdotr = scal[S_RDOTR];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) { const double zi = z[i] + reg * p[i]; z[i] = zi; acc += p[i] * zi; }
+    const double pz = blk_sum(acc, sh);
+    const double v = rdotr / pz;
+    acc = 0.0;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        x[i] += v * p[i];
+        const double ri = r[i] - v * z[i];
+        r[i] = ri;
+        acc += ri * ri;
+    }
+    const double newrdotr = blk_sum(acc, sh);
+    const double mu = newrdotr / rdotr;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) p[i] = r[i] + mu * p[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        scal[S_RDOTR] = newrdotr;
+        scal[S_ITERS] += 1.0;
+        if (newrdotr < tol) scal[S_DONE] = 1.0;
+    }
+}
+
+// initial_step_size = sqrt(2 * max_kl / (d . Hx(d) + 1e-8)); nan -> 1; step = beta * d
+__global__ void k_cg_finish(int P, double reg, double max_kl, const double* x, double* z, double* step, double* scal) {
+    __shared__ double sh[16];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) acc += x[i] * (z[i] + reg * x[i]);
+    const double xhx = blk_sum(acc, sh);
+    double beta = sqrt(2.0 * max_kl * (1.0 / (xhx + 1e-8)));
+    if (isnan(beta)) beta = 1.0;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) step[i] = beta * x[i];
+    if (threadIdx.x == 0) { scal[S_BETA] = beta; scal[S_XHX] = xhx; }
+}
+
+__global__ void k_try_theta(int P, double ratio, const float* __restrict__ prev, const double* __restrict__ step, float* cur) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P) cur[i] = (float)((double)prev[i] - ratio * step[i]);     // cur_param = prev_param - ratio * flat_descent_step
+}
+
+int run_trpo_update(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_params* pr, metrpo_trpo_diag* diag,
+                    double* g_out, double* dir_out, hipStream_t st) {
+    const int P = c->pd.P;
+    CgView v = cg_view(c);
+    int rc;
+#define AR(buf, n) do { if (pr->allreduce && (rc = pr->allreduce(pr->allreduce_user, (buf), (n), (void*)st)) != 0) \
+                            return set_err(c, METRPO_EINVAL, "allreduce callback failed"); } while (0)
+    if ((rc = launch_loss_grad(c, b, v.gout, st))) return rc;
+    AR(v.gout, 1 + P);
+    hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(256), 0, st, P, v.gout, v.x, v.r, v.p, v.scal);
+    for (int i = 0; i < pr->cg_iters; ++i) {
+        if ((rc = launch_fvp(c, b, v.p, v.z, st))) return rc;
+        AR(v.z, P);
+        hipLaunchKernelGGL(k_cg_step, dim3(1), dim3(256), 0, st, P, pr->reg_coeff, pr->residual_tol, v.x, v.r, v.p, v.z, v.scal);
+    }
+    if ((rc = launch_fvp(c, b, v.x, v.z, st))) return rc;
+    AR(v.z, P);
+    hipLaunchKernelGGL(k_cg_finish, dim3(1), dim3(256), 0, st, P, pr->reg_coeff, pr->max_kl, v.x, v.z, v.step, v.scal);
+    if (g_out) HIP_TRY(c, hipMemcpyAsync(g_out, v.gout + 1, sizeof(double) * P, hipMemcpyDeviceToDevice, st));
+    if (dir_out) HIP_TRY(c, hipMemcpyAsync(dir_out, v.x, sizeof(double) * P, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->h_pinned, v.gout, sizeof(double), hipMemcpyDeviceToHost, st));          // loss_before
+    HIP_TRY(c, hipMemcpyAsync(c->h_pinned + 1, v.scal, sizeof(double) * 5, hipMemcpyDeviceToHost, st));
+    double loss = NAN, kl = NAN, loss_before = NAN;
+    int n_iter = 0;
+    bool first = true;
+    for (int n = 0; n < pr->max_backtracks; ++n) {
+        n_iter = n;
+        const double ratio = std::pow(pr->backtrack_ratio, (double)n);
+        hipLaunchKernelGGL(k_try_theta, dim3((P + 255) / 256), dim3(256), 0, st, P, ratio, c->d_theta, v.step, c->d_theta_try);
+        if ((rc = launch_loss_kl(c, b, c->d_theta_try, v.lk, st))) return rc;
+        AR(v.lk, 2);
+        HIP_TRY(c, hipMemcpyAsync(c->h_pinned + 8, v.lk, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        if (first) { loss_before = c->h_pinned[0]; first = false; }
+        loss = c->h_pinned[8]; kl = c->h_pinned[9];
+        if (loss < loss_before && kl <= pr->max_kl) break;
+    }
+    if (first) { HIP_TRY(c, hipStreamSynchronize(st)); loss_before = c->h_pinned[0]; }
+    bool accepted = true;
+    if ((std::isnan(loss) || std::isnan(kl) || loss >= loss_before || kl >= pr->max_kl) && !pr->accept_violation) accepted = false;
+    if (accepted) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_theta, c->d_theta_try, sizeof(float) * P, hipMemcpyDeviceToDevice, st));
+        if (c->mfma_cfg >= 0 && (rc = mfma_prepare_policy(c, st))) return rc;
+    }
+    if (diag) {
+        diag->loss_before = loss_before; diag->loss = loss; diag->kl = kl;
+        diag->beta = c->h_pinned[1 + S_BETA]; diag->n_backtrack = n_iter; diag->accepted = accepted ? 1 : 0;
+        diag->cg_iters_run = (int)c->h_pinned[1 + S_ITERS];
+    }
+    HIP_TRY(c, hipGetLastError());
+#undef AR
+    return METRPO_OK;
+}
+
+extern "C" int32_t metrpo_trpo_update(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_params* pr,
+                                      metrpo_trpo_diag* diag, double* g_out, double* dir_out, void* stream) {
+    if (!c) return METRPO_ENULL;
+    NEED_POL(c);
+    if (!b || !pr) return set_err(c, METRPO_ENULL, "trpo_update: NULL pointer");
+    if (pr->cg_iters < 0 || pr->max_backtracks < 1) return set_err(c, METRPO_EINVAL, "trpo_update: bad cg_iters/max_backtracks");
+    return run_trpo_update(c, b, pr, diag, g_out, dir_out, (hipStream_t)stream);
+}

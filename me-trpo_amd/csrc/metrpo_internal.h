@@ -1,0 +1,80 @@
+// Internal definitions shared by the HIP translation units of libmetrpo.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "metrpo.h"
+
+#define MAXL (METRPO_MAX_LAYERS + 1)   // weight layers per MLP (hidden + output)
+#define WAVE 64
+
+// One MLP as offsets into a flat float vector: [W0 (n_in x n_out row-major), b0, W1, b1, ...].
+struct NetDesc {
+    int n_layers;            // weight layers
+    int dims[MAXL + 1];      // dims[0] = inputs ... dims[n_layers] = outputs
+    int act[MAXL];           // metrpo_act applied after layer l (last: identity)
+    int w_off[MAXL];
+    int b_off[MAXL];
+    int n_params;            // floats of one network (policy: WITHOUT the trailing log_std)
+    int max_width;           // max over dims
+};
+
+// Normaliser block layout in ctx->d_norm: in_mean[ns+na] | in_std[ns+na] | diff_mean[ns] | diff_std[ns]
+struct ProblemDesc {
+    int env, ns, na, K, n_drop, nin;   // nin = ns + na - n_drop
+    NetDesc dyn, pol;
+    int P;                             // policy params incl. log_std
+};
+
+struct metrpo_ctx {
+    int device;
+    metrpo_dims dims;
+    ProblemDesc pd;
+    float* d_dyn;        // [K][dyn.n_params]
+    float* d_norm;       // 2*(ns+na) + 2*ns
+    float* d_theta;      // [P]
+    bool have_dyn, have_pol;
+    // --- MFMA fast path (rollout_mfma.hip): pre-permuted weight images, built by set_* ---
+    float* d_dyn_img;    // per-model register image, see rollout_mfma.hip
+    float* d_pol_img;
+    int mfma_cfg;        // index into the instantiation table, -1 = generic path only
+    // --- workspaces for the update path (lazily sized) ---
+    float* d_partials;   // [n_blocks][P+2] per-block partial sums
+    size_t partials_cap;
+    double* d_cg;        // CG vectors + scalars, see trpo_update.hip
+    float* d_vf;         // [P] float copy of the FVP input
+    float* d_theta_try;  // [P] line-search candidate
+    double* d_valbuf;    // validation-cost accumulators
+    double* h_pinned;    // pinned host scratch for the per-trial read-back
+    int n_sm;            // CU count
+    std::string err;
+};
+
+int set_err(metrpo_ctx* c, int code, const std::string& msg);
+#define HIP_TRY(c, expr)                                                                      \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return set_err((c), METRPO_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+// launch helpers implemented in the individual .hip files
+int launch_policy_actions(metrpo_ctx*, const float*, const float*, int, float*, float*, hipStream_t);
+int launch_step(metrpo_ctx*, const float*, const float*, int, int, const int32_t*, const float*, float*, float*,
+                uint8_t*, float*, hipStream_t);
+int launch_rollout_generic(metrpo_ctx*, const metrpo_rollout_args*, hipStream_t);
+int launch_rollout_mfma(metrpo_ctx*, const metrpo_rollout_args*, hipStream_t);   // returns METRPO_EUNSUPPORTED if no instantiation fits
+int mfma_prepare_dynamics(metrpo_ctx*, hipStream_t);
+int mfma_prepare_policy(metrpo_ctx*, hipStream_t);
+int mfma_select_config(metrpo_ctx*);
+int launch_validation_cost(metrpo_ctx*, const float*, int, int, double, double*, hipStream_t);
+int launch_gae(metrpo_ctx*, const float*, const float*, const uint8_t*, const int32_t*, int, int, const double*,
+               double, double, float*, float*, uint8_t*, double*, hipStream_t);
+int launch_center(metrpo_ctx*, float*, const uint8_t*, int64_t, const double*, hipStream_t);
+int launch_gram(metrpo_ctx*, const float*, const float*, const int32_t*, const uint8_t*, int64_t, double*, double*,
+                hipStream_t);
+int launch_loss_grad(metrpo_ctx*, const metrpo_batch*, double*, hipStream_t);
+int launch_fvp(metrpo_ctx*, const metrpo_batch*, const double*, double*, hipStream_t);
+int launch_loss_kl(metrpo_ctx*, const metrpo_batch*, const float*, double*, hipStream_t);
+int run_trpo_update(metrpo_ctx*, const metrpo_batch*, const metrpo_trpo_params*, metrpo_trpo_diag*, double*,
+                    double*, hipStream_t);

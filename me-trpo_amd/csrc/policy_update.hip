@@ -1,0 +1,369 @@
+// Policy-side kernels of the NPO/TRPO update (algos/npo.py:68-111; [rllab] ConjugateGradientOptimizer,
+// PerlmutterHvp, DiagonalGaussian):
+//   k_loss_grad  -- surrogate loss + flat gradient          (f_loss / f_grad)
+//   k_fvp        -- Hessian(mean_kl) . v  (Gauss-Newton form, exact at theta_old; see oracle docstring)
+//   k_loss_kl    -- surrogate loss + mean KL at a trial theta (f_loss_constraint)
+//   k_finalize   -- fixed-order (deterministic) float64 reduction of the per-block partial rows
+//
+// Generic VALU formulation: a block of PT threads owns tiles of PT samples.  Phase A is thread-per-
+// sample (forward / tangent / back-prop in LDS columns, weights via scalar loads); phase B is
+// thread-per-parameter (weight-gradient outer products over the tile, rows padded to PT+1 floats so
+// that lanes holding different units hit different LDS banks).  Each block accumulates into its own
+// row of a global partial buffer; k_finalize sums rows in block order -> bitwise reproducible.
+#include "device_common.h"
+
+#define PT 128
+#define PLD (PT + 1)
+
+struct PolK {
+    const float* obs; const float* act; const float* adv; const float* old_mean; const float* old_ls;
+    int ls_stride; const uint8_t* valid; long long N; float inv_n;
+};
+
+// offsets (in rows) of the per-layer activation buffers h_0 (= input) .. h_{L-1}; h_L (mean) lives in DM
+__device__ __forceinline__ int hrow(const NetDesc& net, int l) {
+    int o = 0;
+    for (int i = 0; i < l; ++i) o += net.dims[i];
+    return o;
+}
+
+// forward pass storing every layer input; returns nothing, mean is written to DM rows [0,na)
+__device__ __forceinline__ void forward_store(const NetDesc& net, const float* __restrict__ th, float* H, float* DM, int tid) {
+    for (int l = 0; l < net.n_layers; ++l) {
+        float* dst = (l == net.n_layers - 1) ? DM : (H + hrow(net, l + 1) * PLD);
+        dense_col(th + net.w_off[l], th + net.b_off[l], net.dims[l], net.dims[l + 1], net.act[l], H + hrow(net, l) * PLD,
+                  dst, PLD, tid);
+    }
+}
+
+__device__ __forceinline__ bool load_obs_tile(const PolK& k, int ns, long long base, float* H, int tid) {
+    const long long n = base + tid;
+    const bool ok = (n < k.N) && (k.valid == nullptr || k.valid[n]);
+    for (int i = 0; i < ns; ++i) H[i * PLD + tid] = (n < k.N) ? k.obs[n * ns + i] : 0.0f;
+    return ok;
+}
+
+// Phase B for one layer: part[w_off + i*n_out + j] += sum_n h_l[i][n] * d[j][n];  part[b_off + j] += sum_n d[j][n]
+__device__ __forceinline__ void accum_layer(const NetDesc& net, int l, const float* Hl, const float* D, float* part, int tid) {
+    const int n_in = net.dims[l], n_out = net.dims[l + 1];
+    for (int p = tid; p < n_in * n_out; p += PT) {
+        const int i = p / n_out, j = p - i * n_out;
+        const float* hr = Hl + i * PLD;
+        const float* dr = D + j * PLD;
+        float s = 0.0f;
+#pragma unroll 8
+        for (int n = 0; n < PT; ++n) s = fmaf(hr[n], dr[n], s);
+        part[net.w_off[l] + p] += s;
+    }
+    for (int j = tid; j < n_out; j += PT) {
+        const float* dr = D + j * PLD;
+        float s = 0.0f;
+#pragma unroll 8
+        for (int n = 0; n < PT; ++n) s += dr[n];
+        part[net.b_off[l] + j] += s;
+    }
+}
+
+// delta_l[i] = (sum_j W_l[i][j] * delta_{l+1}[j]) * (1 - h_l[i]^2), written in place over h_l (tanh hidden layers)
+__device__ __forceinline__ void backprop_layer(const NetDesc& net, int l, const float* __restrict__ th, float* Hl, const float* D, int tid) {
+    const int n_in = net.dims[l], n_out = net.dims[l + 1];
+    const float* __restrict__ W = th + net.w_off[l];
+    for (int i = 0; i < n_in; ++i) {
+        float s = 0.0f;
+        const float* __restrict__ wr = W + (size_t)i * n_out;
+        for (int j = 0; j < n_out; ++j) s = fmaf(wr[j], D[j * PLD + tid], s);
+        const float h = Hl[i * PLD + tid];
+        Hl[i * PLD + tid] = s * (1.0f - h * h);
+    }
+}
+
+// shared tail of grad and fvp: DM holds d(objective)/d(mean) per sample (already scaled, zero if invalid)
+__device__ __forceinline__ void backward_accumulate(const NetDesc& net, const float* __restrict__ th, float* H, float* DM, float* part, int tid) {
+    const float* D = DM;
+    for (int l = net.n_layers - 1; l >= 0; --l) {
+        float* Hl = H + hrow(net, l) * PLD;
+        __syncthreads();
+        accum_layer(net, l, Hl, D, part, tid);
+        __syncthreads();
+        if (l > 0) { backprop_layer(net, l, th, Hl, D, tid); D = Hl; }
+    }
+}
+
+// partial row layout: [0, P) gradient in theta order (log_std slots at pol.n_params..P), then
+//   [P] = loss (or kl-side scalar), [P+1] = second scalar, [P+2] = valid-sample weight (count*inv_n)
+#define PART_EXTRA 3
+
+__global__ void __launch_bounds__(PT) k_loss_grad(ProblemDesc pd, PolK k, const float* __restrict__ theta, float* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ double red[16];
+    const NetDesc& net = pd.pol;
+    const int tid = threadIdx.x, ns = pd.ns, na = pd.na, P = pd.P;
+    int hrows = 0;
+    for (int l = 0; l < net.n_layers; ++l) hrows += net.dims[l];
+    float* H = lds;
+    float* DM = H + hrows * PLD;
+    float* part = partials + (size_t)blockIdx.x * (P + PART_EXTRA);
+    for (int p = tid; p < P + PART_EXTRA; p += PT) part[p] = 0.0f;
+    const float* __restrict__ raw_ls = theta + net.n_params;
+    double loss_acc = 0.0;
+    float dls_acc[32];            // na <= 32 enforced by the launcher
+#pragma unroll
+    for (int d = 0; d < 32; ++d) dls_acc[d] = 0.0f;
+    for (long long base = (long long)blockIdx.x * PT; base < k.N; base += (long long)gridDim.x * PT) {
+        __syncthreads();
+        const bool ok = load_obs_tile(k, ns, base, H, tid);
+        forward_store(net, theta, H, DM, tid);
+        const long long n = base + tid;
+        float w = 0.0f;
+        if (ok) {
+            float llr = 0.0f;                                   // logli_new - logli_old
+            for (int d = 0; d < na; ++d) {
+                const float ls = fmaxf(raw_ls[d], LOG_MIN_STD), ols = k.old_ls[(size_t)n * k.ls_stride + d];
+                const float a = k.act[n * na + d];
+                const float z = (a - DM[d * PLD + tid]) * expf(-ls);
+                const float zo = (a - k.old_mean[n * na + d]) * expf(-ols);
+                llr += (ols - ls) + 0.5f * (zo * zo - z * z);
+            }
+            const float lr = expf(llr);                          // likelihood_ratio_sym (npo.py:69)
+            const float la = lr * k.adv[n];
+            loss_acc -= (double)la * (double)k.inv_n;            // surr_loss = -mean(lr*adv) (npo.py:75)
+            w = -la * k.inv_n;
+        }
+#pragma unroll
+        for (int d = 0; d < 32; ++d) {
+            if (d < na) {
+                const float ls = fmaxf(raw_ls[d], LOG_MIN_STD);
+                const float inv_std = expf(-ls);
+                const float z = ok ? (k.act[n * na + d] - DM[d * PLD + tid]) * inv_std : 0.0f;
+                DM[d * PLD + tid] = w * z * inv_std;             // d loss / d mean
+                dls_acc[d] += w * (z * z - 1.0f);                // d loss / d log_std
+            }
+        }
+        backward_accumulate(net, theta, H, DM, part, tid);
+    }
+    // block-reduce the per-thread scalars into the partial row
+    const double l = block_sum(loss_acc, red);
+    if (tid == 0) part[P] = (float)l;
+    for (int d = 0; d < na; ++d) {
+        const double s = block_sum((double)dls_acc[d], red);
+        if (tid == 0) part[net.n_params + d] = (raw_ls[d] > LOG_MIN_STD) ? (float)s : 0.0f;
+    }
+}
+
+// tangent forward: dpre_{l+1} = dh_l W_l + h_l V_l + vb_l ; dh_{l+1} = dpre * (1 - h_{l+1}^2)
+__device__ __forceinline__ void tangent_layer(const NetDesc& net, int l, const float* __restrict__ th, const float* __restrict__ v,
+                                              const float* Hl, const float* dHl /*nullptr for l==0*/, const float* Hn /*h_{l+1} or nullptr for output*/,
+                                              float* dst, int tid) {
+    const int n_in = net.dims[l], n_out = net.dims[l + 1];
+    const float* __restrict__ W = th + net.w_off[l];
+    const float* __restrict__ V = v + net.w_off[l];
+    const float* __restrict__ vb = v + net.b_off[l];
+    for (int j0 = 0; j0 < n_out; j0 += DENSE_JB) {
+        float acc[DENSE_JB];
+        const int nj = min(DENSE_JB, n_out - j0);
+#pragma unroll
+        for (int jj = 0; jj < DENSE_JB; ++jj) acc[jj] = (jj < nj) ? vb[j0 + jj] : 0.0f;
+        for (int i = 0; i < n_in; ++i) {
+            const float h = Hl[i * PLD + tid];
+            const float dh = (dHl != nullptr) ? dHl[i * PLD + tid] : 0.0f;
+#pragma unroll
+            for (int jj = 0; jj < DENSE_JB; ++jj)
+                if (jj < nj) acc[jj] = fmaf(h, V[(size_t)i * n_out + j0 + jj], fmaf(dh, W[(size_t)i * n_out + j0 + jj], acc[jj]));
+        }
+#pragma unroll
+        for (int jj = 0; jj < DENSE_JB; ++jj)
+            if (jj < nj) {
+                float o = acc[jj];
+                if (Hn != nullptr) { const float hn = Hn[(j0 + jj) * PLD + tid]; o *= (1.0f - hn * hn); }
+                dst[(j0 + jj) * PLD + tid] = o;
+            }
+    }
+}
+
+__global__ void __launch_bounds__(PT) k_fvp(ProblemDesc pd, PolK k, const float* __restrict__ theta, const float* __restrict__ v,
+                                            float* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ double red[16];
+    const NetDesc& net = pd.pol;
+    const int tid = threadIdx.x, ns = pd.ns, na = pd.na, P = pd.P, L = net.n_layers;
+    int hrows = 0;
+    for (int l = 0; l < L; ++l) hrows += net.dims[l];
+    float* H = lds;                       // h_0..h_{L-1}
+    float* DM = H + hrows * PLD;          // mean, then u
+    float* dH = DM + na * PLD;            // tangents dh_1..dh_{L-1}, indexed with hrow(l) - dims[0]
+    float* part = partials + (size_t)blockIdx.x * (P + PART_EXTRA);
+    for (int p = tid; p < P + PART_EXTRA; p += PT) part[p] = 0.0f;
+    const float* __restrict__ raw_ls = theta + net.n_params;
+    double wsum = 0.0;
+    for (long long base = (long long)blockIdx.x * PT; base < k.N; base += (long long)gridDim.x * PT) {
+        __syncthreads();
+        const bool ok = load_obs_tile(k, ns, base, H, tid);
+        forward_store(net, theta, H, DM, tid);
+        for (int l = 0; l < L; ++l) {
+            const float* Hl = H + hrow(net, l) * PLD;
+            const float* dHl = (l == 0) ? nullptr : dH + (hrow(net, l) - net.dims[0]) * PLD;
+            const float* Hn = (l == L - 1) ? nullptr : H + hrow(net, l + 1) * PLD;
+            float* dst = (l == L - 1) ? DM : dH + (hrow(net, l + 1) - net.dims[0]) * PLD;
+            tangent_layer(net, l, theta, v, Hl, dHl, Hn, dst, tid);
+        }
+        for (int d = 0; d < na; ++d) {
+            const float ls = fmaxf(raw_ls[d], LOG_MIN_STD);
+            const float s2 = expf(2.0f * ls);
+            // d2 KL / d mean^2 = 2 / (2 s^2 + eps) = 1 / (s^2 + eps/2)
+            DM[d * PLD + tid] = ok ? DM[d * PLD + tid] / (s2 + 0.5f * KL_EPS) * k.inv_n : 0.0f;
+        }
+        if (ok) wsum += (double)k.inv_n;
+        backward_accumulate(net, theta, H, DM, part, tid);
+    }
+    const double wtot = block_sum(wsum, red);
+    if (tid == 0) part[P + 2] = (float)wtot;
+}
+
+__global__ void __launch_bounds__(PT) k_loss_kl(ProblemDesc pd, PolK k, const float* __restrict__ theta, float* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ double red[16];
+    const NetDesc& net = pd.pol;
+    const int tid = threadIdx.x, ns = pd.ns, na = pd.na;
+    float* S = lds;
+    float* A = S + ns * PLD;
+    float* Bq = A + net.max_width * PLD;
+    const float* __restrict__ raw_ls = theta + net.n_params;
+    double loss_acc = 0.0, kl_acc = 0.0;
+    for (long long base = (long long)blockIdx.x * PT; base < k.N; base += (long long)gridDim.x * PT) {
+        const bool ok = load_obs_tile(k, ns, base, S, tid);
+        const float* m = mlp_col(net, theta, S, A, Bq, PLD, tid);
+        if (ok) {
+            const long long n = base + tid;
+            float llr = 0.0f, kl = 0.0f;
+            for (int d = 0; d < na; ++d) {
+                const float ls = fmaxf(raw_ls[d], LOG_MIN_STD), ols = k.old_ls[(size_t)n * k.ls_stride + d];
+                const float mu = m[d * PLD + tid], omu = k.old_mean[n * na + d], a = k.act[n * na + d];
+                const float z = (a - mu) * expf(-ls), zo = (a - omu) * expf(-ols);
+                llr += (ols - ls) + 0.5f * (zo * zo - z * z);
+                const float s2 = expf(2.0f * ls), os2 = expf(2.0f * ols);
+                const float dm = omu - mu;
+                kl += (dm * dm + os2 - s2) / (2.0f * s2 + KL_EPS) + ls - ols;      // DiagonalGaussian.kl_sym
+            }
+            loss_acc -= (double)(expf(llr) * k.adv[n]) * (double)k.inv_n;
+            kl_acc += (double)kl * (double)k.inv_n;
+        }
+    }
+    const double l = block_sum(loss_acc, red);
+    const double q = block_sum(kl_acc, red);
+    if (tid == 0) { partials[blockIdx.x * 2] = (float)l; partials[blockIdx.x * 2 + 1] = (float)q; }
+}
+
+// out[p] = sum over blocks (fixed order) of partials[blk][p], float64.
+// mode 0: grad -> out[0] = loss, out[1+p] = g[p]   (row stride P+PART_EXTRA)
+// mode 1: fvp  -> out[p] = Hv[p] for the mean net; log_std rows get c(s) * v_ls * weight
+// mode 2: loss/kl -> out[0], out[1]                 (row stride 2)
+__global__ void k_finalize(ProblemDesc pd, int mode, int nblocks, const float* __restrict__ partials,
+                           const float* __restrict__ theta, const double* __restrict__ v, double* __restrict__ out) {
+    const int P = pd.P, stride = (mode == 2) ? 2 : P + PART_EXTRA;
+    const int nout = (mode == 0) ? P + 1 : (mode == 1) ? P : 2;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nout) return;
+    int col = p;
+    if (mode == 0) col = (p == 0) ? P : p - 1;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += (double)partials[(size_t)b * stride + col];
+    if (mode == 1 && p >= pd.pol.n_params) {
+        // Hessian of mean KL w.r.t. log_std at theta_old: 4 s^2 (2 s^2 - eps) / (2 s^2 + eps)^2  (-> 2 as eps -> 0)
+        double w = 0.0;
+        for (int b = 0; b < nblocks; ++b) w += (double)partials[(size_t)b * stride + P + 2];
+        const double raw = (double)theta[p];
+        const double s2 = exp(2.0 * fmax(raw, (double)LOG_MIN_STD));
+        const double c = 4.0 * s2 * (2.0 * s2 - 1e-8) / ((2.0 * s2 + 1e-8) * (2.0 * s2 + 1e-8));
+        s = (raw > (double)LOG_MIN_STD) ? c * v[p] * w : 0.0;
+    }
+    out[p] = s;
+}
+
+__global__ void k_d2f(const double* __restrict__ in, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+static int update_grid(metrpo_ctx* c, long long N) {
+    long long tiles = (N + PT - 1) / PT;
+    long long g = std::min<long long>(tiles, (long long)c->n_sm * 2);
+    return (int)std::max<long long>(g, 1);
+}
+
+static int ensure_partials(metrpo_ctx* c, int nblocks) {
+    const size_t need = (size_t)nblocks * (c->pd.P + PART_EXTRA);
+    if (need > c->partials_cap) {
+        if (c->d_partials) HIP_TRY(c, hipFree(c->d_partials));
+        c->d_partials = nullptr; c->partials_cap = 0;
+        HIP_TRY(c, hipMalloc(&c->d_partials, need * sizeof(float)));
+        c->partials_cap = need;
+    }
+    return METRPO_OK;
+}
+
+static int fill_polk(metrpo_ctx* c, const metrpo_batch* b, PolK* k) {
+    if (!b || !b->d_obs) return set_err(c, METRPO_ENULL, "batch/d_obs is NULL");
+    if (b->N <= 0) return set_err(c, METRPO_EINVAL, "batch N must be positive");
+    if (c->pd.na > 32) return set_err(c, METRPO_EUNSUPPORTED, "na > 32");
+    k->obs = b->d_obs; k->act = b->d_act; k->adv = b->d_adv; k->old_mean = b->d_old_mean; k->old_ls = b->d_old_log_std;
+    k->ls_stride = b->old_log_std_stride; k->valid = b->d_valid; k->N = b->N; k->inv_n = (float)b->inv_n_global;
+    return METRPO_OK;
+}
+
+template <typename Kern>
+static int lds_attr(metrpo_ctx* c, Kern kern, size_t sh) {
+    if (sh > 160 * 1024) return set_err(c, METRPO_EUNSUPPORTED, "policy too wide for the update kernels' LDS tile");
+    if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    return METRPO_OK;
+}
+
+int launch_loss_grad(metrpo_ctx* c, const metrpo_batch* b, double* out, hipStream_t st) {
+    PolK k; int rc = fill_polk(c, b, &k); if (rc) return rc;
+    if (!b->d_act || !b->d_adv || !b->d_old_mean || !b->d_old_log_std) return set_err(c, METRPO_ENULL, "batch pointer is NULL");
+    const NetDesc& net = c->pd.pol;
+    int hrows = 0; for (int l = 0; l < net.n_layers; ++l) hrows += net.dims[l];
+    const size_t sh = (size_t)(hrows + c->pd.na) * PLD * sizeof(float);
+    if ((rc = lds_attr(c, k_loss_grad, sh))) return rc;
+    const int g = update_grid(c, b->N);
+    if ((rc = ensure_partials(c, g))) return rc;
+    hipLaunchKernelGGL(k_loss_grad, dim3(g), dim3(PT), sh, st, c->pd, k, c->d_theta, c->d_partials);
+    const int nout = c->pd.P + 1;
+    hipLaunchKernelGGL(k_finalize, dim3((nout + 127) / 128), dim3(128), 0, st, c->pd, 0, g, c->d_partials, c->d_theta,
+                       (const double*)nullptr, out);
+    HIP_TRY(c, hipGetLastError());
+    return METRPO_OK;
+}
+
+int launch_fvp(metrpo_ctx* c, const metrpo_batch* b, const double* v, double* hv, hipStream_t st) {
+    PolK k; int rc = fill_polk(c, b, &k); if (rc) return rc;
+    if (!v || !hv) return set_err(c, METRPO_ENULL, "v/hv is NULL");
+    const NetDesc& net = c->pd.pol;
+    int hrows = 0; for (int l = 0; l < net.n_layers; ++l) hrows += net.dims[l];
+    const int trows = hrows - net.dims[0];
+    const size_t sh = (size_t)(hrows + c->pd.na + trows) * PLD * sizeof(float);
+    if ((rc = lds_attr(c, k_fvp, sh))) return rc;
+    const int g = update_grid(c, b->N);
+    if ((rc = ensure_partials(c, g))) return rc;
+    const int P = c->pd.P;
+    hipLaunchKernelGGL(k_d2f, dim3((P + 127) / 128), dim3(128), 0, st, v, c->d_vf, P);
+    hipLaunchKernelGGL(k_fvp, dim3(g), dim3(PT), sh, st, c->pd, k, c->d_theta, c->d_vf, c->d_partials);
+    hipLaunchKernelGGL(k_finalize, dim3((P + 127) / 128), dim3(128), 0, st, c->pd, 1, g, c->d_partials, c->d_theta, v, hv);
+    HIP_TRY(c, hipGetLastError());
+    return METRPO_OK;
+}
+
+int launch_loss_kl(metrpo_ctx* c, const metrpo_batch* b, const float* theta, double* out, hipStream_t st) {
+    PolK k; int rc = fill_polk(c, b, &k); if (rc) return rc;
+    if (!b->d_act || !b->d_adv || !b->d_old_mean || !b->d_old_log_std) return set_err(c, METRPO_ENULL, "batch pointer is NULL");
+    const NetDesc& net = c->pd.pol;
+    const size_t sh = (size_t)(c->pd.ns + 2 * net.max_width) * PLD * sizeof(float);
+    if ((rc = lds_attr(c, k_loss_kl, sh))) return rc;
+    const int g = update_grid(c, b->N);
+    if ((rc = ensure_partials(c, g))) return rc;
+    hipLaunchKernelGGL(k_loss_kl, dim3(g), dim3(PT), sh, st, c->pd, k, theta ? theta : c->d_theta, c->d_partials);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(128), 0, st, c->pd, 2, g, c->d_partials, c->d_theta,
+                       (const double*)nullptr, out);
+    HIP_TRY(c, hipGetLastError());
+    return METRPO_OK;
+}

@@ -1,0 +1,292 @@
+"""Thin tensor-level wrapper of one metrpo_ctx (one GPU).  torch is used for device memory and
+streams only; all arithmetic happens in libmetrpo.so.  Every method enqueues on torch's current
+stream of the engine's device."""
+import ctypes as C
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+Trajectory = namedtuple('Trajectory', 'obs act rew mean done tpath last_obs B T H')
+"""Time-major device tensors of one rollout: obs [T,B,ns], act [T,B,na] (unclipped), rew [T,B],
+mean [T,B,na], done [T,B] uint8, tpath [T,B] int32, last_obs [B,ns]."""
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _f32(t, dev, shape=None):
+    if t is None:
+        return None
+    t = torch.as_tensor(t, device=dev).to(torch.float32).contiguous()
+    if shape is not None:
+        assert tuple(t.shape) == tuple(shape), "expected shape %s, got %s" % (shape, tuple(t.shape))
+    return t
+
+
+def _i32(t, dev, shape=None):
+    if t is None:
+        return None
+    t = torch.as_tensor(t, device=dev).to(torch.int32).contiguous()
+    if shape is not None:
+        assert tuple(t.shape) == tuple(shape), "expected shape %s, got %s" % (shape, tuple(t.shape))
+    return t
+
+
+class Engine(object):
+    """Owns the metrpo_ctx for one (env, ensemble shape, policy shape) on one GPU."""
+
+    def __init__(self, env, n_models, dyn_hidden, pol_hidden, ns=None, na=None, n_drop=None, dyn_act='relu',
+                 device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("metrpo_amd needs an AMD GPU (gfx950); there is no CPU fallback")
+        self.env_name = env.replace('-', '_')
+        specs = {'swimmer': (10, 2, 2), 'half_cheetah': (18, 6, 1), 'ant': (29, 8, 2), 'humanoid': (55, 21, 0),
+                 'hopper': (11, 3, 0), 'snake': (14, 4, 2)}
+        d_ns, d_na, d_drop = specs[self.env_name]
+        self.ns, self.na = ns or d_ns, na or d_na
+        self.n_drop = d_drop if n_drop is None else n_drop
+        self.K = int(n_models)
+        self.dyn_hidden, self.pol_hidden = list(dyn_hidden), list(pol_hidden)
+        self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
+        acts = [dyn_act] * len(self.dyn_hidden) if isinstance(dyn_act, str) else list(dyn_act)
+        d = _lib.Dims()
+        d.env, d.ns, d.na, d.n_models = _lib.ENV_IDS[self.env_name], self.ns, self.na, self.K
+        d.dyn_n_hidden, d.n_drop, d.pol_n_hidden = len(self.dyn_hidden), self.n_drop, len(self.pol_hidden)
+        for i, h in enumerate(self.dyn_hidden):
+            d.dyn_hidden[i], d.dyn_act[i] = h, _lib.ACTS[acts[i]]
+        for i, h in enumerate(self.pol_hidden):
+            d.pol_hidden[i] = h
+        self._ctx = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = lib.metrpo_create(C.byref(self._ctx), self.device.index, C.byref(d))
+        check(rc, self._ctx if self._ctx else None)
+        self.dyn_param_count = lib.metrpo_dyn_param_count(self._ctx)
+        self.P = lib.metrpo_policy_param_count(self._ctx)
+        self.pol_dims = [self.ns] + self.pol_hidden + [self.na]
+        self.has_mfma_path = bool(lib.metrpo_has_mfma_path(self._ctx))
+        self._cb_keepalive = None
+
+    def __del__(self):
+        ctx = getattr(self, '_ctx', None)
+        if ctx:
+            lib.metrpo_destroy(ctx)
+            self._ctx = None
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _chk(self, rc):
+        check(rc, self._ctx)
+
+    # ------------------------------------------------------------------ weights
+    def set_dynamics(self, params, in_mean, in_std, diff_mean, diff_std):
+        """params [K, dyn_param_count] (per model: W0,b0,...,Wout,bout, W row-major (n_in,n_out))."""
+        dev = self.device
+        p = _f32(params, dev, (self.K, self.dyn_param_count))
+        a = _f32(in_mean, dev, (self.ns + self.na,)); b = _f32(in_std, dev, (self.ns + self.na,))
+        c = _f32(diff_mean, dev, (self.ns,)); e = _f32(diff_std, dev, (self.ns,))
+        self._chk(lib.metrpo_set_dynamics(self._ctx, _ptr(p), _ptr(a), _ptr(b), _ptr(c), _ptr(e), self._stream()))
+        torch.cuda.current_stream(dev).synchronize()     # inputs may be temporaries
+
+    def set_dynamics_layers(self, Ws, bs, in_mean, in_std, diff_mean, diff_std):
+        """Ws[l]: [K, n_in, n_out], bs[l]: [K, n_out] -> packs the flat per-model layout."""
+        parts = []
+        for W, b in zip(Ws, bs):
+            W = torch.as_tensor(W); b = torch.as_tensor(b)
+            parts += [W.reshape(self.K, -1), b.reshape(self.K, -1)]
+        self.set_dynamics(torch.cat([p.to(torch.float32) for p in parts], dim=1), in_mean, in_std, diff_mean, diff_std)
+
+    def set_policy(self, theta):
+        t = _f32(theta, self.device, (self.P,))
+        self._chk(lib.metrpo_set_policy(self._ctx, _ptr(t), self._stream()))
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def get_policy(self):
+        out = torch.empty(self.P, dtype=torch.float32, device=self.device)
+        self._chk(lib.metrpo_get_policy(self._ctx, _ptr(out), self._stream()))
+        return out
+
+    # ------------------------------------------------------------------ step-level API
+    def policy_actions(self, obs, eps=None):
+        dev = self.device
+        obs = _f32(obs, dev); B = obs.shape[0]
+        eps = _f32(eps, dev, (B, self.na))
+        actions = torch.empty(B, self.na, dtype=torch.float32, device=dev)
+        mean = torch.empty_like(actions)
+        self._chk(lib.metrpo_policy_actions(self._ctx, _ptr(obs), _ptr(eps), B, _ptr(actions), _ptr(mean), self._stream()))
+        return actions, mean
+
+    def step(self, s, a, sam_mode, model_idx=None, noise=None, want_all=False):
+        dev = self.device
+        s = _f32(s, dev); B = s.shape[0]
+        a = _f32(a, dev, (B, self.na))
+        model_idx = _i32(model_idx, dev, (B,)); noise = _f32(noise, dev, (B, self.ns))
+        s_next = torch.empty(B, self.ns, dtype=torch.float32, device=dev)
+        rew = torch.empty(B, dtype=torch.float32, device=dev)
+        done = torch.empty(B, dtype=torch.uint8, device=dev)
+        nall = torch.empty(self.K, B, self.ns, dtype=torch.float32, device=dev) if want_all else None
+        self._chk(lib.metrpo_step(self._ctx, _ptr(s), _ptr(a), B, _lib.SAM_MODES[sam_mode], _ptr(model_idx), _ptr(noise),
+                                  _ptr(s_next), _ptr(rew), _ptr(done), _ptr(nall), self._stream()))
+        return (s_next, rew, done, nall) if want_all else (s_next, rew, done)
+
+    # ------------------------------------------------------------------ fused rollout
+    def rollout(self, B, T, H, sam_mode, pool, determ=False, eval_all_heads=True, seed=0, stream_offset=0,
+                eps=None, model_idx=None, sel_noise=None, reset_idx=None, reset_model=None, out=None,
+                force_generic=False):
+        dev = self.device
+        pool = _f32(pool, dev); assert pool.dim() == 2 and pool.shape[1] == self.ns
+        eps = _f32(eps, dev, (T, B, self.na)); sel_noise = _f32(sel_noise, dev, (T, B, self.ns))
+        model_idx = _i32(model_idx, dev, (T, B))
+        reset_idx = _i32(reset_idx, dev, (T + 1, B)); reset_model = _i32(reset_model, dev, (T + 1, B))
+        if out is None:
+            out = self.alloc_trajectory(B, T, H)
+        a = _lib.RolloutArgs()
+        a.B, a.T, a.H, a.sam_mode = B, T, H, _lib.SAM_MODES[sam_mode]
+        a.determ, a.eval_all_heads = int(bool(determ)), int(bool(eval_all_heads))
+        a.d_pool, a.n_pool, a.seed, a.stream_offset = pool.data_ptr(), pool.shape[0], int(seed), int(stream_offset)
+        for name, t in (('d_eps', eps), ('d_model_idx', model_idx), ('d_sel_noise', sel_noise),
+                        ('d_reset_idx', reset_idx), ('d_reset_model', reset_model)):
+            setattr(a, name, t.data_ptr() if t is not None else None)
+        a.d_obs, a.d_act, a.d_rew, a.d_mean = out.obs.data_ptr(), out.act.data_ptr(), out.rew.data_ptr(), out.mean.data_ptr()
+        a.d_done, a.d_tpath, a.d_last_obs = out.done.data_ptr(), out.tpath.data_ptr(), out.last_obs.data_ptr()
+        fn = lib.metrpo_rollout_generic if force_generic else lib.metrpo_rollout
+        self._chk(fn(self._ctx, C.byref(a), self._stream()))
+        self._keep = (pool, eps, model_idx, sel_noise, reset_idx, reset_model)   # alive until the stream has consumed them
+        return out
+
+    def alloc_trajectory(self, B, T, H):
+        dev, f = self.device, torch.float32
+        return Trajectory(torch.empty(T, B, self.ns, dtype=f, device=dev), torch.empty(T, B, self.na, dtype=f, device=dev),
+                          torch.empty(T, B, dtype=f, device=dev), torch.empty(T, B, self.na, dtype=f, device=dev),
+                          torch.empty(T, B, dtype=torch.uint8, device=dev), torch.empty(T, B, dtype=torch.int32, device=dev),
+                          torch.empty(B, self.ns, dtype=f, device=dev), B, T, H)
+
+    def validation_cost(self, s0, T, gamma):
+        s0 = _f32(s0, self.device); assert s0.shape[1] == self.ns
+        costs = torch.empty(self.K, dtype=torch.float64, device=self.device)
+        self._chk(lib.metrpo_validation_cost(self._ctx, _ptr(s0), s0.shape[0], int(T), float(gamma), _ptr(costs), self._stream()))
+        return costs
+
+    # ------------------------------------------------------------------ process_samples pieces
+    def gae(self, traj, coeffs, gamma, lam):
+        """-> adv (uncentred), ret, valid, stats[3] = (sum adv, sum adv^2, count) over valid samples."""
+        dev = self.device
+        T, B = traj.T, traj.B
+        adv = torch.empty(T, B, dtype=torch.float32, device=dev); ret = torch.empty_like(adv)
+        valid = torch.empty(T, B, dtype=torch.uint8, device=dev)
+        stats = torch.zeros(3, dtype=torch.float64, device=dev)
+        if coeffs is not None:
+            coeffs = torch.as_tensor(coeffs, device=dev).to(torch.float64).contiguous()
+            assert coeffs.numel() == 2 * self.ns + 4
+        self._chk(lib.metrpo_gae(self._ctx, _ptr(traj.obs), _ptr(traj.rew), _ptr(traj.done), _ptr(traj.tpath), T, B,
+                                 _ptr(coeffs), float(gamma), float(lam), _ptr(adv), _ptr(ret), _ptr(valid), _ptr(stats),
+                                 self._stream()))
+        return adv, ret, valid, stats
+
+    def center_advantages(self, adv, valid, stats):
+        self._chk(lib.metrpo_center_advantages(self._ctx, _ptr(adv), _ptr(valid), adv.numel(), _ptr(stats), self._stream()))
+        return adv
+
+    def baseline_gram(self, obs, ret, tpath, valid):
+        F = 2 * self.ns + 4
+        AtA = torch.zeros(F, F, dtype=torch.float64, device=self.device)
+        Aty = torch.zeros(F, dtype=torch.float64, device=self.device)
+        self._chk(lib.metrpo_baseline_gram(self._ctx, _ptr(obs), _ptr(ret), _ptr(tpath), _ptr(valid), ret.numel(),
+                                           _ptr(AtA), _ptr(Aty), self._stream()))
+        return AtA, Aty
+
+    # ------------------------------------------------------------------ TRPO update pieces
+    def make_batch(self, obs, act, adv, old_mean, old_log_std, valid=None, n_global=None):
+        dev = self.device
+        obs = _f32(obs, dev).reshape(-1, self.ns); N = obs.shape[0]
+        act = _f32(act, dev).reshape(N, self.na); adv = _f32(adv, dev).reshape(N)
+        old_mean = _f32(old_mean, dev).reshape(N, self.na)
+        old_log_std = _f32(old_log_std, dev)
+        stride = 0 if old_log_std.numel() == self.na else self.na
+        if stride:
+            old_log_std = old_log_std.reshape(N, self.na)
+        if valid is not None:
+            valid = torch.as_tensor(valid, device=dev).to(torch.uint8).contiguous().reshape(N)
+        if n_global is None:
+            n_global = int(valid.sum().item()) if valid is not None else N
+        b = _lib.Batch()
+        b.d_obs, b.d_act, b.d_adv, b.d_old_mean = obs.data_ptr(), act.data_ptr(), adv.data_ptr(), old_mean.data_ptr()
+        b.d_old_log_std, b.old_log_std_stride = old_log_std.data_ptr(), stride
+        b.d_valid = valid.data_ptr() if valid is not None else None
+        b.N, b.inv_n_global = N, 1.0 / float(n_global)
+        b._keep = (obs, act, adv, old_mean, old_log_std, valid)
+        return b
+
+    def loss_grad(self, batch):
+        out = torch.empty(self.P + 1, dtype=torch.float64, device=self.device)
+        self._chk(lib.metrpo_loss_grad(self._ctx, C.byref(batch), _ptr(out), self._stream()))
+        return out
+
+    def fvp(self, batch, v):
+        v = torch.as_tensor(v, device=self.device).to(torch.float64).contiguous()
+        hv = torch.empty(self.P, dtype=torch.float64, device=self.device)
+        self._chk(lib.metrpo_fvp(self._ctx, C.byref(batch), _ptr(v), _ptr(hv), self._stream()))
+        return hv
+
+    def loss_kl(self, batch, theta=None):
+        theta = _f32(theta, self.device, (self.P,)) if theta is not None else None
+        out = torch.empty(2, dtype=torch.float64, device=self.device)
+        self._chk(lib.metrpo_loss_kl(self._ctx, C.byref(batch), _ptr(theta), _ptr(out), self._stream()))
+        return out
+
+    def trpo_update(self, batch, max_kl=0.01, cg_iters=10, reg_coeff=1e-5, backtrack_ratio=0.8, max_backtracks=15,
+                    accept_violation=False, residual_tol=1e-10, allreduce=None, want_vectors=False):
+        """One ConjugateGradientOptimizer.optimize; `allreduce(tensor_f64)` reduces in place across ranks."""
+        p = _lib.TrpoParams()
+        p.max_kl, p.cg_iters, p.reg_coeff, p.backtrack_ratio = max_kl, cg_iters, reg_coeff, backtrack_ratio
+        p.max_backtracks, p.accept_violation, p.residual_tol = max_backtracks, int(accept_violation), residual_tol
+        if allreduce is not None:
+            dev = self.device
+
+            def _cb(user, d_buf, count, stream):
+                try:
+                    view = torch.as_tensor(_DevView(d_buf, count), device=dev)
+                    allreduce(view)
+                    return 0
+                except Exception:      # never let an exception cross the C ABI
+                    import traceback
+                    traceback.print_exc()
+                    return -1
+            cb = _lib.ALLREDUCE_FN(_cb)
+            p.allreduce = cb
+            self._cb_keepalive = cb
+        diag = _lib.TrpoDiag()
+        g = d = None
+        if want_vectors:
+            g = torch.empty(self.P, dtype=torch.float64, device=self.device); d = torch.empty_like(g)
+        self._chk(lib.metrpo_trpo_update(self._ctx, C.byref(batch), C.byref(p), C.byref(diag), _ptr(g), _ptr(d), self._stream()))
+        out = dict(loss_before=diag.loss_before, loss=diag.loss, kl=diag.kl, beta=diag.beta,
+                   n_backtrack=diag.n_backtrack, accepted=bool(diag.accepted), cg_iters_run=diag.cg_iters_run)
+        if want_vectors:
+            out['g'], out['d'] = g, d
+        return out
+
+
+class _DevView(object):
+    """Zero-copy float64 view of library-owned device memory for torch (CUDA array interface)."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {'shape': (int(count),), 'typestr': '<f8', 'data': (int(ptr), False), 'version': 2}
+
+
+def xavier_policy_theta(ns, hidden, na, init_std=1.0, seed=0):
+    """[rllab] GaussianMLPPolicy initial parameters: Xavier-uniform W, zero b, log_std = log(init_std)."""
+    rng = np.random.RandomState(seed)
+    dims = [ns] + list(hidden) + [na]
+    parts = []
+    for i in range(len(dims) - 1):
+        lim = np.sqrt(6.0 / (dims[i] + dims[i + 1]))
+        parts += [rng.uniform(-lim, lim, size=dims[i] * dims[i + 1]), np.zeros(dims[i + 1])]
+    parts.append(np.full(na, np.log(init_std)))
+    return np.concatenate(parts).astype(np.float32)

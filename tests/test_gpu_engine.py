@@ -1,0 +1,320 @@
+"""GPU parity: every C-ABI kernel entry point vs the CPU oracle (float64) on identical inputs and
+identical supplied random draws.  Tolerances are those of SURVEY.md 8d (fp32 device vs fp64 oracle)."""
+import numpy as np
+import pytest
+import torch
+from conftest import load_golden, dm_from_golden
+from oracle import metrpo_oracle as O
+import helpers as Hh
+
+pytestmark = pytest.mark.gpu
+
+STEP_TOL = dict(rtol=1e-5, atol=2e-6)
+
+
+def cpu(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+@pytest.mark.parametrize('env,sam_mode', [('swimmer', m) for m in O.SAM_MODES] +
+                         [('ant', 'step_rand'), ('half_cheetah', 'model_med'), ('hopper', 'eps_rand'),
+                          ('snake', 'model_mean_std'), ('humanoid', 'step_rand')])
+def test_step_parity(env, sam_mode):
+    K = 5 if env != 'humanoid' else 4
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (64, 64), (32, 32), seed=3)
+    rng = np.random.RandomState(0)
+    B = 333
+    s = pool[rng.randint(len(pool), size=B)] + rng.randn(B, dm.ns) * 0.05
+    if env == 'ant':
+        s[:, 2] = rng.uniform(0.1, 1.1, size=B)
+    a = rng.randn(B, dm.na) * 0.9
+    idx = rng.randint(K, size=B)
+    noise = rng.randn(B, dm.ns)
+    s32 = s.astype(np.float32).astype(np.float64); a32 = a.astype(np.float32).astype(np.float64)
+    s_next, rew, done, nall = eng.step(s, a, sam_mode, idx, noise.astype(np.float32), want_all=True)
+    ac = np.clip(a32, -1, 1)
+    ref_all = O.dynamics_forward_all(dm, s32, ac)
+    np.testing.assert_allclose(cpu(nall), ref_all, **STEP_TOL)
+    ref_next = O.select_next(ref_all, sam_mode, idx, noise.astype(np.float32).astype(np.float64))
+    np.testing.assert_allclose(cpu(s_next), ref_next, **STEP_TOL)
+    np.testing.assert_allclose(cpu(rew), -O.cost_np_vec(env, s32, ac, ref_next), rtol=1e-5, atol=5e-6)
+    ref_done = O.is_done(env, ref_next, ref_next)
+    near = np.zeros(B, bool)
+    if env == 'ant':   # exclude samples within fp32 rounding of the 0.2/1.0 thresholds
+        near = (np.abs(ref_next[:, 2] - 0.2) < 1e-5) | (np.abs(ref_next[:, 2] - 1.0) < 1e-5)
+        assert ref_done.any() and not ref_done.all()
+    assert np.array_equal(cpu(done).astype(bool)[~near], ref_done[~near])
+
+
+@pytest.mark.parametrize('name', ['vecenv_swimmer_step_rand', 'vecenv_ant_step_rand', 'vecenv_swimmer_model_med',
+                                  'vecenv_swimmer_model_mean_std', 'vecenv_swimmer_eps_rand', 'vecenv_swimmer_one_model',
+                                  'vecenv_swimmer_model_mean'])
+def test_step_against_reference_golden(name):
+    """Teacher-forced replay of the reference's own VecSimpleEnv traces (tests/golden)."""
+    import metrpo_amd
+    d = load_golden(name)
+    env, sam_mode = str(d['env']), str(d['sam_mode'])
+    dm = dm_from_golden(d, env)
+    hidden = [w.shape[2] for w in dm.Ws[:-1]]
+    eng = metrpo_amd.Engine(env, dm.K, hidden, (8, 8))
+    eng.set_dynamics_layers(dm.Ws, dm.bs, dm.in_mean, dm.in_std, dm.diff_mean, dm.diff_std)
+    T, B = d['actions'].shape[:2]
+    state = d['first_obs'].copy()
+    # recover the per-step model indices / noise the reference drew from its recorded K-head outputs
+    for t in range(T):
+        nall_ref = d['next_all'][t]
+        s_next, rew, done, nall = eng.step(state, d['actions'][t], 'one_model', None, None, want_all=True)
+        np.testing.assert_allclose(cpu(nall), nall_ref, rtol=1e-5, atol=2e-6)
+        # the reference's post-step state for non-reset envs must be one of / a function of the heads we computed
+        dn = d['dones'][t]
+        got = cpu(nall)
+        if sam_mode in ('model_mean', 'model_med', 'one_model'):
+            s2, r2, d2 = eng.step(state, d['actions'][t], sam_mode, None, None)
+            keep = ~dn
+            np.testing.assert_allclose(cpu(s2)[keep], d['states'][t][keep], rtol=1e-5, atol=2e-6)
+            np.testing.assert_allclose(cpu(r2), d['rewards'][t], rtol=1e-5, atol=5e-6)
+        elif sam_mode in ('step_rand', 'eps_rand'):
+            # find which head the reference selected, feed that index, compare reward
+            ref_sel = np.array([np.argmin([np.abs(nall_ref[k, b] - (d['states'][t][b] if not dn[b] else nall_ref[k, b])).max()
+                                           for k in range(dm.K)]) for b in range(B)])
+            s2, r2, d2 = eng.step(state, d['actions'][t], sam_mode, ref_sel, None)
+            keep = ~dn
+            np.testing.assert_allclose(cpu(s2)[keep], d['states'][t][keep], rtol=1e-5, atol=2e-6)
+            np.testing.assert_allclose(cpu(r2)[keep], d['rewards'][t][keep], rtol=1e-5, atol=5e-6)
+        state = d['states'][t]          # teacher forcing with the reference's own next state (incl. resets)
+        del got
+
+
+def test_policy_actions_parity():
+    eng, dm, theta, pdims, pool = Hh.make_engine('half_cheetah', 3, (64, 64), (32, 32), seed=5)
+    rng = np.random.RandomState(1)
+    obs = rng.randn(777, dm.ns).astype(np.float32); eps = rng.randn(777, dm.na).astype(np.float32)
+    a, m = eng.policy_actions(obs, eps)
+    ra, info = O.policy_get_actions(theta.astype(np.float32).astype(np.float64), pdims, obs.astype(np.float64), eps.astype(np.float64))
+    np.testing.assert_allclose(cpu(m), info['mean'], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(cpu(a), ra, rtol=1e-5, atol=5e-6)
+    a2, m2 = eng.policy_actions(obs, None)            # determ=True path: actions = mean
+    assert torch.equal(a2, m2) and torch.equal(m2, m)
+
+
+@pytest.mark.parametrize('force_generic', [True, False])
+@pytest.mark.parametrize('env,sam_mode,determ', [('swimmer', 'step_rand', False), ('swimmer', 'eps_rand', True),
+                                                 ('ant', 'step_rand', False), ('swimmer', 'model_mean_std', False),
+                                                 ('half_cheetah', 'model_med', False), ('snake', 'model_mean', False),
+                                                 ('hopper', 'one_model', False)])
+def test_rollout_parity_teacher_forced(env, sam_mode, determ, force_generic):
+    """Fused rollout vs oracle with supplied draws.  Free-running for the discrete structure (dones,
+    tpath, resets), teacher-forced (oracle fed the device's own observations) for the per-step values."""
+    K, B, T, H = 5, 200, 12, 5
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (64, 64), (32, 32), seed=7)
+    if env == 'ant':
+        pool[::3, 2] = 0.21; dm.diff_mean[2] = -0.02
+        eng.set_dynamics_layers(dm.Ws, dm.bs, dm.in_mean, dm.in_std, dm.diff_mean, dm.diff_std)
+    th = theta.astype(np.float32).astype(np.float64)
+    dr = Hh.draws(np.random.RandomState(2), K, B, T, dm.ns, dm.na, len(pool))
+    dr32 = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in dr.items()}
+    traj = eng.rollout(B, T, H, sam_mode, pool, determ=determ, force_generic=force_generic, **dr32)
+    torch.cuda.synchronize()
+    drf = {k: (v.astype(np.float64) if v.dtype == np.float32 else v) for k, v in dr32.items()}
+    pool32 = pool.astype(np.float32).astype(np.float64)
+    ref = Hh.oracle_rollout(dm, th, pdims, env, pool32, drf, B, T, H, sam_mode, determ, teacher_obs=cpu(traj.obs))
+    np.testing.assert_allclose(cpu(traj.mean), ref['mean'], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(cpu(traj.act), ref['act'], rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(cpu(traj.rew), ref['rew'], rtol=1e-5, atol=5e-6)
+    # next state: obs[t+1] == oracle next(t) wherever no reset happened; pool rows where it did
+    dn = cpu(traj.done).astype(bool)
+    for t in range(T - 1):
+        keep = ~dn[t]
+        np.testing.assert_allclose(cpu(traj.obs[t + 1])[keep], ref['next'][t][keep], rtol=1e-5, atol=2e-6)
+        np.testing.assert_array_equal(cpu(traj.obs[t + 1])[~keep], pool32[dr['reset_idx'][t + 1]][~keep])
+    np.testing.assert_array_equal(cpu(traj.obs[0]), pool32[dr['reset_idx'][0]])
+    # discrete structure: horizon resets at exactly H unless terminated early; tpath counts from 0
+    free = Hh.oracle_rollout(dm, th, pdims, env, pool32, drf, B, T, H, sam_mode, determ)
+    if env != 'ant':
+        assert np.array_equal(dn, free['done'])
+        assert np.array_equal(cpu(traj.tpath), free['tpath'])
+        assert dn[H - 1].all() and not dn[:H - 1].any()
+    else:
+        agree = (dn == free['done']).mean()
+        assert agree > 0.98 and dn.any() and (cpu(traj.tpath) <= H - 1).all()
+        assert dn[cpu(traj.tpath) == H - 1].all()
+
+
+def test_rollout_free_running_short():
+    """t <= 10 free-running agreement on the default (fastest available) path."""
+    K, B, T, H = 5, 256, 10, 50
+    eng, dm, theta, pdims, pool = Hh.make_engine('swimmer', K, (64, 64), (32, 32), seed=9)
+    dr = Hh.draws(np.random.RandomState(3), K, B, T, dm.ns, dm.na, len(pool))
+    dr32 = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in dr.items()}
+    traj = eng.rollout(B, T, H, 'step_rand', pool, **dr32)
+    drf = {k: (v.astype(np.float64) if v.dtype == np.float32 else v) for k, v in dr32.items()}
+    ref = Hh.oracle_rollout(dm, theta.astype(np.float32).astype(np.float64), pdims, 'swimmer',
+                            pool.astype(np.float32).astype(np.float64), drf, B, T, H, 'step_rand')
+    np.testing.assert_allclose(cpu(traj.obs), ref['obs'], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(cpu(traj.rew), ref['rew'], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(cpu(traj.last_obs), ref['last_obs'], rtol=1e-4, atol=2e-5)
+
+
+def test_rollout_philox_statistics():
+    """Production RNG: draws are N(0,1) / uniform over K and pool; different seeds differ; same seed repeats."""
+    K, B, T, H = 5, 4096, 8, 4
+    eng, dm, theta, pdims, pool = Hh.make_engine('swimmer', K, (64, 64), (32, 32), seed=11)
+    t1 = eng.rollout(B, T, H, 'step_rand', pool, seed=123)
+    a1 = cpu(t1.act).copy(); o1 = cpu(t1.obs).copy()
+    t2 = eng.rollout(B, T, H, 'step_rand', pool, seed=123)
+    assert np.array_equal(a1, cpu(t2.act)) and np.array_equal(o1, cpu(t2.obs))
+    t3 = eng.rollout(B, T, H, 'step_rand', pool, seed=124)
+    assert not np.array_equal(a1, cpu(t3.act))
+    z = (a1 - cpu(t1.mean)) / np.exp(theta[-dm.na:].astype(np.float32))
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1.0) < 0.02
+    assert abs(np.mean(z ** 3)) < 0.05 and abs(np.mean(z ** 4) - 3.0) < 0.15
+    # initial states are pool rows, spread over the pool
+    rows = {tuple(np.round(r, 6)) for r in pool.astype(np.float32)}
+    assert all(tuple(np.round(r, 6)) in rows for r in o1[0][:64])
+    assert len({tuple(r) for r in o1[0]}) > 0.9 * min(B, len(pool)) * (1 - np.exp(-B / len(pool)))
+    # stream_offset shifts the env counter: rank 1's envs == the upper half of a double-sized run
+    big = eng.rollout(2 * B, T, H, 'step_rand', pool, seed=7)
+    hi = eng.rollout(B, T, H, 'step_rand', pool, seed=7, stream_offset=B)
+    assert np.array_equal(cpu(big.act)[:, B:], cpu(hi.act))
+
+
+@pytest.mark.parametrize('gamma,lam,use_coeffs', [(1.0, 1.0, False), (0.99, 0.95, True), (0.99, 1.0, True)])
+def test_gae_center_gram_parity(gamma, lam, use_coeffs):
+    env, K, B, T, H = 'ant', 4, 96, 23, 6
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (64, 64), (32, 32), seed=13)
+    pool[::3, 2] = 0.21; dm.diff_mean[2] = -0.02
+    eng.set_dynamics_layers(dm.Ws, dm.bs, dm.in_mean, dm.in_std, dm.diff_mean, dm.diff_std)
+    dr = Hh.draws(np.random.RandomState(4), K, B, T, dm.ns, dm.na, len(pool))
+    traj = eng.rollout(B, T, H, 'step_rand', pool, **{k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in dr.items()})
+    coeffs = np.random.RandomState(5).randn(2 * dm.ns + 4) * 0.05 if use_coeffs else None
+    adv, ret, valid, stats = eng.gae(traj, coeffs, gamma, lam)
+    tr = dict(obs=cpu(traj.obs), act=cpu(traj.act), rew=cpu(traj.rew), mean=cpu(traj.mean),
+              done=cpu(traj.done).astype(bool), tpath=cpu(traj.tpath))
+    paths = Hh.paths_from_timemajor(tr)
+    assert len({len(p['rewards']) for p in paths}) > 1            # ragged
+    base = O.LinearFeatureBaselineOracle()
+    base._coeffs = coeffs
+    samples = O.process_samples(paths, base, gamma, lam, center_adv=False)
+    tb = [x for p in paths for x in p['_tb']]
+    tt, bb = np.array(tb).T
+    v = cpu(valid).astype(bool)
+    assert v.sum() == len(tb) and v[tt, bb].all()                 # trailing unfinished paths are masked out
+    np.testing.assert_allclose(cpu(ret)[tt, bb], samples['returns'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(cpu(adv)[tt, bb], samples['advantages'], rtol=1e-5, atol=2e-5)
+    a = samples['advantages']
+    np.testing.assert_allclose(cpu(stats), [a.sum(), (a * a).sum(), len(a)], rtol=1e-5, atol=1e-4)
+    eng.center_advantages(adv, valid, stats)
+    np.testing.assert_allclose(cpu(adv)[tt, bb], O.center_advantages(a), rtol=1e-4, atol=1e-4)
+    assert (cpu(adv)[~v] == 0).all()
+    # baseline normal equations
+    AtA, Aty = eng.baseline_gram(traj.obs, ret, traj.tpath, valid)
+    F = np.concatenate([O.LinearFeatureBaselineOracle.features(p) for p in paths])
+    np.testing.assert_allclose(cpu(AtA), F.T @ F, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(cpu(Aty), F.T @ samples['returns'], rtol=1e-5, atol=1e-4)
+
+
+def _update_problem(env='swimmer', N=5000, seed=21, pol_hidden=(32, 32)):
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, 2, (64, 64), pol_hidden, seed=seed)
+    rng = np.random.RandomState(seed)
+    th = theta.astype(np.float32).astype(np.float64)
+    obs = (rng.randn(N, dm.ns) * 0.5).astype(np.float32).astype(np.float64)
+    old_mean = O.policy_mean(th, pdims, obs).astype(np.float32).astype(np.float64)
+    old_ls = np.broadcast_to(O.policy_log_std(th, pdims), old_mean.shape).copy()
+    act = (old_mean + np.exp(old_ls) * rng.randn(*old_mean.shape)).astype(np.float32).astype(np.float64)
+    adv = O.center_advantages(rng.randn(N)).astype(np.float32).astype(np.float64)
+    return eng, th, pdims, obs, act, adv, old_mean, old_ls
+
+
+def rel_l2(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+@pytest.mark.parametrize('env,pol_hidden,N', [('swimmer', (32, 32), 5000), ('half_cheetah', (32, 32), 3001),
+                                              ('humanoid', (100, 50, 25), 1500)])
+def test_loss_grad_fvp_losskl_parity(env, pol_hidden, N):
+    eng, th, pdims, obs, act, adv, om, ols = _update_problem(env, N, pol_hidden=pol_hidden)
+    valid = np.ones(N, np.uint8); valid[::7] = 0
+    keep = valid.astype(bool)
+    batch = eng.make_batch(obs, act, adv, om, ols, valid=valid)
+    out = cpu(eng.loss_grad(batch))
+    loss, g = O.surrogate_loss_grad(th, pdims, obs[keep], act[keep], adv[keep], om[keep], ols[keep])
+    assert abs(out[0] - loss) <= 1e-5 * max(1.0, abs(loss))
+    assert rel_l2(out[1:], g) <= 1e-5 * 5                         # gradient rel-L2 (fp32 sums over N)
+    v = np.random.RandomState(1).randn(eng.P)
+    hv = cpu(eng.fvp(batch, v))
+    ref = O.fisher_vector_product(th, pdims, obs[keep], v, reg_coeff=0.0)
+    assert rel_l2(hv, ref) <= 1e-4
+    # trial theta away from theta_old (lr != 1, kl > 0) -- also the broadcast log_std form (stride 0)
+    th2 = (th + np.random.RandomState(2).randn(th.size) * 0.02).astype(np.float32)
+    batch0 = eng.make_batch(obs, act, adv, om, ols[0], valid=valid)
+    for bt in (batch, batch0):
+        lk = cpu(eng.loss_kl(bt, th2))
+        l2, k2 = O.surrogate_loss_kl(th2.astype(np.float64), pdims, obs[keep], act[keep], adv[keep], om[keep], ols[keep])
+        assert abs(lk[0] - l2) <= 1e-5 * max(1.0, abs(l2)) and abs(lk[1] - k2) <= max(1e-7, 1e-4 * k2)
+    lk0 = cpu(eng.loss_kl(batch))                                 # at theta_old: lr = 1, kl = 0
+    assert abs(lk0[1]) < 1e-7 and abs(lk0[0] - loss) < 1e-6
+
+
+def test_update_is_bitwise_reproducible():
+    eng, th, pdims, obs, act, adv, om, ols = _update_problem(N=4000)
+    batch = eng.make_batch(obs, act, adv, om, ols)
+    a = eng.loss_grad(batch).clone(); b = eng.loss_grad(batch).clone()
+    assert torch.equal(a, b)
+    v = np.random.RandomState(1).randn(eng.P)
+    assert torch.equal(eng.fvp(batch, v).clone(), eng.fvp(batch, v).clone())
+
+
+@pytest.mark.parametrize('seed', [21, 22])
+def test_trpo_update_parity(seed):
+    eng, th, pdims, obs, act, adv, om, ols = _update_problem(N=6000, seed=seed)
+    batch = eng.make_batch(obs, act, adv, om, ols)
+    out = eng.trpo_update(batch, max_kl=0.01, want_vectors=True)
+    ref = O.cg_optimize(th, pdims, obs, act, adv, om, ols, max_kl=0.01)
+    assert rel_l2(cpu(out['g']), ref['g']) <= 5e-5
+    d, dref = cpu(out['d']), ref['d']
+    cos = d.dot(dref) / (np.linalg.norm(d) * np.linalg.norm(dref))
+    assert cos >= 0.9999 and rel_l2(d, dref) <= 1e-3
+    assert abs(out['beta'] - ref['beta']) <= 1e-3 * ref['beta']
+    assert out['accepted'] == ref['accepted'] and out['n_backtrack'] == ref['n_backtrack']
+    assert out['cg_iters_run'] == 10
+    assert abs(out['loss_before'] - ref['loss_before']) < 1e-6
+    assert abs(out['kl'] - ref['kl']) <= 1e-4 * max(ref['kl'], 1e-3) and out['kl'] <= 0.01 and out['loss'] < out['loss_before']
+    np.testing.assert_allclose(cpu(eng.get_policy()), ref['theta_new'], rtol=0, atol=2e-5)
+
+
+def test_trpo_update_rejects_and_restores():
+    eng, th, pdims, obs, act, adv, om, ols = _update_problem(N=2000)
+    before = eng.get_policy().clone()
+    out = eng.trpo_update(eng.make_batch(obs, act, adv * 0.0, om, ols))       # zero advantage -> nan step -> rejected
+    assert not out['accepted'] and torch.equal(before, eng.get_policy())
+
+
+@pytest.mark.parametrize('env', ['swimmer', 'ant', 'half_cheetah'])
+def test_validation_cost_parity(env):
+    K, Bv, T, gamma = 4, 500, 15, 0.97
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (64, 64), (32, 32), seed=31, n_pool=512)
+    if env == 'ant':
+        pool[::3, 2] = 0.25; dm.diff_mean[2] = -0.01
+        eng.set_dynamics_layers(dm.Ws, dm.bs, dm.in_mean, dm.in_std, dm.diff_mean, dm.diff_std)
+    s0 = pool[:Bv].astype(np.float32)
+    got = cpu(eng.validation_cost(s0, T, gamma))
+    ref = O.validation_costs(dm, theta.astype(np.float32).astype(np.float64), pdims, env, s0.astype(np.float64), T, gamma)
+    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4)
+
+
+def test_error_behaviour():
+    import metrpo_amd
+    from metrpo_amd._lib import MetrpoError
+    eng = metrpo_amd.Engine('swimmer', 3, (16, 16), (8, 8))
+    with pytest.raises(MetrpoError, match='not been called'):
+        eng.step(np.zeros((4, 10), np.float32), np.zeros((4, 2), np.float32), 'one_model')
+    with pytest.raises(KeyError):
+        eng.step(np.zeros((4, 10), np.float32), np.zeros((4, 2), np.float32), 'no_such_mode')
+    with pytest.raises(Exception):
+        metrpo_amd.Engine('swimmer', 0, (16,), (8,))
+    # empty batch is a no-op, not an error
+    eng, dm, theta, pdims, pool = Hh.make_engine('swimmer', 3, (16, 16), (8, 8))
+    s, r, d = eng.step(np.zeros((0, 10), np.float32), np.zeros((0, 2), np.float32), 'one_model')
+    assert s.shape == (0, 10)
+    with pytest.raises(MetrpoError, match='model_idx'):
+        eng.step(np.zeros((4, 10), np.float32), np.zeros((4, 2), np.float32), 'step_rand')
