@@ -8,5 +8,15 @@ ConjugateGradientOptimizer / LinearFeatureBaseline); all arithmetic runs in libm
 """
 from . import _lib                      # raises ImportError if libmetrpo.so is missing
 from .engine import Engine, Trajectory, xavier_policy_theta
+from .parallel import Comm
+from .imagined_env import NeuralNetEnv, VecSimpleEnv, InitStatePool, Box, EnvSpec
+from .policy import GaussianMLPPolicy
+from .baseline import LinearFeatureBaseline
+from .sampler import VectorizedSampler, BaseSampler, DevicePaths
+from .optimizer import ConjugateGradientOptimizer
+from .algos import BatchPolopt, NPO, TRPO
+from . import early_stop
 
-__all__ = ['Engine', 'Trajectory', 'xavier_policy_theta']
+__all__ = ['Engine', 'Trajectory', 'xavier_policy_theta', 'Comm', 'NeuralNetEnv', 'VecSimpleEnv', 'InitStatePool',
+           'Box', 'EnvSpec', 'GaussianMLPPolicy', 'LinearFeatureBaseline', 'VectorizedSampler', 'BaseSampler',
+           'DevicePaths', 'ConjugateGradientOptimizer', 'BatchPolopt', 'NPO', 'TRPO', 'early_stop']

@@ -1,0 +1,98 @@
+"""algos/batch_polopt.py, algos/npo.py, algos/trpo.py of the reference with the same constructor
+arguments, attributes and methods (start_worker / obtain_samples / process_samples /
+optimize_policy), so that the reference's outer loop (model_based_rl.py:1171-1180) drives them
+unchanged:
+
+    algo.start_worker(); paths = algo.obtain_samples(j); samples_data = algo.process_samples(j, paths)
+    algo.optimize_policy(j, samples_data)
+"""
+from .optimizer import ConjugateGradientOptimizer
+from .parallel import Comm
+from .sampler import VectorizedSampler
+
+
+class BatchPolopt(object):
+    def __init__(self, env, policy, baseline, scope=None, n_itr=500, start_itr=0, batch_size=5000,
+                 max_path_length=500, discount=0.99, gae_lambda=1, plot=False, pause_for_plot=False,
+                 center_adv=True, positive_adv=False, store_paths=False, whole_paths=True, fixed_horizon=False,
+                 sampler_cls=None, sampler_args=None, force_batch_sampler=False, comm=None, seed=0, **kwargs):
+        self.env, self.policy, self.baseline = env, policy, baseline
+        self.scope, self.n_itr, self.start_itr = scope, n_itr, start_itr
+        self.batch_size, self.max_path_length = batch_size, max_path_length
+        self.discount, self.gae_lambda = discount, gae_lambda
+        self.plot, self.pause_for_plot = plot, pause_for_plot
+        self.center_adv, self.positive_adv = center_adv, positive_adv
+        self.store_paths, self.whole_paths, self.fixed_horizon = store_paths, whole_paths, fixed_horizon
+        self.kwargs = kwargs
+        self.engine = policy.engine
+        self.comm = comm or Comm()
+        self.seed = seed
+        assert not force_batch_sampler, "BatchSampler is unreachable on this path (batch_polopt.py:86-90)"
+        if sampler_cls is None:
+            assert self.policy.vectorized
+            sampler_cls = VectorizedSampler
+        if sampler_args is None:
+            sampler_args = dict()
+        self.sampler = sampler_cls(self, **sampler_args)
+        self.init_opt()
+
+    def start_worker(self):
+        self.sampler.start_worker()
+
+    def shutdown_worker(self):
+        self.sampler.shutdown_worker()
+
+    def obtain_samples(self, itr, determ=False, **kw):
+        return self.sampler.obtain_samples(itr, determ, **kw)
+
+    def process_samples(self, itr, paths):
+        return self.sampler.process_samples(itr, paths)
+
+    def init_opt(self):
+        raise NotImplementedError
+
+    def optimize_policy(self, itr, samples_data):
+        raise NotImplementedError
+
+
+class NPO(BatchPolopt):
+    """Natural Policy Optimization (algos/npo.py)."""
+
+    def __init__(self, optimizer=None, optimizer_args=None, step_size=0.01, **kwargs):
+        if optimizer is None:
+            raise NotImplementedError("PenaltyLbfgsOptimizer (NPO's default, npo.py:24) is outside the hot path; "
+                                      "use TRPO or pass an optimizer")
+        self.optimizer = optimizer
+        self.step_size = step_size
+        super(NPO, self).__init__(**kwargs)
+
+    def init_opt(self):
+        # npo.py:85-91; the surrogate / mean-KL graph itself (npo.py:68-75) is what the HIP kernels compute
+        self.optimizer.update_opt(loss=None, target=self.policy, leq_constraint=(None, self.step_size),
+                                  inputs=None, constraint_name="mean_kl")
+        return dict()
+
+    def optimize_policy(self, itr, samples_data):
+        """npo.py:95-121: inputs = (observations, actions, advantages, agent_infos[mean], agent_infos[log_std])."""
+        agent_infos = samples_data["agent_infos"]
+        batch = self.engine.make_batch(samples_data["observations"], samples_data["actions"], samples_data["advantages"],
+                                       agent_infos["mean"], agent_infos["log_std"], valid=samples_data.get("valids"),
+                                       n_global=samples_data.get("n_valid_global"))
+        self.optimizer.optimize(self.engine, batch, comm=self.comm)
+        if hasattr(self.sampler, 'finish_baseline_fit'):
+            self.sampler.finish_baseline_fit()
+        return dict()
+
+    def get_itr_snapshot(self, itr, samples_data):
+        return dict(itr=itr, policy=self.policy, baseline=self.baseline, env=self.env)
+
+
+class TRPO(NPO):
+    """Trust Region Policy Optimization (algos/trpo.py)."""
+
+    def __init__(self, optimizer=None, optimizer_args=None, **kwargs):
+        if optimizer is None:
+            if optimizer_args is None:
+                optimizer_args = dict()
+            optimizer = ConjugateGradientOptimizer(**optimizer_args)
+        super(TRPO, self).__init__(optimizer=optimizer, **kwargs)

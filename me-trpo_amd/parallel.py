@@ -1,0 +1,54 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" == RCCL on ROCm,
+"gloo" for the CPU tests).  The imagined-env batch axis B is sharded across ranks; the only
+exchanges on the path are sum all-reduces of small float64 vectors:
+advantage statistics [3], baseline normal equations [F*F+F], loss+gradient [1+P], every
+Fisher-vector product [P] and each line-search (loss, kl) pair [2]."""
+import os
+
+import torch
+
+
+class Comm(object):
+    """World of 1 unless torch.distributed is initialised (or init_from_env() is called)."""
+
+    def __init__(self, group=None):
+        self.dist = torch.distributed if (torch.distributed.is_available() and torch.distributed.is_initialized()) else None
+        self.group = group
+        self.rank = self.dist.get_rank(group) if self.dist else 0
+        self.world = self.dist.get_world_size(group) if self.dist else 1
+
+    @staticmethod
+    def init_from_env(backend=None):
+        """torchrun-style bootstrap: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT."""
+        world = int(os.environ.get('WORLD_SIZE', '1'))
+        if world > 1 and not torch.distributed.is_initialized():
+            if backend is None:
+                backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            if backend == 'nccl':
+                torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            torch.distributed.init_process_group(backend=backend)
+        return Comm()
+
+    def allreduce_sum_(self, t):
+        """In-place sum over ranks; stream-ordered with the caller's current stream (torch semantics)."""
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier(group=self.group)
+
+    def max_float(self, x, device='cpu'):
+        if self.world == 1:
+            return float(x)
+        t = torch.tensor([float(x)], dtype=torch.float64, device=device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
+    def shard(self, total):
+        """Contiguous shard [lo, hi) of `total` items for this rank (sizes differ by at most 1)."""
+        base, rem = divmod(total, self.world)
+        lo = self.rank * base + min(self.rank, rem)
+        return lo, lo + base + (1 if self.rank < rem else 0)
