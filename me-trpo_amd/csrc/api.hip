@@ -160,9 +160,9 @@ extern "C" int32_t metrpo_policy_actions(metrpo_ctx* c, const float* obs, const 
                                          float* mean, void* stream) {
     if (!c) return METRPO_ENULL;
     NEED_POL(c);
-    if (!obs || !actions || !mean) return set_err(c, METRPO_ENULL, "policy_actions: NULL pointer");
     if (B < 0) return set_err(c, METRPO_EINVAL, "policy_actions: B < 0");
     if (B == 0) return METRPO_OK;
+    if (!obs || !actions || !mean) return set_err(c, METRPO_ENULL, "policy_actions: NULL pointer");
     return launch_policy_actions(c, obs, eps, B, actions, mean, (hipStream_t)stream);
 }
 
@@ -173,8 +173,9 @@ extern "C" int32_t metrpo_step(metrpo_ctx* c, const float* s, const float* a, in
                                uint8_t* done, float* next_all, void* stream) {
     if (!c) return METRPO_ENULL;
     NEED_DYN(c);
-    if (!s || !a || !s_next || !reward || !done) return set_err(c, METRPO_ENULL, "step: NULL pointer");
     if (!sam_ok(sam_mode)) return set_err(c, METRPO_EINVAL, "sam mode is not defined");      // env_helpers.py:634
+    if (B == 0) return METRPO_OK;
+    if (!s || !a || !s_next || !reward || !done) return set_err(c, METRPO_ENULL, "step: NULL pointer");
     if ((sam_mode == METRPO_SAM_STEP_RAND || sam_mode == METRPO_SAM_EPS_RAND) && !model_idx)
         return set_err(c, METRPO_ENULL, "step: model_idx required for step_rand/eps_rand");
     if (sam_mode == METRPO_SAM_MODEL_MEAN_STD && !noise) return set_err(c, METRPO_ENULL, "step: noise required for model_mean_std");

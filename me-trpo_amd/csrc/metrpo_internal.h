@@ -50,6 +50,18 @@ struct metrpo_ctx {
     std::string err;
 };
 
+struct RolloutK {          // device-side copy of metrpo_rollout_args (plain pointers)
+    int B, T, H, sam_mode, determ, eval_all, n_pool;
+    uint64_t seed, stream_offset;
+    const float* pool;
+    const float* eps;
+    const int32_t* model_idx;
+    const float* sel_noise;
+    const int32_t* reset_idx;
+    const int32_t* reset_model;
+    float* obs; float* act; float* rew; float* mean; uint8_t* done; int32_t* tpath; float* last_obs;
+};
+
 int set_err(metrpo_ctx* c, int code, const std::string& msg);
 #define HIP_TRY(c, expr)                                                                      \
     do {                                                                                      \

@@ -159,17 +159,6 @@ __global__ void k_step(ProblemDesc pd, const float* __restrict__ dynp, const flo
 }
 
 // -------------------------------------------------------------------------------------------------
-struct RolloutK {          // device-side copy of metrpo_rollout_args (plain pointers)
-    int B, T, H, sam_mode, determ, eval_all, n_pool;
-    uint64_t seed, stream_offset;
-    const float* pool;
-    const float* eps;
-    const int32_t* model_idx;
-    const float* sel_noise;
-    const int32_t* reset_idx;
-    const int32_t* reset_model;
-    float* obs; float* act; float* rew; float* mean; uint8_t* done; int32_t* tpath; float* last_obs;
-};
 
 __global__ void k_rollout_generic(ProblemDesc pd, RolloutK r, const float* __restrict__ dynp,
                                   const float* __restrict__ theta, const float* __restrict__ norm) {
