@@ -78,6 +78,7 @@ SYMBOLS = {
 EXTRA_SYMBOLS = {
     'metrpo_rollout_generic': (_I, [_P, C.POINTER(RolloutArgs), _P]),
     'metrpo_has_mfma_path': (_I, [_P]),
+    'metrpo_set_update_path': (_I, [_P, _I]),
 }
 
 

@@ -72,7 +72,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     if (!c) return METRPO_EINVAL;
     c->device = device; c->dims = *d;
     c->d_dyn = c->d_norm = c->d_theta = nullptr; c->have_dyn = c->have_pol = false;
-    c->d_dyn_img = c->d_pol_img = nullptr; c->mfma_cfg = -1;
+    c->d_dyn_img = c->d_pol_img = nullptr; c->mfma_cfg = -1; c->pol_mfma = -1;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_cg = nullptr; c->d_vf = nullptr; c->d_theta_try = nullptr;
     c->d_valbuf = nullptr; c->h_pinned = nullptr; c->n_sm = 256;
     ProblemDesc& pd = c->pd;
@@ -101,6 +101,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
         return METRPO_EHIP;
     }
     c->mfma_cfg = mfma_select_config(c);
+    c->pol_mfma = policy_mfma_select(pd);
     return METRPO_OK;
 }
 
@@ -212,6 +213,12 @@ extern "C" int32_t metrpo_rollout_generic(metrpo_ctx* c, const metrpo_rollout_ar
     return launch_rollout_generic(c, a, (hipStream_t)stream);
 }
 extern "C" int32_t metrpo_has_mfma_path(const metrpo_ctx* c) { return (c && c->mfma_cfg >= 0) ? 1 : 0; }
+// test hook: 0 forces the generic (VALU) update kernels, 1 restores the MFMA ones when available
+extern "C" int32_t metrpo_set_update_path(metrpo_ctx* c, int32_t use_mfma) {
+    if (!c) return METRPO_ENULL;
+    c->pol_mfma = use_mfma ? policy_mfma_select(c->pd) : -1;
+    return c->pol_mfma >= 0 ? 1 : 0;
+}
 
 extern "C" int32_t metrpo_validation_cost(metrpo_ctx* c, const float* s0, int32_t Bv, int32_t T, double gamma,
                                           double* costs, void* stream) {

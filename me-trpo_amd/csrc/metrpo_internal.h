@@ -38,6 +38,7 @@ struct metrpo_ctx {
     float* d_dyn_img;    // per-model register image, see rollout_mfma.hip
     float* d_pol_img;
     int mfma_cfg;        // index into the instantiation table, -1 = generic path only
+    int pol_mfma;        // index into policy_mfma.hip's table, -1 = generic update kernels
     // --- workspaces for the update path (lazily sized) ---
     float* d_partials;   // [n_blocks][P+2] per-block partial sums
     size_t partials_cap;
@@ -61,6 +62,15 @@ struct RolloutK {          // device-side copy of metrpo_rollout_args (plain poi
     const int32_t* reset_model;
     float* obs; float* act; float* rew; float* mean; uint8_t* done; int32_t* tpath; float* last_obs;
 };
+
+struct PolK {
+    const float* obs; const float* act; const float* adv; const float* old_mean; const float* old_ls;
+    int ls_stride; const uint8_t* valid; long long N; float inv_n;
+};
+
+int policy_mfma_select(const ProblemDesc& pd);
+int policy_mfma_launch(metrpo_ctx*, int idx, int mode, const metrpo_batch*, const float* theta, const float* v,
+                       float* partials, int nblocks, hipStream_t);
 
 int set_err(metrpo_ctx* c, int code, const std::string& msg);
 #define HIP_TRY(c, expr)                                                                      \

@@ -1,0 +1,374 @@
+// MFMA fast path of the policy-side TRPO kernels for the 2-hidden-layer tanh policies the reference
+// ships (params-*.json "policy.hidden_layers": [32, 32]): surrogate loss + gradient, Fisher-vector
+// product, loss + mean-KL.  Same arithmetic as policy_update.hip (algos/npo.py:68-75 graph; [rllab]
+// DiagonalGaussian / PerlmutterHvp), mapped to v_mfma_f32_16x16x4_f32 (exact f32 fmaf chains):
+//
+//   * a wave owns tiles of 16 samples and keeps ALL weight fragments in registers;
+//   * forward, tangent-forward and back-prop run TRANSPOSED (H^T[unit][sample] = W^T X^T): the D
+//     fragment of one layer is the B operand of the next when the k-steps are enumerated (cb, r)
+//     (same trick as rollout_mfma.hip), so these chains never leave registers;
+//   * the weight gradients  G[i][j] = sum_n a[i][n] d[j][n]  contract over SAMPLES, i.e. over the lane
+//     index of the D fragments, so a and d take one 16x16 transpose through LDS (row stride 17, conflict
+//     free) and G accumulates in MFMA accumulators across all tiles of the wave;
+//   * waves -> block partial (LDS, fixed order) -> global partial row -> k_finalize (fixed order,
+//     float64): bitwise reproducible.
+#include "device_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define PART_EXTRA 3
+constexpr int cdiv_(int a, int b) { return (a + b - 1) / b; }
+
+
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ float xsum_q(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
+__device__ __forceinline__ float xsum_c(float v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+enum { MODE_GRAD = 0, MODE_FVP = 1, MODE_LOSSKL = 2 };
+
+template <int NS, int NA, int PH, int MODE>
+__global__ void __launch_bounds__(256) k_policy_mfma(PolK k, const float* __restrict__ theta, const float* __restrict__ v,
+                                                     float* __restrict__ partials) {
+    constexpr int NS_KS = cdiv_(NS, 4), NSI = cdiv_(NS, 16), HB = cdiv_(PH, 16), KK = HB * 4;
+    constexpr int pW0 = 0, pb0 = NS * PH, pW1 = pb0 + PH, pb1 = pW1 + PH * PH, pW2 = pb1 + PH, pb2 = pW2 + PH * NA,
+                  pLS = pb2 + NA, P = pLS + NA, ROW = P + PART_EXTRA;
+    constexpr int TS = 17;                                  // transpose-tile row stride (floats)
+    constexpr int TILE = 16 * TS;
+    constexpr int WTL = (4 * HB + 1) * TILE;                // per-wave: h0,h1,d1,d0 (HB blocks each) + u
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    float* TL = lds + wave * WTL;
+    float* T_h0 = TL, *T_h1 = TL + HB * TILE, *T_d1 = TL + 2 * HB * TILE, *T_d0 = TL + 3 * HB * TILE, *T_u = TL + 4 * HB * TILE;
+
+    // ---------------- weight fragments (registers) -----------------------------------------------
+    float W0f[NS_KS][HB], W1f[KK][HB], W2f[KK];
+#pragma unroll
+    for (int s = 0; s < NS_KS; ++s)
+#pragma unroll
+        for (int cb = 0; cb < HB; ++cb) { const int i = 4 * s + q, o = 16 * cb + c; W0f[s][cb] = (i < NS && o < PH) ? theta[pW0 + i * PH + o] : 0.f; }
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+        const int i = 16 * (kk >> 2) + 4 * q + (kk & 3);
+#pragma unroll
+        for (int cb = 0; cb < HB; ++cb) { const int o = 16 * cb + c; W1f[kk][cb] = (i < PH && o < PH) ? theta[pW1 + i * PH + o] : 0.f; }
+        W2f[kk] = (i < PH && c < NA) ? theta[pW2 + i * NA + c] : 0.f;
+    }
+    f32x4 b0f[HB], b1f[HB], b2f;
+#pragma unroll
+    for (int cb = 0; cb < HB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int u = 16 * cb + 4 * q + r; b0f[cb][r] = (u < PH) ? theta[pb0 + u] : 0.f; b1f[cb][r] = (u < PH) ? theta[pb1 + u] : 0.f; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b2f[r] = (4 * q + r < NA) ? theta[pb2 + 4 * q + r] : 0.f;
+    float ls[4], inv_std[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ls[r] = (4 * q + r < NA) ? fmaxf(theta[pLS + 4 * q + r], LOG_MIN_STD) : 0.f; inv_std[r] = expf(-ls[r]); }
+
+    // tangent (FVP) and backward fragments
+    float V0f[MODE == MODE_FVP ? NS_KS : 1][HB], V1f[MODE == MODE_FVP ? KK : 1][HB], V2f[MODE == MODE_FVP ? KK : 1];
+    f32x4 vb0f[HB], vb1f[HB], vb2f;
+    if (MODE == MODE_FVP) {
+#pragma unroll
+        for (int s = 0; s < NS_KS; ++s)
+#pragma unroll
+            for (int cb = 0; cb < HB; ++cb) { const int i = 4 * s + q, o = 16 * cb + c; V0f[MODE == MODE_FVP ? s : 0][cb] = (i < NS && o < PH) ? v[pW0 + i * PH + o] : 0.f; }
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const int i = 16 * (kk >> 2) + 4 * q + (kk & 3);
+#pragma unroll
+            for (int cb = 0; cb < HB; ++cb) { const int o = 16 * cb + c; V1f[MODE == MODE_FVP ? kk : 0][cb] = (i < PH && o < PH) ? v[pW1 + i * PH + o] : 0.f; }
+            V2f[MODE == MODE_FVP ? kk : 0] = (i < PH && c < NA) ? v[pW2 + i * NA + c] : 0.f;
+        }
+#pragma unroll
+        for (int cb = 0; cb < HB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int u = 16 * cb + 4 * q + r; vb0f[cb][r] = (u < PH) ? v[pb0 + u] : 0.f; vb1f[cb][r] = (u < PH) ? v[pb1 + u] : 0.f; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vb2f[r] = (4 * q + r < NA) ? v[pb2 + 4 * q + r] : 0.f;
+    }
+    float W2b[4][HB], W1b[KK][HB];
+    if (MODE != MODE_LOSSKL) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int cb = 0; cb < HB; ++cb) { const int i = 16 * cb + c, d = 4 * q + r; W2b[r][cb] = (i < PH && d < NA) ? theta[pW2 + i * NA + d] : 0.f; }
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int cb = 0; cb < HB; ++cb) {
+                const int i = 16 * cb + c, j = 16 * (kk >> 2) + 4 * q + (kk & 3);
+                W1b[kk][cb] = (i < PH && j < PH) ? theta[pW1 + i * PH + j] : 0.f;
+            }
+    }
+
+    // ---------------- accumulators -------------------------------------------------------------------
+    const f32x4 Z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 gW0[NSI][HB], gW1[HB][HB], gW2[HB], gb0[HB], gb1[HB], gb2 = Z4;
+#pragma unroll
+    for (int a = 0; a < HB; ++a) {
+        gW2[a] = Z4; gb0[a] = Z4; gb1[a] = Z4;
+#pragma unroll
+        for (int b = 0; b < HB; ++b) gW1[a][b] = Z4;
+#pragma unroll
+        for (int b = 0; b < NSI; ++b) gW0[b][a] = Z4;
+    }
+    float dls[4] = {0.f, 0.f, 0.f, 0.f};
+    float acc0 = 0.f, acc1 = 0.f, accw = 0.f;               // loss, kl, valid weight (per-lane partials)
+
+    const long long ntiles = (k.N + 15) / 16;
+    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+        const long long n0 = tile * 16, n = n0 + c;
+        const bool inr = n < k.N;
+        const bool ok = inr && (k.valid == nullptr || k.valid[n]);
+        // ---- forward (transposed chain) ----------------------------------------------------------
+        float xB[NS_KS];
+#pragma unroll
+        for (int s = 0; s < NS_KS; ++s) { const int f = 4 * s + q; xB[s] = (inr && f < NS) ? k.obs[n * NS + f] : 0.f; }
+        f32x4 h0[HB], h1[HB];
+#pragma unroll
+        for (int cb = 0; cb < HB; ++cb) h0[cb] = b0f[cb];
+#pragma unroll
+        for (int s = 0; s < NS_KS; ++s)
+#pragma unroll
+            for (int cb = 0; cb < HB; ++cb) h0[cb] = MFMA16(W0f[s][cb], xB[s], h0[cb]);
+#pragma unroll
+        for (int cb = 0; cb < HB; ++cb) {
+            h1[cb] = b1f[cb];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h0[cb][r] = tanhf(h0[cb][r]);
+        }
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int cb = 0; cb < HB; ++cb) h1[cb] = MFMA16(W1f[kk][cb], h0[kk >> 2][kk & 3], h1[cb]);
+#pragma unroll
+        for (int cb = 0; cb < HB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h1[cb][r] = tanhf(h1[cb][r]);
+
+        f32x4 um = Z4;                                      // d(objective)/d(mean) in D layout [d = 4q+r][sample c]
+        if (MODE != MODE_FVP) {
+            f32x4 m0 = b2f, m1 = Z4;
+#pragma unroll
+            for (int kk = 0; kk < KK; kk += 2) {
+                m0 = MFMA16(W2f[kk], h1[kk >> 2][kk & 3], m0);
+                m1 = MFMA16(W2f[kk + 1], h1[(kk + 1) >> 2][(kk + 1) & 3], m1);
+            }
+            const f32x4 mu = m0 + m1;
+            float llr = 0.f, kl = 0.f, zz[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = 4 * q + r;
+                if (d < NA && ok) {
+                    const float ols = k.old_ls[(size_t)n * k.ls_stride + d], omu = k.old_mean[n * NA + d], a = k.act[n * NA + d];
+                    const float z = (a - mu[r]) * inv_std[r], zo = (a - omu) * expf(-ols);
+                    llr += (ols - ls[r]) + 0.5f * (zo * zo - z * z);
+                    zz[r] = z;
+                    if (MODE == MODE_LOSSKL) {
+                        const float s2 = expf(2.f * ls[r]), os2 = expf(2.f * ols), dm = omu - mu[r];
+                        kl += (dm * dm + os2 - s2) / (2.f * s2 + KL_EPS) + ls[r] - ols;
+                    }
+                }
+            }
+            llr = xsum_q(llr);                              // sum over action dims held by the 4 q-lanes of sample c
+            const float la = ok ? expf(llr) * k.adv[n] : 0.f;      // lr * adv
+            if (q == 0) acc0 -= la * k.inv_n;               // surr_loss = -mean(lr*adv) (npo.py:75), once per sample
+            if (MODE == MODE_LOSSKL) { acc1 += kl * k.inv_n; continue; }
+            const float w = -la * k.inv_n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                um[r] = w * zz[r] * inv_std[r];             // d loss / d mean = w (a-mu)/std^2
+                dls[r] += w * (zz[r] * zz[r] - ((4 * q + r < NA) ? 1.f : 0.f)) * ((4 * q + r < NA) ? 1.f : 0.f);
+            }
+        } else {
+            // ---- tangent forward: dpre = V^T h + W^T dh + vb ; dh = dpre * (1 - h^2) ------------------
+            f32x4 t0[HB], t1[HB];
+#pragma unroll
+            for (int cb = 0; cb < HB; ++cb) t0[cb] = vb0f[cb];
+#pragma unroll
+            for (int s = 0; s < NS_KS; ++s)
+#pragma unroll
+                for (int cb = 0; cb < HB; ++cb) t0[cb] = MFMA16(V0f[s][cb], xB[s], t0[cb]);
+#pragma unroll
+            for (int cb = 0; cb < HB; ++cb) {
+                t1[cb] = vb1f[cb];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t0[cb][r] *= (1.f - h0[cb][r] * h0[cb][r]);
+            }
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                for (int cb = 0; cb < HB; ++cb) {
+                    t1[cb] = MFMA16(W1f[kk][cb], t0[kk >> 2][kk & 3], t1[cb]);
+                    t1[cb] = MFMA16(V1f[kk][cb], h0[kk >> 2][kk & 3], t1[cb]);
+                }
+#pragma unroll
+            for (int cb = 0; cb < HB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t1[cb][r] *= (1.f - h1[cb][r] * h1[cb][r]);
+            f32x4 m0 = vb2f, m1 = Z4;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                m0 = MFMA16(W2f[kk], t1[kk >> 2][kk & 3], m0);
+                m1 = MFMA16(V2f[kk], h1[kk >> 2][kk & 3], m1);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s2 = expf(2.f * ls[r]);
+                // d2 KL / d mean^2 = 1 / (s^2 + eps/2)
+                um[r] = (ok && 4 * q + r < NA) ? (m0[r] + m1[r]) / (s2 + 0.5f * KL_EPS) * k.inv_n : 0.f;
+            }
+            if (ok && q == 0) accw += k.inv_n;
+        }
+        // ---- back-prop (transposed chain) ----------------------------------------------------------
+        f32x4 d1[HB], d0[HB];
+#pragma unroll
+        for (int cb = 0; cb < HB; ++cb) d1[cb] = Z4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int cb = 0; cb < HB; ++cb) d1[cb] = MFMA16(W2b[r][cb], um[r], d1[cb]);
+#pragma unroll
+        for (int cb = 0; cb < HB; ++cb) {
+            d0[cb] = Z4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d1[cb][r] *= (1.f - h1[cb][r] * h1[cb][r]);
+        }
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int cb = 0; cb < HB; ++cb) d0[cb] = MFMA16(W1b[kk][cb], d1[kk >> 2][kk & 3], d0[cb]);
+#pragma unroll
+        for (int cb = 0; cb < HB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d0[cb][r] *= (1.f - h0[cb][r] * h0[cb][r]);
+        gb2 += um;
+#pragma unroll
+        for (int cb = 0; cb < HB; ++cb) { gb1[cb] += d1[cb]; gb0[cb] += d0[cb]; }
+        // ---- 16x16 transposes through LDS: D fragment [unit 16cb+4q+r][sample c] -> T[unit][sample] ----
+#pragma unroll
+        for (int cb = 0; cb < HB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = (4 * q + r) * TS + c;
+                T_h0[cb * TILE + row] = h0[cb][r]; T_h1[cb * TILE + row] = h1[cb][r];
+                T_d1[cb * TILE + row] = d1[cb][r]; T_d0[cb * TILE + row] = d0[cb][r];
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T_u[(4 * q + r) * TS + c] = um[r];
+        wave_sync_lds();
+        // ---- weight gradients: G[i][j] += sum_n a[i][n] d[j][n], k-step s covers samples 4s+q ---------
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int col = c * TS + 4 * s + q;             // T[unit = c][sample = 4s+q]
+            float aT_h0[HB], aT_h1[HB], bT_d1[HB], bT_d0[HB];
+#pragma unroll
+            for (int cb = 0; cb < HB; ++cb) {
+                aT_h0[cb] = T_h0[cb * TILE + col]; aT_h1[cb] = T_h1[cb * TILE + col];
+                bT_d1[cb] = T_d1[cb * TILE + col]; bT_d0[cb] = T_d0[cb * TILE + col];
+            }
+            const float bT_u = T_u[col];
+            const long long ns_ = n0 + 4 * s + q;
+#pragma unroll
+            for (int ci = 0; ci < NSI; ++ci) {
+                const int f = 16 * ci + c;
+                const float xT = (ns_ < k.N && f < NS) ? k.obs[ns_ * NS + f] : 0.f;
+#pragma unroll
+                for (int cj = 0; cj < HB; ++cj) gW0[ci][cj] = MFMA16(xT, bT_d0[cj], gW0[ci][cj]);
+            }
+#pragma unroll
+            for (int ci = 0; ci < HB; ++ci) {
+#pragma unroll
+                for (int cj = 0; cj < HB; ++cj) gW1[ci][cj] = MFMA16(aT_h0[ci], bT_d1[cj], gW1[ci][cj]);
+                gW2[ci] = MFMA16(aT_h1[ci], bT_u, gW2[ci]);
+            }
+        }
+        wave_sync_lds();
+    }
+
+    // ---------------- epilogue: wave partial -> block partial (fixed order) -> global row -------------
+    __syncthreads();
+    float* RB = lds;                                        // [4][ROW] (transpose tiles are dead)
+    float* row = RB + wave * ROW;
+    for (int i = lane; i < ROW; i += 64) row[i] = 0.f;
+    wave_sync_lds();
+    if (MODE != MODE_LOSSKL) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int cj = 0; cj < HB; ++cj) {
+                const int j = 16 * cj + c;
+#pragma unroll
+                for (int ci = 0; ci < NSI; ++ci) { const int i = 16 * ci + 4 * q + r; if (i < NS && j < PH) row[pW0 + i * PH + j] = gW0[ci][cj][r]; }
+#pragma unroll
+                for (int ci = 0; ci < HB; ++ci) { const int i = 16 * ci + 4 * q + r; if (i < PH && j < PH) row[pW1 + i * PH + j] = gW1[ci][cj][r]; }
+            }
+#pragma unroll
+            for (int ci = 0; ci < HB; ++ci) { const int i = 16 * ci + 4 * q + r; if (i < PH && c < NA) row[pW2 + i * NA + c] = gW2[ci][r]; }
+#pragma unroll
+            for (int cb = 0; cb < HB; ++cb) {
+                const float s0 = xsum_c(gb0[cb][r]), s1 = xsum_c(gb1[cb][r]);
+                const int u = 16 * cb + 4 * q + r;
+                if (c == 0 && u < PH) { row[pb0 + u] = s0; row[pb1 + u] = s1; }
+            }
+            const float s2 = xsum_c(gb2[r]), sl = xsum_c(dls[r]);
+            if (c == 0 && 4 * q + r < NA) {
+                row[pb2 + 4 * q + r] = s2;
+                if (MODE == MODE_GRAD) row[pLS + 4 * q + r] = (theta[pLS + 4 * q + r] > LOG_MIN_STD) ? sl : 0.f;
+            }
+        }
+    }
+    {
+        const float a0 = xsum_c(xsum_q(acc0)), a1 = xsum_c(xsum_q(acc1)), aw = xsum_c(xsum_q(accw));
+        if (lane == 0) { row[P] = a0; row[P + 1] = a1; row[P + 2] = aw; }
+    }
+    __syncthreads();
+    float* out = partials + (size_t)blockIdx.x * ROW;
+    for (int i = tid; i < ROW; i += 256) out[i] = (RB[i] + RB[ROW + i]) + (RB[2 * ROW + i] + RB[3 * ROW + i]);
+}
+
+// -------------------------------------------------------------------------------------------------
+typedef void (*pol_kernel_t)(PolK, const float*, const float*, float*);
+struct PolEntry { int ns, na, ph; pol_kernel_t kern[3]; int lds_floats; };
+template <int NS, int NA, int PH> constexpr int pol_lds() {
+    constexpr int HB = cdiv_(PH, 16);
+    constexpr int a = 4 * (4 * HB + 1) * 16 * 17;
+    constexpr int P = NS * PH + PH + PH * PH + PH + PH * NA + NA + NA;
+    constexpr int b = 4 * (P + PART_EXTRA);
+    return a > b ? a : b;
+}
+#define PENTRY(NS, NA, PH) {NS, NA, PH, {k_policy_mfma<NS, NA, PH, 0>, k_policy_mfma<NS, NA, PH, 1>, k_policy_mfma<NS, NA, PH, 2>}, pol_lds<NS, NA, PH>()}
+static const PolEntry kPol[] = {
+    PENTRY(10, 2, 32),    // swimmer
+    PENTRY(18, 6, 32),    // half-cheetah
+    PENTRY(11, 3, 32),    // hopper
+    PENTRY(14, 4, 32),    // snake
+    PENTRY(29, 8, 32),    // ant
+};
+
+// returns the table index for this ctx or -1 (generic kernels in policy_update.hip)
+int policy_mfma_select(const ProblemDesc& pd) {
+    if (pd.pol.n_layers != 3 || pd.pol.dims[1] != pd.pol.dims[2]) return -1;
+    for (int i = 0; i < (int)(sizeof(kPol) / sizeof(kPol[0])); ++i)
+        if (kPol[i].ns == pd.ns && kPol[i].na == pd.na && kPol[i].ph == pd.pol.dims[1]) return i;
+    return -1;
+}
+
+// launches mode `mode`; per-block rows of P+3 floats land in `partials`; returns the block count via *nblocks
+int policy_mfma_launch(metrpo_ctx* c, int idx, int mode, const metrpo_batch* b, const float* theta, const float* v,
+                       float* partials, int nblocks, hipStream_t st) {
+    const PolEntry& en = kPol[idx];
+    PolK k;
+    k.obs = b->d_obs; k.act = b->d_act; k.adv = b->d_adv; k.old_mean = b->d_old_mean; k.old_ls = b->d_old_log_std;
+    k.ls_stride = b->old_log_std_stride; k.valid = b->d_valid; k.N = b->N; k.inv_n = (float)b->inv_n_global;
+    hipLaunchKernelGGL(en.kern[mode], dim3(nblocks), dim3(256), sizeof(float) * en.lds_floats, st, k, theta, v, partials);
+    HIP_TRY(c, hipGetLastError());
+    return METRPO_OK;
+}

@@ -12,13 +12,7 @@
 // row of a global partial buffer; k_finalize sums rows in block order -> bitwise reproducible.
 #include "device_common.h"
 
-#define PT 128
-#define PLD (PT + 1)
 
-struct PolK {
-    const float* obs; const float* act; const float* adv; const float* old_mean; const float* old_ls;
-    int ls_stride; const uint8_t* valid; long long N; float inv_n;
-};
 
 // offsets (in rows) of the per-layer activation buffers h_0 (= input) .. h_{L-1}; h_L (mean) lives in DM
 __device__ __forceinline__ int hrow(const NetDesc& net, int l) {
@@ -28,7 +22,9 @@ __device__ __forceinline__ int hrow(const NetDesc& net, int l) {
 }
 
 // forward pass storing every layer input; returns nothing, mean is written to DM rows [0,na)
+template <int PT>
 __device__ __forceinline__ void forward_store(const NetDesc& net, const float* __restrict__ th, float* H, float* DM, int tid) {
+    constexpr int PLD = PT + 1;
     for (int l = 0; l < net.n_layers; ++l) {
         float* dst = (l == net.n_layers - 1) ? DM : (H + hrow(net, l + 1) * PLD);
         dense_col(th + net.w_off[l], th + net.b_off[l], net.dims[l], net.dims[l + 1], net.act[l], H + hrow(net, l) * PLD,
@@ -36,7 +32,9 @@ __device__ __forceinline__ void forward_store(const NetDesc& net, const float* _
     }
 }
 
+template <int PT>
 __device__ __forceinline__ bool load_obs_tile(const PolK& k, int ns, long long base, float* H, int tid) {
+    constexpr int PLD = PT + 1;
     const long long n = base + tid;
     const bool ok = (n < k.N) && (k.valid == nullptr || k.valid[n]);
     for (int i = 0; i < ns; ++i) H[i * PLD + tid] = (n < k.N) ? k.obs[n * ns + i] : 0.0f;
@@ -44,7 +42,9 @@ __device__ __forceinline__ bool load_obs_tile(const PolK& k, int ns, long long b
 }
 
 // Phase B for one layer: part[w_off + i*n_out + j] += sum_n h_l[i][n] * d[j][n];  part[b_off + j] += sum_n d[j][n]
+template <int PT>
 __device__ __forceinline__ void accum_layer(const NetDesc& net, int l, const float* Hl, const float* D, float* part, int tid) {
+    constexpr int PLD = PT + 1;
     const int n_in = net.dims[l], n_out = net.dims[l + 1];
     for (int p = tid; p < n_in * n_out; p += PT) {
         const int i = p / n_out, j = p - i * n_out;
@@ -65,7 +65,9 @@ __device__ __forceinline__ void accum_layer(const NetDesc& net, int l, const flo
 }
 
 // delta_l[i] = (sum_j W_l[i][j] * delta_{l+1}[j]) * (1 - h_l[i]^2), written in place over h_l (tanh hidden layers)
+template <int PT>
 __device__ __forceinline__ void backprop_layer(const NetDesc& net, int l, const float* __restrict__ th, float* Hl, const float* D, int tid) {
+    constexpr int PLD = PT + 1;
     const int n_in = net.dims[l], n_out = net.dims[l + 1];
     const float* __restrict__ W = th + net.w_off[l];
     for (int i = 0; i < n_in; ++i) {
@@ -78,14 +80,16 @@ __device__ __forceinline__ void backprop_layer(const NetDesc& net, int l, const 
 }
 
 // shared tail of grad and fvp: DM holds d(objective)/d(mean) per sample (already scaled, zero if invalid)
+template <int PT>
 __device__ __forceinline__ void backward_accumulate(const NetDesc& net, const float* __restrict__ th, float* H, float* DM, float* part, int tid) {
+    constexpr int PLD = PT + 1;
     const float* D = DM;
     for (int l = net.n_layers - 1; l >= 0; --l) {
         float* Hl = H + hrow(net, l) * PLD;
         __syncthreads();
-        accum_layer(net, l, Hl, D, part, tid);
+        accum_layer<PT>(net, l, Hl, D, part, tid);
         __syncthreads();
-        if (l > 0) { backprop_layer(net, l, th, Hl, D, tid); D = Hl; }
+        if (l > 0) { backprop_layer<PT>(net, l, th, Hl, D, tid); D = Hl; }
     }
 }
 
@@ -93,7 +97,9 @@ __device__ __forceinline__ void backward_accumulate(const NetDesc& net, const fl
 //   [P] = loss (or kl-side scalar), [P+1] = second scalar, [P+2] = valid-sample weight (count*inv_n)
 #define PART_EXTRA 3
 
+template <int PT>
 __global__ void __launch_bounds__(PT) k_loss_grad(ProblemDesc pd, PolK k, const float* __restrict__ theta, float* __restrict__ partials) {
+    constexpr int PLD = PT + 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ double red[16];
     const NetDesc& net = pd.pol;
@@ -111,8 +117,8 @@ __global__ void __launch_bounds__(PT) k_loss_grad(ProblemDesc pd, PolK k, const 
     for (int d = 0; d < 32; ++d) dls_acc[d] = 0.0f;
     for (long long base = (long long)blockIdx.x * PT; base < k.N; base += (long long)gridDim.x * PT) {
         __syncthreads();
-        const bool ok = load_obs_tile(k, ns, base, H, tid);
-        forward_store(net, theta, H, DM, tid);
+        const bool ok = load_obs_tile<PT>(k, ns, base, H, tid);
+        forward_store<PT>(net, theta, H, DM, tid);
         const long long n = base + tid;
         float w = 0.0f;
         if (ok) {
@@ -139,7 +145,7 @@ __global__ void __launch_bounds__(PT) k_loss_grad(ProblemDesc pd, PolK k, const 
                 dls_acc[d] += w * (z * z - 1.0f);                // d loss / d log_std
             }
         }
-        backward_accumulate(net, theta, H, DM, part, tid);
+        backward_accumulate<PT>(net, theta, H, DM, part, tid);
     }
     // block-reduce the per-thread scalars into the partial row
     const double l = block_sum(loss_acc, red);
@@ -151,9 +157,11 @@ __global__ void __launch_bounds__(PT) k_loss_grad(ProblemDesc pd, PolK k, const 
 }
 
 // tangent forward: dpre_{l+1} = dh_l W_l + h_l V_l + vb_l ; dh_{l+1} = dpre * (1 - h_{l+1}^2)
+template <int PT>
 __device__ __forceinline__ void tangent_layer(const NetDesc& net, int l, const float* __restrict__ th, const float* __restrict__ v,
-                                              const float* Hl, const float* dHl /*nullptr for l==0*/, const float* Hn /*h_{l+1} or nullptr for output*/,
+                                              const float* Hl, const float* dHl /*nullptr for l==0*/, const float* Hn /* h_(l+1), or nullptr for the output layer */,
                                               float* dst, int tid) {
+    constexpr int PLD = PT + 1;
     const int n_in = net.dims[l], n_out = net.dims[l + 1];
     const float* __restrict__ W = th + net.w_off[l];
     const float* __restrict__ V = v + net.w_off[l];
@@ -180,8 +188,10 @@ __device__ __forceinline__ void tangent_layer(const NetDesc& net, int l, const f
     }
 }
 
+template <int PT>
 __global__ void __launch_bounds__(PT) k_fvp(ProblemDesc pd, PolK k, const float* __restrict__ theta, const float* __restrict__ v,
                                             float* __restrict__ partials) {
+    constexpr int PLD = PT + 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ double red[16];
     const NetDesc& net = pd.pol;
@@ -197,14 +207,14 @@ __global__ void __launch_bounds__(PT) k_fvp(ProblemDesc pd, PolK k, const float*
     double wsum = 0.0;
     for (long long base = (long long)blockIdx.x * PT; base < k.N; base += (long long)gridDim.x * PT) {
         __syncthreads();
-        const bool ok = load_obs_tile(k, ns, base, H, tid);
-        forward_store(net, theta, H, DM, tid);
+        const bool ok = load_obs_tile<PT>(k, ns, base, H, tid);
+        forward_store<PT>(net, theta, H, DM, tid);
         for (int l = 0; l < L; ++l) {
             const float* Hl = H + hrow(net, l) * PLD;
             const float* dHl = (l == 0) ? nullptr : dH + (hrow(net, l) - net.dims[0]) * PLD;
             const float* Hn = (l == L - 1) ? nullptr : H + hrow(net, l + 1) * PLD;
             float* dst = (l == L - 1) ? DM : dH + (hrow(net, l + 1) - net.dims[0]) * PLD;
-            tangent_layer(net, l, theta, v, Hl, dHl, Hn, dst, tid);
+            tangent_layer<PT>(net, l, theta, v, Hl, dHl, Hn, dst, tid);
         }
         for (int d = 0; d < na; ++d) {
             const float ls = fmaxf(raw_ls[d], LOG_MIN_STD);
@@ -213,13 +223,15 @@ __global__ void __launch_bounds__(PT) k_fvp(ProblemDesc pd, PolK k, const float*
             DM[d * PLD + tid] = ok ? DM[d * PLD + tid] / (s2 + 0.5f * KL_EPS) * k.inv_n : 0.0f;
         }
         if (ok) wsum += (double)k.inv_n;
-        backward_accumulate(net, theta, H, DM, part, tid);
+        backward_accumulate<PT>(net, theta, H, DM, part, tid);
     }
     const double wtot = block_sum(wsum, red);
     if (tid == 0) part[P + 2] = (float)wtot;
 }
 
+template <int PT>
 __global__ void __launch_bounds__(PT) k_loss_kl(ProblemDesc pd, PolK k, const float* __restrict__ theta, float* __restrict__ partials) {
+    constexpr int PLD = PT + 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ double red[16];
     const NetDesc& net = pd.pol;
@@ -230,7 +242,7 @@ __global__ void __launch_bounds__(PT) k_loss_kl(ProblemDesc pd, PolK k, const fl
     const float* __restrict__ raw_ls = theta + net.n_params;
     double loss_acc = 0.0, kl_acc = 0.0;
     for (long long base = (long long)blockIdx.x * PT; base < k.N; base += (long long)gridDim.x * PT) {
-        const bool ok = load_obs_tile(k, ns, base, S, tid);
+        const bool ok = load_obs_tile<PT>(k, ns, base, S, tid);
         const float* m = mlp_col(net, theta, S, A, Bq, PLD, tid);
         if (ok) {
             const long long n = base + tid;
@@ -253,30 +265,40 @@ __global__ void __launch_bounds__(PT) k_loss_kl(ProblemDesc pd, PolK k, const fl
     if (tid == 0) { partials[blockIdx.x * 2] = (float)l; partials[blockIdx.x * 2 + 1] = (float)q; }
 }
 
-// out[p] = sum over blocks (fixed order) of partials[blk][p], float64.
-// mode 0: grad -> out[0] = loss, out[1+p] = g[p]   (row stride P+PART_EXTRA)
-// mode 1: fvp  -> out[p] = Hv[p] for the mean net; log_std rows get c(s) * v_ls * weight
-// mode 2: loss/kl -> out[0], out[1]                 (row stride 2)
-__global__ void k_finalize(ProblemDesc pd, int mode, int nblocks, const float* __restrict__ partials,
-                           const float* __restrict__ theta, const double* __restrict__ v, double* __restrict__ out) {
-    const int P = pd.P, stride = (mode == 2) ? 2 : P + PART_EXTRA;
+// out[p] = sum over partial rows (fixed order) of column col(p), float64.  Block = 64 columns x 4 row slices;
+// slice s adds rows s, s+4, ... then the 4 slice sums are added in slice order: deterministic.
+// mode 0: grad -> out[0] = loss (column P), out[1+p] = g[p]
+// mode 1: fvp  -> out[p] = Hv[p] for the mean net; log_std rows get c(s) * v_ls * weight (column P+2)
+// mode 2: loss/kl -> out[0], out[1] from columns (lk_col, lk_col+1)
+__global__ void __launch_bounds__(256) k_finalize(ProblemDesc pd, int mode, int nrows, int stride, int lk_col,
+                                                  const float* __restrict__ partials, const float* __restrict__ theta,
+                                                  const double* __restrict__ v, double* __restrict__ out) {
+    __shared__ double sh[4][65];
+    const int P = pd.P;
     const int nout = (mode == 0) ? P + 1 : (mode == 1) ? P : 2;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= nout) return;
+    const int lc = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + lc;
     int col = p;
     if (mode == 0) col = (p == 0) ? P : p - 1;
+    if (mode == 2) col = lk_col + p;
+    const bool lsrow = (mode == 1 && p >= pd.pol.n_params && p < nout);
+    if (lsrow) col = P + 2;                                   // valid-sample weight column
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += (double)partials[(size_t)b * stride + col];
-    if (mode == 1 && p >= pd.pol.n_params) {
-        // Hessian of mean KL w.r.t. log_std at theta_old: 4 s^2 (2 s^2 - eps) / (2 s^2 + eps)^2  (-> 2 as eps -> 0)
-        double w = 0.0;
-        for (int b = 0; b < nblocks; ++b) w += (double)partials[(size_t)b * stride + P + 2];
-        const double raw = (double)theta[p];
-        const double s2 = exp(2.0 * fmax(raw, (double)LOG_MIN_STD));
-        const double c = 4.0 * s2 * (2.0 * s2 - 1e-8) / ((2.0 * s2 + 1e-8) * (2.0 * s2 + 1e-8));
-        s = (raw > (double)LOG_MIN_STD) ? c * v[p] * w : 0.0;
+    if (p < nout)
+        for (int b = sl; b < nrows; b += 4) s += (double)partials[(size_t)b * stride + col];
+    sh[sl][lc] = s;
+    __syncthreads();
+    if (sl == 0 && p < nout) {
+        double t = (sh[0][lc] + sh[1][lc]) + (sh[2][lc] + sh[3][lc]);
+        if (lsrow) {
+            // Hessian of mean KL w.r.t. log_std at theta_old: 4 s^2 (2 s^2 - eps) / (2 s^2 + eps)^2  (-> 2 as eps -> 0)
+            const double raw = (double)theta[p];
+            const double s2 = exp(2.0 * fmax(raw, (double)LOG_MIN_STD));
+            const double c = 4.0 * s2 * (2.0 * s2 - 1e-8) / ((2.0 * s2 + 1e-8) * (2.0 * s2 + 1e-8));
+            t = (raw > (double)LOG_MIN_STD) ? c * v[p] * t : 0.0;
+        }
+        out[p] = t;
     }
-    out[p] = s;
 }
 
 __global__ void k_d2f(const double* __restrict__ in, float* __restrict__ out, int n) {
@@ -285,14 +307,8 @@ __global__ void k_d2f(const double* __restrict__ in, float* __restrict__ out, in
 }
 
 // ---------------------------------------------------------------------------------------------
-static int update_grid(metrpo_ctx* c, long long N) {
-    long long tiles = (N + PT - 1) / PT;
-    long long g = std::min<long long>(tiles, (long long)c->n_sm * 2);
-    return (int)std::max<long long>(g, 1);
-}
-
-static int ensure_partials(metrpo_ctx* c, int nblocks) {
-    const size_t need = (size_t)nblocks * (c->pd.P + PART_EXTRA);
+static int ensure_partials(metrpo_ctx* c, int nrows) {
+    const size_t need = (size_t)nrows * (c->pd.P + PART_EXTRA);
     if (need > c->partials_cap) {
         if (c->d_partials) HIP_TRY(c, hipFree(c->d_partials));
         c->d_partials = nullptr; c->partials_cap = 0;
@@ -302,68 +318,94 @@ static int ensure_partials(metrpo_ctx* c, int nblocks) {
     return METRPO_OK;
 }
 
-static int fill_polk(metrpo_ctx* c, const metrpo_batch* b, PolK* k) {
+static int fill_polk(metrpo_ctx* c, const metrpo_batch* b, PolK* k, bool need_targets) {
     if (!b || !b->d_obs) return set_err(c, METRPO_ENULL, "batch/d_obs is NULL");
     if (b->N <= 0) return set_err(c, METRPO_EINVAL, "batch N must be positive");
     if (c->pd.na > 32) return set_err(c, METRPO_EUNSUPPORTED, "na > 32");
+    if (need_targets && (!b->d_act || !b->d_adv || !b->d_old_mean || !b->d_old_log_std))
+        return set_err(c, METRPO_ENULL, "batch pointer is NULL");
     k->obs = b->d_obs; k->act = b->d_act; k->adv = b->d_adv; k->old_mean = b->d_old_mean; k->old_ls = b->d_old_log_std;
     k->ls_stride = b->old_log_std_stride; k->valid = b->d_valid; k->N = b->N; k->inv_n = (float)b->inv_n_global;
     return METRPO_OK;
 }
 
-template <typename Kern>
-static int lds_attr(metrpo_ctx* c, Kern kern, size_t sh) {
-    if (sh > 160 * 1024) return set_err(c, METRPO_EUNSUPPORTED, "policy too wide for the update kernels' LDS tile");
-    if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+static void finalize(metrpo_ctx* c, int mode, int nrows, int stride, int lk_col, const double* v, double* out, hipStream_t st) {
+    const int nout = (mode == 0) ? c->pd.P + 1 : (mode == 1) ? c->pd.P : 2;
+    hipLaunchKernelGGL(k_finalize, dim3((nout + 63) / 64), dim3(256), 0, st, c->pd, mode, nrows, stride, lk_col,
+                       c->d_partials, c->d_theta, v, out);
+}
+
+// generic kernels: pick the largest sample tile (threads per block) whose LDS columns fit
+template <int PT>
+static int launch_generic(metrpo_ctx* c, int mode, const PolK& k, const float* theta, const float* vf, int* nrows, hipStream_t st) {
+    const NetDesc& net = c->pd.pol;
+    int hrows = 0; for (int l = 0; l < net.n_layers; ++l) hrows += net.dims[l];
+    size_t rows = (mode == 0) ? hrows + c->pd.na : (mode == 1) ? hrows + c->pd.na + (hrows - net.dims[0])
+                                                              : (size_t)c->pd.ns + 2 * net.max_width;
+    const size_t sh = rows * (PT + 1) * sizeof(float);
+    if (sh > 160 * 1024) return METRPO_EUNSUPPORTED;
+    const long long tiles = (k.N + PT - 1) / PT;
+    const int g = (int)std::max<long long>(1, std::min<long long>(tiles, (long long)c->n_sm * 2));
+    int rc = ensure_partials(c, g); if (rc) return rc;
+    *nrows = g;
+    if (mode == 0) {
+        if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_loss_grad<PT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        hipLaunchKernelGGL(k_loss_grad<PT>, dim3(g), dim3(PT), sh, st, c->pd, k, theta, c->d_partials);
+    } else if (mode == 1) {
+        if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_fvp<PT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        hipLaunchKernelGGL(k_fvp<PT>, dim3(g), dim3(PT), sh, st, c->pd, k, theta, vf, c->d_partials);
+    } else {
+        if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_loss_kl<PT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        hipLaunchKernelGGL(k_loss_kl<PT>, dim3(g), dim3(PT), sh, st, c->pd, k, theta, c->d_partials);
+    }
     return METRPO_OK;
 }
 
+// runs mode on the fastest available path; on return the partial rows are in c->d_partials
+static int run_mode(metrpo_ctx* c, int mode, const metrpo_batch* b, const PolK& k, const float* theta, const float* vf,
+                    int* nrows, int* stride, int* lk_col, hipStream_t st) {
+    const int P = c->pd.P;
+    if (c->pol_mfma >= 0) {
+        const long long tiles = (b->N + 15) / 16;
+        const int g = (int)std::max<long long>(1, std::min<long long>((tiles + 3) / 4, (long long)c->n_sm * 2));
+        int rc = ensure_partials(c, g); if (rc) return rc;
+        *nrows = g; *stride = P + PART_EXTRA; *lk_col = P;
+        return policy_mfma_launch(c, c->pol_mfma, mode, b, theta, vf, c->d_partials, g, st);
+    }
+    *stride = (mode == 2) ? 2 : P + PART_EXTRA; *lk_col = 0;
+    int rc = launch_generic<128>(c, mode, k, theta, vf, nrows, st);
+    if (rc == METRPO_EUNSUPPORTED) rc = launch_generic<64>(c, mode, k, theta, vf, nrows, st);
+    if (rc == METRPO_EUNSUPPORTED) rc = launch_generic<32>(c, mode, k, theta, vf, nrows, st);
+    if (rc == METRPO_EUNSUPPORTED) return set_err(c, rc, "policy too wide for the update kernels' LDS tile");
+    return rc;
+}
+
 int launch_loss_grad(metrpo_ctx* c, const metrpo_batch* b, double* out, hipStream_t st) {
-    PolK k; int rc = fill_polk(c, b, &k); if (rc) return rc;
-    if (!b->d_act || !b->d_adv || !b->d_old_mean || !b->d_old_log_std) return set_err(c, METRPO_ENULL, "batch pointer is NULL");
-    const NetDesc& net = c->pd.pol;
-    int hrows = 0; for (int l = 0; l < net.n_layers; ++l) hrows += net.dims[l];
-    const size_t sh = (size_t)(hrows + c->pd.na) * PLD * sizeof(float);
-    if ((rc = lds_attr(c, k_loss_grad, sh))) return rc;
-    const int g = update_grid(c, b->N);
-    if ((rc = ensure_partials(c, g))) return rc;
-    hipLaunchKernelGGL(k_loss_grad, dim3(g), dim3(PT), sh, st, c->pd, k, c->d_theta, c->d_partials);
-    const int nout = c->pd.P + 1;
-    hipLaunchKernelGGL(k_finalize, dim3((nout + 127) / 128), dim3(128), 0, st, c->pd, 0, g, c->d_partials, c->d_theta,
-                       (const double*)nullptr, out);
+    PolK k; int rc = fill_polk(c, b, &k, true); if (rc) return rc;
+    int nrows, stride, lk;
+    if ((rc = run_mode(c, 0, b, k, c->d_theta, nullptr, &nrows, &stride, &lk, st))) return rc;
+    finalize(c, 0, nrows, stride, lk, nullptr, out, st);
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;
 }
 
 int launch_fvp(metrpo_ctx* c, const metrpo_batch* b, const double* v, double* hv, hipStream_t st) {
-    PolK k; int rc = fill_polk(c, b, &k); if (rc) return rc;
+    PolK k; int rc = fill_polk(c, b, &k, false); if (rc) return rc;
     if (!v || !hv) return set_err(c, METRPO_ENULL, "v/hv is NULL");
-    const NetDesc& net = c->pd.pol;
-    int hrows = 0; for (int l = 0; l < net.n_layers; ++l) hrows += net.dims[l];
-    const int trows = hrows - net.dims[0];
-    const size_t sh = (size_t)(hrows + c->pd.na + trows) * PLD * sizeof(float);
-    if ((rc = lds_attr(c, k_fvp, sh))) return rc;
-    const int g = update_grid(c, b->N);
-    if ((rc = ensure_partials(c, g))) return rc;
     const int P = c->pd.P;
     hipLaunchKernelGGL(k_d2f, dim3((P + 127) / 128), dim3(128), 0, st, v, c->d_vf, P);
-    hipLaunchKernelGGL(k_fvp, dim3(g), dim3(PT), sh, st, c->pd, k, c->d_theta, c->d_vf, c->d_partials);
-    hipLaunchKernelGGL(k_finalize, dim3((P + 127) / 128), dim3(128), 0, st, c->pd, 1, g, c->d_partials, c->d_theta, v, hv);
+    int nrows, stride, lk;
+    if ((rc = run_mode(c, 1, b, k, c->d_theta, c->d_vf, &nrows, &stride, &lk, st))) return rc;
+    finalize(c, 1, nrows, stride, lk, v, hv, st);
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;
 }
 
 int launch_loss_kl(metrpo_ctx* c, const metrpo_batch* b, const float* theta, double* out, hipStream_t st) {
-    PolK k; int rc = fill_polk(c, b, &k); if (rc) return rc;
-    if (!b->d_act || !b->d_adv || !b->d_old_mean || !b->d_old_log_std) return set_err(c, METRPO_ENULL, "batch pointer is NULL");
-    const NetDesc& net = c->pd.pol;
-    const size_t sh = (size_t)(c->pd.ns + 2 * net.max_width) * PLD * sizeof(float);
-    if ((rc = lds_attr(c, k_loss_kl, sh))) return rc;
-    const int g = update_grid(c, b->N);
-    if ((rc = ensure_partials(c, g))) return rc;
-    hipLaunchKernelGGL(k_loss_kl, dim3(g), dim3(PT), sh, st, c->pd, k, theta ? theta : c->d_theta, c->d_partials);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(128), 0, st, c->pd, 2, g, c->d_partials, c->d_theta,
-                       (const double*)nullptr, out);
+    PolK k; int rc = fill_polk(c, b, &k, true); if (rc) return rc;
+    int nrows, stride, lk;
+    if ((rc = run_mode(c, 2, b, k, theta ? theta : c->d_theta, nullptr, &nrows, &stride, &lk, st))) return rc;
+    finalize(c, 2, nrows, stride, lk, nullptr, out, st);
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;
 }

@@ -77,6 +77,10 @@ class Engine(object):
             lib.metrpo_destroy(ctx)
             self._ctx = None
 
+    def set_update_path(self, use_mfma):
+        """Test hook: False forces the generic (VALU) policy-update kernels; returns True if MFMA kernels are active."""
+        return bool(lib.metrpo_set_update_path(self._ctx, int(bool(use_mfma))))
+
     # ------------------------------------------------------------------ helpers
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

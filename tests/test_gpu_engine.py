@@ -229,10 +229,15 @@ def rel_l2(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
 
 
+@pytest.mark.parametrize('use_mfma', [True, False])
 @pytest.mark.parametrize('env,pol_hidden,N', [('swimmer', (32, 32), 5000), ('half_cheetah', (32, 32), 3001),
+                                              ('ant', (32, 32), 2000), ('hopper', (32, 32), 777), ('snake', (32, 32), 1024),
                                               ('humanoid', (100, 50, 25), 1500)])
-def test_loss_grad_fvp_losskl_parity(env, pol_hidden, N):
+def test_loss_grad_fvp_losskl_parity(env, pol_hidden, N, use_mfma):
     eng, th, pdims, obs, act, adv, om, ols = _update_problem(env, N, pol_hidden=pol_hidden)
+    active = eng.set_update_path(use_mfma)
+    if use_mfma and not active:
+        pytest.skip('no MFMA update kernels for this policy shape (generic path covers it)')
     valid = np.ones(N, np.uint8); valid[::7] = 0
     keep = valid.astype(bool)
     batch = eng.make_batch(obs, act, adv, om, ols, valid=valid)
@@ -264,9 +269,11 @@ def test_update_is_bitwise_reproducible():
     assert torch.equal(eng.fvp(batch, v).clone(), eng.fvp(batch, v).clone())
 
 
+@pytest.mark.parametrize('use_mfma', [True, False])
 @pytest.mark.parametrize('seed', [21, 22])
-def test_trpo_update_parity(seed):
+def test_trpo_update_parity(seed, use_mfma):
     eng, th, pdims, obs, act, adv, om, ols = _update_problem(N=6000, seed=seed)
+    assert eng.set_update_path(use_mfma) == use_mfma
     batch = eng.make_batch(obs, act, adv, om, ols)
     out = eng.trpo_update(batch, max_kl=0.01, want_vectors=True)
     ref = O.cg_optimize(th, pdims, obs, act, adv, om, ols, max_kl=0.01)
