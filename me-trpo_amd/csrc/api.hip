@@ -75,6 +75,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     c->d_dyn_img = c->d_pol_img = nullptr; c->mfma_cfg = -1; c->pol_mfma = -1;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_cg = nullptr; c->d_vf = nullptr; c->d_theta_try = nullptr;
     c->d_valbuf = nullptr; c->h_pinned = nullptr; c->n_sm = 256;
+    c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0;
     ProblemDesc& pd = c->pd;
     pd.env = d->env; pd.ns = d->ns; pd.na = d->na; pd.K = d->n_models; pd.n_drop = d->n_drop;
     pd.nin = d->ns + d->na - d->n_drop;
@@ -108,7 +109,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
 extern "C" int32_t metrpo_destroy(metrpo_ctx* c) {
     if (!c) return METRPO_ENULL;
     void* bufs[] = {c->d_dyn, c->d_norm, c->d_theta, c->d_vf, c->d_theta_try, c->d_cg, c->d_valbuf, c->d_partials,
-                    c->d_dyn_img, c->d_pol_img};
+                    c->d_dyn_img, c->d_pol_img, c->d_vbuf, c->d_gram_part};
     for (void* p : bufs) if (p) (void)hipFree(p);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     delete c;
@@ -289,12 +290,12 @@ __device__ __forceinline__ double blk_sum(double v, double* sh) {
     return r;
 }
 
-__global__ void k_cg_init(int P, const double* __restrict__ gout, double* x, double* r, double* p, double* scal) {
+__global__ void k_cg_init(int P, const double* __restrict__ gout, double* x, double* r, double* p, float* pf, double* scal) {
     __shared__ double sh[16];
     double acc = 0.0;
     for (int i = threadIdx.x; i < P; i += blockDim.x) {
         const double g = gout[1 + i];
-        x[i] = 0.0; r[i] = g; p[i] = g;
+        x[i] = 0.0; r[i] = g; p[i] = g; pf[i] = (float)g;
         acc += g * g;
     }
     const double rdotr = blk_sum(acc, sh);
@@ -302,9 +303,12 @@ __global__ void k_cg_init(int P, const double* __restrict__ gout, double* x, dou
 }
 
 // one krylov.cg iteration after z = f_Ax(p) has been formed (z lacks the reg term: added here)
-__global__ void k_cg_step(int P, double reg, double tol, double* x, double* r, double* p, double* z, double* scal) {
+__global__ void k_cg_step(int P, double reg, double tol, int last, double* x, double* r, double* p, double* z, float* pf, double* scal) {
     __shared__ double sh[16];
-    if (scal[S_DONE] != 0.0) return;
+    if (scal[S_DONE] != 0.0) {
+        if (last) for (int i = threadIdx.x; i < P; i += blockDim.x) pf[i] = (float)x[i];   // next FVP input is x (step scale)
+        return;
+    }
     const double rdotr = scal[S_RDOTR];
     double acc = 0.0;
     for (int i = threadIdx.x; i < P; i += blockDim.x) { const double zi = z[i] + reg * p[i]; z[i] = zi; acc += p[i] * zi; }
@@ -319,7 +323,11 @@ __global__ void k_cg_step(int P, double reg, double tol, double* x, double* r, d
     }
     const double newrdotr = blk_sum(acc, sh);
     const double mu = newrdotr / rdotr;
-    for (int i = threadIdx.x; i < P; i += blockDim.x) p[i] = r[i] + mu * p[i];
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        const double pn = r[i] + mu * p[i];
+        p[i] = pn;
+        pf[i] = last ? (float)x[i] : (float)pn;       // float copy of the next FVP input
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         scal[S_RDOTR] = newrdotr;
@@ -340,6 +348,11 @@ __global__ void k_cg_finish(int P, double reg, double max_kl, const double* x, d
     if (threadIdx.x == 0) { scal[S_BETA] = beta; scal[S_XHX] = xhx; }
 }
 
+__global__ void k_zero_f(float* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0f;
+}
+
 __global__ void k_try_theta(int P, double ratio, const float* __restrict__ prev, const double* __restrict__ step, float* cur) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < P) cur[i] = (float)((double)prev[i] - ratio * step[i]);     // cur_param = prev_param - ratio * flat_descent_step
@@ -354,13 +367,15 @@ int run_trpo_update(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_para
                             return set_err(c, METRPO_EINVAL, "allreduce callback failed"); } while (0)
     if ((rc = launch_loss_grad(c, b, v.gout, st))) return rc;
     AR(v.gout, 1 + P);
-    hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(256), 0, st, P, v.gout, v.x, v.r, v.p, v.scal);
+    hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(256), 0, st, P, v.gout, v.x, v.r, v.p, c->d_vf, v.scal);
+    if (pr->cg_iters == 0) { hipLaunchKernelGGL(k_zero_f, dim3((P + 255) / 256), dim3(256), 0, st, c->d_vf, P); }
     for (int i = 0; i < pr->cg_iters; ++i) {
-        if ((rc = launch_fvp(c, b, v.p, v.z, st))) return rc;
+        if ((rc = launch_fvp_f32(c, b, c->d_vf, v.p, v.z, st))) return rc;
         AR(v.z, P);
-        hipLaunchKernelGGL(k_cg_step, dim3(1), dim3(256), 0, st, P, pr->reg_coeff, pr->residual_tol, v.x, v.r, v.p, v.z, v.scal);
+        hipLaunchKernelGGL(k_cg_step, dim3(1), dim3(256), 0, st, P, pr->reg_coeff, pr->residual_tol, (i == pr->cg_iters - 1) ? 1 : 0,
+                           v.x, v.r, v.p, v.z, c->d_vf, v.scal);
     }
-    if ((rc = launch_fvp(c, b, v.x, v.z, st))) return rc;
+    if ((rc = launch_fvp_f32(c, b, c->d_vf, v.x, v.z, st))) return rc;
     AR(v.z, P);
     hipLaunchKernelGGL(k_cg_finish, dim3(1), dim3(256), 0, st, P, pr->reg_coeff, pr->max_kl, v.x, v.z, v.step, v.scal);
     if (g_out) HIP_TRY(c, hipMemcpyAsync(g_out, v.gout + 1, sizeof(double) * P, hipMemcpyDeviceToDevice, st));

@@ -5,9 +5,19 @@
 #define LOG_MIN_STD (-13.815510557964274f)   // log(1e-6): [rllab] GaussianMLPPolicy(min_std=1e-6)
 #define KL_EPS 1e-8f                         // [rllab] DiagonalGaussian.kl_sym denominator constant
 
+// tanh in ~12 VALU ops: odd series for |x| < 0.3 (truncation < 6e-8 relative), 1 - 2/(exp(2x)+1) otherwise
+// (v_exp_f32 + v_rcp_f32, absolute error < 3e-7); libm's tanhf costs ~40 and sat on the rollout's critical path.
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float x2 = x * x;
+    const float p = x * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 0.0218694885f, -0.0539682540f), 0.1333333333f), -0.3333333333f), 1.0f);
+    const float e = __expf(2.0f * x);
+    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+    return (fabsf(x) < 0.3f) ? p : t;
+}
+
 __device__ __forceinline__ float act_apply(int act, float x) {
     if (act == METRPO_ACT_RELU) return fmaxf(x, 0.0f);
-    if (act == METRPO_ACT_TANH) return tanhf(x);
+    if (act == METRPO_ACT_TANH) return tanh_fast(x);
     return x;
 }
 
@@ -15,7 +25,9 @@ __device__ __forceinline__ float act_apply(int act, float x) {
 // Philox4x32-10 counter RNG (production draws; parity tests supply the draws explicitly).
 // counter = (env index lo, env index hi, t, purpose<<16 | chunk), key = seed.
 // ---------------------------------------------------------------------------------------------
-enum { RNG_EPS = 0, RNG_MODEL = 1, RNG_SELNOISE = 2, RNG_RESET = 3, RNG_RESET_MODEL = 4 };
+// RNG_STEP: one block per (env, t): .x = step_rand model index of step t, .y = pool row and .z = cur_model_idx of the
+// reset that follows step t.  RNG_RESET: the initial reset (.x row, .y cur_model_idx).
+enum { RNG_EPS = 0, RNG_STEP = 1, RNG_SELNOISE = 2, RNG_RESET = 3 };
 
 __device__ __forceinline__ uint4 philox4x32(uint4 ctr, uint2 key) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;

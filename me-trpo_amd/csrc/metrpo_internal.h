@@ -46,6 +46,10 @@ struct metrpo_ctx {
     float* d_vf;         // [P] float copy of the FVP input
     float* d_theta_try;  // [P] line-search candidate
     double* d_valbuf;    // validation-cost accumulators
+    double* d_vbuf;      // [N] baseline predictions for the GAE scan
+    size_t vbuf_cap;
+    double* d_gram_part; // per-block Gram partials (process.hip)
+    size_t gram_cap;
     double* h_pinned;    // pinned host scratch for the per-trial read-back
     int n_sm;            // CU count
     std::string err;
@@ -97,6 +101,8 @@ int launch_gram(metrpo_ctx*, const float*, const float*, const int32_t*, const u
                 hipStream_t);
 int launch_loss_grad(metrpo_ctx*, const metrpo_batch*, double*, hipStream_t);
 int launch_fvp(metrpo_ctx*, const metrpo_batch*, const double*, double*, hipStream_t);
+// vf = float copy of v already on the device (skips the conversion launch); v is still needed for the log_std rows
+int launch_fvp_f32(metrpo_ctx*, const metrpo_batch*, const float* vf, const double* v, double* hv, hipStream_t);
 int launch_loss_kl(metrpo_ctx*, const metrpo_batch*, const float*, double*, hipStream_t);
 int run_trpo_update(metrpo_ctx*, const metrpo_batch*, const metrpo_trpo_params*, metrpo_trpo_diag*, double*,
                     double*, hipStream_t);

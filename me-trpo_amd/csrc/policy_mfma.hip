@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(256) k_policy_mfma(PolK k, const float* __rest
         for (int cb = 0; cb < HB; ++cb) {
             h1[cb] = b1f[cb];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h0[cb][r] = tanhf(h0[cb][r]);
+            for (int r = 0; r < 4; ++r) h0[cb][r] = tanh_fast(h0[cb][r]);
         }
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(256) k_policy_mfma(PolK k, const float* __rest
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h1[cb][r] = tanhf(h1[cb][r]);
+            for (int r = 0; r < 4; ++r) h1[cb][r] = tanh_fast(h1[cb][r]);
 
         f32x4 um = Z4;                                      // d(objective)/d(mean) in D layout [d = 4q+r][sample c]
         if (MODE != MODE_FVP) {

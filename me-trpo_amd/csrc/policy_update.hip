@@ -283,9 +283,17 @@ __global__ void __launch_bounds__(256) k_finalize(ProblemDesc pd, int mode, int 
     if (mode == 2) col = lk_col + p;
     const bool lsrow = (mode == 1 && p >= pd.pol.n_params && p < nout);
     if (lsrow) col = P + 2;                                   // valid-sample weight column
-    double s = 0.0;
-    if (p < nout)
-        for (int b = sl; b < nrows; b += 4) s += (double)partials[(size_t)b * stride + col];
+    // 8 independent accumulators keep 8 loads in flight; the combination order is fixed -> deterministic
+    double a8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (p < nout) {
+        int b = sl;
+        for (; b + 28 < nrows; b += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a8[u] += (double)partials[(size_t)(b + 4 * u) * stride + col];
+        }
+        for (int u = 0; b < nrows; b += 4, ++u) a8[u] += (double)partials[(size_t)b * stride + col];
+    }
+    const double s = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
     sh[sl][lc] = s;
     __syncthreads();
     if (sl == 0 && p < nout) {
@@ -390,12 +398,16 @@ int launch_loss_grad(metrpo_ctx* c, const metrpo_batch* b, double* out, hipStrea
 }
 
 int launch_fvp(metrpo_ctx* c, const metrpo_batch* b, const double* v, double* hv, hipStream_t st) {
-    PolK k; int rc = fill_polk(c, b, &k, false); if (rc) return rc;
     if (!v || !hv) return set_err(c, METRPO_ENULL, "v/hv is NULL");
     const int P = c->pd.P;
     hipLaunchKernelGGL(k_d2f, dim3((P + 127) / 128), dim3(128), 0, st, v, c->d_vf, P);
+    return launch_fvp_f32(c, b, c->d_vf, v, hv, st);
+}
+
+int launch_fvp_f32(metrpo_ctx* c, const metrpo_batch* b, const float* vf, const double* v, double* hv, hipStream_t st) {
+    PolK k; int rc = fill_polk(c, b, &k, false); if (rc) return rc;
     int nrows, stride, lk;
-    if ((rc = run_mode(c, 1, b, k, c->d_theta, c->d_vf, &nrows, &stride, &lk, st))) return rc;
+    if ((rc = run_mode(c, 1, b, k, c->d_theta, vf, &nrows, &stride, &lk, st))) return rc;
     finalize(c, 1, nrows, stride, lk, v, hv, st);
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;

@@ -19,31 +19,51 @@ __device__ __forceinline__ double baseline_value(const float* __restrict__ obs_r
     return v;
 }
 
-__global__ void k_gae(const float* __restrict__ obs, const float* __restrict__ rew, const uint8_t* __restrict__ done,
-                      const int32_t* __restrict__ tpath, int T, int B, int ns, const double* __restrict__ coeffs,
-                      double gamma, double lam, float* __restrict__ adv, float* __restrict__ ret,
+// V[n] for every sample in parallel (the scan then needs 3 scalars per step instead of a feature row)
+__global__ void k_baseline_predict(const float* __restrict__ obs, const int32_t* __restrict__ tpath, long long N, int ns,
+                                   const double* __restrict__ coeffs, double* __restrict__ V) {
+    for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (long long)gridDim.x * blockDim.x)
+        V[n] = baseline_value(obs + n * ns, ns, tpath[n], coeffs);
+}
+
+#define GAE_CHUNK 10
+__global__ void k_gae(const double* __restrict__ V, const float* __restrict__ rew, const uint8_t* __restrict__ done,
+                      int T, int B, double gamma, double lam, float* __restrict__ adv, float* __restrict__ ret,
                       uint8_t* __restrict__ valid, double* __restrict__ stats) {
     __shared__ double red[16];
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     double s1 = 0.0, s2 = 0.0, cnt = 0.0;
     if (b < B) {
         double a_next = 0.0, v_next = 0.0, r_next = 0.0;
-        bool complete = false;            // becomes true at the last done of the column: later (earlier-in-time) samples are whole paths
-        for (int t = T - 1; t >= 0; --t) {
-            const size_t tb = (size_t)t * B + b;
-            if (done[tb]) { a_next = 0.0; v_next = 0.0; r_next = 0.0; complete = true; }   // path_baselines = append(V, 0), base.py:58
-            const double r = (double)rew[tb];
-            const double v = (coeffs != nullptr) ? baseline_value(obs + tb * ns, ns, tpath[tb], coeffs) : 0.0;
-            const double delta = r + gamma * v_next - v;                                   // base.py:59-61
-            const double a = delta + gamma * lam * a_next;                                 // discount_cumsum(deltas, g*lam), :62-63
-            const double g = r + gamma * r_next;                                           // discount_cumsum(rewards, g), :64
-            adv[tb] = (float)a; ret[tb] = (float)g; valid[tb] = complete ? 1 : 0;
-            if (complete) { s1 += a; s2 += a * a; cnt += 1.0; }
-            a_next = a; v_next = v; r_next = g;
+        bool complete = false;            // true from the last done of the column backwards: those samples are whole paths
+        for (int t1 = T; t1 > 0; t1 -= GAE_CHUNK) {
+            // issue the loads of a whole chunk before entering the (dependent) recurrence
+            float rr[GAE_CHUNK]; uint8_t dd[GAE_CHUNK]; double vv[GAE_CHUNK];
+#pragma unroll
+            for (int u = 0; u < GAE_CHUNK; ++u) {
+                const int t = t1 - 1 - u;
+                const size_t tb = (size_t)(t < 0 ? 0 : t) * B + b;
+                rr[u] = rew[tb]; dd[u] = done[tb]; vv[u] = (V != nullptr) ? V[tb] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < GAE_CHUNK; ++u) {
+                const int t = t1 - 1 - u;
+                if (t >= 0) {
+                    const size_t tb = (size_t)t * B + b;
+                    if (dd[u]) { a_next = 0.0; v_next = 0.0; r_next = 0.0; complete = true; }   // path_baselines = append(V, 0), base.py:58
+                    const double r = (double)rr[u], v = vv[u];
+                    const double delta = r + gamma * v_next - v;                               // base.py:59-61
+                    const double a = delta + gamma * lam * a_next;                             // discount_cumsum(deltas, g*lam), :62-63
+                    const double g = r + gamma * r_next;                                       // discount_cumsum(rewards, g), :64
+                    adv[tb] = (float)a; ret[tb] = (float)g; valid[tb] = complete ? 1 : 0;
+                    if (complete) { s1 += a; s2 += a * a; cnt += 1.0; }
+                    a_next = a; v_next = v; r_next = g;
+                }
+            }
         }
     }
-    const double t1 = block_sum(s1, red), t2 = block_sum(s2, red), t3 = block_sum(cnt, red);
-    if (threadIdx.x == 0) { atomicAdd(&stats[0], t1); atomicAdd(&stats[1], t2); atomicAdd(&stats[2], t3); }
+    const double t1s = block_sum(s1, red), t2s = block_sum(s2, red), t3s = block_sum(cnt, red);
+    if (threadIdx.x == 0) { atomicAdd(&stats[0], t1s); atomicAdd(&stats[1], t2s); atomicAdd(&stats[2], t3s); }
 }
 
 __global__ void k_center(float* __restrict__ adv, const uint8_t* __restrict__ valid, int64_t N,
@@ -110,12 +130,139 @@ __global__ void k_gram(const float* __restrict__ obs, const float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Gram matrix on the f32 matrix core.  G = F^T F (+ F^T y as an extra feature column) contracts over
+// samples: A[i = feature][k = sample] and B[k = sample][j = feature] are the SAME per-lane value
+// (lane l: feature 16cb + (l&15), sample 4s + (l>>4)), so one feature evaluation feeds both operands.
+// Products are exact f32; each 16-sample tile is accumulated in the MFMA accumulator, then folded
+// into float64 lane accumulators (the reference forms these sums in float64), block-reduced in LDS in
+// fixed order and written as one partial matrix per block; k_gram_final adds the blocks in order.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int NFB>
+__global__ void __launch_bounds__(256) k_gram_mfma(const float* __restrict__ obs, const float* __restrict__ ret,
+                                                   const int32_t* __restrict__ tpath, const uint8_t* __restrict__ valid,
+                                                   long long N, int ns, double* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) double red[];      // [4][M*M]
+    constexpr int M = NFB * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
+    const int F = 2 * ns + 4;
+    double acc[NFB][NFB][4];
+#pragma unroll
+    for (int a = 0; a < NFB; ++a)
+#pragma unroll
+        for (int b = 0; b < NFB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.0;
+    const long long ntiles = (N + 15) / 16;
+    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+        f32x4 g[NFB][NFB];
+#pragma unroll
+        for (int a = 0; a < NFB; ++a)
+#pragma unroll
+            for (int b = 0; b < NFB; ++b) g[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const long long n = tile * 16 + 4 * s + q;
+            const bool ok = (n < N) && (valid == nullptr || valid[n]);
+            float val[NFB];
+#pragma unroll
+            for (int cb = 0; cb < NFB; ++cb) {
+                const int f = 16 * cb + c;
+                float x = 0.f;
+                if (ok) {
+                    if (f < 2 * ns) {
+                        const float o = fminf(fmaxf(obs[n * ns + (f < ns ? f : f - ns)], -10.f), 10.f);
+                        x = (f < ns) ? o : o * o;
+                    } else if (f < F) {
+                        const float al = (float)tpath[n] / 100.0f;
+                        const int k = f - 2 * ns;
+                        x = (k == 0) ? al : (k == 1) ? al * al : (k == 2) ? al * al * al : 1.0f;
+                    } else if (f == F) x = ret[n];
+                }
+                val[cb] = x;
+            }
+#pragma unroll
+            for (int a = 0; a < NFB; ++a)
+#pragma unroll
+                for (int b = 0; b < NFB; ++b) g[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(val[a], val[b], g[a][b], 0, 0, 0);
+        }
+#pragma unroll
+        for (int a = 0; a < NFB; ++a)
+#pragma unroll
+            for (int b = 0; b < NFB; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[a][b][r] += (double)g[a][b][r];
+    }
+    double* mine = red + (size_t)wave * M * M;
+#pragma unroll
+    for (int a = 0; a < NFB; ++a)
+#pragma unroll
+        for (int b = 0; b < NFB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mine[(16 * a + 4 * q + r) * M + 16 * b + c] = acc[a][b][r];   // D layout: row 4q+r, col c
+    __syncthreads();
+    double* out = part + (size_t)blockIdx.x * M * M;
+    for (int i = threadIdx.x; i < M * M; i += 256)
+        out[i] = (red[i] + red[M * M + i]) + (red[2 * M * M + i] + red[3 * M * M + i]);
+}
+
+__global__ void k_gram_final(const double* __restrict__ part, int nblocks, int M, int F, double* __restrict__ AtA,
+                             double* __restrict__ Aty) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= F * F + F) return;
+    const int i = (p < F * F) ? p / F : p - F * F;
+    const int j = (p < F * F) ? p % F : F;
+    double a4[4] = {0, 0, 0, 0};
+    int b = 0;
+    for (; b + 3 < nblocks; b += 4)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a4[u] += part[((size_t)(b + u) * M + i) * M + j];
+    for (int u = 0; b < nblocks; ++b, ++u) a4[u] += part[((size_t)b * M + i) * M + j];
+    const double s = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+    if (p < F * F) AtA[p] += s; else Aty[p - F * F] += s;
+}
+
+template <int NFB>
+static int launch_gram_mfma(metrpo_ctx* c, const float* obs, const float* ret, const int32_t* tpath, const uint8_t* valid,
+                            int64_t N, double* AtA, double* Aty, hipStream_t st) {
+    constexpr int M = NFB * 16;
+    const int F = 2 * c->pd.ns + 4;
+    const long long tiles = (N + 15) / 16;
+    const int g = (int)std::max<long long>(1, std::min<long long>((tiles + 3) / 4, (long long)c->n_sm * (NFB <= 2 ? 2 : 1)));
+    const size_t need = (size_t)g * M * M;
+    if (need > c->gram_cap) {
+        if (c->d_gram_part) HIP_TRY(c, hipFree(c->d_gram_part));
+        c->d_gram_part = nullptr; c->gram_cap = 0;
+        HIP_TRY(c, hipMalloc(&c->d_gram_part, need * sizeof(double)));
+        c->gram_cap = need;
+    }
+    const size_t sh = sizeof(double) * 4 * M * M;
+    if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_gram_mfma<NFB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    hipLaunchKernelGGL(k_gram_mfma<NFB>, dim3(g), dim3(256), sh, st, obs, ret, tpath, valid, (long long)N, c->pd.ns, c->d_gram_part);
+    const int nout = F * F + F;
+    hipLaunchKernelGGL(k_gram_final, dim3((nout + 127) / 128), dim3(128), 0, st, c->d_gram_part, g, M, F, AtA, Aty);
+    HIP_TRY(c, hipGetLastError());
+    return METRPO_OK;
+}
+
 int launch_gae(metrpo_ctx* c, const float* obs, const float* rew, const uint8_t* done, const int32_t* tpath, int T,
                int B, const double* coeffs, double gamma, double lam, float* adv, float* ret, uint8_t* valid,
                double* stats, hipStream_t st) {
+    const long long N = (long long)T * B;
+    double* V = nullptr;
+    if (coeffs != nullptr) {
+        if ((size_t)N > c->vbuf_cap) {
+            if (c->d_vbuf) HIP_TRY(c, hipFree(c->d_vbuf));
+            c->d_vbuf = nullptr; c->vbuf_cap = 0;
+            HIP_TRY(c, hipMalloc(&c->d_vbuf, sizeof(double) * (size_t)N));
+            c->vbuf_cap = (size_t)N;
+        }
+        V = c->d_vbuf;
+        const int g = (int)std::min<long long>((N + 255) / 256, (long long)c->n_sm * 8);
+        hipLaunchKernelGGL(k_baseline_predict, dim3(g), dim3(256), 0, st, obs, tpath, N, c->pd.ns, coeffs, V);
+    }
     const int bs = 64;
-    hipLaunchKernelGGL(k_gae, dim3((B + bs - 1) / bs), dim3(bs), 0, st, obs, rew, done, tpath, T, B, c->pd.ns, coeffs,
-                       gamma, lam, adv, ret, valid, stats);
+    hipLaunchKernelGGL(k_gae, dim3((B + bs - 1) / bs), dim3(bs), 0, st, V, rew, done, T, B, gamma, lam, adv, ret, valid, stats);
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;
 }
@@ -131,6 +278,10 @@ int launch_center(metrpo_ctx* c, float* adv, const uint8_t* valid, int64_t N, co
 int launch_gram(metrpo_ctx* c, const float* obs, const float* ret, const int32_t* tpath, const uint8_t* valid,
                 int64_t N, double* AtA, double* Aty, hipStream_t st) {
     const int F = 2 * c->pd.ns + 4;
+    const int nfb = (F + 1 + 15) / 16;                        // feature columns incl. the return column, in 16-blocks
+    if (nfb <= 2) return launch_gram_mfma<2>(c, obs, ret, tpath, valid, N, AtA, Aty, st);
+    if (nfb == 3) return launch_gram_mfma<3>(c, obs, ret, tpath, valid, N, AtA, Aty, st);
+    if (nfb == 4) return launch_gram_mfma<4>(c, obs, ret, tpath, valid, N, AtA, Aty, st);
     const int bs = 256;
     const size_t sh = sizeof(double) * GRAM_TILE * (F + 1);
     const int grid = (int)std::min<int64_t>((N + GRAM_TILE - 1) / GRAM_TILE, (int64_t)c->n_sm * 4);

@@ -176,9 +176,9 @@ __global__ void k_rollout_generic(ProblemDesc pd, RolloutK r, const float* __res
     {
         int row = 0;
         if (active) {
-            row = (r.reset_idx != nullptr) ? r.reset_idx[b] : rng_index(rng_draw(r.seed, genv, 0, RNG_RESET, 0).x, r.n_pool);
-            cur_model = (r.reset_model != nullptr) ? r.reset_model[b]
-                                                   : rng_index(rng_draw(r.seed, genv, 0, RNG_RESET_MODEL, 0).x, K);
+            const uint4 d0 = rng_draw(r.seed, genv, 0, RNG_RESET, 0);
+            row = (r.reset_idx != nullptr) ? r.reset_idx[b] : rng_index(d0.x, r.n_pool);
+            cur_model = (r.reset_model != nullptr) ? r.reset_model[b] : rng_index(d0.y, K);
         }
         for (int i = 0; i < ns; ++i) e.S[i * LD + tid] = active ? r.pool[(size_t)row * ns + i] : 0.0f;
     }
@@ -204,9 +204,9 @@ __global__ void k_rollout_generic(ProblemDesc pd, RolloutK r, const float* __res
         // ---- vec_env.step(actions) -----------------------------------------------------------
         ts += 1;
         int sel = cur_model;
+        const uint4 dstep = rng_draw(r.seed, genv, t, RNG_STEP, 0);
         if (r.sam_mode == METRPO_SAM_STEP_RAND)
-            sel = (r.model_idx != nullptr) ? (active ? r.model_idx[tb] : 0)
-                                           : rng_index(rng_draw(r.seed, genv, t, RNG_MODEL, 0).x, K);
+            sel = (r.model_idx != nullptr) ? (active ? r.model_idx[tb] : 0) : rng_index(dstep.x, K);
         float* noise_col = e.NEXT;
         if (r.sam_mode == METRPO_SAM_MODEL_MEAN_STD) {
             for (int i0 = 0; i0 < ns; i0 += 4) {
@@ -227,9 +227,8 @@ __global__ void k_rollout_generic(ProblemDesc pd, RolloutK r, const float* __res
             int row = 0;
             if (active) {
                 const size_t rb = (size_t)(t + 1) * r.B + b;
-                row = (r.reset_idx != nullptr) ? r.reset_idx[rb] : rng_index(rng_draw(r.seed, genv, t + 1, RNG_RESET, 0).x, r.n_pool);
-                cur_model = (r.reset_model != nullptr) ? r.reset_model[rb]
-                                                       : rng_index(rng_draw(r.seed, genv, t + 1, RNG_RESET_MODEL, 0).x, K);
+                row = (r.reset_idx != nullptr) ? r.reset_idx[rb] : rng_index(dstep.y, r.n_pool);
+                cur_model = (r.reset_model != nullptr) ? r.reset_model[rb] : rng_index(dstep.z, K);
             }
             for (int i = 0; i < ns; ++i) e.S[i * LD + tid] = active ? r.pool[(size_t)row * ns + i] : 0.0f;
             ts = 0;

@@ -162,8 +162,9 @@ __global__ void __launch_bounds__(512) k_rollout_mfma(RolloutK r, int K, const f
     {
         int row = 0;
         if (active) {
-            row = (r.reset_idx != nullptr) ? r.reset_idx[b] : rng_index(rng_draw(r.seed, genv, 0, RNG_RESET, 0).x, r.n_pool);
-            cur_model = (r.reset_model != nullptr) ? r.reset_model[b] : rng_index(rng_draw(r.seed, genv, 0, RNG_RESET_MODEL, 0).x, K);
+            const uint4 d0 = rng_draw(r.seed, genv, 0, RNG_RESET, 0);
+            row = (r.reset_idx != nullptr) ? r.reset_idx[b] : rng_index(d0.x, r.n_pool);
+            cur_model = (r.reset_model != nullptr) ? r.reset_model[b] : rng_index(d0.y, K);
         }
 #pragma unroll
         for (int cb = 0; cb < C::OUT_CB; ++cb)
@@ -198,7 +199,7 @@ __global__ void __launch_bounds__(512) k_rollout_mfma(RolloutK r, int K, const f
         for (int cb = 0; cb < C::PH_CB; ++cb) {
             p1[cb] = *(const f32x4*)&W[C::W_BP1 + 16 * cb + 4 * q];
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) p0[cb][rr] = tanhf(p0[cb][rr]);
+            for (int rr = 0; rr < 4; ++rr) p0[cb][rr] = tanh_fast(p0[cb][rr]);
         }
 #pragma unroll
         for (int kk = 0; kk < C::PH_CB * 4; ++kk)
@@ -207,7 +208,7 @@ __global__ void __launch_bounds__(512) k_rollout_mfma(RolloutK r, int K, const f
 #pragma unroll
         for (int cb = 0; cb < C::PH_CB; ++cb)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) p1[cb][rr] = tanhf(p1[cb][rr]);
+            for (int rr = 0; rr < 4; ++rr) p1[cb][rr] = tanh_fast(p1[cb][rr]);
         f32x4 m0 = *(const f32x4*)&W[C::W_BP2 + 4 * q], m1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < C::PH_CB * 4; kk += 2) {              // two accumulators: 40-cycle dependent latency
@@ -216,7 +217,7 @@ __global__ void __launch_bounds__(512) k_rollout_mfma(RolloutK r, int K, const f
         }
         const f32x4 mu = m0 + m1;
         float z[4] = {0.f, 0.f, 0.f, 0.f};
-        if (!r.determ && r.eps == nullptr) normal4(rng_draw(r.seed, genv, t, RNG_EPS, q), z);
+        if (!r.determ && r.eps == nullptr && 4 * q < NA) normal4(rng_draw(r.seed, genv, t, RNG_EPS, q), z);
         float su2 = 0.0f;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
@@ -289,8 +290,9 @@ __global__ void __launch_bounds__(512) k_rollout_mfma(RolloutK r, int K, const f
         // ---- get_next_observation selection (env_helpers.py:617-634), redundantly in every wave -----
         ts += 1;
         int sel = cur_model;
+        const uint4 dstep = rng_draw(r.seed, genv, t, RNG_STEP, 0);
         if (r.sam_mode == METRPO_SAM_STEP_RAND)
-            sel = (r.model_idx != nullptr) ? (active ? r.model_idx[tb] : 0) : rng_index(rng_draw(r.seed, genv, t, RNG_MODEL, 0).x, K);
+            sel = (r.model_idx != nullptr) ? (active ? r.model_idx[tb] : 0) : rng_index(dstep.x, K);
         if (r.sam_mode == METRPO_SAM_ONE_MODEL) sel = 0;
         const float* nxt_all = NXT + (size_t)par * K * 16 * NSP;
         f32x4 nx[C::OUT_CB];
@@ -370,8 +372,8 @@ __global__ void __launch_bounds__(512) k_rollout_mfma(RolloutK r, int K, const f
         if (dn) {
             if (active) {
                 const size_t rb = (size_t)(t + 1) * r.B + b;
-                row = (r.reset_idx != nullptr) ? r.reset_idx[rb] : rng_index(rng_draw(r.seed, genv, t + 1, RNG_RESET, 0).x, r.n_pool);
-                cur_model = (r.reset_model != nullptr) ? r.reset_model[rb] : rng_index(rng_draw(r.seed, genv, t + 1, RNG_RESET_MODEL, 0).x, K);
+                row = (r.reset_idx != nullptr) ? r.reset_idx[rb] : rng_index(dstep.y, r.n_pool);
+                cur_model = (r.reset_model != nullptr) ? r.reset_model[rb] : rng_index(dstep.z, K);
             }
             ts = 0;
         }
