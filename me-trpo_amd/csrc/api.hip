@@ -72,7 +72,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     if (!c) return METRPO_EINVAL;
     c->device = device; c->dims = *d;
     c->d_dyn = c->d_norm = c->d_theta = nullptr; c->have_dyn = c->have_pol = false;
-    c->d_dyn_img = c->d_pol_img = nullptr; c->mfma_cfg = -1; c->pol_mfma = -1;
+    c->d_dyn_img = c->d_pol_img = nullptr; c->mfma_cfg = -1; c->pol_mfma = -1; c->coop_cfg = -1; c->rollout_variant = 0;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_cg = nullptr; c->d_vf = nullptr; c->d_theta_try = nullptr;
     c->d_valbuf = nullptr; c->h_pinned = nullptr; c->n_sm = 256;
     c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0;
@@ -103,6 +103,8 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     }
     c->mfma_cfg = mfma_select_config(c);
     c->pol_mfma = policy_mfma_select(pd);
+    c->coop_cfg = coop_select_config(c);
+    c->rollout_variant = 0;
     return METRPO_OK;
 }
 
@@ -214,6 +216,12 @@ extern "C" int32_t metrpo_rollout_generic(metrpo_ctx* c, const metrpo_rollout_ar
     return launch_rollout_generic(c, a, (hipStream_t)stream);
 }
 extern "C" int32_t metrpo_has_mfma_path(const metrpo_ctx* c) { return (c && c->mfma_cfg >= 0) ? 1 : 0; }
+// test hook: 0 = fastest rollout kernel available, 1 = head-per-wave MFMA kernel even where the cooperative one exists
+extern "C" int32_t metrpo_set_rollout_variant(metrpo_ctx* c, int32_t v) {
+    if (!c) return METRPO_ENULL;
+    c->rollout_variant = v;
+    return (v == 0 && c->coop_cfg >= 0) ? 2 : (c->mfma_cfg >= 0 ? 1 : 0);
+}
 // test hook: 0 forces the generic (VALU) update kernels, 1 restores the MFMA ones when available
 extern "C" int32_t metrpo_set_update_path(metrpo_ctx* c, int32_t use_mfma) {
     if (!c) return METRPO_ENULL;

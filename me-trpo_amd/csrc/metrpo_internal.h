@@ -39,6 +39,8 @@ struct metrpo_ctx {
     float* d_pol_img;
     int mfma_cfg;        // index into the instantiation table, -1 = generic path only
     int pol_mfma;        // index into policy_mfma.hip's table, -1 = generic update kernels
+    int coop_cfg;        // index into rollout_coop.hip's table, -1 = head-per-wave kernel (rollout_mfma.hip)
+    int rollout_variant; // test hook: 0 = fastest available, 1 = head-per-wave MFMA kernel
     // --- workspaces for the update path (lazily sized) ---
     float* d_partials;   // [n_blocks][P+2] per-block partial sums
     size_t partials_cap;
@@ -93,6 +95,8 @@ int launch_rollout_mfma(metrpo_ctx*, const metrpo_rollout_args*, hipStream_t);  
 int mfma_prepare_dynamics(metrpo_ctx*, hipStream_t);
 int mfma_prepare_policy(metrpo_ctx*, hipStream_t);
 int mfma_select_config(metrpo_ctx*);
+int coop_select_config(metrpo_ctx*);
+int launch_rollout_coop(metrpo_ctx*, int idx, const RolloutK&, hipStream_t);
 int launch_validation_cost(metrpo_ctx*, const float*, int, int, double, double*, hipStream_t);
 int launch_gae(metrpo_ctx*, const float*, const float*, const uint8_t*, const int32_t*, int, int, const double*,
                double, double, float*, float*, uint8_t*, double*, hipStream_t);

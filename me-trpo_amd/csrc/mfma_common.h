@@ -1,0 +1,49 @@
+// Shared definitions of the MFMA rollout kernels (rollout_mfma.hip: head-per-wave; rollout_coop.hip: cooperative heads).
+#pragma once
+#include "device_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+template <int ENV> struct EnvDim;
+template <> struct EnvDim<METRPO_ENV_SWIMMER>      { static constexpr int NS = 10, NA = 2, NDROP = 2; };
+template <> struct EnvDim<METRPO_ENV_HALF_CHEETAH> { static constexpr int NS = 18, NA = 6, NDROP = 1; };
+template <> struct EnvDim<METRPO_ENV_ANT>          { static constexpr int NS = 29, NA = 8, NDROP = 2; };
+template <> struct EnvDim<METRPO_ENV_HOPPER>       { static constexpr int NS = 11, NA = 3, NDROP = 0; };
+template <> struct EnvDim<METRPO_ENV_SNAKE>        { static constexpr int NS = 14, NA = 4, NDROP = 2; };
+
+constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+template <int ENV, int DH, int PH>
+struct Cfg {
+    static constexpr int NS = EnvDim<ENV>::NS, NA = EnvDim<ENV>::NA, NDROP = EnvDim<ENV>::NDROP;
+    static constexpr int NIN = NS + NA - NDROP;
+    static constexpr int NIN_KS = cdiv(NIN, 4), NS_KS = cdiv(NS, 4);
+    static constexpr int DH_CB = cdiv(DH, 16), PH_CB = cdiv(PH, 16), OUT_CB = cdiv(NS, 16);
+    static constexpr int NSP = 16 * OUT_CB;                        // padded state row in the exchange buffer
+    // flat dynamics layout of one head: W0 b0 W1 b1 W2 b2
+    static constexpr int dW0 = 0, db0 = NIN * DH, dW1 = db0 + DH, db1 = dW1 + DH * DH, dW2 = db1 + DH,
+                         db2 = dW2 + DH * NS, PD = db2 + NS;
+    // flat policy layout (rllab order): W0 b0 W1 b1 Wout bout log_std
+    static constexpr int pW0 = 0, pb0 = NS * PH, pW1 = pb0 + PH, pb1 = pW1 + PH * PH, pW2 = pb1 + PH,
+                         pb2 = pW2 + PH * NA, pLS = pb2 + NA;
+    // per-wave LDS (floats): ST | NX | ACT | dyn biases (3 x padded) | policy biases (3 x padded)
+    static constexpr int BD = 16 * DH_CB, BP = 16 * PH_CB;
+    static constexpr int W_ST = 0, W_NX = W_ST + 16 * NS, W_ACT = W_NX + 16 * NS, W_BD0 = ((W_ACT + 16 * NA + 3) / 4) * 4,
+                         W_BD1 = W_BD0 + BD, W_BD2 = W_BD1 + BD, W_BP0 = W_BD2 + NSP, W_BP1 = W_BP0 + BP,
+                         W_BP2 = W_BP1 + BP, W_TOTAL = W_BP2 + 16;
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS operations of one wave complete in issue order; this only stops the compiler from moving
+    // LDS accesses of different lanes across the point.
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float xor_sum(float v) {      // sum over the 4 lanes (e, q=0..3) of one env
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+

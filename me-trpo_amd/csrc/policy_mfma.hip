@@ -33,7 +33,7 @@ __device__ __forceinline__ float xsum_c(float v) {
 enum { MODE_GRAD = 0, MODE_FVP = 1, MODE_LOSSKL = 2 };
 
 template <int NS, int NA, int PH, int MODE>
-__global__ void __launch_bounds__(256) k_policy_mfma(PolK k, const float* __restrict__ theta, const float* __restrict__ v,
+__global__ void __launch_bounds__(256, 2) k_policy_mfma(PolK k, const float* __restrict__ theta, const float* __restrict__ v,
                                                      float* __restrict__ partials) {
     constexpr int NS_KS = cdiv_(NS, 4), NSI = cdiv_(NS, 16), HB = cdiv_(PH, 16), KK = HB * 4;
     constexpr int pW0 = 0, pb0 = NS * PH, pW1 = pb0 + PH, pb1 = pW1 + PH * PH, pW2 = pb1 + PH, pb2 = pW2 + PH * NA,

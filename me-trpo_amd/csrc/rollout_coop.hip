@@ -1,0 +1,369 @@
+// Cooperative-heads MFMA rollout (second generation of rollout_mfma.hip; same arithmetic, same reference
+// sites: samplers/vectorized_sampler.py:45-116, env_helpers.py:597-635, training.py:218-269).
+//
+// Why: with one head per wave (rollout_mfma.hip) a K=5 workgroup has 5 waves on 4 SIMDs, one SIMD carries two
+// heads (2 x 92 MFMAs per step) and, at ~230 VGPRs, only ONE such workgroup fits a CU -- the 313 tiles of the
+// headline shape (B = 5000) then run in two sequential rounds on 256 CUs (measured: B=4096 0.64 ms, B=5000 1.23 ms).
+// Here a workgroup is exactly 4 waves (one per SIMD) for a 16-env tile and EVERY head is split across them:
+//     wave w owns hidden col-block w (16 of the 64 units) of layers 0 and 1 of all K heads, and the K-slice w of
+//     layer 2 (its own 16 hidden units), i.e. K x (3 + 16 + 4) = 115 MFMAs per step instead of 92 / 184,
+// perfectly balanced over the 4 SIMDs, and two workgroups fit a CU (8 waves, 2 per SIMD).  Costs: the layer-0
+// activations and the layer-2 partial sums cross waves through LDS -> two barriers per step instead of one.
+// The policy (30 MFMAs) is still evaluated redundantly by each wave; its weight fragments live in LDS (shared).
+#include "mfma_common.h"
+
+template <int ENV, int K>
+struct Coop {
+    using C = Cfg<ENV, 64, 32>;
+    static constexpr int NS = C::NS, NA = C::NA, NSP = C::NSP;
+    static constexpr int NPF = C::NS_KS * 2 + 16 + 8;                 // policy weight fragments: wp0[s][2], wp1[8][2], wp2[8]
+    // LDS map (floats)
+    static constexpr int WV = ((16 * NS * 2 + 16 * NA + 3) / 4) * 4;  // per wave: ST | NX | ACT
+    static constexpr int O_BD0 = 4 * WV, O_BD1 = O_BD0 + K * 64, O_BD2 = O_BD1 + K * 64, O_BP0 = O_BD2 + K * NSP,
+                         O_BP1 = O_BP0 + 32, O_BP2 = O_BP1 + 32, O_PW = O_BP2 + 16, O_H0 = O_PW + NPF * 64,
+                         O_PART = O_H0 + K * 1024, TOTAL = O_PART + K * 4 * 16 * NSP;
+};
+
+template <int ENV, int K>
+__global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float* __restrict__ dynp,
+                                                      const float* __restrict__ theta, const float* __restrict__ norm) {
+    using L = Coop<ENV, K>;
+    using C = typename L::C;
+    constexpr int NS = C::NS, NA = C::NA, NSP = C::NSP, DH = 64, PH = 32, OUT_CB = C::OUT_CB;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;      // wave = hidden col-block
+    const int e = lane & 15, q = lane >> 4;
+    const int b0 = blockIdx.x * 16, b = b0 + e;
+    const bool active = b < r.B;
+    const uint64_t genv = r.stream_offset + (uint64_t)b;
+    float* ST = lds + wave * L::WV;  float* NX = ST + 16 * NS;  float* ACT = NX + 16 * NS;
+    float* BD0 = lds + L::O_BD0; float* BD1 = lds + L::O_BD1; float* BD2 = lds + L::O_BD2;
+    float* BP0 = lds + L::O_BP0; float* BP1 = lds + L::O_BP1; float* BP2 = lds + L::O_BP2;
+    float* PW = lds + L::O_PW; float* H0 = lds + L::O_H0; float* PART = lds + L::O_PART;
+
+    // ---------------- one-time: dynamics fragments -> registers ----------------------------------
+    float wd0[K][C::NIN_KS], wd1[K][16], wd2[K][4][OUT_CB];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float* __restrict__ pk = dynp + (size_t)k * C::PD;
+#pragma unroll
+        for (int s = 0; s < C::NIN_KS; ++s) { const int i = 4 * s + q; wd0[k][s] = (i < C::NIN) ? pk[C::dW0 + i * DH + 16 * wave + e] : 0.0f; }
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) { const int i = 16 * (kk >> 2) + 4 * q + (kk & 3); wd1[k][kk] = pk[C::dW1 + i * DH + 16 * wave + e]; }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int cb = 0; cb < OUT_CB; ++cb) { const int i = 16 * wave + 4 * q + rr, o = 16 * cb + e; wd2[k][rr][cb] = (o < NS) ? pk[C::dW2 + i * NS + o] : 0.0f; }
+    }
+    // shared images: biases and policy fragments (each element written by exactly one thread)
+    for (int i = tid; i < K * 64; i += 256) { const int k = i >> 6, u = i & 63; BD0[i] = dynp[(size_t)k * C::PD + C::db0 + u]; BD1[i] = dynp[(size_t)k * C::PD + C::db1 + u]; }
+    for (int i = tid; i < K * NSP; i += 256) { const int k = i / NSP, u = i % NSP; BD2[i] = (u < NS) ? dynp[(size_t)k * C::PD + C::db2 + u] : 0.0f; }
+    if (tid < 32) { BP0[tid] = theta[C::pb0 + tid]; BP1[tid] = theta[C::pb1 + tid]; }
+    if (tid < 16) BP2[tid] = (tid < NA) ? theta[C::pb2 + tid] : 0.0f;
+    for (int i = tid; i < L::NPF * 64; i += 256) {
+        const int f = i >> 6, ln = i & 63, ee = ln & 15, qq = ln >> 4;
+        float w = 0.0f;
+        if (f < C::NS_KS * 2) { const int s = f >> 1, cb = f & 1, in = 4 * s + qq; w = (in < NS) ? theta[C::pW0 + in * PH + 16 * cb + ee] : 0.0f; }
+        else if (f < C::NS_KS * 2 + 16) { const int g = f - C::NS_KS * 2, kk = g >> 1, cb = g & 1, in = 16 * (kk >> 2) + 4 * qq + (kk & 3); w = theta[C::pW1 + in * PH + 16 * cb + ee]; }
+        else { const int kk = f - C::NS_KS * 2 - 16, in = 16 * (kk >> 2) + 4 * qq + (kk & 3); w = (ee < NA) ? theta[C::pW2 + in * NA + ee] : 0.0f; }
+        PW[i] = w;
+    }
+    const float* pw0 = PW + lane, *pw1 = PW + C::NS_KS * 2 * 64 + lane, *pw2 = PW + (C::NS_KS * 2 + 16) * 64 + lane;
+    float sig[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) sig[rr] = (4 * q + rr < NA) ? expf(fmaxf(theta[C::pLS + 4 * q + rr], LOG_MIN_STD)) : 0.0f;
+    float nmean[C::NIN_KS], nstd[C::NIN_KS];
+    int nsrc[C::NIN_KS];
+#pragma unroll
+    for (int s = 0; s < C::NIN_KS; ++s) {
+        const int i = 4 * s + q;
+        int f = 0;
+        if (i < NS - C::NDROP) { f = i + C::NDROP; nsrc[s] = f; }
+        else if (i < C::NIN) { f = NS + (i - (NS - C::NDROP)); nsrc[s] = -(i - (NS - C::NDROP)) - 1; }
+        else { nsrc[s] = -1000000; }
+        nmean[s] = (i < C::NIN) ? norm[f] : 0.0f;
+        nstd[s] = (i < C::NIN) ? norm[(NS + NA) + f] : 1.0f;
+    }
+    f32x4 dmean[OUT_CB], dstd[OUT_CB];
+#pragma unroll
+    for (int cb = 0; cb < OUT_CB; ++cb)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int dim = 16 * cb + 4 * q + rr;
+            dmean[cb][rr] = (dim < NS) ? norm[2 * (NS + NA) + dim] : 0.0f;
+            dstd[cb][rr] = (dim < NS) ? norm[2 * (NS + NA) + NS + dim] : 0.0f;
+        }
+    // ---------------- vec_env.reset() (env_helpers.py:585-595) -------------------------------------
+    int cur_model = 0, ts = 0;
+    {
+        int row = 0;
+        if (active) {
+            const uint4 d0 = rng_draw(r.seed, genv, 0, RNG_RESET, 0);
+            row = (r.reset_idx != nullptr) ? r.reset_idx[b] : rng_index(d0.x, r.n_pool);
+            cur_model = (r.reset_model != nullptr) ? r.reset_model[b] : rng_index(d0.y, K);
+        }
+#pragma unroll
+        for (int cb = 0; cb < OUT_CB; ++cb)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) { const int dim = 16 * cb + 4 * q + rr; if (dim < NS) ST[e * NS + dim] = r.pool[(size_t)row * NS + dim]; }
+    }
+    __syncthreads();
+
+    for (int t = 0; t < r.T; ++t) {
+        const size_t tb = (size_t)t * r.B + b;
+        if (wave == 0) {                                                   // obs[t]: coalesced linear copy of the tile
+            const size_t base = ((size_t)t * r.B + b0) * NS;
+            const int lim = min(16, r.B - b0) * NS;
+            for (int i = lane; i < lim; i += 64) r.obs[base + i] = ST[i];
+        }
+        // ---- policy (redundant in every wave; weight fragments from LDS) -----------------------------
+        f32x4 p0[2], p1[2];
+        p0[0] = *(const f32x4*)&BP0[4 * q]; p0[1] = *(const f32x4*)&BP0[16 + 4 * q];
+#pragma unroll
+        for (int s = 0; s < C::NS_KS; ++s) {
+            const int f = 4 * s + q;
+            const float x = (f < NS) ? ST[e * NS + f] : 0.0f;
+            p0[0] = MFMA16(pw0[(2 * s) * 64], x, p0[0]);
+            p0[1] = MFMA16(pw0[(2 * s + 1) * 64], x, p0[1]);
+        }
+        p1[0] = *(const f32x4*)&BP1[4 * q]; p1[1] = *(const f32x4*)&BP1[16 + 4 * q];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) p0[cb][rr] = tanh_fast(p0[cb][rr]);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            p1[0] = MFMA16(pw1[(2 * kk) * 64], p0[kk >> 2][kk & 3], p1[0]);
+            p1[1] = MFMA16(pw1[(2 * kk + 1) * 64], p0[kk >> 2][kk & 3], p1[1]);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) p1[cb][rr] = tanh_fast(p1[cb][rr]);
+        f32x4 m0 = *(const f32x4*)&BP2[4 * q], m1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 8; kk += 2) {
+            m0 = MFMA16(pw2[kk * 64], p1[kk >> 2][kk & 3], m0);
+            m1 = MFMA16(pw2[(kk + 1) * 64], p1[(kk + 1) >> 2][(kk + 1) & 3], m1);
+        }
+        const f32x4 mu = m0 + m1;
+        float z[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!r.determ && r.eps == nullptr) normal4(rng_draw(r.seed, genv, t, RNG_EPS, q), z);
+        float su2 = 0.0f;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int d = 4 * q + rr;
+            if (d < NA) {
+                float a = mu[rr];
+                if (!r.determ) {
+                    const float zz = (r.eps != nullptr) ? (active ? r.eps[tb * NA + d] : 0.0f) : z[rr];
+                    a = fmaf(zz, sig[rr], a);
+                }
+                if (wave == 1 && active) { r.act[tb * NA + d] = a; r.mean[tb * NA + d] = mu[rr]; }
+                const float ac = fminf(fmaxf(a, -1.0f), 1.0f);            // env_helpers.py:599
+                ACT[e * NA + d] = ac;
+                su2 = fmaf(ac, ac, su2);
+            }
+        }
+        su2 = xor_sum(su2);
+        wave_lds_sync();
+        // ---- dynamics layer 0, col-block `wave`, all K heads ------------------------------------------
+        {
+            float xin[C::NIN_KS];
+#pragma unroll
+            for (int s = 0; s < C::NIN_KS; ++s) {
+                float x = 0.0f;
+                if (nsrc[s] >= 0) x = ST[e * NS + nsrc[s]];
+                else if (nsrc[s] > -1000000) x = ACT[e * NA + (-nsrc[s] - 1)];
+                xin[s] = (nsrc[s] > -1000000) ? (x - nmean[s]) / nstd[s] : 0.0f;          // training.py:228
+            }
+            f32x4 h0[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) h0[k] = *(const f32x4*)&BD0[k * 64 + 16 * wave + 4 * q];
+#pragma unroll
+            for (int s = 0; s < C::NIN_KS; ++s)
+#pragma unroll
+                for (int k = 0; k < K; ++k) h0[k] = MFMA16(wd0[k][s], xin[s], h0[k]);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) h0[k][rr] = fmaxf(h0[k][rr], 0.0f);
+                *(f32x4*)&H0[k * 1024 + wave * 256 + q * 64 + e * 4] = h0[k];            // H0[k][cb][q][env][r]
+            }
+        }
+        __syncthreads();                                                   // B1: layer-0 activations of all heads visible
+        // ---- layer 1 (own col-block) and the layer-2 partial over the own 16 hidden units ----------------
+        f32x4 h1[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) h1[k] = *(const f32x4*)&BD1[k * 64 + 16 * wave + 4 * q];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            f32x4 hb[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) hb[k] = *(const f32x4*)&H0[k * 1024 + cb * 256 + q * 64 + e * 4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int k = 0; k < K; ++k) h1[k] = MFMA16(wd1[k][cb * 4 + rr], hb[k][rr], h1[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) h1[k][rr] = fmaxf(h1[k][rr], 0.0f);
+        {
+            f32x4 po[K][OUT_CB];
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int cb = 0; cb < OUT_CB; ++cb) po[k][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int cb = 0; cb < OUT_CB; ++cb)
+#pragma unroll
+                    for (int k = 0; k < K; ++k) po[k][cb] = MFMA16(wd2[k][rr][cb], h1[k][rr], po[k][cb]);
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int cb = 0; cb < OUT_CB; ++cb) *(f32x4*)&PART[((k * 4 + wave) * 16 + e) * NSP + 16 * cb + 4 * q] = po[k][cb];
+        }
+        __syncthreads();                                                   // B2: all partial sums visible
+        // ---- selection (env_helpers.py:617-634): out_k = b2_k + sum_w partial ; next = dmean + dstd*out + s ----
+        ts += 1;
+        int sel = cur_model;
+        const uint4 dstep = rng_draw(r.seed, genv, t, RNG_STEP, 0);
+        if (r.sam_mode == METRPO_SAM_STEP_RAND) sel = (r.model_idx != nullptr) ? (active ? r.model_idx[tb] : 0) : rng_index(dstep.x, K);
+        if (r.sam_mode == METRPO_SAM_ONE_MODEL) sel = 0;
+        const bool simple = (r.sam_mode == METRPO_SAM_STEP_RAND || r.sam_mode == METRPO_SAM_EPS_RAND || r.sam_mode == METRPO_SAM_ONE_MODEL);
+        f32x4 nx[OUT_CB];
+#pragma unroll
+        for (int cb = 0; cb < OUT_CB; ++cb) {
+            const int off = e * NSP + 16 * cb + 4 * q;
+            f32x4 sv;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) { const int dim = 16 * cb + 4 * q + rr; sv[rr] = (dim < NS) ? ST[e * NS + dim] : 0.0f; }
+            auto head = [&](int k) -> f32x4 {
+                const float* pp = PART + (size_t)k * 4 * 16 * NSP + off;
+                f32x4 o = *(const f32x4*)&BD2[k * NSP + 16 * cb + 4 * q];
+                o += (*(const f32x4*)&pp[0] + *(const f32x4*)&pp[16 * NSP]) + (*(const f32x4*)&pp[2 * 16 * NSP] + *(const f32x4*)&pp[3 * 16 * NSP]);
+                return dstd[cb] * o + dmean[cb] + sv;                     // training.py:257
+            };
+            if (simple) nx[cb] = head(sel);
+            else {
+                f32x4 hv[K], m = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < K; ++k) { hv[k] = head(k); m += hv[k]; }
+                m /= (float)K;
+                if (r.sam_mode == METRPO_SAM_MODEL_MEAN) nx[cb] = m;
+                else if (r.sam_mode == METRPO_SAM_MODEL_MEAN_STD) {
+                    f32x4 var = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < K; ++k) { const f32x4 d = hv[k] - m; var += d * d; }
+                    float zz[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (r.sel_noise == nullptr) normal4(rng_draw(r.seed, genv, t, RNG_SELNOISE, 4 * cb + q), zz);
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int dim = 16 * cb + 4 * q + rr;
+                        const float nz = (r.sel_noise != nullptr) ? ((active && dim < NS) ? r.sel_noise[tb * NS + dim] : 0.0f) : zz[rr];
+                        nx[cb][rr] = fmaf(nz, sqrtf(var[rr] / (float)K), m[rr]);
+                    }
+                } else {                                                  // model_med: np.median over K
+                    constexpr int r_lo = (K - 1) / 2, r_hi = K / 2;
+                    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        int rank[4] = {0, 0, 0, 0};
+#pragma unroll
+                        for (int j = 0; j < K; ++j)
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) rank[rr] += (hv[j][rr] < hv[k][rr]) || (hv[j][rr] == hv[k][rr] && j < k);
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) { if (rank[rr] == r_lo) lo[rr] = hv[k][rr]; if (rank[rr] == r_hi) hi[rr] = hv[k][rr]; }
+                    }
+                    nx[cb] = (lo + hi) * 0.5f;
+                }
+            }
+        }
+        // ---- reward (:601), is_done (:603), horizon (:604) ----------------------------------------------
+        float pen = 0.0f; int fin = 1;
+#pragma unroll
+        for (int cb = 0; cb < OUT_CB; ++cb)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int dim = 16 * cb + 4 * q + rr;
+                if (dim < NS) {
+                    NX[e * NS + dim] = nx[cb][rr];
+                    if (ENV == METRPO_ENV_HOPPER && dim >= 2) pen += fmaxf(fabsf(nx[cb][rr]) - 100.0f, 0.0f);
+                    if (ENV == METRPO_ENV_ANT) fin &= isfinite(nx[cb][rr]) ? 1 : 0;
+                }
+            }
+        wave_lds_sync();
+        const float* xn = NX + e * NS;
+        float cost = 0.0f;
+        bool dn = false;
+        if (ENV == METRPO_ENV_SWIMMER) cost = -(xn[5] - 1e-2f * (su2 / (float)NA));
+        else if (ENV == METRPO_ENV_HALF_CHEETAH) cost = -fminf(fmaxf(xn[9] - 1e-1f * 0.5f * su2, -10.0f), 10.0f);
+        else if (ENV == METRPO_ENV_SNAKE) cost = -(xn[7] - 1e-2f * 0.5f * su2);
+        else if (ENV == METRPO_ENV_HOPPER) {
+            pen = xor_sum(pen);
+            cost = -(xn[5] - 0.01f * 0.5f * su2 - 10.0f * fmaxf(0.45f - xn[0], 0.0f) - 10.0f * fmaxf(fabsf(xn[1]) - 0.2f, 0.0f) - pen);
+        } else if (ENV == METRPO_ENV_ANT) {
+            cost = -(xn[15] - 1e-2f * 0.5f * su2 + 0.05f);
+            int f2 = fin & __shfl_xor(fin, 16, 64);
+            f2 &= __shfl_xor(f2, 32, 64);
+            const float zc = xn[2];
+            dn = !((zc >= 0.2f) && (zc <= 1.0f) && (f2 != 0));
+        }
+        dn = dn || (ts >= r.H);
+        if (wave == 2 && q == 0 && active) { r.rew[tb] = -cost; r.done[tb] = dn ? 1 : 0; r.tpath[tb] = ts - 1; }
+        // ---- reset(dones) (:585-595) or advance; every wave keeps its own copy of the tile state ----------
+        int row = 0;
+        if (dn) {
+            if (active) {
+                const size_t rb = (size_t)(t + 1) * r.B + b;
+                row = (r.reset_idx != nullptr) ? r.reset_idx[rb] : rng_index(dstep.y, r.n_pool);
+                cur_model = (r.reset_model != nullptr) ? r.reset_model[rb] : rng_index(dstep.z, K);
+            }
+            ts = 0;
+        }
+#pragma unroll
+        for (int cb = 0; cb < OUT_CB; ++cb)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int dim = 16 * cb + 4 * q + rr;
+                if (dim < NS) ST[e * NS + dim] = dn ? r.pool[(size_t)row * NS + dim] : nx[cb][rr];
+            }
+        wave_lds_sync();
+    }
+    if (wave == 0 && r.last_obs != nullptr) {
+        const int lim = min(16, r.B - b0) * NS;
+        for (int i = lane; i < lim; i += 64) r.last_obs[(size_t)b0 * NS + i] = ST[i];
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+typedef void (*coop_kernel_t)(RolloutK, const float*, const float*, const float*);
+struct CoopEntry { int env, K; coop_kernel_t kern; int lds_floats; };
+#define CENTRY(ENVID, KK) {ENVID, KK, k_rollout_coop<ENVID, KK>, Coop<ENVID, KK>::TOTAL}
+static const CoopEntry kCoop[] = {
+    CENTRY(METRPO_ENV_SWIMMER, 5), CENTRY(METRPO_ENV_HALF_CHEETAH, 5), CENTRY(METRPO_ENV_HOPPER, 5),
+    CENTRY(METRPO_ENV_SNAKE, 5), CENTRY(METRPO_ENV_ANT, 5),
+};
+
+// index into kCoop or -1; requires the head-per-wave selection to have accepted the shape (same env dims)
+int coop_select_config(metrpo_ctx* c) {
+    const ProblemDesc& pd = c->pd;
+    if (c->mfma_cfg < 0 || pd.dyn.dims[1] != 64 || pd.dyn.dims[2] != 64 || pd.pol.dims[1] != 32 || pd.pol.dims[2] != 32) return -1;
+    for (int i = 0; i < (int)(sizeof(kCoop) / sizeof(kCoop[0])); ++i)
+        if (kCoop[i].env == pd.env && kCoop[i].K == pd.K) return i;
+    return -1;
+}
+
+int launch_rollout_coop(metrpo_ctx* c, int idx, const RolloutK& r, hipStream_t st) {
+    const CoopEntry& en = kCoop[idx];
+    const size_t sh = sizeof(float) * (size_t)en.lds_floats;
+    if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)en.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    hipLaunchKernelGGL(en.kern, dim3((r.B + 15) / 16), dim3(256), sh, st, r, c->d_dyn, c->d_theta, c->d_norm);
+    HIP_TRY(c, hipGetLastError());
+    return METRPO_OK;
+}

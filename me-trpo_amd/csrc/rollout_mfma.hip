@@ -17,52 +17,8 @@
 //     (~120 VGPRs); biases live in LDS and enter as the MFMA C operand.
 //   * state of the tile is kept per wave in LDS in [env][ns] order == the global layout of one
 //     time step of the trajectory, so the obs store is a fully coalesced linear copy.
-#include "device_common.h"
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-
-template <int ENV> struct EnvDim;
-template <> struct EnvDim<METRPO_ENV_SWIMMER>      { static constexpr int NS = 10, NA = 2, NDROP = 2; };
-template <> struct EnvDim<METRPO_ENV_HALF_CHEETAH> { static constexpr int NS = 18, NA = 6, NDROP = 1; };
-template <> struct EnvDim<METRPO_ENV_ANT>          { static constexpr int NS = 29, NA = 8, NDROP = 2; };
-template <> struct EnvDim<METRPO_ENV_HOPPER>       { static constexpr int NS = 11, NA = 3, NDROP = 0; };
-template <> struct EnvDim<METRPO_ENV_SNAKE>        { static constexpr int NS = 14, NA = 4, NDROP = 2; };
-
-constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
-
-template <int ENV, int DH, int PH>
-struct Cfg {
-    static constexpr int NS = EnvDim<ENV>::NS, NA = EnvDim<ENV>::NA, NDROP = EnvDim<ENV>::NDROP;
-    static constexpr int NIN = NS + NA - NDROP;
-    static constexpr int NIN_KS = cdiv(NIN, 4), NS_KS = cdiv(NS, 4);
-    static constexpr int DH_CB = cdiv(DH, 16), PH_CB = cdiv(PH, 16), OUT_CB = cdiv(NS, 16);
-    static constexpr int NSP = 16 * OUT_CB;                        // padded state row in the exchange buffer
-    // flat dynamics layout of one head: W0 b0 W1 b1 W2 b2
-    static constexpr int dW0 = 0, db0 = NIN * DH, dW1 = db0 + DH, db1 = dW1 + DH * DH, dW2 = db1 + DH,
-                         db2 = dW2 + DH * NS, PD = db2 + NS;
-    // flat policy layout (rllab order): W0 b0 W1 b1 Wout bout log_std
-    static constexpr int pW0 = 0, pb0 = NS * PH, pW1 = pb0 + PH, pb1 = pW1 + PH * PH, pW2 = pb1 + PH,
-                         pb2 = pW2 + PH * NA, pLS = pb2 + NA;
-    // per-wave LDS (floats): ST | NX | ACT | dyn biases (3 x padded) | policy biases (3 x padded)
-    static constexpr int BD = 16 * DH_CB, BP = 16 * PH_CB;
-    static constexpr int W_ST = 0, W_NX = W_ST + 16 * NS, W_ACT = W_NX + 16 * NS, W_BD0 = ((W_ACT + 16 * NA + 3) / 4) * 4,
-                         W_BD1 = W_BD0 + BD, W_BD2 = W_BD1 + BD, W_BP0 = W_BD2 + NSP, W_BP1 = W_BP0 + BP,
-                         W_BP2 = W_BP1 + BP, W_TOTAL = W_BP2 + 16;
-};
-
-__device__ __forceinline__ void wave_lds_sync() {
-    // LDS operations of one wave complete in issue order; this only stops the compiler from moving
-    // LDS accesses of different lanes across the point.
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ float xor_sum(float v) {      // sum over the 4 lanes (e, q=0..3) of one env
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
-}
+#include "mfma_common.h"
+#include <cstdlib>
 
 template <int ENV, int DH, int PH>
 __global__ void __launch_bounds__(512) k_rollout_mfma(RolloutK r, int K, const float* __restrict__ dynp,
@@ -443,7 +399,9 @@ int launch_rollout_mfma(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
     r.model_idx = a->d_model_idx; r.sel_noise = a->d_sel_noise; r.reset_idx = a->d_reset_idx;
     r.reset_model = a->d_reset_model; r.obs = a->d_obs; r.act = a->d_act; r.rew = a->d_rew; r.mean = a->d_mean;
     r.done = a->d_done; r.tpath = a->d_tpath; r.last_obs = a->d_last_obs;
-    const size_t sh = sizeof(float) * ((size_t)K * en.w_total + 2 * (size_t)K * 16 * en.nsp);
+    if (c->coop_cfg >= 0 && c->rollout_variant == 0) return launch_rollout_coop(c, c->coop_cfg, r, st);
+    size_t sh = sizeof(float) * ((size_t)K * en.w_total + 2 * (size_t)K * 16 * en.nsp);
+    if (const char* ex = getenv("METRPO_EXTRA_LDS")) sh += (size_t)atoi(ex);          // occupancy experiments only
     const int grid = (a->B + 15) / 16;
     hipLaunchKernelGGL(en.kern, dim3(grid), dim3(K * 64), sh, st, r, K, c->d_dyn, c->d_theta, c->d_norm);
     HIP_TRY(c, hipGetLastError());

@@ -77,6 +77,11 @@ class Engine(object):
             lib.metrpo_destroy(ctx)
             self._ctx = None
 
+    def set_rollout_variant(self, v):
+        """Test hook: 0 = fastest rollout kernel available, 1 = head-per-wave MFMA kernel.  Returns the variant that
+        will run: 2 cooperative-heads MFMA, 1 head-per-wave MFMA, 0 generic."""
+        return int(lib.metrpo_set_rollout_variant(self._ctx, int(v)))
+
     def set_update_path(self, use_mfma):
         """Test hook: False forces the generic (VALU) policy-update kernels; returns True if MFMA kernels are active."""
         return bool(lib.metrpo_set_update_path(self._ctx, int(bool(use_mfma))))

@@ -97,16 +97,20 @@ def test_policy_actions_parity():
     assert torch.equal(a2, m2) and torch.equal(m2, m)
 
 
-@pytest.mark.parametrize('force_generic', [True, False])
+@pytest.mark.parametrize('variant', ['generic', 'head_per_wave', 'coop'])
 @pytest.mark.parametrize('env,sam_mode,determ', [('swimmer', 'step_rand', False), ('swimmer', 'eps_rand', True),
                                                  ('ant', 'step_rand', False), ('swimmer', 'model_mean_std', False),
                                                  ('half_cheetah', 'model_med', False), ('snake', 'model_mean', False),
                                                  ('hopper', 'one_model', False)])
-def test_rollout_parity_teacher_forced(env, sam_mode, determ, force_generic):
+def test_rollout_parity_teacher_forced(env, sam_mode, determ, variant):
     """Fused rollout vs oracle with supplied draws.  Free-running for the discrete structure (dones,
     tpath, resets), teacher-forced (oracle fed the device's own observations) for the per-step values."""
     K, B, T, H = 5, 200, 12, 5
     eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (64, 64), (32, 32), seed=7)
+    force_generic = variant == 'generic'
+    running = eng.set_rollout_variant(1 if variant == 'head_per_wave' else 0)
+    if not force_generic:
+        assert running == (1 if variant == 'head_per_wave' else 2)
     if env == 'ant':
         pool[::3, 2] = 0.21; dm.diff_mean[2] = -0.02
         eng.set_dynamics_layers(dm.Ws, dm.bs, dm.in_mean, dm.in_std, dm.diff_mean, dm.diff_std)
