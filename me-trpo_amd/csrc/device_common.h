@@ -5,14 +5,11 @@
 #define LOG_MIN_STD (-13.815510557964274f)   // log(1e-6): [rllab] GaussianMLPPolicy(min_std=1e-6)
 #define KL_EPS 1e-8f                         // [rllab] DiagonalGaussian.kl_sym denominator constant
 
-// tanh in ~12 VALU ops: odd series for |x| < 0.3 (truncation < 6e-8 relative), 1 - 2/(exp(2x)+1) otherwise
-// (v_exp_f32 + v_rcp_f32, absolute error < 3e-7); libm's tanhf costs ~40 and sat on the rollout's critical path.
+// tanh(x) = 1 - 2 / (1 + exp(2x)) in 5 VALU ops (v_mul, v_exp_f32, v_add, v_rcp_f32, v_fma): absolute error
+// <= ~2e-7 everywhere (exact saturation to +-1); libm's tanhf costs ~40 ops and sat on every kernel's critical path.
 __device__ __forceinline__ float tanh_fast(float x) {
-    const float x2 = x * x;
-    const float p = x * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 0.0218694885f, -0.0539682540f), 0.1333333333f), -0.3333333333f), 1.0f);
-    const float e = __expf(2.0f * x);
-    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-    return (fabsf(x) < 0.3f) ? p : t;
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);          // exp(2x) = 2^(2x log2 e)
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
 }
 
 __device__ __forceinline__ float act_apply(int act, float x) {
@@ -25,9 +22,11 @@ __device__ __forceinline__ float act_apply(int act, float x) {
 // Philox4x32-10 counter RNG (production draws; parity tests supply the draws explicitly).
 // counter = (env index lo, env index hi, t, purpose<<16 | chunk), key = seed.
 // ---------------------------------------------------------------------------------------------
-// RNG_STEP: one block per (env, t): .x = step_rand model index of step t, .y = pool row and .z = cur_model_idx of the
-// reset that follows step t.  RNG_RESET: the initial reset (.x row, .y cur_model_idx).
-enum { RNG_EPS = 0, RNG_STEP = 1, RNG_SELNOISE = 2, RNG_RESET = 3 };
+// RNG_STEP, chunk c of (env, t): .x,.y -> Box-Muller pair = policy noise of action dims 2c, 2c+1.  Chunk 0 also carries
+//   .z -> step_rand model index of step t (high bits) and cur_model_idx of the reset following step t (low 16 bits),
+//   .w -> pool row of that reset.   => the common case (na <= 2) costs ONE Philox block per env-step.
+// RNG_SELNOISE, chunk c: 4 normals = model_mean_std noise of state dims 4c..4c+3.  RNG_RESET: initial reset (.x row, .y model).
+enum { RNG_STEP = 1, RNG_SELNOISE = 2, RNG_RESET = 3 };
 
 __device__ __forceinline__ uint4 philox4x32(uint4 ctr, uint2 key) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
@@ -59,7 +58,17 @@ __device__ __forceinline__ void normal4(uint4 r, float out[4]) {
     out[0] = r0 * c0; out[1] = r0 * s0; out[2] = r1 * c1; out[3] = r1 * s1;
 }
 
+__device__ __forceinline__ void normal2(uint32_t a, uint32_t b, float& n0, float& n1) {
+    const float S = 2.3283064365386963e-10f;
+    const float u0 = ((float)a + 0.5f) * S, u1 = ((float)b + 0.5f) * S;
+    const float rad = sqrtf(-2.0f * __logf(u0));
+    float sn, cs;
+    __sincosf(6.283185307179586f * u1, &sn, &cs);
+    n0 = rad * cs; n1 = rad * sn;
+}
+
 __device__ __forceinline__ int rng_index(uint32_t r, int n) { return (int)(((uint64_t)r * (uint64_t)n) >> 32); }
+__device__ __forceinline__ int rng_index16(uint32_t r, int n) { return (int)(((r & 0xFFFFu) * (uint32_t)n) >> 16); }   // n <= 65535
 
 // ---------------------------------------------------------------------------------------------
 // "Column" layout: one thread = one env/sample; activation u of thread tid lives at buf[u*LD + tid]

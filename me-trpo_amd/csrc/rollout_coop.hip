@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
         else if (i < C::NIN) { f = NS + (i - (NS - C::NDROP)); nsrc[s] = -(i - (NS - C::NDROP)) - 1; }
         else { nsrc[s] = -1000000; }
         nmean[s] = (i < C::NIN) ? norm[f] : 0.0f;
-        nstd[s] = (i < C::NIN) ? norm[(NS + NA) + f] : 1.0f;
+        nstd[s] = (i < C::NIN) ? 1.0f / norm[(NS + NA) + f] : 1.0f;   // reciprocal: (x - mean) * (1/std), <= 1 ulp from the division
     }
     f32x4 dmean[OUT_CB], dstd[OUT_CB];
 #pragma unroll
@@ -147,8 +147,13 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
             m1 = MFMA16(pw2[(kk + 1) * 64], p1[(kk + 1) >> 2][(kk + 1) & 3], m1);
         }
         const f32x4 mu = m0 + m1;
+        const uint4 dstep = rng_draw(r.seed, genv, t, RNG_STEP, 0);
         float z[4] = {0.f, 0.f, 0.f, 0.f};
-        if (!r.determ && r.eps == nullptr) normal4(rng_draw(r.seed, genv, t, RNG_EPS, q), z);
+        if (!r.determ && r.eps == nullptr) {            // lane q owns action dims 4q..4q+3 = chunks 2q, 2q+1 (chunk 0 = dstep)
+            const uint4 b0k = (q == 0) ? dstep : ((NA > 4) ? rng_draw(r.seed, genv, t, RNG_STEP, 2 * q) : dstep);
+            normal2(b0k.x, b0k.y, z[0], z[1]);
+            if (NA > 2) { const uint4 b1k = rng_draw(r.seed, genv, t, RNG_STEP, 2 * q + 1); normal2(b1k.x, b1k.y, z[2], z[3]); }
+        }
         float su2 = 0.0f;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
@@ -175,7 +180,7 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
                 float x = 0.0f;
                 if (nsrc[s] >= 0) x = ST[e * NS + nsrc[s]];
                 else if (nsrc[s] > -1000000) x = ACT[e * NA + (-nsrc[s] - 1)];
-                xin[s] = (nsrc[s] > -1000000) ? (x - nmean[s]) / nstd[s] : 0.0f;          // training.py:228
+                xin[s] = (nsrc[s] > -1000000) ? (x - nmean[s]) * nstd[s] : 0.0f;          // training.py:228
             }
             f32x4 h0[K];
 #pragma unroll
@@ -231,8 +236,7 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
         // ---- selection (env_helpers.py:617-634): out_k = b2_k + sum_w partial ; next = dmean + dstd*out + s ----
         ts += 1;
         int sel = cur_model;
-        const uint4 dstep = rng_draw(r.seed, genv, t, RNG_STEP, 0);
-        if (r.sam_mode == METRPO_SAM_STEP_RAND) sel = (r.model_idx != nullptr) ? (active ? r.model_idx[tb] : 0) : rng_index(dstep.x, K);
+        if (r.sam_mode == METRPO_SAM_STEP_RAND) sel = (r.model_idx != nullptr) ? (active ? r.model_idx[tb] : 0) : rng_index(dstep.z, K);
         if (r.sam_mode == METRPO_SAM_ONE_MODEL) sel = 0;
         const bool simple = (r.sam_mode == METRPO_SAM_STEP_RAND || r.sam_mode == METRPO_SAM_EPS_RAND || r.sam_mode == METRPO_SAM_ONE_MODEL);
         f32x4 nx[OUT_CB];
@@ -321,8 +325,8 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
         if (dn) {
             if (active) {
                 const size_t rb = (size_t)(t + 1) * r.B + b;
-                row = (r.reset_idx != nullptr) ? r.reset_idx[rb] : rng_index(dstep.y, r.n_pool);
-                cur_model = (r.reset_model != nullptr) ? r.reset_model[rb] : rng_index(dstep.z, K);
+                row = (r.reset_idx != nullptr) ? r.reset_idx[rb] : rng_index(dstep.w, r.n_pool);
+                cur_model = (r.reset_model != nullptr) ? r.reset_model[rb] : rng_index16(dstep.z, K);
             }
             ts = 0;
         }

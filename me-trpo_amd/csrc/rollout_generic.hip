@@ -187,10 +187,14 @@ __global__ void k_rollout_generic(ProblemDesc pd, RolloutK r, const float* __res
         const size_t tb = (size_t)t * r.B + b;
         // ---- policy.get_actions(obses) -------------------------------------------------------
         float* m = mlp_col(pd.pol, theta, e.S, e.A, e.Bq, LD, tid);
-        for (int d0 = 0; d0 < na; d0 += 4) {
-            float z[4] = {0.f, 0.f, 0.f, 0.f};
-            if (!r.determ && r.eps == nullptr) normal4(rng_draw(r.seed, genv, t, RNG_EPS, d0 >> 2), z);
-            for (int d = d0; d < min(d0 + 4, na); ++d) {
+        const uint4 dstep = rng_draw(r.seed, genv, t, RNG_STEP, 0);
+        for (int d0 = 0; d0 < na; d0 += 2) {
+            float z[2] = {0.f, 0.f};
+            if (!r.determ && r.eps == nullptr) {
+                const uint4 blk = (d0 == 0) ? dstep : rng_draw(r.seed, genv, t, RNG_STEP, d0 >> 1);
+                normal2(blk.x, blk.y, z[0], z[1]);
+            }
+            for (int d = d0; d < min(d0 + 2, na); ++d) {
                 const float mu = m[d * LD + tid];
                 float a = mu;
                 if (!r.determ) {
@@ -204,9 +208,8 @@ __global__ void k_rollout_generic(ProblemDesc pd, RolloutK r, const float* __res
         // ---- vec_env.step(actions) -----------------------------------------------------------
         ts += 1;
         int sel = cur_model;
-        const uint4 dstep = rng_draw(r.seed, genv, t, RNG_STEP, 0);
         if (r.sam_mode == METRPO_SAM_STEP_RAND)
-            sel = (r.model_idx != nullptr) ? (active ? r.model_idx[tb] : 0) : rng_index(dstep.x, K);
+            sel = (r.model_idx != nullptr) ? (active ? r.model_idx[tb] : 0) : rng_index(dstep.z, K);
         float* noise_col = e.NEXT;
         if (r.sam_mode == METRPO_SAM_MODEL_MEAN_STD) {
             for (int i0 = 0; i0 < ns; i0 += 4) {
@@ -227,8 +230,8 @@ __global__ void k_rollout_generic(ProblemDesc pd, RolloutK r, const float* __res
             int row = 0;
             if (active) {
                 const size_t rb = (size_t)(t + 1) * r.B + b;
-                row = (r.reset_idx != nullptr) ? r.reset_idx[rb] : rng_index(dstep.y, r.n_pool);
-                cur_model = (r.reset_model != nullptr) ? r.reset_model[rb] : rng_index(dstep.z, K);
+                row = (r.reset_idx != nullptr) ? r.reset_idx[rb] : rng_index(dstep.w, r.n_pool);
+                cur_model = (r.reset_model != nullptr) ? r.reset_model[rb] : rng_index16(dstep.z, K);
             }
             for (int i = 0; i < ns; ++i) e.S[i * LD + tid] = active ? r.pool[(size_t)row * ns + i] : 0.0f;
             ts = 0;

@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(512) k_rollout_mfma(RolloutK r, int K, const f
         else if (i < C::NIN) { f = NS + (i - (NS - C::NDROP)); nsrc[s] = -(i - (NS - C::NDROP)) - 1; }
         else { nsrc[s] = -1000000; }
         nmean[s] = (i < C::NIN) ? norm[f] : 0.0f;
-        nstd[s] = (i < C::NIN) ? norm[(NS + NA) + f] : 1.0f;
+        nstd[s] = (i < C::NIN) ? 1.0f / norm[(NS + NA) + f] : 1.0f;   // reciprocal: (x - mean) * (1/std), <= 1 ulp from the division
     }
     f32x4 dmean[C::OUT_CB], dstd[C::OUT_CB];
 #pragma unroll
@@ -172,8 +172,13 @@ __global__ void __launch_bounds__(512) k_rollout_mfma(RolloutK r, int K, const f
             m1 = MFMA16(wp2[kk + 1], p1[(kk + 1) >> 2][(kk + 1) & 3], m1);
         }
         const f32x4 mu = m0 + m1;
+        const uint4 dstep = rng_draw(r.seed, genv, t, RNG_STEP, 0);
         float z[4] = {0.f, 0.f, 0.f, 0.f};
-        if (!r.determ && r.eps == nullptr && 4 * q < NA) normal4(rng_draw(r.seed, genv, t, RNG_EPS, q), z);
+        if (!r.determ && r.eps == nullptr) {            // lane q owns action dims 4q..4q+3 = chunks 2q, 2q+1 (chunk 0 = dstep)
+            const uint4 b0k = (q == 0) ? dstep : ((NA > 4) ? rng_draw(r.seed, genv, t, RNG_STEP, 2 * q) : dstep);
+            normal2(b0k.x, b0k.y, z[0], z[1]);
+            if (NA > 2) { const uint4 b1k = rng_draw(r.seed, genv, t, RNG_STEP, 2 * q + 1); normal2(b1k.x, b1k.y, z[2], z[3]); }
+        }
         float su2 = 0.0f;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
@@ -201,7 +206,7 @@ __global__ void __launch_bounds__(512) k_rollout_mfma(RolloutK r, int K, const f
             float x = 0.0f;
             if (nsrc[s] >= 0) x = ST[e * NS + nsrc[s]];
             else if (nsrc[s] > -1000000) x = ACT[e * NA + (-nsrc[s] - 1)];
-            x = (nsrc[s] > -1000000) ? (x - nmean[s]) / nstd[s] : 0.0f;      // (xgu - in_mean)/in_std, training.py:228
+            x = (nsrc[s] > -1000000) ? (x - nmean[s]) * nstd[s] : 0.0f;      // (xgu - in_mean)/in_std, training.py:228
 #pragma unroll
             for (int cb = 0; cb < C::DH_CB; ++cb) h0[cb] = MFMA16(wd0[s][cb], x, h0[cb]);
         }
@@ -246,9 +251,8 @@ __global__ void __launch_bounds__(512) k_rollout_mfma(RolloutK r, int K, const f
         // ---- get_next_observation selection (env_helpers.py:617-634), redundantly in every wave -----
         ts += 1;
         int sel = cur_model;
-        const uint4 dstep = rng_draw(r.seed, genv, t, RNG_STEP, 0);
         if (r.sam_mode == METRPO_SAM_STEP_RAND)
-            sel = (r.model_idx != nullptr) ? (active ? r.model_idx[tb] : 0) : rng_index(dstep.x, K);
+            sel = (r.model_idx != nullptr) ? (active ? r.model_idx[tb] : 0) : rng_index(dstep.z, K);
         if (r.sam_mode == METRPO_SAM_ONE_MODEL) sel = 0;
         const float* nxt_all = NXT + (size_t)par * K * 16 * NSP;
         f32x4 nx[C::OUT_CB];
@@ -328,8 +332,8 @@ __global__ void __launch_bounds__(512) k_rollout_mfma(RolloutK r, int K, const f
         if (dn) {
             if (active) {
                 const size_t rb = (size_t)(t + 1) * r.B + b;
-                row = (r.reset_idx != nullptr) ? r.reset_idx[rb] : rng_index(dstep.y, r.n_pool);
-                cur_model = (r.reset_model != nullptr) ? r.reset_model[rb] : rng_index(dstep.z, K);
+                row = (r.reset_idx != nullptr) ? r.reset_idx[rb] : rng_index(dstep.w, r.n_pool);
+                cur_model = (r.reset_model != nullptr) ? r.reset_model[rb] : rng_index16(dstep.z, K);
             }
             ts = 0;
         }

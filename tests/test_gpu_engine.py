@@ -182,6 +182,24 @@ def test_rollout_philox_statistics():
     assert np.array_equal(cpu(big.act)[:, B:], cpu(hi.act))
 
 
+@pytest.mark.parametrize('env', ['swimmer', 'half_cheetah', 'hopper'])
+def test_rollout_variants_share_rng_stream(env):
+    """Production (Philox) mode: the three rollout kernels consume the same counter-based stream, so the same seed
+    gives the same trajectory up to fp32 rounding, whichever kernel runs."""
+    K, B, T, H = 5, 300, 6, 3
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (64, 64), (32, 32), seed=17)
+    ref = eng.rollout(B, T, H, 'step_rand', pool, seed=99, force_generic=True)
+    for variant in (1, 0):
+        eng.set_rollout_variant(variant)
+        got = eng.rollout(B, T, H, 'step_rand', pool, seed=99)
+        np.testing.assert_allclose(cpu(got.act), cpu(ref.act), rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(cpu(got.obs), cpu(ref.obs), rtol=1e-4, atol=2e-5)
+        assert torch.equal(got.done, ref.done) and torch.equal(got.tpath, ref.tpath)
+    # the reset rows / models drawn at t = H differ per env and are valid pool rows
+    rows = {r.tobytes() for r in pool.astype(np.float32)}
+    assert all(r.tobytes() in rows for r in cpu(ref.obs)[H].astype(np.float32)[:32])
+
+
 @pytest.mark.parametrize('gamma,lam,use_coeffs', [(1.0, 1.0, False), (0.99, 0.95, True), (0.99, 1.0, True)])
 def test_gae_center_gram_parity(gamma, lam, use_coeffs):
     env, K, B, T, H = 'ant', 4, 96, 23, 6
