@@ -1,7 +1,7 @@
 // Policy-side kernels of the NPO/TRPO update (algos/npo.py:68-111; [rllab] ConjugateGradientOptimizer,
 // PerlmutterHvp, DiagonalGaussian):
 //   k_loss_grad  -- surrogate loss + flat gradient          (f_loss / f_grad)
-//   k_fvp        -- Hessian(mean_kl) . v  (Gauss-Newton form, exact at theta_old; see oracle docstring)
+//   k_fvp        -- Hessian(mean_kl) . v  (Gauss-Newton form, exact at theta_old; derivation in DESIGN.md)
 //   k_loss_kl    -- surrogate loss + mean KL at a trial theta (f_loss_constraint)
 //   k_finalize   -- fixed-order (deterministic) float64 reduction of the per-block partial rows
 //

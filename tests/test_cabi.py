@@ -1,0 +1,74 @@
+"""CPU-side checks of the drop-in boundary: libmetrpo.so loads and exports every symbol declared in
+include/metrpo.h, the ctypes struct layouts match the header, and argument errors come back as status
+codes (no GPU needed: these calls fail before touching the device)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(REPO, 'include', 'metrpo.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(metrpo_[a-z_0-9]+)\s*\(', src)) - {'metrpo_allreduce_fn'})
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    import metrpo_amd
+    from metrpo_amd import _lib
+    names = header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(_lib.lib, n), "libmetrpo.so does not export %s" % n
+        assert n in _lib.SYMBOLS, "%s is declared in metrpo.h but not bound in _lib.SYMBOLS" % n
+    assert set(_lib.SYMBOLS) == set(names)
+    assert _lib.lib.metrpo_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    from metrpo_amd import _lib
+    # sizes implied by the C declarations (LP64): see include/metrpo.h
+    assert C.sizeof(_lib.Dims) == 4 * (4 + 1 + 6 + 6 + 1 + 1 + 6)
+    assert C.sizeof(_lib.RolloutArgs) == 6 * 4 + 8 + 4 + 4 + 8 + 8 + 5 * 8 + 7 * 8
+    assert C.sizeof(_lib.Batch) == 5 * 8 + 4 + 4 + 8 + 8 + 8
+    assert C.sizeof(_lib.TrpoParams) == 8 + 4 + 4 + 8 + 8 + 4 + 4 + 8 + 8 + 8
+    assert C.sizeof(_lib.TrpoDiag) == 4 * 8 + 3 * 4 + 4
+    assert _lib.RolloutArgs.d_pool.offset == 24 and _lib.RolloutArgs.seed.offset == 40
+
+
+def test_status_codes_without_gpu():
+    from metrpo_amd import _lib
+    lib = _lib.lib
+    assert lib.metrpo_status_string(0) == b'ok'
+    assert lib.metrpo_create(None, 0, None) == -2                      # METRPO_ENULL
+    ctx = C.c_void_p()
+    d = _lib.Dims()
+    d.env, d.ns, d.na, d.n_models = 0, 10, 2, 0                         # K = 0
+    assert lib.metrpo_create(C.byref(ctx), 0, C.byref(d)) == -1         # METRPO_EINVAL
+    d.n_models, d.env = 5, 9                                            # unknown env
+    assert lib.metrpo_create(C.byref(ctx), 0, C.byref(d)) == -1
+    d.env, d.ns = 2, 10                                                 # ant reward needs x[15]
+    assert lib.metrpo_create(C.byref(ctx), 0, C.byref(d)) == -1
+    assert lib.metrpo_destroy(None) == -2
+    assert lib.metrpo_step(None, None, None, 0, 0, None, None, None, None, None, None, None) == -2
+
+
+def test_no_cpu_fallback():
+    import torch
+    import metrpo_amd
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        metrpo_amd.Engine('swimmer', 5, (64, 64), (32, 32))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(REPO, 'me-trpo_amd')
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                txt = open(os.path.join(root, f)).read()
+                assert not re.search(r'(import|from)\s+oracle|oracle\.|oracle/', txt), "%s references the oracle" % f

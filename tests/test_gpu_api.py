@@ -1,0 +1,149 @@
+"""GPU tests of the drop-in host interface (NeuralNetEnv / VecSimpleEnv / GaussianMLPPolicy /
+VectorizedSampler / TRPO / early stopping) against the oracle's restatement of the reference."""
+import numpy as np
+import pytest
+import torch
+from oracle import metrpo_oracle as O
+import helpers as Hh
+
+pytestmark = pytest.mark.gpu
+
+
+def cpu(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def build_algo(env='swimmer', K=5, B=64, H=10, batch=None, sam_mode='step_rand', seed=0, gamma=0.99, lam=0.95):
+    import metrpo_amd
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (64, 64), (32, 32), seed=seed)
+    policy = metrpo_amd.GaussianMLPPolicy(eng, init_std=1.0, seed=seed)
+    eng.set_policy(theta)
+    init = metrpo_amd.InitStatePool(pool, dm.na)
+    nne = metrpo_amd.NeuralNetEnv(env=init, inner_env=None, cost_np=env, dynamics_in=None, dynamics_outs=eng, sam_mode=sam_mode)
+    algo = metrpo_amd.TRPO(env=nne, policy=policy, baseline=metrpo_amd.LinearFeatureBaseline(), batch_size=batch or B * H,
+                           max_path_length=H, discount=gamma, gae_lambda=lam, step_size=0.01, sampler_args=dict(n_envs=B))
+    return algo, eng, dm, theta, pdims, pool
+
+
+def test_vec_env_step_api_matches_reference_restatement():
+    """VecSimpleEnv.reset/step with the reference's own np.random call pattern: seeding np.random identically
+    for the device env and the oracle env must give the same trajectory (fp32 vs fp64 tolerance)."""
+    import metrpo_amd
+    for env, sam_mode in (('swimmer', 'step_rand'), ('ant', 'eps_rand'), ('swimmer', 'model_mean_std')):
+        K, B, H, T = 4, 12, 4, 9
+        eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (64, 64), (32, 32), seed=41)
+        if env == 'ant':
+            pool[::3, 2] = 0.21; dm.diff_mean[2] = -0.02
+            eng.set_dynamics_layers(dm.Ws, dm.bs, dm.in_mean, dm.in_std, dm.diff_mean, dm.diff_std)
+        pool32 = pool.astype(np.float32).astype(np.float64)
+        actions = np.random.RandomState(1).randn(T, B, dm.na) * 0.8
+        np.random.seed(77)
+        nne = metrpo_amd.NeuralNetEnv(metrpo_amd.InitStatePool(pool32, dm.na), None, env, None, eng, sam_mode)
+        assert nne.vectorized and nne.observation_space.shape == (dm.ns,)
+        ve = nne.vec_env_executor(n_envs=B, max_path_length=H)
+        first = ve.reset()
+        got = [ve.step(actions[t]) for t in range(T)]
+        np.random.seed(77)
+        pr = Hh_pool_reset(pool32)
+        ref_env = O.VecEnvOracle(env, lambda s, a: O.dynamics_forward_all(dm, s, a), K, B, dm.ns, H, sam_mode, pr)
+        ref_first = ref_env.reset()
+        np.testing.assert_allclose(first, ref_first, atol=1e-6)
+        for t in range(T):
+            s, r, d, _ = ref_env.step(actions[t])
+            np.testing.assert_allclose(got[t][0], s, rtol=2e-4, atol=5e-5)
+            np.testing.assert_allclose(got[t][1], r, rtol=2e-4, atol=5e-5)
+            assert np.array_equal(got[t][2], d)
+            assert np.array_equal(ve.ts, ref_env.ts) or t < T - 1
+        assert ve.num_envs == B and got[0][3] == {}
+        ve.terminate()
+
+
+def Hh_pool_reset(pool):
+    from conftest import PoolReset
+    return PoolReset(pool)
+
+
+def test_policy_get_actions_surface():
+    algo, eng, dm, theta, pdims, pool = build_algo()
+    obs = pool[:7]
+    np.random.seed(5)
+    a, info = algo.policy.get_actions(obs)
+    np.random.seed(5)
+    eps = np.random.normal(size=(7, dm.na))
+    ra, rinfo = O.policy_get_actions(theta.astype(np.float32).astype(np.float64), pdims, obs.astype(np.float32).astype(np.float64), eps)
+    np.testing.assert_allclose(a, ra, rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(info['mean'], rinfo['mean'], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(info['log_std'], rinfo['log_std'], atol=1e-6)
+    assert algo.policy.vectorized and not algo.policy.recurrent
+    th = algo.policy.get_param_values()
+    algo.policy.set_param_values(th * 0.5)
+    np.testing.assert_allclose(algo.policy.get_param_values(), (th * 0.5).astype(np.float32), atol=0)
+    algo.policy.reset_log_std()
+    assert np.allclose(algo.policy.get_param_values()[-dm.na:], 0.0)
+
+
+@pytest.mark.parametrize('env,batch', [('swimmer', 640), ('swimmer', 1500), ('ant', 900)])
+def test_sampler_process_samples_pipeline(env, batch):
+    """start_worker / obtain_samples / process_samples vs BaseSampler.process_samples restated by the oracle,
+    through the list-of-paths view of the device trajectory (completion order, whole rounds, dropped tails)."""
+    B, H = 64, 10
+    algo, eng, dm, theta, pdims, pool = build_algo(env, B=B, H=H, batch=batch)
+    if env == 'ant':
+        pool[::3, 2] = 0.21
+        algo.env.env.states[::3, 2] = 0.21; algo.env.env._dev = None
+    prev = np.random.RandomState(3).randn(2 * dm.ns + 4) * 0.05
+    algo.baseline.set_param_values(prev.copy())
+    algo.start_worker()
+    paths = algo.obtain_samples(0)
+    rounds = -(-batch // (B * H))
+    assert paths.traj.T >= rounds * H and paths.traj.T % H == 0
+    plist = paths.to_paths()
+    assert sum(len(p['rewards']) for p in plist) >= batch                 # quirk 6: n_samples counts completed paths
+    if env != 'ant':
+        assert len(plist) == rounds * B and all(len(p['rewards']) == H for p in plist)
+    else:
+        assert len({len(p['rewards']) for p in plist}) > 1
+    samples = algo.process_samples(0, paths)
+    base = O.LinearFeatureBaselineOracle(); base._coeffs = prev.copy()
+    ref = O.process_samples([dict(p) for p in plist], base, algo.discount, algo.gae_lambda, center_adv=True)
+    v = cpu(samples['valids']).astype(bool)
+    assert v.sum() == len(ref['advantages']) == samples['n_valid_global']
+    # same multiset of samples: compare after sorting by (reward, return) -- time-major vs path-major order differ
+    def srt(ret, adv):
+        o = np.lexsort((adv, ret)); return ret[o], adv[o]
+    gr, ga = srt(cpu(samples['returns'])[v], cpu(samples['advantages'])[v])
+    rr, ra = srt(ref['returns'], ref['advantages'])
+    np.testing.assert_allclose(gr, rr, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ga, ra, rtol=1e-4, atol=2e-4)
+    # baseline refit AFTER the advantages were computed (quirk 8)
+    feat_pred = lambda c: np.concatenate([O.LinearFeatureBaselineOracle.features(p) for p in plist]) @ c
+    np.testing.assert_allclose(feat_pred(algo.baseline.coeffs), feat_pred(base._coeffs), rtol=0,
+                               atol=2e-3 * max(1.0, np.abs(feat_pred(base._coeffs)).max()))
+    assert not np.allclose(algo.baseline.coeffs, prev)
+
+
+def test_trpo_iteration_and_early_stopping_loop():
+    import metrpo_amd
+    algo, eng, dm, theta, pdims, pool = build_algo('swimmer', B=256, H=20, gamma=1.0, lam=1.0)
+    th0 = eng.get_policy().clone()
+    for j in range(3):
+        algo.start_worker()
+        paths = algo.obtain_samples(j)
+        samples = algo.process_samples(j, paths)
+        assert algo.optimize_policy(j, samples) == dict()
+        d = algo.optimizer.last_diag
+        assert d['accepted'] and d['kl'] <= 0.01 and d['loss'] < d['loss_before']
+    assert not torch.equal(th0, eng.get_policy())
+    val0 = pool[:128]
+    out = metrpo_amd.early_stop.optimize_policy(algo, val0, T=15, gamma=1.0, mode='estimated', whole=True, log_every=2,
+                                               num_iters_threshold=4, max_iters=8, reset_log_std=True)
+    assert 0 <= out['best_index'] <= out['last_index'] <= 8 and len(out['history']) >= 1
+    assert out['min_validation_costs']['estimated'].shape == (5,)
+    # after the loop the policy is the best snapshot: its validation cost equals the recorded minimum when whole=True
+    final = cpu(eng.validation_cost(val0, 15, 1.0))
+    if out['best_index'] > 0:
+        np.testing.assert_allclose(final, out['min_validation_costs']['estimated'], rtol=1e-5, atol=1e-6)
+    # trpo_mean mode runs the determ=True sampling path (model_based_rl.py:1221)
+    out2 = metrpo_amd.early_stop.optimize_policy(algo, val0, T=15, gamma=1.0, mode='trpo_mean', log_every=1,
+                                                num_iters_threshold=2, max_iters=3, reset_log_std=False)
+    assert out2['last_index'] <= 3
