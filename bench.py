@@ -68,14 +68,9 @@ def main():
     ev_roll = []
 
     def step(j, timed):
+        algo.rollout_events = ev_roll if timed else None      # HIP events recorded around the rollout launch itself
         algo.start_worker()
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
         paths = algo.obtain_samples(j)
-        if timed:
-            e1.record()
-            ev_roll.append((e0, e1))
         samples = algo.process_samples(j, paths)
         algo.optimize_policy(j, samples)
 
@@ -96,6 +91,10 @@ def main():
     flops_launch = K * B * H * f_dyn + B * H * f_pol            # one rollout launch on one GPU
     achieved = flops_launch / (roll_ms * 1e-3) / 1e12
     PEAK_F32 = 157.3                                            # TFLOP/s, dense f32 MFMA = f32 vector peak (MI355X_MICROARCH.md)
+    traffic = None                                              # HBM bytes per launch from rocprofv3 PMC (profiles/, measured offline)
+    tpath = os.path.join(REPO, 'profiles', 'r01_rollout_traffic.json')
+    if args.config == 'C1' and eng.has_mfma_path and os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
     out = {
         "metric": "imagined env-steps/sec (KxBxH) over the full TRPO iteration", "value": units_per_step / (dt / args.steps),
         "unit": "env-steps/s", "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup,
@@ -106,9 +105,10 @@ def main():
                                                                               list(cfg['pol_hidden']), B, H),
                    "parallelism": "B-sharded x%d, sum all-reduce of g/FVP/scalars" % comm.world},
         "trpo_iter_ms": ms_per_step,
-        "rollout": {"ms": roll_ms, "env_steps_per_s": units_per_step / (roll_ms * 1e-3), "kernel": "mfma" if eng.has_mfma_path else "generic"},
+        "rollout": {"ms": roll_ms, "env_steps_per_s": units_per_step / (roll_ms * 1e-3),
+                    "kernel": {2: "mfma-cooperative", 1: "mfma-head-per-wave", 0: "generic"}[eng.set_rollout_variant(0)]},
         "roofline": {"bound": "mfma", "kernel": "rollout", "achieved": achieved, "peak": PEAK_F32, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_F32, "traffic": None,
+                     "frac": achieved / PEAK_F32, "traffic": traffic,
                      "hbm_frac_unfused_88B": (K * B * H * (2 * ns + na) * 4) / (roll_ms * 1e-3) / 8e12},
     }
     if comm.rank == 0 and comm.world == 1 and not args.no_cpu_baseline:

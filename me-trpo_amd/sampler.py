@@ -129,8 +129,15 @@ class VectorizedSampler(BaseSampler):
         seed = (getattr(algo, 'seed', 0) * 1000003 + itr * 7919 + (1 if determ else 0)) & 0xFFFFFFFFFFFFFFFF
         offset = comm.rank * B
         draws = draws or {}
+        ev = getattr(algo, 'rollout_events', None)          # optional [(start, end)] HIP-event pairs around the launch
+        if ev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         traj = eng.rollout(B, T, H, nne.sam_mode, pool, determ=determ, eval_all_heads=getattr(algo, 'eval_all_heads', True),
                            seed=seed, stream_offset=offset, **draws)
+        if ev is not None:
+            e1.record()
+            ev.append((e0, e1))
         if eng.env_name == 'ant' and not draws:
             # keep stepping in chunks of H until the completed-path sample count reaches batch_size
             while True:
