@@ -94,7 +94,7 @@ class ConjugateGradientOptimizer(object):
     def optimize(self, engine_or_evaluator, batch=None, comm=None):
         comm = comm or Comm()
         if self._fused and batch is not None:
-            ar = (lambda t: comm.allreduce_sum_(t)) if comm.world > 1 else None
+            ar = (lambda t: comm.allreduce_sum_(t)) if (comm.world > 1 or comm.always_reduce) else None
             self.last_diag = engine_or_evaluator.trpo_update(
                 batch, max_kl=self._max_constraint_val, cg_iters=self._cg_iters, reg_coeff=self._reg_coeff,
                 backtrack_ratio=self._backtrack_ratio, max_backtracks=self._max_backtracks,

@@ -11,9 +11,10 @@ import torch
 class Comm(object):
     """World of 1 unless torch.distributed is initialised (or init_from_env() is called)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, always_reduce=False):
         self.dist = torch.distributed if (torch.distributed.is_available() and torch.distributed.is_initialized()) else None
         self.group = group
+        self.always_reduce = always_reduce and self.dist is not None      # exercise the collective even at world size 1 (tests)
         self.rank = self.dist.get_rank(group) if self.dist else 0
         self.world = self.dist.get_world_size(group) if self.dist else 1
 
@@ -32,7 +33,7 @@ class Comm(object):
 
     def allreduce_sum_(self, t):
         """In-place sum over ranks; stream-ordered with the caller's current stream (torch semantics)."""
-        if self.world > 1:
+        if self.world > 1 or self.always_reduce:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t
 

@@ -147,3 +147,39 @@ def test_trpo_iteration_and_early_stopping_loop():
     out2 = metrpo_amd.early_stop.optimize_policy(algo, val0, T=15, gamma=1.0, mode='trpo_mean', log_every=1,
                                                 num_iters_threshold=2, max_iters=3, reset_log_std=False)
     assert out2['last_index'] <= 3
+
+
+def test_allreduce_callback_through_rccl_world1():
+    """The fused C driver calls back into Python for every all-reduce; here the callback runs a REAL RCCL all-reduce
+    (process group of size 1) on a zero-copy view of the library-owned float64 buffers.  Result must be bitwise equal
+    to the run without the callback."""
+    import os, socket
+    import torch.distributed as dist
+    import metrpo_amd
+    from test_gpu_engine import _update_problem
+    eng, th, pdims, obs, act, adv, om, ols = _update_problem(N=4000, seed=33)
+    batch = eng.make_batch(obs, act, adv, om, ols)
+    theta0 = eng.get_policy().clone()
+    ref = eng.trpo_update(batch, want_vectors=True)
+    theta_ref = eng.get_policy().clone()
+    eng.set_policy(theta0)
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        comm = metrpo_amd.Comm(always_reduce=True)
+        calls = []
+        def ar(t):
+            assert t.dtype == torch.float64 and t.is_cuda and t.numel() in (eng.P + 1, eng.P, 2)
+            calls.append(t.numel())
+            comm.allreduce_sum_(t)
+        out = eng.trpo_update(batch, allreduce=ar, want_vectors=True)
+        torch.cuda.synchronize()
+        assert calls[0] == eng.P + 1 and calls.count(eng.P) == 11 and calls[-1] == 2
+        assert torch.equal(eng.get_policy(), theta_ref)
+        assert torch.equal(out['g'], ref['g']) and torch.equal(out['d'], ref['d'])
+        # the object-level path: sampler statistics + optimizer through Comm
+        stats = torch.ones(3, dtype=torch.float64, device='cuda')
+        assert torch.equal(comm.allreduce_sum_(stats), torch.ones(3, dtype=torch.float64, device='cuda'))
+    finally:
+        dist.destroy_process_group()
