@@ -63,7 +63,8 @@ def main():
                                   sam_mode='step_rand')
     algo = metrpo_amd.TRPO(env=nne, policy=policy, baseline=baseline, batch_size=B * H, max_path_length=H,
                            discount=1.0, step_size=0.01, sampler_args=dict(n_envs=B), comm=comm, seed=0)
-    algo.defer_baseline_fit = True            # solve the 24x24 baseline system after the update's own sync
+    algo.defer_baseline_fit = True            # host solve of the 24x24 baseline system overlaps the next rollout
+    algo.reuse_trajectory_buffers = True      # one set of [T,B,.] tensors, overwritten every iteration
 
     ev_roll = []
 

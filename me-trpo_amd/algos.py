@@ -79,7 +79,7 @@ class NPO(BatchPolopt):
                                        agent_infos["mean"], agent_infos["log_std"], valid=samples_data.get("valids"),
                                        n_global=samples_data.get("n_valid_global"))
         self.optimizer.optimize(self.engine, batch, comm=self.comm)
-        if hasattr(self.sampler, 'finish_baseline_fit'):
+        if hasattr(self.sampler, 'finish_baseline_fit') and not getattr(self, 'defer_baseline_fit', False):
             self.sampler.finish_baseline_fit()
         return dict()
 

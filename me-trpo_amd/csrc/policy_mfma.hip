@@ -32,34 +32,57 @@ __device__ __forceinline__ float xsum_c(float v) {
 
 enum { MODE_GRAD = 0, MODE_FVP = 1, MODE_LOSSKL = 2 };
 
+// LDS weight image, shared by the 4 waves of a block (filled once per block).  Tables with a col-block index store the HB
+// col-block fragments of one k-step adjacently per lane, so one ds_read_b64 (HB = 2) feeds both MFMAs of that k-step.
+template <int NS, int NA, int PH>
+struct PolImg {
+    static constexpr int NS_KS = cdiv_(NS, 4), HB = cdiv_(PH, 16), KK = HB * 4;
+    // offsets in floats; [rows][64 lanes][HB] tables first, then [rows][64] tables
+    static constexpr int O_W0F = 0, O_W1F = O_W0F + NS_KS * 64 * HB, O_V0F = O_W1F + KK * 64 * HB, O_V1F = O_V0F + NS_KS * 64 * HB,
+                         O_W2B = O_V1F + KK * 64 * HB, O_W1B = O_W2B + 4 * 64 * HB, O_W2F = O_W1B + KK * 64 * HB,
+                         O_V2F = O_W2F + KK * 64, TOTAL = O_V2F + KK * 64;
+};
+
 template <int NS, int NA, int PH, int MODE>
-__global__ void __launch_bounds__(256, 2) k_policy_mfma(PolK k, const float* __restrict__ theta, const float* __restrict__ v,
-                                                     float* __restrict__ partials) {
-    constexpr int NS_KS = cdiv_(NS, 4), NSI = cdiv_(NS, 16), HB = cdiv_(PH, 16), KK = HB * 4;
+__global__ void __launch_bounds__(256, 3) k_policy_mfma(PolK k, const float* __restrict__ theta, const float* __restrict__ v,
+                                                        float* __restrict__ partials) {
+    using I = PolImg<NS, NA, PH>;
+    constexpr int NS_KS = I::NS_KS, NSI = cdiv_(NS, 16), HB = I::HB, KK = I::KK;
     constexpr int pW0 = 0, pb0 = NS * PH, pW1 = pb0 + PH, pb1 = pW1 + PH * PH, pW2 = pb1 + PH, pb2 = pW2 + PH * NA,
                   pLS = pb2 + NA, P = pLS + NA, ROW = P + PART_EXTRA;
-    constexpr int TS = 17;                                  // transpose-tile row stride (floats)
-    constexpr int TILE = 16 * TS;
-    constexpr int WTL = (4 * HB + 1) * TILE;                // per-wave: h0,h1,d1,d0 (HB blocks each) + u
+    constexpr int TS = 17, TILE = 16 * TS;                  // transpose tile: 16 rows, stride 17 floats (conflict free)
+    constexpr int WTL = 2 * HB * TILE;                      // per-wave transpose scratch, reused by the three weight-gradient phases
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
-    float* TL = lds + wave * WTL;
-    float* T_h0 = TL, *T_h1 = TL + HB * TILE, *T_d1 = TL + 2 * HB * TILE, *T_d0 = TL + 3 * HB * TILE, *T_u = TL + 4 * HB * TILE;
+    float* IMG = lds;
+    float* TL = lds + I::TOTAL + wave * WTL;
 
-    // ---------------- weight fragments (registers) -----------------------------------------------
-    float W0f[NS_KS][HB], W1f[KK][HB], W2f[KK];
-#pragma unroll
-    for (int s = 0; s < NS_KS; ++s)
-#pragma unroll
-        for (int cb = 0; cb < HB; ++cb) { const int i = 4 * s + q, o = 16 * cb + c; W0f[s][cb] = (i < NS && o < PH) ? theta[pW0 + i * PH + o] : 0.f; }
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-        const int i = 16 * (kk >> 2) + 4 * q + (kk & 3);
-#pragma unroll
-        for (int cb = 0; cb < HB; ++cb) { const int o = 16 * cb + c; W1f[kk][cb] = (i < PH && o < PH) ? theta[pW1 + i * PH + o] : 0.f; }
-        W2f[kk] = (i < PH && c < NA) ? theta[pW2 + i * NA + c] : 0.f;
+    // ---------------- weight fragment image -> LDS (each element written by exactly one thread) ----------------
+    for (int i = tid; i < I::TOTAL; i += 256) {
+        float w = 0.f;
+        if (i < I::O_W2F) {                                  // [row][lane][cb] tables
+            int t, base;
+            if (i < I::O_W1F) { t = 0; base = I::O_W0F; } else if (i < I::O_V0F) { t = 1; base = I::O_W1F; }
+            else if (i < I::O_V1F) { t = 2; base = I::O_V0F; } else if (i < I::O_W2B) { t = 3; base = I::O_V1F; }
+            else if (i < I::O_W1B) { t = 4; base = I::O_W2B; } else { t = 5; base = I::O_W1B; }
+            const int j = i - base, cb = j % HB, ln = (j / HB) & 63, row = j / (HB * 64), cc = ln & 15, qq = ln >> 4;
+            const float* __restrict__ src = (t == 2 || t == 3) ? v : theta;
+            if (t == 0 || t == 2) { const int in = 4 * row + qq, o = 16 * cb + cc; if (in < NS && o < PH && (MODE == MODE_FVP || t == 0)) w = src[pW0 + in * PH + o]; }
+            else if (t == 1 || t == 3) { const int in = 16 * (row >> 2) + 4 * qq + (row & 3), o = 16 * cb + cc; if (in < PH && o < PH && (MODE == MODE_FVP || t == 1)) w = src[pW1 + in * PH + o]; }
+            else if (t == 4) { const int ii = 16 * cb + cc, d = 4 * qq + row; if (ii < PH && d < NA && MODE != MODE_LOSSKL) w = theta[pW2 + ii * NA + d]; }
+            else { const int ii = 16 * cb + cc, jj = 16 * (row >> 2) + 4 * qq + (row & 3); if (ii < PH && jj < PH && MODE != MODE_LOSSKL) w = theta[pW1 + ii * PH + jj]; }
+        } else {                                             // [row][lane] tables: W2f, V2f
+            const bool isv = i >= I::O_V2F;
+            const int j = i - (isv ? I::O_V2F : I::O_W2F), ln = j & 63, row = j >> 6, cc = ln & 15, qq = ln >> 4;
+            const int in = 16 * (row >> 2) + 4 * qq + (row & 3);
+            if (in < PH && cc < NA && (!isv || MODE == MODE_FVP)) w = (isv ? v : theta)[pW2 + in * NA + cc];
+        }
+        IMG[i] = w;
     }
+    // fragment accessors (this lane's element)
+#define FRAG2(off, row, cb) IMG[(off) + ((row) * 64 + lane) * HB + (cb)]
+#define FRAG1(off, row) IMG[(off) + (row) * 64 + lane]
     f32x4 b0f[HB], b1f[HB], b2f;
 #pragma unroll
     for (int cb = 0; cb < HB; ++cb)
@@ -70,22 +93,8 @@ __global__ void __launch_bounds__(256, 2) k_policy_mfma(PolK k, const float* __r
     float ls[4], inv_std[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { ls[r] = (4 * q + r < NA) ? fmaxf(theta[pLS + 4 * q + r], LOG_MIN_STD) : 0.f; inv_std[r] = expf(-ls[r]); }
-
-    // tangent (FVP) and backward fragments
-    float V0f[MODE == MODE_FVP ? NS_KS : 1][HB], V1f[MODE == MODE_FVP ? KK : 1][HB], V2f[MODE == MODE_FVP ? KK : 1];
     f32x4 vb0f[HB], vb1f[HB], vb2f;
     if (MODE == MODE_FVP) {
-#pragma unroll
-        for (int s = 0; s < NS_KS; ++s)
-#pragma unroll
-            for (int cb = 0; cb < HB; ++cb) { const int i = 4 * s + q, o = 16 * cb + c; V0f[MODE == MODE_FVP ? s : 0][cb] = (i < NS && o < PH) ? v[pW0 + i * PH + o] : 0.f; }
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-            const int i = 16 * (kk >> 2) + 4 * q + (kk & 3);
-#pragma unroll
-            for (int cb = 0; cb < HB; ++cb) { const int o = 16 * cb + c; V1f[MODE == MODE_FVP ? kk : 0][cb] = (i < PH && o < PH) ? v[pW1 + i * PH + o] : 0.f; }
-            V2f[MODE == MODE_FVP ? kk : 0] = (i < PH && c < NA) ? v[pW2 + i * NA + c] : 0.f;
-        }
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb)
 #pragma unroll
@@ -93,20 +102,7 @@ __global__ void __launch_bounds__(256, 2) k_policy_mfma(PolK k, const float* __r
 #pragma unroll
         for (int r = 0; r < 4; ++r) vb2f[r] = (4 * q + r < NA) ? v[pb2 + 4 * q + r] : 0.f;
     }
-    float W2b[4][HB], W1b[KK][HB];
-    if (MODE != MODE_LOSSKL) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int cb = 0; cb < HB; ++cb) { const int i = 16 * cb + c, d = 4 * q + r; W2b[r][cb] = (i < PH && d < NA) ? theta[pW2 + i * NA + d] : 0.f; }
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-            for (int cb = 0; cb < HB; ++cb) {
-                const int i = 16 * cb + c, j = 16 * (kk >> 2) + 4 * q + (kk & 3);
-                W1b[kk][cb] = (i < PH && j < PH) ? theta[pW1 + i * PH + j] : 0.f;
-            }
-    }
+    __syncthreads();
 
     // ---------------- accumulators -------------------------------------------------------------------
     const f32x4 Z4 = {0.f, 0.f, 0.f, 0.f};
@@ -137,7 +133,7 @@ __global__ void __launch_bounds__(256, 2) k_policy_mfma(PolK k, const float* __r
 #pragma unroll
         for (int s = 0; s < NS_KS; ++s)
 #pragma unroll
-            for (int cb = 0; cb < HB; ++cb) h0[cb] = MFMA16(W0f[s][cb], xB[s], h0[cb]);
+            for (int cb = 0; cb < HB; ++cb) h0[cb] = MFMA16(FRAG2(I::O_W0F, s, cb), xB[s], h0[cb]);
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb) {
             h1[cb] = b1f[cb];
@@ -147,7 +143,7 @@ __global__ void __launch_bounds__(256, 2) k_policy_mfma(PolK k, const float* __r
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-            for (int cb = 0; cb < HB; ++cb) h1[cb] = MFMA16(W1f[kk][cb], h0[kk >> 2][kk & 3], h1[cb]);
+            for (int cb = 0; cb < HB; ++cb) h1[cb] = MFMA16(FRAG2(I::O_W1F, kk, cb), h0[kk >> 2][kk & 3], h1[cb]);
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb)
 #pragma unroll
@@ -158,8 +154,8 @@ __global__ void __launch_bounds__(256, 2) k_policy_mfma(PolK k, const float* __r
             f32x4 m0 = b2f, m1 = Z4;
 #pragma unroll
             for (int kk = 0; kk < KK; kk += 2) {
-                m0 = MFMA16(W2f[kk], h1[kk >> 2][kk & 3], m0);
-                m1 = MFMA16(W2f[kk + 1], h1[(kk + 1) >> 2][(kk + 1) & 3], m1);
+                m0 = MFMA16(FRAG1(I::O_W2F, kk), h1[kk >> 2][kk & 3], m0);
+                m1 = MFMA16(FRAG1(I::O_W2F, kk + 1), h1[(kk + 1) >> 2][(kk + 1) & 3], m1);
             }
             const f32x4 mu = m0 + m1;
             float llr = 0.f, kl = 0.f, zz[4] = {0.f, 0.f, 0.f, 0.f};
@@ -185,7 +181,7 @@ __global__ void __launch_bounds__(256, 2) k_policy_mfma(PolK k, const float* __r
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 um[r] = w * zz[r] * inv_std[r];             // d loss / d mean = w (a-mu)/std^2
-                dls[r] += w * (zz[r] * zz[r] - ((4 * q + r < NA) ? 1.f : 0.f)) * ((4 * q + r < NA) ? 1.f : 0.f);
+                if (4 * q + r < NA) dls[r] += w * (zz[r] * zz[r] - 1.f);      // d loss / d log_std
             }
         } else {
             // ---- tangent forward: dpre = V^T h + W^T dh + vb ; dh = dpre * (1 - h^2) ------------------
@@ -195,29 +191,29 @@ __global__ void __launch_bounds__(256, 2) k_policy_mfma(PolK k, const float* __r
 #pragma unroll
             for (int s = 0; s < NS_KS; ++s)
 #pragma unroll
-                for (int cb = 0; cb < HB; ++cb) t0[cb] = MFMA16(V0f[s][cb], xB[s], t0[cb]);
+                for (int cb = 0; cb < HB; ++cb) t0[cb] = MFMA16(FRAG2(I::O_V0F, s, cb), xB[s], t0[cb]);
 #pragma unroll
             for (int cb = 0; cb < HB; ++cb) {
                 t1[cb] = vb1f[cb];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) t0[cb][r] *= (1.f - h0[cb][r] * h0[cb][r]);
+                for (int r = 0; r < 4; ++r) t0[cb][r] *= fmaf(-h0[cb][r], h0[cb][r], 1.f);
             }
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
                 for (int cb = 0; cb < HB; ++cb) {
-                    t1[cb] = MFMA16(W1f[kk][cb], t0[kk >> 2][kk & 3], t1[cb]);
-                    t1[cb] = MFMA16(V1f[kk][cb], h0[kk >> 2][kk & 3], t1[cb]);
+                    t1[cb] = MFMA16(FRAG2(I::O_W1F, kk, cb), t0[kk >> 2][kk & 3], t1[cb]);
+                    t1[cb] = MFMA16(FRAG2(I::O_V1F, kk, cb), h0[kk >> 2][kk & 3], t1[cb]);
                 }
 #pragma unroll
             for (int cb = 0; cb < HB; ++cb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) t1[cb][r] *= (1.f - h1[cb][r] * h1[cb][r]);
+                for (int r = 0; r < 4; ++r) t1[cb][r] *= fmaf(-h1[cb][r], h1[cb][r], 1.f);
             f32x4 m0 = vb2f, m1 = Z4;
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
-                m0 = MFMA16(W2f[kk], t1[kk >> 2][kk & 3], m0);
-                m1 = MFMA16(V2f[kk], h1[kk >> 2][kk & 3], m1);
+                m0 = MFMA16(FRAG1(I::O_W2F, kk), t1[kk >> 2][kk & 3], m0);
+                m1 = MFMA16(FRAG1(I::O_V2F, kk), h1[kk >> 2][kk & 3], m1);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -234,68 +230,90 @@ __global__ void __launch_bounds__(256, 2) k_policy_mfma(PolK k, const float* __r
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int cb = 0; cb < HB; ++cb) d1[cb] = MFMA16(W2b[r][cb], um[r], d1[cb]);
+            for (int cb = 0; cb < HB; ++cb) d1[cb] = MFMA16(FRAG2(I::O_W2B, r, cb), um[r], d1[cb]);
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb) {
             d0[cb] = Z4;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) d1[cb][r] *= (1.f - h1[cb][r] * h1[cb][r]);
+            for (int r = 0; r < 4; ++r) d1[cb][r] *= fmaf(-h1[cb][r], h1[cb][r], 1.f);
         }
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-            for (int cb = 0; cb < HB; ++cb) d0[cb] = MFMA16(W1b[kk][cb], d1[kk >> 2][kk & 3], d0[cb]);
+            for (int cb = 0; cb < HB; ++cb) d0[cb] = MFMA16(FRAG2(I::O_W1B, kk, cb), d1[kk >> 2][kk & 3], d0[cb]);
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) d0[cb][r] *= (1.f - h0[cb][r] * h0[cb][r]);
+            for (int r = 0; r < 4; ++r) d0[cb][r] *= fmaf(-h0[cb][r], h0[cb][r], 1.f);
         gb2 += um;
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb) { gb1[cb] += d1[cb]; gb0[cb] += d0[cb]; }
-        // ---- 16x16 transposes through LDS: D fragment [unit 16cb+4q+r][sample c] -> T[unit][sample] ----
+        // ---- weight gradients G[i][j] += sum_n a[i][n] d[j][n]: three phases share the wave's 2*HB transpose tiles -------
+        // D fragment [unit 16cb+4q+r][sample c] -> T[unit][sample]; k-step s of the MFMA covers samples 4s+q
+        float* TA = TL, *TB = TL + HB * TILE;
+        // phase 1: gW2 += h1 (x) u
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = (4 * q + r) * TS + c;
-                T_h0[cb * TILE + row] = h0[cb][r]; T_h1[cb * TILE + row] = h1[cb][r];
-                T_d1[cb * TILE + row] = d1[cb][r]; T_d0[cb * TILE + row] = d0[cb][r];
-            }
+            for (int r = 0; r < 4; ++r) TA[cb * TILE + (4 * q + r) * TS + c] = h1[cb][r];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) T_u[(4 * q + r) * TS + c] = um[r];
+        for (int r = 0; r < 4; ++r) TB[(4 * q + r) * TS + c] = um[r];
         wave_sync_lds();
-        // ---- weight gradients: G[i][j] += sum_n a[i][n] d[j][n], k-step s covers samples 4s+q ---------
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int col = c * TS + 4 * s + q;             // T[unit = c][sample = 4s+q]
-            float aT_h0[HB], aT_h1[HB], bT_d1[HB], bT_d0[HB];
+            const int col = c * TS + 4 * s + q;
+            const float bu = TB[col];
 #pragma unroll
-            for (int cb = 0; cb < HB; ++cb) {
-                aT_h0[cb] = T_h0[cb * TILE + col]; aT_h1[cb] = T_h1[cb * TILE + col];
-                bT_d1[cb] = T_d1[cb * TILE + col]; bT_d0[cb] = T_d0[cb * TILE + col];
-            }
-            const float bT_u = T_u[col];
+            for (int ci = 0; ci < HB; ++ci) gW2[ci] = MFMA16(TA[ci * TILE + col], bu, gW2[ci]);
+        }
+        wave_sync_lds();
+        // phase 2: gW1 += h0 (x) d1
+#pragma unroll
+        for (int cb = 0; cb < HB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { TA[cb * TILE + (4 * q + r) * TS + c] = h0[cb][r]; TB[cb * TILE + (4 * q + r) * TS + c] = d1[cb][r]; }
+        wave_sync_lds();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int col = c * TS + 4 * s + q;
+            float a_[HB], b_[HB];
+#pragma unroll
+            for (int cb = 0; cb < HB; ++cb) { a_[cb] = TA[cb * TILE + col]; b_[cb] = TB[cb * TILE + col]; }
+#pragma unroll
+            for (int ci = 0; ci < HB; ++ci)
+#pragma unroll
+                for (int cj = 0; cj < HB; ++cj) gW1[ci][cj] = MFMA16(a_[ci], b_[cj], gW1[ci][cj]);
+        }
+        wave_sync_lds();
+        // phase 3: gW0 += x (x) d0   (x straight from global in A layout)
+#pragma unroll
+        for (int cb = 0; cb < HB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) TB[cb * TILE + (4 * q + r) * TS + c] = d0[cb][r];
+        wave_sync_lds();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int col = c * TS + 4 * s + q;
+            float b_[HB];
+#pragma unroll
+            for (int cb = 0; cb < HB; ++cb) b_[cb] = TB[cb * TILE + col];
             const long long ns_ = n0 + 4 * s + q;
 #pragma unroll
             for (int ci = 0; ci < NSI; ++ci) {
                 const int f = 16 * ci + c;
                 const float xT = (ns_ < k.N && f < NS) ? k.obs[ns_ * NS + f] : 0.f;
 #pragma unroll
-                for (int cj = 0; cj < HB; ++cj) gW0[ci][cj] = MFMA16(xT, bT_d0[cj], gW0[ci][cj]);
-            }
-#pragma unroll
-            for (int ci = 0; ci < HB; ++ci) {
-#pragma unroll
-                for (int cj = 0; cj < HB; ++cj) gW1[ci][cj] = MFMA16(aT_h0[ci], bT_d1[cj], gW1[ci][cj]);
-                gW2[ci] = MFMA16(aT_h1[ci], bT_u, gW2[ci]);
+                for (int cj = 0; cj < HB; ++cj) gW0[ci][cj] = MFMA16(xT, b_[cj], gW0[ci][cj]);
             }
         }
         wave_sync_lds();
     }
+#undef FRAG2
+#undef FRAG1
 
     // ---------------- epilogue: wave partial -> block partial (fixed order) -> global row -------------
     __syncthreads();
-    float* RB = lds;                                        // [4][ROW] (transpose tiles are dead)
+    float* RB = lds;                                        // [4][ROW] (weight image and transpose tiles are dead)
     float* row = RB + wave * ROW;
     for (int i = lane; i < ROW; i += 64) row[i] = 0.f;
     wave_sync_lds();
@@ -339,7 +357,7 @@ typedef void (*pol_kernel_t)(PolK, const float*, const float*, float*);
 struct PolEntry { int ns, na, ph; pol_kernel_t kern[3]; int lds_floats; };
 template <int NS, int NA, int PH> constexpr int pol_lds() {
     constexpr int HB = cdiv_(PH, 16);
-    constexpr int a = 4 * (4 * HB + 1) * 16 * 17;
+    constexpr int a = PolImg<NS, NA, PH>::TOTAL + 4 * (2 * HB) * 16 * 17;
     constexpr int P = NS * PH + PH + PH * PH + PH + PH * NA + NA + NA;
     constexpr int b = 4 * (P + PART_EXTRA);
     return a > b ? a : b;

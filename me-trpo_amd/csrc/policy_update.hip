@@ -375,6 +375,8 @@ static int run_mode(metrpo_ctx* c, int mode, const metrpo_batch* b, const PolK& 
     const int P = c->pd.P;
     if (c->pol_mfma >= 0) {
         const long long tiles = (b->N + 15) / 16;
+        // measured (tools/fvp_sweep.py): 2 and 3 blocks per CU run at the same speed, 1 and 4 are slower; 2 keeps the number
+        // of partial rows (and with it k_finalize) small
         const int g = (int)std::max<long long>(1, std::min<long long>((tiles + 3) / 4, (long long)c->n_sm * 2));
         int rc = ensure_partials(c, g); if (rc) return rc;
         *nrows = g; *stride = P + PART_EXTRA; *lk_col = P;

@@ -103,25 +103,34 @@ class NeuralNetEnv(object):
         self._state = s_next[0].double().cpu().numpy()
         return self._state, float(rew[0].item()), bool(done[0].item()), {}
 
-    def vec_env_executor(self, n_envs, max_path_length):
-        return VecSimpleEnv(env=self, n_envs=n_envs, max_path_length=max_path_length)
+    def vec_env_executor(self, n_envs, max_path_length, fused=False):
+        """fused=True (used by the fused sampler, which never steps the env from the host) skips the per-env host state."""
+        return VecSimpleEnv(env=self, n_envs=n_envs, max_path_length=max_path_length, fused=fused)
 
 
 class VecSimpleEnv(object):
     """Step-granular vectorised env.  States live on the device; per-step host work is the reset of
     finished envs (a host call per env when `env.env` is a real simulator, exactly as the reference)."""
 
-    def __init__(self, env, n_envs, max_path_length):
+    def __init__(self, env, n_envs, max_path_length, fused=False):
         self.env = env
         self.n_envs = self.num_envs = n_envs
         self.engine = env.engine
+        self.max_path_length = max_path_length
+        self.states = self.ts = self.cur_model_idx = None
+        if not fused:                              # fused: the whole loop runs inside metrpo_rollout; host state made on demand
+            self._materialise()
+
+    def _materialise(self):
+        n_envs, env = self.n_envs, self.env
         dev = self.engine.device
         self.states = torch.zeros(n_envs, self.engine.ns, dtype=torch.float32, device=dev)
         self.ts = np.zeros((n_envs,))
-        self.max_path_length = max_path_length
-        self.cur_model_idx = np.random.randint(env.n_models, size=(n_envs,))
+        self.cur_model_idx = np.random.randint(env.n_models, size=(n_envs,))      # env_helpers.py:583
 
     def reset(self, dones=None):
+        if self.states is None:
+            self._materialise()
         if dones is None:
             dones = np.asarray([True] * self.n_envs)
         else:
@@ -138,6 +147,8 @@ class VecSimpleEnv(object):
         return new
 
     def step(self, actions):
+        if self.states is None:
+            self._materialise()
         self.ts += 1
         sam_mode = self.env.sam_mode
         idx = noise = None

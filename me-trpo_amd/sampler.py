@@ -53,6 +53,7 @@ class BaseSampler(object):
         algo, eng = self.algo, self.algo.engine
         comm = getattr(algo, 'comm', None) or Comm()
         tr = paths.traj
+        self.finish_baseline_fit()             # deferred solve of the previous iteration (overlaps the rollout just launched)
         coeffs = algo.baseline.coeffs
         adv, ret, valid, stats = eng.gae(tr, coeffs, algo.discount, algo.gae_lambda)
         comm.allreduce_sum_(stats)
@@ -107,7 +108,7 @@ class VectorizedSampler(BaseSampler):
             n_envs = int(self.algo.batch_size / self.algo.max_path_length)
             n_envs = max(1, min(n_envs, 100))
         assert getattr(self.algo.env, 'vectorized', False), "the imagined env must be vectorized"
-        self.vec_env = self.algo.env.vec_env_executor(n_envs=n_envs, max_path_length=self.algo.max_path_length)
+        self.vec_env = self.algo.env.vec_env_executor(n_envs=n_envs, max_path_length=self.algo.max_path_length, fused=True)
         self.env_spec = self.algo.env.spec
         self._n_envs = n_envs
 
@@ -133,8 +134,14 @@ class VectorizedSampler(BaseSampler):
         if ev is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+        out = None
+        if getattr(algo, 'reuse_trajectory_buffers', False):      # opt-in: later rollouts overwrite earlier DevicePaths
+            key = (B, T, H)
+            if getattr(self, '_traj_key', None) != key:
+                self._traj_buf, self._traj_key = eng.alloc_trajectory(B, T, H), key
+            out = self._traj_buf
         traj = eng.rollout(B, T, H, nne.sam_mode, pool, determ=determ, eval_all_heads=getattr(algo, 'eval_all_heads', True),
-                           seed=seed, stream_offset=offset, **draws)
+                           seed=seed, stream_offset=offset, out=out, **draws)
         if ev is not None:
             e1.record()
             ev.append((e0, e1))

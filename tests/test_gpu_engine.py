@@ -361,3 +361,52 @@ def test_error_behaviour():
     assert s.shape == (0, 10)
     with pytest.raises(MetrpoError, match='model_idx'):
         eng.step(np.zeros((4, 10), np.float32), np.zeros((4, 2), np.float32), 'step_rand')
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs as parity cases (shapes of C0..C4 at batch sizes the oracle finishes in seconds)
+CONFIG_SHAPES = [
+    ('C0-baseline-json', 'swimmer', 5, (64, 64), (32, 32), 100, 50, 50),        # the reference's CPU-runnable case, full size
+    ('C0-params-file', 'swimmer', 5, (512, 512), (32, 32), 100, 8, 8),          # params-swimmer.json:20-23 network
+    ('C2-2x1024', 'half_cheetah', 5, (1024, 1024), (32, 32), 48, 6, 6),         # params-half-cheetah.json:20-21 network
+    ('C3', 'ant', 10, (512, 512), (32, 32), 64, 6, 4),                          # K=10 ensemble, early termination
+    ('C4', 'humanoid', 20, (1024, 1024, 1024), (100, 50, 25), 24, 4, 4),        # K=20, 3x1024, policy 100-50-25
+]
+
+
+@pytest.mark.parametrize('name,env,K,dh,ph,B,T,H', CONFIG_SHAPES)
+def test_baseline_config_shapes_end_to_end(name, env, K, dh, ph, B, T, H):
+    """rollout (whatever kernel the shape selects) -> GAE -> TRPO update, each stage against the oracle."""
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, dh, ph, seed=51)
+    if env == 'ant':
+        pool[::3, 2] = 0.21; dm.diff_mean[2] = -0.02
+        eng.set_dynamics_layers(dm.Ws, dm.bs, dm.in_mean, dm.in_std, dm.diff_mean, dm.diff_std)
+    th = theta.astype(np.float32).astype(np.float64)
+    pool32 = pool.astype(np.float32).astype(np.float64)
+    dr = Hh.draws(np.random.RandomState(6), K, B, T, dm.ns, dm.na, len(pool))
+    dr32 = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in dr.items()}
+    traj = eng.rollout(B, T, H, 'step_rand', pool, **dr32)
+    drf = {k: (v.astype(np.float64) if v.dtype == np.float32 else v) for k, v in dr32.items()}
+    ref = Hh.oracle_rollout(dm, th, pdims, env, pool32, drf, B, T, H, 'step_rand', teacher_obs=cpu(traj.obs))
+    tol = dict(rtol=2e-5, atol=5e-6) if max(dh) <= 64 else dict(rtol=1e-4, atol=5e-5)     # 1024-wide fp32 sums
+    np.testing.assert_allclose(cpu(traj.mean), ref['mean'], **tol)
+    np.testing.assert_allclose(cpu(traj.rew), ref['rew'], **tol)
+    dn = cpu(traj.done).astype(bool)
+    for t in range(T - 1):
+        np.testing.assert_allclose(cpu(traj.obs[t + 1])[~dn[t]], ref['next'][t][~dn[t]], **tol)
+    adv, ret, valid, stats = eng.gae(traj, None, 1.0, 1.0)
+    eng.center_advantages(adv, valid, stats)
+    v = cpu(valid).astype(bool)
+    assert v.any()
+    batch = eng.make_batch(traj.obs, traj.act, adv, traj.mean, eng.get_policy()[-dm.na:], valid=valid)
+    keep = v.reshape(-1)
+    obs, act = cpu(traj.obs).reshape(-1, dm.ns)[keep], cpu(traj.act).reshape(-1, dm.na)[keep]
+    a, om = cpu(adv).reshape(-1)[keep], cpu(traj.mean).reshape(-1, dm.na)[keep]
+    ols = np.broadcast_to(O.policy_log_std(th, pdims), om.shape).copy()
+    out = cpu(eng.loss_grad(batch))
+    loss, g = O.surrogate_loss_grad(th, pdims, obs, act, a, om, ols)
+    assert rel_l2(out[1:], g) <= 1e-4 and abs(out[0] - loss) <= 1e-5
+    vv = np.random.RandomState(2).randn(eng.P)
+    assert rel_l2(cpu(eng.fvp(batch, vv)), O.fisher_vector_product(th, pdims, obs, vv, reg_coeff=0.0)) <= 2e-4
+    res = eng.trpo_update(batch)
+    assert np.isfinite(res['loss_before']) and (not res['accepted'] or (res['kl'] <= 0.01 and res['loss'] < res['loss_before']))
