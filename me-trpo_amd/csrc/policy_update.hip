@@ -265,39 +265,33 @@ __global__ void __launch_bounds__(PT) k_loss_kl(ProblemDesc pd, PolK k, const fl
     if (tid == 0) { partials[blockIdx.x * 2] = (float)l; partials[blockIdx.x * 2 + 1] = (float)q; }
 }
 
-// out[p] = sum over partial rows (fixed order) of column col(p), float64.  Block = 64 columns x 4 row slices;
-// slice s adds rows s, s+4, ... then the 4 slice sums are added in slice order: deterministic.
+// out[p] = sum over partial rows (fixed order) of column col(p), float64.
 // mode 0: grad -> out[0] = loss (column P), out[1+p] = g[p]
 // mode 1: fvp  -> out[p] = Hv[p] for the mean net; log_std rows get c(s) * v_ls * weight (column P+2)
 // mode 2: loss/kl -> out[0], out[1] from columns (lk_col, lk_col+1)
-__global__ void __launch_bounds__(256) k_finalize(ProblemDesc pd, int mode, int nrows, int stride, int lk_col,
-                                                  const float* __restrict__ partials, const float* __restrict__ theta,
-                                                  const double* __restrict__ v, double* __restrict__ out) {
-    __shared__ double sh[4][65];
+__global__ void __launch_bounds__(1024) k_finalize(ProblemDesc pd, int mode, int nrows, int stride, int lk_col,
+                                                   const float* __restrict__ partials, const float* __restrict__ theta,
+                                                   const double* __restrict__ v, double* __restrict__ out) {
+    // block = 16 output columns x 64 row slices (latency-bound sum: many small blocks); slice s adds rows s, s+64, ...
+    // and the 64 slice sums are added in slice order: deterministic.
+    __shared__ double sh[64][17];
     const int P = pd.P;
     const int nout = (mode == 0) ? P + 1 : (mode == 1) ? P : 2;
-    const int lc = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int p = blockIdx.x * 64 + lc;
+    const int lc = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int p = blockIdx.x * 16 + lc;
     int col = p;
     if (mode == 0) col = (p == 0) ? P : p - 1;
     if (mode == 2) col = lk_col + p;
     const bool lsrow = (mode == 1 && p >= pd.pol.n_params && p < nout);
     if (lsrow) col = P + 2;                                   // valid-sample weight column
-    // 8 independent accumulators keep 8 loads in flight; the combination order is fixed -> deterministic
-    double a8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (p < nout) {
-        int b = sl;
-        for (; b + 28 < nrows; b += 32) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) a8[u] += (double)partials[(size_t)(b + 4 * u) * stride + col];
-        }
-        for (int u = 0; b < nrows; b += 4, ++u) a8[u] += (double)partials[(size_t)b * stride + col];
-    }
-    const double s = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
-    sh[sl][lc] = s;
+    double a = 0.0;
+    if (p < nout)
+        for (int b = sl; b < nrows; b += 64) a += (double)partials[(size_t)b * stride + col];
+    sh[sl][lc] = a;
     __syncthreads();
     if (sl == 0 && p < nout) {
-        double t = (sh[0][lc] + sh[1][lc]) + (sh[2][lc] + sh[3][lc]);
+        double t = 0.0;
+        for (int w = 0; w < 64; ++w) t += sh[w][lc];
         if (lsrow) {
             // Hessian of mean KL w.r.t. log_std at theta_old: 4 s^2 (2 s^2 - eps) / (2 s^2 + eps)^2  (-> 2 as eps -> 0)
             const double raw = (double)theta[p];
@@ -339,7 +333,7 @@ static int fill_polk(metrpo_ctx* c, const metrpo_batch* b, PolK* k, bool need_ta
 
 static void finalize(metrpo_ctx* c, int mode, int nrows, int stride, int lk_col, const double* v, double* out, hipStream_t st) {
     const int nout = (mode == 0) ? c->pd.P + 1 : (mode == 1) ? c->pd.P : 2;
-    hipLaunchKernelGGL(k_finalize, dim3((nout + 63) / 64), dim3(256), 0, st, c->pd, mode, nrows, stride, lk_col,
+    hipLaunchKernelGGL(k_finalize, dim3((nout + 15) / 16), dim3(1024), 0, st, c->pd, mode, nrows, stride, lk_col,
                        c->d_partials, c->d_theta, v, out);
 }
 

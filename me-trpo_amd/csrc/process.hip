@@ -160,32 +160,38 @@ __global__ void __launch_bounds__(256) k_gram_mfma(const float* __restrict__ obs
         for (int a = 0; a < NFB; ++a)
 #pragma unroll
             for (int b = 0; b < NFB; ++b) g[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // branch-free feature evaluation: every lane issues its loads unconditionally (clamped indices) so the 4 k-steps'
+        // loads are all in flight together; selection happens in registers
+        float val[4][NFB];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const long long n = tile * 16 + 4 * s + q;
-            const bool ok = (n < N) && (valid == nullptr || valid[n]);
-            float val[NFB];
+            const long long nc = (n < N) ? n : (N - 1);
+            const bool ok = (n < N) && (valid == nullptr || valid[nc]);
+            const float al = (float)tpath[nc] / 100.0f;
+            const float rv = ret[nc];
 #pragma unroll
             for (int cb = 0; cb < NFB; ++cb) {
                 const int f = 16 * cb + c;
-                float x = 0.f;
-                if (ok) {
-                    if (f < 2 * ns) {
-                        const float o = fminf(fmaxf(obs[n * ns + (f < ns ? f : f - ns)], -10.f), 10.f);
-                        x = (f < ns) ? o : o * o;
-                    } else if (f < F) {
-                        const float al = (float)tpath[n] / 100.0f;
-                        const int k = f - 2 * ns;
-                        x = (k == 0) ? al : (k == 1) ? al * al : (k == 2) ? al * al * al : 1.0f;
-                    } else if (f == F) x = ret[n];
-                }
-                val[cb] = x;
+                const int fo = (f < ns) ? f : ((f < 2 * ns) ? f - ns : 0);
+                const float o = fminf(fmaxf(obs[nc * ns + fo], -10.f), 10.f);
+                const int kq = f - 2 * ns;
+                float x = (f < ns) ? o : o * o;
+                x = (kq == 0) ? al : x;
+                x = (kq == 1) ? al * al : x;
+                x = (kq == 2) ? al * al * al : x;
+                x = (kq == 3) ? 1.0f : x;
+                x = (f == F) ? rv : x;
+                x = (f > F) ? 0.0f : x;
+                val[s][cb] = ok ? x : 0.0f;
             }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int a = 0; a < NFB; ++a)
 #pragma unroll
-                for (int b = 0; b < NFB; ++b) g[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(val[a], val[b], g[a][b], 0, 0, 0);
-        }
+                for (int b = 0; b < NFB; ++b) g[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(val[s][a], val[s][b], g[a][b], 0, 0, 0);
 #pragma unroll
         for (int a = 0; a < NFB; ++a)
 #pragma unroll
@@ -201,25 +207,33 @@ __global__ void __launch_bounds__(256) k_gram_mfma(const float* __restrict__ obs
 #pragma unroll
             for (int r = 0; r < 4; ++r) mine[(16 * a + 4 * q + r) * M + 16 * b + c] = acc[a][b][r];   // D layout: row 4q+r, col c
     __syncthreads();
-    double* out = part + (size_t)blockIdx.x * M * M;
-    for (int i = threadIdx.x; i < M * M; i += 256)
-        out[i] = (red[i] + red[M * M + i]) + (red[2 * M * M + i] + red[3 * M * M + i]);
+    // compact partial row: [F*F] Gram entries then [F] entries of F^T y (column F of the padded tile matrix)
+    const int nout = F * F + F;
+    double* out = part + (size_t)blockIdx.x * nout;
+    for (int p = threadIdx.x; p < nout; p += 256) {
+        const int i = (p < F * F) ? p / F : p - F * F, j = (p < F * F) ? p % F : F;
+        const int e = i * M + j;
+        out[p] = (red[e] + red[M * M + e]) + (red[2 * M * M + e] + red[3 * M * M + e]);
+    }
 }
 
-__global__ void k_gram_final(const double* __restrict__ part, int nblocks, int M, int F, double* __restrict__ AtA,
-                             double* __restrict__ Aty) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= F * F + F) return;
-    const int i = (p < F * F) ? p / F : p - F * F;
-    const int j = (p < F * F) ? p % F : F;
-    double a4[4] = {0, 0, 0, 0};
-    int b = 0;
-    for (; b + 3 < nblocks; b += 4)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) a4[u] += part[((size_t)(b + u) * M + i) * M + j];
-    for (int u = 0; b < nblocks; ++b, ++u) a4[u] += part[((size_t)b * M + i) * M + j];
-    const double s = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-    if (p < F * F) AtA[p] += s; else Aty[p - F * F] += s;
+__global__ void __launch_bounds__(1024) k_gram_final(const double* __restrict__ part, int nblocks, int M, int F,
+                                                     double* __restrict__ AtA, double* __restrict__ Aty) {
+    // block = 16 outputs x 64 row-slices (many small blocks: the sum is latency-bound); fixed order -> deterministic
+    __shared__ double sh[64][17];
+    const int lc = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int p = blockIdx.x * 16 + lc;
+    const int nout = F * F + F;
+    double a = 0.0;
+    if (p < nout)
+        for (int b = sl; b < nblocks; b += 64) a += part[(size_t)b * nout + p];
+    sh[sl][lc] = a;
+    __syncthreads();
+    if (sl == 0 && p < nout) {
+        double s = 0.0;
+        for (int w = 0; w < 64; ++w) s += sh[w][lc];
+        if (p < F * F) AtA[p] += s; else Aty[p - F * F] += s;
+    }
 }
 
 template <int NFB>
@@ -228,8 +242,8 @@ static int launch_gram_mfma(metrpo_ctx* c, const float* obs, const float* ret, c
     constexpr int M = NFB * 16;
     const int F = 2 * c->pd.ns + 4;
     const long long tiles = (N + 15) / 16;
-    const int g = (int)std::max<long long>(1, std::min<long long>((tiles + 3) / 4, (long long)c->n_sm * (NFB <= 2 ? 2 : 1)));
-    const size_t need = (size_t)g * M * M;
+    const int g = (int)std::max<long long>(1, std::min<long long>((tiles + 3) / 4, (long long)c->n_sm * (NFB <= 2 ? 8 : 2)));   // latency-bound: many resident waves
+    const size_t need = (size_t)g * (F * F + F);
     if (need > c->gram_cap) {
         if (c->d_gram_part) HIP_TRY(c, hipFree(c->d_gram_part));
         c->d_gram_part = nullptr; c->gram_cap = 0;
@@ -240,7 +254,7 @@ static int launch_gram_mfma(metrpo_ctx* c, const float* obs, const float* ret, c
     if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_gram_mfma<NFB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     hipLaunchKernelGGL(k_gram_mfma<NFB>, dim3(g), dim3(256), sh, st, obs, ret, tpath, valid, (long long)N, c->pd.ns, c->d_gram_part);
     const int nout = F * F + F;
-    hipLaunchKernelGGL(k_gram_final, dim3((nout + 127) / 128), dim3(128), 0, st, c->d_gram_part, g, M, F, AtA, Aty);
+    hipLaunchKernelGGL(k_gram_final, dim3((nout + 15) / 16), dim3(1024), 0, st, c->d_gram_part, g, M, F, AtA, Aty);
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;
 }
