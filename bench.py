@@ -107,7 +107,7 @@ def main():
                    "parallelism": "B-sharded x%d, sum all-reduce of g/FVP/scalars" % comm.world},
         "trpo_iter_ms": ms_per_step,
         "rollout": {"ms": roll_ms, "env_steps_per_s": units_per_step / (roll_ms * 1e-3),
-                    "kernel": {2: "mfma-cooperative", 1: "mfma-head-per-wave", 0: "generic"}[eng.set_rollout_variant(0)]},
+                    "kernel": {3: "gemm-stepwise", 2: "mfma-cooperative", 1: "mfma-head-per-wave", 0: "generic"}[eng.set_rollout_variant(0)]},
         "roofline": {"bound": "mfma", "kernel": "rollout", "achieved": achieved, "peak": PEAK_F32, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_F32, "traffic": traffic,
                      "hbm_frac_unfused_88B": (K * B * H * (2 * ns + na) * 4) / (roll_ms * 1e-3) / 8e12},

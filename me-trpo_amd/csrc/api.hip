@@ -75,7 +75,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     c->d_dyn_img = c->d_pol_img = nullptr; c->mfma_cfg = -1; c->pol_mfma = -1; c->coop_cfg = -1; c->rollout_variant = 0;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_cg = nullptr; c->d_vf = nullptr; c->d_theta_try = nullptr;
     c->d_valbuf = nullptr; c->h_pinned = nullptr; c->n_sm = 256;
-    c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0;
+    c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0;
     ProblemDesc& pd = c->pd;
     pd.env = d->env; pd.ns = d->ns; pd.na = d->na; pd.K = d->n_models; pd.n_drop = d->n_drop;
     pd.nin = d->ns + d->na - d->n_drop;
@@ -111,7 +111,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
 extern "C" int32_t metrpo_destroy(metrpo_ctx* c) {
     if (!c) return METRPO_ENULL;
     void* bufs[] = {c->d_dyn, c->d_norm, c->d_theta, c->d_vf, c->d_theta_try, c->d_cg, c->d_valbuf, c->d_partials,
-                    c->d_dyn_img, c->d_pol_img, c->d_vbuf, c->d_gram_part};
+                    c->d_dyn_img, c->d_pol_img, c->d_vbuf, c->d_gram_part, c->d_big};
     for (void* p : bufs) if (p) (void)hipFree(p);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     delete c;
@@ -201,6 +201,7 @@ extern "C" int32_t metrpo_rollout(metrpo_ctx* c, const metrpo_rollout_args* a, v
         const int rc = launch_rollout_mfma(c, a, (hipStream_t)stream);
         if (rc != METRPO_EUNSUPPORTED) return rc;
     }
+    if (gemm_path_applicable(c)) return launch_rollout_gemm(c, a, (hipStream_t)stream);     // large dynamics nets
     return launch_rollout_generic(c, a, (hipStream_t)stream);
 }
 
@@ -220,7 +221,7 @@ extern "C" int32_t metrpo_has_mfma_path(const metrpo_ctx* c) { return (c && c->m
 extern "C" int32_t metrpo_set_rollout_variant(metrpo_ctx* c, int32_t v) {
     if (!c) return METRPO_ENULL;
     c->rollout_variant = v;
-    return (v == 0 && c->coop_cfg >= 0) ? 2 : (c->mfma_cfg >= 0 ? 1 : 0);
+    return (v == 0 && c->coop_cfg >= 0) ? 2 : (c->mfma_cfg >= 0 ? 1 : (gemm_path_applicable(c) ? 3 : 0));
 }
 // test hook: 0 forces the generic (VALU) update kernels, 1 restores the MFMA ones when available
 extern "C" int32_t metrpo_set_update_path(metrpo_ctx* c, int32_t use_mfma) {

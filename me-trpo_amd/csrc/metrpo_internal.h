@@ -52,6 +52,8 @@ struct metrpo_ctx {
     size_t vbuf_cap;
     double* d_gram_part; // per-block Gram partials (process.hip)
     size_t gram_cap;
+    void* d_big;         // workspace of the GEMM step-wise rollout (rollout_gemm.hip)
+    size_t big_cap;
     double* h_pinned;    // pinned host scratch for the per-trial read-back
     int n_sm;            // CU count
     std::string err;
@@ -91,6 +93,8 @@ int launch_policy_actions(metrpo_ctx*, const float*, const float*, int, float*, 
 int launch_step(metrpo_ctx*, const float*, const float*, int, int, const int32_t*, const float*, float*, float*,
                 uint8_t*, float*, hipStream_t);
 int launch_rollout_generic(metrpo_ctx*, const metrpo_rollout_args*, hipStream_t);
+bool gemm_path_applicable(const metrpo_ctx*);
+int launch_rollout_gemm(metrpo_ctx*, const metrpo_rollout_args*, hipStream_t);
 int launch_rollout_mfma(metrpo_ctx*, const metrpo_rollout_args*, hipStream_t);   // returns METRPO_EUNSUPPORTED if no instantiation fits
 int mfma_prepare_dynamics(metrpo_ctx*, hipStream_t);
 int mfma_prepare_policy(metrpo_ctx*, hipStream_t);

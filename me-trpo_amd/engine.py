@@ -79,7 +79,7 @@ class Engine(object):
 
     def set_rollout_variant(self, v):
         """Test hook: 0 = fastest rollout kernel available, 1 = head-per-wave MFMA kernel.  Returns the variant that
-        will run: 2 cooperative-heads MFMA, 1 head-per-wave MFMA, 0 generic."""
+        will run: 3 step-wise GEMM (large nets), 2 cooperative-heads MFMA, 1 head-per-wave MFMA, 0 generic."""
         return int(lib.metrpo_set_rollout_variant(self._ctx, int(v)))
 
     def set_update_path(self, use_mfma):

@@ -386,9 +386,16 @@ def test_baseline_config_shapes_end_to_end(name, env, K, dh, ph, B, T, H):
     dr = Hh.draws(np.random.RandomState(6), K, B, T, dm.ns, dm.na, len(pool))
     dr32 = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in dr.items()}
     traj = eng.rollout(B, T, H, 'step_rand', pool, **dr32)
+    expected_path = 2 if (max(dh) <= 64 and K == 5) else (3 if min(dh) >= 128 else None)
+    if expected_path is not None:
+        assert eng.set_rollout_variant(0) == expected_path
     drf = {k: (v.astype(np.float64) if v.dtype == np.float32 else v) for k, v in dr32.items()}
     ref = Hh.oracle_rollout(dm, th, pdims, env, pool32, drf, B, T, H, 'step_rand', teacher_obs=cpu(traj.obs))
     tol = dict(rtol=2e-5, atol=5e-6) if max(dh) <= 64 else dict(rtol=1e-4, atol=5e-5)     # 1024-wide fp32 sums
+    if expected_path == 3:      # the step-wise GEMM path and the generic kernel agree (same draws, short horizon)
+        gen = eng.rollout(B, T, H, 'step_rand', pool, force_generic=True, **dr32)
+        np.testing.assert_allclose(cpu(traj.obs), cpu(gen.obs), rtol=2e-3, atol=2e-3)
+        assert torch.equal(traj.tpath, gen.tpath)
     np.testing.assert_allclose(cpu(traj.mean), ref['mean'], **tol)
     np.testing.assert_allclose(cpu(traj.rew), ref['rew'], **tol)
     dn = cpu(traj.done).astype(bool)
@@ -410,3 +417,26 @@ def test_baseline_config_shapes_end_to_end(name, env, K, dh, ph, B, T, H):
     assert rel_l2(cpu(eng.fvp(batch, vv)), O.fisher_vector_product(th, pdims, obs, vv, reg_coeff=0.0)) <= 2e-4
     res = eng.trpo_update(batch)
     assert np.isfinite(res['loss_before']) and (not res['accepted'] or (res['kl'] <= 0.01 and res['loss'] < res['loss_before']))
+
+
+@pytest.mark.parametrize('sam_mode', list(O.SAM_MODES))
+def test_gemm_rollout_all_sam_modes(sam_mode):
+    """Large-net (step-wise GEMM) path: every sam_mode, supplied draws, vs the oracle teacher-forced."""
+    env, K, B, T, H = 'half_cheetah', 4, 70, 7, 3
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (128, 256), (32, 32), seed=61)
+    assert eng.set_rollout_variant(0) == 3
+    th = theta.astype(np.float32).astype(np.float64)
+    pool32 = pool.astype(np.float32).astype(np.float64)
+    dr = Hh.draws(np.random.RandomState(8), K, B, T, dm.ns, dm.na, len(pool))
+    dr32 = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in dr.items()}
+    traj = eng.rollout(B, T, H, sam_mode, pool, **dr32)
+    drf = {k: (v.astype(np.float64) if v.dtype == np.float32 else v) for k, v in dr32.items()}
+    ref = Hh.oracle_rollout(dm, th, pdims, env, pool32, drf, B, T, H, sam_mode, teacher_obs=cpu(traj.obs))
+    np.testing.assert_allclose(cpu(traj.act), ref['act'], rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(cpu(traj.rew), ref['rew'], rtol=1e-4, atol=2e-5)
+    dn = cpu(traj.done).astype(bool)
+    assert dn[H - 1].all() and not dn[:H - 1].any()
+    for t in range(T - 1):
+        np.testing.assert_allclose(cpu(traj.obs[t + 1])[~dn[t]], ref['next'][t][~dn[t]], rtol=1e-4, atol=2e-5)
+        np.testing.assert_array_equal(cpu(traj.obs[t + 1])[dn[t]], pool32[dr['reset_idx'][t + 1]][dn[t]])
+    np.testing.assert_allclose(cpu(traj.last_obs), np.where(dn[T - 1][:, None], pool32[dr['reset_idx'][T]], ref['next'][T - 1]), rtol=1e-4, atol=2e-5)
