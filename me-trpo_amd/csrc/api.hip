@@ -1,6 +1,7 @@
 // C-ABI entry points of libmetrpo.so (include/metrpo.h): context management, argument checking,
 // dispatch to the kernels, and the host driver of one TRPO update.
 #include "metrpo_internal.h"
+#include "cg_device.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -58,7 +59,6 @@ static CgView cg_view(metrpo_ctx* c) {
     v.scal = v.step + P; v.lk = v.scal + 8;
     return v;
 }
-enum { S_RDOTR = 0, S_DONE = 1, S_BETA = 2, S_XHX = 3, S_ITERS = 4 };
 
 extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_dims* d) {
     if (!out || !d) return METRPO_ENULL;
@@ -75,7 +75,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     c->d_dyn_img = c->d_pol_img = nullptr; c->mfma_cfg = -1; c->pol_mfma = -1; c->coop_cfg = -1; c->rollout_variant = 0;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_cg = nullptr; c->d_vf = nullptr; c->d_theta_try = nullptr;
     c->d_valbuf = nullptr; c->h_pinned = nullptr; c->n_sm = 256;
-    c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0;
+    c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0; c->d_ticket = nullptr;
     ProblemDesc& pd = c->pd;
     pd.env = d->env; pd.ns = d->ns; pd.na = d->na; pd.K = d->n_models; pd.n_drop = d->n_drop;
     pd.nin = d->ns + d->na - d->n_drop;
@@ -97,6 +97,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
         hipMalloc(&c->d_theta_try, sizeof(float) * pd.P) != hipSuccess ||
         hipMalloc(&c->d_cg, sizeof(double) * ncg) != hipSuccess ||
         hipMalloc(&c->d_valbuf, sizeof(double) * pd.K) != hipSuccess ||
+        hipMalloc(&c->d_ticket, sizeof(unsigned int)) != hipSuccess ||
         hipHostMalloc(&c->h_pinned, sizeof(double) * 16) != hipSuccess) {
         c->err = "device allocation failed";
         return METRPO_EHIP;
@@ -111,7 +112,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
 extern "C" int32_t metrpo_destroy(metrpo_ctx* c) {
     if (!c) return METRPO_ENULL;
     void* bufs[] = {c->d_dyn, c->d_norm, c->d_theta, c->d_vf, c->d_theta_try, c->d_cg, c->d_valbuf, c->d_partials,
-                    c->d_dyn_img, c->d_pol_img, c->d_vbuf, c->d_gram_part, c->d_big};
+                    c->d_dyn_img, c->d_pol_img, c->d_vbuf, c->d_gram_part, c->d_big, c->d_ticket};
     for (void* p : bufs) if (p) (void)hipFree(p);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     delete c;
@@ -287,18 +288,6 @@ extern "C" int32_t metrpo_loss_kl(metrpo_ctx* c, const metrpo_batch* b, const fl
 // TRPO update driver: [rllab] ConjugateGradientOptimizer.optimize + krylov.cg, vectors resident on
 // the device in float64 (the reference keeps them in host NumPy float64), one block per vector op.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double blk_sum(double v, double* sh) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    __syncthreads();
-    if (l == 0) sh[w] = v;
-    __syncthreads();
-    double r = 0.0;
-    const int nw = (blockDim.x + 63) >> 6;
-    for (int i = 0; i < nw; ++i) r += sh[i];     // every thread sums the same values in the same order
-    return r;
-}
-
 __global__ void k_cg_init(int P, const double* __restrict__ gout, double* x, double* r, double* p, float* pf, double* scal) {
     __shared__ double sh[16];
     double acc = 0.0;
@@ -311,50 +300,14 @@ __global__ void k_cg_init(int P, const double* __restrict__ gout, double* x, dou
     if (threadIdx.x == 0) { scal[S_RDOTR] = rdotr; scal[S_DONE] = 0.0; scal[S_ITERS] = 0.0; }
 }
 
-// one krylov.cg iteration after z = f_Ax(p) has been formed (z lacks the reg term: added here)
 __global__ void k_cg_step(int P, double reg, double tol, int last, double* x, double* r, double* p, double* z, float* pf, double* scal) {
     __shared__ double sh[16];
-    if (scal[S_DONE] != 0.0) {
-        if (last) for (int i = threadIdx.x; i < P; i += blockDim.x) pf[i] = (float)x[i];   // next FVP input is x (step scale)
-        return;
-    }
-    const double rdotr = scal[S_RDOTR];
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < P; i += blockDim.x) { const double zi = z[i] + reg * p[i]; z[i] = zi; acc += p[i] * zi; }
-    const double pz = blk_sum(acc, sh);
-    const double v = rdotr / pz;
-    acc = 0.0;
-    for (int i = threadIdx.x; i < P; i += blockDim.x) {
-        x[i] += v * p[i];
-        const double ri = r[i] - v * z[i];
-        r[i] = ri;
-        acc += ri * ri;
-    }
-    const double newrdotr = blk_sum(acc, sh);
-    const double mu = newrdotr / rdotr;
-    for (int i = threadIdx.x; i < P; i += blockDim.x) {
-        const double pn = r[i] + mu * p[i];
-        p[i] = pn;
-        pf[i] = last ? (float)x[i] : (float)pn;       // float copy of the next FVP input
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        scal[S_RDOTR] = newrdotr;
-        scal[S_ITERS] += 1.0;
-        if (newrdotr < tol) scal[S_DONE] = 1.0;
-    }
+    cg_step_body(P, reg, tol, last, x, r, p, z, pf, scal, sh);
 }
 
-// initial_step_size = sqrt(2 * max_kl / (d . Hx(d) + 1e-8)); nan -> 1; step = beta * d
 __global__ void k_cg_finish(int P, double reg, double max_kl, const double* x, double* z, double* step, double* scal) {
     __shared__ double sh[16];
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < P; i += blockDim.x) acc += x[i] * (z[i] + reg * x[i]);
-    const double xhx = blk_sum(acc, sh);
-    double beta = sqrt(2.0 * max_kl * (1.0 / (xhx + 1e-8)));
-    if (isnan(beta)) beta = 1.0;
-    for (int i = threadIdx.x; i < P; i += blockDim.x) step[i] = beta * x[i];
-    if (threadIdx.x == 0) { scal[S_BETA] = beta; scal[S_XHX] = xhx; }
+    cg_finish_body(P, reg, max_kl, x, z, step, scal, sh);
 }
 
 __global__ void k_zero_f(float* p, int n) {
@@ -376,17 +329,31 @@ int run_trpo_update(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_para
                             return set_err(c, METRPO_EINVAL, "allreduce callback failed"); } while (0)
     if ((rc = launch_loss_grad(c, b, v.gout, st))) return rc;
     AR(v.gout, 1 + P);
+    HIP_TRY(c, hipMemsetAsync(c->d_ticket, 0, sizeof(unsigned int), st));
     hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(256), 0, st, P, v.gout, v.x, v.r, v.p, c->d_vf, v.scal);
     if (pr->cg_iters == 0) { hipLaunchKernelGGL(k_zero_f, dim3((P + 255) / 256), dim3(256), 0, st, c->d_vf, P); }
     for (int i = 0; i < pr->cg_iters; ++i) {
+        const int lastit = (i == pr->cg_iters - 1) ? 1 : 0;
+        if (!pr->allreduce) {                                   // no exchange between the FVP reduction and the CG step: fuse them
+            CgTail tl; tl.op = 1; tl.P = P; tl.last = lastit; tl.reg = pr->reg_coeff; tl.tol = pr->residual_tol; tl.max_kl = pr->max_kl;
+            tl.x = v.x; tl.r = v.r; tl.p = v.p; tl.z = v.z; tl.step = v.step; tl.scal = v.scal; tl.pf = c->d_vf; tl.ticket = c->d_ticket;
+            if ((rc = launch_fvp_tail(c, b, c->d_vf, v.p, v.z, &tl, st))) return rc;
+            continue;
+        }
         if ((rc = launch_fvp_f32(c, b, c->d_vf, v.p, v.z, st))) return rc;
         AR(v.z, P);
-        hipLaunchKernelGGL(k_cg_step, dim3(1), dim3(256), 0, st, P, pr->reg_coeff, pr->residual_tol, (i == pr->cg_iters - 1) ? 1 : 0,
+        hipLaunchKernelGGL(k_cg_step, dim3(1), dim3(1024), 0, st, P, pr->reg_coeff, pr->residual_tol, lastit,
                            v.x, v.r, v.p, v.z, c->d_vf, v.scal);
     }
+    if (!pr->allreduce) {
+        CgTail tl; tl.op = 2; tl.P = P; tl.last = 0; tl.reg = pr->reg_coeff; tl.tol = pr->residual_tol; tl.max_kl = pr->max_kl;
+        tl.x = v.x; tl.r = v.r; tl.p = v.p; tl.z = v.z; tl.step = v.step; tl.scal = v.scal; tl.pf = c->d_vf; tl.ticket = c->d_ticket;
+        if ((rc = launch_fvp_tail(c, b, c->d_vf, v.x, v.z, &tl, st))) return rc;
+    } else {
     if ((rc = launch_fvp_f32(c, b, c->d_vf, v.x, v.z, st))) return rc;
     AR(v.z, P);
-    hipLaunchKernelGGL(k_cg_finish, dim3(1), dim3(256), 0, st, P, pr->reg_coeff, pr->max_kl, v.x, v.z, v.step, v.scal);
+    hipLaunchKernelGGL(k_cg_finish, dim3(1), dim3(1024), 0, st, P, pr->reg_coeff, pr->max_kl, v.x, v.z, v.step, v.scal);
+    }
     if (g_out) HIP_TRY(c, hipMemcpyAsync(g_out, v.gout + 1, sizeof(double) * P, hipMemcpyDeviceToDevice, st));
     if (dir_out) HIP_TRY(c, hipMemcpyAsync(dir_out, v.x, sizeof(double) * P, hipMemcpyDeviceToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->h_pinned, v.gout, sizeof(double), hipMemcpyDeviceToHost, st));          // loss_before

@@ -1,0 +1,75 @@
+// Device-side krylov.cg vector algebra ([rllab] rllab.misc.krylov.cg / ConjugateGradientOptimizer.optimize), float64,
+// one thread block.  Shared by the stand-alone kernels in api.hip and by k_finalize's fused tail (policy_update.hip):
+// when no all-reduce sits between the FVP reduction and the CG step, the LAST block of k_finalize (ticket counter,
+// agent-scope release/acquire as in the guide's inter-workgroup recipe) runs the step itself and saves a launch.
+#pragma once
+#include "metrpo_internal.h"
+
+enum { S_RDOTR = 0, S_DONE = 1, S_BETA = 2, S_XHX = 3, S_ITERS = 4 };
+
+struct CgTail {
+    int op;                 // 0 none, 1 = CG iteration, 2 = step-size finish
+    int P, last;
+    double reg, tol, max_kl;
+    double *x, *r, *p, *z, *step, *scal;
+    float* pf;
+    unsigned int* ticket;   // zeroed by the driver before every CG solve; the last block resets it
+};
+
+__device__ __forceinline__ double blk_sum(double v, double* sh) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) sh[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) r += sh[i];     // every thread sums the same values in the same order
+    return r;
+}
+
+// one krylov.cg iteration after z = f_Ax(p) has been formed (z lacks the reg term: added here)
+__device__ __forceinline__ void cg_step_body(int P, double reg, double tol, int last, double* x, double* r, double* p, double* z,
+                                             float* pf, double* scal, double* sh) {
+    if (scal[S_DONE] != 0.0) {
+        if (last) for (int i = threadIdx.x; i < P; i += blockDim.x) pf[i] = (float)x[i];   // next FVP input is x (step scale)
+        return;
+    }
+    const double rdotr = scal[S_RDOTR];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) { const double zi = z[i] + reg * p[i]; z[i] = zi; acc += p[i] * zi; }
+    const double pz = blk_sum(acc, sh);
+    const double v = rdotr / pz;
+    acc = 0.0;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        x[i] += v * p[i];
+        const double ri = r[i] - v * z[i];
+        r[i] = ri;
+        acc += ri * ri;
+    }
+    const double newrdotr = blk_sum(acc, sh);
+    const double mu = newrdotr / rdotr;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        const double pn = r[i] + mu * p[i];
+        p[i] = pn;
+        pf[i] = last ? (float)x[i] : (float)pn;       // float copy of the next FVP input
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        scal[S_RDOTR] = newrdotr;
+        scal[S_ITERS] += 1.0;
+        if (newrdotr < tol) scal[S_DONE] = 1.0;
+    }
+}
+
+// initial_step_size = sqrt(2 * max_kl / (d . Hx(d) + 1e-8)); nan -> 1; step = beta * d
+__device__ __forceinline__ void cg_finish_body(int P, double reg, double max_kl, const double* x, double* z, double* step,
+                                               double* scal, double* sh) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) acc += x[i] * (z[i] + reg * x[i]);
+    const double xhx = blk_sum(acc, sh);
+    double beta = sqrt(2.0 * max_kl * (1.0 / (xhx + 1e-8)));
+    if (isnan(beta)) beta = 1.0;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) step[i] = beta * x[i];
+    if (threadIdx.x == 0) { scal[S_BETA] = beta; scal[S_XHX] = xhx; }
+}

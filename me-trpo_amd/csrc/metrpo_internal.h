@@ -52,6 +52,7 @@ struct metrpo_ctx {
     size_t vbuf_cap;
     double* d_gram_part; // per-block Gram partials (process.hip)
     size_t gram_cap;
+    unsigned int* d_ticket; // arrival counter of k_finalize's fused CG tail
     void* d_big;         // workspace of the GEMM step-wise rollout (rollout_gemm.hip)
     size_t big_cap;
     double* h_pinned;    // pinned host scratch for the per-trial read-back
@@ -111,6 +112,9 @@ int launch_loss_grad(metrpo_ctx*, const metrpo_batch*, double*, hipStream_t);
 int launch_fvp(metrpo_ctx*, const metrpo_batch*, const double*, double*, hipStream_t);
 // vf = float copy of v already on the device (skips the conversion launch); v is still needed for the log_std rows
 int launch_fvp_f32(metrpo_ctx*, const metrpo_batch*, const float* vf, const double* v, double* hv, hipStream_t);
+struct CgTail;
+// FVP + reduction + (in the reduction kernel's last block) the CG vector step described by `tail`
+int launch_fvp_tail(metrpo_ctx*, const metrpo_batch*, const float* vf, const double* v, double* hv, const CgTail* tail, hipStream_t);
 int launch_loss_kl(metrpo_ctx*, const metrpo_batch*, const float*, double*, hipStream_t);
 int run_trpo_update(metrpo_ctx*, const metrpo_batch*, const metrpo_trpo_params*, metrpo_trpo_diag*, double*,
                     double*, hipStream_t);

@@ -11,6 +11,7 @@
 // that lanes holding different units hit different LDS banks).  Each block accumulates into its own
 // row of a global partial buffer; k_finalize sums rows in block order -> bitwise reproducible.
 #include "device_common.h"
+#include "cg_device.h"
 
 
 
@@ -271,7 +272,7 @@ __global__ void __launch_bounds__(PT) k_loss_kl(ProblemDesc pd, PolK k, const fl
 // mode 2: loss/kl -> out[0], out[1] from columns (lk_col, lk_col+1)
 __global__ void __launch_bounds__(1024) k_finalize(ProblemDesc pd, int mode, int nrows, int stride, int lk_col,
                                                    const float* __restrict__ partials, const float* __restrict__ theta,
-                                                   const double* __restrict__ v, double* __restrict__ out) {
+                                                   const double* __restrict__ v, double* __restrict__ out, CgTail tail) {
     // block = 16 output columns x 64 row slices (latency-bound sum: many small blocks); slice s adds rows s, s+64, ...
     // and the 64 slice sums are added in slice order: deterministic.
     __shared__ double sh[64][17];
@@ -301,6 +302,24 @@ __global__ void __launch_bounds__(1024) k_finalize(ProblemDesc pd, int mode, int
         }
         out[p] = t;
     }
+    if (tail.op == 0) return;
+    // ---- fused CG tail: the last block to arrive owns the complete `out` vector and runs the vector step ----
+    __shared__ unsigned int s_last;
+    __shared__ double cgsh[16];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int tk = __hip_atomic_fetch_add(tail.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (tk == gridDim.x - 1) ? 1u : 0u;
+        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tail.op == 1) cg_step_body(tail.P, tail.reg, tail.tol, tail.last, tail.x, tail.r, tail.p, tail.z, tail.pf, tail.scal, cgsh);
+    else cg_finish_body(tail.P, tail.reg, tail.max_kl, tail.x, tail.z, tail.step, tail.scal, cgsh);
+    if (threadIdx.x == 0) __hip_atomic_store(tail.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
 }
 
 __global__ void k_d2f(const double* __restrict__ in, float* __restrict__ out, int n) {
@@ -331,10 +350,12 @@ static int fill_polk(metrpo_ctx* c, const metrpo_batch* b, PolK* k, bool need_ta
     return METRPO_OK;
 }
 
-static void finalize(metrpo_ctx* c, int mode, int nrows, int stride, int lk_col, const double* v, double* out, hipStream_t st) {
+static void finalize(metrpo_ctx* c, int mode, int nrows, int stride, int lk_col, const double* v, double* out, hipStream_t st,
+                     const CgTail* tail = nullptr) {
     const int nout = (mode == 0) ? c->pd.P + 1 : (mode == 1) ? c->pd.P : 2;
+    CgTail none; none.op = 0; none.ticket = nullptr;
     hipLaunchKernelGGL(k_finalize, dim3((nout + 15) / 16), dim3(1024), 0, st, c->pd, mode, nrows, stride, lk_col,
-                       c->d_partials, c->d_theta, v, out);
+                       c->d_partials, c->d_theta, v, out, tail ? *tail : none);
 }
 
 // generic kernels: pick the largest sample tile (threads per block) whose LDS columns fit
@@ -401,9 +422,14 @@ int launch_fvp(metrpo_ctx* c, const metrpo_batch* b, const double* v, double* hv
 }
 
 int launch_fvp_f32(metrpo_ctx* c, const metrpo_batch* b, const float* vf, const double* v, double* hv, hipStream_t st) {
+    return launch_fvp_tail(c, b, vf, v, hv, nullptr, st);
+}
+
+int launch_fvp_tail(metrpo_ctx* c, const metrpo_batch* b, const float* vf, const double* v, double* hv, const CgTail* tail, hipStream_t st) {
     PolK k; int rc = fill_polk(c, b, &k, false); if (rc) return rc;
     int nrows, stride, lk;
     if ((rc = run_mode(c, 1, b, k, c->d_theta, vf, &nrows, &stride, &lk, st))) return rc;
+    if (tail) { finalize(c, 1, nrows, stride, lk, v, hv, st, tail); HIP_TRY(c, hipGetLastError()); return METRPO_OK; }
     finalize(c, 1, nrows, stride, lk, v, hv, st);
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;
