@@ -1,0 +1,170 @@
+// Batched f32 GEMM on the matrix core (v_mfma_f32_32x32x2_f32, exact f32 fmaf chains) with fused epilogues.
+// Shared by the step-wise rollout (rollout_gemm.hip) and the ensemble dynamics training (dyn_train.hip).
+//   C[h] = epilogue( opA(A[h]) [M x Kd]  *  opB(W[h]) [Kd x N] )        h = blockIdx.z (head / model)
+//   opA = A (row-major [M][Kd], lda) or A^T (A stored [Kd][M]);  opB = W (row-major [Kd][N], ldw) or W^T (stored [N][Kd])
+// block = 256 threads = 2x2 waves; wave tile (32*TM) x (32*TN); block tile (64*TM) x (64*TN); BK = 16; LDS double buffer
+#pragma once
+#include "device_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { EPI_BIAS_ID = 0, EPI_BIAS_RELU = 1, EPI_BIAS_TANH = 2, EPI_RELU_MASK = 3, EPI_ADAM = 4, EPI_PLAIN = 5 };
+
+struct GemmEpi {                 // epilogue operands (unused fields may be null)
+    const float* bias; long long strideBias;          // EPI_BIAS_*: bias[col]
+    const float* mask; long long strideMask; int ldm; // EPI_RELU_MASK: C = acc * (mask[row][col] > 0)
+    float* am; float* av; long long strideAdam;       // EPI_ADAM: C is the weight matrix, updated in place; am/av same layout
+    float lr_t, beta1, beta2, eps, decay;             //           lr_t = lr*sqrt(1-b2^t)/(1-b1^t); decay = lr*reg_constant (SGD on the regulariser)
+};
+
+template <int TM, int TN, int EPI, bool TA, bool TB>
+__global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, long long strideA, int lda,
+                                                   const float* __restrict__ W, long long strideW, int ldw,
+                                                   float* __restrict__ C, long long strideC, int ldc, int M, int N, int Kd, GemmEpi ep) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, BK = 16;
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM + 4];     // As[k][m]
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + 4];     // Bs[k][n]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int head = blockIdx.z;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    A += (size_t)head * strideA; W += (size_t)head * strideW; C += (size_t)head * strideC;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // "strided" staging (source is [X][k] with k contiguous: float4 along k, scattered into S[k][x]) for A when !TA and for B when TB;
+    // "direct" staging (source is [k][X] with X contiguous: float4 along X, stored as float4) for A when TA and for B when !TB.
+    constexpr int SA_Q = 256 / BM, SA_P = (BK / 4) / SA_Q;                 // strided A: quads per pass, passes
+    constexpr int SB_Q = 256 / BN, SB_P = (BK / 4) / SB_Q;                 // strided B
+    constexpr int DA_R = 256 / (BM / 4), DA_P = BK / DA_R;                 // direct A: rows per pass, passes
+    constexpr int DB_R = 256 / (BN / 4), DB_P = BK / DB_R;                 // direct B
+    constexpr int NA = TA ? DA_P : SA_P, NB = TB ? SB_P : DB_P;
+    float4 ra[NA], rb[NB];
+
+    auto ld4 = [](const float* src, int have) -> float4 {               // up to 4 valid floats starting at src
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (have >= 4 && (((uintptr_t)src) & 15) == 0) return *(const float4*)src;
+        if (have > 0) v.x = src[0];
+        if (have > 1) v.y = src[1];
+        if (have > 2) v.z = src[2];
+        if (have > 3) v.w = src[3];
+        return v;
+    };
+    auto load_tiles = [&](int k0) {
+        if (!TA) {
+#pragma unroll
+            for (int p = 0; p < SA_P; ++p) {
+                const int kq = (tid / BM + p * SA_Q) * 4, m = m0 + tid % BM;
+                ra[p] = (m < M) ? ld4(A + (size_t)m * lda + k0 + kq, Kd - (k0 + kq)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < DA_P; ++p) {
+                const int k = k0 + tid / (BM / 4) + p * DA_R, m = m0 + (tid % (BM / 4)) * 4;
+                ra[p] = (k < Kd) ? ld4(A + (size_t)k * lda + m, M - m) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        if (!TB) {
+#pragma unroll
+            for (int p = 0; p < DB_P; ++p) {
+                const int k = k0 + tid / (BN / 4) + p * DB_R, n = n0 + (tid % (BN / 4)) * 4;
+                rb[p] = (k < Kd) ? ld4(W + (size_t)k * ldw + n, N - n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < SB_P; ++p) {
+                const int kq = (tid / BN + p * SB_Q) * 4, n = n0 + tid % BN;
+                rb[p] = (n < N) ? ld4(W + (size_t)n * ldw + k0 + kq, Kd - (k0 + kq)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        if (!TA) {
+#pragma unroll
+            for (int p = 0; p < SA_P; ++p) {
+                const int kq = (tid / BM + p * SA_Q) * 4, m = tid % BM;
+                As[buf][kq + 0][m] = ra[p].x; As[buf][kq + 1][m] = ra[p].y; As[buf][kq + 2][m] = ra[p].z; As[buf][kq + 3][m] = ra[p].w;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < DA_P; ++p) *(float4*)&As[buf][tid / (BM / 4) + p * DA_R][(tid % (BM / 4)) * 4] = ra[p];
+        }
+        if (!TB) {
+#pragma unroll
+            for (int p = 0; p < DB_P; ++p) *(float4*)&Bs[buf][tid / (BN / 4) + p * DB_R][(tid % (BN / 4)) * 4] = rb[p];
+        } else {
+#pragma unroll
+            for (int p = 0; p < SB_P; ++p) {
+                const int kq = (tid / BN + p * SB_Q) * 4, n = tid % BN;
+                Bs[buf][kq + 0][n] = rb[p].x; Bs[buf][kq + 1][n] = rb[p].y; Bs[buf][kq + 2][n] = rb[p].z; Bs[buf][kq + 3][n] = rb[p].w;
+            }
+        }
+    };
+
+    const int nk = (Kd + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tiles((kt + 1) * BK);              // global loads of the next tile fly under the MFMAs
+        const int li = lane & 31, lk = lane >> 5;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = As[buf][kk + lk][wm * 32 * TM + i * 32 + li];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = Bs[buf][kk + lk][wn * 32 * TN + j * 32 + li];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+    // epilogue: C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * 32 * TN + j * 32 + (lane & 31);
+            float bv = 0.0f;
+            if (EPI <= EPI_BIAS_TANH) bv = (col < N) ? ep.bias[(size_t)head * ep.strideBias + col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < M && col < N) {
+                    float v = acc[i][j][r];
+                    const size_t ci = (size_t)row * ldc + col;
+                    if (EPI == EPI_BIAS_ID) v += bv;
+                    else if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bv, 0.0f);
+                    else if (EPI == EPI_BIAS_TANH) v = tanh_fast(v + bv);
+                    else if (EPI == EPI_RELU_MASK) v = (ep.mask[(size_t)head * ep.strideMask + (size_t)row * ep.ldm + col] > 0.0f) ? v : 0.0f;
+                    if (EPI == EPI_ADAM) {                       // tf.train.AdamOptimizer update of one weight, gradient = v
+                        const size_t ai = (size_t)head * ep.strideAdam + ci;
+                        const float m1 = ep.beta1 * ep.am[ai] + (1.0f - ep.beta1) * v;
+                        const float v1 = ep.beta2 * ep.av[ai] + (1.0f - ep.beta2) * v * v;
+                        ep.am[ai] = m1; ep.av[ai] = v1;
+                        const float w = C[ci];
+                        C[ci] = w - ep.lr_t * m1 / (sqrtf(v1) + ep.eps) - ep.decay * w;
+                    } else {
+                        C[ci] = v;
+                    }
+                }
+            }
+        }
+}
+
+template <int TM, int TN, int EPI, bool TA, bool TB>
+static inline void gemm_mfma_launch(const float* A, long long sA, int lda, const float* W, long long sW, int ldw, float* C, long long sC,
+                                    int ldc, int M, int N, int Kd, int heads, const GemmEpi& ep, hipStream_t st) {
+    dim3 grid((N + 64 * TN - 1) / (64 * TN), (M + 64 * TM - 1) / (64 * TM), heads);
+    hipLaunchKernelGGL((k_gemm_mfma<TM, TN, EPI, TA, TB>), grid, dim3(256), 0, st, A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, ep);
+}

@@ -8,119 +8,7 @@
 //     k_big_post   thread per env: de-normalise + residual, sam_mode selection over the K heads, reward, done, reset
 // The weights are streamed from L2/HBM every step (K x 1-9 MB): the tile shape gives >= 128-fold reuse per fetched
 // weight, which keeps the kernel MFMA-bound (AI ~ 60 flop/B at B = 2500).
-#include "device_common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// ------------------------------------------------------------------------------------------------
-// C[b][M][N] = act(A[b][M][Kd] * W[b][Kd][N] + bias[b][N]);  strideA may be 0 (layer 0: all heads share the input)
-// block = 256 threads = 2x2 waves; wave tile = (32*TM) x (32*TN); block tile BM x BN = (64*TM) x (64*TN); BK = 16
-template <int TM, int TN, int ACT>
-__global__ void __launch_bounds__(256) k_gemm_bias_act(const float* __restrict__ A, long long strideA, int lda,
-                                                       const float* __restrict__ W, long long strideW, int ldw,
-                                                       const float* __restrict__ bias, long long strideB,
-                                                       float* __restrict__ C, long long strideC, int ldc, int M, int N, int Kd) {
-    constexpr int BM = 64 * TM, BN = 64 * TN, BK = 16;
-    __shared__ __attribute__((aligned(16))) float As[2][BK][BM + 4];     // transposed: As[k][m]
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + 4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int head = blockIdx.z;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    A += (size_t)head * strideA; W += (size_t)head * strideW; bias += (size_t)head * strideB; C += (size_t)head * strideC;
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    // staging maps.  A: thread -> (row m = tid % BM, k-quad = tid / BM), passes cover BK/4 quads.  B: (k = tid / (BN/4), n4 = tid % (BN/4))
-    constexpr int A_QUADS_PER_PASS = 256 / BM;                 // BM=128 -> 2 quads per pass, BM=64 -> 4
-    constexpr int A_PASSES = (BK / 4) / A_QUADS_PER_PASS;      // 2 or 1
-    constexpr int B_ROWS_PER_PASS = 256 / (BN / 4);            // BN=128 -> 8 rows, BN=64 -> 16
-    constexpr int B_PASSES = BK / B_ROWS_PER_PASS;             // 2 or 1
-    float4 ra[A_PASSES], rb[B_PASSES];
-    const int a_m = tid % BM, a_q = tid / BM;
-    const int b_n = (tid % (BN / 4)) * 4, b_k = tid / (BN / 4);
-
-    auto load_tiles = [&](int k0) {
-#pragma unroll
-        for (int p = 0; p < A_PASSES; ++p) {
-            const int kq = (a_q + p * A_QUADS_PER_PASS) * 4, m = m0 + a_m;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < M) {
-                const float* src = A + (size_t)m * lda + k0 + kq;
-                if (k0 + kq + 3 < Kd && (((uintptr_t)src) & 15) == 0) v = *(const float4*)src;
-                else { if (k0 + kq < Kd) v.x = src[0]; if (k0 + kq + 1 < Kd) v.y = src[1]; if (k0 + kq + 2 < Kd) v.z = src[2]; if (k0 + kq + 3 < Kd) v.w = src[3]; }
-            }
-            ra[p] = v;
-        }
-#pragma unroll
-        for (int p = 0; p < B_PASSES; ++p) {
-            const int k = k0 + b_k + p * B_ROWS_PER_PASS, n = n0 + b_n;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < Kd) {
-                const float* src = W + (size_t)k * ldw + n;
-                if (n + 3 < N && (((uintptr_t)src) & 15) == 0) v = *(const float4*)src;
-                else { if (n < N) v.x = src[0]; if (n + 1 < N) v.y = src[1]; if (n + 2 < N) v.z = src[2]; if (n + 3 < N) v.w = src[3]; }
-            }
-            rb[p] = v;
-        }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < A_PASSES; ++p) {
-            const int kq = (a_q + p * A_QUADS_PER_PASS) * 4;
-            As[buf][kq + 0][a_m] = ra[p].x; As[buf][kq + 1][a_m] = ra[p].y; As[buf][kq + 2][a_m] = ra[p].z; As[buf][kq + 3][a_m] = ra[p].w;
-        }
-#pragma unroll
-        for (int p = 0; p < B_PASSES; ++p) *(float4*)&Bs[buf][b_k + p * B_ROWS_PER_PASS][b_n] = rb[p];
-    };
-
-    const int nk = (Kd + BK - 1) / BK;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles((kt + 1) * BK);              // global loads of the next tile fly under the MFMAs
-        const int li = lane & 31, lk = lane >> 5;
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = As[buf][kk + lk][wm * 32 * TM + i * 32 + li];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = Bs[buf][kk + lk][wn * 32 * TN + j * 32 + li];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
-        __syncthreads();
-    }
-    // epilogue: C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * 32 * TN + j * 32 + (lane & 31);
-            const float bv = (col < N) ? bias[col] : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < M && col < N) {
-                    float v = acc[i][j][r] + bv;
-                    if (ACT == METRPO_ACT_RELU) v = fmaxf(v, 0.0f);
-                    else if (ACT == METRPO_ACT_TANH) v = tanh_fast(v);
-                    C[(size_t)row * ldc + col] = v;
-                }
-            }
-        }
-}
+#include "gemm_mfma.h"
 
 // ------------------------------------------------------------------------------------------------
 struct BigState { float* S; int* ts; int* cur_model; float* X; float* U; float* HA; float* HB; float* OUT; };
@@ -263,10 +151,11 @@ __global__ void k_big_post(ProblemDesc pd, RolloutK r, int t, const float* __res
 template <int TM, int TN>
 static void gemm_launch(int act, const float* A, long long sA, int lda, const float* W, long long sW, int ldw, const float* bias,
                         long long sB, float* C, long long sC, int ldc, int M, int N, int Kd, int heads, hipStream_t st) {
-    dim3 grid((N + 64 * TN - 1) / (64 * TN), (M + 64 * TM - 1) / (64 * TM), heads);
-    if (act == METRPO_ACT_RELU) hipLaunchKernelGGL((k_gemm_bias_act<TM, TN, METRPO_ACT_RELU>), grid, dim3(256), 0, st, A, sA, lda, W, sW, ldw, bias, sB, C, sC, ldc, M, N, Kd);
-    else if (act == METRPO_ACT_TANH) hipLaunchKernelGGL((k_gemm_bias_act<TM, TN, METRPO_ACT_TANH>), grid, dim3(256), 0, st, A, sA, lda, W, sW, ldw, bias, sB, C, sC, ldc, M, N, Kd);
-    else hipLaunchKernelGGL((k_gemm_bias_act<TM, TN, METRPO_ACT_IDENTITY>), grid, dim3(256), 0, st, A, sA, lda, W, sW, ldw, bias, sB, C, sC, ldc, M, N, Kd);
+    GemmEpi ep = {};
+    ep.bias = bias; ep.strideBias = sB;
+    if (act == METRPO_ACT_RELU) gemm_mfma_launch<TM, TN, EPI_BIAS_RELU, false, false>(A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, heads, ep, st);
+    else if (act == METRPO_ACT_TANH) gemm_mfma_launch<TM, TN, EPI_BIAS_TANH, false, false>(A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, heads, ep, st);
+    else gemm_mfma_launch<TM, TN, EPI_BIAS_ID, false, false>(A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, heads, ep, st);
 }
 
 bool gemm_path_applicable(const metrpo_ctx* c) {

@@ -441,7 +441,46 @@ def gen_stoplogic():
          upd1_real=np.array(cols[11]), upd1_tm=np.array(cols[12]), upd1_est=np.array(cols[13]))
 
 
+# ---------------------------------------------------------------- 9. replay buffer / batch slicing
+def gen_dynamics_data():
+    rng = np.random.RandomState(303)
+    dc = ref_utils.data_collection(max_size=50)
+    np.random.seed(99)
+    log = []
+    ops = [('add', 20), ('next', 8), ('next', 8), ('add', 25), ('next', 30), ('sample', 12), ('add', 30), ('next', 45), ('sample', 7),
+           ('next', 10)]
+    adds = []
+    for op, n in ops:
+        if op == 'add':
+            x, y = rng.randn(n, 5), rng.randn(n, 3)
+            adds.append((x, y))
+            dc.add_data(x, y)
+            log.append((0, n, dc.n_data, dc.cur_idx, dc.x.copy(), dc.y.copy()))
+        elif op == 'next':
+            xb, yb = dc.get_next_batch(n)
+            log.append((1, n, dc.n_data, dc.cur_idx, np.array(xb), np.array(yb)))
+        else:
+            xb, yb = dc.sample(n)
+            log.append((2, n, dc.n_data, dc.cur_idx, np.array(xb), np.array(yb)))
+    arrs = dict(ops=np.array([l[0] for l in log]), ns=np.array([l[1] for l in log]), n_data=np.array([l[2] for l in log]),
+                cur_idx=np.array([l[3] for l in log]), seed=np.array(99))
+    for i, l in enumerate(log):
+        arrs['x%d' % i], arrs['y%d' % i] = l[4], l[5]
+    for i, (x, y) in enumerate(adds):
+        arrs['addx%d' % i], arrs['addy%d' % i] = x, y
+    # which samples of a (batch*K, d) block each model sees (model_based_rl.py:961-970 + utils.get_ith_tensor)
+    K, bs, d, dy = 3, 4, 5, 3
+    xb, yb = rng.randn(bs * K, d), rng.randn(bs * K, dy)
+    xf, yf = np.reshape(xb, (bs, -1)), np.reshape(yb, (bs, -1))
+    arrs.update(split_x=xb, split_y=yb, split_K=np.array(K), split_bs=np.array(bs),
+                **{'mx%d' % i: np.array(ref_utils.get_ith_tensor(xf, i, d)) for i in range(K)},
+                **{'my%d' % i: np.array(ref_utils.get_ith_tensor(yf, i, dy)) for i in range(K)})
+    arrs['baseline_loss'] = np.array(ref_mbrl.compute_baseline_loss(xb, yb, K))
+    save('dyn_data', **arrs)
+
+
 if __name__ == '__main__':
+    gen_dynamics_data()
     gen_rewards()
     gen_vecenv()
     gen_sampler()
