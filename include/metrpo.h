@@ -227,6 +227,37 @@ typedef struct {                 /* host-side diagnostics of one optimize() call
 int32_t metrpo_trpo_update(metrpo_ctx* ctx, const metrpo_batch* batch, const metrpo_trpo_params* params,
                            metrpo_trpo_diag* diag, double* d_g_out, double* d_dir_out, void* stream);
 
+/* ---- "next" rows of the scope table: ensemble dynamics training + normaliser statistics ---- */
+typedef struct {
+    double lr;                   /* dynamics_opt_params.learning_rate["scratch"|"refine"] (model_based_rl.py:905-918)      */
+    double beta1, beta2, eps;    /* tf.train.AdamOptimizer defaults 0.9, 0.999, 1e-8 (:162)                                */
+    double reg_constant;         /* dynamics_model.regularization.constant (training.py:271-282); SGD(lr) on it (:169-177) */
+    int32_t batch_size;          /* dynamics_opt_params.batch_size: rows PER MODEL                                         */
+} metrpo_train_params;
+
+/* sess.run(dynamics_adam_init) (model_based_rl.py:912-918): zero the Adam moments and the step count. */
+int32_t metrpo_dyn_train_reset(metrpo_ctx* ctx, void* stream);
+/* One sess.run([dynamics_opt_op, dynamics_loss]) (model_based_rl.py:961-971; loss graph :39-71; optimizers :154-183).
+ * d_x [batch_size*K][ns+na] = (state, action), d_y [batch_size*K][ns] = next state; the block is consumed as the
+ * reference's np.reshape(x_batch, (batch_size, -1)) + utils.get_ith_tensor: model i trains on rows i, K+i, 2K+i, ...
+ * The ctx dynamics weights are updated in place.  d_loss_out [K] float64 (optional): per-model loss BEFORE the update. */
+int32_t metrpo_dyn_train_step(metrpo_ctx* ctx, const float* d_x, const float* d_y, const metrpo_train_params* params,
+                              double* d_loss_out, void* stream);
+/* dynamics_losses on np.tile(validation, n_models) (model_based_rl.py:933-945, 977-983): every model on all n rows.
+ * d_losses [K] float64 = prediction loss + regulariser per model. */
+int32_t metrpo_dyn_eval_losses(metrpo_ctx* ctx, const float* d_x, const float* d_y, int64_t n, double reg_constant,
+                               double* d_losses, void* stream);
+/* per-model savers (model_based_rl.py:499-509, 927-930, 1002-1004; recover_weights :871-878): read all / write one model. */
+int32_t metrpo_get_dynamics(metrpo_ctx* ctx, float* d_params_out, void* stream);
+int32_t metrpo_set_dynamics_model(metrpo_ctx* ctx, int32_t model, const float* d_params_model, void* stream);
+/* RunningMeanStd read-outs changed (after input_rms.update / output_rms.update, model_based_rl.py:834-835). COPIES. */
+int32_t metrpo_set_normalizers(metrpo_ctx* ctx, const float* d_in_mean, const float* d_in_std, const float* d_diff_mean,
+                               const float* d_diff_std, void* stream);
+/* RunningMeanStd.update (running_mean_std.py:35-42): d_sum[dim] += sum_rows x, d_sumsq[dim] += sum_rows x^2 (float64);
+ * count += n, mean and the 0.1-floored std are the caller's (running_mean_std.py:22-27). */
+int32_t metrpo_rms_accumulate(metrpo_ctx* ctx, const float* d_x, int64_t n, int32_t dim, double* d_sum, double* d_sumsq,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,8 @@ from .sampler import VectorizedSampler, BaseSampler, DevicePaths
 from .optimizer import ConjugateGradientOptimizer
 from .algos import BatchPolopt, NPO, TRPO
 from . import early_stop
+from . import dynamics_training
 
 __all__ = ['Engine', 'Trajectory', 'xavier_policy_theta', 'Comm', 'NeuralNetEnv', 'VecSimpleEnv', 'InitStatePool',
            'Box', 'EnvSpec', 'GaussianMLPPolicy', 'LinearFeatureBaseline', 'VectorizedSampler', 'BaseSampler',
-           'DevicePaths', 'ConjugateGradientOptimizer', 'BatchPolopt', 'NPO', 'TRPO', 'early_stop']
+           'DevicePaths', 'ConjugateGradientOptimizer', 'BatchPolopt', 'NPO', 'TRPO', 'early_stop', 'dynamics_training']

@@ -44,6 +44,11 @@ class TrpoParams(C.Structure):
                 ('residual_tol', C.c_double), ('allreduce', ALLREDUCE_FN), ('allreduce_user', C.c_void_p)]
 
 
+class TrainParams(C.Structure):
+    _fields_ = [('lr', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double), ('eps', C.c_double),
+                ('reg_constant', C.c_double), ('batch_size', C.c_int32)]
+
+
 class TrpoDiag(C.Structure):
     _fields_ = [('loss_before', C.c_double), ('loss', C.c_double), ('kl', C.c_double), ('beta', C.c_double),
                 ('n_backtrack', C.c_int32), ('accepted', C.c_int32), ('cg_iters_run', C.c_int32)]
@@ -73,6 +78,13 @@ SYMBOLS = {
     'metrpo_fvp': (_I, [_P, C.POINTER(Batch), _P, _P, _P]),
     'metrpo_loss_kl': (_I, [_P, C.POINTER(Batch), _P, _P, _P]),
     'metrpo_trpo_update': (_I, [_P, C.POINTER(Batch), C.POINTER(TrpoParams), C.POINTER(TrpoDiag), _P, _P, _P]),
+    'metrpo_dyn_train_reset': (_I, [_P, _P]),
+    'metrpo_dyn_train_step': (_I, [_P, _P, _P, C.POINTER(TrainParams), _P, _P]),
+    'metrpo_dyn_eval_losses': (_I, [_P, _P, _P, _L, _D, _P, _P]),
+    'metrpo_get_dynamics': (_I, [_P, _P, _P]),
+    'metrpo_set_dynamics_model': (_I, [_P, _I, _P, _P]),
+    'metrpo_set_normalizers': (_I, [_P, _P, _P, _P, _P, _P]),
+    'metrpo_rms_accumulate': (_I, [_P, _P, _L, _I, _P, _P, _P]),
 }
 # diagnostics hooks exported besides the header's ABI (used by tests to cross-check the two rollout kernels)
 EXTRA_SYMBOLS = {

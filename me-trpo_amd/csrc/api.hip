@@ -75,7 +75,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     c->d_dyn_img = c->d_pol_img = nullptr; c->mfma_cfg = -1; c->pol_mfma = -1; c->coop_cfg = -1; c->rollout_variant = 0;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_cg = nullptr; c->d_vf = nullptr; c->d_theta_try = nullptr;
     c->d_valbuf = nullptr; c->h_pinned = nullptr; c->n_sm = 256;
-    c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0; c->d_ticket = nullptr;
+    c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0; c->d_ticket = nullptr; c->d_adam = nullptr; c->adam_t = 0; c->d_train = nullptr; c->train_cap = 0;
     ProblemDesc& pd = c->pd;
     pd.env = d->env; pd.ns = d->ns; pd.na = d->na; pd.K = d->n_models; pd.n_drop = d->n_drop;
     pd.nin = d->ns + d->na - d->n_drop;
@@ -112,7 +112,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
 extern "C" int32_t metrpo_destroy(metrpo_ctx* c) {
     if (!c) return METRPO_ENULL;
     void* bufs[] = {c->d_dyn, c->d_norm, c->d_theta, c->d_vf, c->d_theta_try, c->d_cg, c->d_valbuf, c->d_partials,
-                    c->d_dyn_img, c->d_pol_img, c->d_vbuf, c->d_gram_part, c->d_big, c->d_ticket};
+                    c->d_dyn_img, c->d_pol_img, c->d_vbuf, c->d_gram_part, c->d_big, c->d_ticket, c->d_adam, c->d_train};
     for (void* p : bufs) if (p) (void)hipFree(p);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     delete c;
@@ -282,6 +282,74 @@ extern "C" int32_t metrpo_loss_kl(metrpo_ctx* c, const metrpo_batch* b, const fl
     NEED_POL(c);
     if (!out) return set_err(c, METRPO_ENULL, "loss_kl: out NULL");
     return launch_loss_kl(c, b, theta, out, (hipStream_t)stream);
+}
+
+// ---- ensemble dynamics training ----------------------------------------------------------
+extern "C" int32_t metrpo_dyn_train_reset(metrpo_ctx* c, void* stream) {
+    if (!c) return METRPO_ENULL;
+    c->adam_t = 0;
+    if (c->d_adam) {
+        const size_t nP = (((size_t)c->pd.K * c->pd.dyn.n_params) + 3) & ~(size_t)3;
+        HIP_TRY(c, hipMemsetAsync(c->d_adam, 0, 2 * nP * sizeof(float), (hipStream_t)stream));
+    }
+    return METRPO_OK;
+}
+
+extern "C" int32_t metrpo_dyn_train_step(metrpo_ctx* c, const float* x, const float* y, const metrpo_train_params* tp, double* loss_out,
+                                         void* stream) {
+    if (!c) return METRPO_ENULL;
+    NEED_DYN(c);
+    if (!x || !y || !tp) return set_err(c, METRPO_ENULL, "dyn_train_step: NULL pointer");
+    if (tp->batch_size <= 0 || !(tp->lr >= 0.0)) return set_err(c, METRPO_EINVAL, "dyn_train_step: bad batch_size / lr");
+    return launch_dyn_train_step(c, x, y, tp, loss_out, (hipStream_t)stream);
+}
+
+extern "C" int32_t metrpo_dyn_eval_losses(metrpo_ctx* c, const float* x, const float* y, int64_t n, double reg_constant, double* losses,
+                                          void* stream) {
+    if (!c) return METRPO_ENULL;
+    NEED_DYN(c);
+    if (!x || !y || !losses) return set_err(c, METRPO_ENULL, "dyn_eval_losses: NULL pointer");
+    if (n <= 0) return set_err(c, METRPO_EINVAL, "dyn_eval_losses: n must be positive");
+    return launch_dyn_eval_losses(c, x, y, n, reg_constant, losses, (hipStream_t)stream);
+}
+
+extern "C" int32_t metrpo_get_dynamics(metrpo_ctx* c, float* out, void* stream) {
+    if (!c) return METRPO_ENULL;
+    NEED_DYN(c);
+    if (!out) return set_err(c, METRPO_ENULL, "get_dynamics: NULL pointer");
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_dyn, sizeof(float) * (size_t)c->pd.K * c->pd.dyn.n_params, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return METRPO_OK;
+}
+
+extern "C" int32_t metrpo_set_dynamics_model(metrpo_ctx* c, int32_t model, const float* p, void* stream) {
+    if (!c) return METRPO_ENULL;
+    NEED_DYN(c);
+    if (!p) return set_err(c, METRPO_ENULL, "set_dynamics_model: NULL pointer");
+    if (model < 0 || model >= c->pd.K) return set_err(c, METRPO_EINVAL, "set_dynamics_model: model index out of range");
+    HIP_TRY(c, hipMemcpyAsync(c->d_dyn + (size_t)model * c->pd.dyn.n_params, p, sizeof(float) * c->pd.dyn.n_params, hipMemcpyDeviceToDevice,
+                              (hipStream_t)stream));
+    return METRPO_OK;
+}
+
+extern "C" int32_t metrpo_set_normalizers(metrpo_ctx* c, const float* in_mean, const float* in_std, const float* diff_mean,
+                                          const float* diff_std, void* stream) {
+    if (!c) return METRPO_ENULL;
+    if (!in_mean || !in_std || !diff_mean || !diff_std) return set_err(c, METRPO_ENULL, "set_normalizers: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int nx = c->pd.ns + c->pd.na, ns = c->pd.ns;
+    HIP_TRY(c, hipMemcpyAsync(c->d_norm, in_mean, sizeof(float) * nx, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_norm + nx, in_std, sizeof(float) * nx, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_norm + 2 * nx, diff_mean, sizeof(float) * ns, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_norm + 2 * nx + ns, diff_std, sizeof(float) * ns, hipMemcpyDeviceToDevice, st));
+    return METRPO_OK;
+}
+
+extern "C" int32_t metrpo_rms_accumulate(metrpo_ctx* c, const float* x, int64_t n, int32_t dim, double* rsum, double* rsumsq, void* stream) {
+    if (!c) return METRPO_ENULL;
+    if (!x || !rsum || !rsumsq) return set_err(c, METRPO_ENULL, "rms_accumulate: NULL pointer");
+    if (n < 0 || dim <= 0) return set_err(c, METRPO_EINVAL, "rms_accumulate: bad n / dim");
+    if (n == 0) return METRPO_OK;
+    return launch_rms_accumulate(c, x, n, dim, rsum, rsumsq, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------

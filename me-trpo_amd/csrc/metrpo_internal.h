@@ -53,6 +53,10 @@ struct metrpo_ctx {
     double* d_gram_part; // per-block Gram partials (process.hip)
     size_t gram_cap;
     unsigned int* d_ticket; // arrival counter of k_finalize's fused CG tail
+    void* d_adam;        // Adam moments [2][K][Pd] + loss accumulators (dyn_train.hip)
+    long long adam_t;    // Adam step count
+    void* d_train;       // training activation workspace
+    size_t train_cap;
     void* d_big;         // workspace of the GEMM step-wise rollout (rollout_gemm.hip)
     size_t big_cap;
     double* h_pinned;    // pinned host scratch for the per-trial read-back
@@ -96,6 +100,9 @@ int launch_step(metrpo_ctx*, const float*, const float*, int, int, const int32_t
 int launch_rollout_generic(metrpo_ctx*, const metrpo_rollout_args*, hipStream_t);
 bool gemm_path_applicable(const metrpo_ctx*);
 int launch_rollout_gemm(metrpo_ctx*, const metrpo_rollout_args*, hipStream_t);
+int launch_dyn_train_step(metrpo_ctx*, const float*, const float*, const metrpo_train_params*, double*, hipStream_t);
+int launch_dyn_eval_losses(metrpo_ctx*, const float*, const float*, long long, double, double*, hipStream_t);
+int launch_rms_accumulate(metrpo_ctx*, const float*, long long, int, double*, double*, hipStream_t);
 int launch_rollout_mfma(metrpo_ctx*, const metrpo_rollout_args*, hipStream_t);   // returns METRPO_EUNSUPPORTED if no instantiation fits
 int mfma_prepare_dynamics(metrpo_ctx*, hipStream_t);
 int mfma_prepare_policy(metrpo_ctx*, hipStream_t);

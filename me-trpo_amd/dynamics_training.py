@@ -1,0 +1,164 @@
+"""Ensemble dynamics training, replay buffer and running normalisers -- the "next" rows of the scope table
+(SURVEY.md 8f rank 1-2), mirroring the reference's interface:
+
+    data_collection(max_size)                       utils.py:44-131     (FIFO replay buffer; add_data / get_next_batch / sample)
+    RunningMeanStd(epsilon, shape)                  running_mean_std.py (sum / sumsq / count; mean; std floored at 0.1)
+    optimize_models(...)                            model_based_rl.py:881-1051 (one scope)
+
+Data lives on the GPU; batch index selection keeps the reference's host-side NumPy semantics (np.random.uniform stream),
+the gather, the K-head forward/backward/Adam step and the validation losses run in libmetrpo.so (dyn_train.hip)."""
+import numpy as np
+import torch
+
+
+class data_collection(object):
+    def __init__(self, max_size=int(5e4), device=None):
+        self.cur_idx, self.x, self.y, self.n_data, self.max_size = 0, None, None, None, max_size
+        self.device = device
+
+    def _t(self, a):
+        return torch.as_tensor(np.asarray(a), dtype=torch.float32, device=self.device) if not isinstance(a, torch.Tensor) else a.to(self.device, torch.float32)
+
+    def cap_data_size(self):
+        new_start_idx = self.x.shape[0] - self.max_size
+        if new_start_idx > 0:
+            self.x, self.y = self.x[new_start_idx:].contiguous(), self.y[new_start_idx:].contiguous()
+            self.n_data = self.max_size
+            self.cur_idx -= new_start_idx
+
+    def add_data(self, x_new, y_new, is_shuffled=False):
+        x_new, y_new = self._t(x_new), self._t(y_new)
+        assert x_new.shape[0] == y_new.shape[0]
+        if self.x is not None:
+            self.cur_idx = self.x.shape[0]                       # point to new data
+            self.x, self.y = torch.cat([self.x, x_new]), torch.cat([self.y, y_new])
+        else:
+            self.cur_idx, self.x, self.y = 0, x_new, y_new
+        self.n_data = self.x.shape[0]
+        self.cap_data_size()
+
+    def get_num_data(self):
+        return 0 if self.n_data is None else self.n_data
+
+    def _gather(self, indices):
+        idx = torch.as_tensor(np.asarray(indices, dtype=np.int64), device=self.x.device)
+        return self.x.index_select(0, idx), self.y.index_select(0, idx)
+
+    def get_next_batch(self, batch_size, is_shuffled=False):
+        assert batch_size <= self.n_data, "Batch size %d is larger than n_data %d" % (batch_size, self.n_data)
+        start_idx, end_idx = self.cur_idx, self.cur_idx + batch_size
+        if end_idx > self.n_data:
+            indices = list(range(start_idx, self.n_data)) + list(range(0, batch_size - (self.n_data - start_idx)))
+            self.cur_idx = batch_size - (self.n_data - start_idx)
+        else:
+            indices = list(range(start_idx, end_idx))
+            self.cur_idx = end_idx
+        return self._gather(indices)
+
+    def sample(self, batch_size):
+        """Uniformly random batch with replacement -- same np.random.uniform draw as utils.py:127-129."""
+        indices = np.floor(self.n_data * np.random.uniform(0.0, 1.0, size=batch_size)).astype(np.intp)
+        return self._gather(indices)
+
+
+class RunningMeanStd(object):
+    def __init__(self, engine, epsilon=1e-2, shape=()):
+        self.engine = engine
+        n = int(np.prod(shape))
+        self._sum = torch.zeros(n, dtype=torch.float64, device=engine.device)
+        self._sumsq = torch.full((n,), float(epsilon), dtype=torch.float64, device=engine.device)
+        self._count = float(epsilon)
+
+    def update(self, x):
+        x = torch.as_tensor(x, device=self.engine.device)
+        self.engine.rms_accumulate(x, self._sum, self._sumsq)
+        self._count += x.shape[0]
+
+    @property
+    def mean(self):
+        return (self._sum / self._count).to(torch.float32)
+
+    @property
+    def std(self):
+        m = self._sum / self._count
+        return torch.sqrt(torch.clamp(self._sumsq / self._count - m * m, min=1e-2)).to(torch.float32)
+
+
+def push_normalizers(engine, input_rms, diff_rms):
+    """training.py:228,257: the dynamics model reads input_rms.mean/std and diff_rms.mean/std[:ns]."""
+    ns = engine.ns
+    engine.set_normalizers(input_rms.mean, input_rms.std, diff_rms.mean[:ns], diff_rms.std[:ns])
+
+
+def xavier_reinitialize(engine, seed=None):
+    """dynamics_initializer (model_based_rl.py:906-918): Xavier-uniform weights AND biases (training.py:179,191-194)."""
+    rng = np.random.RandomState(seed)
+    dims = [engine.ns + engine.na - engine.n_drop] + list(engine.dyn_hidden) + [engine.ns]
+    parts = []
+    for l in range(len(dims) - 1):
+        lim_w = np.sqrt(6.0 / (dims[l] + dims[l + 1])); lim_b = np.sqrt(6.0 / (2 * dims[l + 1]))
+        parts += [rng.uniform(-lim_w, lim_w, size=(engine.K, dims[l] * dims[l + 1])), rng.uniform(-lim_b, lim_b, size=(engine.K, dims[l + 1]))]
+    params = torch.as_tensor(np.concatenate(parts, axis=1), dtype=torch.float32, device=engine.device)
+    for k in range(engine.K):
+        engine.set_dynamics_model(k, params[k])
+
+
+def optimize_models(engine, dynamics_data, dynamics_validation, learning_rate, batch_size=1000, max_passes=2000, log_every=5,
+                    num_passes_threshold=25, reinitialize=False, sample_mode='random', reg_constant=0.0, init_seed=None, logger=None):
+    """model_based_rl.py:881-1051 for one scope.  learning_rate = {"scratch":..., "refine":...}; returns the reference's
+    bookkeeping (training/validation losses, best index) plus '# model updates'."""
+    K = engine.K
+    lr = learning_rate
+    if reinitialize:
+        cur_lr = lr["scratch"]
+        xavier_reinitialize(engine, init_seed)
+    else:
+        cur_lr = lr["refine"]
+    engine.train_reset()                                                   # dynamics_adam_init
+    snapshot = engine.get_dynamics().clone()                               # savers[scope][i].save(...), :927-930
+    x_val, y_val = dynamics_validation.x, dynamics_validation.y           # np.tile(val, n_models): every model sees all of it
+    min_validation_losses = engine.eval_losses(x_val, y_val, reg_constant).cpu().numpy()
+    min_sum_validation_loss = float(np.sum(min_validation_losses))
+    recover_indices, refine_idx, best_j = np.zeros(K), -1, 0
+    training_losses, validation_losses = [], []
+    iter_const = dynamics_data.n_data / batch_size
+    max_iters = int(max_passes * iter_const)
+    log_every_it = max(1, int(log_every * iter_const))
+    num_iters_threshold = int(num_passes_threshold * iter_const)
+    j = 0
+    for j in range(1, max_iters + 1):
+        if sample_mode == 'next_batch':
+            x_batch, y_batch = dynamics_data.get_next_batch(batch_size * K, is_shuffled=False)
+        else:
+            assert sample_mode == 'random'
+            x_batch, y_batch = dynamics_data.sample(batch_size * K)
+        want = (j % log_every_it == 0)
+        tl = engine.train_step(x_batch, y_batch, batch_size, cur_lr, reg_constant, want_loss=want)
+        if want:                                                           # validation and logging, :974-1031
+            training_losses.append(float(tl.sum().item()))
+            _validation_losses = engine.eval_losses(x_val, y_val, reg_constant).cpu().numpy()
+            validation_loss = float(np.sum(_validation_losses))
+            validation_losses.append(validation_loss)
+            if logger:
+                logger('iter %d train %.5f val %.5f' % (j, training_losses[-1], validation_loss))
+            if min_sum_validation_loss > validation_loss:
+                min_sum_validation_loss, best_j = validation_loss, j
+            to_update = min_validation_losses > _validation_losses
+            min_validation_losses[to_update] = _validation_losses[to_update]
+            if to_update.any():
+                cur = engine.get_dynamics()
+                for i in np.nonzero(to_update)[0]:
+                    snapshot[i].copy_(cur[i])                              # per-model saver, :1002-1004
+                    recover_indices[i] = j
+            if j - max(np.amax(recover_indices), refine_idx) >= num_iters_threshold:
+                if reinitialize and refine_idx < 0 and lr["scratch"] > lr["refine"]:
+                    for i in range(K):                                     # recover_weights, then refine with the smaller rate
+                        engine.set_dynamics_model(i, snapshot[i])
+                    cur_lr, refine_idx = lr["refine"], j
+                    continue
+                break
+    for i in range(K):                                                     # recover_weights (:1034), :871-878
+        engine.set_dynamics_model(i, snapshot[i])
+    return {'training_losses': training_losses, 'validation_losses': validation_losses, 'best_index': best_j,
+            'n_model_updates': j, 'min_sum_validation_loss': min_sum_validation_loss,
+            'min_validation_losses': min_validation_losses, 'recover_indices': recover_indices}

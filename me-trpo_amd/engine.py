@@ -282,6 +282,51 @@ class Engine(object):
         return out
 
 
+    # ------------------------------------------------------------------ ensemble dynamics training
+    def get_dynamics(self):
+        out = torch.empty(self.K, self.dyn_param_count, dtype=torch.float32, device=self.device)
+        self._chk(lib.metrpo_get_dynamics(self._ctx, _ptr(out), self._stream()))
+        return out
+
+    def set_dynamics_model(self, k, params_k):
+        p = _f32(params_k, self.device, (self.dyn_param_count,))
+        self._chk(lib.metrpo_set_dynamics_model(self._ctx, int(k), _ptr(p), self._stream()))
+        self._keep_model = p
+
+    def set_normalizers(self, in_mean, in_std, diff_mean, diff_std):
+        dev = self.device
+        a = _f32(in_mean, dev, (self.ns + self.na,)); b = _f32(in_std, dev, (self.ns + self.na,))
+        c = _f32(diff_mean, dev, (self.ns,)); e = _f32(diff_std, dev, (self.ns,))
+        self._chk(lib.metrpo_set_normalizers(self._ctx, _ptr(a), _ptr(b), _ptr(c), _ptr(e), self._stream()))
+        torch.cuda.current_stream(dev).synchronize()
+
+    def train_reset(self):
+        self._chk(lib.metrpo_dyn_train_reset(self._ctx, self._stream()))
+
+    def train_step(self, x, y, batch_size, lr, reg_constant=0.0, beta1=0.9, beta2=0.999, eps=1e-8, want_loss=True):
+        """x [batch_size*K, ns+na], y [batch_size*K, ns] device tensors; returns per-model losses (before the update)."""
+        dev = self.device
+        x = _f32(x, dev, (batch_size * self.K, self.ns + self.na)); y = _f32(y, dev, (batch_size * self.K, self.ns))
+        tp = _lib.TrainParams(lr, beta1, beta2, eps, reg_constant, batch_size)
+        loss = torch.empty(self.K, dtype=torch.float64, device=dev) if want_loss else None
+        self._chk(lib.metrpo_dyn_train_step(self._ctx, _ptr(x), _ptr(y), C.byref(tp), _ptr(loss), self._stream()))
+        self._keep_train = (x, y)
+        return loss
+
+    def eval_losses(self, x, y, reg_constant=0.0):
+        dev = self.device
+        x = _f32(x, dev); y = _f32(y, dev, (x.shape[0], self.ns))
+        out = torch.empty(self.K, dtype=torch.float64, device=dev)
+        self._chk(lib.metrpo_dyn_eval_losses(self._ctx, _ptr(x), _ptr(y), x.shape[0], float(reg_constant), _ptr(out), self._stream()))
+        self._keep_eval = (x, y)
+        return out
+
+    def rms_accumulate(self, x, rsum, rsumsq):
+        x = _f32(x, self.device)
+        self._chk(lib.metrpo_rms_accumulate(self._ctx, _ptr(x), x.shape[0], x.shape[1], _ptr(rsum), _ptr(rsumsq), self._stream()))
+        self._keep_rms = x
+
+
 class _DevView(object):
     """Zero-copy float64 view of library-owned device memory for torch (CUDA array interface)."""
 
