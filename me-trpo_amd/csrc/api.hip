@@ -27,7 +27,7 @@ extern "C" const char* metrpo_status_string(int32_t s) {
 }
 
 static bool build_net(NetDesc* n, int n_in, const int32_t* hidden, const int32_t* acts, int n_hidden, int n_out,
-                      int default_act) {
+                      int default_act, bool align16) {
     if (n_hidden < 0 || n_hidden > METRPO_MAX_LAYERS || n_in <= 0 || n_out <= 0) return false;
     n->n_layers = n_hidden + 1;
     n->dims[0] = n_in;
@@ -39,13 +39,17 @@ static bool build_net(NetDesc* n, int n_in, const int32_t* hidden, const int32_t
     }
     n->dims[n_hidden + 1] = n_out;
     n->act[n_hidden] = METRPO_ACT_IDENTITY;
-    int off = 0, mw = 0;
+    int off = 0, aoff = 0, mw = 0;
+    auto up = [&](int v) { return align16 ? ((v + 3) & ~3) : v; };
     for (int l = 0; l < n->n_layers; ++l) {
-        n->w_off[l] = off; off += n->dims[l] * n->dims[l + 1];
-        n->b_off[l] = off; off += n->dims[l + 1];
+        n->w_off[l] = off; off = up(off + n->dims[l] * n->dims[l + 1]);
+        n->b_off[l] = off; off = up(off + n->dims[l + 1]);
+        n->api_w_off[l] = aoff; aoff += n->dims[l] * n->dims[l + 1];
+        n->api_b_off[l] = aoff; aoff += n->dims[l + 1];
     }
     for (int l = 0; l <= n->n_layers; ++l) mw = std::max(mw, n->dims[l]);
     n->n_params = off;
+    n->api_n_params = aoff;
     n->max_width = mw;
     return true;
 }
@@ -59,6 +63,28 @@ static CgView cg_view(metrpo_ctx* c) {
     v.scal = v.step + P; v.lk = v.scal + 8;
     return v;
 }
+
+// Dense caller-visible dynamics layout <-> 16-byte aligned resident layout (NetDesc).  grid = (blocks, n_models).
+struct RepackDesc { int n_seg; int api_off[2 * MAXL], dev_off[2 * MAXL], len[2 * MAXL]; int api_stride, dev_stride; };
+__global__ void k_repack_dyn(RepackDesc d, const float* __restrict__ src, float* __restrict__ dst, int to_device) {
+    const int k = blockIdx.y;
+    for (int s = 0; s < d.n_seg; ++s) {
+        const float* a = src + (size_t)k * (to_device ? d.api_stride : d.dev_stride) + (to_device ? d.api_off[s] : d.dev_off[s]);
+        float* b = dst + (size_t)k * (to_device ? d.dev_stride : d.api_stride) + (to_device ? d.dev_off[s] : d.api_off[s]);
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.len[s]; i += gridDim.x * blockDim.x) b[i] = a[i];
+    }
+}
+static void repack_dyn(const metrpo_ctx* c, const float* src, float* dst, int n_models, bool to_device, hipStream_t st) {
+    const NetDesc& n = c->pd.dyn;
+    RepackDesc d;
+    d.n_seg = 2 * n.n_layers; d.api_stride = n.api_n_params; d.dev_stride = n.n_params;
+    for (int l = 0; l < n.n_layers; ++l) {
+        d.api_off[2 * l] = n.api_w_off[l]; d.dev_off[2 * l] = n.w_off[l]; d.len[2 * l] = n.dims[l] * n.dims[l + 1];
+        d.api_off[2 * l + 1] = n.api_b_off[l]; d.dev_off[2 * l + 1] = n.b_off[l]; d.len[2 * l + 1] = n.dims[l + 1];
+    }
+    hipLaunchKernelGGL(k_repack_dyn, dim3(64, n_models), dim3(256), 0, st, d, src, dst, to_device ? 1 : 0);
+}
+
 
 extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_dims* d) {
     if (!out || !d) return METRPO_ENULL;
@@ -79,8 +105,8 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     ProblemDesc& pd = c->pd;
     pd.env = d->env; pd.ns = d->ns; pd.na = d->na; pd.K = d->n_models; pd.n_drop = d->n_drop;
     pd.nin = d->ns + d->na - d->n_drop;
-    if (!build_net(&pd.dyn, pd.nin, d->dyn_hidden, d->dyn_act, d->dyn_n_hidden, d->ns, METRPO_ACT_RELU) ||
-        !build_net(&pd.pol, d->ns, d->pol_hidden, nullptr, d->pol_n_hidden, d->na, METRPO_ACT_TANH)) {
+    if (!build_net(&pd.dyn, pd.nin, d->dyn_hidden, d->dyn_act, d->dyn_n_hidden, d->ns, METRPO_ACT_RELU, true) ||
+        !build_net(&pd.pol, d->ns, d->pol_hidden, nullptr, d->pol_n_hidden, d->na, METRPO_ACT_TANH, false)) {
         delete c;
         return METRPO_EINVAL;
     }
@@ -102,6 +128,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
         c->err = "device allocation failed";
         return METRPO_EHIP;
     }
+    if (hipMemset(c->d_dyn, 0, sizeof(float) * (size_t)pd.K * pd.dyn.n_params) != hipSuccess) { c->err = "hipMemset failed"; return METRPO_EHIP; }
     c->mfma_cfg = mfma_select_config(c);
     c->pol_mfma = policy_mfma_select(pd);
     c->coop_cfg = coop_select_config(c);
@@ -120,7 +147,7 @@ extern "C" int32_t metrpo_destroy(metrpo_ctx* c) {
 }
 
 extern "C" const char* metrpo_last_error(const metrpo_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
-extern "C" int32_t metrpo_dyn_param_count(const metrpo_ctx* c) { return c ? c->pd.dyn.n_params : METRPO_ENULL; }
+extern "C" int32_t metrpo_dyn_param_count(const metrpo_ctx* c) { return c ? c->pd.dyn.api_n_params : METRPO_ENULL; }
 extern "C" int32_t metrpo_policy_param_count(const metrpo_ctx* c) { return c ? c->pd.P : METRPO_ENULL; }
 
 extern "C" int32_t metrpo_set_dynamics(metrpo_ctx* c, const float* p, const float* in_mean, const float* in_std,
@@ -130,7 +157,7 @@ extern "C" int32_t metrpo_set_dynamics(metrpo_ctx* c, const float* p, const floa
     hipStream_t st = (hipStream_t)stream;
     const ProblemDesc& pd = c->pd;
     const int nx = pd.ns + pd.na;
-    HIP_TRY(c, hipMemcpyAsync(c->d_dyn, p, sizeof(float) * (size_t)pd.K * pd.dyn.n_params, hipMemcpyDeviceToDevice, st));
+    repack_dyn(c, p, c->d_dyn, pd.K, true, st);
     HIP_TRY(c, hipMemcpyAsync(c->d_norm, in_mean, sizeof(float) * nx, hipMemcpyDeviceToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->d_norm + nx, in_std, sizeof(float) * nx, hipMemcpyDeviceToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->d_norm + 2 * nx, diff_mean, sizeof(float) * pd.ns, hipMemcpyDeviceToDevice, st));
@@ -317,7 +344,8 @@ extern "C" int32_t metrpo_get_dynamics(metrpo_ctx* c, float* out, void* stream) 
     if (!c) return METRPO_ENULL;
     NEED_DYN(c);
     if (!out) return set_err(c, METRPO_ENULL, "get_dynamics: NULL pointer");
-    HIP_TRY(c, hipMemcpyAsync(out, c->d_dyn, sizeof(float) * (size_t)c->pd.K * c->pd.dyn.n_params, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    repack_dyn(c, c->d_dyn, out, c->pd.K, false, (hipStream_t)stream);
+    HIP_TRY(c, hipGetLastError());
     return METRPO_OK;
 }
 
@@ -326,8 +354,8 @@ extern "C" int32_t metrpo_set_dynamics_model(metrpo_ctx* c, int32_t model, const
     NEED_DYN(c);
     if (!p) return set_err(c, METRPO_ENULL, "set_dynamics_model: NULL pointer");
     if (model < 0 || model >= c->pd.K) return set_err(c, METRPO_EINVAL, "set_dynamics_model: model index out of range");
-    HIP_TRY(c, hipMemcpyAsync(c->d_dyn + (size_t)model * c->pd.dyn.n_params, p, sizeof(float) * c->pd.dyn.n_params, hipMemcpyDeviceToDevice,
-                              (hipStream_t)stream));
+    repack_dyn(c, p, c->d_dyn + (size_t)model * c->pd.dyn.n_params, 1, true, (hipStream_t)stream);
+    HIP_TRY(c, hipGetLastError());
     return METRPO_OK;
 }
 

@@ -55,23 +55,6 @@ __global__ void k_train_out(ProblemDesc pd, const float* __restrict__ norm, cons
     if (threadIdx.x == 0) atomicAdd(&loss[k], t * inv_n);
 }
 
-// bias gradient = column sums of dZ over the batch, then Adam (+ SGD on the regulariser) on the bias vector
-__global__ void k_bias_adam(int rows, int n_out, const float* __restrict__ dZ, long long strideZ, float* __restrict__ bias,
-                            float* __restrict__ am, float* __restrict__ av, long long strideP, float lr_t, float b1, float b2,
-                            float eps, float decay) {
-    const int k = blockIdx.y;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_out) return;
-    const float* z = dZ + (size_t)k * strideZ;
-    float g = 0.0f;
-    for (int b = 0; b < rows; ++b) g += z[(size_t)b * n_out + j];
-    const size_t i = (size_t)k * strideP + j;
-    const float m1 = b1 * am[i] + (1.0f - b1) * g, v1 = b2 * av[i] + (1.0f - b2) * g * g;
-    am[i] = m1; av[i] = v1;
-    const float w = bias[i];
-    bias[i] = w - lr_t * m1 / (sqrtf(v1) + eps) - decay * w;
-}
-
 // regulariser value: constant * sum_l (l2_loss(W) + l2_loss(b)) per model (training.py:271-282); one block per model
 __global__ void k_reg_loss(int Pd, const float* __restrict__ params, double constant, double* __restrict__ loss) {
     __shared__ double red[16];
@@ -189,12 +172,10 @@ int launch_dyn_train_step(metrpo_ctx* c, const float* x, const float* y, const m
             gemm_any<EPI_RELU_MASK, false, true>(dz, (long long)rows * n_out, n_out, Wl, pd.dyn.n_params, n_out, dz_next, (long long)rows * n_in, n_in,
                                                  rows, n_in, n_out, K, ep, st);
         }
-        hipLaunchKernelGGL(k_bias_adam, dim3((n_out + 63) / 64, K), dim3(64), 0, st, rows, n_out, dz, (long long)rows * n_out,
-                           c->d_dyn + pd.dyn.b_off[l], ws.am + pd.dyn.b_off[l], ws.av + pd.dyn.b_off[l], (long long)pd.dyn.n_params,
-                           (float)lr_t, (float)tp->beta1, (float)tp->beta2, (float)tp->eps, decay);
         {                       // dW_l = H_{l-1}^T . dZ_l with the Adam update as epilogue (W_l updated in place)
             GemmEpi ep = {};
             ep.am = ws.am + pd.dyn.w_off[l]; ep.av = ws.av + pd.dyn.w_off[l]; ep.strideAdam = pd.dyn.n_params;
+            ep.bvec = c->d_dyn + pd.dyn.b_off[l]; ep.bam = ws.am + pd.dyn.b_off[l]; ep.bav = ws.av + pd.dyn.b_off[l];   // b_l: column sums of dZ_l
             ep.lr_t = (float)lr_t; ep.beta1 = (float)tp->beta1; ep.beta2 = (float)tp->beta2; ep.eps = (float)tp->eps; ep.decay = decay;
             gemm_any<EPI_ADAM, true, false>(ws.H[l], (long long)rows * n_in, n_in, dz, (long long)rows * n_out, n_out, Wl, pd.dyn.n_params, n_out,
                                             n_in, n_out, rows, K, ep, st);

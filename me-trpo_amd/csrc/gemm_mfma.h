@@ -15,6 +15,8 @@ struct GemmEpi {                 // epilogue operands (unused fields may be null
     const float* mask; long long strideMask; int ldm; // EPI_RELU_MASK: C = acc * (mask[row][col] > 0)
     float* am; float* av; long long strideAdam;       // EPI_ADAM: C is the weight matrix, updated in place; am/av same layout
     float lr_t, beta1, beta2, eps, decay;             //           lr_t = lr*sqrt(1-b2^t)/(1-b1^t); decay = lr*reg_constant (SGD on the regulariser)
+    float* bvec; float* bam; float* bav;              // EPI_ADAM: bias of the same layer; its gradient = column sums of opB(W) (= dZ), which the
+                                                      //           blockIdx.y == 0 blocks accumulate while streaming B (fixed order) and apply
 };
 
 template <int TM, int TN, int EPI, bool TA, bool TB>
@@ -107,6 +109,9 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
     };
 
     const int nk = (Kd + BK - 1) / BK;
+    const bool colsum = (EPI == EPI_ADAM) && blockIdx.y == 0 && ep.bvec != nullptr;
+    float csum = 0.0f;                                           // thread (tid % BN, tid / BN): column sum over its k slice
+    constexpr int CS_S = 256 / BN, CS_K = BK / CS_S;             // k slices per tile, rows per slice
     load_tiles(0);
     store_tiles(0);
     __syncthreads();
@@ -126,8 +131,28 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
+        if (colsum) {
+#pragma unroll
+            for (int kk = 0; kk < CS_K; ++kk) csum += Bs[buf][(tid / BN) * CS_K + kk][tid % BN];
+        }
         if (kt + 1 < nk) store_tiles(buf ^ 1);
         __syncthreads();
+    }
+    if (colsum) {                                                // bias gradient + Adam (tf.train.AdamOptimizer) for columns n0..n0+BN
+        float* red = &As[0][0][0];                               // all MFMA reads of As are behind the last barrier
+        red[tid] = csum;
+        __syncthreads();
+        if (tid < BN && n0 + tid < N) {
+            float g = 0.0f;
+#pragma unroll
+            for (int sl = 0; sl < CS_S; ++sl) g += red[sl * BN + tid];
+            const size_t bi = (size_t)head * ep.strideAdam + n0 + tid;
+            const float m1 = ep.beta1 * ep.bam[bi] + (1.0f - ep.beta1) * g;
+            const float v1 = ep.beta2 * ep.bav[bi] + (1.0f - ep.beta2) * g * g;
+            ep.bam[bi] = m1; ep.bav[bi] = v1;
+            const float w = ep.bvec[bi];
+            ep.bvec[bi] = w - ep.lr_t * m1 / (sqrtf(v1) + ep.eps) - ep.decay * w;
+        }
     }
     // epilogue: C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll

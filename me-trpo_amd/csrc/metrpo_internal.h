@@ -13,9 +13,12 @@ struct NetDesc {
     int n_layers;            // weight layers
     int dims[MAXL + 1];      // dims[0] = inputs ... dims[n_layers] = outputs
     int act[MAXL];           // metrpo_act applied after layer l (last: identity)
-    int w_off[MAXL];
-    int b_off[MAXL];
-    int n_params;            // floats of one network (policy: WITHOUT the trailing log_std)
+    int w_off[MAXL];         // offsets in the DEVICE-RESIDENT layout.  Dynamics: every W/b array and every model starts on a
+    int b_off[MAXL];         // 16-byte boundary (pads are zero) so the GEMM/MFMA kernels can use float4 loads for all heads;
+    int n_params;            // policy: identical to the API layout.  n_params = floats of one network (policy: WITHOUT log_std)
+    int api_w_off[MAXL];     // offsets in the dense caller-visible layout of include/metrpo.h
+    int api_b_off[MAXL];
+    int api_n_params;
     int max_width;           // max over dims
 };
 

@@ -13,6 +13,7 @@ template <> struct EnvDim<METRPO_ENV_HOPPER>       { static constexpr int NS = 1
 template <> struct EnvDim<METRPO_ENV_SNAKE>        { static constexpr int NS = 14, NA = 4, NDROP = 2; };
 
 constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+constexpr int al4(int a) { return (a + 3) & ~3; }
 
 template <int ENV, int DH, int PH>
 struct Cfg {
@@ -21,9 +22,9 @@ struct Cfg {
     static constexpr int NIN_KS = cdiv(NIN, 4), NS_KS = cdiv(NS, 4);
     static constexpr int DH_CB = cdiv(DH, 16), PH_CB = cdiv(PH, 16), OUT_CB = cdiv(NS, 16);
     static constexpr int NSP = 16 * OUT_CB;                        // padded state row in the exchange buffer
-    // flat dynamics layout of one head: W0 b0 W1 b1 W2 b2
-    static constexpr int dW0 = 0, db0 = NIN * DH, dW1 = db0 + DH, db1 = dW1 + DH * DH, dW2 = db1 + DH,
-                         db2 = dW2 + DH * NS, PD = db2 + NS;
+    // resident dynamics layout of one head: W0 b0 W1 b1 W2 b2, every array on a 16-byte boundary (NetDesc, api.hip:build_net)
+    static constexpr int dW0 = 0, db0 = al4(NIN * DH), dW1 = al4(db0 + DH), db1 = al4(dW1 + DH * DH), dW2 = al4(db1 + DH),
+                         db2 = al4(dW2 + DH * NS), PD = al4(db2 + NS);
     // flat policy layout (rllab order): W0 b0 W1 b1 Wout bout log_std
     static constexpr int pW0 = 0, pb0 = NS * PH, pW1 = pb0 + PH, pb1 = pW1 + PH * PH, pW2 = pb1 + PH,
                          pb2 = pW2 + PH * NA, pLS = pb2 + NA;
