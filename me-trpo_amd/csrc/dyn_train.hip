@@ -11,7 +11,7 @@
 #include "gemm_mfma.h"
 
 struct TrainWs {             // carved from ctx->d_train
-    float* Xn; float* H[MAXL]; float* OUT; float* dZa; float* dZb; float* am; float* av; double* loss; size_t rows;
+    float* Xn; float* H[MAXL]; float* OUT; float* dZa; float* dZb; float* part; float* am; float* av; double* loss; size_t rows;
 };
 
 // normalise + drop columns (training.py:228,146-151).  train: model k reads sample b*K + k; eval: every model reads sample b
@@ -92,6 +92,39 @@ static void gemm_any(const float* A, long long sA, int lda, const float* W, long
     else gemm_mfma_launch<1, 1, EPI, TA, TB>(A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, heads, ep, st);
 }
 
+// Split-K decision for the weight-gradient GEMM of one layer (M = n_in, N = n_out, contraction over the batch rows).
+struct SplitK { int splits, kchunk; long long stride; };
+static SplitK choose_split(int M, int N, int rows, int heads) {
+    const int bm = (M > 64) ? 128 : 64, bn = (N > 64) ? 128 : 64;
+    const int blocks = ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * heads;
+    SplitK s = {1, rows, 0};
+    if (blocks >= 128 || rows < 256) return s;
+    int want = std::min(std::min((256 + blocks - 1) / blocks, (rows + 127) / 128), 16);
+    if (want <= 1) return s;
+    s.kchunk = ((rows + want - 1) / want + 15) & ~15;
+    s.splits = (rows + s.kchunk - 1) / s.kchunk;
+    s.stride = (((long long)M * N + N) + 3) & ~3LL;
+    return s;
+}
+
+// Sum the split-K partials in split order and apply tf.train.AdamOptimizer (+ SGD on the regulariser) to W_l (i < M*N) and b_l.
+__global__ void k_adam_apply(int splits, int heads, long long stridePart, const float* __restrict__ part, int MN, int N,
+                             float* __restrict__ W, float* __restrict__ am, float* __restrict__ av, float* __restrict__ bvec,
+                             float* __restrict__ bam, float* __restrict__ bav, long long strideP, float lr_t, float b1, float b2, float eps,
+                             float decay) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, head = blockIdx.y;
+    if (i >= MN + N) return;
+    float g = 0.0f;
+    for (int s = 0; s < splits; ++s) g += part[((size_t)s * heads + head) * stridePart + i];
+    float *pw, *pm, *pv;
+    if (i < MN) { const size_t o = (size_t)head * strideP + i; pw = W + o; pm = am + o; pv = av + o; }
+    else { const size_t o = (size_t)head * strideP + (i - MN); pw = bvec + o; pm = bam + o; pv = bav + o; }
+    const float m1 = b1 * *pm + (1.0f - b1) * g, v1 = b2 * *pv + (1.0f - b2) * g * g;
+    *pm = m1; *pv = v1;
+    const float w = *pw;
+    *pw = w - lr_t * m1 / (sqrtf(v1) + eps) - decay * w;
+}
+
 static int ensure_train_ws(metrpo_ctx* c, int rows, TrainWs* ws) {
     const ProblemDesc& pd = c->pd;
     const int K = pd.K, L = pd.dyn.n_layers;
@@ -107,7 +140,12 @@ static int ensure_train_ws(metrpo_ctx* c, int rows, TrainWs* ws) {
         HIP_TRY(c, hipMemset(c->d_adam, 0, 2 * nP * sizeof(float) + 64 * sizeof(double)));
         c->adam_t = 0;
     }
-    const size_t need = (nXn + hsum + nOut + 2 * nZ) * sizeof(float);
+    size_t nPart = 0;
+    for (int l = 0; l < L; ++l) {
+        const SplitK sk = choose_split(pd.dyn.dims[l], pd.dyn.dims[l + 1], rows, K);
+        if (sk.splits > 1) nPart = std::max(nPart, (size_t)sk.splits * (size_t)K * (size_t)sk.stride);
+    }
+    const size_t need = (nXn + hsum + nOut + 2 * nZ + nPart) * sizeof(float);
     if (need > c->train_cap) {
         if (c->d_train) HIP_TRY(c, hipFree(c->d_train));
         c->d_train = nullptr; c->train_cap = 0;
@@ -118,7 +156,7 @@ static int ensure_train_ws(metrpo_ctx* c, int rows, TrainWs* ws) {
     ws->Xn = p; p += nXn;
     for (int l = 1; l < L; ++l) { ws->H[l] = p; p += up4((size_t)K * rows * pd.dyn.dims[l]); }
     ws->H[0] = ws->Xn;
-    ws->OUT = p; p += nOut; ws->dZa = p; p += nZ; ws->dZb = p;
+    ws->OUT = p; p += nOut; ws->dZa = p; p += nZ; ws->dZb = p; p += nZ; ws->part = p;
     ws->am = (float*)c->d_adam; ws->av = ws->am + nP; ws->loss = (double*)(ws->av + nP);
     ws->rows = rows;
     return METRPO_OK;
@@ -177,8 +215,18 @@ int launch_dyn_train_step(metrpo_ctx* c, const float* x, const float* y, const m
             ep.am = ws.am + pd.dyn.w_off[l]; ep.av = ws.av + pd.dyn.w_off[l]; ep.strideAdam = pd.dyn.n_params;
             ep.bvec = c->d_dyn + pd.dyn.b_off[l]; ep.bam = ws.am + pd.dyn.b_off[l]; ep.bav = ws.av + pd.dyn.b_off[l];   // b_l: column sums of dZ_l
             ep.lr_t = (float)lr_t; ep.beta1 = (float)tp->beta1; ep.beta2 = (float)tp->beta2; ep.eps = (float)tp->eps; ep.decay = decay;
-            gemm_any<EPI_ADAM, true, false>(ws.H[l], (long long)rows * n_in, n_in, dz, (long long)rows * n_out, n_out, Wl, pd.dyn.n_params, n_out,
-                                            n_in, n_out, rows, K, ep, st);
+            const SplitK sk = choose_split(n_in, n_out, rows, K);
+            if (sk.splits > 1) {
+                ep.part = ws.part; ep.stridePart = sk.stride; ep.splits = sk.splits; ep.kchunk = sk.kchunk;
+                gemm_any<EPI_PARTIAL, true, false>(ws.H[l], (long long)rows * n_in, n_in, dz, (long long)rows * n_out, n_out, nullptr, 0, n_out,
+                                                   n_in, n_out, rows, K, ep, st);
+                const int tot = n_in * n_out + n_out;
+                hipLaunchKernelGGL(k_adam_apply, dim3((tot + 255) / 256, K), dim3(256), 0, st, sk.splits, K, sk.stride, ws.part, n_in * n_out, n_out,
+                                   Wl, ep.am, ep.av, ep.bvec, ep.bam, ep.bav, (long long)pd.dyn.n_params, ep.lr_t, ep.beta1, ep.beta2, ep.eps, decay);
+            } else {
+                gemm_any<EPI_ADAM, true, false>(ws.H[l], (long long)rows * n_in, n_in, dz, (long long)rows * n_out, n_out, Wl, pd.dyn.n_params, n_out,
+                                                n_in, n_out, rows, K, ep, st);
+            }
         }
         std::swap(dz, dz_next);
     }

@@ -8,7 +8,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { EPI_BIAS_ID = 0, EPI_BIAS_RELU = 1, EPI_BIAS_TANH = 2, EPI_RELU_MASK = 3, EPI_ADAM = 4, EPI_PLAIN = 5 };
+enum { EPI_BIAS_ID = 0, EPI_BIAS_RELU = 1, EPI_BIAS_TANH = 2, EPI_RELU_MASK = 3, EPI_ADAM = 4, EPI_PLAIN = 5, EPI_PARTIAL = 6 };
 
 struct GemmEpi {                 // epilogue operands (unused fields may be null)
     const float* bias; long long strideBias;          // EPI_BIAS_*: bias[col]
@@ -17,6 +17,10 @@ struct GemmEpi {                 // epilogue operands (unused fields may be null
     float lr_t, beta1, beta2, eps, decay;             //           lr_t = lr*sqrt(1-b2^t)/(1-b1^t); decay = lr*reg_constant (SGD on the regulariser)
     float* bvec; float* bam; float* bav;              // EPI_ADAM: bias of the same layer; its gradient = column sums of opB(W) (= dZ), which the
                                                       //           blockIdx.y == 0 blocks accumulate while streaming B (fixed order) and apply
+    // EPI_PARTIAL (split-K for weight-gradient GEMMs with too few output tiles to fill the chip): blockIdx.z = head * splits + split,
+    // split s contracts rows [s*kchunk, (s+1)*kchunk) and writes its M x N partial followed by the N partial column sums to
+    // part + (s * heads + head) * stridePart; k_adam_apply (dyn_train.hip) adds the splits in index order and applies Adam.
+    float* part; long long stridePart; int splits, kchunk;
 };
 
 template <int TM, int TN, int EPI, bool TA, bool TB>
@@ -28,9 +32,17 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + 4];     // Bs[k][n]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int head = blockIdx.z;
+    int head = blockIdx.z, kbeg = 0, kend = Kd;
+    if (EPI == EPI_PARTIAL) {
+        const int sp = blockIdx.z % ep.splits;
+        head = blockIdx.z / ep.splits;
+        kbeg = sp * ep.kchunk; kend = min(Kd, kbeg + ep.kchunk);
+        C = ep.part + ((size_t)sp * (gridDim.z / ep.splits) + head) * ep.stridePart;
+    } else {
+        C += (size_t)head * strideC;
+    }
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    A += (size_t)head * strideA; W += (size_t)head * strideW; C += (size_t)head * strideC;
+    A += (size_t)head * strideA; W += (size_t)head * strideW;
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -62,26 +74,26 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
 #pragma unroll
             for (int p = 0; p < SA_P; ++p) {
                 const int kq = (tid / BM + p * SA_Q) * 4, m = m0 + tid % BM;
-                ra[p] = (m < M) ? ld4(A + (size_t)m * lda + k0 + kq, Kd - (k0 + kq)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                ra[p] = (m < M) ? ld4(A + (size_t)m * lda + k0 + kq, kend - (k0 + kq)) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
 #pragma unroll
             for (int p = 0; p < DA_P; ++p) {
                 const int k = k0 + tid / (BM / 4) + p * DA_R, m = m0 + (tid % (BM / 4)) * 4;
-                ra[p] = (k < Kd) ? ld4(A + (size_t)k * lda + m, M - m) : make_float4(0.f, 0.f, 0.f, 0.f);
+                ra[p] = (k < kend) ? ld4(A + (size_t)k * lda + m, M - m) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         if (!TB) {
 #pragma unroll
             for (int p = 0; p < DB_P; ++p) {
                 const int k = k0 + tid / (BN / 4) + p * DB_R, n = n0 + (tid % (BN / 4)) * 4;
-                rb[p] = (k < Kd) ? ld4(W + (size_t)k * ldw + n, N - n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[p] = (k < kend) ? ld4(W + (size_t)k * ldw + n, N - n) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
 #pragma unroll
             for (int p = 0; p < SB_P; ++p) {
                 const int kq = (tid / BN + p * SB_Q) * 4, n = n0 + tid % BN;
-                rb[p] = (n < N) ? ld4(W + (size_t)n * ldw + k0 + kq, Kd - (k0 + kq)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[p] = (n < N) ? ld4(W + (size_t)n * ldw + k0 + kq, kend - (k0 + kq)) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
@@ -108,16 +120,16 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
         }
     };
 
-    const int nk = (Kd + BK - 1) / BK;
-    const bool colsum = (EPI == EPI_ADAM) && blockIdx.y == 0 && ep.bvec != nullptr;
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    const bool colsum = (EPI == EPI_PARTIAL && blockIdx.y == 0) || (EPI == EPI_ADAM && blockIdx.y == 0 && ep.bvec != nullptr);
     float csum = 0.0f;                                           // thread (tid % BN, tid / BN): column sum over its k slice
     constexpr int CS_S = 256 / BN, CS_K = BK / CS_S;             // k slices per tile, rows per slice
-    load_tiles(0);
+    load_tiles(kbeg);
     store_tiles(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles((kt + 1) * BK);              // global loads of the next tile fly under the MFMAs
+        if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);              // global loads of the next tile fly under the MFMAs
         const int li = lane & 31, lk = lane >> 5;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
@@ -146,12 +158,15 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
             float g = 0.0f;
 #pragma unroll
             for (int sl = 0; sl < CS_S; ++sl) g += red[sl * BN + tid];
+            if (EPI == EPI_PARTIAL) { C[(size_t)M * N + n0 + tid] = g; }
+            else {
             const size_t bi = (size_t)head * ep.strideAdam + n0 + tid;
             const float m1 = ep.beta1 * ep.bam[bi] + (1.0f - ep.beta1) * g;
             const float v1 = ep.beta2 * ep.bav[bi] + (1.0f - ep.beta2) * g * g;
             ep.bam[bi] = m1; ep.bav[bi] = v1;
             const float w = ep.bvec[bi];
             ep.bvec[bi] = w - ep.lr_t * m1 / (sqrtf(v1) + ep.eps) - ep.decay * w;
+            }
         }
     }
     // epilogue: C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -190,6 +205,6 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
 template <int TM, int TN, int EPI, bool TA, bool TB>
 static inline void gemm_mfma_launch(const float* A, long long sA, int lda, const float* W, long long sW, int ldw, float* C, long long sC,
                                     int ldc, int M, int N, int Kd, int heads, const GemmEpi& ep, hipStream_t st) {
-    dim3 grid((N + 64 * TN - 1) / (64 * TN), (M + 64 * TM - 1) / (64 * TM), heads);
+    dim3 grid((N + 64 * TN - 1) / (64 * TN), (M + 64 * TM - 1) / (64 * TM), heads * (EPI == EPI_PARTIAL ? ep.splits : 1));
     hipLaunchKernelGGL((k_gemm_mfma<TM, TN, EPI, TA, TB>), grid, dim3(256), 0, st, A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, ep);
 }
