@@ -4,6 +4,7 @@
     data_collection(max_size)                       utils.py:44-131     (FIFO replay buffer; add_data / get_next_batch / sample)
     RunningMeanStd(epsilon, shape)                  running_mean_std.py (sum / sumsq / count; mean; std floored at 0.1)
     optimize_models(...)                            model_based_rl.py:881-1051 (one scope)
+    trajectories_to_pairs / add_rollouts            model_based_rl.py:793-852  (collect_data after the simulator call)
 
 Data lives on the GPU; batch index selection keeps the reference's host-side NumPy semantics (np.random.uniform stream),
 the gather, the K-head forward/backward/Adam step and the validation losses run in libmetrpo.so (dyn_train.hip)."""
@@ -82,6 +83,45 @@ class RunningMeanStd(object):
     def std(self):
         m = self._sum / self._count
         return torch.sqrt(torch.clamp(self._sumsq / self._count - m * m, min=1e-2)).to(torch.float32)
+
+
+def trajectories_to_pairs(Os, As):
+    """model_based_rl.py:793-807: x = [o_t, a_t], y = o_{t+1} for every t < len-1 of every trajectory (host arrays in)."""
+    x_all = np.concatenate([np.concatenate([np.asarray(o)[:-1], np.asarray(a)[:-1]], axis=1) for o, a in zip(Os, As)])
+    y_all = np.concatenate([np.asarray(o)[1:] for o in Os])
+    return x_all, y_all
+
+
+def add_rollouts(x_all, y_all, dynamics_data, dynamics_validation, splitting_mode, use_same_dataset, split_ratio, input_rms=None,
+                 output_rms=None):
+    """The post-simulator half of collect_data (model_based_rl.py:813-852): np.random.shuffle of the indices in "triplet"
+    mode, per-scope validation / training split, RunningMeanStd fed from the training part (shared-dataset branch only,
+    as in the reference).  The simulator half (sample_trajectories) stays with the caller -- it needs MuJoCo."""
+    x_all, y_all = np.asarray(x_all), np.asarray(y_all)
+    indices = list(range(len(x_all)))
+    if splitting_mode == "triplet":
+        np.random.shuffle(indices)
+    elif splitting_mode != "trajectory":
+        raise AssertionError("splitting_mode must be 'trajectory' or 'triplet'")
+    cur_i, total = 0, len(x_all)
+    n_scopes = len(dynamics_data.keys())
+    for scope in dynamics_data.keys():
+        if use_same_dataset:
+            n = round(split_ratio * total)
+            dynamics_validation[scope].add_data(x_all[indices[:n], :], y_all[indices[:n], :])
+            dynamics_data[scope].add_data(x_all[indices[n:], :], y_all[indices[n:], :])
+            cur_i = len(indices)
+            if input_rms is not None:
+                input_rms.update(x_all[indices[n:], :])
+                output_rms.update(y_all[indices[n:], :] - x_all[indices[n:], :y_all.shape[1]])
+        else:
+            n = int(split_ratio * total / n_scopes)
+            dynamics_validation[scope].add_data(x_all[indices[cur_i:cur_i + n], :], y_all[indices[cur_i:cur_i + n], :])
+            cur_i += n
+            m = int(total / n_scopes - n)
+            dynamics_data[scope].add_data(x_all[indices[cur_i:cur_i + m], :], y_all[indices[cur_i:cur_i + m], :])
+            cur_i += m
+    assert cur_i == total, "sample count must split evenly over the scopes (model_based_rl.py:852)"
 
 
 def push_normalizers(engine, input_rms, diff_rms):

@@ -5,7 +5,10 @@ TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 
 Pinned against the reference's own Python (tests/golden/dyn_*.npz, made by tests/golden/make_golden.py):
 `utils.data_collection` (add_data / cap / get_next_batch / sample with the exact np.random stream),
-`utils.get_ith_tensor` (which rows of a reshaped batch each model trains on), `compute_baseline_loss`.
+`utils.get_ith_tensor` (which rows of a reshaped batch each model trains on), `compute_baseline_loss`, and the
+pair building / train-validation split / normaliser feed of `collect_data` (collect_split.npz: the reference's own
+collect_data run with synthetic trajectories in place of the simulator).  The reference's one known-answer test for
+this path, running_mean_std.py:44-62 (epsilon=0: mean/std equal np.mean/np.std of all rows), is restated in the tests.
 PARITY UNPINNED (TF graph / TF optimizers, not executable here): the per-model MSE loss, its gradient,
 tf.train.AdamOptimizer, the SGD step on the regulariser, RunningMeanStd.update, and the control flow of
 optimize_models (restated line by line from model_based_rl.py:881-1051).  Self-consistency: torch autograd
@@ -57,6 +60,44 @@ class DataCollectionOracle(object):
     def sample(self, batch_size, rng=np.random):
         indices = np.floor(self.n_data * rng.uniform(0.0, 1.0, size=batch_size)).astype(np.intp)
         return self.x[indices, :], self.y[indices, :]
+
+
+def trajectories_to_pairs(Os, As):
+    """model_based_rl.py:793-807: x = [o_t, a_t], y = o_{t+1} for t < len-1 of every trajectory, in order."""
+    x_all, y_all = [], []
+    for o, a in zip(Os, As):
+        for t in range(len(o) - 1):
+            x_all.append(np.concatenate([o[t], a[t]])); y_all.append(o[t + 1])
+    return np.array(x_all), np.array(y_all)
+
+
+def collect_split(x_all, y_all, data, val, splitting_mode, use_same_dataset, split_ratio, input_rms=None, output_rms=None, rng=np.random):
+    """model_based_rl.py:813-852: split new (x, y) pairs into the per-scope training / validation collections
+    (`data`, `val`: ordered dicts scope -> collection) and feed the normalisers from the TRAINING part only
+    (only in the use_same_dataset branch, as the reference does)."""
+    indices = list(range(len(x_all)))
+    if splitting_mode == 'triplet':
+        rng.shuffle(indices)
+    else:
+        assert splitting_mode == 'trajectory'
+    cur_i, total = 0, len(x_all)
+    for scope in data.keys():
+        if use_same_dataset:
+            n = round(split_ratio * total)
+            val[scope].add_data(x_all[indices[:n], :], y_all[indices[:n], :])
+            data[scope].add_data(x_all[indices[n:], :], y_all[indices[n:], :])
+            cur_i = len(indices)
+            if input_rms is not None:
+                input_rms.update(x_all[indices[n:], :])
+                output_rms.update(y_all[indices[n:], :] - x_all[indices[n:], :y_all.shape[1]])
+        else:
+            n = int(split_ratio * total / len(data.keys()))
+            val[scope].add_data(x_all[indices[cur_i:cur_i + n], :], y_all[indices[cur_i:cur_i + n], :])
+            cur_i += n
+            m = int(total / len(data.keys()) - n)
+            data[scope].add_data(x_all[indices[cur_i:cur_i + m], :], y_all[indices[cur_i:cur_i + m], :])
+            cur_i += m
+    assert cur_i == total
 
 
 def compute_baseline_loss(x_batch, y_batch, n_models):

@@ -479,7 +479,52 @@ def gen_dynamics_data():
     save('dyn_data', **arrs)
 
 
+
+# ---------------------------------------------------------------- 10. collect_data: triplets, train/validation split, normaliser feed
+class _RecRms(object):
+    def __init__(self): self.calls = []
+    def update(self, x): self.calls.append(np.array(x))
+
+
+def gen_collect_split():
+    """Drives the reference's own collect_data (model_based_rl.py:758-857) with sample_trajectories replaced by synthetic
+    trajectories (the real one needs MuJoCo); everything after the simulator call is the reference's code."""
+    import tempfile
+    from collections import OrderedDict
+    rng = np.random.RandomState(515)
+    ns, na = 4, 2
+    lens = [6, 9, 5, 14]                      # 30 triplets: the non-shared split asserts exact divisibility (:852)
+    Os = [rng.randn(n, ns) for n in lens]
+    As = [rng.randn(n, na) for n in lens]
+    ref_mbrl.sample_trajectories = lambda *a, **k: (Os, As, [np.zeros(n) for n in lens], {})
+    arrs = dict(lens=np.array(lens), O=np.concatenate(Os), A=np.concatenate(As))
+    logger = NS(info=lambda *a, **k: None)
+    cases = [('trajectory', True, 0.1, 1), ('triplet', True, 0.33, 1), ('triplet', False, 0.2, 2), ('trajectory', False, 0.25, 3)]
+    for ci, (mode, same, ratio, n_scopes) in enumerate(cases):
+        scopes = ['training_dynamics%d' % i for i in range(n_scopes)]
+        data = OrderedDict((sc, ref_utils.data_collection(max_size=1000)) for sc in scopes)
+        val = OrderedDict((sc, ref_utils.data_collection(max_size=1000)) for sc in scopes)
+        irms, orms = _RecRms(), _RecRms()
+        rp = NS(exploration=None, is_monitored=False, monitorpath='', max_timestep=20, render_every=None, splitting_mode=mode,
+                use_same_dataset=same, split_ratio=ratio)
+        np.random.seed(1000 + ci)
+        with tempfile.TemporaryDirectory() as td:
+            ref_mbrl.collect_data(None, 10, data, val, None, None, None, None, None, None, td, rp, 0, logger, None, irms, orms)
+        arrs['c%d_mode' % ci] = np.array(0 if mode == 'trajectory' else 1)
+        arrs['c%d_same' % ci] = np.array(int(same)); arrs['c%d_ratio' % ci] = np.array(ratio); arrs['c%d_scopes' % ci] = np.array(n_scopes)
+        arrs['c%d_seed' % ci] = np.array(1000 + ci)
+        for si, sc in enumerate(scopes):
+            arrs['c%d_s%d_tx' % (ci, si)], arrs['c%d_s%d_ty' % (ci, si)] = np.array(data[sc].x), np.array(data[sc].y)
+            arrs['c%d_s%d_vx' % (ci, si)], arrs['c%d_s%d_vy' % (ci, si)] = np.array(val[sc].x), np.array(val[sc].y)
+        arrs['c%d_n_rms' % ci] = np.array(len(irms.calls))
+        for k, (xi, xo) in enumerate(zip(irms.calls, orms.calls)):
+            arrs['c%d_rms_in%d' % (ci, k)], arrs['c%d_rms_out%d' % (ci, k)] = xi, xo
+    arrs['n_cases'] = np.array(len(cases))
+    save('collect_split', **arrs)
+
+
 if __name__ == '__main__':
+    gen_collect_split()
     gen_dynamics_data()
     gen_rewards()
     gen_vecenv()

@@ -36,6 +36,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.Batch) == 5 * 8 + 4 + 4 + 8 + 8 + 8
     assert C.sizeof(_lib.TrpoParams) == 8 + 4 + 4 + 8 + 8 + 4 + 4 + 8 + 8 + 8
     assert C.sizeof(_lib.TrpoDiag) == 4 * 8 + 3 * 4 + 4
+    assert C.sizeof(_lib.TrainParams) == 5 * 8 + 4 + 4          # 5 doubles, int32 batch_size, tail padding
     assert _lib.RolloutArgs.d_pool.offset == 24 and _lib.RolloutArgs.seed.offset == 40
 
 

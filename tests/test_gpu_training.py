@@ -141,6 +141,42 @@ def test_replay_buffer_and_normalizers_match_reference_semantics():
     np.testing.assert_allclose(cpu(nxt), O.dynamics_forward(dm, 0, s.astype(np.float64), a.astype(np.float64)), rtol=1e-4, atol=1e-4)
 
 
+def test_add_rollouts_matches_reference_collect_data():
+    """product add_rollouts / trajectories_to_pairs vs the reference's collect_data golden (tests/golden/collect_split.npz)."""
+    import metrpo_amd
+    from collections import OrderedDict
+    from metrpo_amd.dynamics_training import data_collection, add_rollouts, trajectories_to_pairs
+    from test_oracle_dynamics import collect_split_cases, _Rec
+    for d, ci, Os, As, c in collect_split_cases():
+        x_all, y_all = trajectories_to_pairs(Os, As)
+        scopes = ['s%d' % i for i in range(c['n_scopes'])]
+        data = OrderedDict((sc, data_collection(1000, device='cuda')) for sc in scopes)
+        val = OrderedDict((sc, data_collection(1000, device='cuda')) for sc in scopes)
+        irms, orms = _Rec(), _Rec()
+        np.random.seed(c['seed'])
+        add_rollouts(x_all, y_all, data, val, c['mode'], c['same'], c['ratio'], irms, orms)
+        for si, sc in enumerate(scopes):
+            for got, key in ((data[sc].x, 'tx'), (data[sc].y, 'ty'), (val[sc].x, 'vx'), (val[sc].y, 'vy')):
+                np.testing.assert_array_equal(cpu(got), d['c%d_s%d_%s' % (ci, si, key)].astype(np.float32))
+        assert len(irms.calls) == int(d['c%d_n_rms' % ci])
+        for k in range(len(irms.calls)):
+            np.testing.assert_array_equal(irms.calls[k], d['c%d_rms_in%d' % (ci, k)]); np.testing.assert_array_equal(orms.calls[k], d['c%d_rms_out%d' % (ci, k)])
+
+
+def test_running_mean_std_known_answer():
+    """the reference's own test for this path (running_mean_std.py:44-62): with epsilon 0 the statistics after two updates
+    equal np.mean / np.std of the concatenation (sizes and moments as in the reference test)."""
+    import metrpo_amd
+    from metrpo_amd.dynamics_training import RunningMeanStd
+    eng, dm, theta, pdims, pool = Hh.make_engine('swimmer', 2, (64, 64), (32, 32), seed=75)
+    rng = np.random.RandomState(5)
+    x = (rng.randn(1000, 3) * 1.0 + 2.0).astype(np.float32); y = (rng.randn(1000, 3) * 3.0 + 1.0).astype(np.float32)
+    z = np.concatenate([x, y], axis=0).astype(np.float64)
+    rms = RunningMeanStd(eng, epsilon=0.0, shape=[3])
+    rms.update(x); rms.update(y)
+    assert np.allclose(cpu(rms.mean), z.mean(0)) and np.allclose(cpu(rms.std), z.std(0))
+
+
 def test_optimize_models_loop_fits_and_restores_best():
     import metrpo_amd
     from metrpo_amd.dynamics_training import data_collection, optimize_models

@@ -97,6 +97,39 @@ def test_train_steps_match_tf_style_adam_on_autograd(reg):
         np.testing.assert_allclose(dm.bs[l], bs[l].detach().numpy(), rtol=1e-9, atol=1e-12)
 
 
+class _Rec(object):
+    def __init__(self): self.calls = []
+    def update(self, x): self.calls.append(np.array(x))
+
+
+def collect_split_cases():
+    """Replays tests/golden/collect_split.npz: yields (case dict, make_collections, check) pieces shared with the GPU test."""
+    d = load_golden('collect_split')
+    lens = d['lens']; off = np.concatenate([[0], np.cumsum(lens)])
+    Os = [d['O'][off[i]:off[i + 1]] for i in range(len(lens))]; As = [d['A'][off[i]:off[i + 1]] for i in range(len(lens))]
+    for ci in range(int(d['n_cases'])):
+        yield d, ci, Os, As, dict(mode='trajectory' if int(d['c%d_mode' % ci]) == 0 else 'triplet', same=bool(d['c%d_same' % ci]),
+                                  ratio=float(d['c%d_ratio' % ci]), n_scopes=int(d['c%d_scopes' % ci]), seed=int(d['c%d_seed' % ci]))
+
+
+def test_collect_split_matches_reference():
+    """the reference's collect_data (model_based_rl.py:793-852) on synthetic trajectories vs the restatement."""
+    from collections import OrderedDict
+    for d, ci, Os, As, c in collect_split_cases():
+        x_all, y_all = D.trajectories_to_pairs(Os, As)
+        scopes = ['s%d' % i for i in range(c['n_scopes'])]
+        data = OrderedDict((sc, D.DataCollectionOracle(1000)) for sc in scopes); val = OrderedDict((sc, D.DataCollectionOracle(1000)) for sc in scopes)
+        irms, orms = _Rec(), _Rec()
+        np.random.seed(c['seed'])
+        D.collect_split(x_all, y_all, data, val, c['mode'], c['same'], c['ratio'], irms, orms)
+        for si, sc in enumerate(scopes):
+            np.testing.assert_array_equal(data[sc].x, d['c%d_s%d_tx' % (ci, si)]); np.testing.assert_array_equal(data[sc].y, d['c%d_s%d_ty' % (ci, si)])
+            np.testing.assert_array_equal(val[sc].x, d['c%d_s%d_vx' % (ci, si)]); np.testing.assert_array_equal(val[sc].y, d['c%d_s%d_vy' % (ci, si)])
+        assert len(irms.calls) == int(d['c%d_n_rms' % ci])
+        for k in range(len(irms.calls)):
+            np.testing.assert_array_equal(irms.calls[k], d['c%d_rms_in%d' % (ci, k)]); np.testing.assert_array_equal(orms.calls[k], d['c%d_rms_out%d' % (ci, k)])
+
+
 def test_rms_update_is_mean_std_of_concatenation():
     """running_mean_std.py:44-60 test_runningmeanstd (epsilon 0 form): matches np.mean/np.std of the concatenation."""
     rng = np.random.RandomState(0)
