@@ -45,9 +45,11 @@ def main():
 
     import metrpo_amd
     from metrpo_amd import synthetic
-    comm = metrpo_amd.Comm.init_from_env('nccl')
+    # test hooks (tests/test_gpu_api.py): METRPO_BENCH_BACKEND=gloo + METRPO_BENCH_DEVICE=0 run N ranks on ONE GPU so the
+    # multi-rank control flow (collectives, barriers, max-over-ranks timing) is exercised on a 1-GPU box
+    comm = metrpo_amd.Comm.init_from_env(os.environ.get('METRPO_BENCH_BACKEND', 'nccl'))
     assert comm.world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    dev = int(os.environ.get('LOCAL_RANK', '0'))
+    dev = int(os.environ.get('METRPO_BENCH_DEVICE', os.environ.get('LOCAL_RANK', '0')))
     torch.cuda.set_device(dev)
 
     cfg = synthetic.CONFIGS[args.config]

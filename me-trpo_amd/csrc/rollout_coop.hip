@@ -12,6 +12,20 @@
 // The policy (30 MFMAs) is still evaluated redundantly by each wave; its weight fragments live in LDS (shared).
 #include "mfma_common.h"
 
+// Developer instrumentation (make EXTRA=-DCOOP_TIMING): per-phase shader-clock sums of wave 0 of workgroup 0 and of the
+// last workgroup, read back with metrpo_debug_coop_phases (tools/coop_phases.py).  Not part of the shipped library.
+#ifdef COOP_TIMING
+__device__ unsigned long long g_coop_phase[2][16];
+#define PH_DECL unsigned long long ph_t = __builtin_readcyclecounter(), ph_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define PH_MARK(i) { const unsigned long long n_ = __builtin_readcyclecounter(); ph_acc[i] += n_ - ph_t; ph_t = n_; }
+#define PH_DUMP { if (lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) for (int i_ = 0; i_ < 10; ++i_) g_coop_phase[blockIdx.x == 0 ? 0 : 1][i_] = ph_acc[i_]; }
+extern "C" int32_t metrpo_debug_coop_phases(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coop_phase), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -1; }
+#else
+#define PH_DECL
+#define PH_MARK(i)
+#define PH_DUMP
+#endif
+
 template <int ENV, int K>
 struct Coop {
     using C = Cfg<ENV, 64, 32>;
@@ -109,52 +123,76 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
     }
     __syncthreads();
 
+    // Per-step draws (Philox block 0 of RNG_STEP: action noise dims 0,1 | step model | reset row/model) are produced ONE STEP AHEAD,
+    // textually inside the layer-1 MFMA phase, so that their ~150 VALU instructions issue in the shadow of the matrix pipe.
+    auto step_draws = [&](int tt, uint4& ds, float (&zz)[4]) {
+        ds = rng_draw(r.seed, genv, tt, RNG_STEP, 0);
+        {   // unconditional (no branch); unused when determ / draws are supplied.
+            // lane q owns action dims 4q..4q+3 = chunks 2q, 2q+1 (chunk 0 = ds)
+            const uint4 b0k = (q == 0) ? ds : ((NA > 4) ? rng_draw(r.seed, genv, tt, RNG_STEP, 2 * q) : ds);
+            normal2(b0k.x, b0k.y, zz[0], zz[1]);
+            if (NA > 2) { const uint4 b1k = rng_draw(r.seed, genv, tt, RNG_STEP, 2 * q + 1); normal2(b1k.x, b1k.y, zz[2], zz[3]); }
+        }
+    };
+    constexpr bool LOCAL_REWARD = (ENV == METRPO_ENV_SWIMMER || ENV == METRPO_ENV_HALF_CHEETAH || ENV == METRPO_ENV_SNAKE);
+    constexpr int RDIM = (ENV == METRPO_ENV_SWIMMER) ? 5 : (ENV == METRPO_ENV_HALF_CHEETAH) ? 9 : 7;   // reward reads next_state[RDIM]
+    // one-step-ahead pipelining only where it fits the register budget (one Philox block per step: na <= 2)
+    constexpr bool AHEAD = (NA <= 2);
+    uint4 dstep = make_uint4(0, 0, 0, 0); float z[4] = {0.f, 0.f, 0.f, 0.f};
+    if (AHEAD) step_draws(0, dstep, z);
+    PH_DECL
     for (int t = 0; t < r.T; ++t) {
+        PH_MARK(9)
         const size_t tb = (size_t)t * r.B + b;
-        if (wave == 0) {                                                   // obs[t]: coalesced linear copy of the tile
-            const size_t base = ((size_t)t * r.B + b0) * NS;
-            const int lim = min(16, r.B - b0) * NS;
-            for (int i = lane; i < lim; i += 64) r.obs[base + i] = ST[i];
-        }
         // ---- policy (redundant in every wave; weight fragments from LDS) -----------------------------
+        // Weight fragments of a layer are fetched as one batch BEFORE the activation of the previous layer is evaluated (the LDS
+        // latency hides under the tanh VALU work), and each tanh is issued right before the MFMA pair that consumes it, so the
+        // matrix pipe works through k-step kk while the VALU evaluates the activation of k-step kk+1.
         f32x4 p0[2], p1[2];
-        p0[0] = *(const f32x4*)&BP0[4 * q]; p0[1] = *(const f32x4*)&BP0[16 + 4 * q];
+        {
+            float w0[C::NS_KS * 2], xs[C::NS_KS];
 #pragma unroll
-        for (int s = 0; s < C::NS_KS; ++s) {
-            const int f = 4 * s + q;
-            const float x = (f < NS) ? ST[e * NS + f] : 0.0f;
-            p0[0] = MFMA16(pw0[(2 * s) * 64], x, p0[0]);
-            p0[1] = MFMA16(pw0[(2 * s + 1) * 64], x, p0[1]);
+            for (int f = 0; f < C::NS_KS * 2; ++f) w0[f] = pw0[f * 64];
+#pragma unroll
+            for (int s = 0; s < C::NS_KS; ++s) { const int f = 4 * s + q; xs[s] = (f < NS) ? ST[e * NS + f] : 0.0f; }
+            p0[0] = *(const f32x4*)&BP0[4 * q]; p0[1] = *(const f32x4*)&BP0[16 + 4 * q];
+#pragma unroll
+            for (int s = 0; s < C::NS_KS; ++s) {
+                p0[0] = MFMA16(w0[2 * s], xs[s], p0[0]);
+                p0[1] = MFMA16(w0[2 * s + 1], xs[s], p0[1]);
+            }
         }
-        p1[0] = *(const f32x4*)&BP1[4 * q]; p1[1] = *(const f32x4*)&BP1[16 + 4 * q];
+        f32x4 m0, m1 = {0.f, 0.f, 0.f, 0.f};
+        {
+            float w1[16];
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+            for (int f = 0; f < 16; ++f) w1[f] = pw1[f * 64];
+            p1[0] = *(const f32x4*)&BP1[4 * q]; p1[1] = *(const f32x4*)&BP1[16 + 4 * q];
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) p0[cb][rr] = tanh_fast(p0[cb][rr]);
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            p1[0] = MFMA16(pw1[(2 * kk) * 64], p0[kk >> 2][kk & 3], p1[0]);
-            p1[1] = MFMA16(pw1[(2 * kk + 1) * 64], p0[kk >> 2][kk & 3], p1[1]);
+            for (int kk = 0; kk < 8; ++kk) {
+                const float hv = tanh_fast(p0[kk >> 2][kk & 3]);
+                p1[0] = MFMA16(w1[2 * kk], hv, p1[0]);
+                p1[1] = MFMA16(w1[2 * kk + 1], hv, p1[1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+        {
+            float w2[8];
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+            for (int f = 0; f < 8; ++f) w2[f] = pw2[f * 64];
+            m0 = *(const f32x4*)&BP2[4 * q];
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) p1[cb][rr] = tanh_fast(p1[cb][rr]);
-        f32x4 m0 = *(const f32x4*)&BP2[4 * q], m1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < 8; kk += 2) {
-            m0 = MFMA16(pw2[kk * 64], p1[kk >> 2][kk & 3], m0);
-            m1 = MFMA16(pw2[(kk + 1) * 64], p1[(kk + 1) >> 2][(kk + 1) & 3], m1);
+            for (int kk = 0; kk < 8; kk += 2) {
+                const float ha = tanh_fast(p1[kk >> 2][kk & 3]);
+                m0 = MFMA16(w2[kk], ha, m0);
+                const float hb = tanh_fast(p1[(kk + 1) >> 2][(kk + 1) & 3]);
+                m1 = MFMA16(w2[kk + 1], hb, m1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         const f32x4 mu = m0 + m1;
-        const uint4 dstep = rng_draw(r.seed, genv, t, RNG_STEP, 0);
-        float z[4] = {0.f, 0.f, 0.f, 0.f};
-        if (!r.determ && r.eps == nullptr) {            // lane q owns action dims 4q..4q+3 = chunks 2q, 2q+1 (chunk 0 = dstep)
-            const uint4 b0k = (q == 0) ? dstep : ((NA > 4) ? rng_draw(r.seed, genv, t, RNG_STEP, 2 * q) : dstep);
-            normal2(b0k.x, b0k.y, z[0], z[1]);
-            if (NA > 2) { const uint4 b1k = rng_draw(r.seed, genv, t, RNG_STEP, 2 * q + 1); normal2(b1k.x, b1k.y, z[2], z[3]); }
-        }
-        float su2 = 0.0f;
+        PH_MARK(0)
+        if (!AHEAD) step_draws(t, dstep, z);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int d = 4 * q + rr;
@@ -167,11 +205,10 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
                 if (wave == 1 && active) { r.act[tb * NA + d] = a; r.mean[tb * NA + d] = mu[rr]; }
                 const float ac = fminf(fmaxf(a, -1.0f), 1.0f);            // env_helpers.py:599
                 ACT[e * NA + d] = ac;
-                su2 = fmaf(ac, ac, su2);
             }
         }
-        su2 = xor_sum(su2);
         wave_lds_sync();
+        PH_MARK(1)
         // ---- dynamics layer 0, col-block `wave`, all K heads ------------------------------------------
         {
             float xin[C::NIN_KS];
@@ -196,8 +233,58 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
                 *(f32x4*)&H0[k * 1024 + wave * 256 + q * 64 + e * 4] = h0[k];            // H0[k][cb][q][env][r]
             }
         }
+        PH_MARK(2)
         __syncthreads();                                                   // B1: layer-0 activations of all heads visible
+        PH_MARK(3)
+        if (wave == 0) {                                                   // obs[t]: coalesced linear copy of the tile
+            const size_t base = ((size_t)t * r.B + b0) * NS;
+            const int lim = min(16, r.B - b0) * NS;
+#pragma unroll
+            for (int j = 0; j < (16 * NS + 63) / 64; ++j) { const int i = lane + 64 * j; if (i < lim) r.obs[base + i] = ST[i]; }
+        }
+        uint4 dstep_n; float z_n[4] = {0.f, 0.f, 0.f, 0.f};
+        // Next step's draws, cut into RNG_PIECES pieces (10 Philox rounds + 3 Box-Muller stages; same arithmetic as rng_draw / normal2)
+        // that are dealt out between the groups of K independent MFMAs below: each piece issues in the matrix pipe's shadow.
+        uint4 pc0, pc1, pc2; uint32_t pk0 = 0, pk1 = 0; float bm_r[2] = {0.f, 0.f}, bm_a[2] = {0.f, 0.f};
+        auto rng_piece = [&](int i) {
+            if (!AHEAD) return;
+            if (i == 0) {
+                const uint32_t tt = (uint32_t)(t + 1);
+                pk0 = (uint32_t)r.seed; pk1 = (uint32_t)(r.seed >> 32);
+                pc0 = make_uint4((uint32_t)genv, (uint32_t)(genv >> 32), tt, ((uint32_t)RNG_STEP << 16));
+                pc1 = make_uint4((uint32_t)genv, (uint32_t)(genv >> 32), tt, ((uint32_t)RNG_STEP << 16) | (uint32_t)(2 * q + 1));
+                pc2 = make_uint4((uint32_t)genv, (uint32_t)(genv >> 32), tt, ((uint32_t)RNG_STEP << 16) | (uint32_t)(2 * q));
+            }
+            if (i < 10) {
+                auto rnd = [&](uint4& c) {
+                    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+                    const uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x, hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+                    c = make_uint4(hi1 ^ c.y ^ pk0, lo1, hi0 ^ c.w ^ pk1, lo0);
+                };
+                rnd(pc0);
+                if (NA > 2) rnd(pc1);
+                if (NA > 4) rnd(pc2);
+                pk0 += 0x9E3779B9u; pk1 += 0xBB67AE85u;
+            } else if (i == 10) {
+                const float S = 2.3283064365386963e-10f;
+                const uint4 a = (NA > 4 && q != 0) ? pc2 : pc0;
+                bm_r[0] = -2.0f * __logf(((float)a.x + 0.5f) * S); bm_a[0] = 6.283185307179586f * (((float)a.y + 0.5f) * S);
+                if (NA > 2) { bm_r[1] = -2.0f * __logf(((float)pc1.x + 0.5f) * S); bm_a[1] = 6.283185307179586f * (((float)pc1.y + 0.5f) * S); }
+            } else if (i == 11) {
+                bm_r[0] = sqrtf(bm_r[0]);
+                if (NA > 2) bm_r[1] = sqrtf(bm_r[1]);
+            } else if (i == 12) {
+                float sn, cs;
+                __sincosf(bm_a[0], &sn, &cs); z_n[0] = bm_r[0] * cs; z_n[1] = bm_r[0] * sn;
+                if (NA > 2) { __sincosf(bm_a[1], &sn, &cs); z_n[2] = bm_r[1] * cs; z_n[3] = bm_r[1] * sn; }
+                dstep_n = pc0;
+            }
+        };
+        float su2 = 0.0f;                                                  // sum_d clip(a_d)^2 of the own env (ACT is complete since B1)
+#pragma unroll
+        for (int d = 0; d < NA; ++d) { const float ac = ACT[e * NA + d]; su2 = fmaf(ac, ac, su2); }
         // ---- layer 1 (own col-block) and the layer-2 partial over the own 16 hidden units ----------------
+        __builtin_amdgcn_s_setprio(1);          // the matrix-heavy phase wins issue arbitration over a co-resident workgroup's VALU phases
         f32x4 h1[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) h1[k] = *(const f32x4*)&BD1[k * 64 + 16 * wave + 4 * q];
@@ -207,9 +294,12 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
 #pragma unroll
             for (int k = 0; k < K; ++k) hb[k] = *(const f32x4*)&H0[k * 1024 + cb * 256 + q * 64 + e * 4];
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
+            for (int rr = 0; rr < 4; ++rr) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) h1[k] = MFMA16(wd1[k][cb * 4 + rr], hb[k][rr], h1[k]);
+                rng_piece(cb * 4 + rr);
+                __builtin_amdgcn_sched_barrier(0x94);                      // only SALU / VMEM / LDS instructions may cross
+            }
         }
 #pragma unroll
         for (int k = 0; k < K; ++k)
@@ -232,7 +322,10 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
 #pragma unroll
                 for (int cb = 0; cb < OUT_CB; ++cb) *(f32x4*)&PART[((k * 4 + wave) * 16 + e) * NSP + 16 * cb + 4 * q] = po[k][cb];
         }
+        __builtin_amdgcn_s_setprio(0);
+        PH_MARK(4)
         __syncthreads();                                                   // B2: all partial sums visible
+        PH_MARK(5)
         // ---- selection (env_helpers.py:617-634): out_k = b2_k + sum_w partial ; next = dmean + dstd*out + s ----
         ts += 1;
         int sel = cur_model;
@@ -288,57 +381,84 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
                 }
             }
         }
+        PH_MARK(6)
         // ---- reward (:601), is_done (:603), horizon (:604) ----------------------------------------------
-        float pen = 0.0f; int fin = 1;
-#pragma unroll
-        for (int cb = 0; cb < OUT_CB; ++cb)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int dim = 16 * cb + 4 * q + rr;
-                if (dim < NS) {
-                    NX[e * NS + dim] = nx[cb][rr];
-                    if (ENV == METRPO_ENV_HOPPER && dim >= 2) pen += fmaxf(fabsf(nx[cb][rr]) - 100.0f, 0.0f);
-                    if (ENV == METRPO_ENV_ANT) fin &= isfinite(nx[cb][rr]) ? 1 : 0;
-                }
-            }
-        wave_lds_sync();
-        const float* xn = NX + e * NS;
         float cost = 0.0f;
         bool dn = false;
-        if (ENV == METRPO_ENV_SWIMMER) cost = -(xn[5] - 1e-2f * (su2 / (float)NA));
-        else if (ENV == METRPO_ENV_HALF_CHEETAH) cost = -fminf(fmaxf(xn[9] - 1e-1f * 0.5f * su2, -10.0f), 10.0f);
-        else if (ENV == METRPO_ENV_SNAKE) cost = -(xn[7] - 1e-2f * 0.5f * su2);
-        else if (ENV == METRPO_ENV_HOPPER) {
-            pen = xor_sum(pen);
-            cost = -(xn[5] - 0.01f * 0.5f * su2 - 10.0f * fmaxf(0.45f - xn[0], 0.0f) - 10.0f * fmaxf(fabsf(xn[1]) - 0.2f, 0.0f) - pen);
-        } else if (ENV == METRPO_ENV_ANT) {
-            cost = -(xn[15] - 1e-2f * 0.5f * su2 + 0.05f);
-            int f2 = fin & __shfl_xor(fin, 16, 64);
-            f2 &= __shfl_xor(f2, 32, 64);
-            const float zc = xn[2];
-            dn = !((zc >= 0.2f) && (zc <= 1.0f) && (f2 != 0));
+        if (LOCAL_REWARD) {
+            // the reward reads ONE next-state dim: the lane that owns it (q == RDIM/4 of col-block 0) evaluates and stores it from
+            // registers -- no LDS round trip; is_done is the horizon only (uniform)
+            const float xr = nx[RDIM / 16][RDIM & 3];
+            if (ENV == METRPO_ENV_SWIMMER) cost = -(xr - 1e-2f * (su2 / (float)NA));
+            else if (ENV == METRPO_ENV_HALF_CHEETAH) cost = -fminf(fmaxf(xr - 1e-1f * 0.5f * su2, -10.0f), 10.0f);
+            else cost = -(xr - 1e-2f * 0.5f * su2);
+            dn = (ts >= r.H);
+            if (wave == 2 && q == ((RDIM & 15) >> 2) && active) { r.rew[tb] = -cost; r.done[tb] = dn ? 1 : 0; r.tpath[tb] = ts - 1; }
+        } else {
+            float pen = 0.0f; int fin = 1;
+#pragma unroll
+            for (int cb = 0; cb < OUT_CB; ++cb)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int dim = 16 * cb + 4 * q + rr;
+                    if (dim < NS) {
+                        NX[e * NS + dim] = nx[cb][rr];
+                        if (ENV == METRPO_ENV_HOPPER && dim >= 2) pen += fmaxf(fabsf(nx[cb][rr]) - 100.0f, 0.0f);
+                        if (ENV == METRPO_ENV_ANT) fin &= isfinite(nx[cb][rr]) ? 1 : 0;
+                    }
+                }
+            wave_lds_sync();
+            const float* xn = NX + e * NS;
+            if (ENV == METRPO_ENV_HOPPER) {
+                pen = xor_sum(pen);
+                cost = -(xn[5] - 0.01f * 0.5f * su2 - 10.0f * fmaxf(0.45f - xn[0], 0.0f) - 10.0f * fmaxf(fabsf(xn[1]) - 0.2f, 0.0f) - pen);
+            } else if (ENV == METRPO_ENV_ANT) {
+                cost = -(xn[15] - 1e-2f * 0.5f * su2 + 0.05f);
+                int f2 = fin & __shfl_xor(fin, 16, 64);
+                f2 &= __shfl_xor(f2, 32, 64);
+                const float zc = xn[2];
+                dn = !((zc >= 0.2f) && (zc <= 1.0f) && (f2 != 0));
+            }
+            dn = dn || (ts >= r.H);
+            if (wave == 2 && q == 0 && active) { r.rew[tb] = -cost; r.done[tb] = dn ? 1 : 0; r.tpath[tb] = ts - 1; }
         }
-        dn = dn || (ts >= r.H);
-        if (wave == 2 && q == 0 && active) { r.rew[tb] = -cost; r.done[tb] = dn ? 1 : 0; r.tpath[tb] = ts - 1; }
+        PH_MARK(7)
         // ---- reset(dones) (:585-595) or advance; every wave keeps its own copy of the tile state ----------
-        int row = 0;
-        if (dn) {
-            if (active) {
-                const size_t rb = (size_t)(t + 1) * r.B + b;
-                row = (r.reset_idx != nullptr) ? r.reset_idx[rb] : rng_index(dstep.w, r.n_pool);
-                cur_model = (r.reset_model != nullptr) ? r.reset_model[rb] : rng_index16(dstep.z, K);
+        if (__any(dn)) {                                                   // rare: horizon reached / Ant fell
+            int row = 0;
+            if (dn) {
+                if (active) {
+                    const size_t rb = (size_t)(t + 1) * r.B + b;
+                    row = (r.reset_idx != nullptr) ? r.reset_idx[rb] : rng_index(dstep.w, r.n_pool);
+                    cur_model = (r.reset_model != nullptr) ? r.reset_model[rb] : rng_index16(dstep.z, K);
+                }
+                ts = 0;
             }
-            ts = 0;
+#pragma unroll
+            for (int cb = 0; cb < OUT_CB; ++cb)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int dim = 16 * cb + 4 * q + rr;
+                    if (dim < NS) ST[e * NS + dim] = dn ? r.pool[(size_t)row * NS + dim] : nx[cb][rr];
+                }
+        } else {
+#pragma unroll
+            for (int cb = 0; cb < OUT_CB; ++cb)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int dim = 16 * cb + 4 * q + rr;
+                    if (dim < NS) ST[e * NS + dim] = nx[cb][rr];
+                }
         }
+        if (AHEAD) {
+            dstep = dstep_n;
 #pragma unroll
-        for (int cb = 0; cb < OUT_CB; ++cb)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int dim = 16 * cb + 4 * q + rr;
-                if (dim < NS) ST[e * NS + dim] = dn ? r.pool[(size_t)row * NS + dim] : nx[cb][rr];
-            }
+            for (int rr = 0; rr < 4; ++rr) z[rr] = z_n[rr];
+        }
         wave_lds_sync();
+        PH_MARK(8)
     }
+    PH_DUMP
     if (wave == 0 && r.last_obs != nullptr) {
         const int lim = min(16, r.B - b0) * NS;
         for (int i = lane; i < lim; i += 64) r.last_obs[(size_t)b0 * NS + i] = ST[i];

@@ -183,3 +183,22 @@ def test_allreduce_callback_through_rccl_world1():
         assert torch.equal(comm.allreduce_sum_(stats), torch.ones(3, dtype=torch.float64, device='cuda'))
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py launched the way the driver launches it for N=2 (torch.distributed.run, one process per rank), with both
+    ranks on cuda:0 over gloo: exercises the B-sharded control flow, every all-reduce of the TRPO driver, the barrier /
+    max-over-ranks timing and the rank-0 JSON line.  (RCCL itself needs two GPUs; world size 1 over RCCL is tested above.)"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, METRPO_BENCH_BACKEND='gloo', METRPO_BENCH_DEVICE='0', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29517', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['steps'] == 3 and rec['scaling'] == 'weak' and rec['value'] > 0
+    assert 'cpu_baseline' not in rec                       # rank 0 at N=1 only
+    assert abs(rec['value'] - 2 * 5 * 5000 * 100 / (rec['ms_per_step'] * 1e-3)) / rec['value'] < 1e-9
