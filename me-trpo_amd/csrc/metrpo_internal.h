@@ -39,7 +39,8 @@ struct metrpo_ctx {
     bool have_dyn, have_pol;
     // --- MFMA fast path (rollout_mfma.hip): pre-permuted weight images, built by set_* ---
     float* d_dyn_img;    // per-model register image, see rollout_mfma.hip
-    float* d_pol_img;
+    float* d_pol_img;    // (int32 payload) gather map of the policy weight-fragment image, see policy_mfma.hip
+    int pol_img_idx;     // table index the map was built for (-1: none)
     int mfma_cfg;        // index into the instantiation table, -1 = generic path only
     int pol_mfma;        // index into policy_mfma.hip's table, -1 = generic update kernels
     int coop_cfg;        // index into rollout_coop.hip's table, -1 = head-per-wave kernel (rollout_mfma.hip)
@@ -82,6 +83,7 @@ struct RolloutK {          // device-side copy of metrpo_rollout_args (plain poi
 struct PolK {
     const float* obs; const float* act; const float* adv; const float* old_mean; const float* old_ls;
     int ls_stride; const uint8_t* valid; long long N; float inv_n;
+    const int* img_map;      // policy_mfma.hip: gather map of the LDS weight-fragment image (built once per ctx on the host)
 };
 
 int policy_mfma_select(const ProblemDesc& pd);

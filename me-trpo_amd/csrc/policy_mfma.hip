@@ -44,14 +44,14 @@ struct PolImg {
 };
 
 template <int NS, int NA, int PH, int MODE>
-__global__ void __launch_bounds__(256, 3) k_policy_mfma(PolK k, const float* __restrict__ theta, const float* __restrict__ v,
+__global__ void __launch_bounds__(256, 2) k_policy_mfma(PolK k, const float* __restrict__ theta, const float* __restrict__ v,
                                                         float* __restrict__ partials) {
     using I = PolImg<NS, NA, PH>;
     constexpr int NS_KS = I::NS_KS, NSI = cdiv_(NS, 16), HB = I::HB, KK = I::KK;
     constexpr int pW0 = 0, pb0 = NS * PH, pW1 = pb0 + PH, pb1 = pW1 + PH * PH, pW2 = pb1 + PH, pb2 = pW2 + PH * NA,
                   pLS = pb2 + NA, P = pLS + NA, ROW = P + PART_EXTRA;
     constexpr int TS = 17, TILE = 16 * TS;                  // transpose tile: 16 rows, stride 17 floats (conflict free)
-    constexpr int WTL = 2 * HB * TILE;                      // per-wave transpose scratch, reused by the three weight-gradient phases
+    constexpr int WTL = (4 * HB + 1) * TILE;                // per-wave transpose tiles: h0, h1, d1, d0 (HB each) and u
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
@@ -59,26 +59,27 @@ __global__ void __launch_bounds__(256, 3) k_policy_mfma(PolK k, const float* __r
     float* TL = lds + I::TOTAL + wave * WTL;
 
     // ---------------- weight fragment image -> LDS (each element written by exactly one thread) ----------------
-    for (int i = tid; i < I::TOTAL; i += 256) {
-        float w = 0.f;
-        if (i < I::O_W2F) {                                  // [row][lane][cb] tables
-            int t, base;
-            if (i < I::O_W1F) { t = 0; base = I::O_W0F; } else if (i < I::O_V0F) { t = 1; base = I::O_W1F; }
-            else if (i < I::O_V1F) { t = 2; base = I::O_V0F; } else if (i < I::O_W2B) { t = 3; base = I::O_V1F; }
-            else if (i < I::O_W1B) { t = 4; base = I::O_W2B; } else { t = 5; base = I::O_W1B; }
-            const int j = i - base, cb = j % HB, ln = (j / HB) & 63, row = j / (HB * 64), cc = ln & 15, qq = ln >> 4;
-            const float* __restrict__ src = (t == 2 || t == 3) ? v : theta;
-            if (t == 0 || t == 2) { const int in = 4 * row + qq, o = 16 * cb + cc; if (in < NS && o < PH && (MODE == MODE_FVP || t == 0)) w = src[pW0 + in * PH + o]; }
-            else if (t == 1 || t == 3) { const int in = 16 * (row >> 2) + 4 * qq + (row & 3), o = 16 * cb + cc; if (in < PH && o < PH && (MODE == MODE_FVP || t == 1)) w = src[pW1 + in * PH + o]; }
-            else if (t == 4) { const int ii = 16 * cb + cc, d = 4 * qq + row; if (ii < PH && d < NA && MODE != MODE_LOSSKL) w = theta[pW2 + ii * NA + d]; }
-            else { const int ii = 16 * cb + cc, jj = 16 * (row >> 2) + 4 * qq + (row & 3); if (ii < PH && jj < PH && MODE != MODE_LOSSKL) w = theta[pW1 + ii * PH + jj]; }
-        } else {                                             // [row][lane] tables: W2f, V2f
-            const bool isv = i >= I::O_V2F;
-            const int j = i - (isv ? I::O_V2F : I::O_W2F), ln = j & 63, row = j >> 6, cc = ln & 15, qq = ln >> 4;
-            const int in = 16 * (row >> 2) + 4 * qq + (row & 3);
-            if (in < PH && cc < NA && (!isv || MODE == MODE_FVP)) w = (isv ? v : theta)[pW2 + in * NA + cc];
+    // k.img_map[i] = source index of image element i in theta (bit 30 clear) or in v (bit 30 set), -1 = zero; built once on the
+    // host (pol_image_map).  Map loads, gathers and LDS stores are issued in independent batches of IMG_U per thread: the
+    // prologue costs ~2 L2 round trips instead of one dependent global load per element.
+    {
+        constexpr int IMG_U = 8;
+        for (int i0 = 0; i0 < I::TOTAL; i0 += 256 * IMG_U) {
+            int m[IMG_U]; float w[IMG_U];
+#pragma unroll
+            for (int u = 0; u < IMG_U; ++u) { const int i = i0 + u * 256 + tid; m[u] = (i < I::TOTAL) ? k.img_map[i] : -1; }
+#pragma unroll
+            for (int u = 0; u < IMG_U; ++u) {
+                const int i = i0 + u * 256 + tid;
+                bool use = m[u] >= 0;
+                if (MODE != MODE_FVP && (m[u] & 0x40000000)) use = false;                       // tangent tables: FVP only
+                if (MODE == MODE_LOSSKL && i >= I::O_W2B && i < I::O_W2F) use = false;          // back-prop tables unused
+                w[u] = 0.f;
+                if (use) w[u] = (m[u] & 0x40000000) ? v[m[u] & 0x3FFFFFFF] : theta[m[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < IMG_U; ++u) { const int i = i0 + u * 256 + tid; if (i < I::TOTAL) IMG[i] = w[u]; }
         }
-        IMG[i] = w;
     }
     // fragment accessors (this lane's element)
 #define FRAG2(off, row, cb) IMG[(off) + ((row) * 64 + lane) * HB + (cb)]
@@ -123,31 +124,66 @@ __global__ void __launch_bounds__(256, 3) k_policy_mfma(PolK k, const float* __r
         const long long n0 = tile * 16, n = n0 + c;
         const bool inr = n < k.N;
         const bool ok = inr && (k.valid == nullptr || k.valid[n]);
-        // ---- forward (transposed chain) ----------------------------------------------------------
+        // The tile is processed as a few long MFMA runs with the VALU work of the neighbouring stages placed textually inside them
+        // (it issues in the matrix pipe's shadow), and every activation is dropped into its own wave-private transpose tile the
+        // moment it exists, so the three sample-contracted weight-gradient products run as ONE run after a single LDS sync.
         float xB[NS_KS];
 #pragma unroll
         for (int s = 0; s < NS_KS; ++s) { const int f = 4 * s + q; xB[s] = (inr && f < NS) ? k.obs[n * NS + f] : 0.f; }
-        f32x4 h0[HB], h1[HB];
+        float* T_H0 = TL, *T_H1 = TL + HB * TILE, *T_D1 = TL + 2 * HB * TILE, *T_D0 = TL + 3 * HB * TILE, *T_UM = TL + 4 * HB * TILE;
+        // ---- S1: layer 0, forward and (FVP) tangent  ------------------------------------------------------
+        f32x4 h0[HB], h1[HB], t0[HB], t1[HB];
 #pragma unroll
-        for (int cb = 0; cb < HB; ++cb) h0[cb] = b0f[cb];
+        for (int cb = 0; cb < HB; ++cb) { h0[cb] = b0f[cb]; if (MODE == MODE_FVP) t0[cb] = vb0f[cb]; }
 #pragma unroll
         for (int s = 0; s < NS_KS; ++s)
 #pragma unroll
-            for (int cb = 0; cb < HB; ++cb) h0[cb] = MFMA16(FRAG2(I::O_W0F, s, cb), xB[s], h0[cb]);
+            for (int cb = 0; cb < HB; ++cb) {
+                h0[cb] = MFMA16(FRAG2(I::O_W0F, s, cb), xB[s], h0[cb]);
+                if (MODE == MODE_FVP) t0[cb] = MFMA16(FRAG2(I::O_V0F, s, cb), xB[s], t0[cb]);
+            }
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb) {
             h1[cb] = b1f[cb];
+            if (MODE == MODE_FVP) t1[cb] = vb1f[cb];
 #pragma unroll
             for (int r = 0; r < 4; ++r) h0[cb][r] = tanh_fast(h0[cb][r]);
         }
+        // ---- S2: layer 1 on h0: forward h1 += W1^T h0 and (FVP) t1 += V1^T h0;  VALU inside: t0 *= 1 - h0^2, h0 -> T_H0 ----
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-            for (int cb = 0; cb < HB; ++cb) h1[cb] = MFMA16(FRAG2(I::O_W1F, kk, cb), h0[kk >> 2][kk & 3], h1[cb]);
+            for (int cb = 0; cb < HB; ++cb) {
+                h1[cb] = MFMA16(FRAG2(I::O_W1F, kk, cb), h0[kk >> 2][kk & 3], h1[cb]);
+                if (MODE == MODE_FVP) t1[cb] = MFMA16(FRAG2(I::O_V1F, kk, cb), h0[kk >> 2][kk & 3], t1[cb]);
+            }
+        if (MODE != MODE_LOSSKL) {
+#pragma unroll
+            for (int cb = 0; cb < HB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) T_H0[cb * TILE + (4 * q + r) * TS + c] = h0[cb][r];
+        }
+        if (MODE == MODE_FVP) {
+#pragma unroll
+            for (int cb = 0; cb < HB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t0[cb][r] *= fmaf(-h0[cb][r], h0[cb][r], 1.f);
+            // ---- S3: t1 += W1^T t0;  VALU inside: tanh(h1) ------------------------------------------------
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                for (int cb = 0; cb < HB; ++cb) t1[cb] = MFMA16(FRAG2(I::O_W1F, kk, cb), t0[kk >> 2][kk & 3], t1[cb]);
+        }
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) h1[cb][r] = tanh_fast(h1[cb][r]);
+        if (MODE != MODE_LOSSKL) {
+#pragma unroll
+            for (int cb = 0; cb < HB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) T_H1[cb * TILE + (4 * q + r) * TS + c] = h1[cb][r];
+        }
 
         f32x4 um = Z4;                                      // d(objective)/d(mean) in D layout [d = 4q+r][sample c]
         if (MODE != MODE_FVP) {
@@ -184,37 +220,16 @@ __global__ void __launch_bounds__(256, 3) k_policy_mfma(PolK k, const float* __r
                 if (4 * q + r < NA) dls[r] += w * (zz[r] * zz[r] - 1.f);      // d loss / d log_std
             }
         } else {
-            // ---- tangent forward: dpre = V^T h + W^T dh + vb ; dh = dpre * (1 - h^2) ------------------
-            f32x4 t0[HB], t1[HB];
+            // ---- S4: tangent of the mean: m1 = V2^T h1 (VALU inside: t1 *= 1 - h1^2), then m0 = vb2 + W2^T t1 ----------
+            f32x4 m0 = vb2f, m1 = Z4;
 #pragma unroll
-            for (int cb = 0; cb < HB; ++cb) t0[cb] = vb0f[cb];
-#pragma unroll
-            for (int s = 0; s < NS_KS; ++s)
-#pragma unroll
-                for (int cb = 0; cb < HB; ++cb) t0[cb] = MFMA16(FRAG2(I::O_V0F, s, cb), xB[s], t0[cb]);
-#pragma unroll
-            for (int cb = 0; cb < HB; ++cb) {
-                t1[cb] = vb1f[cb];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) t0[cb][r] *= fmaf(-h0[cb][r], h0[cb][r], 1.f);
-            }
-#pragma unroll
-            for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-                for (int cb = 0; cb < HB; ++cb) {
-                    t1[cb] = MFMA16(FRAG2(I::O_W1F, kk, cb), t0[kk >> 2][kk & 3], t1[cb]);
-                    t1[cb] = MFMA16(FRAG2(I::O_V1F, kk, cb), h0[kk >> 2][kk & 3], t1[cb]);
-                }
+            for (int kk = 0; kk < KK; ++kk) m1 = MFMA16(FRAG1(I::O_V2F, kk), h1[kk >> 2][kk & 3], m1);
 #pragma unroll
             for (int cb = 0; cb < HB; ++cb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) t1[cb][r] *= fmaf(-h1[cb][r], h1[cb][r], 1.f);
-            f32x4 m0 = vb2f, m1 = Z4;
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) {
-                m0 = MFMA16(FRAG1(I::O_W2F, kk), t1[kk >> 2][kk & 3], m0);
-                m1 = MFMA16(FRAG1(I::O_V2F, kk), h1[kk >> 2][kk & 3], m1);
-            }
+            for (int kk = 0; kk < KK; ++kk) m0 = MFMA16(FRAG1(I::O_W2F, kk), t1[kk >> 2][kk & 3], m0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float s2 = expf(2.f * ls[r]);
@@ -223,19 +238,23 @@ __global__ void __launch_bounds__(256, 3) k_policy_mfma(PolK k, const float* __r
             }
             if (ok && q == 0) accw += k.inv_n;
         }
-        // ---- back-prop (transposed chain) ----------------------------------------------------------
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T_UM[(4 * q + r) * TS + c] = um[r];
+        // ---- S5/S6: back-prop (transposed chain); deltas go straight into their transpose tiles ---------------------
         f32x4 d1[HB], d0[HB];
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb) d1[cb] = Z4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r) {
+            if (r >= NA) continue;                          // k-step r covers action dims r, 4+r, 8+r, 12+r: all padding when r >= na
 #pragma unroll
             for (int cb = 0; cb < HB; ++cb) d1[cb] = MFMA16(FRAG2(I::O_W2B, r, cb), um[r], d1[cb]);
+        }
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb) {
             d0[cb] = Z4;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) d1[cb][r] *= fmaf(-h1[cb][r], h1[cb][r], 1.f);
+            for (int r = 0; r < 4; ++r) { d1[cb][r] *= fmaf(-h1[cb][r], h1[cb][r], 1.f); T_D1[cb * TILE + (4 * q + r) * TS + c] = d1[cb][r]; }
         }
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
@@ -244,67 +263,33 @@ __global__ void __launch_bounds__(256, 3) k_policy_mfma(PolK k, const float* __r
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) d0[cb][r] *= fmaf(-h0[cb][r], h0[cb][r], 1.f);
+            for (int r = 0; r < 4; ++r) { d0[cb][r] *= fmaf(-h0[cb][r], h0[cb][r], 1.f); T_D0[cb * TILE + (4 * q + r) * TS + c] = d0[cb][r]; }
         gb2 += um;
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb) { gb1[cb] += d1[cb]; gb0[cb] += d0[cb]; }
-        // ---- weight gradients G[i][j] += sum_n a[i][n] d[j][n]: three phases share the wave's 2*HB transpose tiles -------
+        // ---- S7: weight gradients G[i][j] += sum_n a[i][n] d[j][n] as one MFMA run ------------------------------------
         // D fragment [unit 16cb+4q+r][sample c] -> T[unit][sample]; k-step s of the MFMA covers samples 4s+q
-        float* TA = TL, *TB = TL + HB * TILE;
-        // phase 1: gW2 += h1 (x) u
-#pragma unroll
-        for (int cb = 0; cb < HB; ++cb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) TA[cb * TILE + (4 * q + r) * TS + c] = h1[cb][r];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) TB[(4 * q + r) * TS + c] = um[r];
         wave_sync_lds();
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int col = c * TS + 4 * s + q;
-            const float bu = TB[col];
+            const float bu = T_UM[col];
+            float a1_[HB], a0_[HB], b1_[HB], b0_[HB], xT[NSI];
 #pragma unroll
-            for (int ci = 0; ci < HB; ++ci) gW2[ci] = MFMA16(TA[ci * TILE + col], bu, gW2[ci]);
-        }
-        wave_sync_lds();
-        // phase 2: gW1 += h0 (x) d1
+            for (int cb = 0; cb < HB; ++cb) { a1_[cb] = T_H1[cb * TILE + col]; a0_[cb] = T_H0[cb * TILE + col]; b1_[cb] = T_D1[cb * TILE + col]; b0_[cb] = T_D0[cb * TILE + col]; }
+            const long long ns_ = n0 + 4 * s + q;
 #pragma unroll
-        for (int cb = 0; cb < HB; ++cb)
+            for (int ci = 0; ci < NSI; ++ci) { const int f = 16 * ci + c; xT[ci] = (ns_ < k.N && f < NS) ? k.obs[ns_ * NS + f] : 0.f; }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { TA[cb * TILE + (4 * q + r) * TS + c] = h0[cb][r]; TB[cb * TILE + (4 * q + r) * TS + c] = d1[cb][r]; }
-        wave_sync_lds();
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int col = c * TS + 4 * s + q;
-            float a_[HB], b_[HB];
-#pragma unroll
-            for (int cb = 0; cb < HB; ++cb) { a_[cb] = TA[cb * TILE + col]; b_[cb] = TB[cb * TILE + col]; }
+            for (int ci = 0; ci < HB; ++ci) gW2[ci] = MFMA16(a1_[ci], bu, gW2[ci]);
 #pragma unroll
             for (int ci = 0; ci < HB; ++ci)
 #pragma unroll
-                for (int cj = 0; cj < HB; ++cj) gW1[ci][cj] = MFMA16(a_[ci], b_[cj], gW1[ci][cj]);
-        }
-        wave_sync_lds();
-        // phase 3: gW0 += x (x) d0   (x straight from global in A layout)
+                for (int cj = 0; cj < HB; ++cj) gW1[ci][cj] = MFMA16(a0_[ci], b1_[cj], gW1[ci][cj]);
 #pragma unroll
-        for (int cb = 0; cb < HB; ++cb)
+            for (int ci = 0; ci < NSI; ++ci)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) TB[cb * TILE + (4 * q + r) * TS + c] = d0[cb][r];
-        wave_sync_lds();
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int col = c * TS + 4 * s + q;
-            float b_[HB];
-#pragma unroll
-            for (int cb = 0; cb < HB; ++cb) b_[cb] = TB[cb * TILE + col];
-            const long long ns_ = n0 + 4 * s + q;
-#pragma unroll
-            for (int ci = 0; ci < NSI; ++ci) {
-                const int f = 16 * ci + c;
-                const float xT = (ns_ < k.N && f < NS) ? k.obs[ns_ * NS + f] : 0.f;
-#pragma unroll
-                for (int cj = 0; cj < HB; ++cj) gW0[ci][cj] = MFMA16(xT, b_[cj], gW0[ci][cj]);
-            }
+                for (int cj = 0; cj < HB; ++cj) gW0[ci][cj] = MFMA16(xT[ci], b0_[cj], gW0[ci][cj]);
         }
         wave_sync_lds();
     }
@@ -352,17 +337,49 @@ __global__ void __launch_bounds__(256, 3) k_policy_mfma(PolK k, const float* __r
     for (int i = tid; i < ROW; i += 256) out[i] = (RB[i] + RB[ROW + i]) + (RB[2 * ROW + i] + RB[3 * ROW + i]);
 }
 
+
+// Host mirror of the image layout: element i of the LDS image <- theta[idx] / v[idx] / 0.
+template <int NS, int NA, int PH>
+static void pol_image_map(std::vector<int>& map) {
+    using I = PolImg<NS, NA, PH>;
+    constexpr int HB = I::HB;
+    constexpr int pW0 = 0, pb0 = NS * PH, pW1 = pb0 + PH, pb1 = pW1 + PH * PH, pW2 = pb1 + PH;
+    const int VFLAG = 0x40000000;
+    map.assign(I::TOTAL, -1);
+    for (int i = 0; i < I::TOTAL; ++i) {
+        int m = -1;
+        if (i < I::O_W2F) {                                  // [row][lane][cb] tables
+            int t, base;
+            if (i < I::O_W1F) { t = 0; base = I::O_W0F; } else if (i < I::O_V0F) { t = 1; base = I::O_W1F; }
+            else if (i < I::O_V1F) { t = 2; base = I::O_V0F; } else if (i < I::O_W2B) { t = 3; base = I::O_V1F; }
+            else if (i < I::O_W1B) { t = 4; base = I::O_W2B; } else { t = 5; base = I::O_W1B; }
+            const int j = i - base, cb = j % HB, ln = (j / HB) & 63, row = j / (HB * 64), cc = ln & 15, qq = ln >> 4;
+            const int flag = (t == 2 || t == 3) ? VFLAG : 0;
+            if (t == 0 || t == 2) { const int in = 4 * row + qq, o = 16 * cb + cc; if (in < NS && o < PH) m = (pW0 + in * PH + o) | flag; }
+            else if (t == 1 || t == 3) { const int in = 16 * (row >> 2) + 4 * qq + (row & 3), o = 16 * cb + cc; if (in < PH && o < PH) m = (pW1 + in * PH + o) | flag; }
+            else if (t == 4) { const int ii = 16 * cb + cc, d = 4 * qq + row; if (ii < PH && d < NA) m = pW2 + ii * NA + d; }
+            else { const int ii = 16 * cb + cc, jj = 16 * (row >> 2) + 4 * qq + (row & 3); if (ii < PH && jj < PH) m = pW1 + ii * PH + jj; }
+        } else {                                             // [row][lane] tables: W2f, V2f
+            const bool isv = i >= I::O_V2F;
+            const int j = i - (isv ? I::O_V2F : I::O_W2F), ln = j & 63, row = j >> 6, cc = ln & 15, qq = ln >> 4;
+            const int in = 16 * (row >> 2) + 4 * qq + (row & 3);
+            if (in < PH && cc < NA) m = (pW2 + in * NA + cc) | (isv ? VFLAG : 0);
+        }
+        map[i] = m;
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 typedef void (*pol_kernel_t)(PolK, const float*, const float*, float*);
-struct PolEntry { int ns, na, ph; pol_kernel_t kern[3]; int lds_floats; };
+struct PolEntry { int ns, na, ph; pol_kernel_t kern[3]; int lds_floats; void (*build_map)(std::vector<int>&); };
 template <int NS, int NA, int PH> constexpr int pol_lds() {
     constexpr int HB = cdiv_(PH, 16);
-    constexpr int a = PolImg<NS, NA, PH>::TOTAL + 4 * (2 * HB) * 16 * 17;
+    constexpr int a = PolImg<NS, NA, PH>::TOTAL + 4 * (4 * HB + 1) * 16 * 17;
     constexpr int P = NS * PH + PH + PH * PH + PH + PH * NA + NA + NA;
     constexpr int b = 4 * (P + PART_EXTRA);
     return a > b ? a : b;
 }
-#define PENTRY(NS, NA, PH) {NS, NA, PH, {k_policy_mfma<NS, NA, PH, 0>, k_policy_mfma<NS, NA, PH, 1>, k_policy_mfma<NS, NA, PH, 2>}, pol_lds<NS, NA, PH>()}
+#define PENTRY(NS, NA, PH) {NS, NA, PH, {k_policy_mfma<NS, NA, PH, 0>, k_policy_mfma<NS, NA, PH, 1>, k_policy_mfma<NS, NA, PH, 2>}, pol_lds<NS, NA, PH>(), pol_image_map<NS, NA, PH>}
 static const PolEntry kPol[] = {
     PENTRY(10, 2, 32),    // swimmer
     PENTRY(18, 6, 32),    // half-cheetah
@@ -386,7 +403,18 @@ int policy_mfma_launch(metrpo_ctx* c, int idx, int mode, const metrpo_batch* b, 
     PolK k;
     k.obs = b->d_obs; k.act = b->d_act; k.adv = b->d_adv; k.old_mean = b->d_old_mean; k.old_ls = b->d_old_log_std;
     k.ls_stride = b->old_log_std_stride; k.valid = b->d_valid; k.N = b->N; k.inv_n = (float)b->inv_n_global;
-    hipLaunchKernelGGL(en.kern[mode], dim3(nblocks), dim3(256), sizeof(float) * en.lds_floats, st, k, theta, v, partials);
+    if (c->pol_img_idx != idx) {                            // first launch for this table entry: upload the gather map
+        std::vector<int> map;
+        en.build_map(map);
+        if (c->d_pol_img) { HIP_TRY(c, hipFree(c->d_pol_img)); c->d_pol_img = nullptr; }
+        HIP_TRY(c, hipMalloc(&c->d_pol_img, sizeof(int) * map.size()));
+        HIP_TRY(c, hipMemcpy(c->d_pol_img, map.data(), sizeof(int) * map.size(), hipMemcpyHostToDevice));
+        c->pol_img_idx = idx;
+    }
+    k.img_map = (const int*)c->d_pol_img;
+    const size_t sh = sizeof(float) * (size_t)en.lds_floats;
+    if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)en.kern[mode], hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    hipLaunchKernelGGL(en.kern[mode], dim3(nblocks), dim3(256), sh, st, k, theta, v, partials);
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;
 }
