@@ -258,6 +258,20 @@ int32_t metrpo_set_normalizers(metrpo_ctx* ctx, const float* d_in_mean, const fl
 int32_t metrpo_rms_accumulate(metrpo_ctx* ctx, const float* d_x, int64_t n, int32_t dim, double* d_sum, double* d_sumsq,
                               void* stream);
 
+/* ---- "next" row of the scope table: BPTT policy update ('bptt' branch, model_based_rl.py:1181-1187) ---- */
+/* Gradient of training_policy_cost = mean_i policy_costs[i] (model_based_rl.py:365) w.r.t. the policy parameters through the
+ * unrolled graph of build_policy_graph (:106-151): x <- d_init [B][ns]; T times u = clip(policy_mean(x)), x' = model_i(x, u),
+ * cost_i += gamma^t * cost_tf(x, u, x') (Ant: masked by the running `dones`).  `stochastic` is 0 (the 'bptt' branch).
+ * d_costs [K] float64 (optional) = policy_costs[i] (same values as metrpo_validation_cost); d_grad [P] float64, log_std slots 0. */
+int32_t metrpo_bptt_grad(metrpo_ctx* ctx, const float* d_init, int32_t B, int32_t T, double gamma, double* d_costs,
+                         double* d_grad, void* stream);
+/* sess.run(policy_adam_init) (model_based_rl.py:202-204): zero the policy optimizer's moments and step count. */
+int32_t metrpo_policy_adam_reset(metrpo_ctx* ctx, void* stream);
+/* policy_opt_op (get_policy_optimizer, model_based_rl.py:186-195): tf.clip_by_norm(grad, clip_val) per VARIABLE (W_l, b_l;
+ * utils.py:262-276; clip_val <= 0: none) then tf.train.AdamOptimizer(lr).apply_gradients on the ctx policy parameters. */
+int32_t metrpo_policy_adam_step(metrpo_ctx* ctx, const double* d_grad, double lr, double beta1, double beta2, double eps,
+                                double clip_val, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,6 +85,9 @@ SYMBOLS = {
     'metrpo_set_dynamics_model': (_I, [_P, _I, _P, _P]),
     'metrpo_set_normalizers': (_I, [_P, _P, _P, _P, _P, _P]),
     'metrpo_rms_accumulate': (_I, [_P, _P, _L, _I, _P, _P, _P]),
+    'metrpo_bptt_grad': (_I, [_P, _P, _I, _I, _D, _P, _P, _P]),
+    'metrpo_policy_adam_reset': (_I, [_P, _P]),
+    'metrpo_policy_adam_step': (_I, [_P, _P, _D, _D, _D, _D, _D, _P]),
 }
 # diagnostics hooks exported besides the header's ABI (used by tests to cross-check the two rollout kernels)
 EXTRA_SYMBOLS = {

@@ -98,7 +98,8 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     if (!c) return METRPO_EINVAL;
     c->device = device; c->dims = *d;
     c->d_dyn = c->d_norm = c->d_theta = nullptr; c->have_dyn = c->have_pol = false;
-    c->d_dyn_img = c->d_pol_img = nullptr; c->pol_img_idx = -1; c->mfma_cfg = -1; c->pol_mfma = -1; c->coop_cfg = -1; c->rollout_variant = 0;
+    c->d_dyn_img = c->d_pol_img = nullptr; c->pol_img_idx = -1;
+    c->d_bptt = nullptr; c->bptt_cap = 0; c->vjp_gm = nullptr; c->d_pol_adam = nullptr; c->pol_adam_t = 0; c->mfma_cfg = -1; c->pol_mfma = -1; c->coop_cfg = -1; c->rollout_variant = 0;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_cg = nullptr; c->d_vf = nullptr; c->d_theta_try = nullptr;
     c->d_valbuf = nullptr; c->h_pinned = nullptr; c->n_sm = 256;
     c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0; c->d_ticket = nullptr; c->d_adam = nullptr; c->adam_t = 0; c->d_train = nullptr; c->train_cap = 0;
@@ -139,7 +140,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
 extern "C" int32_t metrpo_destroy(metrpo_ctx* c) {
     if (!c) return METRPO_ENULL;
     void* bufs[] = {c->d_dyn, c->d_norm, c->d_theta, c->d_vf, c->d_theta_try, c->d_cg, c->d_valbuf, c->d_partials,
-                    c->d_dyn_img, c->d_pol_img, c->d_vbuf, c->d_gram_part, c->d_big, c->d_ticket, c->d_adam, c->d_train};
+                    c->d_dyn_img, c->d_pol_img, c->d_vbuf, c->d_gram_part, c->d_big, c->d_ticket, c->d_adam, c->d_train, c->d_bptt, c->d_pol_adam};
     for (void* p : bufs) if (p) (void)hipFree(p);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     delete c;
@@ -493,4 +494,28 @@ extern "C" int32_t metrpo_trpo_update(metrpo_ctx* c, const metrpo_batch* b, cons
     if (!b || !pr) return set_err(c, METRPO_ENULL, "trpo_update: NULL pointer");
     if (pr->cg_iters < 0 || pr->max_backtracks < 1) return set_err(c, METRPO_EINVAL, "trpo_update: bad cg_iters/max_backtracks");
     return run_trpo_update(c, b, pr, diag, g_out, dir_out, (hipStream_t)stream);
+}
+
+// ---- BPTT policy update -----------------------------------------------------------------------
+extern "C" int32_t metrpo_bptt_grad(metrpo_ctx* c, const float* init, int32_t B, int32_t T, double gamma, double* costs, double* grad,
+                                    void* stream) {
+    if (!c) return METRPO_ENULL;
+    NEED_DYN(c); NEED_POL(c);
+    if (B <= 0 || T <= 0) return set_err(c, METRPO_EINVAL, "bptt_grad: B and T must be positive");
+    if (!init) return set_err(c, METRPO_ENULL, "bptt_grad: NULL pointer");
+    return launch_bptt_grad(c, init, B, T, gamma, costs, grad, (hipStream_t)stream);
+}
+
+extern "C" int32_t metrpo_policy_adam_reset(metrpo_ctx* c, void* stream) {
+    if (!c) return METRPO_ENULL;
+    return launch_policy_adam(c, nullptr, 0.0, 0.9, 0.999, 1e-8, 0.0, true, (hipStream_t)stream);
+}
+
+extern "C" int32_t metrpo_policy_adam_step(metrpo_ctx* c, const double* grad, double lr, double beta1, double beta2, double eps,
+                                           double clip_val, void* stream) {
+    if (!c) return METRPO_ENULL;
+    NEED_POL(c);
+    if (!grad) return set_err(c, METRPO_ENULL, "policy_adam_step: NULL pointer");
+    if (!(lr >= 0.0)) return set_err(c, METRPO_EINVAL, "policy_adam_step: bad learning rate");
+    return launch_policy_adam(c, grad, lr, beta1, beta2, eps, clip_val, false, (hipStream_t)stream);
 }

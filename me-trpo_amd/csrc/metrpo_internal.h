@@ -41,6 +41,10 @@ struct metrpo_ctx {
     float* d_dyn_img;    // per-model register image, see rollout_mfma.hip
     float* d_pol_img;    // (int32 payload) gather map of the policy weight-fragment image, see policy_mfma.hip
     int pol_img_idx;     // table index the map was built for (-1: none)
+    // --- BPTT (bptt.hip) ---
+    void* d_bptt; size_t bptt_cap;      // XS | WT | GM | gout | costs
+    const float* vjp_gm;                // set around the VJP launch of the gradient kernels
+    void* d_pol_adam; int pol_adam_t;   // Adam moments of the policy parameters + segment table
     int mfma_cfg;        // index into the instantiation table, -1 = generic path only
     int pol_mfma;        // index into policy_mfma.hip's table, -1 = generic update kernels
     int coop_cfg;        // index into rollout_coop.hip's table, -1 = head-per-wave kernel (rollout_mfma.hip)
@@ -83,6 +87,7 @@ struct RolloutK {          // device-side copy of metrpo_rollout_args (plain poi
 struct PolK {
     const float* obs; const float* act; const float* adv; const float* old_mean; const float* old_ls;
     int ls_stride; const uint8_t* valid; long long N; float inv_n;
+    const float* gm;         // non-NULL: VJP mode of the gradient kernels (bptt.hip): d objective / d mean [N][na] supplied, no loss terms
     const int* img_map;      // policy_mfma.hip: gather map of the LDS weight-fragment image (built once per ctx on the host)
 };
 
@@ -105,6 +110,9 @@ int launch_step(metrpo_ctx*, const float*, const float*, int, int, const int32_t
 int launch_rollout_generic(metrpo_ctx*, const metrpo_rollout_args*, hipStream_t);
 bool gemm_path_applicable(const metrpo_ctx*);
 int launch_rollout_gemm(metrpo_ctx*, const metrpo_rollout_args*, hipStream_t);
+int launch_bptt_grad(metrpo_ctx*, const float* init, int B, int T, double gamma, double* costs, double* grad, hipStream_t);
+int launch_policy_adam(metrpo_ctx*, const double* grad, double lr, double b1, double b2, double eps, double clip_val, bool reset, hipStream_t);
+int launch_policy_vjp(metrpo_ctx*, const float* obs, const float* gm, long long N, double* out, hipStream_t);
 int launch_dyn_train_step(metrpo_ctx*, const float*, const float*, const metrpo_train_params*, double*, hipStream_t);
 int launch_dyn_eval_losses(metrpo_ctx*, const float*, const float*, long long, double, double*, hipStream_t);
 int launch_rms_accumulate(metrpo_ctx*, const float*, long long, int, double*, double*, hipStream_t);

@@ -186,7 +186,10 @@ __global__ void __launch_bounds__(256, 2) k_policy_mfma(PolK k, const float* __r
         }
 
         f32x4 um = Z4;                                      // d(objective)/d(mean) in D layout [d = 4q+r][sample c]
-        if (MODE != MODE_FVP) {
+        if (MODE == MODE_GRAD && k.gm != nullptr) {         // VJP mode (bptt.hip): the mean-adjoint is an input
+#pragma unroll
+            for (int r = 0; r < 4; ++r) um[r] = (ok && 4 * q + r < NA) ? k.gm[n * NA + 4 * q + r] : 0.f;
+        } else if (MODE != MODE_FVP) {
             f32x4 m0 = b2f, m1 = Z4;
 #pragma unroll
             for (int kk = 0; kk < KK; kk += 2) {
@@ -412,6 +415,7 @@ int policy_mfma_launch(metrpo_ctx* c, int idx, int mode, const metrpo_batch* b, 
         c->pol_img_idx = idx;
     }
     k.img_map = (const int*)c->d_pol_img;
+    k.gm = c->vjp_gm;
     const size_t sh = sizeof(float) * (size_t)en.lds_floats;
     if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)en.kern[mode], hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     hipLaunchKernelGGL(en.kern[mode], dim3(nblocks), dim3(256), sh, st, k, theta, v, partials);

@@ -121,6 +121,11 @@ __global__ void __launch_bounds__(PT) k_loss_grad(ProblemDesc pd, PolK k, const 
         const bool ok = load_obs_tile<PT>(k, ns, base, H, tid);
         forward_store<PT>(net, theta, H, DM, tid);
         const long long n = base + tid;
+        if (k.gm != nullptr) {                                  // VJP mode (bptt.hip): d objective / d mean supplied
+            for (int d = 0; d < na; ++d) DM[d * PLD + tid] = ok ? k.gm[n * na + d] : 0.0f;
+            backward_accumulate<PT>(net, theta, H, DM, part, tid);
+            continue;
+        }
         float w = 0.0f;
         if (ok) {
             float llr = 0.0f;                                   // logli_new - logli_old
@@ -347,6 +352,7 @@ static int fill_polk(metrpo_ctx* c, const metrpo_batch* b, PolK* k, bool need_ta
         return set_err(c, METRPO_ENULL, "batch pointer is NULL");
     k->obs = b->d_obs; k->act = b->d_act; k->adv = b->d_adv; k->old_mean = b->d_old_mean; k->old_ls = b->d_old_log_std;
     k->ls_stride = b->old_log_std_stride; k->valid = b->d_valid; k->N = b->N; k->inv_n = (float)b->inv_n_global;
+    k->gm = nullptr; k->img_map = nullptr;
     return METRPO_OK;
 }
 
@@ -409,6 +415,24 @@ int launch_loss_grad(metrpo_ctx* c, const metrpo_batch* b, double* out, hipStrea
     PolK k; int rc = fill_polk(c, b, &k, true); if (rc) return rc;
     int nrows, stride, lk;
     if ((rc = run_mode(c, 0, b, k, c->d_theta, nullptr, &nrows, &stride, &lk, st))) return rc;
+    finalize(c, 0, nrows, stride, lk, nullptr, out, st);
+    HIP_TRY(c, hipGetLastError());
+    return METRPO_OK;
+}
+
+// sum_n J_policy(obs_n)^T gm_n -> out[1 .. P] (out[0] = 0): the gradient kernels with the mean-adjoint supplied (bptt.hip)
+int launch_policy_vjp(metrpo_ctx* c, const float* obs, const float* gm, long long N, double* out, hipStream_t st) {
+    if (!obs || !gm || !out) return set_err(c, METRPO_ENULL, "policy_vjp: NULL pointer");
+    if (c->pd.na > 32) return set_err(c, METRPO_EUNSUPPORTED, "na > 32");
+    metrpo_batch b = {};
+    b.d_obs = obs; b.N = N; b.inv_n_global = 1.0;
+    PolK k = {};
+    k.obs = obs; k.N = N; k.inv_n = 1.0f; k.gm = gm;
+    int nrows, stride, lk;
+    c->vjp_gm = gm;
+    const int rc = run_mode(c, 0, &b, k, c->d_theta, nullptr, &nrows, &stride, &lk, st);
+    c->vjp_gm = nullptr;
+    if (rc) return rc;
     finalize(c, 0, nrows, stride, lk, nullptr, out, st);
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;

@@ -326,6 +326,26 @@ class Engine(object):
         self._chk(lib.metrpo_rms_accumulate(self._ctx, _ptr(x), x.shape[0], x.shape[1], _ptr(rsum), _ptr(rsumsq), self._stream()))
         self._keep_rms = x
 
+    # ---- BPTT policy update ('bptt' branch of optimize_policy, model_based_rl.py:1181-1187) ----
+    def bptt_grad(self, init_states, T, gamma=1.0):
+        """-> (costs [K] float64 device tensor = policy_costs per model, grad [P] float64 device tensor of mean_k cost)."""
+        x0 = _f32(init_states, self.device)
+        costs = torch.empty(self.K, dtype=torch.float64, device=self.device)
+        grad = torch.empty(self.P, dtype=torch.float64, device=self.device)
+        self._chk(lib.metrpo_bptt_grad(self._ctx, _ptr(x0), x0.shape[0], int(T), float(gamma), _ptr(costs), _ptr(grad), self._stream()))
+        self._keep_bptt = x0
+        return costs, grad
+
+    def policy_adam_reset(self):
+        self._chk(lib.metrpo_policy_adam_reset(self._ctx, self._stream()))
+
+    def policy_adam_step(self, grad, lr, clip_val=None, beta1=0.9, beta2=0.999, eps=1e-8):
+        g = grad if isinstance(grad, torch.Tensor) else torch.as_tensor(grad)
+        g = g.to(self.device, torch.float64).contiguous()
+        self._chk(lib.metrpo_policy_adam_step(self._ctx, _ptr(g), float(lr), float(beta1), float(beta2), float(eps),
+                                              float(clip_val) if clip_val else 0.0, self._stream()))
+        self._keep_adam = g
+
 
 class _DevView(object):
     """Zero-copy float64 view of library-owned device memory for torch (CUDA array interface)."""
