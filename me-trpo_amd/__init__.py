@@ -18,6 +18,7 @@ from .algos import BatchPolopt, NPO, TRPO
 from . import early_stop
 from . import dynamics_training
 from .bptt import BPTT
+from . import formats
 
 __all__ = ['Engine', 'Trajectory', 'xavier_policy_theta', 'Comm', 'NeuralNetEnv', 'VecSimpleEnv', 'InitStatePool',
            'Box', 'EnvSpec', 'GaussianMLPPolicy', 'LinearFeatureBaseline', 'VectorizedSampler', 'BaseSampler',

@@ -510,6 +510,9 @@ def gen_collect_split():
         np.random.seed(1000 + ci)
         with tempfile.TemporaryDirectory() as td:
             ref_mbrl.collect_data(None, 10, data, val, None, None, None, None, None, None, td, rp, 0, logger, None, irms, orms)
+            if ci == 0:                                # the file the reference itself wrote (model_based_rl.py:809-811): a data fixture
+                import shutil
+                shutil.copy(os.path.join(td, 'new_rollouts_0.pkl'), os.path.join(HERE, 'new_rollouts_0.pkl'))
         arrs['c%d_mode' % ci] = np.array(0 if mode == 'trajectory' else 1)
         arrs['c%d_same' % ci] = np.array(int(same)); arrs['c%d_ratio' % ci] = np.array(ratio); arrs['c%d_scopes' % ci] = np.array(n_scopes)
         arrs['c%d_seed' % ci] = np.array(1000 + ci)

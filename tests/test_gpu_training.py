@@ -200,3 +200,20 @@ def test_optimize_models_loop_fits_and_restores_best():
     # the refreshed ensemble is what the rollout kernels now use
     traj = eng.rollout(64, 5, 5, 'step_rand', pool, seed=1)
     assert torch.isfinite(traj.obs).all()
+
+
+def test_dynamics_npz_round_trip(tmp_path):
+    """formats.save_dynamics_npz / load_dynamics_npz: the payload of the reference's <scope>_<i>.ckpt savers under its variable names."""
+    import metrpo_amd
+    from metrpo_amd import formats
+    eng, dm, theta, pdims, pool = Hh.make_engine('swimmer', 3, (24, 16), (8, 8), seed=77)
+    p = str(tmp_path / 'training_dynamics.npz')
+    formats.save_dynamics_npz(p, eng)
+    z = np.load(p)
+    assert sorted(z.files)[:2] == ['model0/layer0/biases', 'model0/layer0/weights']
+    np.testing.assert_array_equal(z['model2/layer1/weights'], dm.Ws[1][2].astype(np.float32))
+    before = eng.get_dynamics().clone()
+    for k in range(3):
+        eng.set_dynamics_model(k, torch.zeros_like(before[k]))
+    formats.load_dynamics_npz(p, eng)
+    assert torch.equal(eng.get_dynamics(), before)
