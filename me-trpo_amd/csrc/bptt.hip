@@ -251,6 +251,7 @@ int launch_bptt_grad(metrpo_ctx* c, const float* init, int B, int T, double gamm
     const size_t nXS = (((size_t)K * (T + 1) * B * ns) + 3) & ~(size_t)3, nWT = (((size_t)K * T * B) + 3) & ~(size_t)3,
                  nGM = (((size_t)K * (T + 1) * B * na) + 3) & ~(size_t)3;
     const size_t need = (nXS + nWT + nGM) * sizeof(float) + sizeof(double) * (size_t)(pd.P + 1 + K);
+    if (c->det_cfg >= 0) { const int rc0 = ensure_detpart(c, B); if (rc0) return rc0; }
     if (need > c->bptt_cap) {
         if (c->d_bptt) HIP_TRY(c, hipFree(c->d_bptt));
         c->d_bptt = nullptr; c->bptt_cap = 0;
@@ -259,6 +260,17 @@ int launch_bptt_grad(metrpo_ctx* c, const float* init, int B, int T, double gamm
     }
     float* XS = (float*)c->d_bptt; float* WT = XS + nXS; float* GM = WT + nWT;
     double* gout = (double*)(GM + nGM); double* cst = gout + pd.P + 1;
+    HIP_TRY(c, hipMemsetAsync(GM, 0, sizeof(float) * nGM, st));
+    if (c->det_cfg >= 0) {                                   // MFMA sweeps (bptt_mfma.hip)
+        int rc1 = launch_det_forward(c, c->det_cfg, init, B, T, gamma, XS, WT, c->d_detpart, cst, st);
+        if (rc1) return rc1;
+        if ((rc1 = launch_det_backward(c, c->det_cfg, B, T, XS, WT, GM, st))) return rc1;
+        const int rc2 = launch_policy_vjp(c, XS, GM, (long long)K * (T + 1) * B, gout, st);
+        if (rc2) return rc2;
+        if (grad) HIP_TRY(c, hipMemcpyAsync(grad, gout + 1, sizeof(double) * pd.P, hipMemcpyDeviceToDevice, st));
+        if (costs) HIP_TRY(c, hipMemcpyAsync(costs, cst, sizeof(double) * K, hipMemcpyDeviceToDevice, st));
+        return METRPO_OK;
+    }
     const size_t fpt = bptt_floats(pd);
     const size_t LDS_MAX = 160 * 1024;
     int bs = 64;
@@ -270,7 +282,6 @@ int launch_bptt_grad(metrpo_ctx* c, const float* init, int B, int T, double gamm
         HIP_TRY(c, hipFuncSetAttribute((const void*)k_bptt_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     }
     HIP_TRY(c, hipMemsetAsync(cst, 0, sizeof(double) * K, st));
-    HIP_TRY(c, hipMemsetAsync(GM, 0, sizeof(float) * nGM, st));
     const dim3 grid((B + bs - 1) / bs, K);
     hipLaunchKernelGGL(k_bptt_forward, grid, dim3(bs), sh, st, pd, c->d_dyn, c->d_theta, c->d_norm, init, B, T, gamma, XS, WT, cst);
     hipLaunchKernelGGL(k_bptt_backward, grid, dim3(bs), sh, st, pd, c->d_dyn, c->d_theta, c->d_norm, B, T, XS, WT, GM);
@@ -306,5 +317,16 @@ int launch_policy_adam(metrpo_ctx* c, const double* grad, double lr, double b1, 
     hipLaunchKernelGGL(k_policy_adam, dim3(nseg), dim3(256), 0, st, nseg, (const int*)(av + P), grad, c->d_theta, am, av, (float)lr_t, (float)b1,
                        (float)b2, (float)eps, clip_val);
     HIP_TRY(c, hipGetLastError());
+    return METRPO_OK;
+}
+
+int ensure_detpart(metrpo_ctx* c, int B) {
+    const size_t need = sizeof(double) * (size_t)c->pd.K * (size_t)(4 * ((B + 63) / 64));
+    if (need > c->detpart_cap) {
+        if (c->d_detpart) HIP_TRY(c, hipFree(c->d_detpart));
+        c->d_detpart = nullptr; c->detpart_cap = 0;
+        HIP_TRY(c, hipMalloc(&c->d_detpart, need));
+        c->detpart_cap = need;
+    }
     return METRPO_OK;
 }

@@ -53,8 +53,7 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
 
     // "strided" staging (source is [X][k] with k contiguous: float4 along k, scattered into S[k][x]) for A when !TA and for B when TB;
     // "direct" staging (source is [k][X] with X contiguous: float4 along X, stored as float4) for A when TA and for B when !TB.
-    constexpr int SA_Q = 256 / BM, SA_P = (BK / 4) / SA_Q;                 // strided A: quads per pass, passes
-    constexpr int SB_Q = 256 / BN, SB_P = (BK / 4) / SB_Q;                 // strided B
+    constexpr int SA_P = BM / 64, SB_P = BN / 64;                          // strided staging: 64 rows x 4 quads per pass
     constexpr int DA_R = 256 / (BM / 4), DA_P = BK / DA_R;                 // direct A: rows per pass, passes
     constexpr int DB_R = 256 / (BN / 4), DB_P = BK / DB_R;                 // direct B
     constexpr int NA = TA ? DA_P : SA_P, NB = TB ? SB_P : DB_P;
@@ -72,8 +71,8 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
     auto load_tiles = [&](int k0) {
         if (!TA) {
 #pragma unroll
-            for (int p = 0; p < SA_P; ++p) {
-                const int kq = (tid / BM + p * SA_Q) * 4, m = m0 + tid % BM;
+            for (int p = 0; p < SA_P; ++p) {                       // 4 consecutive lanes read the 4 quads (64 B) of one row
+                const int kq = (tid & 3) * 4, m = m0 + (tid >> 2) + p * 64;
                 ra[p] = (m < M) ? ld4(A + (size_t)m * lda + k0 + kq, kend - (k0 + kq)) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
@@ -92,7 +91,7 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
         } else {
 #pragma unroll
             for (int p = 0; p < SB_P; ++p) {
-                const int kq = (tid / BN + p * SB_Q) * 4, n = n0 + tid % BN;
+                const int kq = (tid & 3) * 4, n = n0 + (tid >> 2) + p * 64;
                 rb[p] = (n < N) ? ld4(W + (size_t)n * ldw + k0 + kq, kend - (k0 + kq)) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
@@ -101,7 +100,7 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
         if (!TA) {
 #pragma unroll
             for (int p = 0; p < SA_P; ++p) {
-                const int kq = (tid / BM + p * SA_Q) * 4, m = tid % BM;
+                const int kq = (tid & 3) * 4, m = (tid >> 2) + p * 64;
                 As[buf][kq + 0][m] = ra[p].x; As[buf][kq + 1][m] = ra[p].y; As[buf][kq + 2][m] = ra[p].z; As[buf][kq + 3][m] = ra[p].w;
             }
         } else {
@@ -114,7 +113,7 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
         } else {
 #pragma unroll
             for (int p = 0; p < SB_P; ++p) {
-                const int kq = (tid / BN + p * SB_Q) * 4, n = tid % BN;
+                const int kq = (tid & 3) * 4, n = (tid >> 2) + p * 64;
                 Bs[buf][kq + 0][n] = rb[p].x; Bs[buf][kq + 1][n] = rb[p].y; Bs[buf][kq + 2][n] = rb[p].z; Bs[buf][kq + 3][n] = rb[p].w;
             }
         }

@@ -45,6 +45,8 @@ struct metrpo_ctx {
     void* d_bptt; size_t bptt_cap;      // XS | WT | GM | gout | costs
     const float* vjp_gm;                // set around the VJP launch of the gradient kernels
     void* d_pol_adam; int pol_adam_t;   // Adam moments of the policy parameters + segment table
+    int det_cfg;                        // bptt_mfma.hip table index (-1: generic sweeps / generic validation kernel)
+    double* d_detpart; size_t detpart_cap;   // per-tile cost partials of the MFMA forward sweep
     int mfma_cfg;        // index into the instantiation table, -1 = generic path only
     int pol_mfma;        // index into policy_mfma.hip's table, -1 = generic update kernels
     int coop_cfg;        // index into rollout_coop.hip's table, -1 = head-per-wave kernel (rollout_mfma.hip)
@@ -112,6 +114,10 @@ bool gemm_path_applicable(const metrpo_ctx*);
 int launch_rollout_gemm(metrpo_ctx*, const metrpo_rollout_args*, hipStream_t);
 int launch_bptt_grad(metrpo_ctx*, const float* init, int B, int T, double gamma, double* costs, double* grad, hipStream_t);
 int launch_policy_adam(metrpo_ctx*, const double* grad, double lr, double b1, double b2, double eps, double clip_val, bool reset, hipStream_t);
+int det_mfma_select(const metrpo_ctx*);
+int launch_det_forward(metrpo_ctx*, int idx, const float* s0, int B, int T, double gamma, float* XS, float* WT, double* part, double* costs, hipStream_t);
+int launch_det_backward(metrpo_ctx*, int idx, int B, int T, const float* XS, const float* WT, float* GM, hipStream_t);
+int ensure_detpart(metrpo_ctx*, int B);
 int launch_policy_vjp(metrpo_ctx*, const float* obs, const float* gm, long long N, double* out, hipStream_t);
 int launch_dyn_train_step(metrpo_ctx*, const float*, const float*, const metrpo_train_params*, double*, hipStream_t);
 int launch_dyn_eval_losses(metrpo_ctx*, const float*, const float*, long long, double, double*, hipStream_t);

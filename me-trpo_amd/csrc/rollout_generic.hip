@@ -345,6 +345,10 @@ int launch_rollout_generic(metrpo_ctx* c, const metrpo_rollout_args* a, hipStrea
 
 int launch_validation_cost(metrpo_ctx* c, const float* s0, int Bv, int T, double gamma, double* costs, hipStream_t st) {
     const ProblemDesc& pd = c->pd;
+    if (c->det_cfg >= 0) {                                   // MFMA forward sweep (bptt_mfma.hip), costs only
+        const int rc0 = ensure_detpart(c, Bv); if (rc0) return rc0;
+        return launch_det_forward(c, c->det_cfg, s0, Bv, T, gamma, nullptr, nullptr, c->d_detpart, costs, st);
+    }
     int bs; size_t sh;
     int rc = pick_block(c, envbufs_floats(pd, METRPO_SAM_EPS_RAND, 1), Bv, &bs, &sh);
     if (rc) return rc;

@@ -326,6 +326,10 @@ class Engine(object):
         self._chk(lib.metrpo_rms_accumulate(self._ctx, _ptr(x), x.shape[0], x.shape[1], _ptr(rsum), _ptr(rsumsq), self._stream()))
         self._keep_rms = x
 
+    def set_det_path(self, use_mfma):
+        """test hook: per-model deterministic rollouts (validation cost, BPTT sweeps) on the MFMA kernels (True) or the generic ones."""
+        return int(lib.metrpo_set_det_path(self._ctx, 1 if use_mfma else 0))
+
     # ---- BPTT policy update (SURVEY 8f rank 3; 'bptt' branch of optimize_policy, model_based_rl.py:1181-1187) ----
     def bptt_grad(self, init_states, T, gamma=1.0):
         """-> (costs [K] float64 device tensor = policy_costs per model, grad [P] float64 device tensor of mean_k cost)."""

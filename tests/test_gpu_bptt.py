@@ -55,6 +55,32 @@ def test_bptt_gradient_matches_oracle(env, K, dh, ph, B, T, gamma):
     assert cosine > 1.0 - 1e-7
 
 
+@pytest.mark.parametrize('env', ['swimmer', 'half_cheetah', 'hopper', 'snake', 'ant'])
+def test_mfma_and_generic_sweeps_agree(env):
+    """every env of the MFMA table: MFMA sweeps (default) vs the generic sweep kernels vs the oracle, incl. ragged batch sizes."""
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, 3, (64, 64), (32, 32), seed=95)
+    rng = np.random.RandomState(6)
+    theta = theta + 0.2 * rng.randn(theta.size); theta[-dm.na:] = 0.0
+    eng.set_policy(theta)
+    B, T, gamma = 77, 11, 0.98                                   # 77 = one full 64-env workgroup + a ragged 13-env tile
+    x0 = (pool[:B] * (3.0 if env in ('hopper', 'half_cheetah') else 1.0)).astype(np.float32)
+    if env == 'ant':
+        x0[:20, 2] = 0.15
+    if env == 'hopper':
+        x0[:10, 1] = 0.5; x0[10:20, 0] = 0.2; x0[20:24, 4] = 150.0
+    assert eng.set_det_path(True) == 1
+    cm, gm = eng.bptt_grad(x0, T, gamma); vm = eng.validation_cost(x0, T, gamma)
+    cm, gm, vm = cpu(cm), cpu(gm), cpu(vm)
+    assert eng.set_det_path(False) == 0
+    cg, gg = eng.bptt_grad(x0, T, gamma); vg = eng.validation_cost(x0, T, gamma)
+    eng.set_det_path(True)
+    th32 = cpu(eng.get_policy()).astype(np.float64)
+    oc, og = Bp.policy_costs_and_grad(dm.astype(np.float32).astype(np.float64), th32, pdims, env, x0.astype(np.float64), T, gamma)
+    np.testing.assert_allclose(cm, oc, rtol=2e-4, atol=2e-5); np.testing.assert_allclose(vm, cm, rtol=1e-12)
+    np.testing.assert_allclose(cpu(cg), oc, rtol=2e-4, atol=2e-5); np.testing.assert_allclose(cpu(vg), cpu(cg), rtol=1e-6, atol=1e-7)
+    assert rel_l2(gm, og) < 2e-4 and rel_l2(cpu(gg), og) < 2e-4 and rel_l2(gm, cpu(gg)) < 2e-4
+
+
 def test_bptt_gradient_is_bitwise_reproducible_and_linear_in_weights():
     eng, dm, theta, pdims, pool = Hh.make_engine('swimmer', 5, (64, 64), (32, 32), seed=92)
     x0 = pool[:256].astype(np.float32)
