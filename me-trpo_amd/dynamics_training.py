@@ -27,6 +27,22 @@ class data_collection(object):
             self.n_data = self.max_size
             self.cur_idx -= new_start_idx
 
+    def clone(self, dc, first_i=None):
+        assert first_i is None or first_i <= dc.n_data, "Not enough data for first_i."
+        self.set_data(dc.x[:first_i], dc.y[:first_i])
+
+    def set_data(self, x, y, is_shuffled=False):
+        """utils.py:67-76 incl. its quirks: cur_idx wraps with the uncapped row count; is_shuffled permutes idx_mapping only
+        (remap() is the identity, :110-111), i.e. it consumes np.random and changes no batch."""
+        x, y = self._t(x), self._t(y)
+        assert x.shape[0] == y.shape[0]
+        self.n_data, self.x, self.y = x.shape[0], x, y
+        self.cur_idx %= self.n_data
+        self.cap_data_size()
+        self.idx_mapping = list(range(self.n_data))
+        if is_shuffled:
+            self.reshuffle_indices()
+
     def add_data(self, x_new, y_new, is_shuffled=False):
         x_new, y_new = self._t(x_new), self._t(y_new)
         assert x_new.shape[0] == y_new.shape[0]
@@ -37,6 +53,18 @@ class data_collection(object):
             self.cur_idx, self.x, self.y = 0, x_new, y_new
         self.n_data = self.x.shape[0]
         self.cap_data_size()
+        self.idx_mapping = list(range(self.n_data))
+        if is_shuffled:
+            self.reshuffle_indices()
+
+    def reshuffle_indices(self):
+        np.random.shuffle(self.idx_mapping)
+
+    def reshuffle_data(self):
+        shuffled = list(range(self.n_data))
+        np.random.shuffle(shuffled)
+        idx = torch.as_tensor(np.asarray(shuffled, dtype=np.int64), device=self.x.device)
+        self.x, self.y = self.x.index_select(0, idx), self.y.index_select(0, idx)
 
     def get_num_data(self):
         return 0 if self.n_data is None else self.n_data
@@ -60,6 +88,17 @@ class data_collection(object):
         """Uniformly random batch with replacement -- same np.random.uniform draw as utils.py:127-129."""
         indices = np.floor(self.n_data * np.random.uniform(0.0, 1.0, size=batch_size)).astype(np.intp)
         return self._gather(indices)
+
+
+def combine_data_collections(dc1, dc2):
+    """utils.py:133-142."""
+    out = data_collection(max_size=max(dc1.max_size, dc2.max_size), device=dc1.device)
+    if dc2.max_size < dc1.max_size:
+        x, y = torch.cat([dc1.x, dc2.x]), torch.cat([dc1.y, dc2.y])
+    else:
+        x, y = torch.cat([dc2.x, dc1.x]), torch.cat([dc2.y, dc1.y])
+    out.set_data(x, y)
+    return out
 
 
 class RunningMeanStd(object):

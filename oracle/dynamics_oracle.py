@@ -32,7 +32,22 @@ class DataCollectionOracle(object):
             self.n_data = self.max_size
             self.cur_idx -= new_start_idx
 
-    def add_data(self, x_new, y_new):
+    def clone(self, dc, first_i=None):
+        assert first_i is None or first_i <= dc.n_data
+        self.set_data(dc.x[:first_i], dc.y[:first_i])
+
+    def set_data(self, x, y, is_shuffled=False, rng=np.random):
+        """utils.py:67-76.  Quirks kept: cur_idx is wrapped with the UNCAPPED row count, and shuffling only permutes idx_mapping,
+        which remap() ignores (:110-111) -- it consumes np.random but never changes a batch."""
+        assert x.shape[0] == y.shape[0]
+        self.n_data, self.x, self.y = x.shape[0], x, y
+        self.cur_idx %= self.n_data
+        self.cap_data_size()
+        self.idx_mapping = list(range(self.n_data))
+        if is_shuffled:
+            rng.shuffle(self.idx_mapping)
+
+    def add_data(self, x_new, y_new, is_shuffled=False, rng=np.random):
         assert x_new.shape[0] == y_new.shape[0]
         if self.x is not None:
             self.cur_idx = self.x.shape[0]
@@ -42,6 +57,9 @@ class DataCollectionOracle(object):
             self.cur_idx, self.x, self.y = 0, x_new, y_new
         self.n_data = self.x.shape[0]
         self.cap_data_size()
+        self.idx_mapping = list(range(self.n_data))
+        if is_shuffled:
+            rng.shuffle(self.idx_mapping)
 
     def get_num_data(self):
         return 0 if self.n_data is None else self.n_data
@@ -98,6 +116,17 @@ def collect_split(x_all, y_all, data, val, splitting_mode, use_same_dataset, spl
             data[scope].add_data(x_all[indices[cur_i:cur_i + m], :], y_all[indices[cur_i:cur_i + m], :])
             cur_i += m
     assert cur_i == total
+
+
+def combine_data_collections(dc1, dc2):
+    """utils.py:133-142: the collection with the SMALLER max_size goes last (its rows survive the FIFO cap)."""
+    out = DataCollectionOracle(max(dc1.max_size, dc2.max_size))
+    if dc2.max_size < dc1.max_size:
+        x, y = np.concatenate([dc1.x, dc2.x], axis=0), np.concatenate([dc1.y, dc2.y], axis=0)
+    else:
+        x, y = np.concatenate([dc2.x, dc1.x], axis=0), np.concatenate([dc2.y, dc1.y], axis=0)
+    out.set_data(x, y)
+    return out
 
 
 def compute_baseline_loss(x_batch, y_batch, n_models):

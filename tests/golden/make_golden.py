@@ -526,7 +526,34 @@ def gen_collect_split():
     save('collect_split', **arrs)
 
 
+
+# ---------------------------------------------------------------- 11. the reference's own replay-buffer tests (utils.py:145-176)
+def gen_reference_buffer_tests():
+    """Runs utils.test_data_collection / test_combine_data_collection with get_next_batch recorded: their known answers."""
+    log = []
+    orig = ref_utils.data_collection.get_next_batch
+    def rec(self, batch_size, is_shuffled=False):
+        xb, yb = orig(self, batch_size, is_shuffled)
+        log.append((np.array(xb), np.array(yb), self.cur_idx, self.n_data))
+        return xb, yb
+    ref_utils.data_collection.get_next_batch = rec
+    np.random.seed(4242)
+    try:
+        ref_utils.test_data_collection()
+    finally:
+        ref_utils.data_collection.get_next_batch = orig
+    a, b = ref_utils.test_combine_data_collection()
+    arrs = dict(n_batches=np.array(len(log)), seed=np.array(4242), comb_ax=np.array(a.x), comb_ay=np.array(a.y), comb_bx=np.array(b.x),
+                comb_by=np.array(b.y), comb_a_n=np.array(a.n_data), comb_b_n=np.array(b.n_data), comb_a_cur=np.array(a.cur_idx),
+                comb_b_cur=np.array(b.cur_idx), comb_a_max=np.array(a.max_size), comb_b_max=np.array(b.max_size),
+                rng_after=np.array(np.random.randint(1 << 30)))
+    for i, (xb, yb, cur, n) in enumerate(log):
+        arrs['bx%d' % i], arrs['by%d' % i], arrs['cur%d' % i], arrs['n%d' % i] = xb, yb, np.array(cur), np.array(n)
+    save('dyn_buffer_reftests', **arrs)
+
+
 if __name__ == '__main__':
+    gen_reference_buffer_tests()
     gen_collect_split()
     gen_dynamics_data()
     gen_rewards()

@@ -217,3 +217,11 @@ def test_dynamics_npz_round_trip(tmp_path):
         eng.set_dynamics_model(k, torch.zeros_like(before[k]))
     formats.load_dynamics_npz(p, eng)
     assert torch.equal(eng.get_dynamics(), before)
+
+
+def test_reference_own_buffer_tests_on_the_device_collection():
+    """utils.test_data_collection / test_combine_data_collection (the reference's own tests of this row) on the GPU-resident buffer."""
+    import metrpo_amd
+    from metrpo_amd.dynamics_training import data_collection, combine_data_collections
+    from test_oracle_dynamics import run_reference_buffer_tests
+    run_reference_buffer_tests(lambda m: data_collection(m, device='cuda'), combine_data_collections, to_np=cpu)

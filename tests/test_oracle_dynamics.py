@@ -97,6 +97,41 @@ def test_train_steps_match_tf_style_adam_on_autograd(reg):
         np.testing.assert_allclose(dm.bs[l], bs[l].detach().numpy(), rtol=1e-9, atol=1e-12)
 
 
+def run_reference_buffer_tests(make, combine, to_np=np.asarray):
+    """The bodies of the reference's OWN tests utils.test_data_collection / test_combine_data_collection (utils.py:145-176),
+    replayed on `make(max_size)` collections; every get_next_batch result and the combined collections are compared with what the
+    reference's classes produced (tests/golden/dyn_buffer_reftests.npz)."""
+    d = load_golden('dyn_buffer_reftests')
+    np.random.seed(int(d['seed']))
+    got = []
+    dc = make(3)
+    x = np.array([[1, 2], [3, 4], [5, 6], [7, 8]])
+    def nb(n):
+        xb, yb = dc.get_next_batch(n)
+        got.append((to_np(xb), to_np(yb), dc.cur_idx, dc.n_data))
+    dc.set_data(x, x); nb(2); nb(2); nb(2)
+    dc.set_data(x, x, True); nb(2); nb(2); nb(2)
+    x_new = np.array([[0, 0]])
+    dc.add_data(x_new, x_new); nb(2); nb(2); nb(2)
+    x_new = np.array([[9, 9], [8, 8]])
+    dc.add_data(x_new, x_new, True); nb(2); nb(2); nb(2)
+    assert len(got) == int(d['n_batches'])
+    for i, (xb, yb, cur, n) in enumerate(got):
+        np.testing.assert_array_equal(xb, d['bx%d' % i]); np.testing.assert_array_equal(yb, d['by%d' % i])
+        assert cur == int(d['cur%d' % i]) and n == int(d['n%d' % i])
+    dc1 = make(10); xx = np.reshape(np.arange(20), (10, 2)); dc1.set_data(xx, xx)
+    yy = np.reshape(-np.arange(10), (5, 2)); dc2 = make(5); dc2.set_data(yy, yy)
+    a, b = combine(dc1, dc2), combine(dc2, dc1)
+    for c, k in ((a, 'a'), (b, 'b')):
+        np.testing.assert_array_equal(to_np(c.x), d['comb_%sx' % k]); np.testing.assert_array_equal(to_np(c.y), d['comb_%sy' % k])
+        assert c.n_data == int(d['comb_%s_n' % k]) and c.cur_idx == int(d['comb_%s_cur' % k]) and c.max_size == int(d['comb_%s_max' % k])
+    assert np.random.randint(1 << 30) == int(d['rng_after'])          # the shuffles consumed exactly the reference's share of np.random
+
+
+def test_reference_own_buffer_tests_on_the_oracle():
+    run_reference_buffer_tests(D.DataCollectionOracle, D.combine_data_collections)
+
+
 class _Rec(object):
     def __init__(self): self.calls = []
     def update(self, x): self.calls.append(np.array(x))
