@@ -70,7 +70,9 @@ class data_collection(object):
         return 0 if self.n_data is None else self.n_data
 
     def _gather(self, indices):
-        idx = torch.as_tensor(np.asarray(indices, dtype=np.int64), device=self.x.device)
+        idx = np.asarray(indices, dtype=np.int64)
+        idx = np.where(idx < 0, idx + self.x.shape[0], idx)          # NumPy semantics: the reference reaches cur_idx = -1 after a capped set_data
+        idx = torch.as_tensor(idx, device=self.x.device)
         return self.x.index_select(0, idx), self.y.index_select(0, idx)
 
     def get_next_batch(self, batch_size, is_shuffled=False):
