@@ -103,6 +103,26 @@ __global__ void __launch_bounds__(256, 2) k_policy_mfma(PolK k, const float* __r
 #pragma unroll
         for (int r = 0; r < 4; ++r) vb2f[r] = (4 * q + r < NA) ? v[pb2 + 4 * q + r] : 0.f;
     }
+    // Output layer on the VALU when it is only 1-2 units wide (na <= 2): a 16-wide MFMA would be 87 % padding there.  Each lane keeps
+    // the weights of its 8 hidden units (D layout) for every action dim; partial sums are combined over the 4 q-lanes of a sample.
+    constexpr bool L2V = (NA <= 2);
+    constexpr int NAV = L2V ? NA : 1;
+    float w2l[HB][4][NAV], v2l[HB][4][NAV], gw2l[HB][4][NAV], b2l[NAV], vb2l[NAV];
+    if (L2V) {
+#pragma unroll
+        for (int cb = 0; cb < HB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int d = 0; d < NAV; ++d) {
+                    const int u = 16 * cb + 4 * q + r;
+                    w2l[cb][r][d] = (u < PH) ? theta[pW2 + u * NA + d] : 0.f;
+                    v2l[cb][r][d] = (MODE == MODE_FVP && u < PH) ? v[pW2 + u * NA + d] : 0.f;
+                    gw2l[cb][r][d] = 0.f;
+                }
+#pragma unroll
+        for (int d = 0; d < NAV; ++d) { b2l[d] = theta[pb2 + d]; vb2l[d] = (MODE == MODE_FVP) ? v[pb2 + d] : 0.f; }
+    }
     __syncthreads();
 
     // ---------------- accumulators -------------------------------------------------------------------
@@ -190,13 +210,27 @@ __global__ void __launch_bounds__(256, 2) k_policy_mfma(PolK k, const float* __r
 #pragma unroll
             for (int r = 0; r < 4; ++r) um[r] = (ok && 4 * q + r < NA) ? k.gm[n * NA + 4 * q + r] : 0.f;
         } else if (MODE != MODE_FVP) {
-            f32x4 m0 = b2f, m1 = Z4;
+            f32x4 mu = Z4;
+            if (L2V) {
 #pragma unroll
-            for (int kk = 0; kk < KK; kk += 2) {
-                m0 = MFMA16(FRAG1(I::O_W2F, kk), h1[kk >> 2][kk & 3], m0);
-                m1 = MFMA16(FRAG1(I::O_W2F, kk + 1), h1[(kk + 1) >> 2][(kk + 1) & 3], m1);
+                for (int d = 0; d < NAV; ++d) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int cb = 0; cb < HB; ++cb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) a = fmaf(w2l[cb][r][d], h1[cb][r], a);
+                    a = xsum_q(a) + b2l[d];
+                    if (q == 0) mu[d] = a;                  // D layout: action dim d = 4q + r lives in lane q = 0, register d
+                }
+            } else {
+                f32x4 m0 = b2f, m1 = Z4;
+#pragma unroll
+                for (int kk = 0; kk < KK; kk += 2) {
+                    m0 = MFMA16(FRAG1(I::O_W2F, kk), h1[kk >> 2][kk & 3], m0);
+                    m1 = MFMA16(FRAG1(I::O_W2F, kk + 1), h1[(kk + 1) >> 2][(kk + 1) & 3], m1);
+                }
+                mu = m0 + m1;
             }
-            const f32x4 mu = m0 + m1;
             float llr = 0.f, kl = 0.f, zz[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -225,14 +259,30 @@ __global__ void __launch_bounds__(256, 2) k_policy_mfma(PolK k, const float* __r
         } else {
             // ---- S4: tangent of the mean: m1 = V2^T h1 (VALU inside: t1 *= 1 - h1^2), then m0 = vb2 + W2^T t1 ----------
             f32x4 m0 = vb2f, m1 = Z4;
+            if (!L2V) {
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) m1 = MFMA16(FRAG1(I::O_V2F, kk), h1[kk >> 2][kk & 3], m1);
+                for (int kk = 0; kk < KK; ++kk) m1 = MFMA16(FRAG1(I::O_V2F, kk), h1[kk >> 2][kk & 3], m1);
+            }
 #pragma unroll
             for (int cb = 0; cb < HB; ++cb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) t1[cb][r] *= fmaf(-h1[cb][r], h1[cb][r], 1.f);
+            if (L2V) {
+                m0 = Z4;
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) m0 = MFMA16(FRAG1(I::O_W2F, kk), t1[kk >> 2][kk & 3], m0);
+                for (int d = 0; d < NAV; ++d) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int cb = 0; cb < HB; ++cb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) a = fmaf(w2l[cb][r][d], t1[cb][r], fmaf(v2l[cb][r][d], h1[cb][r], a));
+                    a = xsum_q(a) + vb2l[d];
+                    if (q == 0) m0[d] = a;
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) m0 = MFMA16(FRAG1(I::O_W2F, kk), t1[kk >> 2][kk & 3], m0);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float s2 = expf(2.f * ls[r]);
@@ -241,17 +291,32 @@ __global__ void __launch_bounds__(256, 2) k_policy_mfma(PolK k, const float* __r
             }
             if (ok && q == 0) accw += k.inv_n;
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) T_UM[(4 * q + r) * TS + c] = um[r];
         // ---- S5/S6: back-prop (transposed chain); deltas go straight into their transpose tiles ---------------------
         f32x4 d1[HB], d0[HB];
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb) d1[cb] = Z4;
+        if (L2V) {
+            float ua[NAV];                                  // the sample's mean-adjoint, broadcast from its q = 0 lane to all 4 lanes
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (r >= NA) continue;                          // k-step r covers action dims r, 4+r, 8+r, 12+r: all padding when r >= na
+            for (int d = 0; d < NAV; ++d) ua[d] = __shfl(um[d], c, 64);
 #pragma unroll
-            for (int cb = 0; cb < HB; ++cb) d1[cb] = MFMA16(FRAG2(I::O_W2B, r, cb), um[r], d1[cb]);
+            for (int cb = 0; cb < HB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int d = 0; d < NAV; ++d) {
+                        d1[cb][r] = fmaf(w2l[cb][r][d], ua[d], d1[cb][r]);
+                        gw2l[cb][r][d] = fmaf(h1[cb][r], ua[d], gw2l[cb][r][d]);      // weight gradient of the output layer, per lane
+                    }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T_UM[(4 * q + r) * TS + c] = um[r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r >= NA) continue;                      // k-step r covers action dims r, 4+r, 8+r, 12+r: all padding when r >= na
+#pragma unroll
+                for (int cb = 0; cb < HB; ++cb) d1[cb] = MFMA16(FRAG2(I::O_W2B, r, cb), um[r], d1[cb]);
+            }
         }
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb) {
@@ -276,15 +341,17 @@ __global__ void __launch_bounds__(256, 2) k_policy_mfma(PolK k, const float* __r
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int col = c * TS + 4 * s + q;
-            const float bu = T_UM[col];
+            const float bu = L2V ? 0.f : T_UM[col];
             float a1_[HB], a0_[HB], b1_[HB], b0_[HB], xT[NSI];
 #pragma unroll
             for (int cb = 0; cb < HB; ++cb) { a1_[cb] = T_H1[cb * TILE + col]; a0_[cb] = T_H0[cb * TILE + col]; b1_[cb] = T_D1[cb * TILE + col]; b0_[cb] = T_D0[cb * TILE + col]; }
             const long long ns_ = n0 + 4 * s + q;
 #pragma unroll
             for (int ci = 0; ci < NSI; ++ci) { const int f = 16 * ci + c; xT[ci] = (ns_ < k.N && f < NS) ? k.obs[ns_ * NS + f] : 0.f; }
+            if (!L2V) {
 #pragma unroll
-            for (int ci = 0; ci < HB; ++ci) gW2[ci] = MFMA16(a1_[ci], bu, gW2[ci]);
+                for (int ci = 0; ci < HB; ++ci) gW2[ci] = MFMA16(a1_[ci], bu, gW2[ci]);
+            }
 #pragma unroll
             for (int ci = 0; ci < HB; ++ci)
 #pragma unroll
@@ -316,8 +383,19 @@ __global__ void __launch_bounds__(256, 2) k_policy_mfma(PolK k, const float* __r
 #pragma unroll
                 for (int ci = 0; ci < HB; ++ci) { const int i = 16 * ci + 4 * q + r; if (i < PH && j < PH) row[pW1 + i * PH + j] = gW1[ci][cj][r]; }
             }
+            if (L2V) {
 #pragma unroll
-            for (int ci = 0; ci < HB; ++ci) { const int i = 16 * ci + 4 * q + r; if (i < PH && c < NA) row[pW2 + i * NA + c] = gW2[ci][r]; }
+                for (int ci = 0; ci < HB; ++ci)
+#pragma unroll
+                    for (int d = 0; d < NAV; ++d) {
+                        const float sg = xsum_c(gw2l[ci][r][d]);               // sum over the 16 samples (lanes c) of the wave's tiles
+                        const int i = 16 * ci + 4 * q + r;
+                        if (c == 0 && i < PH) row[pW2 + i * NA + d] = sg;
+                    }
+            } else {
+#pragma unroll
+                for (int ci = 0; ci < HB; ++ci) { const int i = 16 * ci + 4 * q + r; if (i < PH && c < NA) row[pW2 + i * NA + c] = gW2[ci][r]; }
+            }
 #pragma unroll
             for (int cb = 0; cb < HB; ++cb) {
                 const float s0 = xsum_c(gb0[cb][r]), s1 = xsum_c(gb1[cb][r]);
