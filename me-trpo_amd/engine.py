@@ -191,7 +191,21 @@ class Engine(object):
         valid = torch.empty(T, B, dtype=torch.uint8, device=dev)
         stats = torch.zeros(3, dtype=torch.float64, device=dev)
         if coeffs is not None:
-            coeffs = torch.as_tensor(coeffs, device=dev).to(torch.float64).contiguous()
+            if isinstance(coeffs, torch.Tensor) and coeffs.is_cuda:
+                coeffs = coeffs.to(torch.float64).contiguous()
+            else:
+                # host coefficients: pinned staging + async copy, so that this call does not block the host behind the rollout that is
+                # still running on the stream (a pageable H2D copy would) and the GAE kernels are queued while it runs
+                F = 2 * self.ns + 4
+                if getattr(self, '_coef_pin', None) is None:
+                    self._coef_pin = [torch.empty(F, dtype=torch.float64).pin_memory() for _ in range(2)]
+                    self._coef_dev = [torch.empty(F, dtype=torch.float64, device=dev) for _ in range(2)]
+                    self._coef_i = 0
+                self._coef_i ^= 1
+                pin, cd = self._coef_pin[self._coef_i], self._coef_dev[self._coef_i]
+                pin.copy_(torch.as_tensor(np.asarray(coeffs, dtype=np.float64)))
+                cd.copy_(pin, non_blocking=True)
+                coeffs = cd
             assert coeffs.numel() == 2 * self.ns + 4
         self._chk(lib.metrpo_gae(self._ctx, _ptr(traj.obs), _ptr(traj.rew), _ptr(traj.done), _ptr(traj.tpath), T, B,
                                  _ptr(coeffs), float(gamma), float(lam), _ptr(adv), _ptr(ret), _ptr(valid), _ptr(stats),
