@@ -99,7 +99,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     c->device = device; c->dims = *d;
     c->d_dyn = c->d_norm = c->d_theta = nullptr; c->have_dyn = c->have_pol = false;
     c->d_dyn_img = c->d_pol_img = nullptr; c->pol_img_idx = -1;
-    c->d_bptt = nullptr; c->bptt_cap = 0; c->det_cfg = -1; c->d_detpart = nullptr; c->detpart_cap = 0; c->vjp_gm = nullptr; c->d_pol_adam = nullptr; c->pol_adam_t = 0; c->mfma_cfg = -1; c->pol_mfma = -1; c->coop_cfg = -1; c->rollout_variant = 0;
+    c->d_bptt = nullptr; c->bptt_cap = 0; c->det_cfg = -1; c->d_detpart = nullptr; c->detpart_cap = 0; c->det_gemm = 0; c->d_dg = nullptr; c->dg_cap = 0; c->vjp_gm = nullptr; c->d_pol_adam = nullptr; c->pol_adam_t = 0; c->mfma_cfg = -1; c->pol_mfma = -1; c->coop_cfg = -1; c->rollout_variant = 0;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_cg = nullptr; c->d_vf = nullptr; c->d_theta_try = nullptr;
     c->d_valbuf = nullptr; c->h_pinned = nullptr; c->n_sm = 256;
     c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0; c->d_ticket = nullptr; c->d_adam = nullptr; c->adam_t = 0; c->d_train = nullptr; c->train_cap = 0;
@@ -134,6 +134,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     c->pol_mfma = policy_mfma_select(pd);
     c->coop_cfg = coop_select_config(c);
     c->det_cfg = det_mfma_select(c);
+    c->det_gemm = det_gemm_applicable(c) ? 1 : 0;
     c->rollout_variant = 0;
     return METRPO_OK;
 }
@@ -141,7 +142,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
 extern "C" int32_t metrpo_destroy(metrpo_ctx* c) {
     if (!c) return METRPO_ENULL;
     void* bufs[] = {c->d_dyn, c->d_norm, c->d_theta, c->d_vf, c->d_theta_try, c->d_cg, c->d_valbuf, c->d_partials,
-                    c->d_dyn_img, c->d_pol_img, c->d_vbuf, c->d_gram_part, c->d_big, c->d_ticket, c->d_adam, c->d_train, c->d_bptt, c->d_pol_adam, c->d_detpart};
+                    c->d_dyn_img, c->d_pol_img, c->d_vbuf, c->d_gram_part, c->d_big, c->d_ticket, c->d_adam, c->d_train, c->d_bptt, c->d_pol_adam, c->d_detpart, c->d_dg};
     for (void* p : bufs) if (p) (void)hipFree(p);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     delete c;
@@ -521,9 +522,11 @@ extern "C" int32_t metrpo_policy_adam_step(metrpo_ctx* c, const double* grad, do
     return launch_policy_adam(c, grad, lr, beta1, beta2, eps, clip_val, false, (hipStream_t)stream);
 }
 
-// test hook (not in metrpo.h): 0 = generic sweep / validation kernels, 1 = MFMA path when the shape has one.  Returns the path in use.
+// test hook (not in metrpo.h): 0 = generic sweep / validation kernels, 1 = fastest path the shape has.  Returns the path in use:
+// 1 fused MFMA sweeps (bptt_mfma.hip), 2 GEMM-path sweeps (det_gemm.hip), 0 generic.
 extern "C" int32_t metrpo_set_det_path(metrpo_ctx* c, int32_t use_mfma) {
     if (!c) return METRPO_ENULL;
     c->det_cfg = use_mfma ? det_mfma_select(c) : -1;
-    return c->det_cfg >= 0 ? 1 : 0;
+    c->det_gemm = (use_mfma && det_gemm_applicable(c)) ? 1 : 0;
+    return c->det_cfg >= 0 ? 1 : (c->det_gemm ? 2 : 0);
 }

@@ -271,6 +271,16 @@ int launch_bptt_grad(metrpo_ctx* c, const float* init, int B, int T, double gamm
         if (costs) HIP_TRY(c, hipMemcpyAsync(costs, cst, sizeof(double) * K, hipMemcpyDeviceToDevice, st));
         return METRPO_OK;
     }
+    if (c->det_gemm) {                                       // GEMM-path sweeps for large dynamics nets (det_gemm.hip)
+        int rc1 = launch_dg_forward(c, init, B, T, gamma, XS, WT, cst, st);
+        if (rc1) return rc1;
+        if ((rc1 = launch_dg_backward(c, B, T, XS, WT, GM, st))) return rc1;
+        const int rc2 = launch_policy_vjp(c, XS, GM, (long long)K * (T + 1) * B, gout, st);
+        if (rc2) return rc2;
+        if (grad) HIP_TRY(c, hipMemcpyAsync(grad, gout + 1, sizeof(double) * pd.P, hipMemcpyDeviceToDevice, st));
+        if (costs) HIP_TRY(c, hipMemcpyAsync(costs, cst, sizeof(double) * K, hipMemcpyDeviceToDevice, st));
+        return METRPO_OK;
+    }
     const size_t fpt = bptt_floats(pd);
     const size_t LDS_MAX = 160 * 1024;
     int bs = 64;

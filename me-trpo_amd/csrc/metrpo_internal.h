@@ -47,6 +47,8 @@ struct metrpo_ctx {
     void* d_pol_adam; int pol_adam_t;   // Adam moments of the policy parameters + segment table
     int det_cfg;                        // bptt_mfma.hip table index (-1: generic sweeps / generic validation kernel)
     double* d_detpart; size_t detpart_cap;   // per-tile cost partials of the MFMA forward sweep
+    int det_gemm;                       // 1: GEMM-path sweeps (det_gemm.hip) for large dynamics nets
+    void* d_dg; size_t dg_cap;          // workspace of the GEMM-path sweeps
     int mfma_cfg;        // index into the instantiation table, -1 = generic path only
     int pol_mfma;        // index into policy_mfma.hip's table, -1 = generic update kernels
     int coop_cfg;        // index into rollout_coop.hip's table, -1 = head-per-wave kernel (rollout_mfma.hip)
@@ -118,6 +120,9 @@ int det_mfma_select(const metrpo_ctx*);
 int launch_det_forward(metrpo_ctx*, int idx, const float* s0, int B, int T, double gamma, float* XS, float* WT, double* part, double* costs, hipStream_t);
 int launch_det_backward(metrpo_ctx*, int idx, int B, int T, const float* XS, const float* WT, float* GM, hipStream_t);
 int ensure_detpart(metrpo_ctx*, int B);
+bool det_gemm_applicable(const metrpo_ctx*);
+int launch_dg_forward(metrpo_ctx*, const float* s0, int B, int T, double gamma, float* XS, float* WT, double* costs, hipStream_t);
+int launch_dg_backward(metrpo_ctx*, int B, int T, const float* XS, const float* WT, float* GM, hipStream_t);
 int launch_policy_vjp(metrpo_ctx*, const float* obs, const float* gm, long long N, double* out, hipStream_t);
 int launch_dyn_train_step(metrpo_ctx*, const float*, const float*, const metrpo_train_params*, double*, hipStream_t);
 int launch_dyn_eval_losses(metrpo_ctx*, const float*, const float*, long long, double, double*, hipStream_t);

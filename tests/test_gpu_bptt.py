@@ -81,6 +81,34 @@ def test_mfma_and_generic_sweeps_agree(env):
     assert rel_l2(gm, og) < 2e-4 and rel_l2(cpu(gg), og) < 2e-4 and rel_l2(gm, cpu(gg)) < 2e-4
 
 
+@pytest.mark.parametrize('env,K,dh,ph,B,T', [('swimmer', 3, (128, 128), (32, 32), 150, 9), ('half_cheetah', 2, (256, 128), (32, 32), 70, 7),
+                                             ('ant', 2, (128, 160, 128), (24, 16), 90, 8), ('hopper', 2, (128, 128), (32, 32), 64, 8),
+                                             ('humanoid', 2, (128, 128), (20, 10, 5), 40, 5)])
+def test_gemm_path_sweeps_match_oracle_and_generic(env, K, dh, ph, B, T):
+    """large dynamics nets (hidden >= 128): GEMM-path sweeps (det_gemm.hip) vs the generic sweep kernels vs the oracle."""
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, dh, ph, seed=96)
+    rng = np.random.RandomState(7)
+    theta = theta + 0.2 * rng.randn(theta.size); theta[-dm.na:] = 0.0
+    eng.set_policy(theta)
+    gamma = 0.97
+    x0 = (pool[:B] * (3.0 if env in ('hopper', 'half_cheetah') else 1.0)).astype(np.float32)
+    if env == 'ant':
+        x0[:20, 2] = 0.15
+    if env == 'hopper':
+        x0[:10, 1] = 0.5; x0[10:20, 0] = 0.2; x0[20:24, 4] = 150.0
+    assert eng.set_det_path(True) == 2
+    cm, gm = eng.bptt_grad(x0, T, gamma); vm = eng.validation_cost(x0, T, gamma)
+    cm, gm, vm = cpu(cm), cpu(gm), cpu(vm)
+    assert eng.set_det_path(False) == 0
+    cg, gg = eng.bptt_grad(x0, T, gamma); vg = eng.validation_cost(x0, T, gamma)
+    eng.set_det_path(True)
+    th32 = cpu(eng.get_policy()).astype(np.float64)
+    oc, og = Bp.policy_costs_and_grad(dm.astype(np.float32).astype(np.float64), th32, pdims, env, x0.astype(np.float64), T, gamma)
+    np.testing.assert_allclose(cm, oc, rtol=2e-4, atol=2e-5); np.testing.assert_allclose(vm, cm, rtol=1e-12)
+    np.testing.assert_allclose(cpu(cg), oc, rtol=2e-4, atol=2e-5); np.testing.assert_allclose(cpu(vg), cpu(cg), rtol=1e-6, atol=1e-7)
+    assert rel_l2(gm, og) < 3e-4 and rel_l2(cpu(gg), og) < 3e-4 and rel_l2(gm, cpu(gg)) < 3e-4
+
+
 def test_bptt_gradient_is_bitwise_reproducible_and_linear_in_weights():
     eng, dm, theta, pdims, pool = Hh.make_engine('swimmer', 5, (64, 64), (32, 32), seed=92)
     x0 = pool[:256].astype(np.float32)

@@ -48,5 +48,6 @@ if __name__ == '__main__':
     run('swimmer', 5, (64, 64), (32, 32), 500, 100, cpu=True)
     run('swimmer', 5, (64, 64), (32, 32), 5000, 100)
     run('swimmer', 5, (512, 512), (32, 32), 500, 100, cpu=True)
+    run('half_cheetah', 5, (1024, 1024), (32, 32), 500, 100)
     run('half_cheetah', 5, (64, 64), (32, 32), 2000, 200)
     run('ant', 5, (64, 64), (32, 32), 2000, 100)
