@@ -210,13 +210,6 @@ __global__ void k_dg_back(ProblemDesc pd, int B, int T, int t, const float* __re
 // ------------------------------------------------------------------------------------------------
 bool gemm_path_applicable(const metrpo_ctx* c);
 
-template <int EPI, bool TA, bool TB>
-static void dg_gemm(const float* A, long long sA, int lda, const float* W, long long sW, int ldw, float* C, long long sC, int ldc, int M, int N,
-                    int Kd, int heads, const GemmEpi& ep, hipStream_t st) {
-    const bool bigN = N > 64;
-    if (bigN) gemm_mfma_launch<2, 2, EPI, TA, TB>(A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, heads, ep, st);
-    else gemm_mfma_launch<2, 1, EPI, TA, TB>(A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, heads, ep, st);
-}
 
 bool det_gemm_applicable(const metrpo_ctx* c) {
     const ProblemDesc& pd = c->pd;
@@ -259,8 +252,8 @@ static void dg_forward_layers(metrpo_ctx* c, const DgState& s, int B, int n_laye
         GemmEpi ep = {};
         ep.bias = c->d_dyn + pd.dyn.b_off[l]; ep.strideBias = pd.dyn.n_params;
         const float* Wl = c->d_dyn + pd.dyn.w_off[l];
-        if (l == L - 1) dg_gemm<EPI_BIAS_ID, false, false>(in, (long long)B * Kd, ldin, Wl, pd.dyn.n_params, N, out, (long long)B * N, N, B, N, Kd, K, ep, st);
-        else dg_gemm<EPI_BIAS_RELU, false, false>(in, (long long)B * Kd, ldin, Wl, pd.dyn.n_params, N, out, (long long)B * N, N, B, N, Kd, K, ep, st);
+        if (l == L - 1) gemm_auto<EPI_BIAS_ID, false, false>(in, (long long)B * Kd, ldin, Wl, pd.dyn.n_params, N, out, (long long)B * N, N, B, N, Kd, K, ep, st);
+        else gemm_auto<EPI_BIAS_RELU, false, false>(in, (long long)B * Kd, ldin, Wl, pd.dyn.n_params, N, out, (long long)B * N, N, B, N, Kd, K, ep, st);
         in = out; ldin = N;
     }
 }
@@ -322,10 +315,10 @@ int launch_dg_backward(metrpo_ctx* c, int B, int T, const float* XS, const float
             GemmEpi ep = {};
             if (l > 0) {
                 ep.mask = s.H[l - 1]; ep.strideMask = (long long)B * n_in; ep.ldm = n_in;
-                dg_gemm<EPI_RELU_MASK, false, true>(dz, (long long)B * n_out, n_out, Wl, pd.dyn.n_params, n_out, dzn, (long long)B * n_in, n_in, B, n_in,
+                gemm_auto<EPI_RELU_MASK, false, true>(dz, (long long)B * n_out, n_out, Wl, pd.dyn.n_params, n_out, dzn, (long long)B * n_in, n_in, B, n_in,
                                                     n_out, K, ep, st);
             } else {
-                dg_gemm<EPI_PLAIN, false, true>(dz, (long long)B * n_out, n_out, Wl, pd.dyn.n_params, n_out, dzn, (long long)B * n_in, n_in, B, n_in, n_out,
+                gemm_auto<EPI_PLAIN, false, true>(dz, (long long)B * n_out, n_out, Wl, pd.dyn.n_params, n_out, dzn, (long long)B * n_in, n_in, B, n_in, n_out,
                                                 K, ep, st);
             }
             float* tmp = dz; dz = dzn; dzn = tmp;

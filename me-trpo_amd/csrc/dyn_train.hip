@@ -82,15 +82,6 @@ __global__ void k_rms_accumulate(const float* __restrict__ x, long long n, int d
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int EPI, bool TA, bool TB>
-static void gemm_any(const float* A, long long sA, int lda, const float* W, long long sW, int ldw, float* C, long long sC, int ldc,
-                     int M, int N, int Kd, int heads, const GemmEpi& ep, hipStream_t st) {
-    const bool bigM = M > 64, bigN = N > 64;
-    if (bigM && bigN) gemm_mfma_launch<2, 2, EPI, TA, TB>(A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, heads, ep, st);
-    else if (bigM) gemm_mfma_launch<2, 1, EPI, TA, TB>(A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, heads, ep, st);
-    else if (bigN) gemm_mfma_launch<1, 2, EPI, TA, TB>(A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, heads, ep, st);
-    else gemm_mfma_launch<1, 1, EPI, TA, TB>(A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, heads, ep, st);
-}
 
 // Split-K decision for the weight-gradient GEMM of one layer (M = n_in, N = n_out, contraction over the batch rows).
 struct SplitK { int splits, kchunk; long long stride; };
@@ -172,9 +163,9 @@ static void train_forward(metrpo_ctx* c, const TrainWs& ws, int rows, hipStream_
         GemmEpi ep = {};
         ep.bias = c->d_dyn + pd.dyn.b_off[l]; ep.strideBias = pd.dyn.n_params;
         const float* Wl = c->d_dyn + pd.dyn.w_off[l];
-        if (l == L - 1) gemm_any<EPI_BIAS_ID, false, false>(ws.H[l], (long long)rows * Kd, Kd, Wl, pd.dyn.n_params, N, out, (long long)rows * N, N, rows, N, Kd, K, ep, st);
-        else if (pd.dyn.act[l] == METRPO_ACT_RELU) gemm_any<EPI_BIAS_RELU, false, false>(ws.H[l], (long long)rows * Kd, Kd, Wl, pd.dyn.n_params, N, out, (long long)rows * N, N, rows, N, Kd, K, ep, st);
-        else gemm_any<EPI_BIAS_TANH, false, false>(ws.H[l], (long long)rows * Kd, Kd, Wl, pd.dyn.n_params, N, out, (long long)rows * N, N, rows, N, Kd, K, ep, st);
+        if (l == L - 1) gemm_auto<EPI_BIAS_ID, false, false>(ws.H[l], (long long)rows * Kd, Kd, Wl, pd.dyn.n_params, N, out, (long long)rows * N, N, rows, N, Kd, K, ep, st);
+        else if (pd.dyn.act[l] == METRPO_ACT_RELU) gemm_auto<EPI_BIAS_RELU, false, false>(ws.H[l], (long long)rows * Kd, Kd, Wl, pd.dyn.n_params, N, out, (long long)rows * N, N, rows, N, Kd, K, ep, st);
+        else gemm_auto<EPI_BIAS_TANH, false, false>(ws.H[l], (long long)rows * Kd, Kd, Wl, pd.dyn.n_params, N, out, (long long)rows * N, N, rows, N, Kd, K, ep, st);
     }
 }
 
@@ -207,7 +198,7 @@ int launch_dyn_train_step(metrpo_ctx* c, const float* x, const float* y, const m
         if (l > 0) {            // dH_{l-1} = dZ_l . W_l^T, masked by relu'(H_{l-1})  -- uses W_l BEFORE its update
             GemmEpi ep = {};
             ep.mask = ws.H[l]; ep.strideMask = (long long)rows * n_in; ep.ldm = n_in;
-            gemm_any<EPI_RELU_MASK, false, true>(dz, (long long)rows * n_out, n_out, Wl, pd.dyn.n_params, n_out, dz_next, (long long)rows * n_in, n_in,
+            gemm_auto<EPI_RELU_MASK, false, true>(dz, (long long)rows * n_out, n_out, Wl, pd.dyn.n_params, n_out, dz_next, (long long)rows * n_in, n_in,
                                                  rows, n_in, n_out, K, ep, st);
         }
         {                       // dW_l = H_{l-1}^T . dZ_l with the Adam update as epilogue (W_l updated in place)
@@ -218,13 +209,13 @@ int launch_dyn_train_step(metrpo_ctx* c, const float* x, const float* y, const m
             const SplitK sk = choose_split(n_in, n_out, rows, K);
             if (sk.splits > 1) {
                 ep.part = ws.part; ep.stridePart = sk.stride; ep.splits = sk.splits; ep.kchunk = sk.kchunk;
-                gemm_any<EPI_PARTIAL, true, false>(ws.H[l], (long long)rows * n_in, n_in, dz, (long long)rows * n_out, n_out, nullptr, 0, n_out,
+                gemm_auto<EPI_PARTIAL, true, false>(ws.H[l], (long long)rows * n_in, n_in, dz, (long long)rows * n_out, n_out, nullptr, 0, n_out,
                                                    n_in, n_out, rows, K, ep, st);
                 const int tot = n_in * n_out + n_out;
                 hipLaunchKernelGGL(k_adam_apply, dim3((tot + 255) / 256, K), dim3(256), 0, st, sk.splits, K, sk.stride, ws.part, n_in * n_out, n_out,
                                    Wl, ep.am, ep.av, ep.bvec, ep.bam, ep.bav, (long long)pd.dyn.n_params, ep.lr_t, ep.beta1, ep.beta2, ep.eps, decay);
             } else {
-                gemm_any<EPI_ADAM, true, false>(ws.H[l], (long long)rows * n_in, n_in, dz, (long long)rows * n_out, n_out, Wl, pd.dyn.n_params, n_out,
+                gemm_auto<EPI_ADAM, true, false>(ws.H[l], (long long)rows * n_in, n_in, dz, (long long)rows * n_out, n_out, Wl, pd.dyn.n_params, n_out,
                                                 n_in, n_out, rows, K, ep, st);
             }
         }

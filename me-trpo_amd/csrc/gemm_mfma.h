@@ -207,3 +207,20 @@ static inline void gemm_mfma_launch(const float* A, long long sA, int lda, const
     dim3 grid((N + 64 * TN - 1) / (64 * TN), (M + 64 * TM - 1) / (64 * TM), heads * (EPI == EPI_PARTIAL ? ep.splits : 1));
     hipLaunchKernelGGL((k_gemm_mfma<TM, TN, EPI, TA, TB>), grid, dim3(256), 0, st, A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, ep);
 }
+
+// Tile choice shared by every caller: 128x128 block tiles when that already yields enough workgroups to fill the 256 CUs a few
+// times over, otherwise halve the tile in M and then in N (more, smaller workgroups beat idle CUs on the small-batch shapes:
+// M = 500 rows x N = 512 x 5 heads is 80 tiles of 128x128 but 320 of 64x64).
+template <int EPI, bool TA, bool TB>
+static inline void gemm_auto(const float* A, long long sA, int lda, const float* W, long long sW, int ldw, float* C, long long sC, int ldc, int M,
+                             int N, int Kd, int heads, const GemmEpi& ep, hipStream_t st) {
+    auto blocks = [&](int tm, int tn) { return (long long)((M + 64 * tm - 1) / (64 * tm)) * ((N + 64 * tn - 1) / (64 * tn)) * heads; };
+    int tm = (M > 64) ? 2 : 1, tn = (N > 64) ? 2 : 1;
+    const long long want = 384;
+    if (tm == 2 && blocks(tm, tn) < want) tm = 1;
+    if (tn == 2 && blocks(tm, tn) < want) tn = 1;
+    if (tm == 2 && tn == 2) gemm_mfma_launch<2, 2, EPI, TA, TB>(A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, heads, ep, st);
+    else if (tm == 2) gemm_mfma_launch<2, 1, EPI, TA, TB>(A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, heads, ep, st);
+    else if (tn == 2) gemm_mfma_launch<1, 2, EPI, TA, TB>(A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, heads, ep, st);
+    else gemm_mfma_launch<1, 1, EPI, TA, TB>(A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, heads, ep, st);
+}

@@ -148,14 +148,13 @@ __global__ void k_big_post(ProblemDesc pd, RolloutK r, int t, const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int TM, int TN>
 static void gemm_launch(int act, const float* A, long long sA, int lda, const float* W, long long sW, int ldw, const float* bias,
                         long long sB, float* C, long long sC, int ldc, int M, int N, int Kd, int heads, hipStream_t st) {
     GemmEpi ep = {};
     ep.bias = bias; ep.strideBias = sB;
-    if (act == METRPO_ACT_RELU) gemm_mfma_launch<TM, TN, EPI_BIAS_RELU, false, false>(A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, heads, ep, st);
-    else if (act == METRPO_ACT_TANH) gemm_mfma_launch<TM, TN, EPI_BIAS_TANH, false, false>(A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, heads, ep, st);
-    else gemm_mfma_launch<TM, TN, EPI_BIAS_ID, false, false>(A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, heads, ep, st);
+    if (act == METRPO_ACT_RELU) gemm_auto<EPI_BIAS_RELU, false, false>(A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, heads, ep, st);
+    else if (act == METRPO_ACT_TANH) gemm_auto<EPI_BIAS_TANH, false, false>(A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, heads, ep, st);
+    else gemm_auto<EPI_BIAS_ID, false, false>(A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, heads, ep, st);
 }
 
 bool gemm_path_applicable(const metrpo_ctx* c) {
@@ -206,8 +205,7 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
             const long long sOut = (long long)B * N;
             const float* Wl = c->d_dyn + pd.dyn.w_off[l];
             const float* bl = c->d_dyn + pd.dyn.b_off[l];
-            if (N > 64) gemm_launch<2, 2>(pd.dyn.act[l], in, sIn, ldin, Wl, pd.dyn.n_params, N, bl, pd.dyn.n_params, out, sOut, N, B, N, Kd, K, st);
-            else gemm_launch<2, 1>(pd.dyn.act[l], in, sIn, ldin, Wl, pd.dyn.n_params, N, bl, pd.dyn.n_params, out, sOut, N, B, N, Kd, K, st);
+            gemm_launch(pd.dyn.act[l], in, sIn, ldin, Wl, pd.dyn.n_params, N, bl, pd.dyn.n_params, out, sOut, N, B, N, Kd, K, st);
             in = out; sIn = sOut; ldin = N;
         }
         hipLaunchKernelGGL(k_big_post, dim3((B + 127) / 128), dim3(128), 0, st, pd, r, t, c->d_norm, bs);
