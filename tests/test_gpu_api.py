@@ -202,3 +202,17 @@ def test_bench_two_ranks_on_one_gpu():
     assert rec['n_gpus'] == 2 and rec['steps'] == 3 and rec['scaling'] == 'weak' and rec['value'] > 0
     assert 'cpu_baseline' not in rec                       # rank 0 at N=1 only
     assert abs(rec['value'] - 2 * 5 * 5000 * 100 / (rec['ms_per_step'] * 1e-3)) / rec['value'] < 1e-9
+
+
+def test_end_to_end_outer_loop_example():
+    """examples/me_trpo_loop.py: collect (surrogate real env) -> split / normalise -> train the ensemble -> TRPO with validation-cost
+    early stopping, two outer iterations at tiny sizes: the rows interoperate on one context without host copies of the weights."""
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('me_trpo_loop', os.path.join(root, 'examples', 'me_trpo_loop.py'))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    hist = mod.main(['--outer', '2', '--K', '3', '--T', '20', '--traj', '40', '--n-envs', '200', '--policy-iters', '6', '--model-passes', '6',
+                     '--quiet'])
+    assert len(hist) == 2 and hist[1]['n_data'] > hist[0]['n_data'] > 0
+    assert all(np.isfinite([h['real_cost'], h['model_val'], h['est_cost']]).all() for h in hist)
+    assert hist[1]['model_val'] < 10 * hist[0]['model_val'] + 1.0          # training did not blow up on the grown buffer
