@@ -216,7 +216,7 @@ static inline void gemm_auto(const float* A, long long sA, int lda, const float*
                              int N, int Kd, int heads, const GemmEpi& ep, hipStream_t st) {
     auto blocks = [&](int tm, int tn) { return (long long)((M + 64 * tm - 1) / (64 * tm)) * ((N + 64 * tn - 1) / (64 * tn)) * heads; };
     int tm = (M > 64) ? 2 : 1, tn = (N > 64) ? 2 : 1;
-    const long long want = 384;
+    const long long want = 2048;            // ~8 workgroups per CU (measured: 64x64 tiles beat 128x128 by 15 % at 800 tiles, 128x128 wins from ~8k tiles)
     if (tm == 2 && blocks(tm, tn) < want) tm = 1;
     if (tn == 2 && blocks(tm, tn) < want) tn = 1;
     if (tm == 2 && tn == 2) gemm_mfma_launch<2, 2, EPI, TA, TB>(A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, heads, ep, st);

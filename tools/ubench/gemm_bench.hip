@@ -24,14 +24,17 @@ static void bench(const char* name, int M, int N, int Kd, int heads) {
 }
 
 int main() {
-    bench<2, 2, EPI_BIAS_RELU, false, false>("fwd 128x128 relu", 2500, 1024, 1024, 5);
-    bench<2, 2, EPI_BIAS_RELU, false, false>("fwd 128x128 relu", 2560, 1024, 1024, 5);
-    bench<2, 2, EPI_BIAS_RELU, false, false>("fwd 128x128 relu", 6250, 1024, 1024, 20);
-    bench<2, 2, EPI_BIAS_RELU, false, false>("fwd 128x128 relu", 1000, 1024, 1024, 5);
-    bench<2, 2, EPI_BIAS_RELU, false, false>("fwd 128x128 relu", 1000, 1024, 1024, 20);
-    bench<2, 2, EPI_BIAS_RELU, false, false>("fwd 128x128 relu", 2500, 512, 512, 10);
-    bench<2, 2, EPI_RELU_MASK, false, true>("dH  128x128 mask (TB)", 1000, 1024, 1024, 20);
-    bench<2, 2, EPI_PLAIN, true, false>("dW  128x128 plain (TA)", 1024, 1024, 1000, 20);
-    bench<2, 2, EPI_BIAS_RELU, false, false>("fwd 128x128 relu", 8192, 4096, 4096, 1);
+    for (int heads : {5, 10}) {
+        const int M = 2500, N = heads == 5 ? 1024 : 512, K = N;
+        bench<2, 2, EPI_BIAS_RELU, false, false>("128x128", M, N, K, heads);
+        bench<1, 2, EPI_BIAS_RELU, false, false>(" 64x128", M, N, K, heads);
+        bench<2, 1, EPI_BIAS_RELU, false, false>("128x 64", M, N, K, heads);
+        bench<1, 1, EPI_BIAS_RELU, false, false>(" 64x 64", M, N, K, heads);
+    }
+    bench<2, 2, EPI_BIAS_RELU, false, false>("128x128", 1000, 1024, 1024, 5);
+    bench<1, 2, EPI_BIAS_RELU, false, false>(" 64x128", 1000, 1024, 1024, 5);
+    bench<1, 1, EPI_BIAS_RELU, false, false>(" 64x 64", 1000, 1024, 1024, 5);
+    bench<2, 2, EPI_BIAS_RELU, false, false>("128x128", 6250, 1024, 1024, 20);
+    bench<2, 2, EPI_BIAS_RELU, false, false>("128x128", 8192, 4096, 4096, 1);
     return 0;
 }
