@@ -23,7 +23,7 @@ struct GemmEpi {                 // epilogue operands (unused fields may be null
     float* part; long long stridePart; int splits, kchunk;
 };
 
-template <int TM, int TN, int EPI, bool TA, bool TB>
+template <int TM, int TN, int EPI, bool TA, bool TB, bool AL>
 __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, long long strideA, int lda,
                                                    const float* __restrict__ W, long long strideW, int ldw,
                                                    float* __restrict__ C, long long strideC, int ldc, int M, int N, int Kd, GemmEpi ep) {
@@ -59,8 +59,11 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
     constexpr int NA = TA ? DA_P : SA_P, NB = TB ? SB_P : DB_P;
     float4 ra[NA], rb[NB];
 
+    // AL (host-checked: every base pointer, leading dimension and head stride is a multiple of 4 floats and so are the extents along the
+    // contiguous axes): a quad is either fully inside or fully outside -> one predicated 16-byte load, no alignment test, no scalar tail.
     auto ld4 = [](const float* src, int have) -> float4 {               // up to 4 valid floats starting at src
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (AL) { if (have > 0) v = *(const float4*)src; return v; }
         if (have >= 4 && (((uintptr_t)src) & 15) == 0) return *(const float4*)src;
         if (have > 0) v.x = src[0];
         if (have > 1) v.y = src[1];
@@ -205,7 +208,12 @@ template <int TM, int TN, int EPI, bool TA, bool TB>
 static inline void gemm_mfma_launch(const float* A, long long sA, int lda, const float* W, long long sW, int ldw, float* C, long long sC,
                                     int ldc, int M, int N, int Kd, int heads, const GemmEpi& ep, hipStream_t st) {
     dim3 grid((N + 64 * TN - 1) / (64 * TN), (M + 64 * TM - 1) / (64 * TM), heads * (EPI == EPI_PARTIAL ? ep.splits : 1));
-    hipLaunchKernelGGL((k_gemm_mfma<TM, TN, EPI, TA, TB>), grid, dim3(256), 0, st, A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, ep);
+    auto m4 = [](long long v) { return (v & 3) == 0; };
+    // contiguous axes: A rows run along Kd (or along M when TA), W rows along N (or along Kd when TB)
+    const bool al = m4((long long)(uintptr_t)A >> 2) && (((uintptr_t)A & 15) == 0) && (((uintptr_t)W & 15) == 0) && m4(sA) && m4(sW) && m4(lda) && m4(ldw) &&
+                    m4(TA ? M : Kd) && m4(TB ? Kd : N) && (EPI != EPI_PARTIAL || m4(ep.kchunk));
+    if (al) hipLaunchKernelGGL((k_gemm_mfma<TM, TN, EPI, TA, TB, true>), grid, dim3(256), 0, st, A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, ep);
+    else hipLaunchKernelGGL((k_gemm_mfma<TM, TN, EPI, TA, TB, false>), grid, dim3(256), 0, st, A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, ep);
 }
 
 // Tile choice shared by every caller: 128x128 block tiles when that already yields enough workgroups to fill the 256 CUs a few
