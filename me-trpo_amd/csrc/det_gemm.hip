@@ -10,7 +10,7 @@
 #include "gemm_mfma.h"
 
 struct DgState {
-    float *S, *X, *U, *MU, *OUT, *G, *DZa, *DZb, *LAM, *DONES;
+    float *S, *X, *U, *MU, *OUT, *G, *DZa, *DZb, *LAM, *DONES, *PART;
     float* H[MAXL];
     double* ACC;
 };
@@ -227,7 +227,8 @@ static int dg_workspace(metrpo_ctx* c, int B, DgState* s) {
     size_t nH = 0;
     for (int l = 1; l < L; ++l) { maxw = std::max(maxw, pd.dyn.dims[l]); nH += up4(R * pd.dyn.dims[l]); }
     const size_t nS = up4(R * pd.ns), nX = up4(R * pd.nin), nU = up4(R * pd.na), nZ = up4(R * maxw), nD = up4(R);
-    const size_t need = (4 * nS + nX + 2 * nU + nH + 2 * nZ + nD) * sizeof(float) + R * sizeof(double) + 64;
+    const size_t nP = up4(skinny_part_floats(B, pd.ns, pd.dyn.dims[L - 1], K));
+    const size_t need = (4 * nS + nX + 2 * nU + nH + 2 * nZ + nD + nP) * sizeof(float) + R * sizeof(double) + 64;
     if (need > c->dg_cap) {
         if (c->d_dg) HIP_TRY(c, hipFree(c->d_dg));
         c->d_dg = nullptr; c->dg_cap = 0;
@@ -237,7 +238,7 @@ static int dg_workspace(metrpo_ctx* c, int B, DgState* s) {
     float* p = (float*)c->d_dg;
     s->S = p; p += nS; s->OUT = p; p += nS; s->G = p; p += nS; s->LAM = p; p += nS; s->X = p; p += nX; s->U = p; p += nU; s->MU = p; p += nU;
     for (int l = 1; l < L; ++l) { s->H[l - 1] = p; p += up4(R * pd.dyn.dims[l]); }
-    s->DZa = p; p += nZ; s->DZb = p; p += nZ; s->DONES = p; p += nD;
+    s->DZa = p; p += nZ; s->DZb = p; p += nZ; s->DONES = p; p += nD; s->PART = nP ? p : nullptr; p += nP;
     s->ACC = (double*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
     return METRPO_OK;
 }
@@ -252,7 +253,7 @@ static void dg_forward_layers(metrpo_ctx* c, const DgState& s, int B, int n_laye
         GemmEpi ep = {};
         ep.bias = c->d_dyn + pd.dyn.b_off[l]; ep.strideBias = pd.dyn.n_params;
         const float* Wl = c->d_dyn + pd.dyn.w_off[l];
-        if (l == L - 1) gemm_auto<EPI_BIAS_ID, false, false>(in, (long long)B * Kd, ldin, Wl, pd.dyn.n_params, N, out, (long long)B * N, N, B, N, Kd, K, ep, st);
+        if (l == L - 1) gemm_skinny_bias(in, (long long)B * Kd, ldin, Wl, pd.dyn.n_params, N, ep.bias, ep.strideBias, out, (long long)B * N, B, N, Kd, K, s.PART, st);
         else gemm_auto<EPI_BIAS_RELU, false, false>(in, (long long)B * Kd, ldin, Wl, pd.dyn.n_params, N, out, (long long)B * N, N, B, N, Kd, K, ep, st);
         in = out; ldin = N;
     }

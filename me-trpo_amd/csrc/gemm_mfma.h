@@ -4,6 +4,7 @@
 //   opA = A (row-major [M][Kd], lda) or A^T (A stored [Kd][M]);  opB = W (row-major [Kd][N], ldw) or W^T (stored [N][Kd])
 // block = 256 threads = 2x2 waves; wave tile (32*TM) x (32*TN); block tile (64*TM) x (64*TN); BK = 16; LDS double buffer
 #pragma once
+#include <algorithm>
 #include "device_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -231,4 +232,46 @@ static inline void gemm_auto(const float* A, long long sA, int lda, const float*
     else if (tm == 2) gemm_mfma_launch<2, 1, EPI, TA, TB>(A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, heads, ep, st);
     else if (tn == 2) gemm_mfma_launch<1, 2, EPI, TA, TB>(A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, heads, ep, st);
     else gemm_mfma_launch<1, 1, EPI, TA, TB>(A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, heads, ep, st);
+}
+
+// ---- skinny output layers (N <= 64 columns, long contraction): C[h] = bias[h] + A[h] . W[h] as split-K partials + an ordered reduce ----
+// A 64-column tile per (64 rows, head) leaves most CUs idle and every workgroup walks the whole K axis; splitting K multiplies the
+// workgroups and shortens each walk (the layer is bound by reading A).  Partials are summed in split order: deterministic.
+static __global__ void k_splitk_bias_reduce(int splits, int heads, long long stridePart, const float* __restrict__ part, int M, int N,
+                                     const float* __restrict__ bias, long long strideBias, float* __restrict__ C, long long strideC) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int head = blockIdx.y;
+    if (i >= (long long)M * N) return;
+    float v = bias ? bias[(size_t)head * strideBias + (int)(i % N)] : 0.0f;
+    for (int s = 0; s < splits; ++s) v += part[((size_t)s * heads + head) * stridePart + i];
+    C[(size_t)head * strideC + i] = v;
+}
+
+static inline int skinny_splits(int M, int N, int Kd, int heads) {
+    if (N > 64 || Kd < 256) return 1;
+    const long long blocks = (long long)((M + 63) / 64) * heads;
+    int want = (int)std::min<long long>(8, std::max<long long>(1, 1024 / std::max<long long>(blocks, 1)));
+    want = std::min(want, Kd / 128);
+    return std::max(want, 1);
+}
+static inline size_t skinny_part_floats(int M, int N, int Kd, int heads) {
+    const int s = skinny_splits(M, N, Kd, heads);
+    return s > 1 ? (size_t)s * heads * ((((size_t)M * N + N) + 3) & ~(size_t)3) : 0;
+}
+// part: workspace of >= skinny_part_floats(...) floats (may be NULL when that is 0).  Identity activation only (output layers).
+static inline void gemm_skinny_bias(const float* A, long long sA, int lda, const float* W, long long sW, int ldw, const float* bias, long long sBias,
+                                    float* C, long long sC, int M, int N, int Kd, int heads, float* part, hipStream_t st) {
+    const int S = skinny_splits(M, N, Kd, heads);
+    if (S <= 1 || part == nullptr) {
+        GemmEpi ep = {}; ep.bias = bias; ep.strideBias = sBias;
+        gemm_auto<EPI_BIAS_ID, false, false>(A, sA, lda, W, sW, ldw, C, sC, N, M, N, Kd, heads, ep, st);
+        return;
+    }
+    GemmEpi ep = {};
+    ep.part = part; ep.stridePart = (((long long)M * N + N) + 3) & ~3LL; ep.splits = S; ep.kchunk = (((Kd + S - 1) / S) + 15) & ~15;
+    ep.splits = (Kd + ep.kchunk - 1) / ep.kchunk;
+    gemm_mfma_launch<1, 1, EPI_PARTIAL, false, false>(A, sA, lda, W, sW, ldw, nullptr, 0, N, M, N, Kd, heads, ep, st);
+    const long long tot = (long long)M * N;
+    hipLaunchKernelGGL(k_splitk_bias_reduce, dim3((unsigned)((tot + 255) / 256), heads), dim3(256), 0, st, ep.splits, heads, ep.stridePart, part, M, N,
+                       bias, sBias, C, sC);
 }

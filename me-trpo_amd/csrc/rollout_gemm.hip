@@ -11,7 +11,7 @@
 #include "gemm_mfma.h"
 
 // ------------------------------------------------------------------------------------------------
-struct BigState { float* S; int* ts; int* cur_model; float* X; float* U; float* HA; float* HB; float* OUT; };
+struct BigState { float* S; int* ts; int* cur_model; float* X; float* U; float* HA; float* HB; float* OUT; float* PART; };
 
 // policy.get_actions + clip + normalise/drop; one thread per env; policy activations in LDS columns
 __global__ void k_big_pre(ProblemDesc pd, RolloutK r, int t, const float* __restrict__ theta, const float* __restrict__ norm,
@@ -173,7 +173,8 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
     // workspace (floats): S, X, U, HA, HB, OUT + ints ts, cur_model
     auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };       // keep every sub-buffer 16-byte aligned
     const size_t nS = up4((size_t)B * pd.ns), nX = up4((size_t)B * pd.nin), nU = up4((size_t)B * pd.na), nH = up4((size_t)K * B * maxh), nO = up4((size_t)K * B * pd.ns);
-    const size_t need = (nS + nX + nU + 2 * nH + nO) * sizeof(float) + 2 * (size_t)B * sizeof(int) + 256;
+    const size_t nP = up4(skinny_part_floats(B, pd.ns, pd.dyn.dims[L - 1], K));
+    const size_t need = (nS + nX + nU + 2 * nH + nO + nP) * sizeof(float) + 2 * (size_t)B * sizeof(int) + 256;
     if (need > c->big_cap) {
         if (c->d_big) HIP_TRY(c, hipFree(c->d_big));
         c->d_big = nullptr; c->big_cap = 0;
@@ -182,7 +183,7 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
     }
     BigState bs;
     float* p = (float*)c->d_big;
-    bs.S = p; p += nS; bs.X = p; p += nX; bs.U = p; p += nU; bs.HA = p; p += nH; bs.HB = p; p += nH; bs.OUT = p; p += nO;
+    bs.S = p; p += nS; bs.X = p; p += nX; bs.U = p; p += nU; bs.HA = p; p += nH; bs.HB = p; p += nH; bs.OUT = p; p += nO; bs.PART = nP ? p : nullptr; p += nP;
     bs.ts = (int*)p; bs.cur_model = bs.ts + B;
     RolloutK r;
     r.B = a->B; r.T = a->T; r.H = a->H; r.sam_mode = a->sam_mode; r.determ = a->determ; r.eval_all = a->eval_all_heads;
@@ -205,7 +206,9 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
             const long long sOut = (long long)B * N;
             const float* Wl = c->d_dyn + pd.dyn.w_off[l];
             const float* bl = c->d_dyn + pd.dyn.b_off[l];
-            gemm_launch(pd.dyn.act[l], in, sIn, ldin, Wl, pd.dyn.n_params, N, bl, pd.dyn.n_params, out, sOut, N, B, N, Kd, K, st);
+            if (lastl && pd.dyn.act[l] == METRPO_ACT_IDENTITY)
+                gemm_skinny_bias(in, sIn, ldin, Wl, pd.dyn.n_params, N, bl, pd.dyn.n_params, out, sOut, B, N, Kd, K, bs.PART, st);
+            else gemm_launch(pd.dyn.act[l], in, sIn, ldin, Wl, pd.dyn.n_params, N, bl, pd.dyn.n_params, out, sOut, N, B, N, Kd, K, st);
             in = out; sIn = sOut; ldin = N;
         }
         hipLaunchKernelGGL(k_big_post, dim3((B + 127) / 128), dim3(128), 0, st, pd, r, t, c->d_norm, bs);
