@@ -9,6 +9,7 @@
 // The weights are streamed from L2/HBM every step (K x 1-9 MB): the tile shape gives >= 128-fold reuse per fetched
 // weight, which keeps the kernel MFMA-bound (AI ~ 60 flop/B at B = 2500).
 #include "gemm_mfma.h"
+#include "mfma_common.h"
 
 // ------------------------------------------------------------------------------------------------
 struct BigState { float* S; int* ts; int* cur_model; float* X; float* U; float* HA; float* HB; float* OUT; float* PART; };
@@ -58,6 +59,119 @@ __global__ void k_big_pre(ProblemDesc pd, RolloutK r, int t, const float* __rest
             st.X[(size_t)b * pd.nin + (ns - pd.n_drop) + d] = (ac - in_mean[ns + d]) / in_std[ns + d];
         }
     }
+}
+
+// MFMA variant of k_big_pre for the 2x32 tanh policies (every shipped params file except Humanoid): a wave evaluates the policy of a 16-env
+// tile as the transposed MFMA chain of the fused rollout kernels (30 MFMAs) instead of 64 threads walking three dense layers each;
+// identical draws (same Philox blocks) and identical outputs layout.  grid = ceil(B/64) blocks of 4 waves.
+template <int ENV>
+__global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r, int t, const float* __restrict__ theta,
+                                                      const float* __restrict__ norm, BigState st) {
+    using C = Cfg<ENV, 64, 32>;
+    constexpr int NS = C::NS, NA = C::NA, NDROP = C::NDROP, NIN = C::NIN, PH = 32, NS_KS = C::NS_KS;
+    constexpr int O_PF1 = NS_KS * 2 * 64, O_PF2 = O_PF1 + 16 * 64, O_B0 = O_PF2 + 8 * 64, O_B1 = O_B0 + 32, O_B2 = O_B1 + 32, IMG = O_B2 + 16;
+    __shared__ __attribute__((aligned(16))) float lds[IMG + 4 * 16 * NS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int b0 = (blockIdx.x * 4 + wave) * 16, b = b0 + c;
+    const bool active = b < r.B;
+    float* ST = lds + IMG + wave * 16 * NS;
+    for (int i = tid; i < IMG; i += 256) {
+        float w = 0.0f;
+        const int ln = i & 63, cc = ln & 15, qq = ln >> 4;
+        if (i < O_PF1) { const int f = i >> 6, s_ = f >> 1, cb = f & 1, in = 4 * s_ + qq; if (in < NS) w = theta[C::pW0 + in * PH + 16 * cb + cc]; }
+        else if (i < O_PF2) { const int f = (i - O_PF1) >> 6, kk = f >> 1, cb = f & 1; w = theta[C::pW1 + (16 * (kk >> 2) + 4 * qq + (kk & 3)) * PH + 16 * cb + cc]; }
+        else if (i < O_B0) { const int kk = (i - O_PF2) >> 6; if (cc < NA) w = theta[C::pW2 + (16 * (kk >> 2) + 4 * qq + (kk & 3)) * NA + cc]; }
+        else if (i < O_B1) w = theta[C::pb0 + (i - O_B0)];
+        else if (i < O_B2) w = theta[C::pb1 + (i - O_B1)];
+        else { const int d = i - O_B2; if (d < NA) w = theta[C::pb2 + d]; }
+        lds[i] = w;
+    }
+    const uint64_t genv = r.stream_offset + (uint64_t)b;
+    if (t == 0 && active && q == 0) {                            // vec_env.reset() (env_helpers.py:585-595)
+        const uint4 d0 = rng_draw(r.seed, genv, 0, RNG_RESET, 0);
+        const int row = (r.reset_idx != nullptr) ? r.reset_idx[b] : rng_index(d0.x, r.n_pool);
+        st.cur_model[b] = (r.reset_model != nullptr) ? r.reset_model[b] : rng_index(d0.y, pd.K);
+        st.ts[b] = 0;
+        for (int i = 0; i < NS; ++i) st.S[(size_t)b * NS + i] = r.pool[(size_t)row * NS + i];
+    }
+    __syncthreads();                                             // image complete; the reset rows of this tile are written by its own wave
+    const int lim = min(16, max(0, r.B - b0)) * NS;
+    for (int i = lane; i < 16 * NS; i += 64) ST[i] = (i < lim) ? st.S[(size_t)b0 * NS + i] : 0.0f;
+    wave_lds_sync();
+    if (lim > 0) { const size_t base = ((size_t)t * r.B + b0) * NS; for (int i = lane; i < lim; i += 64) r.obs[base + i] = ST[i]; }
+    f32x4 p0[2], p1[2];
+    p0[0] = *(const f32x4*)&lds[O_B0 + 4 * q]; p0[1] = *(const f32x4*)&lds[O_B0 + 16 + 4 * q];
+#pragma unroll
+    for (int s_ = 0; s_ < NS_KS; ++s_) {
+        const int f = 4 * s_ + q;
+        const float x = (f < NS) ? ST[c * NS + f] : 0.0f;
+        p0[0] = MFMA16(lds[(s_ * 2 + 0) * 64 + lane], x, p0[0]);
+        p0[1] = MFMA16(lds[(s_ * 2 + 1) * 64 + lane], x, p0[1]);
+    }
+    p1[0] = *(const f32x4*)&lds[O_B1 + 4 * q]; p1[1] = *(const f32x4*)&lds[O_B1 + 16 + 4 * q];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) p0[cb][rr] = tanh_fast(p0[cb][rr]);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        p1[0] = MFMA16(lds[O_PF1 + (kk * 2 + 0) * 64 + lane], p0[kk >> 2][kk & 3], p1[0]);
+        p1[1] = MFMA16(lds[O_PF1 + (kk * 2 + 1) * 64 + lane], p0[kk >> 2][kk & 3], p1[1]);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) p1[cb][rr] = tanh_fast(p1[cb][rr]);
+    f32x4 m0 = *(const f32x4*)&lds[O_B2 + 4 * q], m1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 8; kk += 2) {
+        m0 = MFMA16(lds[O_PF2 + kk * 64 + lane], p1[kk >> 2][kk & 3], m0);
+        m1 = MFMA16(lds[O_PF2 + (kk + 1) * 64 + lane], p1[(kk + 1) >> 2][(kk + 1) & 3], m1);
+    }
+    const f32x4 mu = m0 + m1;
+    if (!active) return;
+    const size_t tb = (size_t)t * r.B + b;
+    const float* in_mean = norm; const float* in_std = norm + (NS + NA);
+    const float* __restrict__ log_std = theta + C::pLS;
+    // state part of the normalised, dropped input: lane (c, q) writes its dims 4q .. (every 16th column block)
+    for (int i = q; i < NS; i += 4) if (i >= NDROP) st.X[(size_t)b * NIN + i - NDROP] = (ST[c * NS + i] - in_mean[i]) / in_std[i];     // training.py:228,146-151
+    // action dims 4q .. 4q+3 of this lane = Philox chunks 2q, 2q+1 (chunk 0 = the step block), exactly as k_big_pre
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int d0 = 4 * q + 2 * h;
+        if (d0 >= NA) continue;
+        float z[2] = {0.f, 0.f};
+        if (!r.determ && r.eps == nullptr) {
+            const uint4 blk = rng_draw(r.seed, genv, t, RNG_STEP, d0 >> 1);
+            normal2(blk.x, blk.y, z[0], z[1]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int d = d0 + j;
+            if (d >= NA) continue;
+            const float m = mu[2 * h + j];
+            float a = m;
+            if (!r.determ) a = fmaf((r.eps != nullptr) ? r.eps[tb * NA + d] : z[j], __expf(fmaxf(log_std[d], LOG_MIN_STD)), m);
+            r.act[tb * NA + d] = a; r.mean[tb * NA + d] = m;
+            const float ac = fminf(fmaxf(a, -1.0f), 1.0f);          // env_helpers.py:599
+            st.U[(size_t)b * NA + d] = ac;
+            st.X[(size_t)b * NIN + (NS - NDROP) + d] = (ac - in_mean[NS + d]) / in_std[NS + d];
+        }
+    }
+}
+
+typedef void (*big_pre_mfma_t)(ProblemDesc, RolloutK, int, const float*, const float*, BigState);
+static big_pre_mfma_t big_pre_mfma_select(const ProblemDesc& pd) {
+    if (pd.pol.n_layers != 3 || pd.pol.dims[1] != 32 || pd.pol.dims[2] != 32 || pd.pol.act[0] != METRPO_ACT_TANH) return nullptr;
+    switch (pd.env) {
+    case METRPO_ENV_SWIMMER: return (pd.ns == 10 && pd.na == 2 && pd.n_drop == 2) ? k_big_pre_mfma<METRPO_ENV_SWIMMER> : nullptr;
+    case METRPO_ENV_HALF_CHEETAH: return (pd.ns == 18 && pd.na == 6 && pd.n_drop == 1) ? k_big_pre_mfma<METRPO_ENV_HALF_CHEETAH> : nullptr;
+    case METRPO_ENV_ANT: return (pd.ns == 29 && pd.na == 8 && pd.n_drop == 2) ? k_big_pre_mfma<METRPO_ENV_ANT> : nullptr;
+    case METRPO_ENV_HOPPER: return (pd.ns == 11 && pd.na == 3 && pd.n_drop == 0) ? k_big_pre_mfma<METRPO_ENV_HOPPER> : nullptr;
+    case METRPO_ENV_SNAKE: return (pd.ns == 14 && pd.na == 4 && pd.n_drop == 2) ? k_big_pre_mfma<METRPO_ENV_SNAKE> : nullptr;
+    }
+    return nullptr;
 }
 
 // de-normalise + residual (training.py:257), selection (env_helpers.py:617-634), reward (:601), done (:603-604), reset (:585-595)
@@ -195,8 +309,10 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
     const size_t psh = (size_t)(pd.ns + 2 * pd.pol.max_width) * pbs * sizeof(float);
     if (psh > 160 * 1024) return set_err(c, METRPO_EUNSUPPORTED, "policy too wide for k_big_pre");
     if (psh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_big_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psh));
+    const big_pre_mfma_t pre_mfma = big_pre_mfma_select(pd);
     for (int t = 0; t < a->T; ++t) {
-        hipLaunchKernelGGL(k_big_pre, dim3((B + pbs - 1) / pbs), dim3(pbs), psh, st, pd, r, t, c->d_theta, c->d_norm, bs);
+        if (pre_mfma) hipLaunchKernelGGL(pre_mfma, dim3((B + 63) / 64), dim3(256), 0, st, pd, r, t, c->d_theta, c->d_norm, bs);
+        else hipLaunchKernelGGL(k_big_pre, dim3((B + pbs - 1) / pbs), dim3(pbs), psh, st, pd, r, t, c->d_theta, c->d_norm, bs);
         const float* in = bs.X; long long sIn = 0; int ldin = pd.nin;
         float* bufs[2] = {bs.HA, bs.HB};
         for (int l = 0; l < L; ++l) {

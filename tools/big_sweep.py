@@ -8,8 +8,10 @@ def flops(env, dh):
     ns, na, nd = synthetic.ENV_SPECS[env]
     d = [ns + na - nd] + list(dh) + [ns]
     return 2 * sum(d[i] * d[i + 1] for i in range(len(d) - 1))
+only = sys.argv[1] if len(sys.argv) > 1 else None
 for name, env, K, dh, ph, B, T in [('C0-params', 'swimmer', 5, (512, 512), (32, 32), 100, 20), ('C2-2x1024', 'half_cheetah', 5, (1024, 1024), (32, 32), 2500, 10),
                                    ('C3', 'ant', 10, (512, 512), (32, 32), 2500, 10), ('C4', 'humanoid', 20, (1024, 1024, 1024), (100, 50, 25), 6250, 5)]:
+    if only and only != name: continue
     eng = metrpo_amd.Engine(env, K, dh, ph)
     Ws, bs, norm = synthetic.make_dynamics(env, K, dh, seed=0)
     eng.set_dynamics_layers(Ws, bs, norm['in_mean'], norm['in_std'], norm['diff_mean'], norm['diff_std'])
