@@ -36,6 +36,41 @@ __device__ __forceinline__ void cg_step_body(int P, double reg, double tol, int 
         return;
     }
     const double rdotr = scal[S_RDOTR];
+    // every vector element is read ONCE (one global round trip) and kept in registers across the two reductions: element i = tid + j*blockDim
+    constexpr int CG_R = 4;
+    if (P <= CG_R * (int)blockDim.x) {
+        double pv[CG_R], zv[CG_R], rv[CG_R], xv[CG_R];
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < CG_R; ++j) {
+            const int i = threadIdx.x + j * blockDim.x;
+            pv[j] = zv[j] = rv[j] = xv[j] = 0.0;
+            if (i < P) { pv[j] = p[i]; zv[j] = z[i] + reg * pv[j]; rv[j] = r[i]; xv[j] = x[i]; acc += pv[j] * zv[j]; }
+        }
+        const double pz = blk_sum(acc, sh);
+        const double v = rdotr / pz;
+        acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < CG_R; ++j) { xv[j] += v * pv[j]; rv[j] -= v * zv[j]; acc += rv[j] * rv[j]; }
+        const double newrdotr = blk_sum(acc, sh);
+        const double mu = newrdotr / rdotr;
+#pragma unroll
+        for (int j = 0; j < CG_R; ++j) {
+            const int i = threadIdx.x + j * blockDim.x;
+            if (i < P) {
+                const double pn = rv[j] + mu * pv[j];
+                z[i] = zv[j]; x[i] = xv[j]; r[i] = rv[j]; p[i] = pn;
+                pf[i] = last ? (float)xv[j] : (float)pn;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            scal[S_RDOTR] = newrdotr;
+            scal[S_ITERS] += 1.0;
+            if (newrdotr < tol) scal[S_DONE] = 1.0;
+        }
+        return;
+    }
     double acc = 0.0;
     for (int i = threadIdx.x; i < P; i += blockDim.x) { const double zi = z[i] + reg * p[i]; z[i] = zi; acc += p[i] * zi; }
     const double pz = blk_sum(acc, sh);
