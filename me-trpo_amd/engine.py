@@ -149,6 +149,16 @@ class Engine(object):
                 eps=None, model_idx=None, sel_noise=None, reset_idx=None, reset_model=None, out=None,
                 force_generic=False):
         dev = self.device
+        # launch fast path (the bench / training loop): same buffers, same modes, production draws -> only the seed changes in the cached struct
+        no_draws = eps is None and model_idx is None and sel_noise is None and reset_idx is None and reset_model is None
+        if no_draws and out is not None and not force_generic and isinstance(pool, torch.Tensor):
+            key = (id(out), pool.data_ptr(), B, T, H, sam_mode, bool(determ), bool(eval_all_heads), int(stream_offset))
+            cached = getattr(self, '_ra_cache', None)
+            if cached is not None and cached[0] == key:
+                a = cached[1]
+                a.seed = int(seed)
+                self._chk(lib.metrpo_rollout(self._ctx, C.byref(a), self._stream()))
+                return out
         pool = _f32(pool, dev); assert pool.dim() == 2 and pool.shape[1] == self.ns
         eps = _f32(eps, dev, (T, B, self.na)); sel_noise = _f32(sel_noise, dev, (T, B, self.ns))
         model_idx = _i32(model_idx, dev, (T, B))
@@ -167,6 +177,8 @@ class Engine(object):
         fn = lib.metrpo_rollout_generic if force_generic else lib.metrpo_rollout
         self._chk(fn(self._ctx, C.byref(a), self._stream()))
         self._keep = (pool, eps, model_idx, sel_noise, reset_idx, reset_model)   # alive until the stream has consumed them
+        if no_draws and not force_generic:
+            self._ra_cache = ((id(out), pool.data_ptr(), B, T, H, sam_mode, bool(determ), bool(eval_all_heads), int(stream_offset)), a, out, pool)
         return out
 
     def alloc_trajectory(self, B, T, H):
