@@ -227,7 +227,8 @@ static int dg_workspace(metrpo_ctx* c, int B, DgState* s) {
     size_t nH = 0;
     for (int l = 1; l < L; ++l) { maxw = std::max(maxw, pd.dyn.dims[l]); nH += up4(R * pd.dyn.dims[l]); }
     const size_t nS = up4(R * pd.ns), nX = up4(R * pd.nin), nU = up4(R * pd.na), nZ = up4(R * maxw), nD = up4(R);
-    const size_t nP = up4(skinny_part_floats(B, pd.ns, pd.dyn.dims[L - 1], K));
+    size_t nP = 0;
+    for (int l = 0; l < L; ++l) nP = std::max(nP, up4(skinny_part_floats(B, pd.dyn.dims[l + 1], pd.dyn.dims[l], K)));
     const size_t need = (4 * nS + nX + 2 * nU + nH + 2 * nZ + nD + nP) * sizeof(float) + R * sizeof(double) + 64;
     if (need > c->dg_cap) {
         if (c->d_dg) HIP_TRY(c, hipFree(c->d_dg));
@@ -253,8 +254,8 @@ static void dg_forward_layers(metrpo_ctx* c, const DgState& s, int B, int n_laye
         GemmEpi ep = {};
         ep.bias = c->d_dyn + pd.dyn.b_off[l]; ep.strideBias = pd.dyn.n_params;
         const float* Wl = c->d_dyn + pd.dyn.w_off[l];
-        if (l == L - 1) gemm_skinny_bias(in, (long long)B * Kd, ldin, Wl, pd.dyn.n_params, N, ep.bias, ep.strideBias, out, (long long)B * N, B, N, Kd, K, s.PART, st);
-        else gemm_auto<EPI_BIAS_RELU, false, false>(in, (long long)B * Kd, ldin, Wl, pd.dyn.n_params, N, out, (long long)B * N, N, B, N, Kd, K, ep, st);
+        gemm_skinny_bias(in, (long long)B * Kd, ldin, Wl, pd.dyn.n_params, N, ep.bias, ep.strideBias, out, (long long)B * N, B, N, Kd, K, s.PART, st,
+                         (l == L - 1) ? 0 : 1);
         in = out; ldin = N;
     }
 }

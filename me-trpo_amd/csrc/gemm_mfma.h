@@ -238,18 +238,20 @@ static inline void gemm_auto(const float* A, long long sA, int lda, const float*
 // A 64-column tile per (64 rows, head) leaves most CUs idle and every workgroup walks the whole K axis; splitting K multiplies the
 // workgroups and shortens each walk (the layer is bound by reading A).  Partials are summed in split order: deterministic.
 static __global__ void k_splitk_bias_reduce(int splits, int heads, long long stridePart, const float* __restrict__ part, int M, int N,
-                                     const float* __restrict__ bias, long long strideBias, float* __restrict__ C, long long strideC) {
+                                     const float* __restrict__ bias, long long strideBias, float* __restrict__ C, long long strideC, int act) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int head = blockIdx.y;
     if (i >= (long long)M * N) return;
     float v = bias ? bias[(size_t)head * strideBias + (int)(i % N)] : 0.0f;
     for (int s = 0; s < splits; ++s) v += part[((size_t)s * heads + head) * stridePart + i];
-    C[(size_t)head * strideC + i] = v;
+    C[(size_t)head * strideC + i] = (act == 1) ? fmaxf(v, 0.0f) : (act == 2) ? tanh_fast(v) : v;
 }
 
+// split-K pays when the launch has few output tiles and a long contraction: skinny output layers (N <= 64) and small-batch hidden layers
 static inline int skinny_splits(int M, int N, int Kd, int heads) {
-    if (N > 64 || Kd < 256) return 1;
-    const long long blocks = (long long)((M + 63) / 64) * heads;
+    if (Kd < 256) return 1;
+    const long long blocks = (long long)((M + 63) / 64) * ((N + 63) / 64) * heads;
+    if (blocks >= 512) return 1;
     int want = (int)std::min<long long>(8, std::max<long long>(1, 1024 / std::max<long long>(blocks, 1)));
     want = std::min(want, Kd / 128);
     return std::max(want, 1);
@@ -258,13 +260,15 @@ static inline size_t skinny_part_floats(int M, int N, int Kd, int heads) {
     const int s = skinny_splits(M, N, Kd, heads);
     return s > 1 ? (size_t)s * heads * ((((size_t)M * N + N) + 3) & ~(size_t)3) : 0;
 }
-// part: workspace of >= skinny_part_floats(...) floats (may be NULL when that is 0).  Identity activation only (output layers).
+// part: workspace of >= skinny_part_floats(...) floats (may be NULL when that is 0).  act: 0 identity, 1 relu, 2 tanh (METRPO_ACT_*).
 static inline void gemm_skinny_bias(const float* A, long long sA, int lda, const float* W, long long sW, int ldw, const float* bias, long long sBias,
-                                    float* C, long long sC, int M, int N, int Kd, int heads, float* part, hipStream_t st) {
+                                    float* C, long long sC, int M, int N, int Kd, int heads, float* part, hipStream_t st, int act = 0) {
     const int S = skinny_splits(M, N, Kd, heads);
     if (S <= 1 || part == nullptr) {
         GemmEpi ep = {}; ep.bias = bias; ep.strideBias = sBias;
-        gemm_auto<EPI_BIAS_ID, false, false>(A, sA, lda, W, sW, ldw, C, sC, N, M, N, Kd, heads, ep, st);
+        if (act == 1) gemm_auto<EPI_BIAS_RELU, false, false>(A, sA, lda, W, sW, ldw, C, sC, N, M, N, Kd, heads, ep, st);
+        else if (act == 2) gemm_auto<EPI_BIAS_TANH, false, false>(A, sA, lda, W, sW, ldw, C, sC, N, M, N, Kd, heads, ep, st);
+        else gemm_auto<EPI_BIAS_ID, false, false>(A, sA, lda, W, sW, ldw, C, sC, N, M, N, Kd, heads, ep, st);
         return;
     }
     GemmEpi ep = {};
@@ -273,5 +277,5 @@ static inline void gemm_skinny_bias(const float* A, long long sA, int lda, const
     gemm_mfma_launch<1, 1, EPI_PARTIAL, false, false>(A, sA, lda, W, sW, ldw, nullptr, 0, N, M, N, Kd, heads, ep, st);
     const long long tot = (long long)M * N;
     hipLaunchKernelGGL(k_splitk_bias_reduce, dim3((unsigned)((tot + 255) / 256), heads), dim3(256), 0, st, ep.splits, heads, ep.stridePart, part, M, N,
-                       bias, sBias, C, sC);
+                       bias, sBias, C, sC, act);
 }

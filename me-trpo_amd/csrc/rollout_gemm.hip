@@ -287,7 +287,8 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
     // workspace (floats): S, X, U, HA, HB, OUT + ints ts, cur_model
     auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };       // keep every sub-buffer 16-byte aligned
     const size_t nS = up4((size_t)B * pd.ns), nX = up4((size_t)B * pd.nin), nU = up4((size_t)B * pd.na), nH = up4((size_t)K * B * maxh), nO = up4((size_t)K * B * pd.ns);
-    const size_t nP = up4(skinny_part_floats(B, pd.ns, pd.dyn.dims[L - 1], K));
+    size_t nP = 0;
+    for (int l = 0; l < L; ++l) nP = std::max(nP, up4(skinny_part_floats(B, pd.dyn.dims[l + 1], pd.dyn.dims[l], K)));
     const size_t need = (nS + nX + nU + 2 * nH + nO + nP) * sizeof(float) + 2 * (size_t)B * sizeof(int) + 256;
     if (need > c->big_cap) {
         if (c->d_big) HIP_TRY(c, hipFree(c->d_big));
@@ -322,9 +323,7 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
             const long long sOut = (long long)B * N;
             const float* Wl = c->d_dyn + pd.dyn.w_off[l];
             const float* bl = c->d_dyn + pd.dyn.b_off[l];
-            if (lastl && pd.dyn.act[l] == METRPO_ACT_IDENTITY)
-                gemm_skinny_bias(in, sIn, ldin, Wl, pd.dyn.n_params, N, bl, pd.dyn.n_params, out, sOut, B, N, Kd, K, bs.PART, st);
-            else gemm_launch(pd.dyn.act[l], in, sIn, ldin, Wl, pd.dyn.n_params, N, bl, pd.dyn.n_params, out, sOut, N, B, N, Kd, K, st);
+            gemm_skinny_bias(in, sIn, ldin, Wl, pd.dyn.n_params, N, bl, pd.dyn.n_params, out, sOut, B, N, Kd, K, bs.PART, st, pd.dyn.act[l]);
             in = out; sIn = sOut; ldin = N;
         }
         hipLaunchKernelGGL(k_big_post, dim3((B + 127) / 128), dim3(128), 0, st, pd, r, t, c->d_norm, bs);

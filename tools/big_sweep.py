@@ -9,7 +9,8 @@ def flops(env, dh):
     d = [ns + na - nd] + list(dh) + [ns]
     return 2 * sum(d[i] * d[i + 1] for i in range(len(d) - 1))
 only = sys.argv[1] if len(sys.argv) > 1 else None
-for name, env, K, dh, ph, B, T in [('C0-params', 'swimmer', 5, (512, 512), (32, 32), 100, 20), ('C2-2x1024', 'half_cheetah', 5, (1024, 1024), (32, 32), 2500, 10),
+for name, env, K, dh, ph, B, T in [('hc-params-B100', 'half_cheetah', 5, (1024, 1024), (32, 32), 100, 20), ('hc-params-B500', 'half_cheetah', 5, (1024, 1024), (32, 32), 500, 20),
+                                   ('C0-params', 'swimmer', 5, (512, 512), (32, 32), 100, 20), ('C2-2x1024', 'half_cheetah', 5, (1024, 1024), (32, 32), 2500, 10),
                                    ('C3', 'ant', 10, (512, 512), (32, 32), 2500, 10), ('C4', 'humanoid', 20, (1024, 1024, 1024), (100, 50, 25), 6250, 5)]:
     if only and only != name: continue
     eng = metrpo_amd.Engine(env, K, dh, ph)
