@@ -8,6 +8,7 @@
 //                  (dZ . W^T with the relu mask of the layer below as epilogue)  ->  k_dg_back (normalisers, residual, clip gate,
 //                  mean-adjoint output, policy input VJP)
 #include "gemm_mfma.h"
+#include "mfma_common.h"
 
 struct DgState {
     float *S, *X, *U, *MU, *OUT, *G, *DZa, *DZb, *LAM, *DONES, *PART;
@@ -41,6 +42,99 @@ __global__ void k_dg_pre(ProblemDesc pd, int B, const float* __restrict__ theta,
         st.MU[row * na + d] = mu; st.U[row * na + d] = ac;
         st.X[row * pd.nin + (ns - pd.n_drop) + d] = (ac - in_mean[ns + d]) / in_std[ns + d];
     }
+}
+
+// MFMA variant of k_dg_pre for the 2x32 tanh policies: a wave evaluates the policy of a 16-row tile of one model as the transposed MFMA
+// chain of the fused kernels (30 MFMAs) instead of 64 threads walking three dense layers each.  grid = (ceil(B/64), K) blocks of 4 waves.
+template <int ENV>
+__global__ void __launch_bounds__(256) k_dg_pre_mfma(ProblemDesc pd, int B, const float* __restrict__ theta, const float* __restrict__ norm,
+                                                     const float* __restrict__ xs_t, long long xs_model_stride, DgState st) {
+    using C = Cfg<ENV, 64, 32>;
+    constexpr int NS = C::NS, NA = C::NA, NDROP = C::NDROP, NIN = C::NIN, PH = 32, NS_KS = C::NS_KS;
+    constexpr int O_PF1 = NS_KS * 2 * 64, O_PF2 = O_PF1 + 16 * 64, O_B0 = O_PF2 + 8 * 64, O_B1 = O_B0 + 32, O_B2 = O_B1 + 32, IMG = O_B2 + 16;
+    __shared__ __attribute__((aligned(16))) float lds[IMG + 4 * 16 * NS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int k = blockIdx.y;
+    const int b0 = (blockIdx.x * 4 + wave) * 16, b = b0 + c;
+    const bool active = b < B;
+    float* ST = lds + IMG + wave * 16 * NS;
+    for (int i = tid; i < IMG; i += 256) {
+        float w = 0.0f;
+        const int ln = i & 63, cc = ln & 15, qq = ln >> 4;
+        if (i < O_PF1) { const int f = i >> 6, s_ = f >> 1, cb = f & 1, in = 4 * s_ + qq; if (in < NS) w = theta[C::pW0 + in * PH + 16 * cb + cc]; }
+        else if (i < O_PF2) { const int f = (i - O_PF1) >> 6, kk = f >> 1, cb = f & 1; w = theta[C::pW1 + (16 * (kk >> 2) + 4 * qq + (kk & 3)) * PH + 16 * cb + cc]; }
+        else if (i < O_B0) { const int kk = (i - O_PF2) >> 6; if (cc < NA) w = theta[C::pW2 + (16 * (kk >> 2) + 4 * qq + (kk & 3)) * NA + cc]; }
+        else if (i < O_B1) w = theta[C::pb0 + (i - O_B0)];
+        else if (i < O_B2) w = theta[C::pb1 + (i - O_B1)];
+        else { const int d = i - O_B2; if (d < NA) w = theta[C::pb2 + d]; }
+        lds[i] = w;
+    }
+    const size_t row0 = (size_t)k * B + b0;
+    const float* src = (xs_t != nullptr) ? xs_t + (size_t)k * xs_model_stride + (size_t)b0 * NS : st.S + row0 * NS;
+    const int lim = min(16, max(0, B - b0)) * NS;
+    for (int i = lane; i < 16 * NS; i += 64) {
+        const float v = (i < lim) ? src[i] : 0.0f;
+        ST[i] = v;
+        if (xs_t != nullptr && i < lim) st.S[row0 * NS + i] = v;
+    }
+    __syncthreads();
+    f32x4 p0[2], p1[2];
+    p0[0] = *(const f32x4*)&lds[O_B0 + 4 * q]; p0[1] = *(const f32x4*)&lds[O_B0 + 16 + 4 * q];
+#pragma unroll
+    for (int s_ = 0; s_ < NS_KS; ++s_) {
+        const int f = 4 * s_ + q;
+        const float x = (f < NS) ? ST[c * NS + f] : 0.0f;
+        p0[0] = MFMA16(lds[(s_ * 2 + 0) * 64 + lane], x, p0[0]);
+        p0[1] = MFMA16(lds[(s_ * 2 + 1) * 64 + lane], x, p0[1]);
+    }
+    p1[0] = *(const f32x4*)&lds[O_B1 + 4 * q]; p1[1] = *(const f32x4*)&lds[O_B1 + 16 + 4 * q];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) p0[cb][rr] = tanh_fast(p0[cb][rr]);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        p1[0] = MFMA16(lds[O_PF1 + (kk * 2 + 0) * 64 + lane], p0[kk >> 2][kk & 3], p1[0]);
+        p1[1] = MFMA16(lds[O_PF1 + (kk * 2 + 1) * 64 + lane], p0[kk >> 2][kk & 3], p1[1]);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) p1[cb][rr] = tanh_fast(p1[cb][rr]);
+    f32x4 m0 = *(const f32x4*)&lds[O_B2 + 4 * q], m1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 8; kk += 2) {
+        m0 = MFMA16(lds[O_PF2 + kk * 64 + lane], p1[kk >> 2][kk & 3], m0);
+        m1 = MFMA16(lds[O_PF2 + (kk + 1) * 64 + lane], p1[(kk + 1) >> 2][(kk + 1) & 3], m1);
+    }
+    const f32x4 mu = m0 + m1;
+    if (!active) return;
+    const size_t row = (size_t)k * B + b;
+    const float* in_mean = norm; const float* in_std = norm + (NS + NA);
+    for (int i = q; i < NS; i += 4) if (i >= NDROP) st.X[row * NIN + i - NDROP] = (ST[c * NS + i] - in_mean[i]) / in_std[i];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int d = 4 * q + rr;
+        if (d < NA) {
+            const float ac = fminf(fmaxf(mu[rr], -1.0f), 1.0f);                           // model_based_rl.py:128
+            st.MU[row * NA + d] = mu[rr]; st.U[row * NA + d] = ac;
+            st.X[row * NIN + (NS - NDROP) + d] = (ac - in_mean[NS + d]) / in_std[NS + d];
+        }
+    }
+}
+
+typedef void (*dg_pre_mfma_t)(ProblemDesc, int, const float*, const float*, const float*, long long, DgState);
+static dg_pre_mfma_t dg_pre_mfma_select(const ProblemDesc& pd) {
+    if (pd.pol.n_layers != 3 || pd.pol.dims[1] != 32 || pd.pol.dims[2] != 32 || pd.pol.act[0] != METRPO_ACT_TANH) return nullptr;
+    switch (pd.env) {
+    case METRPO_ENV_SWIMMER: return (pd.ns == 10 && pd.na == 2 && pd.n_drop == 2) ? k_dg_pre_mfma<METRPO_ENV_SWIMMER> : nullptr;
+    case METRPO_ENV_HALF_CHEETAH: return (pd.ns == 18 && pd.na == 6 && pd.n_drop == 1) ? k_dg_pre_mfma<METRPO_ENV_HALF_CHEETAH> : nullptr;
+    case METRPO_ENV_ANT: return (pd.ns == 29 && pd.na == 8 && pd.n_drop == 2) ? k_dg_pre_mfma<METRPO_ENV_ANT> : nullptr;
+    case METRPO_ENV_HOPPER: return (pd.ns == 11 && pd.na == 3 && pd.n_drop == 0) ? k_dg_pre_mfma<METRPO_ENV_HOPPER> : nullptr;
+    case METRPO_ENV_SNAKE: return (pd.ns == 14 && pd.na == 4 && pd.n_drop == 2) ? k_dg_pre_mfma<METRPO_ENV_SNAKE> : nullptr;
+    }
+    return nullptr;
 }
 
 __device__ __forceinline__ float dg_cost(int env, int ns, int na, const float* xn, const float* u) {
@@ -278,8 +372,10 @@ int launch_dg_forward(metrpo_ctx* c, const float* s0, int B, int T, double gamma
     if (psh > 160 * 1024) return set_err(c, METRPO_EUNSUPPORTED, "policy too wide for k_dg_pre");
     if (psh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_dg_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psh));
     double g = 1.0;
+    const dg_pre_mfma_t pre_mfma = dg_pre_mfma_select(pd);
     for (int t = 0; t < T; ++t) {
-        hipLaunchKernelGGL(k_dg_pre, dim3((B + pbs - 1) / pbs, K), dim3(pbs), psh, st, pd, B, c->d_theta, c->d_norm, (const float*)nullptr, 0LL, s);
+        if (pre_mfma) hipLaunchKernelGGL(pre_mfma, dim3((B + 63) / 64, K), dim3(256), 0, st, pd, B, c->d_theta, c->d_norm, (const float*)nullptr, 0LL, s);
+        else hipLaunchKernelGGL(k_dg_pre, dim3((B + pbs - 1) / pbs, K), dim3(pbs), psh, st, pd, B, c->d_theta, c->d_norm, (const float*)nullptr, 0LL, s);
         dg_forward_layers(c, s, B, L, st);
         hipLaunchKernelGGL(k_dg_post, dim3((B + 127) / 128, K), dim3(128), 0, st, pd, B, T, t, g, c->d_norm, s, XS, WT);
         g *= gamma;
@@ -305,9 +401,11 @@ int launch_dg_backward(metrpo_ctx* c, int B, int T, const float* XS, const float
     if (psh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_dg_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psh));
     if (bsh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_dg_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bsh));
     const long long xs_model = (long long)(T + 1) * B * pd.ns;
+    const dg_pre_mfma_t pre_mfma = dg_pre_mfma_select(pd);
     for (int t = T - 1; t >= 0; --t) {
-        hipLaunchKernelGGL(k_dg_pre, dim3((B + pbs - 1) / pbs, K), dim3(pbs), psh, st, pd, B, c->d_theta, c->d_norm,
-                           XS + (size_t)t * B * pd.ns, xs_model, s);
+        if (pre_mfma) hipLaunchKernelGGL(pre_mfma, dim3((B + 63) / 64, K), dim3(256), 0, st, pd, B, c->d_theta, c->d_norm, XS + (size_t)t * B * pd.ns, xs_model, s);
+        else hipLaunchKernelGGL(k_dg_pre, dim3((B + pbs - 1) / pbs, K), dim3(pbs), psh, st, pd, B, c->d_theta, c->d_norm,
+                                XS + (size_t)t * B * pd.ns, xs_model, s);
         dg_forward_layers(c, s, B, L - 1, st);                                    // hidden activations only
         hipLaunchKernelGGL(k_dg_mid, dim3((B + 127) / 128, K), dim3(128), 0, st, pd, B, T, t, c->d_norm, XS, WT, s);
         float* dz = s.DZa; float* dzn = s.DZb;
