@@ -251,8 +251,8 @@ static __global__ void k_splitk_bias_reduce(int splits, int heads, long long str
 static inline int skinny_splits(int M, int N, int Kd, int heads) {
     if (Kd < 256) return 1;
     const long long blocks = (long long)((M + 63) / 64) * ((N + 63) / 64) * heads;
-    if (blocks >= 1024) return 1;
-    int want = (int)std::min<long long>(8, std::max<long long>(1, 2048 / std::max<long long>(blocks, 1)));
+    if (blocks >= 512) return 1;
+    int want = (int)std::min<long long>(8, std::max<long long>(1, 1024 / std::max<long long>(blocks, 1)));
     want = std::min(want, Kd / 128);
     return std::max(want, 1);
 }
