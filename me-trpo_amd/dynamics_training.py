@@ -13,83 +13,131 @@ import torch
 
 
 class data_collection(object):
+    """FIFO replay buffer with the interface and the index stream of the reference's `data_collection` (utils.py:44-131),
+    stored as a PREALLOCATED RING in HBM: two [max_size, d] device tensors, a physical `_head` (row of the oldest sample) and
+    `n_data`.  Appending writes at most two contiguous slices and evicting the oldest rows moves `_head` -- nothing is
+    re-allocated or shifted (the reference concatenates and re-slices the whole array on every add).  Logical row i (0 = oldest)
+    lives at physical row (_head + i) % max_size; `cur_idx`, the batches of get_next_batch / sample and `.x` / `.y` are all in
+    logical order, so every consumer sees exactly what the reference's arrays would hold
+    (tests/golden/dyn_data.npz, dyn_buffer_reftests.npz)."""
+
     def __init__(self, max_size=int(5e4), device=None):
-        self.cur_idx, self.x, self.y, self.n_data, self.max_size = 0, None, None, None, max_size
-        self.device = device
+        self.max_size, self.device = int(max_size), device
+        self.cur_idx, self.n_data = 0, None
+        self._head, self._xs, self._ys = 0, None, None
+        self.idx_mapping = []
 
-    def _t(self, a):
-        return torch.as_tensor(np.asarray(a), dtype=torch.float32, device=self.device) if not isinstance(a, torch.Tensor) else a.to(self.device, torch.float32)
+    # ---- storage
+    def _dev(self, a):
+        if isinstance(a, torch.Tensor):
+            return a.to(self.device, torch.float32)
+        return torch.as_tensor(np.asarray(a), dtype=torch.float32, device=self.device)
 
-    def cap_data_size(self):
-        new_start_idx = self.x.shape[0] - self.max_size
-        if new_start_idx > 0:
-            self.x, self.y = self.x[new_start_idx:].contiguous(), self.y[new_start_idx:].contiguous()
-            self.n_data = self.max_size
-            self.cur_idx -= new_start_idx
+    def _ensure_storage(self, x, y):
+        if self._xs is None:
+            self._xs = torch.empty(self.max_size, x.shape[1], dtype=torch.float32, device=x.device)
+            self._ys = torch.empty(self.max_size, y.shape[1], dtype=torch.float32, device=y.device)
+
+    def _append(self, x, y):
+        """Write rows after the newest sample; returns how many of the OLDEST logical rows (of old + new) fell out."""
+        cap, held, m = self.max_size, self.n_data or 0, x.shape[0]
+        if m >= cap:                                           # the new block alone fills the ring
+            self._xs.copy_(x[m - cap:]); self._ys.copy_(y[m - cap:])
+            self._head, self.n_data = 0, cap
+            return held + m - cap
+        w = (self._head + held) % cap                          # first free physical row
+        first = min(m, cap - w)
+        self._xs[w:w + first] = x[:first]; self._ys[w:w + first] = y[:first]
+        if first < m:
+            self._xs[:m - first] = x[first:]; self._ys[:m - first] = y[first:]
+        dropped = max(0, held + m - cap)
+        self._head = (self._head + dropped) % cap
+        self.n_data = held + m - dropped
+        return dropped
+
+    def _physical(self, logical):
+        idx = np.asarray(logical, dtype=np.int64)
+        idx = np.where(idx < 0, idx + self.n_data, idx)        # NumPy wrap: the reference can hold cur_idx = -1 after a capped set_data
+        if np.any((idx < 0) | (idx >= self.n_data)):
+            raise IndexError("replay-buffer index out of range")
+        return torch.as_tensor((idx + self._head) % self.max_size, device=self._xs.device)
+
+    def _rows(self, logical):
+        phys = self._physical(logical)
+        return self._xs.index_select(0, phys), self._ys.index_select(0, phys)
+
+    @property
+    def x(self):
+        return None if self._xs is None else self._rows(np.arange(self.n_data))[0]
+
+    @property
+    def y(self):
+        return None if self._ys is None else self._rows(np.arange(self.n_data))[1]
+
+    def _fresh_mapping(self, is_shuffled):
+        self.idx_mapping = list(range(self.n_data))
+        if is_shuffled:                                        # permutes idx_mapping only; batches never read it (utils.py:110-111)
+            self.reshuffle_indices()
+
+    # ---- reference interface
+    def add_data(self, x_new, y_new, is_shuffled=False):
+        """utils.py:78-90: the cursor moves to the first new row, then follows the eviction."""
+        x_new, y_new = self._dev(x_new), self._dev(y_new)
+        if x_new.shape[0] != y_new.shape[0]:
+            raise AssertionError("x and y row counts differ")
+        self._ensure_storage(x_new, y_new)
+        self.cur_idx = self.n_data or 0
+        self.cur_idx -= self._append(x_new, y_new)
+        self._fresh_mapping(is_shuffled)
+
+    def set_data(self, x, y, is_shuffled=False):
+        """utils.py:67-76.  Kept quirk: the cursor is wrapped with the row count BEFORE the cap is applied."""
+        x, y = self._dev(x), self._dev(y)
+        if x.shape[0] != y.shape[0]:
+            raise AssertionError("x and y row counts differ")
+        self._ensure_storage(x, y)
+        self.cur_idx %= x.shape[0]
+        self.n_data, self._head = 0, 0
+        self.cur_idx -= self._append(x, y)
+        self._fresh_mapping(is_shuffled)
 
     def clone(self, dc, first_i=None):
         assert first_i is None or first_i <= dc.n_data, "Not enough data for first_i."
         self.set_data(dc.x[:first_i], dc.y[:first_i])
 
-    def set_data(self, x, y, is_shuffled=False):
-        """utils.py:67-76 incl. its quirks: cur_idx wraps with the uncapped row count; is_shuffled permutes idx_mapping only
-        (remap() is the identity, :110-111), i.e. it consumes np.random and changes no batch."""
-        x, y = self._t(x), self._t(y)
-        assert x.shape[0] == y.shape[0]
-        self.n_data, self.x, self.y = x.shape[0], x, y
-        self.cur_idx %= self.n_data
-        self.cap_data_size()
-        self.idx_mapping = list(range(self.n_data))
-        if is_shuffled:
-            self.reshuffle_indices()
-
-    def add_data(self, x_new, y_new, is_shuffled=False):
-        x_new, y_new = self._t(x_new), self._t(y_new)
-        assert x_new.shape[0] == y_new.shape[0]
-        if self.x is not None:
-            self.cur_idx = self.x.shape[0]                       # point to new data
-            self.x, self.y = torch.cat([self.x, x_new]), torch.cat([self.y, y_new])
-        else:
-            self.cur_idx, self.x, self.y = 0, x_new, y_new
-        self.n_data = self.x.shape[0]
-        self.cap_data_size()
-        self.idx_mapping = list(range(self.n_data))
-        if is_shuffled:
-            self.reshuffle_indices()
+    def cap_data_size(self):
+        """The ring never exceeds max_size; kept for interface parity (utils.py:55-61)."""
 
     def reshuffle_indices(self):
         np.random.shuffle(self.idx_mapping)
 
     def reshuffle_data(self):
-        shuffled = list(range(self.n_data))
-        np.random.shuffle(shuffled)
-        idx = torch.as_tensor(np.asarray(shuffled, dtype=np.int64), device=self.x.device)
-        self.x, self.y = self.x.index_select(0, idx), self.y.index_select(0, idx)
+        order = list(range(self.n_data))
+        np.random.shuffle(order)
+        x, y = self._rows(order)
+        self._head = 0
+        self._xs[:self.n_data] = x; self._ys[:self.n_data] = y
 
     def get_num_data(self):
-        return 0 if self.n_data is None else self.n_data
-
-    def _gather(self, indices):
-        idx = np.asarray(indices, dtype=np.int64)
-        idx = np.where(idx < 0, idx + self.x.shape[0], idx)          # NumPy semantics: the reference reaches cur_idx = -1 after a capped set_data
-        idx = torch.as_tensor(idx, device=self.x.device)
-        return self.x.index_select(0, idx), self.y.index_select(0, idx)
+        return self.n_data or 0
 
     def get_next_batch(self, batch_size, is_shuffled=False):
-        assert batch_size <= self.n_data, "Batch size %d is larger than n_data %d" % (batch_size, self.n_data)
-        start_idx, end_idx = self.cur_idx, self.cur_idx + batch_size
-        if end_idx > self.n_data:
-            indices = list(range(start_idx, self.n_data)) + list(range(0, batch_size - (self.n_data - start_idx)))
-            self.cur_idx = batch_size - (self.n_data - start_idx)
+        """Sequential window of `batch_size` logical rows starting at the cursor, wrapping to row 0 (utils.py:113-125)."""
+        n = self.n_data
+        assert batch_size <= n, "Batch size %d is larger than n_data %d" % (batch_size, n)
+        stop = self.cur_idx + batch_size
+        if stop > n:
+            window = np.concatenate([np.arange(self.cur_idx, n), np.arange(0, stop - n)])
+            self.cur_idx = stop - n
         else:
-            indices = list(range(start_idx, end_idx))
-            self.cur_idx = end_idx
-        return self._gather(indices)
+            window = np.arange(self.cur_idx, stop)
+            self.cur_idx = stop
+        return self._rows(window)
 
     def sample(self, batch_size):
-        """Uniformly random batch with replacement -- same np.random.uniform draw as utils.py:127-129."""
-        indices = np.floor(self.n_data * np.random.uniform(0.0, 1.0, size=batch_size)).astype(np.intp)
-        return self._gather(indices)
+        """Uniform with replacement from one np.random.uniform call, floor(n*u) -- the draw of utils.py:127-129."""
+        u = np.random.uniform(0.0, 1.0, size=batch_size)
+        return self._rows(np.floor(self.n_data * u).astype(np.int64))
 
 
 def combine_data_collections(dc1, dc2):

@@ -5,50 +5,60 @@ iterations evaluate the K per-model validation costs (build_policy_graph forward
 keep/restore the best policy, stop after `num_iters_threshold` iterations without improvement.
 Host control flow in NumPy exactly as the reference; the costs come from the validation kernel."""
 import numpy as np
+import torch
 
 
-def stop_critereon(threshold, offset, percent_models_threshold=0.5):
-    def f(loss_old, loss_new, mode='scalar'):
-        if mode == 'scalar':
-            assert not hasattr(loss_new, '__iter__')
-            return (loss_new - loss_old) / (np.abs(loss_old) + offset) > threshold
-        else:
-            assert mode == 'vector'
-            assert isinstance(loss_new, np.ndarray)
-            out = loss_new > loss_old
-            return np.mean(out) > percent_models_threshold
-    return f
+class StopCriterion(object):
+    """Callable with the reference's signature `f(loss_old, loss_new, mode='scalar')` (utils.py:285-296).
+    scalar: relative increase of the loss above `threshold`; vector: fraction of models that got worse above
+    `percent_models_threshold` (ties are not "worse")."""
+
+    def __init__(self, threshold, offset, percent_models_threshold=0.5):
+        self.threshold, self.offset, self.percent_models_threshold = threshold, offset, percent_models_threshold
+
+    def __call__(self, loss_old, loss_new, mode='scalar'):
+        if mode == 'vector':
+            if not isinstance(loss_new, np.ndarray):
+                raise AssertionError("vector mode compares per-model cost arrays")
+            worse = np.count_nonzero(np.asarray(loss_new) > np.asarray(loss_old))
+            return worse / float(np.size(loss_new)) > self.percent_models_threshold
+        if mode != 'scalar' or np.ndim(loss_new) != 0:
+            raise AssertionError("scalar mode compares two numbers")
+        return (loss_new - loss_old) / (abs(loss_old) + self.offset) > self.threshold
+
+
+stop_critereon = StopCriterion          # the reference's (mis-spelt) factory name, same argument order
+
+
+def _per_model(costs):
+    """True for the K-vector trackers (handled element-wise), False for scalars and length-1 arrays (replaced whole)."""
+    return np.ndim(costs) > 0 and np.size(costs) != 1
 
 
 def is_done(mode, stop_fn, min_validation_costs, candidates):
-    if mode == 'real':
-        return min_validation_costs['real'] < candidates['real']
-    elif mode == 'trpo_mean':
-        assert 'trpo_mean' in min_validation_costs.keys()
-        return min_validation_costs['trpo_mean'] < candidates['trpo_mean']
-    elif mode == 'one_model':
-        return min_validation_costs['estimated'][0] < candidates['estimated'][0]
-    elif mode == 'no_early':
+    """Stop decision of model_based_rl.py:1339-1371 for one validation round: True = the new policy is worse."""
+    if mode == 'no_early':
         return False
-    else:
-        assert 'estimated' in mode
-        for _mode in min_validation_costs.keys():
-            if 'estimated' in _mode and stop_fn(min_validation_costs[_mode], candidates[_mode], mode='vector'):
-                return True
-        return False
+    if mode in ('real', 'trpo_mean'):
+        return bool(min_validation_costs[mode] < candidates[mode])
+    if mode == 'one_model':
+        return bool(min_validation_costs['estimated'][0] < candidates['estimated'][0])
+    if 'estimated' not in mode:
+        raise AssertionError("unknown early-stopping mode %r" % (mode,))
+    return any(bool(stop_fn(best, candidates[key], mode='vector'))
+               for key, best in min_validation_costs.items() if 'estimated' in key)
 
 
 def update_stats(min_validation_costs, candidates, whole=False):
-    for _mode in min_validation_costs.keys():
-        costs = min_validation_costs[_mode]
-        if hasattr(costs, '__iter__') and len(costs) != 1:
-            if whole:
-                min_validation_costs[_mode][:] = candidates[_mode][:]
-            else:
-                to_update = costs > candidates[_mode]
-                min_validation_costs[_mode][to_update] = candidates[_mode][to_update]
-        elif whole or costs > candidates[_mode]:
-            min_validation_costs[_mode] = candidates[_mode]
+    """Bookkeeping of model_based_rl.py:1403-1419: with `whole` every tracker takes the candidate; otherwise each entry keeps
+    its minimum (per model for the K-vectors, which are updated in place)."""
+    for key in list(min_validation_costs):
+        best, new = min_validation_costs[key], candidates[key]
+        if _per_model(best):
+            take = np.ones(np.shape(best), dtype=bool) if whole else np.asarray(best) > np.asarray(new)
+            best[take] = np.asarray(new)[take]
+        elif whole or best > new:
+            min_validation_costs[key] = new
 
 
 def optimize_policy(algo, validation_init, T, gamma, mode='estimated', whole=True, log_every=5,
@@ -61,6 +71,7 @@ def optimize_policy(algo, validation_init, T, gamma, mode='estimated', whole=Tru
     if reset_log_std:
         algo.policy.reset_log_std()                                        # kwargs['reset_opt'], :1119-1121
     snapshot = eng.get_policy().clone()                                    # saver.save(policy.ckpt), :1127-1129
+    # real_cost_fn must return the same value on every rank (evaluate it on rank 0 and broadcast, or on identical simulators)
     real = (lambda: float(real_cost_fn())) if real_cost_fn else (lambda: 0.0)
     est = lambda: eng.validation_cost(validation_init, T, gamma).cpu().numpy()
     min_costs = {'real': real(), 'trpo_mean': np.inf, 'estimated': est()}  # :1153-1163
@@ -76,7 +87,12 @@ def optimize_policy(algo, validation_init, T, gamma, mode='estimated', whole=Tru
                 determ = algo.obtain_samples(j, determ=True)
                 tr = determ.traj
                 comp = tr.done.flip(0).cummax(0).values.flip(0).bool()
-                candidates['trpo_mean'] = float(-(tr.rew * comp).sum().item() / max(1, int(tr.done.sum().item())))
+                # every rank must take the same stop decision (else they issue different numbers of all-reduces): the mean
+                # return is formed from the GLOBAL (sum of returns, number of paths) pair
+                pair = torch.stack([(tr.rew * comp).sum().double(), tr.done.sum().double()])
+                algo.comm.allreduce_sum_(pair)
+                pair = pair.cpu()
+                candidates['trpo_mean'] = float(-pair[0].item() / max(1.0, pair[1].item()))
             else:
                 candidates['trpo_mean'] = 0.0
             candidates['estimated'] = est()                                # :1239-1241
