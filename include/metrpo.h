@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define METRPO_ABI_VERSION 1
+#define METRPO_ABI_VERSION 2
 #define METRPO_MAX_LAYERS 6      /* hidden layers per MLP */
 
 typedef struct metrpo_ctx metrpo_ctx;
@@ -143,8 +143,33 @@ typedef struct {
     uint8_t* d_done;             /* [T][B]      done flag returned by step (incl. ts>=H, :604)   */
     int32_t* d_tpath;            /* [T][B]      0-based step index inside its path               */
     float* d_last_obs;           /* [B][ns]     state after the last step (optional, may be NULL) */
+    /* ---- continuation (ABI 2; all zero / NULL = a fresh rollout starting with vec_env.reset()) ----
+     * The reference's sampling loop `while n_samples < batch_size` (samplers/vectorized_sampler.py:60) runs an unknown number
+     * of steps when the env terminates early (Ant).  A caller issues the steps in chunks: each further chunk resumes from the
+     * d_last_* outputs of the previous one, and chunks enqueued after the stop condition was met do nothing.                   */
+    int32_t t0;                  /* global index of this call's first step: Philox counters use t0 + t, so a chunked rollout
+                                    draws exactly what one long call would; output tensors and the supplied-draw tensors are
+                                    indexed by the LOCAL step t (row 0 of d_reset_* is unused when resuming)                */
+    const float* d_init_obs;     /* [B][ns]     resume from these states instead of resetting (with d_init_ts/_model)       */
+    const int32_t* d_init_ts;    /* [B]         steps already taken in each env's current path                              */
+    const int32_t* d_init_model; /* [B]         cur_model_idx of each env (eps_rand, env_helpers.py:583,593)                */
+    int32_t* d_last_ts;          /* [B]         outputs matching d_init_* (optional; may alias the d_init_* arrays)         */
+    int32_t* d_last_model;
+    const int32_t* d_stop;       /* optional device flag: if *d_stop != 0 when the call executes, nothing is computed or
+                                    written (see metrpo_sampler_progress)                                                   */
 } metrpo_rollout_args;
 int32_t metrpo_rollout(metrpo_ctx* ctx, const metrpo_rollout_args* args, void* stream);
+
+/* Loop condition of obtain_samples (samplers/vectorized_sampler.py:60,104): n_samples counts the samples of COMPLETED paths
+ * only and is tested once per time step.  For the chunk [t0, t0+T) just rolled out (d_done, d_tpath [T][B]) this adds each
+ * step's completed-path samples, sum_b done[t][b] * (tpath[t][b] + 1), to d_state[0] in step order; the first step at which
+ * the total reaches batch_size is written to d_state[1] (global index, -1 until then) and *d_stop is set to 1.  A chunk
+ * processed while *d_stop is already 1 changes nothing.  d_state [2] float64 (caller initialises {0, -1}), d_counts [T]
+ * float64 scratch, d_stop int32 (caller zeroes).  The caller keeps steps 0..d_state[1]; paths still open there are dropped
+ * by metrpo_gae's valid mask, as the reference drops them. */
+int32_t metrpo_sampler_progress(metrpo_ctx* ctx, const uint8_t* d_done, const int32_t* d_tpath, int32_t T, int32_t B,
+                                int32_t t0, int64_t batch_size, double* d_counts, double* d_state, int32_t* d_stop,
+                                void* stream);
 
 /* build_policy_graph forward (model_based_rl.py:106-151): per model i, deterministic clipped
  * policy, model i for the whole trajectory, cost_i = sum_t gamma^t mean_b cost (Ant: masked by the

@@ -26,7 +26,10 @@ class RolloutArgs(C.Structure):
                 ('stream_offset', C.c_uint64), ('d_eps', C.c_void_p), ('d_model_idx', C.c_void_p),
                 ('d_sel_noise', C.c_void_p), ('d_reset_idx', C.c_void_p), ('d_reset_model', C.c_void_p),
                 ('d_obs', C.c_void_p), ('d_act', C.c_void_p), ('d_rew', C.c_void_p), ('d_mean', C.c_void_p),
-                ('d_done', C.c_void_p), ('d_tpath', C.c_void_p), ('d_last_obs', C.c_void_p)]
+                ('d_done', C.c_void_p), ('d_tpath', C.c_void_p), ('d_last_obs', C.c_void_p),
+                # continuation (ABI 2)
+                ('t0', C.c_int32), ('d_init_obs', C.c_void_p), ('d_init_ts', C.c_void_p), ('d_init_model', C.c_void_p),
+                ('d_last_ts', C.c_void_p), ('d_last_model', C.c_void_p), ('d_stop', C.c_void_p)]
 
 
 class Batch(C.Structure):
@@ -70,6 +73,7 @@ SYMBOLS = {
     'metrpo_policy_actions': (_I, [_P, _P, _P, _I, _P, _P, _P]),
     'metrpo_step': (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     'metrpo_rollout': (_I, [_P, C.POINTER(RolloutArgs), _P]),
+    'metrpo_sampler_progress': (_I, [_P, _P, _P, _I, _I, _I, _L, _P, _P, _P, _P]),
     'metrpo_validation_cost': (_I, [_P, _P, _I, _I, _D, _P, _P]),
     'metrpo_gae': (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _D, _D, _P, _P, _P, _P, _P]),
     'metrpo_center_advantages': (_I, [_P, _P, _P, _L, _P, _P]),
@@ -108,7 +112,7 @@ def load():
         for name, (res, args) in table.items():
             fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
             fn.restype, fn.argtypes = res, args
-    if lib.metrpo_abi_version() != 1:
+    if lib.metrpo_abi_version() != 2:
         raise ImportError("libmetrpo.so ABI version mismatch")
     return lib
 

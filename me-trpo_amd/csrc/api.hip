@@ -227,6 +227,9 @@ extern "C" int32_t metrpo_rollout(metrpo_ctx* c, const metrpo_rollout_args* a, v
     if (a->B < 0 || a->T < 0 || a->H <= 0 || a->n_pool <= 0) return set_err(c, METRPO_EINVAL, "rollout: bad B/T/H/n_pool");
     if (!a->d_pool || !a->d_obs || !a->d_act || !a->d_rew || !a->d_mean || !a->d_done || !a->d_tpath)
         return set_err(c, METRPO_ENULL, "rollout: required pointer is NULL");
+    if (a->t0 < 0) return set_err(c, METRPO_EINVAL, "rollout: t0 < 0");
+    if ((a->d_init_obs != nullptr) != (a->d_init_ts != nullptr) || (a->d_init_obs != nullptr) != (a->d_init_model != nullptr))
+        return set_err(c, METRPO_EINVAL, "rollout: d_init_obs, d_init_ts and d_init_model must be given together");
     if (a->B == 0 || a->T == 0) return METRPO_OK;
     if (c->mfma_cfg >= 0) {
         const int rc = launch_rollout_mfma(c, a, (hipStream_t)stream);
@@ -234,6 +237,15 @@ extern "C" int32_t metrpo_rollout(metrpo_ctx* c, const metrpo_rollout_args* a, v
     }
     if (gemm_path_applicable(c)) return launch_rollout_gemm(c, a, (hipStream_t)stream);     // large dynamics nets
     return launch_rollout_generic(c, a, (hipStream_t)stream);
+}
+
+extern "C" int32_t metrpo_sampler_progress(metrpo_ctx* c, const uint8_t* done, const int32_t* tpath, int32_t T, int32_t B, int32_t t0,
+                                           int64_t batch_size, double* counts, double* state, int32_t* stop, void* stream) {
+    if (!c) return METRPO_ENULL;
+    if (!done || !tpath || !counts || !state || !stop) return set_err(c, METRPO_ENULL, "sampler_progress: NULL pointer");
+    if (T < 0 || B < 0 || t0 < 0 || batch_size < 0) return set_err(c, METRPO_EINVAL, "sampler_progress: bad T/B/t0/batch_size");
+    if (T == 0 || B == 0) return METRPO_OK;
+    return launch_sampler_progress(c, done, tpath, T, B, t0, batch_size, counts, state, stop, (hipStream_t)stream);
 }
 
 // test/diagnostic hook: force the generic kernel regardless of the MFMA table

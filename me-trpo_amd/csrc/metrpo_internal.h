@@ -86,7 +86,22 @@ struct RolloutK {          // device-side copy of metrpo_rollout_args (plain poi
     const int32_t* reset_idx;
     const int32_t* reset_model;
     float* obs; float* act; float* rew; float* mean; uint8_t* done; int32_t* tpath; float* last_obs;
+    // continuation (metrpo_rollout_args ABI 2)
+    int t0; const float* init_obs; const int32_t* init_ts; const int32_t* init_model;
+    int32_t* last_ts; int32_t* last_model; const int32_t* stop;
 };
+
+static inline RolloutK make_rollout_k(const metrpo_rollout_args* a) {
+    RolloutK r;
+    r.B = a->B; r.T = a->T; r.H = a->H; r.sam_mode = a->sam_mode; r.determ = a->determ; r.eval_all = a->eval_all_heads;
+    r.n_pool = a->n_pool; r.seed = a->seed; r.stream_offset = a->stream_offset; r.pool = a->d_pool; r.eps = a->d_eps;
+    r.model_idx = a->d_model_idx; r.sel_noise = a->d_sel_noise; r.reset_idx = a->d_reset_idx;
+    r.reset_model = a->d_reset_model; r.obs = a->d_obs; r.act = a->d_act; r.rew = a->d_rew; r.mean = a->d_mean;
+    r.done = a->d_done; r.tpath = a->d_tpath; r.last_obs = a->d_last_obs;
+    r.t0 = a->t0; r.init_obs = a->d_init_obs; r.init_ts = a->d_init_ts; r.init_model = a->d_init_model;
+    r.last_ts = a->d_last_ts; r.last_model = a->d_last_model; r.stop = a->d_stop;
+    return r;
+}
 
 struct PolK {
     const float* obs; const float* act; const float* adv; const float* old_mean; const float* old_ls;
@@ -137,6 +152,7 @@ int launch_validation_cost(metrpo_ctx*, const float*, int, int, double, double*,
 int launch_gae(metrpo_ctx*, const float*, const float*, const uint8_t*, const int32_t*, int, int, const double*,
                double, double, float*, float*, uint8_t*, double*, hipStream_t);
 int launch_center(metrpo_ctx*, float*, const uint8_t*, int64_t, const double*, hipStream_t);
+int launch_sampler_progress(metrpo_ctx*, const uint8_t*, const int32_t*, int, int, int, long long, double*, double*, int32_t*, hipStream_t);
 int launch_gram(metrpo_ctx*, const float*, const float*, const int32_t*, const uint8_t*, int64_t, double*, double*,
                 hipStream_t);
 int launch_loss_grad(metrpo_ctx*, const metrpo_batch*, double*, hipStream_t);

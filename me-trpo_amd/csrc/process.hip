@@ -303,3 +303,38 @@ int launch_gram(metrpo_ctx* c, const float* obs, const float* ret, const int32_t
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Loop condition of VectorizedSampler.obtain_samples (samplers/vectorized_sampler.py:60,104) for chunked rollouts:
+// per-step completed-path sample counts, then the sequential "first step at which the total reaches batch_size" scan.
+// Counts are small integers held in float64 (exact), like the other per-iteration statistics of this file.
+__global__ void __launch_bounds__(256) k_path_counts(const uint8_t* __restrict__ done, const int32_t* __restrict__ tpath, int B,
+                                                     double* __restrict__ counts, const int32_t* __restrict__ stop) {
+    __shared__ double sh[16];
+    if (*stop != 0) return;
+    const size_t row = (size_t)blockIdx.x * B;
+    long long acc = 0;
+    for (int b = threadIdx.x; b < B; b += 256)
+        if (done[row + b]) acc += (long long)tpath[row + b] + 1;              // path length = 0-based index of its last step + 1
+    const double tot = block_sum((double)acc, sh);
+    if (threadIdx.x == 0) counts[blockIdx.x] = tot;
+}
+
+__global__ void k_stop_scan(const double* __restrict__ counts, int T, int t0, double batch_size, double* __restrict__ state,
+                            int32_t* __restrict__ stop) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || *stop != 0) return;
+    double cum = state[0];
+    for (int t = 0; t < T; ++t) {
+        cum += counts[t];
+        if (cum >= batch_size) { state[0] = cum; state[1] = (double)(t0 + t); *stop = 1; __threadfence(); return; }
+    }
+    state[0] = cum;
+}
+
+int launch_sampler_progress(metrpo_ctx* c, const uint8_t* done, const int32_t* tpath, int T, int B, int t0, long long batch_size,
+                            double* counts, double* state, int32_t* stop, hipStream_t st) {
+    hipLaunchKernelGGL(k_path_counts, dim3(T), dim3(256), 0, st, done, tpath, B, counts, stop);
+    hipLaunchKernelGGL(k_stop_scan, dim3(1), dim3(64), 0, st, counts, T, t0, (double)batch_size, state, stop);
+    HIP_TRY(c, hipGetLastError());
+    return METRPO_OK;
+}

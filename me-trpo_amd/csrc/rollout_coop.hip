@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
     const int b0 = blockIdx.x * 16, b = b0 + e;
     const bool active = b < r.B;
     const uint64_t genv = r.stream_offset + (uint64_t)b;
+    if (r.stop != nullptr && *r.stop != 0) return;           // the sampling loop already ended (metrpo_sampler_progress)
     float* ST = lds + wave * L::WV;  float* NX = ST + 16 * NS;  float* ACT = NX + 16 * NS;
     float* BD0 = lds + L::O_BD0; float* BD1 = lds + L::O_BD1; float* BD2 = lds + L::O_BD2;
     float* BP0 = lds + L::O_BP0; float* BP1 = lds + L::O_BP1; float* BP2 = lds + L::O_BP2;
@@ -108,18 +109,23 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
             dstd[cb][rr] = (dim < NS) ? norm[2 * (NS + NA) + NS + dim] : 0.0f;
         }
     // ---------------- vec_env.reset() (env_helpers.py:585-595) -------------------------------------
+    const bool resume = r.init_obs != nullptr;
     int cur_model = 0, ts = 0;
     {
         int row = 0;
-        if (active) {
+        if (active && !resume) {
             const uint4 d0 = rng_draw(r.seed, genv, 0, RNG_RESET, 0);
             row = (r.reset_idx != nullptr) ? r.reset_idx[b] : rng_index(d0.x, r.n_pool);
             cur_model = (r.reset_model != nullptr) ? r.reset_model[b] : rng_index(d0.y, K);
         }
+        if (active && resume) { cur_model = r.init_model[b]; ts = r.init_ts[b]; }      // continuation of a chunked rollout
 #pragma unroll
         for (int cb = 0; cb < OUT_CB; ++cb)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) { const int dim = 16 * cb + 4 * q + rr; if (dim < NS) ST[e * NS + dim] = r.pool[(size_t)row * NS + dim]; }
+            for (int rr = 0; rr < 4; ++rr) {
+                const int dim = 16 * cb + 4 * q + rr;
+                if (dim < NS) ST[e * NS + dim] = resume ? r.init_obs[(size_t)(active ? b : 0) * NS + dim] : r.pool[(size_t)row * NS + dim];
+            }
     }
     __syncthreads();
 
@@ -139,7 +145,7 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
     // one-step-ahead pipelining only where it fits the register budget (one Philox block per step: na <= 2)
     constexpr bool AHEAD = (NA <= 2);
     uint4 dstep = make_uint4(0, 0, 0, 0); float z[4] = {0.f, 0.f, 0.f, 0.f};
-    if (AHEAD) step_draws(0, dstep, z);
+    if (AHEAD) step_draws(r.t0, dstep, z);
     PH_DECL
     for (int t = 0; t < r.T; ++t) {
         PH_MARK(9)
@@ -192,7 +198,7 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
         }
         const f32x4 mu = m0 + m1;
         PH_MARK(0)
-        if (!AHEAD) step_draws(t, dstep, z);
+        if (!AHEAD) step_draws(r.t0 + t, dstep, z);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int d = 4 * q + rr;
@@ -249,7 +255,7 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
         auto rng_piece = [&](int i) {
             if (!AHEAD) return;
             if (i == 0) {
-                const uint32_t tt = (uint32_t)(t + 1);
+                const uint32_t tt = (uint32_t)(r.t0 + t + 1);
                 pk0 = (uint32_t)r.seed; pk1 = (uint32_t)(r.seed >> 32);
                 pc0 = make_uint4((uint32_t)genv, (uint32_t)(genv >> 32), tt, ((uint32_t)RNG_STEP << 16));
                 pc1 = make_uint4((uint32_t)genv, (uint32_t)(genv >> 32), tt, ((uint32_t)RNG_STEP << 16) | (uint32_t)(2 * q + 1));
@@ -357,7 +363,7 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
 #pragma unroll
                     for (int k = 0; k < K; ++k) { const f32x4 d = hv[k] - m; var += d * d; }
                     float zz[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (r.sel_noise == nullptr) normal4(rng_draw(r.seed, genv, t, RNG_SELNOISE, 4 * cb + q), zz);
+                    if (r.sel_noise == nullptr) normal4(rng_draw(r.seed, genv, r.t0 + t, RNG_SELNOISE, 4 * cb + q), zz);
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
                         const int dim = 16 * cb + 4 * q + rr;
@@ -462,6 +468,10 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
     if (wave == 0 && r.last_obs != nullptr) {
         const int lim = min(16, r.B - b0) * NS;
         for (int i = lane; i < lim; i += 64) r.last_obs[(size_t)b0 * NS + i] = ST[i];
+    }
+    if (wave == 0 && q == 0 && active) {
+        if (r.last_ts != nullptr) r.last_ts[b] = ts;
+        if (r.last_model != nullptr) r.last_model[b] = cur_model;
     }
 }
 

@@ -24,7 +24,11 @@ __global__ void k_big_pre(ProblemDesc pd, RolloutK r, int t, const float* __rest
     const int ns = pd.ns, na = pd.na;
     float* Sc = lds; float* A = Sc + ns * LD; float* Bq = A + pd.pol.max_width * LD;
     const uint64_t genv = r.stream_offset + (uint64_t)b;
-    if (t == 0 && active) {                                      // vec_env.reset() (env_helpers.py:585-595)
+    if (r.stop != nullptr && *r.stop != 0) return;               // the sampling loop already ended (metrpo_sampler_progress)
+    if (t == 0 && active && r.init_obs != nullptr) {             // continuation of a chunked rollout
+        st.cur_model[b] = r.init_model[b]; st.ts[b] = r.init_ts[b];
+        for (int i = 0; i < ns; ++i) st.S[(size_t)b * ns + i] = r.init_obs[(size_t)b * ns + i];
+    } else if (t == 0 && active) {                               // vec_env.reset() (env_helpers.py:585-595)
         const uint4 d0 = rng_draw(r.seed, genv, 0, RNG_RESET, 0);
         const int row = (r.reset_idx != nullptr) ? r.reset_idx[b] : rng_index(d0.x, r.n_pool);
         st.cur_model[b] = (r.reset_model != nullptr) ? r.reset_model[b] : rng_index(d0.y, pd.K);
@@ -37,7 +41,7 @@ __global__ void k_big_pre(ProblemDesc pd, RolloutK r, int t, const float* __rest
     const size_t tb = (size_t)t * r.B + b;
     const float* __restrict__ log_std = theta + pd.pol.n_params;
     const float* in_mean = norm; const float* in_std = norm + (ns + na);
-    const uint4 dstep = rng_draw(r.seed, genv, t, RNG_STEP, 0);
+    const uint4 dstep = rng_draw(r.seed, genv, r.t0 + t, RNG_STEP, 0);
     for (int i = 0; i < ns; ++i) {
         const float s = Sc[i * LD + tid];
         r.obs[tb * ns + i] = s;
@@ -46,7 +50,7 @@ __global__ void k_big_pre(ProblemDesc pd, RolloutK r, int t, const float* __rest
     for (int d0 = 0; d0 < na; d0 += 2) {
         float z[2] = {0.f, 0.f};
         if (!r.determ && r.eps == nullptr) {
-            const uint4 blk = (d0 == 0) ? dstep : rng_draw(r.seed, genv, t, RNG_STEP, d0 >> 1);
+            const uint4 blk = (d0 == 0) ? dstep : rng_draw(r.seed, genv, r.t0 + t, RNG_STEP, d0 >> 1);
             normal2(blk.x, blk.y, z[0], z[1]);
         }
         for (int d = d0; d < min(d0 + 2, na); ++d) {
@@ -76,6 +80,7 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
     const int b0 = (blockIdx.x * 4 + wave) * 16, b = b0 + c;
     const bool active = b < r.B;
     float* ST = lds + IMG + wave * 16 * NS;
+    if (r.stop != nullptr && *r.stop != 0) return;               // the sampling loop already ended (metrpo_sampler_progress)
     for (int i = tid; i < IMG; i += 256) {
         float w = 0.0f;
         const int ln = i & 63, cc = ln & 15, qq = ln >> 4;
@@ -88,7 +93,10 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
         lds[i] = w;
     }
     const uint64_t genv = r.stream_offset + (uint64_t)b;
-    if (t == 0 && active && q == 0) {                            // vec_env.reset() (env_helpers.py:585-595)
+    if (t == 0 && active && q == 0 && r.init_obs != nullptr) {   // continuation of a chunked rollout
+        st.cur_model[b] = r.init_model[b]; st.ts[b] = r.init_ts[b];
+        for (int i = 0; i < NS; ++i) st.S[(size_t)b * NS + i] = r.init_obs[(size_t)b * NS + i];
+    } else if (t == 0 && active && q == 0) {                     // vec_env.reset() (env_helpers.py:585-595)
         const uint4 d0 = rng_draw(r.seed, genv, 0, RNG_RESET, 0);
         const int row = (r.reset_idx != nullptr) ? r.reset_idx[b] : rng_index(d0.x, r.n_pool);
         st.cur_model[b] = (r.reset_model != nullptr) ? r.reset_model[b] : rng_index(d0.y, pd.K);
@@ -143,7 +151,7 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
         if (d0 >= NA) continue;
         float z[2] = {0.f, 0.f};
         if (!r.determ && r.eps == nullptr) {
-            const uint4 blk = rng_draw(r.seed, genv, t, RNG_STEP, d0 >> 1);
+            const uint4 blk = rng_draw(r.seed, genv, r.t0 + t, RNG_STEP, d0 >> 1);
             normal2(blk.x, blk.y, z[0], z[1]);
         }
 #pragma unroll
@@ -177,12 +185,12 @@ static big_pre_mfma_t big_pre_mfma_select(const ProblemDesc& pd) {
 // de-normalise + residual (training.py:257), selection (env_helpers.py:617-634), reward (:601), done (:603-604), reset (:585-595)
 __global__ void k_big_post(ProblemDesc pd, RolloutK r, int t, const float* __restrict__ norm, BigState st) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= r.B) return;
+    if (b >= r.B || (r.stop != nullptr && *r.stop != 0)) return;
     const int ns = pd.ns, na = pd.na, K = pd.K;
     const size_t tb = (size_t)t * r.B + b;
     const uint64_t genv = r.stream_offset + (uint64_t)b;
     const float* diff_mean = norm + 2 * (ns + na); const float* diff_std = diff_mean + ns;
-    const uint4 dstep = rng_draw(r.seed, genv, t, RNG_STEP, 0);
+    const uint4 dstep = rng_draw(r.seed, genv, r.t0 + t, RNG_STEP, 0);
     int sel = st.cur_model[b];
     if (r.sam_mode == METRPO_SAM_STEP_RAND) sel = (r.model_idx != nullptr) ? r.model_idx[tb] : rng_index(dstep.z, K);
     if (r.sam_mode == METRPO_SAM_ONE_MODEL) sel = 0;
@@ -209,7 +217,7 @@ __global__ void k_big_post(ProblemDesc pd, RolloutK r, int t, const float* __res
                 float z4[4];
                 float nz;
                 if (r.sel_noise != nullptr) nz = r.sel_noise[tb * ns + i];
-                else { normal4(rng_draw(r.seed, genv, t, RNG_SELNOISE, i >> 2), z4); nz = z4[i & 3]; }
+                else { normal4(rng_draw(r.seed, genv, r.t0 + t, RNG_SELNOISE, i >> 2), z4); nz = z4[i & 3]; }
                 v = fmaf(nz, sqrtf(var / (float)K), m);
             } else if (r.sam_mode == METRPO_SAM_MODEL_MED) {
                 const int r_lo = (K - 1) / 2, r_hi = K / 2;
@@ -258,7 +266,11 @@ __global__ void k_big_post(ProblemDesc pd, RolloutK r, int t, const float* __res
         for (int i = 0; i < ns; ++i) S[i] = nxt_small[i];
     }
     st.ts[b] = ts;
-    if (t == r.T - 1 && r.last_obs != nullptr) for (int i = 0; i < ns; ++i) r.last_obs[(size_t)b * ns + i] = S[i];
+    if (t == r.T - 1) {
+        if (r.last_obs != nullptr) for (int i = 0; i < ns; ++i) r.last_obs[(size_t)b * ns + i] = S[i];
+        if (r.last_ts != nullptr) r.last_ts[b] = ts;
+        if (r.last_model != nullptr) r.last_model[b] = st.cur_model[b];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -300,12 +312,7 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
     float* p = (float*)c->d_big;
     bs.S = p; p += nS; bs.X = p; p += nX; bs.U = p; p += nU; bs.HA = p; p += nH; bs.HB = p; p += nH; bs.OUT = p; p += nO; bs.PART = nP ? p : nullptr; p += nP;
     bs.ts = (int*)p; bs.cur_model = bs.ts + B;
-    RolloutK r;
-    r.B = a->B; r.T = a->T; r.H = a->H; r.sam_mode = a->sam_mode; r.determ = a->determ; r.eval_all = a->eval_all_heads;
-    r.n_pool = a->n_pool; r.seed = a->seed; r.stream_offset = a->stream_offset; r.pool = a->d_pool; r.eps = a->d_eps;
-    r.model_idx = a->d_model_idx; r.sel_noise = a->d_sel_noise; r.reset_idx = a->d_reset_idx;
-    r.reset_model = a->d_reset_model; r.obs = a->d_obs; r.act = a->d_act; r.rew = a->d_rew; r.mean = a->d_mean;
-    r.done = a->d_done; r.tpath = a->d_tpath; r.last_obs = a->d_last_obs;
+    RolloutK r = make_rollout_k(a);
     const int pbs = 64;
     const size_t psh = (size_t)(pd.ns + 2 * pd.pol.max_width) * pbs * sizeof(float);
     if (psh > 160 * 1024) return set_err(c, METRPO_EUNSUPPORTED, "policy too wide for k_big_pre");

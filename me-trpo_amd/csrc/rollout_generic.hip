@@ -172,26 +172,30 @@ __global__ void k_rollout_generic(ProblemDesc pd, RolloutK r, const float* __res
     const float* __restrict__ log_std = theta + pd.pol.n_params;
 
     // vec_env.reset(): every env draws an initial state and a cur_model_idx (env_helpers.py:585-595)
+    if (r.stop != nullptr && *r.stop != 0) return;           // the sampling loop already ended (metrpo_sampler_progress)
+    const bool resume = r.init_obs != nullptr;
     int cur_model = 0, ts = 0;
     {
         int row = 0;
-        if (active) {
+        if (active && !resume) {
             const uint4 d0 = rng_draw(r.seed, genv, 0, RNG_RESET, 0);
             row = (r.reset_idx != nullptr) ? r.reset_idx[b] : rng_index(d0.x, r.n_pool);
             cur_model = (r.reset_model != nullptr) ? r.reset_model[b] : rng_index(d0.y, K);
         }
-        for (int i = 0; i < ns; ++i) e.S[i * LD + tid] = active ? r.pool[(size_t)row * ns + i] : 0.0f;
+        if (active && resume) { cur_model = r.init_model[b]; ts = r.init_ts[b]; }      // continuation of a chunked rollout
+        const float* src = resume ? r.init_obs + (size_t)(active ? b : 0) * ns : r.pool + (size_t)row * ns;
+        for (int i = 0; i < ns; ++i) e.S[i * LD + tid] = active ? src[i] : 0.0f;
     }
 
     for (int t = 0; t < r.T; ++t) {
         const size_t tb = (size_t)t * r.B + b;
         // ---- policy.get_actions(obses) -------------------------------------------------------
         float* m = mlp_col(pd.pol, theta, e.S, e.A, e.Bq, LD, tid);
-        const uint4 dstep = rng_draw(r.seed, genv, t, RNG_STEP, 0);
+        const uint4 dstep = rng_draw(r.seed, genv, r.t0 + t, RNG_STEP, 0);
         for (int d0 = 0; d0 < na; d0 += 2) {
             float z[2] = {0.f, 0.f};
             if (!r.determ && r.eps == nullptr) {
-                const uint4 blk = (d0 == 0) ? dstep : rng_draw(r.seed, genv, t, RNG_STEP, d0 >> 1);
+                const uint4 blk = (d0 == 0) ? dstep : rng_draw(r.seed, genv, r.t0 + t, RNG_STEP, d0 >> 1);
                 normal2(blk.x, blk.y, z[0], z[1]);
             }
             for (int d = d0; d < min(d0 + 2, na); ++d) {
@@ -214,7 +218,7 @@ __global__ void k_rollout_generic(ProblemDesc pd, RolloutK r, const float* __res
         if (r.sam_mode == METRPO_SAM_MODEL_MEAN_STD) {
             for (int i0 = 0; i0 < ns; i0 += 4) {
                 float z[4] = {0.f, 0.f, 0.f, 0.f};
-                if (r.sel_noise == nullptr) normal4(rng_draw(r.seed, genv, t, RNG_SELNOISE, i0 >> 2), z);
+                if (r.sel_noise == nullptr) normal4(rng_draw(r.seed, genv, r.t0 + t, RNG_SELNOISE, i0 >> 2), z);
                 for (int i = i0; i < min(i0 + 4, ns); ++i)
                     noise_col[i * LD + tid] = (r.sel_noise != nullptr) ? (active ? r.sel_noise[tb * ns + i] : 0.0f) : z[i - i0];
             }
@@ -241,6 +245,8 @@ __global__ void k_rollout_generic(ProblemDesc pd, RolloutK r, const float* __res
     }
     if (active && r.last_obs != nullptr)
         for (int i = 0; i < ns; ++i) r.last_obs[(size_t)b * ns + i] = e.S[i * LD + tid];
+    if (active && r.last_ts != nullptr) r.last_ts[b] = ts;
+    if (active && r.last_model != nullptr) r.last_model[b] = cur_model;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -331,12 +337,7 @@ int launch_rollout_generic(metrpo_ctx* c, const metrpo_rollout_args* a, hipStrea
     int rc = pick_block(c, envbufs_floats(pd, a->sam_mode, 1), a->B, &bs, &sh);
     if (rc) return rc;
     if ((rc = allow_lds(c, k_rollout_generic, sh))) return rc;
-    RolloutK r;
-    r.B = a->B; r.T = a->T; r.H = a->H; r.sam_mode = a->sam_mode; r.determ = a->determ; r.eval_all = a->eval_all_heads;
-    r.n_pool = a->n_pool; r.seed = a->seed; r.stream_offset = a->stream_offset; r.pool = a->d_pool; r.eps = a->d_eps;
-    r.model_idx = a->d_model_idx; r.sel_noise = a->d_sel_noise; r.reset_idx = a->d_reset_idx;
-    r.reset_model = a->d_reset_model; r.obs = a->d_obs; r.act = a->d_act; r.rew = a->d_rew; r.mean = a->d_mean;
-    r.done = a->d_done; r.tpath = a->d_tpath; r.last_obs = a->d_last_obs;
+    RolloutK r = make_rollout_k(a);
     hipLaunchKernelGGL(k_rollout_generic, dim3((a->B + bs - 1) / bs), dim3(bs), sh, st, pd, r, c->d_dyn, c->d_theta,
                        c->d_norm);
     HIP_TRY(c, hipGetLastError());

@@ -31,6 +31,7 @@ __global__ void __launch_bounds__(512) k_rollout_mfma(RolloutK r, int K, const f
     const int b0 = blockIdx.x * 16, b = b0 + e;
     const bool active = b < r.B;
     const uint64_t genv = r.stream_offset + (uint64_t)b;
+    if (r.stop != nullptr && *r.stop != 0) return;           // the sampling loop already ended (metrpo_sampler_progress)
     float* W = lds + wave * C::W_TOTAL;                                  // this wave's private region
     float* ST = W + C::W_ST;  float* NX = W + C::W_NX;  float* ACT = W + C::W_ACT;
     float* NXT = lds + K * C::W_TOTAL;                                   // [2][K][16][NSP] exchange buffer
@@ -114,20 +115,22 @@ __global__ void __launch_bounds__(512) k_rollout_mfma(RolloutK r, int K, const f
         }
 
     // ---------------- vec_env.reset(): initial state + cur_model_idx (env_helpers.py:585-595) ------
+    const bool resume = r.init_obs != nullptr;
     int cur_model = 0, ts = 0;
     {
         int row = 0;
-        if (active) {
+        if (active && !resume) {
             const uint4 d0 = rng_draw(r.seed, genv, 0, RNG_RESET, 0);
             row = (r.reset_idx != nullptr) ? r.reset_idx[b] : rng_index(d0.x, r.n_pool);
             cur_model = (r.reset_model != nullptr) ? r.reset_model[b] : rng_index(d0.y, K);
         }
+        if (active && resume) { cur_model = r.init_model[b]; ts = r.init_ts[b]; }      // continuation of a chunked rollout
 #pragma unroll
         for (int cb = 0; cb < C::OUT_CB; ++cb)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int dim = 16 * cb + 4 * q + rr;
-                if (dim < NS) ST[e * NS + dim] = r.pool[(size_t)row * NS + dim];
+                if (dim < NS) ST[e * NS + dim] = resume ? r.init_obs[(size_t)(active ? b : 0) * NS + dim] : r.pool[(size_t)row * NS + dim];
             }
     }
     wave_lds_sync();
@@ -172,12 +175,12 @@ __global__ void __launch_bounds__(512) k_rollout_mfma(RolloutK r, int K, const f
             m1 = MFMA16(wp2[kk + 1], p1[(kk + 1) >> 2][(kk + 1) & 3], m1);
         }
         const f32x4 mu = m0 + m1;
-        const uint4 dstep = rng_draw(r.seed, genv, t, RNG_STEP, 0);
+        const uint4 dstep = rng_draw(r.seed, genv, r.t0 + t, RNG_STEP, 0);
         float z[4] = {0.f, 0.f, 0.f, 0.f};
         if (!r.determ && r.eps == nullptr) {            // lane q owns action dims 4q..4q+3 = chunks 2q, 2q+1 (chunk 0 = dstep)
-            const uint4 b0k = (q == 0) ? dstep : ((NA > 4) ? rng_draw(r.seed, genv, t, RNG_STEP, 2 * q) : dstep);
+            const uint4 b0k = (q == 0) ? dstep : ((NA > 4) ? rng_draw(r.seed, genv, r.t0 + t, RNG_STEP, 2 * q) : dstep);
             normal2(b0k.x, b0k.y, z[0], z[1]);
-            if (NA > 2) { const uint4 b1k = rng_draw(r.seed, genv, t, RNG_STEP, 2 * q + 1); normal2(b1k.x, b1k.y, z[2], z[3]); }
+            if (NA > 2) { const uint4 b1k = rng_draw(r.seed, genv, r.t0 + t, RNG_STEP, 2 * q + 1); normal2(b1k.x, b1k.y, z[2], z[3]); }
         }
         float su2 = 0.0f;
 #pragma unroll
@@ -270,7 +273,7 @@ __global__ void __launch_bounds__(512) k_rollout_mfma(RolloutK r, int K, const f
                     f32x4 var = {0.f, 0.f, 0.f, 0.f};
                     for (int k = 0; k < K; ++k) { const f32x4 d = *(const f32x4*)&nxt_all[(size_t)k * 16 * NSP + off] - m; var += d * d; }
                     float zz[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (r.sel_noise == nullptr) normal4(rng_draw(r.seed, genv, t, RNG_SELNOISE, 4 * cb + q), zz);
+                    if (r.sel_noise == nullptr) normal4(rng_draw(r.seed, genv, r.t0 + t, RNG_SELNOISE, 4 * cb + q), zz);
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
                         const int dim = 16 * cb + 4 * q + rr;
@@ -350,6 +353,10 @@ __global__ void __launch_bounds__(512) k_rollout_mfma(RolloutK r, int K, const f
         const int lim = min(16, r.B - b0) * NS;
         for (int i = lane; i < lim; i += 64) r.last_obs[(size_t)b0 * NS + i] = ST[i];
     }
+    if (wave == 0 && q == 0 && active) {
+        if (r.last_ts != nullptr) r.last_ts[b] = ts;
+        if (r.last_model != nullptr) r.last_model[b] = cur_model;
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -397,12 +404,7 @@ int launch_rollout_mfma(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
     if (c->mfma_cfg < 0) return METRPO_EUNSUPPORTED;
     const MfmaEntry& en = kTable[c->mfma_cfg];
     const int K = c->pd.K;
-    RolloutK r;
-    r.B = a->B; r.T = a->T; r.H = a->H; r.sam_mode = a->sam_mode; r.determ = a->determ; r.eval_all = a->eval_all_heads;
-    r.n_pool = a->n_pool; r.seed = a->seed; r.stream_offset = a->stream_offset; r.pool = a->d_pool; r.eps = a->d_eps;
-    r.model_idx = a->d_model_idx; r.sel_noise = a->d_sel_noise; r.reset_idx = a->d_reset_idx;
-    r.reset_model = a->d_reset_model; r.obs = a->d_obs; r.act = a->d_act; r.rew = a->d_rew; r.mean = a->d_mean;
-    r.done = a->d_done; r.tpath = a->d_tpath; r.last_obs = a->d_last_obs;
+    RolloutK r = make_rollout_k(a);
     if (c->coop_cfg >= 0 && c->rollout_variant == 0) return launch_rollout_coop(c, c->coop_cfg, r, st);
     size_t sh = sizeof(float) * ((size_t)K * en.w_total + 2 * (size_t)K * 16 * en.nsp);
     if (const char* ex = getenv("METRPO_EXTRA_LDS")) sh += (size_t)atoi(ex);          // occupancy experiments only

@@ -80,6 +80,7 @@ class Engine(object):
     def set_rollout_variant(self, v):
         """Test hook: 0 = fastest rollout kernel available, 1 = head-per-wave MFMA kernel.  Returns the variant that
         will run: 3 step-wise GEMM (large nets), 2 cooperative-heads MFMA, 1 head-per-wave MFMA, 0 generic."""
+        self._variant = int(v)
         return int(lib.metrpo_set_rollout_variant(self._ctx, int(v)))
 
     def set_update_path(self, use_mfma):
@@ -147,11 +148,15 @@ class Engine(object):
     # ------------------------------------------------------------------ fused rollout
     def rollout(self, B, T, H, sam_mode, pool, determ=False, eval_all_heads=True, seed=0, stream_offset=0,
                 eps=None, model_idx=None, sel_noise=None, reset_idx=None, reset_model=None, out=None,
-                force_generic=False):
+                force_generic=False, t0=0, resume=None, last_state=None, stop=None):
+        """`resume` = (obs [B,ns] f32, ts [B] i32, model [B] i32) continues a chunked rollout at global step `t0` (the supplied
+        draw tensors are then indexed from this chunk's first step); `last_state` = (ts, model) int32 output tensors;
+        `stop` = int32 device flag that turns the call into a no-op when set (metrpo_sampler_progress)."""
         dev = self.device
         # launch fast path (the bench / training loop): same buffers, same modes, production draws -> only the seed changes in the cached struct
         no_draws = eps is None and model_idx is None and sel_noise is None and reset_idx is None and reset_model is None
-        if no_draws and out is not None and not force_generic and isinstance(pool, torch.Tensor):
+        chunked = resume is not None or last_state is not None or stop is not None or t0 != 0
+        if no_draws and not chunked and out is not None and not force_generic and isinstance(pool, torch.Tensor):
             key = (id(out), pool.data_ptr(), B, T, H, sam_mode, bool(determ), bool(eval_all_heads), int(stream_offset))
             cached = getattr(self, '_ra_cache', None)
             if cached is not None and cached[0] == key:
@@ -174,12 +179,35 @@ class Engine(object):
             setattr(a, name, t.data_ptr() if t is not None else None)
         a.d_obs, a.d_act, a.d_rew, a.d_mean = out.obs.data_ptr(), out.act.data_ptr(), out.rew.data_ptr(), out.mean.data_ptr()
         a.d_done, a.d_tpath, a.d_last_obs = out.done.data_ptr(), out.tpath.data_ptr(), out.last_obs.data_ptr()
+        a.t0 = int(t0)
+        if resume is not None:
+            r_obs, r_ts, r_model = resume
+            assert r_obs.dtype == torch.float32 and r_ts.dtype == torch.int32 and r_model.dtype == torch.int32
+            assert tuple(r_obs.shape) == (B, self.ns) and r_ts.numel() == B and r_model.numel() == B
+            a.d_init_obs, a.d_init_ts, a.d_init_model = r_obs.data_ptr(), r_ts.data_ptr(), r_model.data_ptr()
+        if last_state is not None:
+            assert all(t.dtype == torch.int32 and t.numel() == B for t in last_state)
+            a.d_last_ts, a.d_last_model = last_state[0].data_ptr(), last_state[1].data_ptr()
+        if stop is not None:
+            assert stop.dtype == torch.int32
+            a.d_stop = stop.data_ptr()
         fn = lib.metrpo_rollout_generic if force_generic else lib.metrpo_rollout
         self._chk(fn(self._ctx, C.byref(a), self._stream()))
-        self._keep = (pool, eps, model_idx, sel_noise, reset_idx, reset_model)   # alive until the stream has consumed them
-        if no_draws and not force_generic:
+        self._keep = (pool, eps, model_idx, sel_noise, reset_idx, reset_model, resume, last_state, stop)   # alive until the stream has consumed them
+        if no_draws and not chunked and not force_generic:
             self._ra_cache = ((id(out), pool.data_ptr(), B, T, H, sam_mode, bool(determ), bool(eval_all_heads), int(stream_offset)), a, out, pool)
         return out
+
+    def sampler_progress(self, done, tpath, t0, batch_size, counts, state, stop):
+        """Loop condition of obtain_samples for the chunk (done, tpath [T,B]) that starts at global step t0; see metrpo.h."""
+        T, B = done.shape
+        assert counts.dtype == torch.float64 and counts.numel() >= T and state.dtype == torch.float64 and stop.dtype == torch.int32
+        self._chk(lib.metrpo_sampler_progress(self._ctx, _ptr(done), _ptr(tpath), int(T), int(B), int(t0), int(batch_size),
+                                              _ptr(counts), _ptr(state), _ptr(stop), self._stream()))
+
+    def rollout_path(self):
+        """3 step-wise GEMM (large nets), 2 cooperative-heads MFMA, 1 head-per-wave MFMA, 0 generic (current selection)."""
+        return int(lib.metrpo_set_rollout_variant(self._ctx, int(getattr(self, '_variant', 0))))
 
     def alloc_trajectory(self, B, T, H):
         dev, f = self.device, torch.float32

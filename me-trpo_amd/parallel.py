@@ -37,6 +37,11 @@ class Comm(object):
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def allreduce_min_(self, t):
+        if self.world > 1 or self.always_reduce:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+        return t
+
     def barrier(self):
         if self.world > 1:
             self.dist.barrier(group=self.group)

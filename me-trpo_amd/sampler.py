@@ -62,8 +62,10 @@ class BaseSampler(object):
         n_global = comm.world * tr.T * tr.B if static and self._uniform_B(comm, tr.B) else int(stats[2].item())
         if algo.center_adv:
             eng.center_advantages(adv, valid, stats)
-        if algo.positive_adv:
-            adv.sub_(adv.min()).add_(1e-8)                      # [rllab] util.shift_advantages_to_positive
+        if algo.positive_adv:                                   # [rllab] util.shift_advantages_to_positive, min over ALL ranks' valid samples
+            lo = torch.where(valid.bool(), adv, torch.full_like(adv, float('inf'))).min().reshape(1)
+            comm.allreduce_min_(lo)
+            adv.sub_(lo).add_(1e-8)
         AtA, Aty = eng.baseline_gram(tr.obs, ret, tr.tpath, valid)
         gram = torch.cat([AtA.reshape(-1), Aty])
         comm.allreduce_sum_(gram)
@@ -117,47 +119,93 @@ class VectorizedSampler(BaseSampler):
 
     def obtain_samples(self, itr, determ=False, draws=None):
         """Loop `while n_samples < batch_size` (:60) with n_samples counting completed paths only (:104).
-        Fixed-horizon envs: ceil(batch/(n_envs*H)) rounds of H steps in ONE launch.  Ant (early
-        termination): launches of H steps until enough completed samples exist."""
+        Fixed-horizon envs: ceil(batch/(n_envs*H)) rounds of H steps in ONE launch.  Early-terminating envs (Ant): the
+        reference tests the condition after EVERY time step, see _obtain_until_enough."""
         algo, eng = self.algo, self.algo.engine
         comm = getattr(algo, 'comm', None) or Comm()
         B, H = self._n_envs, algo.max_path_length
         nne = algo.env
         pool = nne.env.device_tensor(eng.device) if hasattr(nne.env, 'device_tensor') else \
             torch.as_tensor(np.stack([nne.env.reset() for _ in range(max(B, 1))]), dtype=torch.float32, device=eng.device)
-        rounds = max(1, -(-algo.batch_size // (B * H)))
-        T = rounds * H
-        seed = (getattr(algo, 'seed', 0) * 1000003 + itr * 7919 + (1 if determ else 0)) & 0xFFFFFFFFFFFFFFFF
+        # Philox key of this launch: a running per-sampler counter, NOT `itr` -- the outer ME-TRPO loop restarts itr at 1 every
+        # sweep (model_based_rl.py:1171) and must not replay the same noise (the reference draws from one continuing np.random)
+        seed = (getattr(algo, 'seed', 0) * 1000003 + self._itr_seed * 7919 + (1 if determ else 0)) & 0xFFFFFFFFFFFFFFFF
+        self._itr_seed += 1
         offset = comm.rank * B
         draws = draws or {}
         ev = getattr(algo, 'rollout_events', None)          # optional [(start, end)] HIP-event pairs around the launch
         if ev is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        out = None
-        if getattr(algo, 'reuse_trajectory_buffers', False):      # opt-in: later rollouts overwrite earlier DevicePaths
-            key = (B, T, H)
-            if getattr(self, '_traj_key', None) != key:
-                self._traj_buf, self._traj_key = eng.alloc_trajectory(B, T, H), key
-            out = self._traj_buf
-        traj = eng.rollout(B, T, H, nne.sam_mode, pool, determ=determ, eval_all_heads=getattr(algo, 'eval_all_heads', True),
-                           seed=seed, stream_offset=offset, out=out, **draws)
+        common = dict(determ=determ, eval_all_heads=getattr(algo, 'eval_all_heads', True), seed=seed, stream_offset=offset)
+        if eng.env_name == 'ant':
+            traj = self._obtain_until_enough(B, H, nne.sam_mode, pool, draws, common)
+        else:
+            rounds = max(1, -(-algo.batch_size // (B * H)))
+            T = rounds * H
+            out = None
+            if getattr(algo, 'reuse_trajectory_buffers', False):      # opt-in: later rollouts overwrite earlier DevicePaths
+                key = (B, T, H)
+                if getattr(self, '_traj_key', None) != key:
+                    self._traj_buf, self._traj_key = eng.alloc_trajectory(B, T, H), key
+                out = self._traj_buf
+            traj = eng.rollout(B, T, H, nne.sam_mode, pool, out=out, **common, **draws)
         if ev is not None:
             e1.record()
             ev.append((e0, e1))
-        if eng.env_name == 'ant' and not draws:
-            # keep stepping in chunks of H until the completed-path sample count reaches batch_size
-            while True:
-                n_done = self._completed_samples(traj)
-                if n_done >= algo.batch_size or traj.T >= 64 * H:
-                    break
-                T2 = traj.T + H
-                traj = eng.rollout(B, T2, H, nne.sam_mode, pool, determ=determ, seed=seed, stream_offset=offset)
         log_std = algo.policy.log_std()
         return DevicePaths(traj, log_std, None)
 
-    @staticmethod
-    def _completed_samples(traj):
-        done = traj.done.to(torch.int32)
-        last = (done * torch.arange(1, traj.T + 1, device=done.device, dtype=torch.int32)[:, None]).max(dim=0).values
-        return int(last.sum().item())
+    def _obtain_until_enough(self, B, H, sam_mode, pool, draws, common):
+        """Early-terminating envs.  The reference steps all envs once, adds the lengths of the paths that just completed to
+        n_samples and stops as soon as n_samples >= batch_size (vectorized_sampler.py:60,104); paths still open are dropped.
+        Completed samples after t steps lie in (B*(t-H), B*t], so the stop step t* is in [ceil(batch/B), ceil(batch/B)+H):
+        the first ceil(batch/B) steps are one launch, then chunks CONTINUE from the previous chunk's end state (same Philox
+        streams as one long launch: counters use the global step).  metrpo_sampler_progress evaluates the loop condition on
+        the device after every chunk and raises a flag that turns the chunks already enqueued behind it into no-ops, so
+        there is no host round trip inside the loop (large-net rollouts, where a chunk is tens of ms of GEMMs, poll the flag
+        instead of enqueuing dead GEMMs).  One read-back of t* at the end; the returned tensors are the [0, t*] prefix views.
+        In sharded runs each rank applies the rule to its own envs and its own batch_size share (no collective)."""
+        algo, eng = self.algo, self.algo.engine
+        dev = eng.device
+        batch = int(algo.batch_size)
+        T_first = max(1, -(-batch // B))
+        T_max = T_first + H
+        chunk = max(1, int(getattr(algo, 'sampler_chunk', max(8, H // 8))))
+        key = (B, T_max, H)
+        if getattr(self, '_ant_key', None) != key or not getattr(algo, 'reuse_trajectory_buffers', False):
+            self._ant_buf, self._ant_key = eng.alloc_trajectory(B, T_max, H), key
+            self._ant_state = (torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev))
+            self._ant_counts = torch.empty(max(T_first, chunk), dtype=torch.float64, device=dev)
+        buf, (last_ts, last_model) = self._ant_buf, self._ant_state
+        state = torch.tensor([0.0, -1.0], dtype=torch.float64, device=dev)
+        stop = torch.zeros(1, dtype=torch.int32, device=dev)
+        poll = eng.rollout_path() == 3
+
+        def view(t_lo, t_hi):
+            from .engine import Trajectory
+            return Trajectory(buf.obs[t_lo:t_hi], buf.act[t_lo:t_hi], buf.rew[t_lo:t_hi], buf.mean[t_lo:t_hi], buf.done[t_lo:t_hi],
+                              buf.tpath[t_lo:t_hi], buf.last_obs, B, t_hi - t_lo, H)
+
+        def chunk_draws(t_lo, t_hi):
+            d = {}
+            for k, v in draws.items():
+                if v is not None:
+                    d[k] = v[t_lo:t_hi + 1] if k in ('reset_idx', 'reset_model') else v[t_lo:t_hi]
+            return d
+
+        t = 0
+        while t < T_max:
+            t_hi = min(T_max, t + (T_first if t == 0 else chunk))
+            out = view(t, t_hi)
+            eng.rollout(B, t_hi - t, H, sam_mode, pool, out=out, t0=t, last_state=(last_ts, last_model), stop=stop,
+                        resume=None if t == 0 else (buf.last_obs, last_ts, last_model), **common, **chunk_draws(t, t_hi))
+            eng.sampler_progress(out.done, out.tpath, t, batch, self._ant_counts, state, stop)
+            t = t_hi
+            if poll and t < T_max and int(stop.item()):
+                break
+        t_stop = int(state[1].item())
+        if t_stop < 0:
+            raise RuntimeError("obtain_samples: %d completed samples < batch_size %d after %d steps (draws too short?)"
+                               % (int(state[0].item()), batch, t))
+        return view(0, t_stop + 1)

@@ -74,3 +74,55 @@ def paths_from_timemajor(tr):
                                   _tb=[(tt, b) for tt in range(start[b], t + 1)]))
                 start[b] = t + 1
     return paths
+
+
+def reference_sampler_draws(d, T_pad=0):
+    """Turn the np.random stream the REFERENCE's VectorizedSampler consumed (recorded in a sampler_*.npz golden) into the
+    explicit per-step draw tensors of metrpo_rollout.  The stream's call pattern is fixed by the reference's code
+    (env_helpers.py:583 initial cur_model_idx; :590-593 one randint per reset env in index order; policy noise per step;
+    :619 step_rand indices or :626 mean_std noise), but WHICH envs reset depends on the simulated dones, so the pinned oracle
+    replays the run once to supply them.  The pool is handed out sequentially (make_golden.PoolEnv).  Returns (draws, n_steps)."""
+    from conftest import ReplayRNG, dm_from_golden, PoolReset
+    env, sam_mode = str(d['env']), str(d['sam_mode'])
+    dm = dm_from_golden(d, env)
+    K, B, H = int(d['K']), int(d['B']), int(d['H'])
+    theta, pdims = d['theta'], [int(x) for x in d['pdims']]
+    rng = ReplayRNG(d['rng_kinds'], d['rng_offs'], d['rng_flat'])
+    log = []                                                       # every value the reference drew, in order
+
+    class Rec(object):
+        def randint(self, high, size=None):
+            v = rng.randint(high, size=size); log.append(np.array(v)); return v
+
+        def normal(self, size=None):
+            v = rng.normal(size=size); log.append(np.array(v)); return v
+    rec = Rec()
+    ve = O.VecEnvOracle(env, lambda s, a: O.dynamics_forward_all(dm, s, a), K, B, dm.ns, H, sam_mode, PoolReset(d['pool']), rng=rec)
+    dones = []
+    orig_step = ve.step
+    ve.step = lambda a: (lambda out: (dones.append(np.array(out[2])), out)[1])(orig_step(a))
+    O.obtain_samples(ve, lambda obs: O.policy_get_actions(theta, pdims, np.asarray(obs), rec.normal(size=(len(obs), pdims[-1]))),
+                     int(d['batch_size']), determ=bool(d['determ']))
+    assert rng.exhausted()
+    T = len(dones)
+    Tp = T + T_pad
+    n_pool = len(d['pool'])
+    dr = dict(eps=np.zeros((Tp, B, dm.na)), model_idx=np.zeros((Tp, B), np.int64), sel_noise=np.zeros((Tp, B, dm.ns)),
+              reset_idx=np.zeros((Tp + 1, B), np.int64), reset_model=np.zeros((Tp + 1, B), np.int64))
+    it = iter(log)
+    next(it)                                                       # env_helpers.py:583 (overwritten by the first reset)
+    pool_i = 0
+    for b in range(B):
+        dr['reset_idx'][0, b] = pool_i % n_pool; pool_i += 1
+        dr['reset_model'][0, b] = int(next(it))
+    for t in range(T):
+        dr['eps'][t] = next(it)
+        if sam_mode == 'step_rand':
+            dr['model_idx'][t] = next(it)
+        elif sam_mode == 'model_mean_std':
+            dr['sel_noise'][t] = next(it)
+        for b in np.nonzero(dones[t])[0]:
+            dr['reset_idx'][t + 1, b] = pool_i % n_pool; pool_i += 1
+            dr['reset_model'][t + 1, b] = int(next(it))
+    assert next(it, None) is None
+    return dr, T

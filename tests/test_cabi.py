@@ -25,14 +25,14 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(_lib.lib, n), "libmetrpo.so does not export %s" % n
         assert n in _lib.SYMBOLS, "%s is declared in metrpo.h but not bound in _lib.SYMBOLS" % n
     assert set(_lib.SYMBOLS) == set(names)
-    assert _lib.lib.metrpo_abi_version() == 1
+    assert _lib.lib.metrpo_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
     from metrpo_amd import _lib
     # sizes implied by the C declarations (LP64): see include/metrpo.h
     assert C.sizeof(_lib.Dims) == 4 * (4 + 1 + 6 + 6 + 1 + 1 + 6)
-    assert C.sizeof(_lib.RolloutArgs) == 6 * 4 + 8 + 4 + 4 + 8 + 8 + 5 * 8 + 7 * 8
+    assert C.sizeof(_lib.RolloutArgs) == 6 * 4 + 8 + 4 + 4 + 8 + 8 + 5 * 8 + 7 * 8 + (4 + 4 + 6 * 8)
     assert C.sizeof(_lib.Batch) == 5 * 8 + 4 + 4 + 8 + 8 + 8
     assert C.sizeof(_lib.TrpoParams) == 8 + 4 + 4 + 8 + 8 + 4 + 4 + 8 + 8 + 8
     assert C.sizeof(_lib.TrpoDiag) == 4 * 8 + 3 * 4 + 4

@@ -46,7 +46,7 @@ def test_step_parity(env, sam_mode):
     assert np.array_equal(cpu(done).astype(bool)[~near], ref_done[~near])
 
 
-@pytest.mark.parametrize('name', ['vecenv_swimmer_step_rand', 'vecenv_ant_step_rand', 'vecenv_swimmer_model_med',
+@pytest.mark.parametrize('name', ['vecenv_swimmer_step_rand', 'vecenv_ant_step_rand', 'vecenv_ant_eps_rand', 'vecenv_swimmer_model_med',
                                   'vecenv_swimmer_model_mean_std', 'vecenv_swimmer_eps_rand', 'vecenv_swimmer_one_model',
                                   'vecenv_swimmer_model_mean'])
 def test_step_against_reference_golden(name):

@@ -1,0 +1,90 @@
+"""Full-size runs of BASELINE.json's configs (C1 whole, C2/C3/C4 at their per-GPU share) checked through size-independent
+properties: path/done structure, step indices, reward recomputed from the stored (obs, action) of the next step where the
+path continues, bitwise repeatability of rollout and update, TRPO invariants (accepted => loss decreased and KL <= delta),
+centred advantages, Ant's step-granular stop rule."""
+import numpy as np
+import pytest
+import torch
+from oracle import metrpo_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    # name: env, K, dyn hidden, policy hidden, B (per GPU), H
+    'C1': ('swimmer', 5, (64, 64), (32, 32), 5000, 100),
+    'C2': ('half_cheetah', 5, (1024, 1024), (32, 32), 2500, 200),
+    'C2-2x64': ('half_cheetah', 5, (64, 64), (32, 32), 2500, 200),
+    'C3': ('ant', 10, (512, 512), (32, 32), 2500, 500),
+    'C4': ('humanoid', 20, (1024, 1024, 1024), (100, 50, 25), 6250, 1000),
+}
+
+
+def build(name, seed=0):
+    import metrpo_amd
+    env, K, dh, ph, B, H = CONFIGS[name]
+    dm, theta, pdims, pool = O.make_problem(env, K=K, dyn_hidden=dh, pol_hidden=ph, seed=seed, n_pool=4096, dtype=np.float32)
+    eng = metrpo_amd.Engine(env, K, dh, ph)
+    eng.set_dynamics_layers(dm.Ws, dm.bs, dm.in_mean, dm.in_std, dm.diff_mean, dm.diff_std)
+    policy = metrpo_amd.GaussianMLPPolicy(eng, init_std=1.0, seed=seed)
+    eng.set_policy(theta)
+    nne = metrpo_amd.NeuralNetEnv(env=metrpo_amd.InitStatePool(pool, dm.na), inner_env=None, cost_np=env, dynamics_in=None,
+                                  dynamics_outs=eng, sam_mode='step_rand')
+    algo = metrpo_amd.TRPO(env=nne, policy=policy, baseline=metrpo_amd.LinearFeatureBaseline(), batch_size=B * H, max_path_length=H,
+                           discount=1.0, gae_lambda=1.0, step_size=0.01, sampler_args=dict(n_envs=B), seed=3)
+    return algo, eng, dm, theta
+
+
+@pytest.mark.parametrize('name', list(CONFIGS))
+def test_full_size_iteration_properties(name):
+    env, K, dh, ph, B, H = CONFIGS[name]
+    algo, eng, dm, theta = build(name)
+    algo.start_worker()
+    paths = algo.obtain_samples(0)
+    tr = paths.traj
+    T = tr.T
+    done, tpath = tr.done.bool(), tr.tpath.long()
+    # --- step indices and done structure
+    assert int(tpath.min()) == 0 and int(tpath.max()) <= H - 1
+    assert bool((tpath[0] == 0).all())
+    cont = ~done[:-1]
+    assert bool((tpath[1:][cont] == tpath[:-1][cont] + 1).all()) and bool((tpath[1:][~cont] == 0).all())
+    assert bool(done[tpath == H - 1].all())                               # horizon reached => done (env_helpers.py:604)
+    if env != 'ant':
+        assert T == H and bool(done[-1].all()) and int(done.sum()) == B   # every path has length H
+    else:
+        lens = (done * (tpath + 1)).sum(dim=1).cumsum(0)                   # completed-path samples after each step
+        assert int(lens[-1]) >= B * H and int(lens[-2]) < B * H           # vectorized_sampler.py:60,104
+        assert int((done & (tpath < H - 1)).sum()) > 0                    # early terminations happened
+        assert H <= T < 2 * H
+    # --- continuing steps: next stored observation is a state whose reward we can recompute from (action, next obs)
+    ns = eng.ns
+    t_s = torch.randint(0, T - 1, (2000,), device=eng.device); b_s = torch.randint(0, B, (2000,), device=eng.device)
+    keep = ~done[t_s, b_s]
+    t_s, b_s = t_s[keep], b_s[keep]
+    xn = tr.obs[t_s + 1, b_s].double().cpu().numpy(); x = tr.obs[t_s, b_s].double().cpu().numpy()
+    u = np.clip(tr.act[t_s, b_s].double().cpu().numpy(), -1, 1)
+    np.testing.assert_allclose(tr.rew[t_s, b_s].double().cpu().numpy(), -O.cost_np_vec(env, x, u, xn), rtol=1e-5, atol=2e-5)
+    assert bool(torch.isfinite(tr.obs).all()) and bool(torch.isfinite(tr.rew).all())
+    # --- bitwise repeat of the rollout (same launch counter -> same Philox key)
+    algo.sampler._itr_seed -= 1
+    again = algo.obtain_samples(0).traj
+    assert again.T == T and torch.equal(again.obs, tr.obs) and torch.equal(again.rew, tr.rew) and torch.equal(again.done, tr.done)
+    del again
+    # --- process_samples + TRPO update
+    samples = algo.process_samples(0, paths)
+    v = samples['valids'].bool()
+    adv = samples['advantages'][v].double()
+    assert abs(float(adv.mean())) < 1e-4 and abs(float(adv.std(unbiased=False)) - 1.0) < 1e-3
+    assert int(v.sum()) == samples['n_valid_global']
+    theta0 = eng.get_policy().clone()
+    batch = eng.make_batch(samples['observations'], samples['actions'], samples['advantages'], samples['agent_infos']['mean'],
+                           samples['agent_infos']['log_std'], valid=samples['valids'], n_global=samples['n_valid_global'])
+    out = eng.trpo_update(batch)
+    theta1 = eng.get_policy().clone()
+    assert np.isfinite(out['loss_before']) and out['accepted']
+    assert out['loss'] < out['loss_before'] and out['kl'] <= 0.01 + 1e-9
+    lk = eng.loss_kl(batch).cpu().numpy()                                  # independent re-evaluation at the accepted theta
+    np.testing.assert_allclose(lk, [out['loss'], out['kl']], rtol=1e-6, atol=1e-9)
+    eng.set_policy(theta0)
+    out2 = eng.trpo_update(batch)
+    assert torch.equal(eng.get_policy(), theta1) and out2['n_backtrack'] == out['n_backtrack']      # bitwise repeat of the update
