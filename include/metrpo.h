@@ -237,6 +237,9 @@ typedef struct {
     double residual_tol;         /* 1e-10 ([rllab] krylov.cg)                                    */
     metrpo_allreduce_fn allreduce;
     void* allreduce_user;
+    int32_t explicit_final_hvp;  /* 0 (default): d.(H d) of the step scale is taken from the CG recurrence (H d = g - r, the
+                                    identity krylov.cg maintains); 1: evaluate f_Hx(descent_direction) once more, as [rllab]
+                                    ConjugateGradientOptimizer.optimize literally does.  Same value up to float32 rounding   */
 } metrpo_trpo_params;
 
 typedef struct {                 /* host-side diagnostics of one optimize() call                 */

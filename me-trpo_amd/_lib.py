@@ -44,7 +44,8 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_voi
 class TrpoParams(C.Structure):
     _fields_ = [('max_kl', C.c_double), ('cg_iters', C.c_int32), ('reg_coeff', C.c_double),
                 ('backtrack_ratio', C.c_double), ('max_backtracks', C.c_int32), ('accept_violation', C.c_int32),
-                ('residual_tol', C.c_double), ('allreduce', ALLREDUCE_FN), ('allreduce_user', C.c_void_p)]
+                ('residual_tol', C.c_double), ('allreduce', ALLREDUCE_FN), ('allreduce_user', C.c_void_p),
+                ('explicit_final_hvp', C.c_int32)]
 
 
 class TrainParams(C.Structure):

@@ -401,19 +401,17 @@ extern "C" int32_t metrpo_rms_accumulate(metrpo_ctx* c, const float* x, int64_t 
 // ------------------------------------------------------------------------------------------------
 __global__ void k_cg_init(int P, const double* __restrict__ gout, double* x, double* r, double* p, float* pf, double* scal) {
     __shared__ double sh[16];
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < P; i += blockDim.x) {
-        const double g = gout[1 + i];
-        x[i] = 0.0; r[i] = g; p[i] = g; pf[i] = (float)g;
-        acc += g * g;
-    }
-    const double rdotr = blk_sum(acc, sh);
-    if (threadIdx.x == 0) { scal[S_RDOTR] = rdotr; scal[S_DONE] = 0.0; scal[S_ITERS] = 0.0; }
+    cg_init_body(P, gout, x, r, p, pf, scal, sh);
 }
 
-__global__ void k_cg_step(int P, double reg, double tol, int last, double* x, double* r, double* p, double* z, float* pf, double* scal) {
+__global__ void k_cg_step(CgTail t, int) {
     __shared__ double sh[16];
-    cg_step_body(P, reg, tol, last, x, r, p, z, pf, scal, sh);
+    cg_tail_run(t, sh);
+}
+
+__global__ void k_cg_finish_implicit(int P, double max_kl, const double* x, const double* r, const double* gout, double* step, double* scal) {
+    __shared__ double sh[16];
+    cg_finish_implicit(P, max_kl, x, r, gout + 1, step, scal, sh);
 }
 
 __global__ void k_cg_finish(int P, double reg, double max_kl, const double* x, double* z, double* step, double* scal) {
@@ -438,32 +436,39 @@ int run_trpo_update(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_para
     int rc;
 #define AR(buf, n) do { if (pr->allreduce && (rc = pr->allreduce(pr->allreduce_user, (buf), (n), (void*)st)) != 0) \
                             return set_err(c, METRPO_EINVAL, "allreduce callback failed"); } while (0)
-    if ((rc = launch_loss_grad(c, b, v.gout, st))) return rc;
-    AR(v.gout, 1 + P);
+    // krylov.cg with every vector step fused into the tail of the kernel that produced its input (no all-reduce in between) or
+    // as stand-alone one-block kernels after the caller's all-reduce.  The step scale needs d.(H d): by default it is taken
+    // from the CG recurrence (cg_device.h: A x = g - r), explicit_final_hvp = 1 spends the extra FVP rllab spends.
+    const bool fused = (pr->allreduce == nullptr);
+    const int implicit_hd = pr->explicit_final_hvp ? 0 : 1;
+    CgTail tl; tl.P = P; tl.last = 0; tl.implicit_hd = implicit_hd; tl.reg = pr->reg_coeff; tl.tol = pr->residual_tol; tl.max_kl = pr->max_kl;
+    tl.x = v.x; tl.r = v.r; tl.p = v.p; tl.z = v.z; tl.step = v.step; tl.scal = v.scal; tl.gout = v.gout; tl.pf = c->d_vf; tl.ticket = c->d_ticket;
     HIP_TRY(c, hipMemsetAsync(c->d_ticket, 0, sizeof(unsigned int), st));
-    hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(256), 0, st, P, v.gout, v.x, v.r, v.p, c->d_vf, v.scal);
-    if (pr->cg_iters == 0) { hipLaunchKernelGGL(k_zero_f, dim3((P + 255) / 256), dim3(256), 0, st, c->d_vf, P); }
+    tl.op = 3;
+    if ((rc = launch_loss_grad(c, b, v.gout, st, fused ? &tl : nullptr))) return rc;
+    if (!fused) {
+        AR(v.gout, 1 + P);
+        hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(256), 0, st, P, v.gout, v.x, v.r, v.p, c->d_vf, v.scal);
+    }
+    if (pr->cg_iters == 0) {
+        hipLaunchKernelGGL(k_zero_f, dim3((P + 255) / 256), dim3(256), 0, st, c->d_vf, P);
+        hipLaunchKernelGGL(k_cg_finish_implicit, dim3(1), dim3(1024), 0, st, P, pr->max_kl, v.x, v.r, v.gout, v.step, v.scal);
+    }
     for (int i = 0; i < pr->cg_iters; ++i) {
-        const int lastit = (i == pr->cg_iters - 1) ? 1 : 0;
-        if (!pr->allreduce) {                                   // no exchange between the FVP reduction and the CG step: fuse them
-            CgTail tl; tl.op = 1; tl.P = P; tl.last = lastit; tl.reg = pr->reg_coeff; tl.tol = pr->residual_tol; tl.max_kl = pr->max_kl;
-            tl.x = v.x; tl.r = v.r; tl.p = v.p; tl.z = v.z; tl.step = v.step; tl.scal = v.scal; tl.pf = c->d_vf; tl.ticket = c->d_ticket;
-            if ((rc = launch_fvp_tail(c, b, c->d_vf, v.p, v.z, &tl, st))) return rc;
-            continue;
-        }
+        tl.op = 1; tl.last = (i == pr->cg_iters - 1) ? 1 : 0;
+        if (fused) { if ((rc = launch_fvp_tail(c, b, c->d_vf, v.p, v.z, &tl, st))) return rc; continue; }
         if ((rc = launch_fvp_f32(c, b, c->d_vf, v.p, v.z, st))) return rc;
         AR(v.z, P);
-        hipLaunchKernelGGL(k_cg_step, dim3(1), dim3(1024), 0, st, P, pr->reg_coeff, pr->residual_tol, lastit,
-                           v.x, v.r, v.p, v.z, c->d_vf, v.scal);
+        hipLaunchKernelGGL(k_cg_step, dim3(1), dim3(1024), 0, st, tl, pr->cg_iters);
     }
-    if (!pr->allreduce) {
-        CgTail tl; tl.op = 2; tl.P = P; tl.last = 0; tl.reg = pr->reg_coeff; tl.tol = pr->residual_tol; tl.max_kl = pr->max_kl;
-        tl.x = v.x; tl.r = v.r; tl.p = v.p; tl.z = v.z; tl.step = v.step; tl.scal = v.scal; tl.pf = c->d_vf; tl.ticket = c->d_ticket;
-        if ((rc = launch_fvp_tail(c, b, c->d_vf, v.x, v.z, &tl, st))) return rc;
-    } else {
-    if ((rc = launch_fvp_f32(c, b, c->d_vf, v.x, v.z, st))) return rc;
-    AR(v.z, P);
-    hipLaunchKernelGGL(k_cg_finish, dim3(1), dim3(1024), 0, st, P, pr->reg_coeff, pr->max_kl, v.x, v.z, v.step, v.scal);
+    if (!implicit_hd && pr->cg_iters > 0) {                      // rllab's literal route: one more f_Hx on the descent direction
+        tl.op = 2; tl.last = 0;
+        if (fused) { if ((rc = launch_fvp_tail(c, b, c->d_vf, v.x, v.z, &tl, st))) return rc; }
+        else {
+            if ((rc = launch_fvp_f32(c, b, c->d_vf, v.x, v.z, st))) return rc;
+            AR(v.z, P);
+            hipLaunchKernelGGL(k_cg_finish, dim3(1), dim3(1024), 0, st, P, pr->reg_coeff, pr->max_kl, v.x, v.z, v.step, v.scal);
+        }
     }
     if (g_out) HIP_TRY(c, hipMemcpyAsync(g_out, v.gout + 1, sizeof(double) * P, hipMemcpyDeviceToDevice, st));
     if (dir_out) HIP_TRY(c, hipMemcpyAsync(dir_out, v.x, sizeof(double) * P, hipMemcpyDeviceToDevice, st));

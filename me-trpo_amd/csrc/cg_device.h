@@ -8,13 +8,18 @@
 enum { S_RDOTR = 0, S_DONE = 1, S_BETA = 2, S_XHX = 3, S_ITERS = 4 };
 
 struct CgTail {
-    int op;                 // 0 none, 1 = CG iteration, 2 = step-size finish
-    int P, last;
+    int op;                 // 0 none, 1 = CG iteration, 2 = step-size finish from an explicit H.d, 3 = CG initialisation from the gradient
+    int P, last;            // last: final CG iteration; with `implicit_hd` it also finishes (step = beta * x) from the CG recurrence
+    int implicit_hd;
     double reg, tol, max_kl;
     double *x, *r, *p, *z, *step, *scal;
+    const double* gout;     // [1 + P]: loss, gradient (b of the solve)
     float* pf;
     unsigned int* ticket;   // zeroed by the driver before every CG solve; the last block resets it
 };
+
+// r, p <- g; x <- 0; pf <- (float) g   (krylov.cg prologue)
+__device__ __forceinline__ void cg_init_body(int P, const double* gout, double* x, double* r, double* p, float* pf, double* scal, double* sh);
 
 __device__ __forceinline__ double blk_sum(double v, double* sh) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -28,6 +33,33 @@ __device__ __forceinline__ double blk_sum(double v, double* sh) {
     return r;
 }
 
+// d . (H + reg I) d without another Fisher-vector product.  krylov.cg keeps r = b - A x as a recurrence (r -= v * A p with the
+// very z = A p the FVP kernels returned), so A x = g - r holds to float64 rounding and
+//     initial_step_size = sqrt(2 max_kl / (x . A x + 1e-8)),  x . A x = x . (g - r)
+// is the quantity [rllab] ConjugateGradientOptimizer.optimize obtains from an 11th f_Hx(descent_direction) call.  Both carry the
+// float32 rounding of the FVPs (relative 1e-6); tests/test_gpu_engine.py compares the two routes.
+__device__ __forceinline__ void cg_finish_implicit(int P, double max_kl, const double* x, const double* r, const double* g,
+                                                   double* step, double* scal, double* sh) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) acc += x[i] * (g[i] - r[i]);
+    const double xhx = blk_sum(acc, sh);
+    double beta = sqrt(2.0 * max_kl * (1.0 / (xhx + 1e-8)));
+    if (isnan(beta)) beta = 1.0;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) step[i] = beta * x[i];
+    if (threadIdx.x == 0) { scal[S_BETA] = beta; scal[S_XHX] = xhx; }
+}
+
+__device__ __forceinline__ void cg_init_body(int P, const double* gout, double* x, double* r, double* p, float* pf, double* scal, double* sh) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        const double g = gout[1 + i];
+        x[i] = 0.0; r[i] = g; p[i] = g; pf[i] = (float)g;
+        acc += g * g;
+    }
+    const double rdotr = blk_sum(acc, sh);
+    if (threadIdx.x == 0) { scal[S_RDOTR] = rdotr; scal[S_DONE] = 0.0; scal[S_ITERS] = 0.0; }
+}
+
 // one krylov.cg iteration after z = f_Ax(p) has been formed (z lacks the reg term: added here)
 __device__ __forceinline__ void cg_step_body(int P, double reg, double tol, int last, double* x, double* r, double* p, double* z,
                                              float* pf, double* scal, double* sh) {
@@ -37,7 +69,7 @@ __device__ __forceinline__ void cg_step_body(int P, double reg, double tol, int 
     }
     const double rdotr = scal[S_RDOTR];
     // every vector element is read ONCE (one global round trip) and kept in registers across the two reductions: element i = tid + j*blockDim
-    constexpr int CG_R = 4;
+    constexpr int CG_R = 2;          // register-resident fast path: P <= 2 * blockDim (stand-alone k_cg_step with 1024 threads)
     if (P <= CG_R * (int)blockDim.x) {
         double pv[CG_R], zv[CG_R], rv[CG_R], xv[CG_R];
         double acc = 0.0;
@@ -107,4 +139,16 @@ __device__ __forceinline__ void cg_finish_body(int P, double reg, double max_kl,
     if (isnan(beta)) beta = 1.0;
     for (int i = threadIdx.x; i < P; i += blockDim.x) step[i] = beta * x[i];
     if (threadIdx.x == 0) { scal[S_BETA] = beta; scal[S_XHX] = xhx; }
+}
+
+// CG tail dispatch shared by k_finalize and the in-kernel reduction of policy_mfma.hip (one block, all threads)
+__device__ __forceinline__ void cg_tail_run(const CgTail& t, double* sh) {
+    if (t.op == 1) {
+        cg_step_body(t.P, t.reg, t.tol, t.last, t.x, t.r, t.p, t.z, t.pf, t.scal, sh);
+        if (t.last && t.implicit_hd) {
+            __syncthreads();
+            cg_finish_implicit(t.P, t.max_kl, t.x, t.r, t.gout + 1, t.step, t.scal, sh);
+        }
+    } else if (t.op == 2) cg_finish_body(t.P, t.reg, t.max_kl, t.x, t.z, t.step, t.scal, sh);
+    else if (t.op == 3) cg_init_body(t.P, t.gout, t.x, t.r, t.p, t.pf, t.scal, sh);
 }

@@ -111,6 +111,7 @@ struct PolK {
 };
 
 int policy_mfma_select(const ProblemDesc& pd);
+struct CgTail;
 int policy_mfma_launch(metrpo_ctx*, int idx, int mode, const metrpo_batch*, const float* theta, const float* v,
                        float* partials, int nblocks, hipStream_t);
 
@@ -155,11 +156,10 @@ int launch_center(metrpo_ctx*, float*, const uint8_t*, int64_t, const double*, h
 int launch_sampler_progress(metrpo_ctx*, const uint8_t*, const int32_t*, int, int, int, long long, double*, double*, int32_t*, hipStream_t);
 int launch_gram(metrpo_ctx*, const float*, const float*, const int32_t*, const uint8_t*, int64_t, double*, double*,
                 hipStream_t);
-int launch_loss_grad(metrpo_ctx*, const metrpo_batch*, double*, hipStream_t);
+int launch_loss_grad(metrpo_ctx*, const metrpo_batch*, double*, hipStream_t, const CgTail* tail = nullptr);
 int launch_fvp(metrpo_ctx*, const metrpo_batch*, const double*, double*, hipStream_t);
 // vf = float copy of v already on the device (skips the conversion launch); v is still needed for the log_std rows
 int launch_fvp_f32(metrpo_ctx*, const metrpo_batch*, const float* vf, const double* v, double* hv, hipStream_t);
-struct CgTail;
 // FVP + reduction + (in the reduction kernel's last block) the CG vector step described by `tail`
 int launch_fvp_tail(metrpo_ctx*, const metrpo_batch*, const float* vf, const double* v, double* hv, const CgTail* tail, hipStream_t);
 int launch_loss_kl(metrpo_ctx*, const metrpo_batch*, const float*, double*, hipStream_t);

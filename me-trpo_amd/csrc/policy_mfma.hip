@@ -17,6 +17,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define PART_EXTRA 3
+#define NWAVES 8                // waves per block: one block per CU (2 waves per SIMD), the weight image is shared by all 8
 constexpr int cdiv_(int a, int b) { return (a + b - 1) / b; }
 
 
@@ -44,7 +45,7 @@ struct PolImg {
 };
 
 template <int NS, int NA, int PH, int MODE>
-__global__ void __launch_bounds__(256, 2) k_policy_mfma(PolK k, const float* __restrict__ theta, const float* __restrict__ v,
+__global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const float* __restrict__ theta, const float* __restrict__ v,
                                                         float* __restrict__ partials) {
     using I = PolImg<NS, NA, PH>;
     constexpr int NS_KS = I::NS_KS, NSI = cdiv_(NS, 16), HB = I::HB, KK = I::KK;
@@ -64,13 +65,13 @@ __global__ void __launch_bounds__(256, 2) k_policy_mfma(PolK k, const float* __r
     // prologue costs ~2 L2 round trips instead of one dependent global load per element.
     {
         constexpr int IMG_U = 8;
-        for (int i0 = 0; i0 < I::TOTAL; i0 += 256 * IMG_U) {
+        for (int i0 = 0; i0 < I::TOTAL; i0 += NWAVES * 64 * IMG_U) {
             int m[IMG_U]; float w[IMG_U];
 #pragma unroll
-            for (int u = 0; u < IMG_U; ++u) { const int i = i0 + u * 256 + tid; m[u] = (i < I::TOTAL) ? k.img_map[i] : -1; }
+            for (int u = 0; u < IMG_U; ++u) { const int i = i0 + u * NWAVES * 64 + tid; m[u] = (i < I::TOTAL) ? k.img_map[i] : -1; }
 #pragma unroll
             for (int u = 0; u < IMG_U; ++u) {
-                const int i = i0 + u * 256 + tid;
+                const int i = i0 + u * NWAVES * 64 + tid;
                 bool use = m[u] >= 0;
                 if (MODE != MODE_FVP && (m[u] & 0x40000000)) use = false;                       // tangent tables: FVP only
                 if (MODE == MODE_LOSSKL && i >= I::O_W2B && i < I::O_W2F) use = false;          // back-prop tables unused
@@ -78,7 +79,7 @@ __global__ void __launch_bounds__(256, 2) k_policy_mfma(PolK k, const float* __r
                 if (use) w[u] = (m[u] & 0x40000000) ? v[m[u] & 0x3FFFFFFF] : theta[m[u]];
             }
 #pragma unroll
-            for (int u = 0; u < IMG_U; ++u) { const int i = i0 + u * 256 + tid; if (i < I::TOTAL) IMG[i] = w[u]; }
+            for (int u = 0; u < IMG_U; ++u) { const int i = i0 + u * NWAVES * 64 + tid; if (i < I::TOTAL) IMG[i] = w[u]; }
         }
     }
     // fragment accessors (this lane's element)
@@ -140,7 +141,7 @@ __global__ void __launch_bounds__(256, 2) k_policy_mfma(PolK k, const float* __r
     float acc0 = 0.f, acc1 = 0.f, accw = 0.f;               // loss, kl, valid weight (per-lane partials)
 
     const long long ntiles = (k.N + 15) / 16;
-    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+    for (long long tile = (long long)blockIdx.x * NWAVES + wave; tile < ntiles; tile += (long long)gridDim.x * NWAVES) {
         const long long n0 = tile * 16, n = n0 + c;
         const bool inr = n < k.N;
         const bool ok = inr && (k.valid == nullptr || k.valid[n]);
@@ -368,7 +369,7 @@ __global__ void __launch_bounds__(256, 2) k_policy_mfma(PolK k, const float* __r
 
     // ---------------- epilogue: wave partial -> block partial (fixed order) -> global row -------------
     __syncthreads();
-    float* RB = lds;                                        // [4][ROW] (weight image and transpose tiles are dead)
+    float* RB = lds;                                        // [NWAVES][ROW] (weight image and transpose tiles are dead)
     float* row = RB + wave * ROW;
     for (int i = lane; i < ROW; i += 64) row[i] = 0.f;
     wave_sync_lds();
@@ -415,7 +416,12 @@ __global__ void __launch_bounds__(256, 2) k_policy_mfma(PolK k, const float* __r
     }
     __syncthreads();
     float* out = partials + (size_t)blockIdx.x * ROW;
-    for (int i = tid; i < ROW; i += 256) out[i] = (RB[i] + RB[ROW + i]) + (RB[2 * ROW + i] + RB[3 * ROW + i]);
+    for (int i = tid; i < ROW; i += NWAVES * 64) {            // fixed pairwise order over the waves
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWAVES; w += 4) a += (RB[w * ROW + i] + RB[(w + 1) * ROW + i]) + (RB[(w + 2) * ROW + i] + RB[(w + 3) * ROW + i]);
+        out[i] = a;
+    }
 }
 
 
@@ -455,9 +461,9 @@ typedef void (*pol_kernel_t)(PolK, const float*, const float*, float*);
 struct PolEntry { int ns, na, ph; pol_kernel_t kern[3]; int lds_floats; void (*build_map)(std::vector<int>&); };
 template <int NS, int NA, int PH> constexpr int pol_lds() {
     constexpr int HB = cdiv_(PH, 16);
-    constexpr int a = PolImg<NS, NA, PH>::TOTAL + 4 * (4 * HB + 1) * 16 * 17;
+    constexpr int a = PolImg<NS, NA, PH>::TOTAL + NWAVES * (4 * HB + 1) * 16 * 17;
     constexpr int P = NS * PH + PH + PH * PH + PH + PH * NA + NA + NA;
-    constexpr int b = 4 * (P + PART_EXTRA);
+    constexpr int b = NWAVES * (P + PART_EXTRA);
     return a > b ? a : b;
 }
 #define PENTRY(NS, NA, PH) {NS, NA, PH, {k_policy_mfma<NS, NA, PH, 0>, k_policy_mfma<NS, NA, PH, 1>, k_policy_mfma<NS, NA, PH, 2>}, pol_lds<NS, NA, PH>(), pol_image_map<NS, NA, PH>}
@@ -496,7 +502,7 @@ int policy_mfma_launch(metrpo_ctx* c, int idx, int mode, const metrpo_batch* b, 
     k.gm = c->vjp_gm;
     const size_t sh = sizeof(float) * (size_t)en.lds_floats;
     if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)en.kern[mode], hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    hipLaunchKernelGGL(en.kern[mode], dim3(nblocks), dim3(256), sh, st, k, theta, v, partials);
+    hipLaunchKernelGGL(en.kern[mode], dim3(nblocks), dim3(NWAVES * 64), sh, st, k, theta, v, partials);
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;
 }

@@ -275,29 +275,38 @@ __global__ void __launch_bounds__(PT) k_loss_kl(ProblemDesc pd, PolK k, const fl
 // mode 0: grad -> out[0] = loss (column P), out[1+p] = g[p]
 // mode 1: fvp  -> out[p] = Hv[p] for the mean net; log_std rows get c(s) * v_ls * weight (column P+2)
 // mode 2: loss/kl -> out[0], out[1] from columns (lk_col, lk_col+1)
+#define FIN_C 32
 __global__ void __launch_bounds__(1024) k_finalize(ProblemDesc pd, int mode, int nrows, int stride, int lk_col,
                                                    const float* __restrict__ partials, const float* __restrict__ theta,
                                                    const double* __restrict__ v, double* __restrict__ out, CgTail tail) {
-    // block = 16 output columns x 64 row slices (latency-bound sum: many small blocks); slice s adds rows s, s+64, ...
-    // and the 64 slice sums are added in slice order: deterministic.
-    __shared__ double sh[64][17];
+    // block = FIN_C output columns x (1024 / FIN_C) row slices (latency-bound sum: many small blocks); slice s adds rows
+    // s, s+NSL, ... and the slice sums are added in slice order: deterministic.  32 columns = one 128-byte line per row read.
+    constexpr int NSL = 1024 / FIN_C;
+    __shared__ double sh[NSL][FIN_C + 1];
     const int P = pd.P;
     const int nout = (mode == 0) ? P + 1 : (mode == 1) ? P : 2;
-    const int lc = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int p = blockIdx.x * 16 + lc;
+    const int lc = threadIdx.x % FIN_C, sl = threadIdx.x / FIN_C;
+    const int p = blockIdx.x * FIN_C + lc;
     int col = p;
     if (mode == 0) col = (p == 0) ? P : p - 1;
     if (mode == 2) col = lk_col + p;
     const bool lsrow = (mode == 1 && p >= pd.pol.n_params && p < nout);
     if (lsrow) col = P + 2;                                   // valid-sample weight column
     double a = 0.0;
-    if (p < nout)
-        for (int b = sl; b < nrows; b += 64) a += (double)partials[(size_t)b * stride + col];
+    if (p < nout) {
+        int b = sl;
+        for (; b + 3 * NSL < nrows; b += 4 * NSL) {             // four independent loads in flight per thread
+            const float v0 = partials[(size_t)b * stride + col], v1 = partials[(size_t)(b + NSL) * stride + col];
+            const float v2 = partials[(size_t)(b + 2 * NSL) * stride + col], v3 = partials[(size_t)(b + 3 * NSL) * stride + col];
+            a += (double)v0; a += (double)v1; a += (double)v2; a += (double)v3;
+        }
+        for (; b < nrows; b += NSL) a += (double)partials[(size_t)b * stride + col];
+    }
     sh[sl][lc] = a;
     __syncthreads();
     if (sl == 0 && p < nout) {
         double t = 0.0;
-        for (int w = 0; w < 64; ++w) t += sh[w][lc];
+        for (int w = 0; w < NSL; ++w) t += sh[w][lc];
         if (lsrow) {
             // Hessian of mean KL w.r.t. log_std at theta_old: 4 s^2 (2 s^2 - eps) / (2 s^2 + eps)^2  (-> 2 as eps -> 0)
             const double raw = (double)theta[p];
@@ -322,8 +331,7 @@ __global__ void __launch_bounds__(1024) k_finalize(ProblemDesc pd, int mode, int
     }
     __syncthreads();
     if (!s_last) return;
-    if (tail.op == 1) cg_step_body(tail.P, tail.reg, tail.tol, tail.last, tail.x, tail.r, tail.p, tail.z, tail.pf, tail.scal, cgsh);
-    else cg_finish_body(tail.P, tail.reg, tail.max_kl, tail.x, tail.z, tail.step, tail.scal, cgsh);
+    cg_tail_run(tail, cgsh);
     if (threadIdx.x == 0) __hip_atomic_store(tail.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
 }
 
@@ -360,7 +368,7 @@ static void finalize(metrpo_ctx* c, int mode, int nrows, int stride, int lk_col,
                      const CgTail* tail = nullptr) {
     const int nout = (mode == 0) ? c->pd.P + 1 : (mode == 1) ? c->pd.P : 2;
     CgTail none; none.op = 0; none.ticket = nullptr;
-    hipLaunchKernelGGL(k_finalize, dim3((nout + 15) / 16), dim3(1024), 0, st, c->pd, mode, nrows, stride, lk_col,
+    hipLaunchKernelGGL(k_finalize, dim3((nout + FIN_C - 1) / FIN_C), dim3(1024), 0, st, c->pd, mode, nrows, stride, lk_col,
                        c->d_partials, c->d_theta, v, out, tail ? *tail : none);
 }
 
@@ -396,9 +404,9 @@ static int run_mode(metrpo_ctx* c, int mode, const metrpo_batch* b, const PolK& 
     const int P = c->pd.P;
     if (c->pol_mfma >= 0) {
         const long long tiles = (b->N + 15) / 16;
-        // measured (tools/fvp_sweep.py): 2 and 3 blocks per CU run at the same speed, 1 and 4 are slower; 2 keeps the number
-        // of partial rows (and with it k_finalize) small
-        const int g = (int)std::max<long long>(1, std::min<long long>((tiles + 3) / 4, (long long)c->n_sm * 2));
+        // one 8-wave block per CU = 2 waves per SIMD (measured in round 1: 2 and 3 waves per SIMD run at the same speed, 1 and 4
+        // are slower) and only n_sm partial rows for k_finalize
+        const int g = (int)std::max<long long>(1, std::min<long long>((tiles + 7) / 8, (long long)c->n_sm));
         int rc = ensure_partials(c, g); if (rc) return rc;
         *nrows = g; *stride = P + PART_EXTRA; *lk_col = P;
         return policy_mfma_launch(c, c->pol_mfma, mode, b, theta, vf, c->d_partials, g, st);
@@ -411,11 +419,11 @@ static int run_mode(metrpo_ctx* c, int mode, const metrpo_batch* b, const PolK& 
     return rc;
 }
 
-int launch_loss_grad(metrpo_ctx* c, const metrpo_batch* b, double* out, hipStream_t st) {
+int launch_loss_grad(metrpo_ctx* c, const metrpo_batch* b, double* out, hipStream_t st, const CgTail* tail) {
     PolK k; int rc = fill_polk(c, b, &k, true); if (rc) return rc;
     int nrows, stride, lk;
     if ((rc = run_mode(c, 0, b, k, c->d_theta, nullptr, &nrows, &stride, &lk, st))) return rc;
-    finalize(c, 0, nrows, stride, lk, nullptr, out, st);
+    finalize(c, 0, nrows, stride, lk, nullptr, out, st, tail);
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;
 }
@@ -453,8 +461,7 @@ int launch_fvp_tail(metrpo_ctx* c, const metrpo_batch* b, const float* vf, const
     PolK k; int rc = fill_polk(c, b, &k, false); if (rc) return rc;
     int nrows, stride, lk;
     if ((rc = run_mode(c, 1, b, k, c->d_theta, vf, &nrows, &stride, &lk, st))) return rc;
-    if (tail) { finalize(c, 1, nrows, stride, lk, v, hv, st, tail); HIP_TRY(c, hipGetLastError()); return METRPO_OK; }
-    finalize(c, 1, nrows, stride, lk, v, hv, st);
+    finalize(c, 1, nrows, stride, lk, v, hv, st, tail);
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;
 }

@@ -304,11 +304,12 @@ class Engine(object):
         return out
 
     def trpo_update(self, batch, max_kl=0.01, cg_iters=10, reg_coeff=1e-5, backtrack_ratio=0.8, max_backtracks=15,
-                    accept_violation=False, residual_tol=1e-10, allreduce=None, want_vectors=False):
+                    accept_violation=False, residual_tol=1e-10, allreduce=None, want_vectors=False, explicit_final_hvp=False):
         """One ConjugateGradientOptimizer.optimize; `allreduce(tensor_f64)` reduces in place across ranks."""
         p = _lib.TrpoParams()
         p.max_kl, p.cg_iters, p.reg_coeff, p.backtrack_ratio = max_kl, cg_iters, reg_coeff, backtrack_ratio
         p.max_backtracks, p.accept_violation, p.residual_tol = max_backtracks, int(accept_violation), residual_tol
+        p.explicit_final_hvp = int(bool(explicit_final_hvp))
         if allreduce is not None:
             dev = self.device
 

@@ -325,6 +325,27 @@ def test_trpo_update_parity(seed, use_mfma):
     np.testing.assert_allclose(cpu(eng.get_policy()), ref['theta_new'], rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize('use_mfma', [True, False])
+def test_step_scale_from_cg_recurrence_equals_explicit_hvp(use_mfma):
+    """[rllab] optimize() evaluates f_Hx(descent_direction) once more for the step scale; the default here takes d.(H d) from
+    krylov.cg's own recurrence (H d = g - r).  Both routes must give the same beta / step / accepted theta (float32 FVP rounding)."""
+    eng, th, pdims, obs, act, adv, om, ols = _update_problem(N=20000, seed=23)
+    assert eng.set_update_path(use_mfma) == use_mfma
+    batch = eng.make_batch(obs, act, adv, om, ols)
+    theta0 = eng.get_policy().clone()
+    a = eng.trpo_update(batch, max_kl=0.01, want_vectors=True, explicit_final_hvp=False)
+    ta = eng.get_policy().clone()
+    eng.set_policy(theta0)
+    b = eng.trpo_update(batch, max_kl=0.01, want_vectors=True, explicit_final_hvp=True)
+    tb = eng.get_policy().clone()
+    assert torch.equal(a['d'], b['d']) and torch.equal(a['g'], b['g'])          # identical CG trajectory
+    assert abs(a['beta'] - b['beta']) <= 2e-6 * b['beta']
+    assert a['n_backtrack'] == b['n_backtrack'] and a['accepted'] and b['accepted']
+    np.testing.assert_allclose(cpu(ta), cpu(tb), rtol=0, atol=1e-7)
+    ref = O.cg_optimize(th, pdims, obs, act, adv, om, ols, max_kl=0.01)          # the oracle takes rllab's explicit route
+    assert abs(a['beta'] - ref['beta']) <= 1e-3 * ref['beta']
+
+
 def test_trpo_update_rejects_and_restores():
     eng, th, pdims, obs, act, adv, om, ols = _update_problem(N=2000)
     before = eng.get_policy().clone()
