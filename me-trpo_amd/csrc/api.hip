@@ -102,7 +102,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     c->d_bptt = nullptr; c->bptt_cap = 0; c->det_cfg = -1; c->d_detpart = nullptr; c->detpart_cap = 0; c->det_gemm = 0; c->d_dg = nullptr; c->dg_cap = 0; c->vjp_gm = nullptr; c->d_pol_adam = nullptr; c->pol_adam_t = 0; c->mfma_cfg = -1; c->pol_mfma = -1; c->coop_cfg = -1; c->rollout_variant = 0;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_cg = nullptr; c->d_vf = nullptr; c->d_theta_try = nullptr;
     c->d_valbuf = nullptr; c->h_pinned = nullptr; c->n_sm = 256;
-    c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0; c->d_ticket = nullptr; c->d_adam = nullptr; c->adam_t = 0; c->d_train = nullptr; c->train_cap = 0;
+    c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0; c->d_ticket = nullptr; c->d_hcache = nullptr; c->hcache_cap = 0; c->hcache_on = 0; c->d_adam = nullptr; c->adam_t = 0; c->d_train = nullptr; c->train_cap = 0;
     ProblemDesc& pd = c->pd;
     pd.env = d->env; pd.ns = d->ns; pd.na = d->na; pd.K = d->n_models; pd.n_drop = d->n_drop;
     pd.nin = d->ns + d->na - d->n_drop;
@@ -142,7 +142,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
 extern "C" int32_t metrpo_destroy(metrpo_ctx* c) {
     if (!c) return METRPO_ENULL;
     void* bufs[] = {c->d_dyn, c->d_norm, c->d_theta, c->d_vf, c->d_theta_try, c->d_cg, c->d_valbuf, c->d_partials,
-                    c->d_dyn_img, c->d_pol_img, c->d_vbuf, c->d_gram_part, c->d_big, c->d_ticket, c->d_adam, c->d_train, c->d_bptt, c->d_pol_adam, c->d_detpart, c->d_dg};
+                    c->d_dyn_img, c->d_pol_img, c->d_vbuf, c->d_gram_part, c->d_big, c->d_ticket, c->d_hcache, c->d_adam, c->d_train, c->d_bptt, c->d_pol_adam, c->d_detpart, c->d_dg};
     for (void* p : bufs) if (p) (void)hipFree(p);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     delete c;
@@ -445,10 +445,12 @@ int run_trpo_update(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_para
     tl.x = v.x; tl.r = v.r; tl.p = v.p; tl.z = v.z; tl.step = v.step; tl.scal = v.scal; tl.gout = v.gout; tl.pf = c->d_vf; tl.ticket = c->d_ticket;
     HIP_TRY(c, hipMemsetAsync(c->d_ticket, 0, sizeof(unsigned int), st));
     tl.op = 3;
+    c->hcache_on = 1;                    // the gradient kernel publishes tanh activations, the CG products of this solve reuse them
+    struct CacheOff { metrpo_ctx* c; ~CacheOff() { c->hcache_on = 0; } } cache_off{c};
     if ((rc = launch_loss_grad(c, b, v.gout, st, fused ? &tl : nullptr))) return rc;
     if (!fused) {
         AR(v.gout, 1 + P);
-        hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(256), 0, st, P, v.gout, v.x, v.r, v.p, c->d_vf, v.scal);
+        hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(1024), 0, st, P, v.gout, v.x, v.r, v.p, c->d_vf, v.scal);   // same block shape as the fused tail: identical summation order
     }
     if (pr->cg_iters == 0) {
         hipLaunchKernelGGL(k_zero_f, dim3((P + 255) / 256), dim3(256), 0, st, c->d_vf, P);

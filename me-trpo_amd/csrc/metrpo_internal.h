@@ -65,6 +65,7 @@ struct metrpo_ctx {
     double* d_gram_part; // per-block Gram partials (process.hip)
     size_t gram_cap;
     unsigned int* d_ticket; // arrival counter of k_finalize's fused CG tail
+    float* d_hcache; size_t hcache_cap; int hcache_on;   // activation cache of one CG solve (policy_mfma.hip MODE_FVPC)
     void* d_adam;        // Adam moments [2][K][Pd] + loss accumulators (dyn_train.hip)
     long long adam_t;    // Adam step count
     void* d_train;       // training activation workspace
@@ -108,6 +109,7 @@ struct PolK {
     int ls_stride; const uint8_t* valid; long long N; float inv_n;
     const float* gm;         // non-NULL: VJP mode of the gradient kernels (bptt.hip): d objective / d mean [N][na] supplied, no loss terms
     const int* img_map;      // policy_mfma.hip: gather map of the LDS weight-fragment image (built once per ctx on the host)
+    float* hcache;           // policy_mfma.hip: hidden activations of (theta, batch): written by the gradient kernel, read by MODE_FVPC
 };
 
 int policy_mfma_select(const ProblemDesc& pd);

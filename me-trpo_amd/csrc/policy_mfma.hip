@@ -31,7 +31,12 @@ __device__ __forceinline__ float xsum_c(float v) {
     return v;
 }
 
-enum { MODE_GRAD = 0, MODE_FVP = 1, MODE_LOSSKL = 2 };
+enum { MODE_GRAD = 0, MODE_FVP = 1, MODE_LOSSKL = 2, MODE_FVPC = 3 };
+// MODE_FVPC: Fisher-vector product with the hidden activations h0, h1 = tanh(.) read from the cache the gradient kernel of the
+// same (theta, batch) wrote (PolK::hcache) instead of being recomputed: all 10 products of a CG solve share theta and the
+// observations, so the forward pass (22 of the 100 MFMAs of a tile and all 16 tanh per lane) is done once per update, not 11 times.
+// Cache layout per 16-sample tile: [h0 cb0 | h0 cb1 | .. | h1 cb0 | ..][64 lanes] float4 in the MFMA D layout -- each wave
+// instruction reads or writes 1 KB contiguously.
 
 // LDS weight image, shared by the 4 waves of a block (filled once per block).  Tables with a col-block index store the HB
 // col-block fragments of one k-step adjacently per lane, so one ds_read_b64 (HB = 2) feeds both MFMAs of that k-step.
@@ -44,10 +49,12 @@ struct PolImg {
                          O_V2F = O_W2F + KK * 64, TOTAL = O_V2F + KK * 64;
 };
 
-template <int NS, int NA, int PH, int MODE>
+template <int NS, int NA, int PH, int MODE_>
 __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const float* __restrict__ theta, const float* __restrict__ v,
                                                         float* __restrict__ partials) {
     using I = PolImg<NS, NA, PH>;
+    constexpr bool CACHED = (MODE_ == MODE_FVPC);
+    constexpr int MODE = CACHED ? MODE_FVP : MODE_;
     constexpr int NS_KS = I::NS_KS, NSI = cdiv_(NS, 16), HB = I::HB, KK = I::KK;
     constexpr int pW0 = 0, pb0 = NS * PH, pW1 = pb0 + PH, pb1 = pW1 + PH * PH, pW2 = pb1 + PH, pb2 = pW2 + PH * NA,
                   pLS = pb2 + NA, P = pLS + NA, ROW = P + PART_EXTRA;
@@ -75,6 +82,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
                 bool use = m[u] >= 0;
                 if (MODE != MODE_FVP && (m[u] & 0x40000000)) use = false;                       // tangent tables: FVP only
                 if (MODE == MODE_LOSSKL && i >= I::O_W2B && i < I::O_W2F) use = false;          // back-prop tables unused
+                if (CACHED && i < I::O_W1F) use = false;                                        // W0 forward table unused
                 w[u] = 0.f;
                 if (use) w[u] = (m[u] & 0x40000000) ? v[m[u] & 0x3FFFFFFF] : theta[m[u]];
             }
@@ -141,6 +149,13 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
     float acc0 = 0.f, acc1 = 0.f, accw = 0.f;               // loss, kl, valid weight (per-lane partials)
 
     const long long ntiles = (k.N + 15) / 16;
+    const f32x4* __restrict__ hc = (const f32x4*)k.hcache;
+    f32x4 hn[2 * HB];                                       // cached activations of the NEXT tile (register double buffer: HBM latency)
+    if (CACHED) {
+        const long long t_first = (long long)blockIdx.x * NWAVES + wave;
+#pragma unroll
+        for (int j = 0; j < 2 * HB; ++j) hn[j] = (t_first < ntiles) ? hc[(t_first * (2 * HB) + j) * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     for (long long tile = (long long)blockIdx.x * NWAVES + wave; tile < ntiles; tile += (long long)gridDim.x * NWAVES) {
         const long long n0 = tile * 16, n = n0 + c;
         const bool inr = n < k.N;
@@ -154,28 +169,39 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
         float* T_H0 = TL, *T_H1 = TL + HB * TILE, *T_D1 = TL + 2 * HB * TILE, *T_D0 = TL + 3 * HB * TILE, *T_UM = TL + 4 * HB * TILE;
         // ---- S1: layer 0, forward and (FVP) tangent  ------------------------------------------------------
         f32x4 h0[HB], h1[HB], t0[HB], t1[HB];
+        if (CACHED) {
 #pragma unroll
-        for (int cb = 0; cb < HB; ++cb) { h0[cb] = b0f[cb]; if (MODE == MODE_FVP) t0[cb] = vb0f[cb]; }
+            for (int cb = 0; cb < HB; ++cb) { h0[cb] = hn[cb]; h1[cb] = hn[HB + cb]; }
+            const long long t_next = tile + (long long)gridDim.x * NWAVES;
+            if (t_next < ntiles) {
+#pragma unroll
+                for (int j = 0; j < 2 * HB; ++j) hn[j] = hc[(t_next * (2 * HB) + j) * 64 + lane];
+            }
+        }
+#pragma unroll
+        for (int cb = 0; cb < HB; ++cb) { if (!CACHED) h0[cb] = b0f[cb]; if (MODE == MODE_FVP) t0[cb] = vb0f[cb]; }
 #pragma unroll
         for (int s = 0; s < NS_KS; ++s)
 #pragma unroll
             for (int cb = 0; cb < HB; ++cb) {
-                h0[cb] = MFMA16(FRAG2(I::O_W0F, s, cb), xB[s], h0[cb]);
+                if (!CACHED) h0[cb] = MFMA16(FRAG2(I::O_W0F, s, cb), xB[s], h0[cb]);
                 if (MODE == MODE_FVP) t0[cb] = MFMA16(FRAG2(I::O_V0F, s, cb), xB[s], t0[cb]);
             }
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb) {
-            h1[cb] = b1f[cb];
+            if (!CACHED) h1[cb] = b1f[cb];
             if (MODE == MODE_FVP) t1[cb] = vb1f[cb];
+            if (!CACHED) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h0[cb][r] = tanh_fast(h0[cb][r]);
+                for (int r = 0; r < 4; ++r) h0[cb][r] = tanh_fast(h0[cb][r]);
+            }
         }
         // ---- S2: layer 1 on h0: forward h1 += W1^T h0 and (FVP) t1 += V1^T h0;  VALU inside: t0 *= 1 - h0^2, h0 -> T_H0 ----
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
             for (int cb = 0; cb < HB; ++cb) {
-                h1[cb] = MFMA16(FRAG2(I::O_W1F, kk, cb), h0[kk >> 2][kk & 3], h1[cb]);
+                if (!CACHED) h1[cb] = MFMA16(FRAG2(I::O_W1F, kk, cb), h0[kk >> 2][kk & 3], h1[cb]);
                 if (MODE == MODE_FVP) t1[cb] = MFMA16(FRAG2(I::O_V1F, kk, cb), h0[kk >> 2][kk & 3], t1[cb]);
             }
         if (MODE != MODE_LOSSKL) {
@@ -195,15 +221,22 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
 #pragma unroll
                 for (int cb = 0; cb < HB; ++cb) t1[cb] = MFMA16(FRAG2(I::O_W1F, kk, cb), t0[kk >> 2][kk & 3], t1[cb]);
         }
+        if (!CACHED) {
 #pragma unroll
-        for (int cb = 0; cb < HB; ++cb)
+            for (int cb = 0; cb < HB; ++cb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h1[cb][r] = tanh_fast(h1[cb][r]);
+                for (int r = 0; r < 4; ++r) h1[cb][r] = tanh_fast(h1[cb][r]);
+        }
         if (MODE != MODE_LOSSKL) {
 #pragma unroll
             for (int cb = 0; cb < HB; ++cb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) T_H1[cb * TILE + (4 * q + r) * TS + c] = h1[cb][r];
+        }
+        if (MODE == MODE_GRAD && k.hcache != nullptr) {     // publish the activations for the FVPs of this update
+            f32x4* hw = (f32x4*)k.hcache + (size_t)tile * (2 * HB) * 64 + lane;
+#pragma unroll
+            for (int cb = 0; cb < HB; ++cb) { hw[cb * 64] = h0[cb]; hw[(HB + cb) * 64] = h1[cb]; }
         }
 
         f32x4 um = Z4;                                      // d(objective)/d(mean) in D layout [d = 4q+r][sample c]
@@ -458,7 +491,7 @@ static void pol_image_map(std::vector<int>& map) {
 
 // -------------------------------------------------------------------------------------------------
 typedef void (*pol_kernel_t)(PolK, const float*, const float*, float*);
-struct PolEntry { int ns, na, ph; pol_kernel_t kern[3]; int lds_floats; void (*build_map)(std::vector<int>&); };
+struct PolEntry { int ns, na, ph; pol_kernel_t kern[4]; int lds_floats; void (*build_map)(std::vector<int>&); };
 template <int NS, int NA, int PH> constexpr int pol_lds() {
     constexpr int HB = cdiv_(PH, 16);
     constexpr int a = PolImg<NS, NA, PH>::TOTAL + NWAVES * (4 * HB + 1) * 16 * 17;
@@ -466,7 +499,7 @@ template <int NS, int NA, int PH> constexpr int pol_lds() {
     constexpr int b = NWAVES * (P + PART_EXTRA);
     return a > b ? a : b;
 }
-#define PENTRY(NS, NA, PH) {NS, NA, PH, {k_policy_mfma<NS, NA, PH, 0>, k_policy_mfma<NS, NA, PH, 1>, k_policy_mfma<NS, NA, PH, 2>}, pol_lds<NS, NA, PH>(), pol_image_map<NS, NA, PH>}
+#define PENTRY(NS, NA, PH) {NS, NA, PH, {k_policy_mfma<NS, NA, PH, 0>, k_policy_mfma<NS, NA, PH, 1>, k_policy_mfma<NS, NA, PH, 2>, k_policy_mfma<NS, NA, PH, 3>}, pol_lds<NS, NA, PH>(), pol_image_map<NS, NA, PH>}
 static const PolEntry kPol[] = {
     PENTRY(10, 2, 32),    // swimmer
     PENTRY(18, 6, 32),    // half-cheetah
@@ -500,6 +533,17 @@ int policy_mfma_launch(metrpo_ctx* c, int idx, int mode, const metrpo_batch* b, 
     }
     k.img_map = (const int*)c->d_pol_img;
     k.gm = c->vjp_gm;
+    k.hcache = nullptr;
+    if (c->hcache_on && (mode == MODE_GRAD || mode == MODE_FVP) && k.gm == nullptr) {      // set by run_trpo_update around one CG solve
+        const size_t need = (size_t)((b->N + 15) / 16) * 2 * (size_t)cdiv_(en.ph, 16) * 64 * 4;
+        if (need > c->hcache_cap) {
+            if (c->d_hcache) { HIP_TRY(c, hipFree(c->d_hcache)); c->d_hcache = nullptr; c->hcache_cap = 0; }
+            HIP_TRY(c, hipMalloc(&c->d_hcache, need * sizeof(float)));
+            c->hcache_cap = need;
+        }
+        k.hcache = c->d_hcache;
+        if (mode == MODE_FVP) mode = MODE_FVPC;
+    }
     const size_t sh = sizeof(float) * (size_t)en.lds_floats;
     if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)en.kern[mode], hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     hipLaunchKernelGGL(en.kern[mode], dim3(nblocks), dim3(NWAVES * 64), sh, st, k, theta, v, partials);

@@ -360,7 +360,7 @@ static int fill_polk(metrpo_ctx* c, const metrpo_batch* b, PolK* k, bool need_ta
         return set_err(c, METRPO_ENULL, "batch pointer is NULL");
     k->obs = b->d_obs; k->act = b->d_act; k->adv = b->d_adv; k->old_mean = b->d_old_mean; k->old_ls = b->d_old_log_std;
     k->ls_stride = b->old_log_std_stride; k->valid = b->d_valid; k->N = b->N; k->inv_n = (float)b->inv_n_global;
-    k->gm = nullptr; k->img_map = nullptr;
+    k->gm = nullptr; k->img_map = nullptr; k->hcache = nullptr;
     return METRPO_OK;
 }
 

@@ -77,4 +77,4 @@ def test_edge_vectors_through_fused_rollouts(env, variant):
     fin = np.isfinite(xn).all(axis=1)      # non-finite states make the policy output NaN: np.clip keeps NaN, fminf/fmaxf do not -- the reward of such a row is meaningless in both
     np.testing.assert_allclose(cpu(traj.rew[0])[fin], ref_rew[fin], rtol=2e-6, atol=2e-6)
     assert np.array_equal(cpu(traj.done[0]).astype(bool), ref_done)
-    np.testing.assert_array_equal(cpu(traj.act[0]), u.astype(np.float32).astype(np.float64))
+    np.testing.assert_array_equal(cpu(traj.act[0])[fin], u.astype(np.float32).astype(np.float64)[fin])

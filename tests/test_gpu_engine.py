@@ -322,7 +322,10 @@ def test_trpo_update_parity(seed, use_mfma):
     # post-update KL/loss are evaluated at slightly different theta_new (d matches to rel-L2 1e-3): relative 5e-3
     assert abs(out['kl'] - ref['kl']) <= 5e-3 * ref['kl'] and out['kl'] <= 0.01 and out['loss'] < out['loss_before']
     assert abs(out['loss'] - ref['loss']) <= 5e-3 * abs(ref['loss'])
-    np.testing.assert_allclose(cpu(eng.get_policy()), ref['theta_new'], rtol=0, atol=2e-5)
+    # theta_new = theta - ratio * beta * d inherits d's tolerance (rel-L2 <= 1e-3 after 10 CG iterations)
+    step_ref = ref['theta_new'] - th
+    np.testing.assert_allclose(cpu(eng.get_policy()), ref['theta_new'], rtol=0, atol=1e-3 * np.linalg.norm(step_ref) + 1e-6)
+    assert rel_l2(cpu(eng.get_policy()) - th.astype(np.float32).astype(np.float64), step_ref) <= 2e-3
 
 
 @pytest.mark.parametrize('use_mfma', [True, False])
