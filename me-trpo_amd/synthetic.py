@@ -8,12 +8,15 @@ ENV_SPECS = {'swimmer': (10, 2, 2), 'half_cheetah': (18, 6, 1), 'ant': (29, 8, 2
              'hopper': (11, 3, 0), 'snake': (14, 4, 2)}
 
 CONFIGS = {
-    # name: env, K, dyn_hidden, pol_hidden, B (per GPU), H
-    'C0': dict(env='swimmer', K=5, dyn_hidden=(64, 64), pol_hidden=(32, 32), B=100, H=50),
-    'C1': dict(env='swimmer', K=5, dyn_hidden=(64, 64), pol_hidden=(32, 32), B=5000, H=100),
-    'C2': dict(env='half_cheetah', K=5, dyn_hidden=(64, 64), pol_hidden=(32, 32), B=10000, H=200),
-    'C3': dict(env='ant', K=10, dyn_hidden=(512, 512), pol_hidden=(32, 32), B=20000, H=500),
-    'C4': dict(env='humanoid', K=20, dyn_hidden=(1024, 1024, 1024), pol_hidden=(100, 50, 25), B=50000, H=1000),
+    # name: env, K, dyn_hidden, pol_hidden, B (whole job), H, gpus BASELINE.json quotes the config on.  bench.py runs B / gpus
+    # envs per GPU (the per-GPU share; weak scaling keeps that share fixed when --gpus differs).
+    'C0': dict(env='swimmer', K=5, dyn_hidden=(64, 64), pol_hidden=(32, 32), B=100, H=50, gpus=1),
+    'C0p': dict(env='swimmer', K=5, dyn_hidden=(512, 512), pol_hidden=(32, 32), B=100, H=200, gpus=1),    # params-swimmer.json shape
+    'C1': dict(env='swimmer', K=5, dyn_hidden=(64, 64), pol_hidden=(32, 32), B=5000, H=100, gpus=1),
+    'C2': dict(env='half_cheetah', K=5, dyn_hidden=(1024, 1024), pol_hidden=(32, 32), B=10000, H=200, gpus=4),  # params-half-cheetah.json nets
+    'C2s': dict(env='half_cheetah', K=5, dyn_hidden=(64, 64), pol_hidden=(32, 32), B=10000, H=200, gpus=4),     # BASELINE leaves the MLP open: 2x64 variant
+    'C3': dict(env='ant', K=10, dyn_hidden=(512, 512), pol_hidden=(32, 32), B=20000, H=500, gpus=8),
+    'C4': dict(env='humanoid', K=20, dyn_hidden=(1024, 1024, 1024), pol_hidden=(100, 50, 25), B=50000, H=1000, gpus=8),
 }
 
 
