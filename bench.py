@@ -157,7 +157,7 @@ def main():
                      "hbm_frac_unfused_88B": (K * B * T_mean * (2 * ns + na) * 4) / (roll_ms * 1e-3) / PEAK_HBM,
                      "update": {"kernel": "policy update (1 gradient + %d Fisher-vector products + %d line-search evaluations, N=%d)"
                                           % (n_hvp, n_ls, int(N_local)),
-                                "path": "mfma" if eng.set_update_path(True) else "generic",
+                                "path": eng.update_path(int(N_local)),
                                 "ms": upd_ms, "achieved": upd_achieved, "peak": PEAK_F32, "unit": "TFLOP/s", "frac": upd_achieved / PEAK_F32}},
     }
     if comm.rank == 0 and comm.world == 1 and not args.no_cpu_baseline:

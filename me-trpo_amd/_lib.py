@@ -99,6 +99,7 @@ EXTRA_SYMBOLS = {
     'metrpo_rollout_generic': (_I, [_P, C.POINTER(RolloutArgs), _P]),
     'metrpo_has_mfma_path': (_I, [_P]),
     'metrpo_set_update_path': (_I, [_P, _I]),
+    'metrpo_update_path': (_I, [_P, _L]),
     'metrpo_set_rollout_variant': (_I, [_P, _I]),
     'metrpo_set_det_path': (_I, [_P, _I]),
 }

@@ -9,11 +9,11 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { EPI_BIAS_ID = 0, EPI_BIAS_RELU = 1, EPI_BIAS_TANH = 2, EPI_RELU_MASK = 3, EPI_ADAM = 4, EPI_PLAIN = 5, EPI_PARTIAL = 6 };
+enum { EPI_BIAS_ID = 0, EPI_BIAS_RELU = 1, EPI_BIAS_TANH = 2, EPI_RELU_MASK = 3, EPI_ADAM = 4, EPI_PLAIN = 5, EPI_PARTIAL = 6, EPI_DTANH = 7 };
 
 struct GemmEpi {                 // epilogue operands (unused fields may be null)
     const float* bias; long long strideBias;          // EPI_BIAS_*: bias[col]
-    const float* mask; long long strideMask; int ldm; // EPI_RELU_MASK: C = acc * (mask[row][col] > 0)
+    const float* mask; long long strideMask; int ldm; // EPI_RELU_MASK: C = acc * (mask[row][col] > 0);  EPI_DTANH: C = (acc + bias?) * (1 - mask[row][col]^2)
     float* am; float* av; long long strideAdam;       // EPI_ADAM: C is the weight matrix, updated in place; am/av same layout
     float lr_t, beta1, beta2, eps, decay;             //           lr_t = lr*sqrt(1-b2^t)/(1-b1^t); decay = lr*reg_constant (SGD on the regulariser)
     float* bvec; float* bam; float* bav;              // EPI_ADAM: bias of the same layer; its gradient = column sums of opB(W) (= dZ), which the
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + wn * 32 * TN + j * 32 + (lane & 31);
             float bv = 0.0f;
-            if (EPI <= EPI_BIAS_TANH) bv = (col < N) ? ep.bias[(size_t)head * ep.strideBias + col] : 0.0f;
+            if (EPI <= EPI_BIAS_TANH || (EPI == EPI_DTANH && ep.bias != nullptr)) bv = (col < N) ? ep.bias[(size_t)head * ep.strideBias + col] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -190,6 +190,7 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
                     else if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bv, 0.0f);
                     else if (EPI == EPI_BIAS_TANH) v = tanh_fast(v + bv);
                     else if (EPI == EPI_RELU_MASK) v = (ep.mask[(size_t)head * ep.strideMask + (size_t)row * ep.ldm + col] > 0.0f) ? v : 0.0f;
+                    else if (EPI == EPI_DTANH) { const float hm = ep.mask[(size_t)head * ep.strideMask + (size_t)row * ep.ldm + col]; v = (v + bv) * fmaf(-hm, hm, 1.0f); }
                     if (EPI == EPI_ADAM) {                       // tf.train.AdamOptimizer update of one weight, gradient = v
                         const size_t ai = (size_t)head * ep.strideAdam + ci;
                         const float m1 = ep.beta1 * ep.am[ai] + (1.0f - ep.beta1) * v;

@@ -421,6 +421,7 @@ static int run_mode(metrpo_ctx* c, int mode, const metrpo_batch* b, const PolK& 
 
 int launch_loss_grad(metrpo_ctx* c, const metrpo_batch* b, double* out, hipStream_t st, const CgTail* tail) {
     PolK k; int rc = fill_polk(c, b, &k, true); if (rc) return rc;
+    if (policy_gemm_applicable(c, b->N)) return policy_gemm_run(c, 0, b, k, c->d_theta, nullptr, nullptr, out, tail, st);
     int nrows, stride, lk;
     if ((rc = run_mode(c, 0, b, k, c->d_theta, nullptr, &nrows, &stride, &lk, st))) return rc;
     finalize(c, 0, nrows, stride, lk, nullptr, out, st, tail);
@@ -438,6 +439,11 @@ int launch_policy_vjp(metrpo_ctx* c, const float* obs, const float* gm, long lon
     k.obs = obs; k.N = N; k.inv_n = 1.0f; k.gm = gm;
     int nrows, stride, lk;
     c->vjp_gm = gm;
+    if (policy_gemm_applicable(c, N)) {
+        const int rcg = policy_gemm_run(c, 0, &b, k, c->d_theta, nullptr, nullptr, out, nullptr, st);
+        c->vjp_gm = nullptr;
+        return rcg;
+    }
     const int rc = run_mode(c, 0, &b, k, c->d_theta, nullptr, &nrows, &stride, &lk, st);
     c->vjp_gm = nullptr;
     if (rc) return rc;
@@ -459,6 +465,7 @@ int launch_fvp_f32(metrpo_ctx* c, const metrpo_batch* b, const float* vf, const 
 
 int launch_fvp_tail(metrpo_ctx* c, const metrpo_batch* b, const float* vf, const double* v, double* hv, const CgTail* tail, hipStream_t st) {
     PolK k; int rc = fill_polk(c, b, &k, false); if (rc) return rc;
+    if (policy_gemm_applicable(c, b->N)) return policy_gemm_run(c, 1, b, k, c->d_theta, vf, v, hv, tail, st);
     int nrows, stride, lk;
     if ((rc = run_mode(c, 1, b, k, c->d_theta, vf, &nrows, &stride, &lk, st))) return rc;
     finalize(c, 1, nrows, stride, lk, v, hv, st, tail);
@@ -468,6 +475,7 @@ int launch_fvp_tail(metrpo_ctx* c, const metrpo_batch* b, const float* vf, const
 
 int launch_loss_kl(metrpo_ctx* c, const metrpo_batch* b, const float* theta, double* out, hipStream_t st) {
     PolK k; int rc = fill_polk(c, b, &k, true); if (rc) return rc;
+    if (policy_gemm_applicable(c, b->N)) return policy_gemm_run(c, 2, b, k, theta ? theta : c->d_theta, nullptr, nullptr, out, nullptr, st);
     int nrows, stride, lk;
     if ((rc = run_mode(c, 2, b, k, theta ? theta : c->d_theta, nullptr, &nrows, &stride, &lk, st))) return rc;
     finalize(c, 2, nrows, stride, lk, nullptr, out, st);

@@ -84,8 +84,16 @@ class Engine(object):
         return int(lib.metrpo_set_rollout_variant(self._ctx, int(v)))
 
     def set_update_path(self, use_mfma):
-        """Test hook: False forces the generic (VALU) policy-update kernels; returns True if MFMA kernels are active."""
-        return bool(lib.metrpo_set_update_path(self._ctx, int(bool(use_mfma))))
+        """Test hook: False forces the generic (VALU) policy-update kernels, True selects the fastest path of the shape (fused
+        MFMA kernels, else the GEMM path for large N), 'gemm' forces the GEMM path (policy_gemm.hip).  Returns True if the fused
+        MFMA kernels are active, 'gemm' if the GEMM path is forced, else False."""
+        code = 2 if use_mfma == 'gemm' else int(bool(use_mfma))
+        r = int(lib.metrpo_set_update_path(self._ctx, code))
+        return 'gemm' if r == 2 else bool(r)
+
+    def update_path(self, N):
+        """Kernel family the policy update of an N-sample batch runs on: 'mfma' (fused), 'gemm' or 'generic'."""
+        return {1: 'mfma', 2: 'gemm', 0: 'generic'}[int(lib.metrpo_update_path(self._ctx, int(N)))]
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):

@@ -263,15 +263,17 @@ def rel_l2(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
 
 
-@pytest.mark.parametrize('use_mfma', [True, False])
+@pytest.mark.parametrize('use_mfma', [True, False, 'gemm'])
 @pytest.mark.parametrize('env,pol_hidden,N', [('swimmer', (32, 32), 5000), ('half_cheetah', (32, 32), 3001),
                                               ('ant', (32, 32), 2000), ('hopper', (32, 32), 777), ('snake', (32, 32), 1024),
-                                              ('humanoid', (100, 50, 25), 1500)])
+                                              ('humanoid', (100, 50, 25), 1500), ('humanoid', (100, 50, 25), 20011), ('swimmer', (17,), 3000)])
 def test_loss_grad_fvp_losskl_parity(env, pol_hidden, N, use_mfma):
     eng, th, pdims, obs, act, adv, om, ols = _update_problem(env, N, pol_hidden=pol_hidden)
     active = eng.set_update_path(use_mfma)
-    if use_mfma and not active:
-        pytest.skip('no MFMA update kernels for this policy shape (generic path covers it)')
+    if use_mfma is True and not active:
+        pytest.skip('no fused MFMA update kernels for this policy shape (generic / GEMM paths cover it)')
+    if use_mfma == 'gemm':
+        assert active == 'gemm'
     valid = np.ones(N, np.uint8); valid[::7] = 0
     keep = valid.astype(bool)
     batch = eng.make_batch(obs, act, adv, om, ols, valid=valid)
@@ -303,7 +305,7 @@ def test_update_is_bitwise_reproducible():
     assert torch.equal(eng.fvp(batch, v).clone(), eng.fvp(batch, v).clone())
 
 
-@pytest.mark.parametrize('use_mfma', [True, False])
+@pytest.mark.parametrize('use_mfma', [True, False, 'gemm'])
 @pytest.mark.parametrize('seed', [21, 22])
 def test_trpo_update_parity(seed, use_mfma):
     eng, th, pdims, obs, act, adv, om, ols = _update_problem(N=6000, seed=seed)
@@ -328,7 +330,7 @@ def test_trpo_update_parity(seed, use_mfma):
     assert rel_l2(cpu(eng.get_policy()) - th.astype(np.float32).astype(np.float64), step_ref) <= 2e-3
 
 
-@pytest.mark.parametrize('use_mfma', [True, False])
+@pytest.mark.parametrize('use_mfma', [True, False, 'gemm'])
 def test_step_scale_from_cg_recurrence_equals_explicit_hvp(use_mfma):
     """[rllab] optimize() evaluates f_Hx(descent_direction) once more for the step scale; the default here takes d.(H d) from
     krylov.cg's own recurrence (H d = g - r).  Both routes must give the same beta / step / accepted theta (float32 FVP rounding)."""
