@@ -91,6 +91,7 @@ def main():
                                   sam_mode='step_rand')
     algo = metrpo_amd.TRPO(env=nne, policy=policy, baseline=baseline, batch_size=B * H, max_path_length=H,
                            discount=1.0, step_size=0.01, sampler_args=dict(n_envs=B), comm=comm, seed=0)
+    rccl_in_ctx = comm.world > 1 and comm.attach_engine(eng)   # N > 1 over RCCL: the ctx owns the communicator, all-reduces issued from C
     algo.defer_baseline_fit = True            # host solve of the 24x24 baseline system overlaps the next rollout
     algo.reuse_trajectory_buffers = True      # one set of [T,B,.] tensors, overwritten every iteration
 
@@ -160,6 +161,21 @@ def main():
                                 "path": eng.update_path(int(N_local)),
                                 "ms": upd_ms, "achieved": upd_achieved, "peak": PEAK_F32, "unit": "TFLOP/s", "frac": upd_achieved / PEAK_F32}},
     }
+    if comm.world > 1:                                          # latency of the exchanges of the path: P and 2 float64 values
+        lat = {}
+        for n_el in (eng.P, 2):
+            buf = torch.zeros(n_el, dtype=torch.float64, device='cuda')
+            for _ in range(10):
+                comm.allreduce_sum_(buf)
+            torch.cuda.synchronize(); comm.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(100):
+                comm.allreduce_sum_(buf)
+            e1.record(); torch.cuda.synchronize()
+            lat["%d_f64" % n_el] = comm.max_float(e0.elapsed_time(e1) * 10.0, device='cuda')     # us per all-reduce
+        out["allreduce_us"] = dict(lat, transport="rccl-in-ctx (ncclAllReduce issued by libmetrpo.so)" if rccl_in_ctx
+                                   else "torch.distributed %s via host callback" % os.environ.get('METRPO_BENCH_BACKEND', 'nccl'))
     if comm.rank == 0 and comm.world == 1 and not args.no_cpu_baseline:
         try:
             # bounded sample: ~10-30 s of 1-thread CPU work (about 0.4 TFLOP of dynamics forwards), same per-step structure

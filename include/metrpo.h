@@ -222,7 +222,21 @@ int32_t metrpo_fvp(metrpo_ctx* ctx, const metrpo_batch* batch, const double* d_v
 int32_t metrpo_loss_kl(metrpo_ctx* ctx, const metrpo_batch* batch, const float* d_theta, double* d_out,
                        void* stream);
 
-/* all-reduce(sum) hook for sharded runs: called on the host while enqueuing, must reduce `count`
+/* ---- multi-GPU: one process and one ctx per GPU, the env batch B sharded over the ranks.  The only exchanges on
+ * the path are sum all-reduces of small float64 vectors.  Attach an RCCL communicator to the ctx and metrpo_trpo_update issues
+ * its all-reduces itself (ncclAllReduce on the caller's stream, in-place, float64); the reference has no counterpart (it is a
+ * single-process TF session, utils.py:229-232).  Bootstrap: rank 0 calls metrpo_comm_get_unique_id and ships the 128 bytes to
+ * the other ranks by any side channel (bench.py: a torch.distributed broadcast); then EVERY rank calls metrpo_comm_init
+ * (collective, blocks until all ranks arrive).  librccl is loaded on first use. */
+#define METRPO_COMM_ID_BYTES 128
+int32_t metrpo_comm_get_unique_id(void* id_out /* METRPO_COMM_ID_BYTES */);
+int32_t metrpo_comm_init(metrpo_ctx* ctx, const void* id /* METRPO_COMM_ID_BYTES */, int32_t world, int32_t rank);
+int32_t metrpo_comm_destroy(metrpo_ctx* ctx);
+/* in-place sum over the ranks of the attached communicator, stream-ordered (advantage statistics, baseline normal equations) */
+int32_t metrpo_allreduce_sum_f64(metrpo_ctx* ctx, double* d_buf, int64_t count, void* stream);
+
+/* all-reduce(sum) hook for sharded runs WITHOUT an attached communicator (e.g. a gloo group in the CPU-side tests; takes
+ * precedence over the communicator when both are given): called on the host while enqueuing, must reduce `count`
  * float64 values at device pointer d_buf in place across ranks, ordered after prior work on
  * `stream` and before later work on it.  NULL = single rank. */
 typedef int32_t (*metrpo_allreduce_fn)(void* user, double* d_buf, int64_t count, void* stream);

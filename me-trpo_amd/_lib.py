@@ -74,6 +74,10 @@ SYMBOLS = {
     'metrpo_policy_actions': (_I, [_P, _P, _P, _I, _P, _P, _P]),
     'metrpo_step': (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     'metrpo_rollout': (_I, [_P, C.POINTER(RolloutArgs), _P]),
+    'metrpo_comm_get_unique_id': (_I, [_P]),
+    'metrpo_comm_init': (_I, [_P, _P, _I, _I]),
+    'metrpo_comm_destroy': (_I, [_P]),
+    'metrpo_allreduce_sum_f64': (_I, [_P, _P, _L, _P]),
     'metrpo_sampler_progress': (_I, [_P, _P, _P, _I, _I, _I, _L, _P, _P, _P, _P]),
     'metrpo_validation_cost': (_I, [_P, _P, _I, _I, _D, _P, _P]),
     'metrpo_gae': (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _D, _D, _P, _P, _P, _P, _P]),

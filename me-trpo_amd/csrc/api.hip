@@ -102,7 +102,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     c->d_bptt = nullptr; c->bptt_cap = 0; c->det_cfg = -1; c->d_detpart = nullptr; c->detpart_cap = 0; c->det_gemm = 0; c->d_dg = nullptr; c->dg_cap = 0; c->vjp_gm = nullptr; c->d_pol_adam = nullptr; c->pol_adam_t = 0; c->mfma_cfg = -1; c->pol_mfma = -1; c->coop_cfg = -1; c->rollout_variant = 0;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_cg = nullptr; c->d_vf = nullptr; c->d_theta_try = nullptr;
     c->d_valbuf = nullptr; c->h_pinned = nullptr; c->n_sm = 256;
-    c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0; c->d_ticket = nullptr; c->d_hcache = nullptr; c->hcache_cap = 0; c->hcache_on = 0; c->pol_path = 1; c->d_pg = nullptr; c->pg_cap = 0; c->pg_fwd_rows = -1; c->pg_fwd_obs = nullptr; c->d_adam = nullptr; c->adam_t = 0; c->d_train = nullptr; c->train_cap = 0;
+    c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0; c->d_ticket = nullptr; c->d_hcache = nullptr; c->hcache_cap = 0; c->hcache_on = 0; c->nccl_comm = nullptr; c->comm_world = 0; c->comm_rank = 0; c->pol_path = 1; c->d_pg = nullptr; c->pg_cap = 0; c->pg_fwd_rows = -1; c->pg_fwd_obs = nullptr; c->d_adam = nullptr; c->adam_t = 0; c->d_train = nullptr; c->train_cap = 0;
     ProblemDesc& pd = c->pd;
     pd.env = d->env; pd.ns = d->ns; pd.na = d->na; pd.K = d->n_models; pd.n_drop = d->n_drop;
     pd.nin = d->ns + d->na - d->n_drop;
@@ -141,6 +141,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
 
 extern "C" int32_t metrpo_destroy(metrpo_ctx* c) {
     if (!c) return METRPO_ENULL;
+    if (c->nccl_comm) (void)metrpo_comm_destroy(c);
     void* bufs[] = {c->d_dyn, c->d_norm, c->d_theta, c->d_vf, c->d_theta_try, c->d_cg, c->d_valbuf, c->d_partials,
                     c->d_dyn_img, c->d_pol_img, c->d_vbuf, c->d_gram_part, c->d_big, c->d_ticket, c->d_hcache, c->d_pg, c->d_adam, c->d_train, c->d_bptt, c->d_pol_adam, c->d_detpart, c->d_dg};
     for (void* p : bufs) if (p) (void)hipFree(p);
@@ -442,12 +443,14 @@ int run_trpo_update(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_para
     const int P = c->pd.P;
     CgView v = cg_view(c);
     int rc;
-#define AR(buf, n) do { if (pr->allreduce && (rc = pr->allreduce(pr->allreduce_user, (buf), (n), (void*)st)) != 0) \
-                            return set_err(c, METRPO_EINVAL, "allreduce callback failed"); } while (0)
+    // sum over ranks: the caller's callback if given, else the RCCL communicator attached to the ctx (comm.hip), else single rank
+#define AR(buf, n) do { if (pr->allreduce) { if ((rc = pr->allreduce(pr->allreduce_user, (buf), (n), (void*)st)) != 0) \
+                                                 return set_err(c, METRPO_EINVAL, "allreduce callback failed"); } \
+                        else if (c->nccl_comm) { if ((rc = comm_allreduce_f64(c, (buf), (n), st)) != 0) return rc; } } while (0)
     // krylov.cg with every vector step fused into the tail of the kernel that produced its input (no all-reduce in between) or
     // as stand-alone one-block kernels after the caller's all-reduce.  The step scale needs d.(H d): by default it is taken
     // from the CG recurrence (cg_device.h: A x = g - r), explicit_final_hvp = 1 spends the extra FVP rllab spends.
-    const bool fused = (pr->allreduce == nullptr);
+    const bool fused = (pr->allreduce == nullptr && c->nccl_comm == nullptr);
     const int implicit_hd = pr->explicit_final_hvp ? 0 : 1;
     CgTail tl; tl.P = P; tl.last = 0; tl.implicit_hd = implicit_hd; tl.reg = pr->reg_coeff; tl.tol = pr->residual_tol; tl.max_kl = pr->max_kl;
     tl.x = v.x; tl.r = v.r; tl.p = v.p; tl.z = v.z; tl.step = v.step; tl.scal = v.scal; tl.gout = v.gout; tl.pf = c->d_vf; tl.ticket = c->d_ticket;

@@ -66,6 +66,7 @@ struct metrpo_ctx {
     size_t gram_cap;
     unsigned int* d_ticket; // arrival counter of k_finalize's fused CG tail
     float* d_hcache; size_t hcache_cap; int hcache_on;   // activation cache of one CG solve (policy_mfma.hip MODE_FVPC)
+    void* nccl_comm; int comm_world, comm_rank;   // comm.hip: RCCL communicator attached by metrpo_comm_init (NULL: single rank)
     int pol_path;        // 1 auto (fused MFMA kernels where the shape has them, GEMM path for large N otherwise), 0 generic forced, 2 GEMM path forced
     void* d_pg; size_t pg_cap; long long pg_fwd_rows; const float* pg_fwd_obs;   // policy_gemm.hip workspace + validity of its cached forward pass
     void* d_adam;        // Adam moments [2][K][Pd] + loss accumulators (dyn_train.hip)
@@ -161,6 +162,7 @@ int launch_sampler_progress(metrpo_ctx*, const uint8_t*, const int32_t*, int, in
 int launch_gram(metrpo_ctx*, const float*, const float*, const int32_t*, const uint8_t*, int64_t, double*, double*,
                 hipStream_t);
 int launch_loss_grad(metrpo_ctx*, const metrpo_batch*, double*, hipStream_t, const CgTail* tail = nullptr);
+int comm_allreduce_f64(metrpo_ctx*, double* buf, long long count, hipStream_t);
 bool policy_gemm_applicable(const metrpo_ctx*, long long N);
 int policy_gemm_run(metrpo_ctx*, int mode, const metrpo_batch*, const PolK&, const float* theta, const float* vf, const double* v64, double* out,
                     const CgTail* tail, hipStream_t);

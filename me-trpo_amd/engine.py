@@ -70,6 +70,7 @@ class Engine(object):
         self.pol_dims = [self.ns] + self.pol_hidden + [self.na]
         self.has_mfma_path = bool(lib.metrpo_has_mfma_path(self._ctx))
         self._cb_keepalive = None
+        self.comm_world = 0                  # > 0 once comm_init attached an RCCL communicator
 
     def __del__(self):
         ctx = getattr(self, '_ctx', None)
@@ -90,6 +91,31 @@ class Engine(object):
         code = 2 if use_mfma == 'gemm' else int(bool(use_mfma))
         r = int(lib.metrpo_set_update_path(self._ctx, code))
         return 'gemm' if r == 2 else bool(r)
+
+    # ------------------------------------------------------------------ multi-GPU: RCCL communicator owned by the ctx
+    @staticmethod
+    def comm_unique_id():
+        """128 opaque bytes (ncclGetUniqueId) that rank 0 ships to the other ranks before every rank calls comm_init."""
+        buf = C.create_string_buffer(128)
+        check(lib.metrpo_comm_get_unique_id(buf), None)
+        return buf.raw
+
+    def comm_init(self, unique_id, world, rank):
+        """Collective: attach an RCCL communicator; metrpo_trpo_update then issues its all-reduces itself (no host callback)."""
+        assert len(unique_id) == 128
+        with torch.cuda.device(self.device):
+            self._chk(lib.metrpo_comm_init(self._ctx, C.c_char_p(unique_id), int(world), int(rank)))
+        self.comm_world = int(world)
+
+    def comm_destroy(self):
+        self._chk(lib.metrpo_comm_destroy(self._ctx))
+        self.comm_world = 0
+
+    def allreduce_sum_(self, t):
+        """In-place sum of a float64 device tensor over the ranks of the attached communicator (stream-ordered)."""
+        assert t.dtype == torch.float64 and t.is_cuda and t.is_contiguous()
+        self._chk(lib.metrpo_allreduce_sum_f64(self._ctx, _ptr(t), t.numel(), self._stream()))
+        return t
 
     def update_path(self, N):
         """Kernel family the policy update of an N-sample batch runs on: 'mfma' (fused), 'gemm' or 'generic'."""

@@ -94,7 +94,9 @@ class ConjugateGradientOptimizer(object):
     def optimize(self, engine_or_evaluator, batch=None, comm=None):
         comm = comm or Comm()
         if self._fused and batch is not None:
-            ar = (lambda t: comm.allreduce_sum_(t)) if (comm.world > 1 or comm.always_reduce) else None
+            # ranks > 1: the ctx's own RCCL communicator when one is attached (all-reduces issued from C), else a host callback
+            need = comm.world > 1 or comm.always_reduce
+            ar = (lambda t: comm.allreduce_sum_(t)) if (need and not getattr(engine_or_evaluator, 'comm_world', 0)) else None
             self.last_diag = engine_or_evaluator.trpo_update(
                 batch, max_kl=self._max_constraint_val, cg_iters=self._cg_iters, reg_coeff=self._reg_coeff,
                 backtrack_ratio=self._backtrack_ratio, max_backtracks=self._max_backtracks,

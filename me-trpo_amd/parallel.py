@@ -31,9 +31,26 @@ class Comm(object):
             torch.distributed.init_process_group(backend=backend)
         return Comm()
 
+    def attach_engine(self, engine):
+        """Bootstrap an RCCL communicator INSIDE the engine's ctx (rank 0's unique id is broadcast through torch.distributed
+        once): from then on the float64 sum all-reduces of the path go through libmetrpo.so itself -- metrpo_trpo_update issues
+        them from C with no host callback in the CG loop, and allreduce_sum_ below uses the same communicator."""
+        if self.dist is None or self.dist.get_backend(self.group) != 'nccl':
+            return False                                     # gloo (CPU-side tests): keep the torch.distributed callback path
+        uid = torch.zeros(128, dtype=torch.uint8, device=engine.device)
+        if self.rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(engine.comm_unique_id()), dtype=torch.uint8))
+        self.dist.broadcast(uid, src=0, group=self.group)
+        engine.comm_init(bytes(uid.cpu().numpy().tobytes()), self.world, self.rank)
+        self.engine = engine
+        return True
+
     def allreduce_sum_(self, t):
-        """In-place sum over ranks; stream-ordered with the caller's current stream (torch semantics)."""
+        """In-place sum over ranks; stream-ordered with the caller's current stream."""
         if self.world > 1 or self.always_reduce:
+            eng = getattr(self, 'engine', None)
+            if eng is not None and t.dtype == torch.float64 and t.is_cuda and t.is_contiguous():
+                return eng.allreduce_sum_(t)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t
 

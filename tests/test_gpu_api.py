@@ -191,6 +191,61 @@ def test_allreduce_callback_through_rccl_world1():
         dist.destroy_process_group()
 
 
+def test_attached_rccl_communicator_world1():
+    """metrpo_comm_init attaches an RCCL communicator to the ctx (here of size 1 -- a 1-GPU box): metrpo_trpo_update then issues
+    ncclAllReduce itself at every exchange point, with no host callback.  Must be bitwise equal to the single-rank fused run."""
+    import metrpo_amd
+    from test_gpu_engine import _update_problem
+    eng, th, pdims, obs, act, adv, om, ols = _update_problem(N=4000, seed=34)
+    batch = eng.make_batch(obs, act, adv, om, ols)
+    theta0 = eng.get_policy().clone()
+    ref = eng.trpo_update(batch, want_vectors=True)
+    theta_ref = eng.get_policy().clone()
+    eng.set_policy(theta0)
+    eng.comm_init(metrpo_amd.Engine.comm_unique_id(), 1, 0)
+    try:
+        assert eng.comm_world == 1
+        out = eng.trpo_update(batch, want_vectors=True)
+        assert torch.equal(eng.get_policy(), theta_ref) and torch.equal(out['g'], ref['g']) and torch.equal(out['d'], ref['d'])
+        assert out['n_backtrack'] == ref['n_backtrack'] and out['beta'] == ref['beta']
+        t = torch.arange(5, dtype=torch.float64, device='cuda')
+        assert torch.equal(eng.allreduce_sum_(t.clone()), t)
+        with pytest.raises(metrpo_amd._lib.MetrpoError, match='already attached'):
+            eng.comm_init(metrpo_amd.Engine.comm_unique_id(), 1, 0)
+    finally:
+        eng.comm_destroy()
+    with pytest.raises(metrpo_amd._lib.MetrpoError, match='no communicator'):
+        eng.allreduce_sum_(torch.zeros(2, dtype=torch.float64, device='cuda'))
+
+
+@pytest.mark.parametrize('path', ['mfma', 'gemm'])
+def test_two_ranks_equal_one_rank_fused_update(path, tmp_path):
+    """theta(2 ranks x N/2 samples) == theta(1 rank x N samples) for the fused HIP update (metrpo_trpo_update with the all-reduce
+    hook, two processes on this GPU over gloo): same g, d, beta, backtrack index and theta up to the float64 summation order."""
+    import os, subprocess, sys
+    from test_gpu_engine import _update_problem
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out_file = str(tmp_path / 'two_rank.npz')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29519', os.path.join(root, 'tests', '_two_rank_update.py'), out_file, path]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, MASTER_ADDR='127.0.0.1'), cwd=root)
+    assert res.returncode == 0, res.stderr[-3000:]
+    two = np.load(out_file)
+    eng, th, pdims, obs, act, adv, om, ols = _update_problem(N=6000, seed=29)
+    eng.set_update_path({'mfma': True, 'gemm': 'gemm'}[path])
+    one = eng.trpo_update(eng.make_batch(obs, act, adv, om, ols), want_vectors=True)
+    assert list(two['calls'][:1]) == [eng.P + 1] and list(two['calls']).count(eng.P) == 10
+    # the kernels sum float32 partials over different sample groupings on 1 and 2 ranks: float32-level (1e-7 relative) differences
+    # in g, amplified by the 10 CG iterations in d (SURVEY 8d allows rel-L2 1e-3 there)
+    np.testing.assert_allclose(two['g'], cpu(one['g']), rtol=0, atol=2e-6 * np.abs(cpu(one['g'])).max())
+    rel = np.linalg.norm(two['d'] - cpu(one['d'])) / np.linalg.norm(cpu(one['d']))
+    assert rel < 1e-3
+    assert abs(float(two['beta']) - one['beta']) < 1e-3 * one['beta'] and int(two['n_backtrack']) == one['n_backtrack']
+    assert bool(two['accepted']) and one['accepted']
+    step = np.abs(cpu(eng.get_policy()) - th).max()
+    np.testing.assert_allclose(two['theta'], cpu(eng.get_policy()), rtol=0, atol=2e-3 * step + 1e-7)
+
+
 def test_bench_two_ranks_on_one_gpu():
     """bench.py launched the way the driver launches it for N=2 (torch.distributed.run, one process per rank), with both
     ranks on cuda:0 over gloo: exercises the B-sharded control flow, every all-reduce of the TRPO driver, the barrier /
