@@ -35,7 +35,7 @@ struct Coop {
     static constexpr int WV = ((16 * NS * 2 + 16 * NA + 3) / 4) * 4;  // per wave: ST | NX | ACT
     static constexpr int O_BD0 = 4 * WV, O_BD1 = O_BD0 + K * 64, O_BD2 = O_BD1 + K * 64, O_BP0 = O_BD2 + K * NSP,
                          O_BP1 = O_BP0 + 32, O_BP2 = O_BP1 + 32, O_PW = O_BP2 + 16, O_H0 = O_PW + NPF * 64,
-                         O_PART = O_H0 + K * 1024, TOTAL = O_PART + K * 4 * 16 * NSP;
+                         O_PART = O_H0 + K * 1024, O_RNG = O_PART + K * 4 * 16 * NSP, TOTAL = O_RNG + 2 * 16 * 8;
 };
 
 template <int ENV, int K>
@@ -51,10 +51,13 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
     const bool active = b < r.B;
     const uint64_t genv = r.stream_offset + (uint64_t)b;
     if (r.stop != nullptr && *r.stop != 0) return;           // the sampling loop already ended (metrpo_sampler_progress)
-    float* ST = lds + wave * L::WV;  float* NX = ST + 16 * NS;  float* ACT = NX + 16 * NS;
+    float* ST = lds + wave * L::WV;  float* NX = ST + 16 * NS;
+    float* ACT = lds + 32 * NS;                                         // clipped actions of the tile: written by wave 0 (the policy wave), read by all
+
     float* BD0 = lds + L::O_BD0; float* BD1 = lds + L::O_BD1; float* BD2 = lds + L::O_BD2;
     float* BP0 = lds + L::O_BP0; float* BP1 = lds + L::O_BP1; float* BP2 = lds + L::O_BP2;
     float* PW = lds + L::O_PW; float* H0 = lds + L::O_H0; float* PART = lds + L::O_PART;
+    float* RNGB = lds + L::O_RNG;                                       // [2 parities][16 envs][dstep (4 x u32) | z (4 floats)]
 
     // ---------------- one-time: dynamics fragments -> registers ----------------------------------
     float wd0[K][C::NIN_KS], wd1[K][16], wd2[K][4][OUT_CB];
@@ -154,82 +157,109 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
         // Weight fragments of a layer are fetched as one batch BEFORE the activation of the previous layer is evaluated (the LDS
         // latency hides under the tanh VALU work), and each tanh is issued right before the MFMA pair that consumes it, so the
         // matrix pipe works through k-step kk while the VALU evaluates the activation of k-step kk+1.
-        f32x4 p0[2], p1[2];
-        {
-            float w0[C::NS_KS * 2], xs[C::NS_KS];
+        // The policy (30 MFMAs, 16 tanh per lane) is evaluated by wave 0 ONLY and its clipped action handed to the other waves through
+        // LDS (one more barrier per step).  Evaluating it redundantly in all 4 waves kept the step free of that barrier but cost
+        // 90 of the 580 MFMAs and three quarters of the tanh VALU work of a tile-step -- issue slots a co-resident workgroup can use.
+        if (!AHEAD) step_draws(r.t0 + t, dstep, z);                        // every wave needs the step's model / reset draws
+        // dynamics layer 0, k-steps that read only the STATE (inputs 4s..4s+3 all below ns - n_drop): independent of the action, so
+        // waves 1-3 run them while wave 0 evaluates the policy
+        constexpr int KS_STATE = (NS - C::NDROP) / 4;
+        f32x4 h0[K];
 #pragma unroll
-            for (int f = 0; f < C::NS_KS * 2; ++f) w0[f] = pw0[f * 64];
+        for (int k = 0; k < K; ++k) h0[k] = *(const f32x4*)&BD0[k * 64 + 16 * wave + 4 * q];
 #pragma unroll
-            for (int s = 0; s < C::NS_KS; ++s) { const int f = 4 * s + q; xs[s] = (f < NS) ? ST[e * NS + f] : 0.0f; }
-            p0[0] = *(const f32x4*)&BP0[4 * q]; p0[1] = *(const f32x4*)&BP0[16 + 4 * q];
+        for (int s = 0; s < KS_STATE; ++s) {
+            const float x = (ST[e * NS + nsrc[s]] - nmean[s]) * nstd[s];                  // training.py:228
 #pragma unroll
-            for (int s = 0; s < C::NS_KS; ++s) {
-                p0[0] = MFMA16(w0[2 * s], xs[s], p0[0]);
-                p0[1] = MFMA16(w0[2 * s + 1], xs[s], p0[1]);
+            for (int k = 0; k < K; ++k) h0[k] = MFMA16(wd0[k][s], x, h0[k]);
+        }
+        if (AHEAD && wave == 1) {
+            // Next step's Philox block + Box-Muller for the 16 envs of the tile, produced by wave 1 while wave 0 evaluates the policy
+            // (waves 1-3 have nothing else to do until the action exists) and handed over through LDS, double-buffered by step
+            // parity: every wave picks its copy up after barrier B2.  (It used to be dealt out in pieces between the layer-1 MFMAs
+            // of every wave: 16x redundant, and ~1000 cycles of VALU inside the phase two co-resident workgroups fight over.)
+            uint4 dn; float zn[4] = {0.f, 0.f, 0.f, 0.f};
+            step_draws(r.t0 + t + 1, dn, zn);
+            if (q == 0) {
+                float* dst = RNGB + (((t + 1) & 1) * 16 + e) * 8;
+                *(uint4*)dst = dn;
+                *(float4*)(dst + 4) = make_float4(zn[0], zn[1], zn[2], zn[3]);
             }
         }
-        f32x4 m0, m1 = {0.f, 0.f, 0.f, 0.f};
-        {
-            float w1[16];
+        if (wave == 0) {
+            f32x4 p0[2], p1[2];
+            {
+                float w0[C::NS_KS * 2], xs[C::NS_KS];
 #pragma unroll
-            for (int f = 0; f < 16; ++f) w1[f] = pw1[f * 64];
-            p1[0] = *(const f32x4*)&BP1[4 * q]; p1[1] = *(const f32x4*)&BP1[16 + 4 * q];
+                for (int f = 0; f < C::NS_KS * 2; ++f) w0[f] = pw0[f * 64];
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                const float hv = tanh_fast(p0[kk >> 2][kk & 3]);
-                p1[0] = MFMA16(w1[2 * kk], hv, p1[0]);
-                p1[1] = MFMA16(w1[2 * kk + 1], hv, p1[1]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        {
-            float w2[8];
+                for (int s = 0; s < C::NS_KS; ++s) { const int f = 4 * s + q; xs[s] = (f < NS) ? ST[e * NS + f] : 0.0f; }
+                p0[0] = *(const f32x4*)&BP0[4 * q]; p0[1] = *(const f32x4*)&BP0[16 + 4 * q];
 #pragma unroll
-            for (int f = 0; f < 8; ++f) w2[f] = pw2[f * 64];
-            m0 = *(const f32x4*)&BP2[4 * q];
-#pragma unroll
-            for (int kk = 0; kk < 8; kk += 2) {
-                const float ha = tanh_fast(p1[kk >> 2][kk & 3]);
-                m0 = MFMA16(w2[kk], ha, m0);
-                const float hb = tanh_fast(p1[(kk + 1) >> 2][(kk + 1) & 3]);
-                m1 = MFMA16(w2[kk + 1], hb, m1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        const f32x4 mu = m0 + m1;
-        PH_MARK(0)
-        if (!AHEAD) step_draws(r.t0 + t, dstep, z);
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int d = 4 * q + rr;
-            if (d < NA) {
-                float a = mu[rr];
-                if (!r.determ) {
-                    const float zz = (r.eps != nullptr) ? (active ? r.eps[tb * NA + d] : 0.0f) : z[rr];
-                    a = fmaf(zz, sig[rr], a);
+                for (int s = 0; s < C::NS_KS; ++s) {
+                    p0[0] = MFMA16(w0[2 * s], xs[s], p0[0]);
+                    p0[1] = MFMA16(w0[2 * s + 1], xs[s], p0[1]);
                 }
-                if (wave == 1 && active) { r.act[tb * NA + d] = a; r.mean[tb * NA + d] = mu[rr]; }
-                const float ac = fminf(fmaxf(a, -1.0f), 1.0f);            // env_helpers.py:599
-                ACT[e * NA + d] = ac;
+            }
+            f32x4 m0, m1 = {0.f, 0.f, 0.f, 0.f};
+            {
+                float w1[16];
+#pragma unroll
+                for (int f = 0; f < 16; ++f) w1[f] = pw1[f * 64];
+                p1[0] = *(const f32x4*)&BP1[4 * q]; p1[1] = *(const f32x4*)&BP1[16 + 4 * q];
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const float hv = tanh_fast(p0[kk >> 2][kk & 3]);
+                    p1[0] = MFMA16(w1[2 * kk], hv, p1[0]);
+                    p1[1] = MFMA16(w1[2 * kk + 1], hv, p1[1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            {
+                float w2[8];
+#pragma unroll
+                for (int f = 0; f < 8; ++f) w2[f] = pw2[f * 64];
+                m0 = *(const f32x4*)&BP2[4 * q];
+#pragma unroll
+                for (int kk = 0; kk < 8; kk += 2) {
+                    const float ha = tanh_fast(p1[kk >> 2][kk & 3]);
+                    m0 = MFMA16(w2[kk], ha, m0);
+                    const float hb = tanh_fast(p1[(kk + 1) >> 2][(kk + 1) & 3]);
+                    m1 = MFMA16(w2[kk + 1], hb, m1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            const f32x4 mu = m0 + m1;
+            PH_MARK(0)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int d = 4 * q + rr;
+                if (d < NA) {
+                    float a = mu[rr];
+                    if (!r.determ) {
+                        const float zz = (r.eps != nullptr) ? (active ? r.eps[tb * NA + d] : 0.0f) : z[rr];
+                        a = fmaf(zz, sig[rr], a);
+                    }
+                    if (active) { r.act[tb * NA + d] = a; r.mean[tb * NA + d] = mu[rr]; }
+                    const float ac = fminf(fmaxf(a, -1.0f), 1.0f);            // env_helpers.py:599
+                    ACT[e * NA + d] = ac;
+                }
             }
         }
-        wave_lds_sync();
+        __syncthreads();                                                   // B0: actions visible
         PH_MARK(1)
         // ---- dynamics layer 0, col-block `wave`, all K heads ------------------------------------------
         {
             float xin[C::NIN_KS];
 #pragma unroll
-            for (int s = 0; s < C::NIN_KS; ++s) {
+            for (int s = KS_STATE; s < C::NIN_KS; ++s) {
                 float x = 0.0f;
                 if (nsrc[s] >= 0) x = ST[e * NS + nsrc[s]];
                 else if (nsrc[s] > -1000000) x = ACT[e * NA + (-nsrc[s] - 1)];
                 xin[s] = (nsrc[s] > -1000000) ? (x - nmean[s]) * nstd[s] : 0.0f;          // training.py:228
             }
-            f32x4 h0[K];
 #pragma unroll
-            for (int k = 0; k < K; ++k) h0[k] = *(const f32x4*)&BD0[k * 64 + 16 * wave + 4 * q];
-#pragma unroll
-            for (int s = 0; s < C::NIN_KS; ++s)
+            for (int s = KS_STATE; s < C::NIN_KS; ++s)
 #pragma unroll
                 for (int k = 0; k < K; ++k) h0[k] = MFMA16(wd0[k][s], xin[s], h0[k]);
 #pragma unroll
@@ -248,44 +278,6 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
 #pragma unroll
             for (int j = 0; j < (16 * NS + 63) / 64; ++j) { const int i = lane + 64 * j; if (i < lim) r.obs[base + i] = ST[i]; }
         }
-        uint4 dstep_n; float z_n[4] = {0.f, 0.f, 0.f, 0.f};
-        // Next step's draws, cut into RNG_PIECES pieces (10 Philox rounds + 3 Box-Muller stages; same arithmetic as rng_draw / normal2)
-        // that are dealt out between the groups of K independent MFMAs below: each piece issues in the matrix pipe's shadow.
-        uint4 pc0, pc1, pc2; uint32_t pk0 = 0, pk1 = 0; float bm_r[2] = {0.f, 0.f}, bm_a[2] = {0.f, 0.f};
-        auto rng_piece = [&](int i) {
-            if (!AHEAD) return;
-            if (i == 0) {
-                const uint32_t tt = (uint32_t)(r.t0 + t + 1);
-                pk0 = (uint32_t)r.seed; pk1 = (uint32_t)(r.seed >> 32);
-                pc0 = make_uint4((uint32_t)genv, (uint32_t)(genv >> 32), tt, ((uint32_t)RNG_STEP << 16));
-                pc1 = make_uint4((uint32_t)genv, (uint32_t)(genv >> 32), tt, ((uint32_t)RNG_STEP << 16) | (uint32_t)(2 * q + 1));
-                pc2 = make_uint4((uint32_t)genv, (uint32_t)(genv >> 32), tt, ((uint32_t)RNG_STEP << 16) | (uint32_t)(2 * q));
-            }
-            if (i < 10) {
-                auto rnd = [&](uint4& c) {
-                    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-                    const uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x, hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
-                    c = make_uint4(hi1 ^ c.y ^ pk0, lo1, hi0 ^ c.w ^ pk1, lo0);
-                };
-                rnd(pc0);
-                if (NA > 2) rnd(pc1);
-                if (NA > 4) rnd(pc2);
-                pk0 += 0x9E3779B9u; pk1 += 0xBB67AE85u;
-            } else if (i == 10) {
-                const float S = 2.3283064365386963e-10f;
-                const uint4 a = (NA > 4 && q != 0) ? pc2 : pc0;
-                bm_r[0] = -2.0f * __logf(((float)a.x + 0.5f) * S); bm_a[0] = 6.283185307179586f * (((float)a.y + 0.5f) * S);
-                if (NA > 2) { bm_r[1] = -2.0f * __logf(((float)pc1.x + 0.5f) * S); bm_a[1] = 6.283185307179586f * (((float)pc1.y + 0.5f) * S); }
-            } else if (i == 11) {
-                bm_r[0] = sqrtf(bm_r[0]);
-                if (NA > 2) bm_r[1] = sqrtf(bm_r[1]);
-            } else if (i == 12) {
-                float sn, cs;
-                __sincosf(bm_a[0], &sn, &cs); z_n[0] = bm_r[0] * cs; z_n[1] = bm_r[0] * sn;
-                if (NA > 2) { __sincosf(bm_a[1], &sn, &cs); z_n[2] = bm_r[1] * cs; z_n[3] = bm_r[1] * sn; }
-                dstep_n = pc0;
-            }
-        };
         float su2 = 0.0f;                                                  // sum_d clip(a_d)^2 of the own env (ACT is complete since B1)
 #pragma unroll
         for (int d = 0; d < NA; ++d) { const float ac = ACT[e * NA + d]; su2 = fmaf(ac, ac, su2); }
@@ -303,7 +295,6 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
             for (int rr = 0; rr < 4; ++rr) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) h1[k] = MFMA16(wd1[k][cb * 4 + rr], hb[k][rr], h1[k]);
-                rng_piece(cb * 4 + rr);
                 __builtin_amdgcn_sched_barrier(0x94);                      // only SALU / VMEM / LDS instructions may cross
             }
         }
@@ -456,10 +447,11 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
                     if (dim < NS) ST[e * NS + dim] = nx[cb][rr];
                 }
         }
-        if (AHEAD) {
-            dstep = dstep_n;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) z[rr] = z_n[rr];
+        if (AHEAD) {                                                       // written by wave 1 before B0 of this step
+            const float* src = RNGB + (((t + 1) & 1) * 16 + e) * 8;
+            dstep = *(const uint4*)src;
+            const float4 zf = *(const float4*)(src + 4);
+            z[0] = zf.x; z[1] = zf.y; z[2] = zf.z; z[3] = zf.w;
         }
         wave_lds_sync();
         PH_MARK(8)

@@ -111,8 +111,12 @@ def dynamics_variable_names(n_layers, model):
     return names
 
 
-def save_dynamics_npz(path, engine):
-    """All K models + normalisers under the reference's variable names (the payload of <scope>_<i>.ckpt, as .npz)."""
+def save_dynamics_npz(path, engine, input_rms=None, diff_rms=None, scope='training_dynamics'):
+    """All K models AND the running normalisers under the reference's TF variable names -- the payload of the checkpoint the
+    reference writes (model_based_rl.py:728; variables training.py:183-194 and running_mean_std.py:5-20):
+        <scope>/model<k>/layer<l>/weights | biases,   input_rms/runningsum | runningsumsq | count,   diff_rms/...
+    input_rms / diff_rms: dynamics_training.RunningMeanStd objects (their sums are what TF checkpoints hold); without them
+    the file carries weights only and load_dynamics_npz needs the normalisers supplied."""
     flat = engine.get_dynamics().detach().cpu().numpy()
     dims = [engine.ns + engine.na - engine.n_drop] + list(engine.dyn_hidden) + [engine.ns]
     arrs, L = {}, len(dims) - 1
@@ -120,18 +124,43 @@ def save_dynamics_npz(path, engine):
         o = 0
         for l in range(L):
             n = dims[l] * dims[l + 1]
-            arrs['model%d/layer%d/weights' % (k, l)] = flat[k, o:o + n].reshape(dims[l], dims[l + 1]); o += n
-            arrs['model%d/layer%d/biases' % (k, l)] = flat[k, o:o + dims[l + 1]]; o += dims[l + 1]
+            arrs['%s/model%d/layer%d/weights' % (scope, k, l)] = flat[k, o:o + n].reshape(dims[l], dims[l + 1]); o += n
+            arrs['%s/model%d/layer%d/biases' % (scope, k, l)] = flat[k, o:o + dims[l + 1]]; o += dims[l + 1]
+    for name, rms in (('input_rms', input_rms), ('diff_rms', diff_rms)):
+        if rms is not None:
+            arrs[name + '/runningsum'] = rms._sum.detach().cpu().numpy()
+            arrs[name + '/runningsumsq'] = rms._sumsq.detach().cpu().numpy()
+            arrs[name + '/count'] = np.array(rms._count, dtype=np.float64)
     np.savez(path, **arrs)
 
 
-def load_dynamics_npz(path, engine):
+def load_dynamics_npz(path, engine, input_rms=None, diff_rms=None, scope='training_dynamics'):
+    """Inverse of save_dynamics_npz; works on a FRESH engine (one set_dynamics call with all K models and the normalisers).
+    If the file holds the running sums they are restored into input_rms / diff_rms (when given) and mean/std (0.1 floor,
+    running_mean_std.py:22-27) are derived from them; otherwise the given objects supply the normalisers."""
+    import torch
     z = np.load(path)
     dims = [engine.ns + engine.na - engine.n_drop] + list(engine.dyn_hidden) + [engine.ns]
     L = len(dims) - 1
-    import torch
+    pref = scope + '/' if ('%s/model0/layer0/weights' % scope) in z.files else ''      # files written before the scope prefix
+    rows = []
     for k in range(engine.K):
         parts = []
         for l in range(L):
-            parts += [z['model%d/layer%d/weights' % (k, l)].reshape(-1), z['model%d/layer%d/biases' % (k, l)].reshape(-1)]
-        engine.set_dynamics_model(k, torch.as_tensor(np.concatenate(parts).astype(np.float32), device=engine.device))
+            parts += [z['%smodel%d/layer%d/weights' % (pref, k, l)].reshape(-1), z['%smodel%d/layer%d/biases' % (pref, k, l)].reshape(-1)]
+        rows.append(np.concatenate(parts))
+    stats = {}
+    for name, rms in (('input_rms', input_rms), ('diff_rms', diff_rms)):
+        if name + '/runningsum' in z.files:
+            rsum, rsq, cnt = z[name + '/runningsum'], z[name + '/runningsumsq'], float(z[name + '/count'])
+            if rms is not None:
+                rms._sum.copy_(torch.as_tensor(rsum)); rms._sumsq.copy_(torch.as_tensor(rsq)); rms._count = cnt
+            mean = rsum / cnt
+            stats[name] = (mean, np.sqrt(np.maximum(rsq / cnt - mean * mean, 1e-2)))
+        elif rms is not None:
+            stats[name] = (rms.mean.cpu().numpy(), rms.std.cpu().numpy())
+        else:
+            raise KeyError("%s holds no %s statistics and none were supplied" % (path, name))
+    ns = engine.ns
+    engine.set_dynamics(torch.as_tensor(np.stack(rows).astype(np.float32)), stats['input_rms'][0], stats['input_rms'][1],
+                        stats['diff_rms'][0][:ns], stats['diff_rms'][1][:ns])

@@ -203,20 +203,30 @@ def test_optimize_models_loop_fits_and_restores_best():
 
 
 def test_dynamics_npz_round_trip(tmp_path):
-    """formats.save_dynamics_npz / load_dynamics_npz: the payload of the reference's <scope>_<i>.ckpt savers under its variable names."""
+    """formats.save_dynamics_npz / load_dynamics_npz: weights AND running-normaliser sums under the reference's TF variable names
+    (model_based_rl.py:728 checkpoint payload); restoring into a FRESH engine reproduces the predictions."""
     import metrpo_amd
     from metrpo_amd import formats
+    from metrpo_amd.dynamics_training import RunningMeanStd, push_normalizers
     eng, dm, theta, pdims, pool = Hh.make_engine('swimmer', 3, (24, 16), (8, 8), seed=77)
-    p = str(tmp_path / 'training_dynamics.npz')
-    formats.save_dynamics_npz(p, eng)
+    rng = np.random.RandomState(1)
+    r_in, r_diff = RunningMeanStd(eng, epsilon=0.0, shape=(12,)), RunningMeanStd(eng, epsilon=0.0, shape=(10,))
+    r_in.update((rng.randn(300, 12) * 1.7 + 0.4).astype(np.float32)); r_diff.update((rng.randn(300, 10) * 0.3).astype(np.float32))
+    push_normalizers(eng, r_in, r_diff)
+    p = str(tmp_path / 'policy-and-models-0.npz')
+    formats.save_dynamics_npz(p, eng, r_in, r_diff)
     z = np.load(p)
-    assert sorted(z.files)[:2] == ['model0/layer0/biases', 'model0/layer0/weights']
-    np.testing.assert_array_equal(z['model2/layer1/weights'], dm.Ws[1][2].astype(np.float32))
-    before = eng.get_dynamics().clone()
-    for k in range(3):
-        eng.set_dynamics_model(k, torch.zeros_like(before[k]))
-    formats.load_dynamics_npz(p, eng)
-    assert torch.equal(eng.get_dynamics(), before)
+    assert 'training_dynamics/model0/layer0/weights' in z.files and 'input_rms/runningsum' in z.files and 'diff_rms/count' in z.files
+    np.testing.assert_array_equal(z['training_dynamics/model2/layer1/weights'], dm.Ws[1][2].astype(np.float32))
+    s, a = pool[:32].astype(np.float32), (rng.rand(32, 2) * 2 - 1).astype(np.float32)
+    want = eng.step(s, a, 'one_model', None, None, want_all=True)[3].clone()
+    fresh = metrpo_amd.Engine('swimmer', 3, (24, 16), (8, 8))                  # never saw set_dynamics
+    f_in, f_diff = RunningMeanStd(fresh, epsilon=0.0, shape=(12,)), RunningMeanStd(fresh, epsilon=0.0, shape=(10,))
+    formats.load_dynamics_npz(p, fresh, f_in, f_diff)
+    fresh.set_policy(theta)
+    assert torch.equal(fresh.get_dynamics(), eng.get_dynamics())
+    assert torch.equal(fresh.step(s, a, 'one_model', None, None, want_all=True)[3], want)
+    assert torch.equal(f_in._sum, r_in._sum) and f_in._count == r_in._count and torch.equal(f_diff.std, r_diff.std)
 
 
 def test_reference_own_buffer_tests_on_the_device_collection():
