@@ -35,11 +35,13 @@ struct Coop {
     static constexpr int WV = ((16 * NS * 2 + 16 * NA + 3) / 4) * 4;  // per wave: ST | NX | ACT
     static constexpr int O_BD0 = 4 * WV, O_BD1 = O_BD0 + K * 64, O_BD2 = O_BD1 + K * 64, O_BP0 = O_BD2 + K * NSP,
                          O_BP1 = O_BP0 + 32, O_BP2 = O_BP1 + 32, O_PW = O_BP2 + 16, O_H0 = O_PW + NPF * 64,
-                         O_PART = O_H0 + K * 1024, O_RNG = O_PART + K * 4 * 16 * NSP, TOTAL = O_RNG + 2 * 16 * 8;
+                         O_PART = O_H0 + K * 1024, O_RNG = O_PART + K * 4 * 16 * NSP, TOTAL = O_RNG + 2 * 16 * 20;
 };
 
-template <int ENV, int K>
-__global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float* __restrict__ dynp,
+// ONE: instantiation for launches with at most one tile per CU -- the whole register file (512 lanes-wide registers per SIMD) belongs to
+// one workgroup, so the half-cheetah / Ant weight fragments (150 VGPRs) stop spilling to scratch.
+template <int ENV, int K, bool ONE>
+__global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, const float* __restrict__ dynp,
                                                       const float* __restrict__ theta, const float* __restrict__ norm) {
     using L = Coop<ENV, K>;
     using C = typename L::C;
@@ -57,7 +59,7 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
     float* BD0 = lds + L::O_BD0; float* BD1 = lds + L::O_BD1; float* BD2 = lds + L::O_BD2;
     float* BP0 = lds + L::O_BP0; float* BP1 = lds + L::O_BP1; float* BP2 = lds + L::O_BP2;
     float* PW = lds + L::O_PW; float* H0 = lds + L::O_H0; float* PART = lds + L::O_PART;
-    float* RNGB = lds + L::O_RNG;                                       // [2 parities][16 envs][dstep (4 x u32) | z (4 floats)]
+    float* RNGB = lds + L::O_RNG;                                       // [2 parities][16 envs][dstep (4 x u32) | z of q-lane 0..3 (4 floats each)]
 
     // ---------------- one-time: dynamics fragments -> registers ----------------------------------
     float wd0[K][C::NIN_KS], wd1[K][16], wd2[K][4][OUT_CB];
@@ -145,8 +147,7 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
     };
     constexpr bool LOCAL_REWARD = (ENV == METRPO_ENV_SWIMMER || ENV == METRPO_ENV_HALF_CHEETAH || ENV == METRPO_ENV_SNAKE);
     constexpr int RDIM = (ENV == METRPO_ENV_SWIMMER) ? 5 : (ENV == METRPO_ENV_HALF_CHEETAH) ? 9 : 7;   // reward reads next_state[RDIM]
-    // one-step-ahead pipelining only where it fits the register budget (one Philox block per step: na <= 2)
-    constexpr bool AHEAD = (NA <= 2);
+    constexpr bool AHEAD = true;        // the draws of step t+1 are produced during step t (by wave 1, below) for every env family
     uint4 dstep = make_uint4(0, 0, 0, 0); float z[4] = {0.f, 0.f, 0.f, 0.f};
     if (AHEAD) step_draws(r.t0, dstep, z);
     PH_DECL
@@ -180,11 +181,9 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
             // of every wave: 16x redundant, and ~1000 cycles of VALU inside the phase two co-resident workgroups fight over.)
             uint4 dn; float zn[4] = {0.f, 0.f, 0.f, 0.f};
             step_draws(r.t0 + t + 1, dn, zn);
-            if (q == 0) {
-                float* dst = RNGB + (((t + 1) & 1) * 16 + e) * 8;
-                *(uint4*)dst = dn;
-                *(float4*)(dst + 4) = make_float4(zn[0], zn[1], zn[2], zn[3]);
-            }
+            float* dst = RNGB + (((t + 1) & 1) * 16 + e) * 20;
+            if (q == 0) *(uint4*)dst = dn;
+            *(float4*)(dst + 4 + 4 * q) = make_float4(zn[0], zn[1], zn[2], zn[3]);          // lane q owns action dims 4q .. 4q+3
         }
         if (wave == 0) {
             f32x4 p0[2], p1[2];
@@ -448,9 +447,9 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
                 }
         }
         if (AHEAD) {                                                       // written by wave 1 before B0 of this step
-            const float* src = RNGB + (((t + 1) & 1) * 16 + e) * 8;
+            const float* src = RNGB + (((t + 1) & 1) * 16 + e) * 20;
             dstep = *(const uint4*)src;
-            const float4 zf = *(const float4*)(src + 4);
+            const float4 zf = *(const float4*)(src + 4 + 4 * q);
             z[0] = zf.x; z[1] = zf.y; z[2] = zf.z; z[3] = zf.w;
         }
         wave_lds_sync();
@@ -469,8 +468,8 @@ __global__ void __launch_bounds__(256, 2) k_rollout_coop(RolloutK r, const float
 
 // -------------------------------------------------------------------------------------------------
 typedef void (*coop_kernel_t)(RolloutK, const float*, const float*, const float*);
-struct CoopEntry { int env, K; coop_kernel_t kern; int lds_floats; };
-#define CENTRY(ENVID, KK) {ENVID, KK, k_rollout_coop<ENVID, KK>, Coop<ENVID, KK>::TOTAL}
+struct CoopEntry { int env, K; coop_kernel_t kern, kern_one; int lds_floats; };
+#define CENTRY(ENVID, KK) {ENVID, KK, k_rollout_coop<ENVID, KK, false>, k_rollout_coop<ENVID, KK, true>, Coop<ENVID, KK>::TOTAL}
 static const CoopEntry kCoop[] = {
     CENTRY(METRPO_ENV_SWIMMER, 5), CENTRY(METRPO_ENV_HALF_CHEETAH, 5), CENTRY(METRPO_ENV_HOPPER, 5),
     CENTRY(METRPO_ENV_SNAKE, 5), CENTRY(METRPO_ENV_ANT, 5),
@@ -488,8 +487,10 @@ int coop_select_config(metrpo_ctx* c) {
 int launch_rollout_coop(metrpo_ctx* c, int idx, const RolloutK& r, hipStream_t st) {
     const CoopEntry& en = kCoop[idx];
     const size_t sh = sizeof(float) * (size_t)en.lds_floats;
-    if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)en.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    hipLaunchKernelGGL(en.kern, dim3((r.B + 15) / 16), dim3(256), sh, st, r, c->d_dyn, c->d_theta, c->d_norm);
+    const int tiles = (r.B + 15) / 16;
+    const coop_kernel_t kern = (tiles <= c->n_sm) ? en.kern_one : en.kern;       // one tile per CU at most: the spill-free instantiation
+    if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), sh, st, r, c->d_dyn, c->d_theta, c->d_norm);
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;
 }
