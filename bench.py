@@ -137,10 +137,10 @@ def main():
     upd_achieved = upd_flops / (upd_ms * 1e-3) / 1e12
     variant = eng.rollout_path()
     traffic, traffic_src = None, None                           # HBM bytes per rollout launch: rocprofv3 PMC, measured OFFLINE (profiles/)
-    tpath = os.path.join(REPO, 'profiles', 'r01_rollout_traffic.json')
+    tpath = os.path.join(REPO, 'profiles', 'r02_rollout_traffic.json')
     if args.config == 'C1' and variant == 2 and os.path.exists(tpath):
         traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
-        traffic_src = 'profiles/r01_rollout_traffic.json (rocprofv3 --pmc, offline run of the same launch)'
+        traffic_src = 'profiles/r02_rollout_traffic.json (rocprofv3 --pmc, offline run of the same launch)'
     out = {
         "metric": "imagined env-steps/sec (KxBxH) over the full TRPO iteration", "value": units_per_step / (dt / args.steps),
         "unit": "env-steps/s", "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup,

@@ -166,6 +166,17 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
         float xB[NS_KS];
 #pragma unroll
         for (int s = 0; s < NS_KS; ++s) { const int f = 4 * s + q; xB[s] = (inr && f < NS) ? k.obs[n * NS + f] : 0.f; }
+        // the sample-contracted products of S7 read the observations transposed ([feature 16ci + c][sample 4s + q]): fetched HERE, at
+        // the top of the tile, so that their global-memory latency is covered by the whole forward / back-prop chain
+        float xTs[4][NSI];
+        if (MODE != MODE_LOSSKL) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const long long ns_ = n0 + 4 * s + q;
+#pragma unroll
+                for (int ci = 0; ci < NSI; ++ci) { const int f = 16 * ci + c; xTs[s][ci] = (ns_ < k.N && f < NS) ? k.obs[ns_ * NS + f] : 0.f; }
+            }
+        }
         float* T_H0 = TL, *T_H1 = TL + HB * TILE, *T_D1 = TL + 2 * HB * TILE, *T_D0 = TL + 3 * HB * TILE, *T_UM = TL + 4 * HB * TILE;
         // ---- S1: layer 0, forward and (FVP) tangent  ------------------------------------------------------
         f32x4 h0[HB], h1[HB], t0[HB], t1[HB];
@@ -379,9 +390,8 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
             float a1_[HB], a0_[HB], b1_[HB], b0_[HB], xT[NSI];
 #pragma unroll
             for (int cb = 0; cb < HB; ++cb) { a1_[cb] = T_H1[cb * TILE + col]; a0_[cb] = T_H0[cb * TILE + col]; b1_[cb] = T_D1[cb * TILE + col]; b0_[cb] = T_D0[cb * TILE + col]; }
-            const long long ns_ = n0 + 4 * s + q;
 #pragma unroll
-            for (int ci = 0; ci < NSI; ++ci) { const int f = 16 * ci + c; xT[ci] = (ns_ < k.N && f < NS) ? k.obs[ns_ * NS + f] : 0.f; }
+            for (int ci = 0; ci < NSI; ++ci) xT[ci] = xTs[s][ci];
             if (!L2V) {
 #pragma unroll
                 for (int ci = 0; ci < HB; ++ci) gW2[ci] = MFMA16(a1_[ci], bu, gW2[ci]);
