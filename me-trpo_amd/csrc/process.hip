@@ -27,41 +27,90 @@ __global__ void k_baseline_predict(const float* __restrict__ obs, const int32_t*
 }
 
 #define GAE_CHUNK 10
-__global__ void k_gae(const double* __restrict__ V, const float* __restrict__ rew, const uint8_t* __restrict__ done,
-                      int T, int B, double gamma, double lam, float* __restrict__ adv, float* __restrict__ ret,
-                      uint8_t* __restrict__ valid, double* __restrict__ stats) {
-    __shared__ double red[16];
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    double s1 = 0.0, s2 = 0.0, cnt = 0.0;
-    if (b < B) {
-        double a_next = 0.0, v_next = 0.0, r_next = 0.0;
-        bool complete = false;            // true from the last done of the column backwards: those samples are whole paths
-        for (int t1 = T; t1 > 0; t1 -= GAE_CHUNK) {
-            // issue the loads of a whole chunk before entering the (dependent) recurrence
-            float rr[GAE_CHUNK]; uint8_t dd[GAE_CHUNK]; double vv[GAE_CHUNK];
+#define GAE_NW 4          // wavefronts per 64-env tile = time chunks scanned concurrently
+
+// One reverse pass over the steps [t_lo, t_hi) of env column b, starting from the carry (a_next, v_next, r_next, complete) of step t_hi:
+// the arithmetic of samplers/base.py:57-64 in float64.  WRITE = false only returns the carry at t_lo (chunk aggregate).
+template <bool WRITE>
+__device__ __forceinline__ void gae_chunk_pass(const double* __restrict__ V, const float* __restrict__ rew, const uint8_t* __restrict__ done,
+                                               int t_lo, int t_hi, int B, int b, double gamma, double lam, double& a_next, double& v_next,
+                                               double& r_next, bool& complete, float* __restrict__ adv, float* __restrict__ ret,
+                                               uint8_t* __restrict__ valid, double& s1, double& s2, double& cnt) {
+    for (int t1 = t_hi; t1 > t_lo; t1 -= GAE_CHUNK) {
+        // issue the loads of a whole chunk before entering the (dependent) recurrence
+        float rr[GAE_CHUNK]; uint8_t dd[GAE_CHUNK]; double vv[GAE_CHUNK];
 #pragma unroll
-            for (int u = 0; u < GAE_CHUNK; ++u) {
-                const int t = t1 - 1 - u;
-                const size_t tb = (size_t)(t < 0 ? 0 : t) * B + b;
-                rr[u] = rew[tb]; dd[u] = done[tb]; vv[u] = (V != nullptr) ? V[tb] : 0.0;
-            }
+        for (int u = 0; u < GAE_CHUNK; ++u) {
+            const int t = t1 - 1 - u;
+            const size_t tb = (size_t)(t < t_lo ? t_lo : t) * B + b;
+            rr[u] = rew[tb]; dd[u] = done[tb]; vv[u] = (V != nullptr) ? V[tb] : 0.0;
+        }
 #pragma unroll
-            for (int u = 0; u < GAE_CHUNK; ++u) {
-                const int t = t1 - 1 - u;
-                if (t >= 0) {
+        for (int u = 0; u < GAE_CHUNK; ++u) {
+            const int t = t1 - 1 - u;
+            if (t >= t_lo) {
+                if (dd[u]) { a_next = 0.0; v_next = 0.0; r_next = 0.0; complete = true; }   // path_baselines = append(V, 0), base.py:58
+                const double r = (double)rr[u], v = vv[u];
+                const double delta = r + gamma * v_next - v;                               // base.py:59-61
+                const double a = delta + gamma * lam * a_next;                             // discount_cumsum(deltas, g*lam), :62-63
+                const double g = r + gamma * r_next;                                       // discount_cumsum(rewards, g), :64
+                if (WRITE) {
                     const size_t tb = (size_t)t * B + b;
-                    if (dd[u]) { a_next = 0.0; v_next = 0.0; r_next = 0.0; complete = true; }   // path_baselines = append(V, 0), base.py:58
-                    const double r = (double)rr[u], v = vv[u];
-                    const double delta = r + gamma * v_next - v;                               // base.py:59-61
-                    const double a = delta + gamma * lam * a_next;                             // discount_cumsum(deltas, g*lam), :62-63
-                    const double g = r + gamma * r_next;                                       // discount_cumsum(rewards, g), :64
                     adv[tb] = (float)a; ret[tb] = (float)g; valid[tb] = complete ? 1 : 0;
                     if (complete) { s1 += a; s2 += a * a; cnt += 1.0; }
-                    a_next = a; v_next = v; r_next = g;
                 }
+                a_next = a; v_next = v; r_next = g;
             }
         }
     }
+}
+
+// GAE / returns as a prefix sum ACROSS wavefronts (reduce-then-scan over time): a 64-env tile is handled by GAE_NW waves, wave w owning
+// the time chunk [w*Tc, (w+1)*Tc) with one lane per env (time-major rows -> coalesced).  The reverse recurrences
+//     a_t = delta_t + g*lam*a_{t+1},  ret_t = r_t + g*ret_{t+1}     (reset at every done)
+// are affine in the carry that enters a chunk from later time, so
+//   pass 1  every wave scans its chunk with a ZERO carry and publishes the chunk aggregate (carry it hands to the earlier chunk for a
+//           zero carry-in, the coefficients by which a non-zero carry-in would change it, whether a done cut the dependence);
+//   combine after one barrier every wave composes the aggregates of the later chunks (<= GAE_NW-1 fused multiply-adds per env);
+//   pass 2  every wave rescans its chunk from its true carry with exactly the float64 arithmetic of the sequential scan and writes
+//           adv / ret / valid (equal to a single sequential pass up to float64 rounding of the composed carry).
+// The dependent chain per env is 2*T/GAE_NW steps instead of T, and 4x as many waves are in flight.
+__global__ void __launch_bounds__(64 * GAE_NW) k_gae(const double* __restrict__ V, const float* __restrict__ rew, const uint8_t* __restrict__ done,
+                                                      int T, int B, double gamma, double lam, float* __restrict__ adv, float* __restrict__ ret,
+                                                      uint8_t* __restrict__ valid, double* __restrict__ stats) {
+    __shared__ double red[16];
+    __shared__ double agg[GAE_NW][5][64];           // per chunk and env: A0, G0, v_first, CA, CG   (carry-out = A0 + CA*E_in, G0 + CG*r_in)
+    __shared__ uint8_t cut[GAE_NW][64];             // a done inside the chunk: the carry-in does not reach the chunk's first step
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.x * 64 + lane;
+    const int Tc = (T + GAE_NW - 1) / GAE_NW;
+    const int t_lo = min(T, w * Tc), t_hi = min(T, (w + 1) * Tc);
+    const bool act = b < B;
+    double s1 = 0.0, s2 = 0.0, cnt = 0.0;
+    {   // pass 1: zero carry-in
+        double a_n = 0.0, v_n = 0.0, r_n = 0.0; bool comp = false;
+        if (act) gae_chunk_pass<false>(V, rew, done, t_lo, t_hi, B, b, gamma, lam, a_n, v_n, r_n, comp, adv, ret, valid, s1, s2, cnt);
+        const int len = t_hi - t_lo;
+        agg[w][0][lane] = a_n; agg[w][1][lane] = r_n; agg[w][2][lane] = v_n;
+        // the carry enters the last step of the chunk as E = g*v_in + g*lam*a_in and r_in; without a done it reaches the first step scaled
+        // by (g*lam)^(len-1) and g^len
+        agg[w][3][lane] = (comp || len == 0) ? 0.0 : pow(gamma * lam, (double)(len - 1));
+        agg[w][4][lane] = (comp || len == 0) ? 0.0 : pow(gamma, (double)len);
+        cut[w][lane] = comp ? 1 : 0;
+    }
+    __syncthreads();
+    // combine: carry entering chunk w = carry-out of chunk w+1 (which in turn depends on the carry entering it, ...), from the last chunk down
+    double a_in = 0.0, v_in = 0.0, r_in = 0.0; bool c_in = false;
+    for (int j = GAE_NW - 1; j > w; --j) {
+        const int lo = min(T, j * Tc), hi = min(T, (j + 1) * Tc);
+        if (hi <= lo) continue;                          // empty chunk: the carry passes through
+        const double E = gamma * v_in + gamma * lam * a_in;
+        a_in = agg[j][0][lane] + agg[j][3][lane] * E;
+        r_in = agg[j][1][lane] + agg[j][4][lane] * r_in;
+        v_in = agg[j][2][lane];
+        c_in = c_in || cut[j][lane];
+    }
+    if (act) gae_chunk_pass<true>(V, rew, done, t_lo, t_hi, B, b, gamma, lam, a_in, v_in, r_in, c_in, adv, ret, valid, s1, s2, cnt);
     const double t1s = block_sum(s1, red), t2s = block_sum(s2, red), t3s = block_sum(cnt, red);
     if (threadIdx.x == 0) { atomicAdd(&stats[0], t1s); atomicAdd(&stats[1], t2s); atomicAdd(&stats[2], t3s); }
 }
@@ -275,8 +324,7 @@ int launch_gae(metrpo_ctx* c, const float* obs, const float* rew, const uint8_t*
         const int g = (int)std::min<long long>((N + 255) / 256, (long long)c->n_sm * 8);
         hipLaunchKernelGGL(k_baseline_predict, dim3(g), dim3(256), 0, st, obs, tpath, N, c->pd.ns, coeffs, V);
     }
-    const int bs = 64;
-    hipLaunchKernelGGL(k_gae, dim3((B + bs - 1) / bs), dim3(bs), 0, st, V, rew, done, T, B, gamma, lam, adv, ret, valid, stats);
+    hipLaunchKernelGGL(k_gae, dim3((B + 63) / 64), dim3(64 * GAE_NW), 0, st, V, rew, done, T, B, gamma, lam, adv, ret, valid, stats);
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;
 }
