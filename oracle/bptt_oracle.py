@@ -8,9 +8,11 @@ cost += gamma^t * cost_tf(x,u,x') [Ant: masked by the running `dones`, updated a
 training_policy_cost = reduce_mean over the K models (:365), get_policy_optimizer (:186-206: Adam with per-variable
 tf.clip_by_norm, utils.py:262-276), the 'bptt' branch of optimize_policy (:1181-1187).
 
-PARITY UNPINNED: this is a TF-graph gradient (tf.gradients of the unrolled graph + tf.train.AdamOptimizer), not executable
-here.  The restatement is the hand-derived adjoint recursion below; tests/test_oracle_bptt.py checks it against torch autograd
-of the same unrolled computation (an independent derivation) and against finite differences.
+PINNED (round 2): the reference's build_policy_graph + get_policy_optimizer run unmodified on the eager tf stand-in
+(tests/golden/make_golden_tf.py); autograd through the reference's OWN unrolled graph gives policy_grads_and_vars, which the
+hand-derived adjoint recursion below reproduces to 1e-9 relative, as do three clipped Adam steps (tests/test_oracle_tfgraph.py;
+the Adam rule itself is the stand-in's restatement of the TF 1.4 documentation).  tests/test_oracle_bptt.py additionally checks the
+recursion against torch autograd of an independently written unrolled computation and against finite differences.
 """
 import numpy as np
 from . import metrpo_oracle as O

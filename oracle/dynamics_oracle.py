@@ -9,10 +9,13 @@ Pinned against the reference's own Python (tests/golden/dyn_*.npz, made by tests
 pair building / train-validation split / normaliser feed of `collect_data` (collect_split.npz: the reference's own
 collect_data run with synthetic trajectories in place of the simulator).  The reference's one known-answer test for
 this path, running_mean_std.py:44-62 (epsilon=0: mean/std equal np.mean/np.std of all rows), is restated in the tests.
-PARITY UNPINNED (TF graph / TF optimizers, not executable here): the per-model MSE loss, its gradient,
-tf.train.AdamOptimizer, the SGD step on the regulariser, RunningMeanStd.update, and the control flow of
-optimize_models (restated line by line from model_based_rl.py:881-1051).  Self-consistency: torch autograd
-and torch.optim.Adam in tests/test_oracle_dynamics.py.
+Also pinned, by the reference's own TF-graph code run unmodified on the eager tf stand-in (tests/golden/make_golden_tf.py ->
+tfgraph_*.npz, tests/test_oracle_tfgraph.py): the per-model prediction loss and regulariser of build_dynamics_graph
+(model_based_rl.py:23-104), the gradient of that loss graph (autograd over the reference's graph), RunningMeanStd.update, and three
+optimiser steps of get_dynamics_optimizer (:154-183) -- where the Adam / SGD update RULES are the stand-in's restatement of the
+TF 1.4 documentation (TensorFlow itself is not installable), not TF's code.
+PARITY UNPINNED: the control flow of optimize_models (restated line by line from model_based_rl.py:881-1051; it needs a live
+tf.Session loop).  Self-consistency: torch autograd and torch.optim.Adam in tests/test_oracle_dynamics.py.
 """
 import numpy as np
 from . import metrpo_oracle as O
