@@ -109,6 +109,45 @@ __device__ __forceinline__ void dense_col(const float* __restrict__ W, const flo
     }
 }
 
+// dense_col restricted to the output columns [j_lo, j_hi) -- lets G thread groups of a block share one layer of one env tile
+__device__ __forceinline__ void dense_col_range(const float* __restrict__ W, const float* __restrict__ b, int n_in, int n_out, int j_lo,
+                                                int j_hi, int act, const float* in, float* out, int LD, int tid) {
+    for (int j0 = j_lo; j0 < j_hi; j0 += DENSE_JB) {
+        float acc[DENSE_JB];
+        const int nj = min(DENSE_JB, j_hi - j0);
+#pragma unroll
+        for (int jj = 0; jj < DENSE_JB; ++jj) acc[jj] = (jj < nj) ? b[j0 + jj] : 0.0f;
+        for (int i = 0; i < n_in; ++i) {
+            const float a = in[i * LD + tid];
+            const float* __restrict__ w = W + (size_t)i * n_out + j0;
+#pragma unroll
+            for (int jj = 0; jj < DENSE_JB; ++jj)
+                if (jj < nj) acc[jj] = fmaf(a, w[jj], acc[jj]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < DENSE_JB; ++jj)
+            if (jj < nj) out[(j0 + jj) * LD + tid] = act_apply(act, acc[jj]);
+    }
+}
+
+// mlp_col with the outputs of every layer split over the G thread groups of the block (group g = threadIdx.x / LD); every thread of the
+// block must call it (block barriers between layers).  Returns the buffer holding the outputs.
+__device__ __forceinline__ float* mlp_col_groups(const NetDesc& net, const float* __restrict__ params, const float* in, float* bufA, float* bufB,
+                                                 int LD, int lane, int g, int G) {
+    const float* cur = in;
+    float* dst = bufA;
+    for (int l = 0; l < net.n_layers; ++l) {
+        const int n_out = net.dims[l + 1];
+        const int per = ((n_out + G * DENSE_JB - 1) / (G * DENSE_JB)) * DENSE_JB;       // columns per group, a multiple of the register block
+        const int j_lo = min(n_out, g * per), j_hi = min(n_out, j_lo + per);
+        dense_col_range(params + net.w_off[l], params + net.b_off[l], net.dims[l], n_out, j_lo, j_hi, net.act[l], cur, dst, LD, lane);
+        __syncthreads();
+        cur = dst;
+        dst = (dst == bufA) ? bufB : bufA;
+    }
+    return const_cast<float*>(cur);
+}
+
 // Full MLP in column layout.  `in` is read-only; hidden activations ping-pong between bufA/bufB;
 // returns the pointer (bufA or bufB) holding the n_out outputs.
 __device__ __forceinline__ float* mlp_col(const NetDesc& net, const float* __restrict__ params, const float* in,

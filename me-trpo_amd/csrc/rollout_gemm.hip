@@ -14,17 +14,19 @@
 // ------------------------------------------------------------------------------------------------
 struct BigState { float* S; int* ts; int* cur_model; float* X; float* U; float* HA; float* HB; float* OUT; float* PART; };
 
-// policy.get_actions + clip + normalise/drop; one thread per env; policy activations in LDS columns
+// policy.get_actions + clip + normalise/drop for policies without an MFMA pre-kernel (Humanoid's 100-50-25): a block = 64 envs x G thread
+// groups; the outputs of every policy layer are split over the groups (activations in LDS columns), group 0 owns the env's bookkeeping
 __global__ void k_big_pre(ProblemDesc pd, RolloutK r, int t, const float* __restrict__ theta, const float* __restrict__ norm,
                           BigState st) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int LD = blockDim.x, tid = threadIdx.x;
-    const int b = blockIdx.x * blockDim.x + tid;
+    const int LD = 64, tid = threadIdx.x & 63, grp = threadIdx.x >> 6, G = blockDim.x >> 6;
+    const int b = blockIdx.x * 64 + tid;
     const bool active = b < r.B;
     const int ns = pd.ns, na = pd.na;
     float* Sc = lds; float* A = Sc + ns * LD; float* Bq = A + pd.pol.max_width * LD;
     const uint64_t genv = r.stream_offset + (uint64_t)b;
     if (r.stop != nullptr && *r.stop != 0) return;               // the sampling loop already ended (metrpo_sampler_progress)
+    if (grp == 0) {
     if (t == 0 && active && r.init_obs != nullptr) {             // continuation of a chunked rollout
         st.cur_model[b] = r.init_model[b]; st.ts[b] = r.init_ts[b];
         for (int i = 0; i < ns; ++i) st.S[(size_t)b * ns + i] = r.init_obs[(size_t)b * ns + i];
@@ -36,8 +38,10 @@ __global__ void k_big_pre(ProblemDesc pd, RolloutK r, int t, const float* __rest
         for (int i = 0; i < ns; ++i) st.S[(size_t)b * ns + i] = r.pool[(size_t)row * ns + i];
     }
     for (int i = 0; i < ns; ++i) Sc[i * LD + tid] = active ? st.S[(size_t)b * ns + i] : 0.0f;
-    float* m = mlp_col(pd.pol, theta, Sc, A, Bq, LD, tid);
-    if (!active) return;
+    }
+    __syncthreads();
+    float* m = mlp_col_groups(pd.pol, theta, Sc, A, Bq, LD, tid, grp, G);
+    if (!active || grp != 0) return;
     const size_t tb = (size_t)t * r.B + b;
     const float* __restrict__ log_std = theta + pd.pol.n_params;
     const float* in_mean = norm; const float* in_std = norm + (ns + na);
@@ -313,14 +317,14 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
     bs.S = p; p += nS; bs.X = p; p += nX; bs.U = p; p += nU; bs.HA = p; p += nH; bs.HB = p; p += nH; bs.OUT = p; p += nO; bs.PART = nP ? p : nullptr; p += nP;
     bs.ts = (int*)p; bs.cur_model = bs.ts + B;
     RolloutK r = make_rollout_k(a);
-    const int pbs = 64;
-    const size_t psh = (size_t)(pd.ns + 2 * pd.pol.max_width) * pbs * sizeof(float);
+    const int pbs = 256;                                     // 64 envs x 4 output groups
+    const size_t psh = (size_t)(pd.ns + 2 * pd.pol.max_width) * 64 * sizeof(float);
     if (psh > 160 * 1024) return set_err(c, METRPO_EUNSUPPORTED, "policy too wide for k_big_pre");
     if (psh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_big_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psh));
     const big_pre_mfma_t pre_mfma = big_pre_mfma_select(pd);
     for (int t = 0; t < a->T; ++t) {
         if (pre_mfma) hipLaunchKernelGGL(pre_mfma, dim3((B + 63) / 64), dim3(256), 0, st, pd, r, t, c->d_theta, c->d_norm, bs);
-        else hipLaunchKernelGGL(k_big_pre, dim3((B + pbs - 1) / pbs), dim3(pbs), psh, st, pd, r, t, c->d_theta, c->d_norm, bs);
+        else hipLaunchKernelGGL(k_big_pre, dim3((B + 63) / 64), dim3(pbs), psh, st, pd, r, t, c->d_theta, c->d_norm, bs);
         const float* in = bs.X; long long sIn = 0; int ldin = pd.nin;
         float* bufs[2] = {bs.HA, bs.HB};
         for (int l = 0; l < L; ++l) {
