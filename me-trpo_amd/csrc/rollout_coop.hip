@@ -162,6 +162,7 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
         // LDS (one more barrier per step).  Evaluating it redundantly in all 4 waves kept the step free of that barrier but cost
         // 90 of the 580 MFMAs and three quarters of the tanh VALU work of a tile-step -- issue slots a co-resident workgroup can use.
         if (!AHEAD) step_draws(r.t0 + t, dstep, z);                        // every wave needs the step's model / reset draws
+        float a_keep[4] = {0.f, 0.f, 0.f, 0.f}, mu_keep[4] = {0.f, 0.f, 0.f, 0.f};   // policy wave: unclipped action / mean, stored to HBM after B1
         // dynamics layer 0, k-steps that read only the STATE (inputs 4s..4s+3 all below ns - n_drop): independent of the action, so
         // waves 1-3 run them while wave 0 evaluates the policy
         constexpr int KS_STATE = (NS - C::NDROP) / 4;
@@ -239,7 +240,7 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
                         const float zz = (r.eps != nullptr) ? (active ? r.eps[tb * NA + d] : 0.0f) : z[rr];
                         a = fmaf(zz, sig[rr], a);
                     }
-                    if (active) { r.act[tb * NA + d] = a; r.mean[tb * NA + d] = mu[rr]; }
+                    a_keep[rr] = a; mu_keep[rr] = mu[rr];
                     const float ac = fminf(fmaxf(a, -1.0f), 1.0f);            // env_helpers.py:599
                     ACT[e * NA + d] = ac;
                 }
@@ -271,6 +272,12 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
         PH_MARK(2)
         __syncthreads();                                                   // B1: layer-0 activations of all heads visible
         PH_MARK(3)
+        // Global stores are issued HERE, at the start of the long matrix phase: a workgroup barrier waits for the wave's outstanding
+        // stores (vmcnt(0)), so stores issued right before B0 / B1 put their ~600-cycle acknowledge latency on the step's critical path
+        if (wave == 0 && active) {                                         // wave 0 is the policy wave: unclipped action and mean
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) { const int d = 4 * q + rr; if (d < NA) { r.act[tb * NA + d] = a_keep[rr]; r.mean[tb * NA + d] = mu_keep[rr]; } }
+        }
         if (wave == 0) {                                                   // obs[t]: coalesced linear copy of the tile
             const size_t base = ((size_t)t * r.B + b0) * NS;
             const int lim = min(16, r.B - b0) * NS;
