@@ -91,7 +91,13 @@ def main():
                                   sam_mode='step_rand')
     algo = metrpo_amd.TRPO(env=nne, policy=policy, baseline=baseline, batch_size=B * H, max_path_length=H,
                            discount=1.0, step_size=0.01, sampler_args=dict(n_envs=B), comm=comm, seed=0)
-    rccl_in_ctx = comm.world > 1 and comm.attach_engine(eng)   # N > 1 over RCCL: the ctx owns the communicator, all-reduces issued from C
+    rccl_in_ctx = False                       # N > 1 over RCCL: the ctx owns the communicator, all-reduces issued from C
+    if comm.world > 1 and os.environ.get('METRPO_BENCH_NO_CTX_COMM', '0') != '1':
+        try:
+            rccl_in_ctx = bool(comm.attach_engine(eng))
+        except Exception as e:                # never lose the multi-GPU line: fall back to torch.distributed through the host callback
+            sys.stderr.write('rank %d: ctx-owned RCCL communicator unavailable (%r); using the torch.distributed callback\n' % (comm.rank, e))
+            comm.engine = None
     algo.defer_baseline_fit = True            # host solve of the 24x24 baseline system overlaps the next rollout
     algo.reuse_trajectory_buffers = True      # one set of [T,B,.] tensors, overwritten every iteration
 

@@ -12,7 +12,8 @@
 #include "mfma_common.h"
 
 // ------------------------------------------------------------------------------------------------
-struct BigState { float* S; int* ts; int* cur_model; float* X; float* U; float* HA; float* HB; float* OUT; float* PART; };
+struct BigState { float* S; int* ts; int* cur_model; float* X; float* U; float* HA; float* HB; float* OUT; float* PART;
+                  int ldx; };   // ldx: row stride of X = n_in rounded up to 4 floats, so every row is 16-byte aligned for the layer-0 GEMM's loads
 
 // policy.get_actions + clip + normalise/drop for policies without an MFMA pre-kernel (Humanoid's 100-50-25): a block = 64 envs x G thread
 // groups; the outputs of every policy layer are split over the groups (activations in LDS columns), group 0 owns the env's bookkeeping
@@ -49,7 +50,7 @@ __global__ void k_big_pre(ProblemDesc pd, RolloutK r, int t, const float* __rest
     for (int i = 0; i < ns; ++i) {
         const float s = Sc[i * LD + tid];
         r.obs[tb * ns + i] = s;
-        if (i >= pd.n_drop) st.X[(size_t)b * pd.nin + i - pd.n_drop] = (s - in_mean[i]) / in_std[i];       // training.py:228,146-151
+        if (i >= pd.n_drop) st.X[(size_t)b * st.ldx + i - pd.n_drop] = (s - in_mean[i]) / in_std[i];       // training.py:228,146-151
     }
     for (int d0 = 0; d0 < na; d0 += 2) {
         float z[2] = {0.f, 0.f};
@@ -64,7 +65,7 @@ __global__ void k_big_pre(ProblemDesc pd, RolloutK r, int t, const float* __rest
             r.act[tb * na + d] = a; r.mean[tb * na + d] = mu;
             const float ac = fminf(fmaxf(a, -1.0f), 1.0f);          // env_helpers.py:599
             st.U[(size_t)b * na + d] = ac;
-            st.X[(size_t)b * pd.nin + (ns - pd.n_drop) + d] = (ac - in_mean[ns + d]) / in_std[ns + d];
+            st.X[(size_t)b * st.ldx + (ns - pd.n_drop) + d] = (ac - in_mean[ns + d]) / in_std[ns + d];
         }
     }
 }
@@ -76,7 +77,7 @@ template <int ENV>
 __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r, int t, const float* __restrict__ theta,
                                                       const float* __restrict__ norm, BigState st) {
     using C = Cfg<ENV, 64, 32>;
-    constexpr int NS = C::NS, NA = C::NA, NDROP = C::NDROP, NIN = C::NIN, PH = 32, NS_KS = C::NS_KS;
+    constexpr int NS = C::NS, NA = C::NA, NDROP = C::NDROP, PH = 32, NS_KS = C::NS_KS;
     constexpr int O_PF1 = NS_KS * 2 * 64, O_PF2 = O_PF1 + 16 * 64, O_B0 = O_PF2 + 8 * 64, O_B1 = O_B0 + 32, O_B2 = O_B1 + 32, IMG = O_B2 + 16;
     __shared__ __attribute__((aligned(16))) float lds[IMG + 4 * 16 * NS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -147,7 +148,7 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
     const float* in_mean = norm; const float* in_std = norm + (NS + NA);
     const float* __restrict__ log_std = theta + C::pLS;
     // state part of the normalised, dropped input: lane (c, q) writes its dims 4q .. (every 16th column block)
-    for (int i = q; i < NS; i += 4) if (i >= NDROP) st.X[(size_t)b * NIN + i - NDROP] = (ST[c * NS + i] - in_mean[i]) / in_std[i];     // training.py:228,146-151
+    for (int i = q; i < NS; i += 4) if (i >= NDROP) st.X[(size_t)b * st.ldx + i - NDROP] = (ST[c * NS + i] - in_mean[i]) / in_std[i];     // training.py:228,146-151
     // action dims 4q .. 4q+3 of this lane = Philox chunks 2q, 2q+1 (chunk 0 = the step block), exactly as k_big_pre
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -168,7 +169,7 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
             r.act[tb * NA + d] = a; r.mean[tb * NA + d] = m;
             const float ac = fminf(fmaxf(a, -1.0f), 1.0f);          // env_helpers.py:599
             st.U[(size_t)b * NA + d] = ac;
-            st.X[(size_t)b * NIN + (NS - NDROP) + d] = (ac - in_mean[NS + d]) / in_std[NS + d];
+            st.X[(size_t)b * st.ldx + (NS - NDROP) + d] = (ac - in_mean[NS + d]) / in_std[NS + d];
         }
     }
 }
@@ -302,7 +303,7 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
     for (int l = 1; l < L; ++l) maxh = std::max(maxh, pd.dyn.dims[l]);
     // workspace (floats): S, X, U, HA, HB, OUT + ints ts, cur_model
     auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };       // keep every sub-buffer 16-byte aligned
-    const size_t nS = up4((size_t)B * pd.ns), nX = up4((size_t)B * pd.nin), nU = up4((size_t)B * pd.na), nH = up4((size_t)K * B * maxh), nO = up4((size_t)K * B * pd.ns);
+    const size_t nS = up4((size_t)B * pd.ns), nX = up4((size_t)B * ((pd.nin + 3) & ~3)), nU = up4((size_t)B * pd.na), nH = up4((size_t)K * B * maxh), nO = up4((size_t)K * B * pd.ns);
     size_t nP = 0;
     for (int l = 0; l < L; ++l) nP = std::max(nP, up4(skinny_part_floats(B, pd.dyn.dims[l + 1], pd.dyn.dims[l], K)));
     const size_t need = (nS + nX + nU + 2 * nH + nO + nP) * sizeof(float) + 2 * (size_t)B * sizeof(int) + 256;
@@ -316,6 +317,7 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
     float* p = (float*)c->d_big;
     bs.S = p; p += nS; bs.X = p; p += nX; bs.U = p; p += nU; bs.HA = p; p += nH; bs.HB = p; p += nH; bs.OUT = p; p += nO; bs.PART = nP ? p : nullptr; p += nP;
     bs.ts = (int*)p; bs.cur_model = bs.ts + B;
+    bs.ldx = (pd.nin + 3) & ~3;
     RolloutK r = make_rollout_k(a);
     const int pbs = 256;                                     // 64 envs x 4 output groups
     const size_t psh = (size_t)(pd.ns + 2 * pd.pol.max_width) * 64 * sizeof(float);
@@ -325,7 +327,7 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
     for (int t = 0; t < a->T; ++t) {
         if (pre_mfma) hipLaunchKernelGGL(pre_mfma, dim3((B + 63) / 64), dim3(256), 0, st, pd, r, t, c->d_theta, c->d_norm, bs);
         else hipLaunchKernelGGL(k_big_pre, dim3((B + 63) / 64), dim3(pbs), psh, st, pd, r, t, c->d_theta, c->d_norm, bs);
-        const float* in = bs.X; long long sIn = 0; int ldin = pd.nin;
+        const float* in = bs.X; long long sIn = 0; int ldin = bs.ldx;
         float* bufs[2] = {bs.HA, bs.HB};
         for (int l = 0; l < L; ++l) {
             const int Kd = pd.dyn.dims[l], N = pd.dyn.dims[l + 1];
