@@ -257,13 +257,14 @@ class Engine(object):
         return costs
 
     # ------------------------------------------------------------------ process_samples pieces
-    def gae(self, traj, coeffs, gamma, lam):
+    def gae(self, traj, coeffs, gamma, lam, stats=None):
         """-> adv (uncentred), ret, valid, stats[3] = (sum adv, sum adv^2, count) over valid samples."""
         dev = self.device
         T, B = traj.T, traj.B
         adv = torch.empty(T, B, dtype=torch.float32, device=dev); ret = torch.empty_like(adv)
         valid = torch.empty(T, B, dtype=torch.uint8, device=dev)
-        stats = torch.zeros(3, dtype=torch.float64, device=dev)
+        if stats is None:
+            stats = torch.zeros(3, dtype=torch.float64, device=dev)       # else: caller-provided, already zero
         if coeffs is not None:
             if isinstance(coeffs, torch.Tensor) and coeffs.is_cuda:
                 coeffs = coeffs.to(torch.float64).contiguous()
@@ -290,10 +291,12 @@ class Engine(object):
         self._chk(lib.metrpo_center_advantages(self._ctx, _ptr(adv), _ptr(valid), adv.numel(), _ptr(stats), self._stream()))
         return adv
 
-    def baseline_gram(self, obs, ret, tpath, valid):
+    def baseline_gram(self, obs, ret, tpath, valid, out=None):
+        """out: optional zeroed float64 buffer of F*F + F elements (AtA row-major, then Aty) that receives the sums."""
         F = 2 * self.ns + 4
-        AtA = torch.zeros(F, F, dtype=torch.float64, device=self.device)
-        Aty = torch.zeros(F, dtype=torch.float64, device=self.device)
+        if out is None:
+            out = torch.zeros(F * F + F, dtype=torch.float64, device=self.device)
+        AtA, Aty = out[:F * F].view(F, F), out[F * F:]
         self._chk(lib.metrpo_baseline_gram(self._ctx, _ptr(obs), _ptr(ret), _ptr(tpath), _ptr(valid), ret.numel(),
                                            _ptr(AtA), _ptr(Aty), self._stream()))
         return AtA, Aty

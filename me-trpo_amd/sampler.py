@@ -55,7 +55,9 @@ class BaseSampler(object):
         tr = paths.traj
         self.finish_baseline_fit()             # deferred solve of the previous iteration (overlaps the rollout just launched)
         coeffs = algo.baseline.coeffs
-        adv, ret, valid, stats = eng.gae(tr, coeffs, algo.discount, algo.gae_lambda)
+        F = 2 * eng.ns + 4
+        acc = torch.zeros(3 + F * F + F, dtype=torch.float64, device=eng.device)     # one fill: [advantage statistics | AtA | Aty]
+        adv, ret, valid, stats = eng.gae(tr, coeffs, algo.discount, algo.gae_lambda, stats=acc[:3])
         comm.allreduce_sum_(stats)
         # fixed-horizon envs: every sample is valid and the global count is known without a host sync
         static = (eng.env_name != 'ant') and (tr.T % tr.H == 0)
@@ -66,8 +68,8 @@ class BaseSampler(object):
             lo = torch.where(valid.bool(), adv, torch.full_like(adv, float('inf'))).min().reshape(1)
             comm.allreduce_min_(lo)
             adv.sub_(lo).add_(1e-8)
-        AtA, Aty = eng.baseline_gram(tr.obs, ret, tr.tpath, valid)
-        gram = torch.cat([AtA.reshape(-1), Aty])
+        gram = acc[3:]
+        eng.baseline_gram(tr.obs, ret, tr.tpath, valid, out=gram)
         comm.allreduce_sum_(gram)
         self._pending_gram = gram.to('cpu', non_blocking=True) if gram.is_cuda else gram
         self._gram_event = torch.cuda.Event() if gram.is_cuda else None
