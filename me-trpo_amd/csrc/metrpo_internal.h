@@ -66,6 +66,7 @@ struct metrpo_ctx {
     size_t gram_cap;
     unsigned int* d_ticket; // arrival counter of k_finalize's fused CG tail
     float* d_hcache; size_t hcache_cap; int hcache_on;   // activation cache of one CG solve (policy_mfma.hip MODE_FVPC)
+    void* d_mig; int mig_cap, mig_epoch;            // rollout_coop.hip: hand-over slots of migrating tiles (flag | ts | model | obs per tile)
     void* nccl_comm; int comm_world, comm_rank;   // comm.hip: RCCL communicator attached by metrpo_comm_init (NULL: single rank)
     int pol_path;        // 1 auto (fused MFMA kernels where the shape has them, GEMM path for large N otherwise), 0 generic forced, 2 GEMM path forced
     void* d_pg; size_t pg_cap; long long pg_fwd_rows; const float* pg_fwd_obs;   // policy_gemm.hip workspace + validity of its cached forward pass
@@ -93,6 +94,8 @@ struct RolloutK {          // device-side copy of metrpo_rollout_args (plain poi
     // continuation (metrpo_rollout_args ABI 2)
     int t0; const float* init_obs; const int32_t* init_ts; const int32_t* init_model;
     int32_t* last_ts; int32_t* last_model; const int32_t* stop;
+    // tile migration of the cooperative kernel (rollout_coop.hip; ctx-owned hand-over slots, NULL elsewhere)
+    int32_t* mig_flag; float* mig_obs; int32_t* mig_ts; int32_t* mig_model; int mig_epoch;
 };
 
 static inline RolloutK make_rollout_k(const metrpo_rollout_args* a) {
@@ -104,6 +107,7 @@ static inline RolloutK make_rollout_k(const metrpo_rollout_args* a) {
     r.done = a->d_done; r.tpath = a->d_tpath; r.last_obs = a->d_last_obs;
     r.t0 = a->t0; r.init_obs = a->d_init_obs; r.init_ts = a->d_init_ts; r.init_model = a->d_init_model;
     r.last_ts = a->d_last_ts; r.last_model = a->d_last_model; r.stop = a->d_stop;
+    r.mig_flag = nullptr; r.mig_obs = nullptr; r.mig_ts = nullptr; r.mig_model = nullptr; r.mig_epoch = 0;
     return r;
 }
 

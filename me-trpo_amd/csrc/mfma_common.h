@@ -5,6 +5,28 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// Compile-time-only fence that ties K independent accumulator chains together: every chain's MFMA issued so far is an input of the
+// (empty) statement and every later one consumes its output, so no instruction scheduler can run one chain ahead of the others and
+// turn K interleaved independent chains into back-to-back DEPENDENT matrix instructions (seen in the single-tile instantiation of
+// rollout_coop.hip: 8 dependent MFMAs in a row, each waiting out the full pipeline depth).  Emits no instruction.
+template <int K> __device__ __forceinline__ void pin_order(f32x4 (&a)[K]) {
+    // "a": the accumulation registers, where the register allocator keeps MFMA results of a kernel that owns the whole register file
+    if constexpr (K == 5) asm volatile("" : "+a"(a[0]), "+a"(a[1]), "+a"(a[2]), "+a"(a[3]), "+a"(a[4]));
+    else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) asm volatile("" : "+a"(a[k]));
+    }
+}
+
+// max(x, 0) as ONE instruction (v_max_i32 on the bit pattern: negative floats, -0 included, are negative integers): fmaxf costs two on
+// an MFMA result, a canonicalising v_max x, x first, and every float builtin is folded back into it.  NaNs with a clear sign bit
+// propagate (as in the reference's tf.nn.relu); no inline assembly -- the compiler must see the read of the MFMA result to place
+// the wait states the hardware does not interlock.
+__device__ __forceinline__ float relu1(float x) {
+    const int i = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, i > 0 ? i : 0);
+}
+
 template <int ENV> struct EnvDim;
 template <> struct EnvDim<METRPO_ENV_SWIMMER>      { static constexpr int NS = 10, NA = 2, NDROP = 2; };
 template <> struct EnvDim<METRPO_ENV_HALF_CHEETAH> { static constexpr int NS = 18, NA = 6, NDROP = 1; };

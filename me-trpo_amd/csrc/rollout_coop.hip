@@ -16,9 +16,9 @@
 // last workgroup, read back with metrpo_debug_coop_phases (tools/coop_phases.py).  Not part of the shipped library.
 #ifdef COOP_TIMING
 __device__ unsigned long long g_coop_phase[2][16];
-#define PH_DECL unsigned long long ph_t = __builtin_readcyclecounter(), ph_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define PH_DECL unsigned long long ph_t = __builtin_readcyclecounter(), ph_acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define PH_MARK(i) { const unsigned long long n_ = __builtin_readcyclecounter(); ph_acc[i] += n_ - ph_t; ph_t = n_; }
-#define PH_DUMP { if (lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) for (int i_ = 0; i_ < 10; ++i_) g_coop_phase[blockIdx.x == 0 ? 0 : 1][i_] = ph_acc[i_]; }
+#define PH_DUMP { if (lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) for (int i_ = 0; i_ < 14; ++i_) g_coop_phase[blockIdx.x == 0 ? 0 : 1][i_] = ph_acc[i_]; }
 extern "C" int32_t metrpo_debug_coop_phases(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coop_phase), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -1; }
 #else
 #define PH_DECL
@@ -35,7 +35,8 @@ struct Coop {
     static constexpr int WV = ((16 * NS * 2 + 16 * NA + 3) / 4) * 4;  // per wave: ST | NX | ACT
     static constexpr int O_BD0 = 4 * WV, O_BD1 = O_BD0 + K * 64, O_BD2 = O_BD1 + K * 64, O_BP0 = O_BD2 + K * NSP,
                          O_BP1 = O_BP0 + 32, O_BP2 = O_BP1 + 32, O_PW = O_BP2 + 16, O_H0 = O_PW + NPF * 64,
-                         O_PART = O_H0 + K * 1024, O_RNG = O_PART + K * 4 * 16 * NSP, TOTAL = O_RNG + 2 * 16 * 20;
+                         O_PART = O_H0 + K * 1024, O_RNG = O_PART + K * 4 * 16 * NSP, O_WX = O_RNG + 2 * 16 * 20,
+                         O_AK = O_WX + 3 * ((K + 2) / 3) * C::NIN_KS * 64, TOTAL = O_AK + 2 * 16 * NA;   // O_AK: unclipped action | mean of the step          // O_WX: col-block-0 layer-0 fragments of the helper waves (two-tile kernel)
 };
 
 // ONE: instantiation for launches with at most one tile per CU -- the whole register file (512 lanes-wide registers per SIMD) belongs to
@@ -49,16 +50,33 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;      // wave = hidden col-block
     const int e = lane & 15, q = lane >> 4;
-    const int b0 = blockIdx.x * 16, b = b0 + e;
-    const bool active = b < r.B;
-    const uint64_t genv = r.stream_offset + (uint64_t)b;
     if (r.stop != nullptr && *r.stop != 0) return;           // the sampling loop already ended (metrpo_sampler_progress)
+    // ---------------- which (tile, step range) pieces this workgroup runs ------------------------------------------------------
+    // !ONE: workgroup = tile, all T steps.  ONE: the launch has at most one workgroup per CU and the tiles x T tile-steps are dealt
+    // out evenly in tile-major order (wrap-around rule): workgroup i owns the linear range [i Q, (i+1) Q), i.e. the END of tile
+    // c_first (steps s_first..T-1), whole tiles, and the BEGINNING of tile c_last (steps 0..e_last-1).  It runs the beginning piece
+    // first, then the whole tiles, then the ending piece, whose state it takes over from workgroup i-1 through a hand-over slot in
+    // HBM (flag = launch epoch, agent-scope release / acquire).  Workgroup i-1 runs that tile's beginning before anything else and
+    // waits for nobody first, so with in-order dispatch the wait cannot deadlock; Q >= T keeps a tile on at most two workgroups.
+    int c_first = blockIdx.x, c_last = blockIdx.x, s_first = 0, e_last = r.T;
+    if (ONE) {
+        const long long total = (long long)((r.B + 15) / 16) * r.T;
+        const long long Q = (total + gridDim.x - 1) / gridDim.x;
+        const long long lo = (long long)blockIdx.x * Q, hi = (lo + Q < total) ? lo + Q : total;
+        if (lo >= hi) return;
+        c_first = (int)(lo / r.T); s_first = (int)(lo % r.T); c_last = (int)((hi - 1) / r.T); e_last = (int)((hi - 1) % r.T) + 1;
+    }
+    const int npc = c_last - c_first + 1;
+    int b0 = 0, b = 0;
+    bool active = false;
+    uint64_t genv = 0;
     float* ST = lds + wave * L::WV;  float* NX = ST + 16 * NS;
     float* ACT = lds + 32 * NS;                                         // clipped actions of the tile: written by wave 0 (the policy wave), read by all
 
     float* BD0 = lds + L::O_BD0; float* BD1 = lds + L::O_BD1; float* BD2 = lds + L::O_BD2;
     float* BP0 = lds + L::O_BP0; float* BP1 = lds + L::O_BP1; float* BP2 = lds + L::O_BP2;
     float* PW = lds + L::O_PW; float* H0 = lds + L::O_H0; float* PART = lds + L::O_PART;
+    float* AK = lds + L::O_AK;                                          // [action | mean][16 envs][na], staged for wave 0's coalesced stores
     float* RNGB = lds + L::O_RNG;                                       // [2 parities][16 envs][dstep (4 x u32) | z of q-lane 0..3 (4 floats each)]
 
     // ---------------- one-time: dynamics fragments -> registers ----------------------------------
@@ -74,6 +92,22 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
         for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
             for (int cb = 0; cb < OUT_CB; ++cb) { const int i = 16 * wave + 4 * q + rr, o = 16 * cb + e; wd2[k][rr][cb] = (o < NS) ? pk[C::dW2 + i * NS + o] : 0.0f; }
+    }
+    // Layer 0 of col-block 0 is NOT computed by wave 0 (the policy wave, whose step is the longest): waves 1, 2, 3 take it for heads
+    // {0,1}, {2,3}, {4,..} on top of their own col-block -- they idle while the policy is evaluated anyway.
+    constexpr int XH = (K + 2) / 3;                                    // heads of col-block 0 per helper wave
+    float wx0[ONE ? XH : 1][C::NIN_KS];                                // registers when the workgroup owns the CU, else an LDS image (no room)
+    float* WXL = lds + L::O_WX + (wave >= 1 ? wave - 1 : 0) * XH * C::NIN_KS * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < XH; ++j) {
+        const int hx = XH * (wave - 1) + j;
+        const float* __restrict__ pk = dynp + (size_t)((wave >= 1 && hx < K) ? hx : 0) * C::PD;
+#pragma unroll
+        for (int s = 0; s < C::NIN_KS; ++s) {
+            const int i = 4 * s + q;
+            const float w = (i < C::NIN && wave >= 1 && hx < K) ? pk[C::dW0 + i * DH + e] : 0.0f;
+            if (ONE) wx0[j][s] = w; else if (wave >= 1) WXL[(j * C::NIN_KS + s) * 64] = w;
+        }
     }
     // shared images: biases and policy fragments (each element written by exactly one thread)
     for (int i = tid; i < K * 64; i += 256) { const int k = i >> 6, u = i & 63; BD0[i] = dynp[(size_t)k * C::PD + C::db0 + u]; BD1[i] = dynp[(size_t)k * C::PD + C::db1 + u]; }
@@ -113,10 +147,40 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
             dmean[cb][rr] = (dim < NS) ? norm[2 * (NS + NA) + dim] : 0.0f;
             dstd[cb][rr] = (dim < NS) ? norm[2 * (NS + NA) + NS + dim] : 0.0f;
         }
-    // ---------------- vec_env.reset() (env_helpers.py:585-595) -------------------------------------
+    // Per-step draws (Philox block 0 of RNG_STEP: action noise dims 0,1 | step model | reset row/model) are produced ONE STEP AHEAD.
+    auto step_draws = [&](int tt, uint4& ds, float (&zz)[4]) {
+        ds = rng_draw(r.seed, genv, tt, RNG_STEP, 0);
+        {   // unconditional (no branch); unused when determ / draws are supplied.
+            // lane q owns action dims 4q..4q+3 = chunks 2q, 2q+1 (chunk 0 = ds)
+            const uint4 b0k = (q == 0) ? ds : ((NA > 4) ? rng_draw(r.seed, genv, tt, RNG_STEP, 2 * q) : ds);
+            normal2(b0k.x, b0k.y, zz[0], zz[1]);
+            if (NA > 2) { const uint4 b1k = rng_draw(r.seed, genv, tt, RNG_STEP, 2 * q + 1); normal2(b1k.x, b1k.y, zz[2], zz[3]); }
+        }
+    };
+    constexpr bool LOCAL_REWARD = (ENV == METRPO_ENV_SWIMMER || ENV == METRPO_ENV_HALF_CHEETAH || ENV == METRPO_ENV_SNAKE);
+    constexpr int RDIM = (ENV == METRPO_ENV_SWIMMER) ? 5 : (ENV == METRPO_ENV_HALF_CHEETAH) ? 9 : 7;   // reward reads next_state[RDIM]
+    constexpr bool AHEAD = true;        // the draws of step t+1 are produced during step t (by wave 1, below) for every env family
+    PH_DECL
+    for (int pc = 0; pc < npc; ++pc) {
+    const int tile = (pc == npc - 1) ? c_first : (pc == 0 ? c_last : c_first + pc);
+    const int t_begin = (tile == c_first) ? s_first : 0, t_end = (tile == c_last) ? e_last : r.T;
+    b0 = tile * 16; b = b0 + e; active = b < r.B; genv = r.stream_offset + (uint64_t)b;
+    // ---------------- vec_env.reset() (env_helpers.py:585-595), or the state handed over by the previous owner -------------
     const bool resume = r.init_obs != nullptr;
     int cur_model = 0, ts = 0;
-    {
+    if (ONE && t_begin > 0) {
+        if (tid == 0) while (__hip_atomic_load(&r.mig_flag[tile], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != r.mig_epoch) __builtin_amdgcn_s_sleep(4);
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        cur_model = r.mig_model[b]; ts = r.mig_ts[b];
+#pragma unroll
+        for (int cb = 0; cb < OUT_CB; ++cb)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int dim = 16 * cb + 4 * q + rr;
+                if (dim < NS) ST[e * NS + dim] = r.mig_obs[(size_t)b * NS + dim];
+            }
+    } else {
         int row = 0;
         if (active && !resume) {
             const uint4 d0 = rng_draw(r.seed, genv, 0, RNG_RESET, 0);
@@ -134,26 +198,12 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
     }
     __syncthreads();
 
-    // Per-step draws (Philox block 0 of RNG_STEP: action noise dims 0,1 | step model | reset row/model) are produced ONE STEP AHEAD,
-    // textually inside the layer-1 MFMA phase, so that their ~150 VALU instructions issue in the shadow of the matrix pipe.
-    auto step_draws = [&](int tt, uint4& ds, float (&zz)[4]) {
-        ds = rng_draw(r.seed, genv, tt, RNG_STEP, 0);
-        {   // unconditional (no branch); unused when determ / draws are supplied.
-            // lane q owns action dims 4q..4q+3 = chunks 2q, 2q+1 (chunk 0 = ds)
-            const uint4 b0k = (q == 0) ? ds : ((NA > 4) ? rng_draw(r.seed, genv, tt, RNG_STEP, 2 * q) : ds);
-            normal2(b0k.x, b0k.y, zz[0], zz[1]);
-            if (NA > 2) { const uint4 b1k = rng_draw(r.seed, genv, tt, RNG_STEP, 2 * q + 1); normal2(b1k.x, b1k.y, zz[2], zz[3]); }
-        }
-    };
-    constexpr bool LOCAL_REWARD = (ENV == METRPO_ENV_SWIMMER || ENV == METRPO_ENV_HALF_CHEETAH || ENV == METRPO_ENV_SNAKE);
-    constexpr int RDIM = (ENV == METRPO_ENV_SWIMMER) ? 5 : (ENV == METRPO_ENV_HALF_CHEETAH) ? 9 : 7;   // reward reads next_state[RDIM]
-    constexpr bool AHEAD = true;        // the draws of step t+1 are produced during step t (by wave 1, below) for every env family
     uint4 dstep = make_uint4(0, 0, 0, 0); float z[4] = {0.f, 0.f, 0.f, 0.f};
-    if (AHEAD) step_draws(r.t0, dstep, z);
-    PH_DECL
-    for (int t = 0; t < r.T; ++t) {
+    if (AHEAD) step_draws(r.t0 + t_begin, dstep, z);
+    for (int t = t_begin; t < t_end; ++t) {
         PH_MARK(9)
-        const size_t tb = (size_t)t * r.B + b;
+        const size_t trow = (size_t)t * r.B;                               // uniform row base; lane offsets stay 32-bit (scalar base + offset addressing)
+        const unsigned ub = (unsigned)b;
         // ---- policy (redundant in every wave; weight fragments from LDS) -----------------------------
         // Weight fragments of a layer are fetched as one batch BEFORE the activation of the previous layer is evaluated (the LDS
         // latency hides under the tanh VALU work), and each tanh is issued right before the MFMA pair that consumes it, so the
@@ -162,18 +212,23 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
         // LDS (one more barrier per step).  Evaluating it redundantly in all 4 waves kept the step free of that barrier but cost
         // 90 of the 580 MFMAs and three quarters of the tanh VALU work of a tile-step -- issue slots a co-resident workgroup can use.
         if (!AHEAD) step_draws(r.t0 + t, dstep, z);                        // every wave needs the step's model / reset draws
-        float a_keep[4] = {0.f, 0.f, 0.f, 0.f}, mu_keep[4] = {0.f, 0.f, 0.f, 0.f};   // policy wave: unclipped action / mean, stored to HBM after B1
         // dynamics layer 0, k-steps that read only the STATE (inputs 4s..4s+3 all below ns - n_drop): independent of the action, so
         // waves 1-3 run them while wave 0 evaluates the policy
         constexpr int KS_STATE = (NS - C::NDROP) / 4;
-        f32x4 h0[K];
+        f32x4 h0[K], hx0[XH];
+        if (wave != 0) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) h0[k] = *(const f32x4*)&BD0[k * 64 + 16 * wave + 4 * q];
+            for (int k = 0; k < K; ++k) h0[k] = *(const f32x4*)&BD0[k * 64 + 16 * wave + 4 * q];
 #pragma unroll
-        for (int s = 0; s < KS_STATE; ++s) {
-            const float x = (ST[e * NS + nsrc[s]] - nmean[s]) * nstd[s];                  // training.py:228
+            for (int j = 0; j < XH; ++j) { const int hx = XH * (wave - 1) + j; hx0[j] = *(const f32x4*)&BD0[(hx < K ? hx : 0) * 64 + 4 * q]; }
 #pragma unroll
-            for (int k = 0; k < K; ++k) h0[k] = MFMA16(wd0[k][s], x, h0[k]);
+            for (int s = 0; s < KS_STATE; ++s) {
+                const float x = (ST[e * NS + nsrc[s]] - nmean[s]) * nstd[s];              // training.py:228
+#pragma unroll
+                for (int k = 0; k < K; ++k) h0[k] = MFMA16(wd0[k][s], x, h0[k]);
+#pragma unroll
+                for (int j = 0; j < XH; ++j) hx0[j] = MFMA16(ONE ? wx0[ONE ? j : 0][s] : WXL[(j * C::NIN_KS + s) * 64], x, hx0[j]);
+            }
         }
         if (AHEAD && wave == 1) {
             // Next step's Philox block + Box-Muller for the 16 envs of the tile, produced by wave 1 while wave 0 evaluates the policy
@@ -237,10 +292,10 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
                 if (d < NA) {
                     float a = mu[rr];
                     if (!r.determ) {
-                        const float zz = (r.eps != nullptr) ? (active ? r.eps[tb * NA + d] : 0.0f) : z[rr];
+                        const float zz = (r.eps != nullptr) ? (active ? (r.eps + trow * NA)[ub * NA + d] : 0.0f) : z[rr];
                         a = fmaf(zz, sig[rr], a);
                     }
-                    a_keep[rr] = a; mu_keep[rr] = mu[rr];
+                    AK[e * NA + d] = a; AK[16 * NA + e * NA + d] = mu[rr];
                     const float ac = fminf(fmaxf(a, -1.0f), 1.0f);            // env_helpers.py:599
                     ACT[e * NA + d] = ac;
                 }
@@ -248,8 +303,9 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
         }
         __syncthreads();                                                   // B0: actions visible
         PH_MARK(1)
-        // ---- dynamics layer 0, col-block `wave`, all K heads ------------------------------------------
-        {
+        // ---- dynamics layer 0: waves 1-3 finish their col-block and their share of col-block 0; wave 0 issues the step's global
+        //      stores meanwhile (it has no layer-0 work, and nothing waits for a store: barriers wait for LDS traffic only) -------
+        if (wave != 0) {
             float xin[C::NIN_KS];
 #pragma unroll
             for (int s = KS_STATE; s < C::NIN_KS; ++s) {
@@ -259,55 +315,85 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
                 xin[s] = (nsrc[s] > -1000000) ? (x - nmean[s]) * nstd[s] : 0.0f;          // training.py:228
             }
 #pragma unroll
-            for (int s = KS_STATE; s < C::NIN_KS; ++s)
+            for (int s = KS_STATE; s < C::NIN_KS; ++s) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) h0[k] = MFMA16(wd0[k][s], xin[s], h0[k]);
 #pragma unroll
+                for (int j = 0; j < XH; ++j) hx0[j] = MFMA16(ONE ? wx0[ONE ? j : 0][s] : WXL[(j * C::NIN_KS + s) * 64], xin[s], hx0[j]);
+            }
+#pragma unroll
             for (int k = 0; k < K; ++k) {
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) h0[k][rr] = fmaxf(h0[k][rr], 0.0f);
+                for (int rr = 0; rr < 4; ++rr) h0[k][rr] = relu1(h0[k][rr]);
                 *(f32x4*)&H0[k * 1024 + wave * 256 + q * 64 + e * 4] = h0[k];            // H0[k][cb][q][env][r]
             }
+#pragma unroll
+            for (int j = 0; j < XH; ++j) {
+                const int hx = XH * (wave - 1) + j;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) hx0[j][rr] = relu1(hx0[j][rr]);
+                if (hx < K) *(f32x4*)&H0[hx * 1024 + q * 64 + e * 4] = hx0[j];
+            }
+        } else {
+            {                                                              // unclipped action and mean: coalesced linear copies of the tile
+                const size_t base_a = (trow + b0) * NA;
+                const int lim_a = min(16, r.B - b0) * NA;
+#pragma unroll
+                for (int j = 0; j < (16 * NA + 63) / 64; ++j) {
+                    const int i = lane + 64 * j;
+                    if (i < lim_a) { (r.act + base_a)[(unsigned)i] = AK[i]; (r.mean + base_a)[(unsigned)i] = AK[16 * NA + i]; }
+                }
+            }
+            const size_t base = (trow + b0) * NS;               // obs[t]: coalesced linear copy of the tile
+            const int lim = min(16, r.B - b0) * NS;
+            float ov[(16 * NS + 63) / 64];                                 // all LDS reads first: one register per store, no store waits for another
+#pragma unroll
+            for (int j = 0; j < (16 * NS + 63) / 64; ++j) ov[j] = ST[min(lane + 64 * j, 16 * NS - 1)];
+#pragma unroll
+            for (int j = 0; j < (16 * NS + 63) / 64; ++j) { const int i = lane + 64 * j; if (i < lim) (r.obs + base)[(unsigned)i] = ov[j]; }
         }
         PH_MARK(2)
         __syncthreads();                                                   // B1: layer-0 activations of all heads visible
         PH_MARK(3)
-        // Global stores are issued HERE, at the start of the long matrix phase: a workgroup barrier waits for the wave's outstanding
-        // stores (vmcnt(0)), so stores issued right before B0 / B1 put their ~600-cycle acknowledge latency on the step's critical path
-        if (wave == 0 && active) {                                         // wave 0 is the policy wave: unclipped action and mean
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) { const int d = 4 * q + rr; if (d < NA) { r.act[tb * NA + d] = a_keep[rr]; r.mean[tb * NA + d] = mu_keep[rr]; } }
-        }
-        if (wave == 0) {                                                   // obs[t]: coalesced linear copy of the tile
-            const size_t base = ((size_t)t * r.B + b0) * NS;
-            const int lim = min(16, r.B - b0) * NS;
-#pragma unroll
-            for (int j = 0; j < (16 * NS + 63) / 64; ++j) { const int i = lane + 64 * j; if (i < lim) r.obs[base + i] = ST[i]; }
-        }
         float su2 = 0.0f;                                                  // sum_d clip(a_d)^2 of the own env (ACT is complete since B1)
 #pragma unroll
         for (int d = 0; d < NA; ++d) { const float ac = ACT[e * NA + d]; su2 = fmaf(ac, ac, su2); }
         // ---- layer 1 (own col-block) and the layer-2 partial over the own 16 hidden units ----------------
+        PH_MARK(10)
         __builtin_amdgcn_s_setprio(1);          // the matrix-heavy phase wins issue arbitration over a co-resident workgroup's VALU phases
         f32x4 h1[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) h1[k] = *(const f32x4*)&BD1[k * 64 + 16 * wave + 4 * q];
+        constexpr int NHB = ONE ? 2 : 1;                                   // ONE: layer-0 activations fetched one col-block ahead (registers to spare)
+        f32x4 hb[NHB][K];
+        if (ONE) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) hb[0][k] = *(const f32x4*)&H0[k * 1024 + q * 64 + e * 4];
+        }
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
-            f32x4 hb[K];
+            if (ONE) {
+                if (cb < 3) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) hb[k] = *(const f32x4*)&H0[k * 1024 + cb * 256 + q * 64 + e * 4];
+                    for (int k = 0; k < K; ++k) hb[(cb + 1) % NHB][k] = *(const f32x4*)&H0[k * 1024 + (cb + 1) * 256 + q * 64 + e * 4];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; ++k) hb[0][k] = *(const f32x4*)&H0[k * 1024 + cb * 256 + q * 64 + e * 4];
+            }
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
 #pragma unroll
-                for (int k = 0; k < K; ++k) h1[k] = MFMA16(wd1[k][cb * 4 + rr], hb[k][rr], h1[k]);
+                for (int k = 0; k < K; ++k) h1[k] = MFMA16(wd1[k][cb * 4 + rr], hb[cb % NHB][k][rr], h1[k]);
                 __builtin_amdgcn_sched_barrier(0x94);                      // only SALU / VMEM / LDS instructions may cross
+                if (ONE) pin_order(h1);                                    // and the K chains advance in lock-step (mfma_common.h)
             }
         }
+        PH_MARK(11)
 #pragma unroll
         for (int k = 0; k < K; ++k)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) h1[k][rr] = fmaxf(h1[k][rr], 0.0f);
+            for (int rr = 0; rr < 4; ++rr) h1[k][rr] = relu1(h1[k][rr]);
         {
             f32x4 po[K][OUT_CB];
 #pragma unroll
@@ -332,7 +418,7 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
         // ---- selection (env_helpers.py:617-634): out_k = b2_k + sum_w partial ; next = dmean + dstd*out + s ----
         ts += 1;
         int sel = cur_model;
-        if (r.sam_mode == METRPO_SAM_STEP_RAND) sel = (r.model_idx != nullptr) ? (active ? r.model_idx[tb] : 0) : rng_index(dstep.z, K);
+        if (r.sam_mode == METRPO_SAM_STEP_RAND) sel = (r.model_idx != nullptr) ? (active ? (r.model_idx + trow)[ub] : 0) : rng_index(dstep.z, K);
         if (r.sam_mode == METRPO_SAM_ONE_MODEL) sel = 0;
         const bool simple = (r.sam_mode == METRPO_SAM_STEP_RAND || r.sam_mode == METRPO_SAM_EPS_RAND || r.sam_mode == METRPO_SAM_ONE_MODEL);
         f32x4 nx[OUT_CB];
@@ -364,7 +450,7 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
                         const int dim = 16 * cb + 4 * q + rr;
-                        const float nz = (r.sel_noise != nullptr) ? ((active && dim < NS) ? r.sel_noise[tb * NS + dim] : 0.0f) : zz[rr];
+                        const float nz = (r.sel_noise != nullptr) ? ((active && dim < NS) ? (r.sel_noise + trow * NS)[ub * NS + dim] : 0.0f) : zz[rr];
                         nx[cb][rr] = fmaf(nz, sqrtf(var[rr] / (float)K), m[rr]);
                     }
                 } else {                                                  // model_med: np.median over K
@@ -396,7 +482,7 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
             else if (ENV == METRPO_ENV_HALF_CHEETAH) cost = -fminf(fmaxf(xr - 1e-1f * 0.5f * su2, -10.0f), 10.0f);
             else cost = -(xr - 1e-2f * 0.5f * su2);
             dn = (ts >= r.H);
-            if (wave == 2 && q == ((RDIM & 15) >> 2) && active) { r.rew[tb] = -cost; r.done[tb] = dn ? 1 : 0; r.tpath[tb] = ts - 1; }
+            if (wave == 2 && q == ((RDIM & 15) >> 2) && active) { (r.rew + trow)[ub] = -cost; (r.done + trow)[ub] = dn ? 1 : 0; (r.tpath + trow)[ub] = ts - 1; }
         } else {
             float pen = 0.0f; int fin = 1;
 #pragma unroll
@@ -423,7 +509,7 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
                 dn = !((zc >= 0.2f) && (zc <= 1.0f) && (f2 != 0));
             }
             dn = dn || (ts >= r.H);
-            if (wave == 2 && q == 0 && active) { r.rew[tb] = -cost; r.done[tb] = dn ? 1 : 0; r.tpath[tb] = ts - 1; }
+            if (wave == 2 && q == 0 && active) { (r.rew + trow)[ub] = -cost; (r.done + trow)[ub] = dn ? 1 : 0; (r.tpath + trow)[ub] = ts - 1; }
         }
         PH_MARK(7)
         // ---- reset(dones) (:585-595) or advance; every wave keeps its own copy of the tile state ----------
@@ -431,9 +517,8 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
             int row = 0;
             if (dn) {
                 if (active) {
-                    const size_t rb = (size_t)(t + 1) * r.B + b;
-                    row = (r.reset_idx != nullptr) ? r.reset_idx[rb] : rng_index(dstep.w, r.n_pool);
-                    cur_model = (r.reset_model != nullptr) ? r.reset_model[rb] : rng_index16(dstep.z, K);
+                    row = (r.reset_idx != nullptr) ? (r.reset_idx + trow + r.B)[ub] : rng_index(dstep.w, r.n_pool);
+                    cur_model = (r.reset_model != nullptr) ? (r.reset_model + trow + r.B)[ub] : rng_index16(dstep.z, K);
                 }
                 ts = 0;
             }
@@ -442,7 +527,7 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
                     const int dim = 16 * cb + 4 * q + rr;
-                    if (dim < NS) ST[e * NS + dim] = dn ? r.pool[(size_t)row * NS + dim] : nx[cb][rr];
+                    if (dim < NS) ST[e * NS + dim] = dn ? r.pool[(unsigned)(row * NS + dim)] : nx[cb][rr];
                 }
         } else {
 #pragma unroll
@@ -462,15 +547,27 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
         wave_lds_sync();
         PH_MARK(8)
     }
+    if (ONE && t_end < r.T) {                                              // hand the tile over (another workgroup runs steps t_end..T-1)
+        if (wave == 0) {
+            const int lim = 16 * NS;
+            for (int i = lane; i < lim; i += 64) r.mig_obs[(size_t)b0 * NS + i] = ST[i];
+            if (q == 0) { r.mig_ts[b] = ts; r.mig_model[b] = cur_model; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (lane == 0) __hip_atomic_store(&r.mig_flag[tile], r.mig_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+        if (wave == 0 && r.last_obs != nullptr) {
+            const int lim = min(16, r.B - b0) * NS;
+            for (int i = lane; i < lim; i += 64) r.last_obs[(size_t)b0 * NS + i] = ST[i];
+        }
+        if (wave == 0 && q == 0 && active) {
+            if (r.last_ts != nullptr) r.last_ts[b] = ts;
+            if (r.last_model != nullptr) r.last_model[b] = cur_model;
+        }
+    }
+    __syncthreads();                                                       // the next piece re-initialises the tile state in LDS
+    }
     PH_DUMP
-    if (wave == 0 && r.last_obs != nullptr) {
-        const int lim = min(16, r.B - b0) * NS;
-        for (int i = lane; i < lim; i += 64) r.last_obs[(size_t)b0 * NS + i] = ST[i];
-    }
-    if (wave == 0 && q == 0 && active) {
-        if (r.last_ts != nullptr) r.last_ts[b] = ts;
-        if (r.last_model != nullptr) r.last_model[b] = cur_model;
-    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -491,13 +588,36 @@ int coop_select_config(metrpo_ctx* c) {
     return -1;
 }
 
-int launch_rollout_coop(metrpo_ctx* c, int idx, const RolloutK& r, hipStream_t st) {
+// Launch rule.  tiles <= n_sm: one workgroup per tile, each alone on its CU (spill-free instantiation with the whole register file).
+// n_sm < tiles <= MIG_RATIO x n_sm (the shipped B = 5000: 313 tiles on 256 CUs): still ONE workgroup per CU, and the tiles x T
+// tile-steps are dealt out evenly with tiles migrating between two workgroups once (see the kernel) -- co-residency would leave 57
+// CUs with two tiles setting the wall time while 199 idle half of it.  Beyond: two co-resident workgroups per CU (more throughput per
+// CU than one tile at a time once every CU has two).
+static constexpr double MIG_RATIO = 1.55;
+int launch_rollout_coop(metrpo_ctx* c, int idx, const RolloutK& r_in, hipStream_t st) {
     const CoopEntry& en = kCoop[idx];
     const size_t sh = sizeof(float) * (size_t)en.lds_floats;
-    const int tiles = (r.B + 15) / 16;
-    const coop_kernel_t kern = (tiles <= c->n_sm) ? en.kern_one : en.kern;       // one tile per CU at most: the spill-free instantiation
+    const int tiles = (r_in.B + 15) / 16;
+    RolloutK r = r_in;
+    const bool one = tiles <= (int)(MIG_RATIO * c->n_sm) && c->rollout_variant != 2;
+    const int grid = one ? (tiles < c->n_sm ? tiles : c->n_sm) : tiles;
+    if (one && tiles > grid) {                                           // hand-over slots: flag[tiles] | ts[16 tiles] | model[16 tiles] | obs[16 tiles][ns]
+        const int ns = c->pd.ns;
+        if (c->mig_cap < tiles) {
+            if (c->d_mig) { HIP_TRY(c, hipFree(c->d_mig)); c->d_mig = nullptr; c->mig_cap = 0; }
+            const size_t bytes = sizeof(int32_t) * (size_t)tiles * (1 + 32 + 16 * ns);
+            HIP_TRY(c, hipMalloc(&c->d_mig, bytes));
+            HIP_TRY(c, hipMemsetAsync(c->d_mig, 0, bytes, st));
+            c->mig_cap = tiles; c->mig_epoch = 0;
+        }
+        int32_t* base = (int32_t*)c->d_mig;
+        r.mig_flag = base; r.mig_ts = base + c->mig_cap; r.mig_model = base + 17 * (size_t)c->mig_cap;
+        r.mig_obs = (float*)(base + 33 * (size_t)c->mig_cap);
+        r.mig_epoch = ++c->mig_epoch;
+    }
+    const coop_kernel_t kern = one ? en.kern_one : en.kern;
     if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), sh, st, r, c->d_dyn, c->d_theta, c->d_norm);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), sh, st, r, c->d_dyn, c->d_theta, c->d_norm);
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;
 }

@@ -79,7 +79,8 @@ class Engine(object):
             self._ctx = None
 
     def set_rollout_variant(self, v):
-        """Test hook: 0 = fastest rollout kernel available, 1 = head-per-wave MFMA kernel.  Returns the variant that
+        """Test hook: 0 = fastest rollout kernel available, 1 = head-per-wave MFMA kernel, 2 = cooperative kernel in its
+        two-workgroups-per-CU instantiation at any batch size.  Returns the variant that
         will run: 3 step-wise GEMM (large nets), 2 cooperative-heads MFMA, 1 head-per-wave MFMA, 0 generic."""
         self._variant = int(v)
         return int(lib.metrpo_set_rollout_variant(self._ctx, int(v)))

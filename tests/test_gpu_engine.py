@@ -97,7 +97,7 @@ def test_policy_actions_parity():
     assert torch.equal(a2, m2) and torch.equal(m2, m)
 
 
-@pytest.mark.parametrize('variant', ['generic', 'head_per_wave', 'coop'])
+@pytest.mark.parametrize('variant', ['generic', 'head_per_wave', 'coop', 'coop_two_per_cu'])
 @pytest.mark.parametrize('env,sam_mode,determ', [('swimmer', 'step_rand', False), ('swimmer', 'eps_rand', True),
                                                  ('ant', 'step_rand', False), ('swimmer', 'model_mean_std', False),
                                                  ('half_cheetah', 'model_med', False), ('snake', 'model_mean', False),
@@ -108,7 +108,7 @@ def test_rollout_parity_teacher_forced(env, sam_mode, determ, variant):
     K, B, T, H = 5, 200, 12, 5
     eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (64, 64), (32, 32), seed=7)
     force_generic = variant == 'generic'
-    running = eng.set_rollout_variant(1 if variant == 'head_per_wave' else 0)
+    running = eng.set_rollout_variant({'head_per_wave': 1, 'coop_two_per_cu': 2}.get(variant, 0))
     if not force_generic:
         assert running == (1 if variant == 'head_per_wave' else 2)
     if env == 'ant':
@@ -189,7 +189,7 @@ def test_rollout_variants_share_rng_stream(env):
     K, B, T, H = 5, 300, 6, 3
     eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (64, 64), (32, 32), seed=17)
     ref = eng.rollout(B, T, H, 'step_rand', pool, seed=99, force_generic=True)
-    for variant in (1, 0):
+    for variant in (1, 0, 2):
         eng.set_rollout_variant(variant)
         got = eng.rollout(B, T, H, 'step_rand', pool, seed=99)
         np.testing.assert_allclose(cpu(got.act), cpu(ref.act), rtol=1e-4, atol=2e-5)

@@ -88,3 +88,37 @@ def test_full_size_iteration_properties(name):
     eng.set_policy(theta0)
     out2 = eng.trpo_update(batch)
     assert torch.equal(eng.get_policy(), theta1) and out2['n_backtrack'] == out['n_backtrack']      # bitwise repeat of the update
+
+
+@pytest.mark.parametrize('env,H,mode', [('swimmer', 100, 'step_rand'), ('ant', 12, 'eps_rand'), ('half_cheetah', 37, 'model_mean_std')])
+def test_migrating_tiles_equal_whole_tiles(env, H, mode):
+    """B = 5000 is 313 tiles on 256 CUs: the cooperative kernel deals the tile-steps out evenly and hands tiles from one workgroup
+    to the next in the middle of a trajectory (rollout_coop.hip).  The trajectories must be bitwise those of the same environments
+    run as two launches small enough that every tile stays on one workgroup (same Philox streams through stream_offset)."""
+    import metrpo_amd
+    B, T = 5000, H + 3                                                      # T > H: horizon resets inside the launch as well
+    dm, theta, pdims, pool = O.make_problem(env, K=5, dyn_hidden=(64, 64), pol_hidden=(32, 32), seed=4, n_pool=512, dtype=np.float32)
+    eng = metrpo_amd.Engine(env, 5, (64, 64), (32, 32))
+    eng.set_dynamics_layers(dm.Ws, dm.bs, dm.in_mean, dm.in_std, dm.diff_mean, dm.diff_std)
+    eng.set_policy(theta)
+    if eng.rollout_path() != 2:
+        pytest.skip('cooperative kernel not selected')
+    pool_d = torch.as_tensor(pool, device=eng.device)
+    ls = lambda n: (torch.empty(n, dtype=torch.int32, device=eng.device), torch.empty(n, dtype=torch.int32, device=eng.device))
+    whole_ls = ls(B)
+    whole = eng.rollout(B, T, H, mode, pool_d, seed=11, last_state=whole_ls)
+    B1 = 2496
+    parts, parts_ls = [], []
+    for off, n in ((0, B1), (B1, B - B1)):
+        parts_ls.append(ls(n))
+        parts.append(eng.rollout(n, T, H, mode, pool_d, seed=11, stream_offset=off, last_state=parts_ls[-1]))
+    torch.cuda.synchronize()
+    for name in ('obs', 'act', 'rew', 'mean', 'done', 'tpath'):
+        cat = torch.cat([getattr(p, name) for p in parts], dim=1)
+        assert torch.equal(getattr(whole, name), cat), name
+    assert torch.equal(whole.last_obs, torch.cat([p.last_obs for p in parts], dim=0))
+    for i in range(2):
+        assert torch.equal(whole_ls[i], torch.cat([p[i] for p in parts_ls]))
+    # and a second launch on the same context (hand-over flags are epoch-stamped, not cleared)
+    again = eng.rollout(B, T, H, mode, pool_d, seed=11)
+    assert torch.equal(again.obs, whole.obs) and torch.equal(again.rew, whole.rew)

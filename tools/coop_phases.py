@@ -15,7 +15,7 @@ eng.set_policy(metrpo_amd.xavier_policy_theta(eng.ns, (32, 32), eng.na))
 pool = torch.as_tensor(synthetic.make_pool(env), device='cuda')
 lib = C.CDLL(_lib.LIB_PATH)
 names = ['policy', 'rng+action', 'dyn L0 + H0 write', 'barrier 1', 'dyn L1 + L2 + PART write', 'barrier 2', 'selection',
-         'reward/done/stores', 'reset/advance', 'obs store + loop']
+         'reward/done/stores', 'reset/advance', 'obs store + loop', '  (stores + su2 after B1)', '  (layer 1)', '-', '-']
 for B in (4096, 8192):
     out = eng.alloc_trajectory(B, H, H)
     for i in range(3):
@@ -24,7 +24,7 @@ for B in (4096, 8192):
     buf = (C.c_ulonglong * 32)()
     assert lib.metrpo_debug_coop_phases(buf) == 0
     for w, lab in ((0, 'first workgroup'),) if B == 4096 else ((0, 'first workgroup'), (1, 'last workgroup')):
-        v = [buf[16 * w + i] / H for i in range(10)]
+        v = [buf[16 * w + i] / H for i in range(14)]
         print('B=%d %s: total %.0f cycles/step' % (B, lab, sum(v)))
         for n, x in zip(names, v):
             print('    %-28s %7.0f' % (n, x))
