@@ -258,30 +258,42 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
             }
             f32x4 m0, m1 = {0.f, 0.f, 0.f, 0.f};
             {
-                float w1[16];
+                // Straight-line code plus an explicit issue pipeline (sched_group_barrier): each tanh (v_mul, v_exp, v_add, v_rcp, v_fma:
+                // ~45 cycles of VALU / transcendental issue) is placed behind the MFMA pair (layer 1) or MFMA (layer 2) of the PREVIOUS
+                // k-step, so that it runs while the matrix pipe works.  Left to itself the compiler evaluates all eight tanh of a layer
+                // first and then lets every MFMA wait for the final fma of its operand.
+                float w1[16], w2[8];
 #pragma unroll
                 for (int f = 0; f < 16; ++f) w1[f] = pw1[f * 64];
+#pragma unroll
+                for (int f = 0; f < 8; ++f) w2[f] = pw2[f * 64];
                 p1[0] = *(const f32x4*)&BP1[4 * q]; p1[1] = *(const f32x4*)&BP1[16 + 4 * q];
+                m0 = *(const f32x4*)&BP2[4 * q];
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) {
                     const float hv = tanh_fast(p0[kk >> 2][kk & 3]);
                     p1[0] = MFMA16(w1[2 * kk], hv, p1[0]);
                     p1[1] = MFMA16(w1[2 * kk + 1], hv, p1[1]);
-                    __builtin_amdgcn_sched_barrier(0);
                 }
-            }
-            {
-                float w2[8];
-#pragma unroll
-                for (int f = 0; f < 8; ++f) w2[f] = pw2[f * 64];
-                m0 = *(const f32x4*)&BP2[4 * q];
 #pragma unroll
                 for (int kk = 0; kk < 8; kk += 2) {
                     const float ha = tanh_fast(p1[kk >> 2][kk & 3]);
                     m0 = MFMA16(w2[kk], ha, m0);
                     const float hb = tanh_fast(p1[(kk + 1) >> 2][(kk + 1) & 3]);
                     m1 = MFMA16(w2[kk + 1], hb, m1);
-                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 64, 0);                // every LDS read of the block (inputs, weight fragments, biases) up front
+                __builtin_amdgcn_sched_group_barrier(0x008, C::NS_KS * 2, 0);      // layer 0
+                __builtin_amdgcn_sched_group_barrier(0x402, 5, 0);                 // tanh of k-step 0
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);             // layer 1, k-step kk
+                    __builtin_amdgcn_sched_group_barrier(0x402, 5, 0);             // tanh of k-step kk+1 (the last one: layer 2's first)
+                }
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // layer 2, k-step kk
+                    if (kk < 7) __builtin_amdgcn_sched_group_barrier(0x402, 5, 0);
                 }
             }
             const f32x4 mu = m0 + m1;
