@@ -10,11 +10,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // turn K interleaved independent chains into back-to-back DEPENDENT matrix instructions (seen in the single-tile instantiation of
 // rollout_coop.hip: 8 dependent MFMAs in a row, each waiting out the full pipeline depth).  Emits no instruction.
 template <int K> __device__ __forceinline__ void pin_order(f32x4 (&a)[K]) {
-    // "a": the accumulation registers, where the register allocator keeps MFMA results of a kernel that owns the whole register file
-    if constexpr (K == 5) asm volatile("" : "+a"(a[0]), "+a"(a[1]), "+a"(a[2]), "+a"(a[3]), "+a"(a[4]));
+    // "v": rollout_coop.hip is compiled with -amdgpu-mfma-vgpr-form, MFMA results live in the vector half.  (With "a" the layer-1
+    // results sat in accumulation registers and every ReLU needed a v_accvgpr_read first -- which queues behind the MFMA in flight:
+    // the 20 layer-2 MFMAs took 80 cycles each instead of 32.)
+    if constexpr (K == 5) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]));
     else {
 #pragma unroll
-        for (int k = 0; k < K; ++k) asm volatile("" : "+a"(a[k]));
+        for (int k = 0; k < K; ++k) asm volatile("" : "+v"(a[k]));
     }
 }
 

@@ -103,6 +103,9 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
     float ls[4], inv_std[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { ls[r] = (4 * q + r < NA) ? fmaxf(theta[pLS + 4 * q + r], LOG_MIN_STD) : 0.f; inv_std[r] = expf(-ls[r]); }
+    float fisher_w[4];                                      // 1 / (std^2 + eps/2), hoisted out of the tile loop (exp + full-precision division per tile)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) fisher_w[r] = 1.0f / (expf(2.f * ls[r]) + 0.5f * KL_EPS);
     f32x4 vb0f[HB], vb1f[HB], vb2f;
     if (MODE == MODE_FVP) {
 #pragma unroll
@@ -150,44 +153,70 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
 
     const long long ntiles = (k.N + 15) / 16;
     const f32x4* __restrict__ hc = (const f32x4*)k.hcache;
-    f32x4 hn[2 * HB];                                       // cached activations of the NEXT tile (register double buffer: HBM latency)
-    if (CACHED) {
-        const long long t_first = (long long)blockIdx.x * NWAVES + wave;
-#pragma unroll
-        for (int j = 0; j < 2 * HB; ++j) hn[j] = (t_first < ntiles) ? hc[(t_first * (2 * HB) + j) * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    for (long long tile = (long long)blockIdx.x * NWAVES + wave; tile < ntiles; tile += (long long)gridDim.x * NWAVES) {
+    // Everything a tile reads from HBM (observations in both layouts, valid flag, cached activations, and for the loss modes the old
+    // distribution / action / advantage) is fetched ONE TILE AHEAD into registers: consumed in the iteration that issued them, the
+    // valid flag and the observation loads each put a full HBM round trip (~2000 cycles) on the wave's critical path, per tile.
+    struct TileIn {
+        float xB[NS_KS]; float xTs[4][NSI]; float ols[4], omu[4], act[4], adv; f32x4 gmv; int vld; f32x4 h[2 * HB];
+    };
+    auto fetch = [&](long long tile, TileIn& in) {
         const long long n0 = tile * 16, n = n0 + c;
-        const bool inr = n < k.N;
-        const bool ok = inr && (k.valid == nullptr || k.valid[n]);
-        // The tile is processed as a few long MFMA runs with the VALU work of the neighbouring stages placed textually inside them
-        // (it issues in the matrix pipe's shadow), and every activation is dropped into its own wave-private transpose tile the
-        // moment it exists, so the three sample-contracted weight-gradient products run as ONE run after a single LDS sync.
-        float xB[NS_KS];
+        const bool inr = tile < ntiles && n < k.N;
 #pragma unroll
-        for (int s = 0; s < NS_KS; ++s) { const int f = 4 * s + q; xB[s] = (inr && f < NS) ? k.obs[n * NS + f] : 0.f; }
-        // the sample-contracted products of S7 read the observations transposed ([feature 16ci + c][sample 4s + q]): fetched HERE, at
-        // the top of the tile, so that their global-memory latency is covered by the whole forward / back-prop chain
-        float xTs[4][NSI];
+        for (int s = 0; s < NS_KS; ++s) { const int f = 4 * s + q; in.xB[s] = (inr && f < NS) ? k.obs[n * NS + f] : 0.f; }
         if (MODE != MODE_LOSSKL) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const long long ns_ = n0 + 4 * s + q;
 #pragma unroll
-                for (int ci = 0; ci < NSI; ++ci) { const int f = 16 * ci + c; xTs[s][ci] = (ns_ < k.N && f < NS) ? k.obs[ns_ * NS + f] : 0.f; }
+                for (int ci = 0; ci < NSI; ++ci) { const int f = 16 * ci + c; in.xTs[s][ci] = (tile < ntiles && ns_ < k.N && f < NS) ? k.obs[ns_ * NS + f] : 0.f; }
             }
         }
+        in.vld = inr ? ((k.valid == nullptr) ? 1 : (int)k.valid[n]) : 0;
+        if (MODE != MODE_FVP) {
+            if (MODE == MODE_GRAD && k.gm != nullptr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) in.gmv[r] = (inr && 4 * q + r < NA) ? k.gm[n * NA + 4 * q + r] : 0.f;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int d = 4 * q + r;
+                    const bool on = inr && d < NA;
+                    in.ols[r] = on ? k.old_ls[(size_t)n * k.ls_stride + d] : 0.f;
+                    in.omu[r] = on ? k.old_mean[n * NA + d] : 0.f;
+                    in.act[r] = on ? k.act[n * NA + d] : 0.f;
+                }
+                in.adv = inr ? k.adv[n] : 0.f;
+            }
+        }
+        if (CACHED) {
+#pragma unroll
+            for (int j = 0; j < 2 * HB; ++j) in.h[j] = (tile < ntiles) ? hc[(tile * (2 * HB) + j) * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    TileIn nxt;
+    fetch((long long)blockIdx.x * NWAVES + wave, nxt);
+    // vmcnt(0) HERE: otherwise the wait for these first loads is placed inside the loop, at the top of every iteration, right
+    // behind the prefetch of the next tile -- which it then waits for as well
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (long long tile = (long long)blockIdx.x * NWAVES + wave; tile < ntiles; tile += (long long)gridDim.x * NWAVES) {
+        const long long n0 = tile * 16, n = n0 + c;
+        const bool inr = n < k.N;
+        const TileIn in = nxt;
+        fetch(tile + (long long)gridDim.x * NWAVES, nxt);
+        asm volatile("" ::: "memory");                      // the loads are issued HERE (left alone, the compiler sinks them to the end of the iteration)
+        const bool ok = inr && in.vld != 0;
+        // The tile is processed as a few long MFMA runs with the VALU work of the neighbouring stages placed textually inside them
+        // (it issues in the matrix pipe's shadow), and every activation is dropped into its own wave-private transpose tile the
+        // moment it exists, so the three sample-contracted weight-gradient products run as ONE run after a single LDS sync.
+        const float (&xB)[NS_KS] = in.xB;
+        const float (&xTs)[4][NSI] = in.xTs;                // observations transposed ([feature 16ci + c][sample 4s + q]) for S7
         float* T_H0 = TL, *T_H1 = TL + HB * TILE, *T_D1 = TL + 2 * HB * TILE, *T_D0 = TL + 3 * HB * TILE, *T_UM = TL + 4 * HB * TILE;
         // ---- S1: layer 0, forward and (FVP) tangent  ------------------------------------------------------
         f32x4 h0[HB], h1[HB], t0[HB], t1[HB];
         if (CACHED) {
 #pragma unroll
-            for (int cb = 0; cb < HB; ++cb) { h0[cb] = hn[cb]; h1[cb] = hn[HB + cb]; }
-            const long long t_next = tile + (long long)gridDim.x * NWAVES;
-            if (t_next < ntiles) {
-#pragma unroll
-                for (int j = 0; j < 2 * HB; ++j) hn[j] = hc[(t_next * (2 * HB) + j) * 64 + lane];
-            }
+            for (int cb = 0; cb < HB; ++cb) { h0[cb] = in.h[cb]; h1[cb] = in.h[HB + cb]; }
         }
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb) { if (!CACHED) h0[cb] = b0f[cb]; if (MODE == MODE_FVP) t0[cb] = vb0f[cb]; }
@@ -253,7 +282,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
         f32x4 um = Z4;                                      // d(objective)/d(mean) in D layout [d = 4q+r][sample c]
         if (MODE == MODE_GRAD && k.gm != nullptr) {         // VJP mode (bptt.hip): the mean-adjoint is an input
 #pragma unroll
-            for (int r = 0; r < 4; ++r) um[r] = (ok && 4 * q + r < NA) ? k.gm[n * NA + 4 * q + r] : 0.f;
+            for (int r = 0; r < 4; ++r) um[r] = (ok && 4 * q + r < NA) ? in.gmv[r] : 0.f;
         } else if (MODE != MODE_FVP) {
             f32x4 mu = Z4;
             if (L2V) {
@@ -281,7 +310,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
             for (int r = 0; r < 4; ++r) {
                 const int d = 4 * q + r;
                 if (d < NA && ok) {
-                    const float ols = k.old_ls[(size_t)n * k.ls_stride + d], omu = k.old_mean[n * NA + d], a = k.act[n * NA + d];
+                    const float ols = in.ols[r], omu = in.omu[r], a = in.act[r];
                     const float z = (a - mu[r]) * inv_std[r], zo = (a - omu) * expf(-ols);
                     llr += (ols - ls[r]) + 0.5f * (zo * zo - z * z);
                     zz[r] = z;
@@ -292,7 +321,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
                 }
             }
             llr = xsum_q(llr);                              // sum over action dims held by the 4 q-lanes of sample c
-            const float la = ok ? expf(llr) * k.adv[n] : 0.f;      // lr * adv
+            const float la = ok ? expf(llr) * in.adv : 0.f;         // lr * adv
             if (q == 0) acc0 -= la * k.inv_n;               // surr_loss = -mean(lr*adv) (npo.py:75), once per sample
             if (MODE == MODE_LOSSKL) { acc1 += kl * k.inv_n; continue; }
             const float w = -la * k.inv_n;
@@ -329,11 +358,8 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
                 for (int kk = 0; kk < KK; ++kk) m0 = MFMA16(FRAG1(I::O_W2F, kk), t1[kk >> 2][kk & 3], m0);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float s2 = expf(2.f * ls[r]);
-                // d2 KL / d mean^2 = 1 / (s^2 + eps/2)
-                um[r] = (ok && 4 * q + r < NA) ? (m0[r] + m1[r]) / (s2 + 0.5f * KL_EPS) * k.inv_n : 0.f;
-            }
+            for (int r = 0; r < 4; ++r)                     // d2 KL / d mean^2 = 1 / (s^2 + eps/2)
+                um[r] = (ok && 4 * q + r < NA) ? (m0[r] + m1[r]) * fisher_w[r] * k.inv_n : 0.f;
             if (ok && q == 0) accw += k.inv_n;
         }
         // ---- S5/S6: back-prop (transposed chain); deltas go straight into their transpose tiles ---------------------

@@ -15,11 +15,14 @@
 // Developer instrumentation (make EXTRA=-DCOOP_TIMING): per-phase shader-clock sums of wave 0 of workgroup 0 and of the
 // last workgroup, read back with metrpo_debug_coop_phases (tools/coop_phases.py).  Not part of the shipped library.
 #ifdef COOP_TIMING
-__device__ unsigned long long g_coop_phase[2][16];
-#define PH_DECL unsigned long long ph_t = __builtin_readcyclecounter(), ph_acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define PH_MARK(i) { const unsigned long long n_ = __builtin_readcyclecounter(); ph_acc[i] += n_ - ph_t; ph_t = n_; }
-#define PH_DUMP { if (lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) for (int i_ = 0; i_ < 14; ++i_) g_coop_phase[blockIdx.x == 0 ? 0 : 1][i_] = ph_acc[i_]; }
-extern "C" int32_t metrpo_debug_coop_phases(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coop_phase), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -1; }
+// s_memtime (the SHADER_CYCLES hardware register reads 0 on gfx950); all four waves of workgroup 0.  Every mark also drains the wave's
+// LDS queue (s_memtime returns through lgkmcnt), so phases that overlap LDS latency with later work look longer than they are.
+__device__ unsigned long long g_coop_phase[4][16];
+#define PH_NOW() __builtin_readcyclecounter()
+#define PH_DECL unsigned long long ph_t = PH_NOW(); unsigned long long ph_acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define PH_MARK(i) { if ((COOP_TIMING >> (i)) & 1) { const unsigned long long n_ = PH_NOW(); ph_acc[i] += n_ - ph_t; ph_t = n_; } }   // -DCOOP_TIMING=<bit mask of live marks>
+#define PH_DUMP { if (lane == 0 && blockIdx.x == 0) for (int i_ = 0; i_ < 14; ++i_) g_coop_phase[wave][i_] = ph_acc[i_]; }
+extern "C" int32_t metrpo_debug_coop_phases(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coop_phase), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1; }
 #else
 #define PH_DECL
 #define PH_MARK(i)
@@ -41,7 +44,10 @@ struct Coop {
 
 // ONE: instantiation for launches with at most one tile per CU -- the whole register file (512 lanes-wide registers per SIMD) belongs to
 // one workgroup, so the half-cheetah / Ant weight fragments (150 VGPRs) stop spilling to scratch.
-template <int ENV, int K, bool ONE>
+// DRAWS: instantiation for launches that SUPPLY draws (eps / model_idx / sel_noise / reset_idx / reset_model: the parity tests).  The
+// production instantiation (Philox draws) has no global load in the step loop outside the rare reset branch, hence no s_waitcnt
+// vmcnt in it: a vmcnt wait also waits for the step's stores, whose acknowledge latency then lands on the critical path.
+template <int ENV, int K, bool ONE, bool DRAWS>
 __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, const float* __restrict__ dynp,
                                                       const float* __restrict__ theta, const float* __restrict__ norm) {
     using L = Coop<ENV, K>;
@@ -184,8 +190,8 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
         int row = 0;
         if (active && !resume) {
             const uint4 d0 = rng_draw(r.seed, genv, 0, RNG_RESET, 0);
-            row = (r.reset_idx != nullptr) ? r.reset_idx[b] : rng_index(d0.x, r.n_pool);
-            cur_model = (r.reset_model != nullptr) ? r.reset_model[b] : rng_index(d0.y, K);
+            row = (DRAWS && r.reset_idx != nullptr) ? r.reset_idx[b] : rng_index(d0.x, r.n_pool);
+            cur_model = (DRAWS && r.reset_model != nullptr) ? r.reset_model[b] : rng_index(d0.y, K);
         }
         if (active && resume) { cur_model = r.init_model[b]; ts = r.init_ts[b]; }      // continuation of a chunked rollout
 #pragma unroll
@@ -200,6 +206,10 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
 
     uint4 dstep = make_uint4(0, 0, 0, 0); float z[4] = {0.f, 0.f, 0.f, 0.f};
     if (AHEAD) step_draws(r.t0 + t_begin, dstep, z);
+    // vmcnt(0) HERE: every global load above (weight fragments, normaliser, initial state) is complete before the step loop.  Without
+    // it the compiler places the wait for those loop-invariant loads at their first use INSIDE the loop, where it is executed every
+    // step and then also waits for the stores of the previous step (HBM acknowledge latency on the step's critical path).
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     for (int t = t_begin; t < t_end; ++t) {
         PH_MARK(9)
         const size_t trow = (size_t)t * r.B;                               // uniform row base; lane offsets stay 32-bit (scalar base + offset addressing)
@@ -304,7 +314,7 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
                 if (d < NA) {
                     float a = mu[rr];
                     if (!r.determ) {
-                        const float zz = (r.eps != nullptr) ? (active ? (r.eps + trow * NA)[ub * NA + d] : 0.0f) : z[rr];
+                        const float zz = (DRAWS && r.eps != nullptr) ? (active ? (r.eps + trow * NA)[ub * NA + d] : 0.0f) : z[rr];
                         a = fmaf(zz, sig[rr], a);
                     }
                     AK[e * NA + d] = a; AK[16 * NA + e * NA + d] = mu[rr];
@@ -430,7 +440,7 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
         // ---- selection (env_helpers.py:617-634): out_k = b2_k + sum_w partial ; next = dmean + dstd*out + s ----
         ts += 1;
         int sel = cur_model;
-        if (r.sam_mode == METRPO_SAM_STEP_RAND) sel = (r.model_idx != nullptr) ? (active ? (r.model_idx + trow)[ub] : 0) : rng_index(dstep.z, K);
+        if (r.sam_mode == METRPO_SAM_STEP_RAND) sel = (DRAWS && r.model_idx != nullptr) ? (active ? (r.model_idx + trow)[ub] : 0) : rng_index(dstep.z, K);
         if (r.sam_mode == METRPO_SAM_ONE_MODEL) sel = 0;
         const bool simple = (r.sam_mode == METRPO_SAM_STEP_RAND || r.sam_mode == METRPO_SAM_EPS_RAND || r.sam_mode == METRPO_SAM_ONE_MODEL);
         f32x4 nx[OUT_CB];
@@ -458,11 +468,11 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
 #pragma unroll
                     for (int k = 0; k < K; ++k) { const f32x4 d = hv[k] - m; var += d * d; }
                     float zz[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (r.sel_noise == nullptr) normal4(rng_draw(r.seed, genv, r.t0 + t, RNG_SELNOISE, 4 * cb + q), zz);
+                    if (!DRAWS || r.sel_noise == nullptr) normal4(rng_draw(r.seed, genv, r.t0 + t, RNG_SELNOISE, 4 * cb + q), zz);
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
                         const int dim = 16 * cb + 4 * q + rr;
-                        const float nz = (r.sel_noise != nullptr) ? ((active && dim < NS) ? (r.sel_noise + trow * NS)[ub * NS + dim] : 0.0f) : zz[rr];
+                        const float nz = (DRAWS && r.sel_noise != nullptr) ? ((active && dim < NS) ? (r.sel_noise + trow * NS)[ub * NS + dim] : 0.0f) : zz[rr];
                         nx[cb][rr] = fmaf(nz, sqrtf(var[rr] / (float)K), m[rr]);
                     }
                 } else {                                                  // model_med: np.median over K
@@ -529,8 +539,8 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
             int row = 0;
             if (dn) {
                 if (active) {
-                    row = (r.reset_idx != nullptr) ? (r.reset_idx + trow + r.B)[ub] : rng_index(dstep.w, r.n_pool);
-                    cur_model = (r.reset_model != nullptr) ? (r.reset_model + trow + r.B)[ub] : rng_index16(dstep.z, K);
+                    row = (DRAWS && r.reset_idx != nullptr) ? (r.reset_idx + trow + r.B)[ub] : rng_index(dstep.w, r.n_pool);
+                    cur_model = (DRAWS && r.reset_model != nullptr) ? (r.reset_model + trow + r.B)[ub] : rng_index16(dstep.z, K);
                 }
                 ts = 0;
             }
@@ -584,8 +594,9 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
 
 // -------------------------------------------------------------------------------------------------
 typedef void (*coop_kernel_t)(RolloutK, const float*, const float*, const float*);
-struct CoopEntry { int env, K; coop_kernel_t kern, kern_one; int lds_floats; };
-#define CENTRY(ENVID, KK) {ENVID, KK, k_rollout_coop<ENVID, KK, false>, k_rollout_coop<ENVID, KK, true>, Coop<ENVID, KK>::TOTAL}
+struct CoopEntry { int env, K; coop_kernel_t kern[2][2]; int lds_floats; };     // kern[one workgroup per CU][draws supplied]
+#define CENTRY(ENVID, KK) {ENVID, KK, {{k_rollout_coop<ENVID, KK, false, false>, k_rollout_coop<ENVID, KK, false, true>}, \
+                                       {k_rollout_coop<ENVID, KK, true, false>, k_rollout_coop<ENVID, KK, true, true>}}, Coop<ENVID, KK>::TOTAL}
 static const CoopEntry kCoop[] = {
     CENTRY(METRPO_ENV_SWIMMER, 5), CENTRY(METRPO_ENV_HALF_CHEETAH, 5), CENTRY(METRPO_ENV_HOPPER, 5),
     CENTRY(METRPO_ENV_SNAKE, 5), CENTRY(METRPO_ENV_ANT, 5),
@@ -627,7 +638,8 @@ int launch_rollout_coop(metrpo_ctx* c, int idx, const RolloutK& r_in, hipStream_
         r.mig_obs = (float*)(base + 33 * (size_t)c->mig_cap);
         r.mig_epoch = ++c->mig_epoch;
     }
-    const coop_kernel_t kern = one ? en.kern_one : en.kern;
+    const bool draws = r.eps || r.model_idx || r.sel_noise || r.reset_idx || r.reset_model;
+    const coop_kernel_t kern = en.kern[one ? 1 : 0][draws ? 1 : 0];
     if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), sh, st, r, c->d_dyn, c->d_theta, c->d_norm);
     HIP_TRY(c, hipGetLastError());

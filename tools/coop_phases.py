@@ -16,15 +16,16 @@ pool = torch.as_tensor(synthetic.make_pool(env), device='cuda')
 lib = C.CDLL(_lib.LIB_PATH)
 names = ['policy', 'rng+action', 'dyn L0 + H0 write', 'barrier 1', 'dyn L1 + L2 + PART write', 'barrier 2', 'selection',
          'reward/done/stores', 'reset/advance', 'obs store + loop', '  (stores + su2 after B1)', '  (layer 1)', '-', '-']
-for B in (4096, 8192):
+for B in (4096, 5000):
     out = eng.alloc_trajectory(B, H, H)
     for i in range(3):
         eng.rollout(B, H, H, 'step_rand', pool, seed=i, out=out)
     torch.cuda.synchronize()
-    buf = (C.c_ulonglong * 32)()
+    buf = (C.c_ulonglong * 64)()
     assert lib.metrpo_debug_coop_phases(buf) == 0
-    for w, lab in ((0, 'first workgroup'),) if B == 4096 else ((0, 'first workgroup'), (1, 'last workgroup')):
-        v = [buf[16 * w + i] / H for i in range(14)]
-        print('B=%d %s: total %.0f cycles/step' % (B, lab, sum(v)))
-        for n, x in zip(names, v):
-            print('    %-28s %7.0f' % (n, x))
+    steps = H if B == 4096 else None            # B = 5000: workgroup 0 runs 123 tile-steps (migration schedule)
+    n = H if B == 4096 else -(-((B + 15) // 16) * H // 256)
+    v = [[buf[16 * w + i] / n for i in range(14)] for w in range(4)]
+    print('B=%d workgroup 0, cycles/step per wave: totals %s' % (B, ' '.join('%6.0f' % sum(x) for x in v)))
+    for i, nme in enumerate(names):
+        print('    %-28s %s' % (nme, ' '.join('%6.0f' % v[w][i] for w in range(4))))
