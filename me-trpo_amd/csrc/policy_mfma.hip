@@ -8,8 +8,8 @@
 //     fragment of one layer is the B operand of the next when the k-steps are enumerated (cb, r)
 //     (same trick as rollout_mfma.hip), so these chains never leave registers;
 //   * the weight gradients  G[i][j] = sum_n a[i][n] d[j][n]  contract over SAMPLES, i.e. over the lane
-//     index of the D fragments, so a and d take one 16x16 transpose through LDS (row stride 17, conflict
-//     free) and G accumulates in MFMA accumulators across all tiles of the wave;
+//     index of the D fragments, so a and d take one 16x16 transpose through LDS (sample order permuted so that
+//     the contracting side reads 16 bytes at a time) and G accumulates in MFMA accumulators across all tiles of the wave;
 //   * waves -> block partial (LDS, fixed order) -> global partial row -> k_finalize (fixed order,
 //     float64): bitwise reproducible.
 #include "device_common.h"
@@ -17,6 +17,9 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define PART_EXTRA 3
+#ifndef POL_SKIP
+#define POL_SKIP 0              // developer experiments (tools/build_variant.sh): bit mask of tile stages to leave out; results are then meaningless
+#endif
 #define NWAVES 8                // waves per block: one block per CU (2 waves per SIMD), the weight image is shared by all 8
 constexpr int cdiv_(int a, int b) { return (a + b - 1) / b; }
 
@@ -58,7 +61,10 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
     constexpr int NS_KS = I::NS_KS, NSI = cdiv_(NS, 16), HB = I::HB, KK = I::KK;
     constexpr int pW0 = 0, pb0 = NS * PH, pW1 = pb0 + PH, pb1 = pW1 + PH * PH, pW2 = pb1 + PH, pb2 = pW2 + PH * NA,
                   pLS = pb2 + NA, P = pLS + NA, ROW = P + PART_EXTRA;
-    constexpr int TS = 17, TILE = 16 * TS;                  // transpose tile: 16 rows, stride 17 floats (conflict free)
+    // transpose tile T[unit][sample position]: sample n sits at position 4 (n & 3) + (n >> 2), so the four samples 4s + q (s = 0..3) that lane
+    // q contracts in S7 are CONTIGUOUS: one ds_read_b128 per tile and array instead of four scalar reads (S7's LDS reads were 11 of an
+    // FVP's 70 us).  Row stride 20 floats keeps the 16-byte reads aligned (2-way bank conflicts on both sides).
+    constexpr int TS = 20, TILE = 16 * TS;
     constexpr int WTL = (4 * HB + 1) * TILE;                // per-wave transpose tiles: h0, h1, d1, d0 (HB each) and u
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -211,6 +217,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
         // moment it exists, so the three sample-contracted weight-gradient products run as ONE run after a single LDS sync.
         const float (&xB)[NS_KS] = in.xB;
         const float (&xTs)[4][NSI] = in.xTs;                // observations transposed ([feature 16ci + c][sample 4s + q]) for S7
+        const int wpos = 4 * (c & 3) + (c >> 2);            // this lane's sample in the permuted row order
         float* T_H0 = TL, *T_H1 = TL + HB * TILE, *T_D1 = TL + 2 * HB * TILE, *T_D0 = TL + 3 * HB * TILE, *T_UM = TL + 4 * HB * TILE;
         // ---- S1: layer 0, forward and (FVP) tangent  ------------------------------------------------------
         f32x4 h0[HB], h1[HB], t0[HB], t1[HB];
@@ -242,13 +249,13 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
 #pragma unroll
             for (int cb = 0; cb < HB; ++cb) {
                 if (!CACHED) h1[cb] = MFMA16(FRAG2(I::O_W1F, kk, cb), h0[kk >> 2][kk & 3], h1[cb]);
-                if (MODE == MODE_FVP) t1[cb] = MFMA16(FRAG2(I::O_V1F, kk, cb), h0[kk >> 2][kk & 3], t1[cb]);
+                if (MODE == MODE_FVP) { if (POL_SKIP & 4) t1[cb][0] += h0[kk >> 2][kk & 3]; else t1[cb] = MFMA16(FRAG2(I::O_V1F, kk, cb), h0[kk >> 2][kk & 3], t1[cb]); }
             }
         if (MODE != MODE_LOSSKL) {
 #pragma unroll
             for (int cb = 0; cb < HB; ++cb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) T_H0[cb * TILE + (4 * q + r) * TS + c] = h0[cb][r];
+                for (int r = 0; r < ((POL_SKIP & 8) ? 0 : 4); ++r) T_H0[cb * TILE + (4 * q + r) * TS + wpos] = h0[cb][r];
         }
         if (MODE == MODE_FVP) {
 #pragma unroll
@@ -259,7 +266,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-                for (int cb = 0; cb < HB; ++cb) t1[cb] = MFMA16(FRAG2(I::O_W1F, kk, cb), t0[kk >> 2][kk & 3], t1[cb]);
+                for (int cb = 0; cb < HB; ++cb) { if (POL_SKIP & 4) t1[cb][1] += t0[kk >> 2][kk & 3]; else t1[cb] = MFMA16(FRAG2(I::O_W1F, kk, cb), t0[kk >> 2][kk & 3], t1[cb]); }
         }
         if (!CACHED) {
 #pragma unroll
@@ -271,7 +278,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
 #pragma unroll
             for (int cb = 0; cb < HB; ++cb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) T_H1[cb * TILE + (4 * q + r) * TS + c] = h1[cb][r];
+                for (int r = 0; r < ((POL_SKIP & 8) ? 0 : 4); ++r) T_H1[cb * TILE + (4 * q + r) * TS + wpos] = h1[cb][r];
         }
         if (MODE == MODE_GRAD && k.hcache != nullptr) {     // publish the activations for the FVPs of this update
             f32x4* hw = (f32x4*)k.hcache + (size_t)tile * (2 * HB) * 64 + lane;
@@ -381,7 +388,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
                     }
         } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) T_UM[(4 * q + r) * TS + c] = um[r];
+            for (int r = 0; r < 4; ++r) T_UM[(4 * q + r) * TS + wpos] = um[r];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (r >= NA) continue;                      // k-step r covers action dims r, 4+r, 8+r, 12+r: all padding when r >= na
@@ -393,31 +400,38 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
         for (int cb = 0; cb < HB; ++cb) {
             d0[cb] = Z4;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { d1[cb][r] *= fmaf(-h1[cb][r], h1[cb][r], 1.f); T_D1[cb * TILE + (4 * q + r) * TS + c] = d1[cb][r]; }
+            for (int r = 0; r < 4; ++r) { d1[cb][r] *= fmaf(-h1[cb][r], h1[cb][r], 1.f); T_D1[cb * TILE + (4 * q + r) * TS + wpos] = d1[cb][r]; }
         }
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-            for (int cb = 0; cb < HB; ++cb) d0[cb] = MFMA16(FRAG2(I::O_W1B, kk, cb), d1[kk >> 2][kk & 3], d0[cb]);
+            for (int cb = 0; cb < HB; ++cb) { if (POL_SKIP & 4) d0[cb][2] += d1[kk >> 2][kk & 3]; else d0[cb] = MFMA16(FRAG2(I::O_W1B, kk, cb), d1[kk >> 2][kk & 3], d0[cb]); }
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { d0[cb][r] *= fmaf(-h0[cb][r], h0[cb][r], 1.f); T_D0[cb * TILE + (4 * q + r) * TS + c] = d0[cb][r]; }
+            for (int r = 0; r < 4; ++r) { d0[cb][r] *= fmaf(-h0[cb][r], h0[cb][r], 1.f); T_D0[cb * TILE + (4 * q + r) * TS + wpos] = d0[cb][r]; }
         gb2 += um;
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb) { gb1[cb] += d1[cb]; gb0[cb] += d0[cb]; }
         // ---- S7: weight gradients G[i][j] += sum_n a[i][n] d[j][n] as one MFMA run ------------------------------------
         // D fragment [unit 16cb+4q+r][sample c] -> T[unit][sample]; k-step s of the MFMA covers samples 4s+q
         wave_sync_lds();
+        f32x4 a1v[HB], a0v[HB], b1v[HB], b0v[HB], buv = Z4;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int col = c * TS + 4 * s + q;
-            const float bu = L2V ? 0.f : T_UM[col];
+        for (int cb = 0; cb < HB; ++cb) {
+            a1v[cb] = *(const f32x4*)&T_H1[cb * TILE + c * TS + 4 * q]; a0v[cb] = *(const f32x4*)&T_H0[cb * TILE + c * TS + 4 * q];
+            b1v[cb] = *(const f32x4*)&T_D1[cb * TILE + c * TS + 4 * q]; b0v[cb] = *(const f32x4*)&T_D0[cb * TILE + c * TS + 4 * q];
+        }
+        if (!L2V) buv = *(const f32x4*)&T_UM[c * TS + 4 * q];
+#pragma unroll
+        for (int s = 0; s < ((POL_SKIP & 2) ? 0 : 4); ++s) {
+            const float bu = buv[s];
             float a1_[HB], a0_[HB], b1_[HB], b0_[HB], xT[NSI];
 #pragma unroll
-            for (int cb = 0; cb < HB; ++cb) { a1_[cb] = T_H1[cb * TILE + col]; a0_[cb] = T_H0[cb * TILE + col]; b1_[cb] = T_D1[cb * TILE + col]; b0_[cb] = T_D0[cb * TILE + col]; }
+            for (int cb = 0; cb < HB; ++cb) { a1_[cb] = a1v[cb][s]; a0_[cb] = a0v[cb][s]; b1_[cb] = b1v[cb][s]; b0_[cb] = b0v[cb][s]; }
 #pragma unroll
             for (int ci = 0; ci < NSI; ++ci) xT[ci] = xTs[s][ci];
+            if (POL_SKIP & 1) { gW1[0][0][0] += a0_[0] + b1_[0] + a1_[0] + b0_[0] + xT[0] + a0_[HB - 1] + b1_[HB - 1] + a1_[HB - 1] + b0_[HB - 1] + bu; continue; }
             if (!L2V) {
 #pragma unroll
                 for (int ci = 0; ci < HB; ++ci) gW2[ci] = MFMA16(a1_[ci], bu, gW2[ci]);
@@ -530,7 +544,7 @@ typedef void (*pol_kernel_t)(PolK, const float*, const float*, float*);
 struct PolEntry { int ns, na, ph; pol_kernel_t kern[4]; int lds_floats; void (*build_map)(std::vector<int>&); };
 template <int NS, int NA, int PH> constexpr int pol_lds() {
     constexpr int HB = cdiv_(PH, 16);
-    constexpr int a = PolImg<NS, NA, PH>::TOTAL + NWAVES * (4 * HB + 1) * 16 * 17;
+    constexpr int a = PolImg<NS, NA, PH>::TOTAL + NWAVES * (4 * HB + 1) * 16 * 20;      // 20 = TS of the kernel's transpose tiles
     constexpr int P = NS * PH + PH + PH * PH + PH + PH * NA + NA + NA;
     constexpr int b = NWAVES * (P + PART_EXTRA);
     return a > b ? a : b;
