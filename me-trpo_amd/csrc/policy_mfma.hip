@@ -20,7 +20,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef POL_SKIP
 #define POL_SKIP 0              // developer experiments (tools/build_variant.sh): bit mask of tile stages to leave out; results are then meaningless
 #endif
+#ifndef NWAVES
 #define NWAVES 8                // waves per block: one block per CU (2 waves per SIMD), the weight image is shared by all 8
+#endif
 constexpr int cdiv_(int a, int b) { return (a + b - 1) / b; }
 
 
@@ -65,7 +67,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
     // q contracts in S7 are CONTIGUOUS: one ds_read_b128 per tile and array instead of four scalar reads (S7's LDS reads were 11 of an
     // FVP's 70 us).  Row stride 20 floats keeps the 16-byte reads aligned (2-way bank conflicts on both sides).
     constexpr int TS = 20, TILE = 16 * TS;
-    constexpr int WTL = (4 * HB + 1) * TILE;                // per-wave transpose tiles: h0, h1, d1, d0 (HB each) and u
+    constexpr int WTL = (4 * HB + (NA <= 2 ? 0 : 1)) * TILE;   // per-wave transpose tiles: h0, h1, d1, d0 (HB each) and, with the output layer on the MFMA, u
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
@@ -544,7 +546,7 @@ typedef void (*pol_kernel_t)(PolK, const float*, const float*, float*);
 struct PolEntry { int ns, na, ph; pol_kernel_t kern[4]; int lds_floats; void (*build_map)(std::vector<int>&); };
 template <int NS, int NA, int PH> constexpr int pol_lds() {
     constexpr int HB = cdiv_(PH, 16);
-    constexpr int a = PolImg<NS, NA, PH>::TOTAL + NWAVES * (4 * HB + 1) * 16 * 20;      // 20 = TS of the kernel's transpose tiles
+    constexpr int a = PolImg<NS, NA, PH>::TOTAL + NWAVES * (4 * HB + (NA <= 2 ? 0 : 1)) * 16 * 20;      // 20 = TS of the kernel's transpose tiles
     constexpr int P = NS * PH + PH + PH * PH + PH + PH * NA + NA + NA;
     constexpr int b = NWAVES * (P + PART_EXTRA);
     return a > b ? a : b;
