@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
                 for (int rr = 0; rr < 4; ++rr) hx0[j][rr] = relu1(hx0[j][rr]);
                 if (hx < K) *(f32x4*)&H0[hx * 1024 + q * 64 + e * 4] = hx0[j];
             }
-        } else {
+        } else if (!(COOP_SKIP & 256)) {
             {                                                              // unclipped action and mean: coalesced linear copies of the tile
                 const size_t base_a = (trow + b0) * NA;
                 const int lim_a = min(16, r.B - b0) * NA;
@@ -482,6 +482,7 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
             const int off = e * NSP + 16 * cb + 4 * q;
             const f32x4 sv = xc[cb];
             auto head = [&](int k) -> f32x4 {
+                if (COOP_SKIP & 128) return sv * 0.999f;
                 const float* pp = PART + (size_t)k * 4 * 16 * NSP + off;
                 f32x4 o = *(const f32x4*)&BD2[k * NSP + 16 * cb + 4 * q];
                 o += (*(const f32x4*)&pp[0] + *(const f32x4*)&pp[16 * NSP]) + (*(const f32x4*)&pp[2 * 16 * NSP] + *(const f32x4*)&pp[3 * 16 * NSP]);
