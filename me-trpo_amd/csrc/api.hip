@@ -130,6 +130,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
         return METRPO_EHIP;
     }
     if (hipMemset(c->d_dyn, 0, sizeof(float) * (size_t)pd.K * pd.dyn.n_params) != hipSuccess) { c->err = "hipMemset failed"; return METRPO_EHIP; }
+    if (hipMemset(c->d_ticket, 0, sizeof(unsigned int)) != hipSuccess) { c->err = "hipMemset failed"; return METRPO_EHIP; }   // the reductions' arrival counter resets itself
     c->mfma_cfg = mfma_select_config(c);
     c->pol_mfma = policy_mfma_select(pd);
     c->coop_cfg = coop_select_config(c);
@@ -455,7 +456,6 @@ int run_trpo_update(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_para
     const int implicit_hd = pr->explicit_final_hvp ? 0 : 1;
     CgTail tl; tl.P = P; tl.last = 0; tl.implicit_hd = implicit_hd; tl.reg = pr->reg_coeff; tl.tol = pr->residual_tol; tl.max_kl = pr->max_kl;
     tl.x = v.x; tl.r = v.r; tl.p = v.p; tl.z = v.z; tl.step = v.step; tl.scal = v.scal; tl.gout = v.gout; tl.pf = c->d_vf; tl.ticket = c->d_ticket;
-    HIP_TRY(c, hipMemsetAsync(c->d_ticket, 0, sizeof(unsigned int), st));
     tl.op = 3;
     c->hcache_on = 1;                    // the gradient kernel publishes tanh activations, the CG products of this solve reuse them
     struct CacheOff { metrpo_ctx* c; ~CacheOff() { c->hcache_on = 0; } } cache_off{c};
@@ -486,8 +486,7 @@ int run_trpo_update(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_para
     }
     if (g_out) HIP_TRY(c, hipMemcpyAsync(g_out, v.gout + 1, sizeof(double) * P, hipMemcpyDeviceToDevice, st));
     if (dir_out) HIP_TRY(c, hipMemcpyAsync(dir_out, v.x, sizeof(double) * P, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->h_pinned, v.gout, sizeof(double), hipMemcpyDeviceToHost, st));          // loss_before
-    HIP_TRY(c, hipMemcpyAsync(c->h_pinned + 1, v.scal, sizeof(double) * 5, hipMemcpyDeviceToHost, st));
+    // read-backs: ONE copy per line-search trial fetches scal[8] | lk[2] (loss at theta, beta, CG iterations, trial loss and KL)
     double loss = NAN, kl = NAN, loss_before = NAN;
     int n_iter = 0;
     bool first = true;
@@ -497,23 +496,26 @@ int run_trpo_update(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_para
         hipLaunchKernelGGL(k_try_theta, dim3((P + 255) / 256), dim3(256), 0, st, P, ratio, c->d_theta, v.step, c->d_theta_try);
         if ((rc = launch_loss_kl(c, b, c->d_theta_try, v.lk, st))) return rc;
         AR(v.lk, 2);
-        HIP_TRY(c, hipMemcpyAsync(c->h_pinned + 8, v.lk, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(c->h_pinned, v.scal, sizeof(double) * 10, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
-        if (first) { loss_before = c->h_pinned[0]; first = false; }
+        if (first) { loss_before = c->h_pinned[S_LOSS0]; first = false; }
         loss = c->h_pinned[8]; kl = c->h_pinned[9];
         if (loss < loss_before && kl <= pr->max_kl) break;
     }
-    if (first) { HIP_TRY(c, hipStreamSynchronize(st)); loss_before = c->h_pinned[0]; }
+    if (first) {
+        HIP_TRY(c, hipMemcpyAsync(c->h_pinned, v.scal, sizeof(double) * 10, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st)); loss_before = c->h_pinned[S_LOSS0];
+    }
     bool accepted = true;
     if ((std::isnan(loss) || std::isnan(kl) || loss >= loss_before || kl >= pr->max_kl) && !pr->accept_violation) accepted = false;
     if (accepted) {
-        HIP_TRY(c, hipMemcpyAsync(c->d_theta, c->d_theta_try, sizeof(float) * P, hipMemcpyDeviceToDevice, st));
+        std::swap(c->d_theta, c->d_theta_try);               // both ctx-owned, every launch takes c->d_theta afresh: no copy
         if (c->mfma_cfg >= 0 && (rc = mfma_prepare_policy(c, st))) return rc;
     }
     if (diag) {
         diag->loss_before = loss_before; diag->loss = loss; diag->kl = kl;
-        diag->beta = c->h_pinned[1 + S_BETA]; diag->n_backtrack = n_iter; diag->accepted = accepted ? 1 : 0;
-        diag->cg_iters_run = (int)c->h_pinned[1 + S_ITERS];
+        diag->beta = c->h_pinned[S_BETA]; diag->n_backtrack = n_iter; diag->accepted = accepted ? 1 : 0;
+        diag->cg_iters_run = (int)c->h_pinned[S_ITERS];
     }
     HIP_TRY(c, hipGetLastError());
 #undef AR

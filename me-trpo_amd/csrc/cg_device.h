@@ -5,7 +5,7 @@
 #pragma once
 #include "metrpo_internal.h"
 
-enum { S_RDOTR = 0, S_DONE = 1, S_BETA = 2, S_XHX = 3, S_ITERS = 4 };
+enum { S_RDOTR = 0, S_DONE = 1, S_BETA = 2, S_XHX = 3, S_ITERS = 4, S_LOSS0 = 5 };   // S_LOSS0: surrogate loss at theta (copy of gout[0]: one read-back fetches scal | lk)
 
 struct CgTail {
     int op;                 // 0 none, 1 = CG iteration, 2 = step-size finish from an explicit H.d, 3 = CG initialisation from the gradient
@@ -15,7 +15,7 @@ struct CgTail {
     double *x, *r, *p, *z, *step, *scal;
     const double* gout;     // [1 + P]: loss, gradient (b of the solve)
     float* pf;
-    unsigned int* ticket;   // zeroed by the driver before every CG solve; the last block resets it
+    unsigned int* ticket;   // zero at allocation; the last block of every reduction resets it
 };
 
 // r, p <- g; x <- 0; pf <- (float) g   (krylov.cg prologue)
@@ -57,7 +57,7 @@ __device__ __forceinline__ void cg_init_body(int P, const double* gout, double* 
         acc += g * g;
     }
     const double rdotr = blk_sum(acc, sh);
-    if (threadIdx.x == 0) { scal[S_RDOTR] = rdotr; scal[S_DONE] = 0.0; scal[S_ITERS] = 0.0; }
+    if (threadIdx.x == 0) { scal[S_RDOTR] = rdotr; scal[S_DONE] = 0.0; scal[S_ITERS] = 0.0; scal[S_LOSS0] = gout[0]; }
 }
 
 // one krylov.cg iteration after z = f_Ax(p) has been formed (z lacks the reg term: added here)
