@@ -543,7 +543,7 @@ static void pol_image_map(std::vector<int>& map) {
 
 // -------------------------------------------------------------------------------------------------
 typedef void (*pol_kernel_t)(PolK, const float*, const float*, float*);
-struct PolEntry { int ns, na, ph; pol_kernel_t kern[4]; int lds_floats; void (*build_map)(std::vector<int>&); };
+struct PolEntry { int ns, na, ph; pol_kernel_t kern[4]; int lds_floats, lds_floats_eval; void (*build_map)(std::vector<int>&); };
 template <int NS, int NA, int PH> constexpr int pol_lds() {
     constexpr int HB = cdiv_(PH, 16);
     constexpr int a = PolImg<NS, NA, PH>::TOTAL + NWAVES * (4 * HB + (NA <= 2 ? 0 : 1)) * 16 * 20;      // 20 = TS of the kernel's transpose tiles
@@ -551,7 +551,12 @@ template <int NS, int NA, int PH> constexpr int pol_lds() {
     constexpr int b = NWAVES * (P + PART_EXTRA);
     return a > b ? a : b;
 }
-#define PENTRY(NS, NA, PH) {NS, NA, PH, {k_policy_mfma<NS, NA, PH, 0>, k_policy_mfma<NS, NA, PH, 1>, k_policy_mfma<NS, NA, PH, 2>, k_policy_mfma<NS, NA, PH, 3>}, pol_lds<NS, NA, PH>(), pol_image_map<NS, NA, PH>}
+template <int NS, int NA, int PH> constexpr int pol_lds_eval() {       // MODE_LOSSKL: weight image, then the epilogue's [NWAVES][ROW] rows
+    constexpr int P = NS * PH + PH + PH * PH + PH + PH * NA + NA + NA;
+    constexpr int a = PolImg<NS, NA, PH>::TOTAL, b = NWAVES * (P + PART_EXTRA);
+    return a > b ? a : b;
+}
+#define PENTRY(NS, NA, PH) {NS, NA, PH, {k_policy_mfma<NS, NA, PH, 0>, k_policy_mfma<NS, NA, PH, 1>, k_policy_mfma<NS, NA, PH, 2>, k_policy_mfma<NS, NA, PH, 3>}, pol_lds<NS, NA, PH>(), pol_lds_eval<NS, NA, PH>(), pol_image_map<NS, NA, PH>}
 static const PolEntry kPol[] = {
     PENTRY(10, 2, 32),    // swimmer
     PENTRY(18, 6, 32),    // half-cheetah
@@ -596,7 +601,9 @@ int policy_mfma_launch(metrpo_ctx* c, int idx, int mode, const metrpo_batch* b, 
         k.hcache = c->d_hcache;
         if (mode == MODE_FVP) mode = MODE_FVPC;
     }
-    const size_t sh = sizeof(float) * (size_t)en.lds_floats;
+    // loss + KL evaluation (line search): no transpose tiles, 128 VGPRs -> two blocks fit a CU (run_mode launches 2 x n_sm of them)
+    size_t sh = sizeof(float) * (size_t)en.lds_floats;
+    if (mode == MODE_LOSSKL) sh = sizeof(float) * (size_t)en.lds_floats_eval;
     if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)en.kern[mode], hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     hipLaunchKernelGGL(en.kern[mode], dim3(nblocks), dim3(NWAVES * 64), sh, st, k, theta, v, partials);
     HIP_TRY(c, hipGetLastError());

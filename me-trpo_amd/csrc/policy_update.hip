@@ -406,7 +406,8 @@ static int run_mode(metrpo_ctx* c, int mode, const metrpo_batch* b, const PolK& 
         const long long tiles = (b->N + 15) / 16;
         // one 8-wave block per CU = 2 waves per SIMD (measured in round 1: 2 and 3 waves per SIMD run at the same speed, 1 and 4
         // are slower) and only n_sm partial rows for k_finalize
-        const int g = (int)std::max<long long>(1, std::min<long long>((tiles + 7) / 8, (long long)c->n_sm));
+        // (the loss + KL evaluation of the line search needs no transpose tiles and half the registers: two blocks per CU)
+        const int g = (int)std::max<long long>(1, std::min<long long>((tiles + 7) / 8, (long long)c->n_sm * (mode == 2 ? 2 : 1)));
         int rc = ensure_partials(c, g); if (rc) return rc;
         *nrows = g; *stride = P + PART_EXTRA; *lk_col = P;
         return policy_mfma_launch(c, c->pol_mfma, mode, b, theta, vf, c->d_partials, g, st);
