@@ -203,27 +203,47 @@ __global__ void __launch_bounds__(256) k_gram_mfma(const float* __restrict__ obs
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.0;
     const long long ntiles = (N + 15) / 16;
+    // Raw inputs of a tile (4 k-steps x {valid, step index, return, NFB observation columns}) are fetched ONE TILE AHEAD: 20 small
+    // gathers per lane whose HBM latency otherwise sits between every two tiles of a wave (the kernel ran at 0.5 TB/s).
+    struct TileIn { float o[4][NFB]; float rv[4]; int tp[4]; int ok[4]; };
+    auto fetch = [&](long long tile, TileIn& in) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const long long n = tile * 16 + 4 * s + q;
+            const bool inr = tile < ntiles && n < N;
+            const long long nc = inr ? n : 0;
+            in.ok[s] = inr ? ((valid == nullptr) ? 1 : (int)valid[nc]) : 0;
+            in.tp[s] = tpath[nc];
+            in.rv[s] = ret[nc];
+#pragma unroll
+            for (int cb = 0; cb < NFB; ++cb) {
+                const int f = 16 * cb + c;
+                const int fo = (f < ns) ? f : ((f < 2 * ns) ? f - ns : 0);
+                in.o[s][cb] = obs[nc * ns + fo];
+            }
+        }
+    };
+    TileIn nxt;
+    fetch((long long)blockIdx.x * 4 + wave, nxt);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0) here, not at the top of every iteration (see policy_mfma.hip)
     for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+        const TileIn in = nxt;
+        fetch(tile + (long long)gridDim.x * 4, nxt);
+        asm volatile("" ::: "memory");                      // the loads are issued here, before this tile's arithmetic
         f32x4 g[NFB][NFB];
 #pragma unroll
         for (int a = 0; a < NFB; ++a)
 #pragma unroll
             for (int b = 0; b < NFB; ++b) g[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // branch-free feature evaluation: every lane issues its loads unconditionally (clamped indices) so the 4 k-steps'
-        // loads are all in flight together; selection happens in registers
-        float val[4][NFB];
+        float val[4][NFB];                                  // branch-free feature evaluation (selection in registers)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const long long n = tile * 16 + 4 * s + q;
-            const long long nc = (n < N) ? n : (N - 1);
-            const bool ok = (n < N) && (valid == nullptr || valid[nc]);
-            const float al = (float)tpath[nc] / 100.0f;
-            const float rv = ret[nc];
+            const float al = (float)in.tp[s] / 100.0f;
+            const float rv = in.rv[s];
 #pragma unroll
             for (int cb = 0; cb < NFB; ++cb) {
                 const int f = 16 * cb + c;
-                const int fo = (f < ns) ? f : ((f < 2 * ns) ? f - ns : 0);
-                const float o = fminf(fmaxf(obs[nc * ns + fo], -10.f), 10.f);
+                const float o = fminf(fmaxf(in.o[s][cb], -10.f), 10.f);
                 const int kq = f - 2 * ns;
                 float x = (f < ns) ? o : o * o;
                 x = (kq == 0) ? al : x;
@@ -232,7 +252,7 @@ __global__ void __launch_bounds__(256) k_gram_mfma(const float* __restrict__ obs
                 x = (kq == 3) ? 1.0f : x;
                 x = (f == F) ? rv : x;
                 x = (f > F) ? 0.0f : x;
-                val[s][cb] = ok ? x : 0.0f;
+                val[s][cb] = in.ok[s] ? x : 0.0f;
             }
         }
 #pragma unroll
@@ -291,7 +311,7 @@ static int launch_gram_mfma(metrpo_ctx* c, const float* obs, const float* ret, c
     constexpr int M = NFB * 16;
     const int F = 2 * c->pd.ns + 4;
     const long long tiles = (N + 15) / 16;
-    const int g = (int)std::max<long long>(1, std::min<long long>((tiles + 3) / 4, (long long)c->n_sm * (NFB <= 2 ? 8 : 2)));   // latency-bound: many resident waves
+    const int g = (int)std::max<long long>(1, std::min<long long>((tiles + 3) / 4, (long long)c->n_sm * 2));   // inputs are prefetched one tile ahead: few blocks, few partial matrices
     const size_t need = (size_t)g * (F * F + F);
     if (need > c->gram_cap) {
         if (c->d_gram_part) HIP_TRY(c, hipFree(c->d_gram_part));
