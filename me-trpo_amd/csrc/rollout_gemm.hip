@@ -86,16 +86,24 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
     const bool active = b < r.B;
     float* ST = lds + IMG + wave * 16 * NS;
     if (r.stop != nullptr && *r.stop != 0) return;               // the sampling loop already ended (metrpo_sampler_progress)
-    for (int i = tid; i < IMG; i += 256) {
-        float w = 0.0f;
-        const int ln = i & 63, cc = ln & 15, qq = ln >> 4;
-        if (i < O_PF1) { const int f = i >> 6, s_ = f >> 1, cb = f & 1, in = 4 * s_ + qq; if (in < NS) w = theta[C::pW0 + in * PH + 16 * cb + cc]; }
-        else if (i < O_PF2) { const int f = (i - O_PF1) >> 6, kk = f >> 1, cb = f & 1; w = theta[C::pW1 + (16 * (kk >> 2) + 4 * qq + (kk & 3)) * PH + 16 * cb + cc]; }
-        else if (i < O_B0) { const int kk = (i - O_PF2) >> 6; if (cc < NA) w = theta[C::pW2 + (16 * (kk >> 2) + 4 * qq + (kk & 3)) * NA + cc]; }
-        else if (i < O_B1) w = theta[C::pb0 + (i - O_B0)];
-        else if (i < O_B2) w = theta[C::pb1 + (i - O_B1)];
-        else { const int d = i - O_B2; if (d < NA) w = theta[C::pb2 + d]; }
-        lds[i] = w;
+    {   // weight image: all gathers of a thread are issued before the first LDS store (one L2 round trip, not one per element)
+        constexpr int NIT = (IMG + 255) / 256;
+        float wv[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + 256 * it;
+            float w = 0.0f;
+            const int ln = i & 63, cc = ln & 15, qq = ln >> 4;
+            if (i < O_PF1) { const int f = i >> 6, s_ = f >> 1, cb = f & 1, in = 4 * s_ + qq; if (in < NS) w = theta[C::pW0 + in * PH + 16 * cb + cc]; }
+            else if (i < O_PF2) { const int f = (i - O_PF1) >> 6, kk = f >> 1, cb = f & 1; w = theta[C::pW1 + (16 * (kk >> 2) + 4 * qq + (kk & 3)) * PH + 16 * cb + cc]; }
+            else if (i < O_B0) { const int kk = (i - O_PF2) >> 6; if (cc < NA) w = theta[C::pW2 + (16 * (kk >> 2) + 4 * qq + (kk & 3)) * NA + cc]; }
+            else if (i < O_B1) w = theta[C::pb0 + (i - O_B0)];
+            else if (i < O_B2) w = theta[C::pb1 + (i - O_B1)];
+            else if (i < IMG) { const int d = i - O_B2; if (d < NA) w = theta[C::pb2 + d]; }
+            wv[it] = w;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) { const int i = tid + 256 * it; if (i < IMG) lds[i] = wv[it]; }
     }
     const uint64_t genv = r.stream_offset + (uint64_t)b;
     if (t == 0 && active && q == 0 && r.init_obs != nullptr) {   // continuation of a chunked rollout
