@@ -7,13 +7,16 @@
 // Here a workgroup is exactly 4 waves (one per SIMD) for a 16-env tile and EVERY head is split across them:
 //     wave w owns hidden col-block w (16 of the 64 units) of layers 0 and 1 of all K heads, and the K-slice w of
 //     layer 2 (its own 16 hidden units), i.e. K x (3 + 16 + 4) = 115 MFMAs per step instead of 92 / 184,
-// perfectly balanced over the 4 SIMDs, and two workgroups fit a CU (8 waves, 2 per SIMD).  Costs: the layer-0
-// activations and the layer-2 partial sums cross waves through LDS -> two barriers per step instead of one.
-// The policy (30 MFMAs) is still evaluated redundantly by each wave; its weight fragments live in LDS (shared).
+// balanced over the 4 SIMDs, and two workgroups fit a CU (8 waves, 2 per SIMD).  Costs: the layer-0 activations and the layer-2
+// partial sums cross waves through LDS -> three barriers per step (action, layer-0 activations, layer-2 partials).
+// Round 2: the policy (32 MFMAs, 16 tanh per lane) runs on wave 0 only; waves 1-3 meanwhile run the state-only k-steps of layer 0
+// (their own col-block and wave 0's) and wave 1 the next step's Philox draws; launches with up to 1.55 tiles per CU run ONE workgroup
+// per CU with the tile-steps dealt out evenly and tiles migrating between workgroups (see the kernel and launch_rollout_coop);
+// this file is compiled with -amdgpu-mfma-vgpr-form (Makefile) so that MFMA results stay in the vector half of the register file.
 #include "mfma_common.h"
 
-// Developer instrumentation (make EXTRA=-DCOOP_TIMING): per-phase shader-clock sums of wave 0 of workgroup 0 and of the
-// last workgroup, read back with metrpo_debug_coop_phases (tools/coop_phases.py).  Not part of the shipped library.
+// Developer instrumentation (tools/build_variant.sh timing -DCOOP_TIMING=0xFFF): per-phase shader-clock sums of the four waves of
+// workgroup 0, read back with metrpo_debug_coop_phases (tools/coop_phases.py).  Not part of the shipped library.
 #ifdef COOP_TIMING
 // s_memtime (the SHADER_CYCLES hardware register reads 0 on gfx950); all four waves of workgroup 0.  Every mark also drains the wave's
 // LDS queue (s_memtime returns through lgkmcnt), so phases that overlap LDS latency with later work look longer than they are.
