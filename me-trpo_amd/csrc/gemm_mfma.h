@@ -262,8 +262,13 @@ static inline size_t skinny_part_floats(int M, int N, int Kd, int heads) {
     return s > 1 ? (size_t)s * heads * ((((size_t)M * N + N) + 3) & ~(size_t)3) : 0;
 }
 // part: workspace of >= skinny_part_floats(...) floats (may be NULL when that is 0).  act: 0 identity, 1 relu, 2 tanh (METRPO_ACT_*).
+// defer != NULL: when the layer runs as split-K partials, skip the reduce launch and report {splits, stridePart} instead -- the
+// caller's next kernel adds the partials and the bias itself (rollout_gemm.hip: k_big_post); {0, 0} when C was written directly.
+struct SkinnyDefer { int splits; long long stridePart; };
 static inline void gemm_skinny_bias(const float* A, long long sA, int lda, const float* W, long long sW, int ldw, const float* bias, long long sBias,
-                                    float* C, long long sC, int M, int N, int Kd, int heads, float* part, hipStream_t st, int act = 0) {
+                                    float* C, long long sC, int M, int N, int Kd, int heads, float* part, hipStream_t st, int act = 0,
+                                    SkinnyDefer* defer = nullptr) {
+    if (defer) { defer->splits = 0; defer->stridePart = 0; }
     const int S = skinny_splits(M, N, Kd, heads);
     if (S <= 1 || part == nullptr) {
         GemmEpi ep = {}; ep.bias = bias; ep.strideBias = sBias;
@@ -276,6 +281,7 @@ static inline void gemm_skinny_bias(const float* A, long long sA, int lda, const
     ep.part = part; ep.stridePart = (((long long)M * N + N) + 3) & ~3LL; ep.splits = S; ep.kchunk = (((Kd + S - 1) / S) + 15) & ~15;
     ep.splits = (Kd + ep.kchunk - 1) / ep.kchunk;
     gemm_mfma_launch<1, 1, EPI_PARTIAL, false, false>(A, sA, lda, W, sW, ldw, nullptr, 0, N, M, N, Kd, heads, ep, st);
+    if (defer && act == 0) { defer->splits = ep.splits; defer->stridePart = ep.stridePart; return; }
     const long long tot = (long long)M * N;
     hipLaunchKernelGGL(k_splitk_bias_reduce, dim3((unsigned)((tot + 255) / 256), heads), dim3(256), 0, st, ep.splits, heads, ep.stridePart, part, M, N,
                        bias, sBias, C, sC, act);

@@ -13,7 +13,9 @@
 
 // ------------------------------------------------------------------------------------------------
 struct BigState { float* S; int* ts; int* cur_model; float* X; float* U; float* HA; float* HB; float* OUT; float* PART;
-                  int ldx; };   // ldx: row stride of X = n_in rounded up to 4 floats, so every row is 16-byte aligned for the layer-0 GEMM's loads
+                  int ldx;
+                  // output layer left as split-K partials (gemm_skinny_bias with defer): k_big_post adds them and the bias
+                  int out_splits; long long out_stride; const float* out_bias; long long out_bias_stride; };   // ldx: row stride of X = n_in rounded up to 4 floats, so every row is 16-byte aligned for the layer-0 GEMM's loads
 
 // policy.get_actions + clip + normalise/drop for policies without an MFMA pre-kernel (Humanoid's 100-50-25): a block = 64 envs x G thread
 // groups; the outputs of every policy layer are split over the groups (activations in LDS columns), group 0 owns the env's bookkeeping
@@ -222,7 +224,13 @@ __global__ void __launch_bounds__(256) k_big_post(ProblemDesc pd, RolloutK r, in
     for (int d = 0; d < na; ++d) { const float a = grp(ua, d); su2 = fmaf(a, a, su2); }
     float* S = st.S + (size_t)bc * ns;
     const float s_old = S[ic], dm = diff_mean[ic], ds = diff_std[ic];
-    auto head = [&](int k) { return fmaf(ds, st.OUT[((size_t)k * r.B + bc) * ns + ic], dm) + s_old; };
+    auto outv = [&](int k) {                                     // output layer of head k, dim i (partials in split order, like k_splitk_bias_reduce)
+        if (st.out_splits == 0) return st.OUT[((size_t)k * r.B + bc) * ns + ic];
+        float o = st.out_bias[(size_t)k * st.out_bias_stride + ic];
+        for (int sp = 0; sp < st.out_splits; ++sp) o += st.PART[((size_t)sp * K + k) * st.out_stride + (size_t)bc * ns + ic];
+        return o;
+    };
+    auto head = [&](int k) { return fmaf(ds, outv(k), dm) + s_old; };
     float v;
     if (simple) v = head(sel);
     else {
@@ -326,7 +334,7 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
         HIP_TRY(c, hipMalloc(&c->d_big, need));
         c->big_cap = need;
     }
-    BigState bs;
+    BigState bs = {};
     float* p = (float*)c->d_big;
     bs.S = p; p += nS; bs.X = p; p += nX; bs.U = p; p += nU; bs.HA = p; p += nH; bs.HB = p; p += nH; bs.OUT = p; p += nO; bs.PART = nP ? p : nullptr; p += nP;
     bs.ts = (int*)p; bs.cur_model = bs.ts + B;
@@ -349,7 +357,9 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
             const long long sOut = (long long)B * N;
             const float* Wl = c->d_dyn + pd.dyn.w_off[l];
             const float* bl = c->d_dyn + pd.dyn.b_off[l];
-            gemm_skinny_bias(in, sIn, ldin, Wl, pd.dyn.n_params, N, bl, pd.dyn.n_params, out, sOut, B, N, Kd, K, bs.PART, st, pd.dyn.act[l]);
+            SkinnyDefer df = {0, 0};
+            gemm_skinny_bias(in, sIn, ldin, Wl, pd.dyn.n_params, N, bl, pd.dyn.n_params, out, sOut, B, N, Kd, K, bs.PART, st, pd.dyn.act[l], lastl ? &df : nullptr);
+            if (lastl) { bs.out_splits = df.splits; bs.out_stride = df.stridePart; bs.out_bias = bl; bs.out_bias_stride = pd.dyn.n_params; }
             in = out; sIn = sOut; ldin = N;
         }
         if (pd.ns <= 32) hipLaunchKernelGGL(k_big_post<32>, dim3((B + 7) / 8), dim3(256), 0, st, pd, r, t, c->d_norm, bs);
