@@ -327,6 +327,11 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
     const size_t nS = up4((size_t)B * pd.ns), nX = up4((size_t)B * ((pd.nin + 3) & ~3)), nU = up4((size_t)B * pd.na), nH = up4((size_t)K * B * maxh), nO = up4((size_t)K * B * pd.ns);
     size_t nP = 0;
     for (int l = 0; l < L; ++l) nP = std::max(nP, up4(skinny_part_floats(B, pd.dyn.dims[l + 1], pd.dyn.dims[l], K)));
+    // last hidden layer + output layer as ONE launch when the hidden layer runs on 64x64 tiles anyway (C0-params-file, C2, C3 shapes): its
+    // activations (K x B x width floats: 51 MB at C3) are then neither written nor read back; k_big_post adds the width/64 partials
+    const bool fuse_out = L >= 2 && pd.dyn.act[L - 2] == METRPO_ACT_RELU && pd.dyn.act[L - 1] == METRPO_ACT_IDENTITY && getenv("METRPO_NO_FUSED_OUT") == nullptr &&
+                          gemm_fused_out_applicable(B, pd.dyn.dims[L - 1], K, pd.ns);
+    if (fuse_out) nP = std::max(nP, up4(gemm_fused_out_part_floats(B, pd.dyn.dims[L - 1], K, pd.ns)));
     const size_t need = (nS + nX + nU + 2 * nH + nO + nP) * sizeof(float) + 2 * (size_t)B * sizeof(int) + 256;
     if (need > c->big_cap) {
         if (c->d_big) HIP_TRY(c, hipFree(c->d_big));
@@ -357,6 +362,13 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
             const long long sOut = (long long)B * N;
             const float* Wl = c->d_dyn + pd.dyn.w_off[l];
             const float* bl = c->d_dyn + pd.dyn.b_off[l];
+            if (fuse_out && l == L - 2) {
+                const float* W2 = c->d_dyn + pd.dyn.w_off[L - 1];
+                gemm_relu_fused_out(in, sIn, ldin, Wl, pd.dyn.n_params, N, bl, pd.dyn.n_params, W2, pd.dyn.n_params, pd.ns, B, N, Kd, K, bs.PART, st,
+                                    &bs.out_splits, &bs.out_stride);
+                bs.out_bias = c->d_dyn + pd.dyn.b_off[L - 1]; bs.out_bias_stride = pd.dyn.n_params;
+                break;
+            }
             SkinnyDefer df = {0, 0};
             gemm_skinny_bias(in, sIn, ldin, Wl, pd.dyn.n_params, N, bl, pd.dyn.n_params, out, sOut, B, N, Kd, K, bs.PART, st, pd.dyn.act[l], lastl ? &df : nullptr);
             if (lastl) { bs.out_splits = df.splits; bs.out_stride = df.stridePart; bs.out_bias = bl; bs.out_bias_stride = pd.dyn.n_params; }
