@@ -15,7 +15,8 @@
 struct BigState { float* S; int* ts; int* cur_model; float* X; float* U; float* HA; float* HB; float* OUT; float* PART;
                   int ldx;
                   // output layer left as split-K partials (gemm_skinny_bias with defer): k_big_post adds them and the bias
-                  int out_splits; long long out_stride; const float* out_bias; long long out_bias_stride; };   // ldx: row stride of X = n_in rounded up to 4 floats, so every row is 16-byte aligned for the layer-0 GEMM's loads
+                  int out_splits; long long out_stride; const float* out_bias; long long out_bias_stride;
+                  float* PA; float* PB; };      // policy activations of the GEMM pre-path [B][max policy width]   // ldx: row stride of X = n_in rounded up to 4 floats, so every row is 16-byte aligned for the layer-0 GEMM's loads
 
 // policy.get_actions + clip + normalise/drop for policies without an MFMA pre-kernel (Humanoid's 100-50-25): a block = 64 envs x G thread
 // groups; the outputs of every policy layer are split over the groups (activations in LDS columns), group 0 owns the env's bookkeeping
@@ -184,6 +185,59 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
     }
 }
 
+// ---- pre-step for policies without an MFMA pre-kernel at LARGE batch (Humanoid's 100-50-25 at B = 6250): the policy layers run as GEMMs over
+// the batch (k_gemm_mfma, tanh epilogue) between a gather kernel and an action kernel.  k_big_pre walks the three dense layers on 64-env
+// blocks with weights through scalar loads: 0.31 ms per step at C4 for 140 MFLOP.
+// gather: vec_env.reset() at t = 0, obs[t] = S, X state columns; one lane per (env, state dim)
+__global__ void __launch_bounds__(256) k_big_pre_gather(ProblemDesc pd, RolloutK r, int t, const float* __restrict__ norm, BigState st) {
+    const int ns = pd.ns, na = pd.na;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)r.B * ns || (r.stop != nullptr && *r.stop != 0)) return;
+    const int b = (int)(idx / ns), i = (int)(idx % ns);
+    float s;
+    if (t == 0) {
+        if (r.init_obs != nullptr) {                              // continuation of a chunked rollout
+            s = r.init_obs[(size_t)b * ns + i];
+            if (i == 0) { st.cur_model[b] = r.init_model[b]; st.ts[b] = r.init_ts[b]; }
+        } else {                                                  // env_helpers.py:585-595
+            const uint4 d0 = rng_draw(r.seed, r.stream_offset + (uint64_t)b, 0, RNG_RESET, 0);
+            const int row = (r.reset_idx != nullptr) ? r.reset_idx[b] : rng_index(d0.x, r.n_pool);
+            s = r.pool[(size_t)row * ns + i];
+            if (i == 0) { st.cur_model[b] = (r.reset_model != nullptr) ? r.reset_model[b] : rng_index(d0.y, pd.K); st.ts[b] = 0; }
+        }
+        st.S[(size_t)b * ns + i] = s;
+    } else s = st.S[(size_t)b * ns + i];
+    r.obs[((size_t)t * r.B + b) * ns + i] = s;
+    const float* in_mean = norm; const float* in_std = norm + (ns + na);
+    if (i >= pd.n_drop) st.X[(size_t)b * st.ldx + i - pd.n_drop] = (s - in_mean[i]) / in_std[i];       // training.py:228,146-151
+    if (i == 0) for (int j = pd.nin; j < st.ldx; ++j) st.X[(size_t)b * st.ldx + j] = 0.0f;              // pad columns of the 16-byte aligned rows
+}
+// action: a = mu + sigma z (policy noise from the step's Philox blocks), clip, act / mean / U / X action columns; one lane per (env, dim pair)
+__global__ void __launch_bounds__(256) k_big_pre_action(ProblemDesc pd, RolloutK r, int t, const float* __restrict__ theta, const float* __restrict__ norm,
+                                                        const float* __restrict__ MU, BigState st) {
+    const int ns = pd.ns, na = pd.na, npair = (na + 1) / 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)r.B * npair || (r.stop != nullptr && *r.stop != 0)) return;
+    const int b = (int)(idx / npair), d0 = 2 * (int)(idx % npair);
+    const size_t tb = (size_t)t * r.B + b;
+    const float* __restrict__ log_std = theta + pd.pol.n_params;
+    const float* in_mean = norm; const float* in_std = norm + (ns + na);
+    float z[2] = {0.f, 0.f};
+    if (!r.determ && r.eps == nullptr) {
+        const uint4 blk = rng_draw(r.seed, r.stream_offset + (uint64_t)b, r.t0 + t, RNG_STEP, d0 >> 1);
+        normal2(blk.x, blk.y, z[0], z[1]);
+    }
+    for (int d = d0; d < min(d0 + 2, na); ++d) {
+        const float mu = MU[(size_t)b * na + d];
+        float a = mu;
+        if (!r.determ) a = fmaf((r.eps != nullptr) ? r.eps[tb * na + d] : z[d - d0], __expf(fmaxf(log_std[d], LOG_MIN_STD)), mu);
+        r.act[tb * na + d] = a; r.mean[tb * na + d] = mu;
+        const float ac = fminf(fmaxf(a, -1.0f), 1.0f);              // env_helpers.py:599
+        st.U[(size_t)b * na + d] = ac;
+        st.X[(size_t)b * st.ldx + (ns - pd.n_drop) + d] = (ac - in_mean[ns + d]) / in_std[ns + d];
+    }
+}
+
 typedef void (*big_pre_mfma_t)(ProblemDesc, RolloutK, int, const float*, const float*, BigState);
 static big_pre_mfma_t big_pre_mfma_select(const ProblemDesc& pd) {
     if (pd.pol.n_layers != 3 || pd.pol.dims[1] != 32 || pd.pol.dims[2] != 32 || pd.pol.act[0] != METRPO_ACT_TANH) return nullptr;
@@ -332,7 +386,12 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
     const bool fuse_out = L >= 2 && pd.dyn.act[L - 2] == METRPO_ACT_RELU && pd.dyn.act[L - 1] == METRPO_ACT_IDENTITY && getenv("METRPO_NO_FUSED_OUT") == nullptr &&
                           gemm_fused_out_applicable(B, pd.dyn.dims[L - 1], K, pd.ns);
     if (fuse_out) nP = std::max(nP, up4(gemm_fused_out_part_floats(B, pd.dyn.dims[L - 1], K, pd.ns)));
-    const size_t need = (nS + nX + nU + 2 * nH + nO + nP) * sizeof(float) + 2 * (size_t)B * sizeof(int) + 256;
+    const big_pre_mfma_t pre_mfma = big_pre_mfma_select(pd);
+    // policies without an MFMA pre-kernel: GEMM chain over the batch from B = 1024 up (METRPO_PRE_GEMM=1 forces it, =0 forbids it: tests)
+    const char* pg_env = getenv("METRPO_PRE_GEMM");
+    const bool pre_gemm = !pre_mfma && ((pg_env && pg_env[0] == '1') || (!(pg_env && pg_env[0] == '0') && B >= 1024));
+    const size_t nPol = pre_gemm ? up4((size_t)B * pd.pol.max_width) : 0;
+    const size_t need = (nS + nX + nU + 2 * nH + nO + nP + 2 * nPol) * sizeof(float) + 2 * (size_t)B * sizeof(int) + 256;
     if (need > c->big_cap) {
         if (c->d_big) HIP_TRY(c, hipFree(c->d_big));
         c->d_big = nullptr; c->big_cap = 0;
@@ -341,7 +400,7 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
     }
     BigState bs = {};
     float* p = (float*)c->d_big;
-    bs.S = p; p += nS; bs.X = p; p += nX; bs.U = p; p += nU; bs.HA = p; p += nH; bs.HB = p; p += nH; bs.OUT = p; p += nO; bs.PART = nP ? p : nullptr; p += nP;
+    bs.S = p; p += nS; bs.X = p; p += nX; bs.U = p; p += nU; bs.HA = p; p += nH; bs.HB = p; p += nH; bs.OUT = p; p += nO; bs.PART = nP ? p : nullptr; p += nP; bs.PA = p; p += nPol; bs.PB = p; p += nPol;
     bs.ts = (int*)p; bs.cur_model = bs.ts + B;
     bs.ldx = (pd.nin + 3) & ~3;
     RolloutK r = make_rollout_k(a);
@@ -349,9 +408,21 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
     const size_t psh = (size_t)(pd.ns + 2 * pd.pol.max_width) * 64 * sizeof(float);
     if (psh > 160 * 1024) return set_err(c, METRPO_EUNSUPPORTED, "policy too wide for k_big_pre");
     if (psh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_big_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psh));
-    const big_pre_mfma_t pre_mfma = big_pre_mfma_select(pd);
     for (int t = 0; t < a->T; ++t) {
         if (pre_mfma) hipLaunchKernelGGL(pre_mfma, dim3((B + 63) / 64), dim3(256), 0, st, pd, r, t, c->d_theta, c->d_norm, bs);
+        else if (pre_gemm) {
+            hipLaunchKernelGGL(k_big_pre_gather, dim3((unsigned)(((long long)B * pd.ns + 255) / 256)), dim3(256), 0, st, pd, r, t, c->d_norm, bs);
+            const float* pin = bs.S; int ldp = pd.ns;
+            float* pbuf[2] = {bs.PA, bs.PB};
+            for (int l = 0; l < pd.pol.n_layers; ++l) {
+                const int Kp = pd.pol.dims[l], Np = pd.pol.dims[l + 1];
+                float* pout = pbuf[l & 1];
+                gemm_launch(pd.pol.act[l], pin, 0, ldp, c->d_theta + pd.pol.w_off[l], 0, Np, c->d_theta + pd.pol.b_off[l], 0, pout, 0, Np, B, Np, Kp, 1, st);
+                pin = pout; ldp = Np;
+            }
+            const int npair = (pd.na + 1) / 2;
+            hipLaunchKernelGGL(k_big_pre_action, dim3((unsigned)(((long long)B * npair + 255) / 256)), dim3(256), 0, st, pd, r, t, c->d_theta, c->d_norm, pin, bs);
+        }
         else hipLaunchKernelGGL(k_big_pre, dim3((B + 63) / 64), dim3(pbs), psh, st, pd, r, t, c->d_theta, c->d_norm, bs);
         const float* in = bs.X; long long sIn = 0; int ldin = bs.ldx;
         float* bufs[2] = {bs.HA, bs.HB};

@@ -466,3 +466,33 @@ def test_gemm_rollout_all_sam_modes(sam_mode):
         np.testing.assert_allclose(cpu(traj.obs[t + 1])[~dn[t]], ref['next'][t][~dn[t]], rtol=1e-4, atol=2e-5)
         np.testing.assert_array_equal(cpu(traj.obs[t + 1])[dn[t]], pool32[dr['reset_idx'][t + 1]][dn[t]])
     np.testing.assert_allclose(cpu(traj.last_obs), np.where(dn[T - 1][:, None], pool32[dr['reset_idx'][T]], ref['next'][T - 1]), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize('draws', [True, False])
+def test_gemm_rollout_wide_policy_gemm_prestep(draws, monkeypatch):
+    """Humanoid-shaped policy (100-50-25: no MFMA pre-kernel) on the step-wise GEMM rollout: the pre-step that runs the policy layers as
+    GEMMs over the batch (large B in production, forced here) vs the oracle, and vs the 64-env-block pre-kernel it replaces there."""
+    env, K, B, T, H = 'humanoid', 3, 90, 6, 4
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (128, 128), (100, 50, 25), seed=23)
+    assert eng.set_rollout_variant(0) == 3
+    kw = {}
+    if draws:
+        dr = Hh.draws(np.random.RandomState(5), K, B, T, dm.ns, dm.na, len(pool))
+        kw = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in dr.items()}
+    monkeypatch.setenv('METRPO_PRE_GEMM', '0')
+    blocks = eng.rollout(B, T, H, 'step_rand', pool, seed=3, **kw)
+    ref = {k: cpu(getattr(blocks, k)).copy() for k in ('obs', 'act', 'mean', 'rew')}
+    ref_done = blocks.done.clone()
+    monkeypatch.setenv('METRPO_PRE_GEMM', '1')
+    gemm = eng.rollout(B, T, H, 'step_rand', pool, seed=3, **kw)
+    for k in ref:
+        np.testing.assert_allclose(cpu(getattr(gemm, k)), ref[k], rtol=2e-4, atol=5e-5, err_msg=k)
+    assert torch.equal(gemm.done, ref_done)
+    if draws:
+        th = theta.astype(np.float32).astype(np.float64)
+        pool32 = pool.astype(np.float32).astype(np.float64)
+        drf = {k: (v.astype(np.float64) if v.dtype == np.float32 else v) for k, v in kw.items()}
+        orc = Hh.oracle_rollout(dm, th, pdims, env, pool32, drf, B, T, H, 'step_rand', teacher_obs=cpu(gemm.obs))
+        np.testing.assert_allclose(cpu(gemm.mean), orc['mean'], rtol=2e-5, atol=1e-5)
+        np.testing.assert_allclose(cpu(gemm.act), orc['act'], rtol=2e-5, atol=1e-5)
+        np.testing.assert_allclose(cpu(gemm.rew), orc['rew'], rtol=1e-4, atol=2e-5)
