@@ -9,7 +9,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { EPI_BIAS_ID = 0, EPI_BIAS_RELU = 1, EPI_BIAS_TANH = 2, EPI_RELU_MASK = 3, EPI_ADAM = 4, EPI_PLAIN = 5, EPI_PARTIAL = 6, EPI_DTANH = 7, EPI_RELU_OUT = 8 };
+enum { EPI_BIAS_ID = 0, EPI_BIAS_RELU = 1, EPI_BIAS_TANH = 2, EPI_RELU_MASK = 3, EPI_ADAM = 4, EPI_PLAIN = 5, EPI_PARTIAL = 6, EPI_DTANH = 7, EPI_RELU_OUT = 8, EPI_RELU_OUT64 = 9 };   // EPI_RELU_OUT: fused skinny layer of <= 32 columns, EPI_RELU_OUT64: <= 64
 
 struct GemmEpi {                 // epilogue operands (unused fields may be null)
     const float* bias; long long strideBias;          // EPI_BIAS_*: bias[col]
@@ -22,9 +22,9 @@ struct GemmEpi {                 // epilogue operands (unused fields may be null
     // split s contracts rows [s*kchunk, (s+1)*kchunk) and writes its M x N partial followed by the N partial column sums to
     // part + (s * heads + head) * stridePart; k_adam_apply (dyn_train.hip) adds the splits in index order and applies Adam.
     float* part; long long stridePart; int splits, kchunk;
-    // EPI_RELU_OUT (64x64 tiles only): the tile relu(acc + bias) is NOT stored; it is contracted on the spot with the next (skinny, <= 32
-    // column) layer's weights w2[head][N][no] and the 64 x no partial goes to part + (blockIdx.x * heads + head) * stridePart, row stride no --
-    // one partial per 64-column block of this layer, added (in block order, plus that layer's bias) by the consumer.  The hidden
+    // EPI_RELU_OUT (64x64 or 128x128 tiles): the tile relu(acc + bias) is NOT stored; it is contracted on the spot with the next (skinny, <= 64
+    // column) layer's weights w2[head][N][no] and the BM x no partial goes to part + (blockIdx.x * heads + head) * stridePart, row stride no --
+    // one partial per column block of this layer, added (in block order, plus that layer's bias) by the consumer.  The hidden
     // activation matrix (M x N floats per head) is then never written to or read back from HBM.
     const float* w2; long long strideW2; int no;
 };
@@ -177,40 +177,72 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
             }
         }
     }
-    if constexpr (EPI == EPI_RELU_OUT) {
-        static_assert(TM == 1 && TN == 1, "fused skinny output layer: 64x64 tiles");
-        // stage 1: H = relu(acc + bias) -> LDS, k-major for the second product (k = this block's 64 columns): rows 0..31 in As, 32..63 in Bs
-        __shared__ float W2s[64][33];
-        float* Hlo = &As[0][0][0]; float* Hhi = &Bs[0][0][0];                      // each 32 x (64 + 4) floats; all reads of the main loop are behind its last barrier
-        {
-            const int nl = wn * 32 + (lane & 31);
-            const float bv = ep.bias[(size_t)head * ep.strideBias + n0 + nl];
-            float* dst = (nl < 32 ? Hlo + nl * (BM + 4) : Hhi + (nl - 32) * (BM + 4)) + wm * 32 + 4 * (lane >> 5);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dst[(r & 3) + 8 * (r >> 2)] = fmaxf(acc[0][0][r] + bv, 0.0f);
-        }
-        for (int i = tid; i < 64 * 32; i += 256) { const int k = i >> 5, j = i & 31; W2s[k][j] = (j < ep.no) ? ep.w2[(size_t)head * ep.strideW2 + (size_t)(n0 + k) * ep.no + j] : 0.0f; }
-        __syncthreads();
-        // stage 2: wave w -> rows 16w..16w+15, two 16-column tiles, 16 k-steps of v_mfma_f32_16x16x4_f32
+    if constexpr (EPI == EPI_RELU_OUT || EPI == EPI_RELU_OUT64) {
+        static_assert(TM == TN, "fused skinny output layer: square block tiles");
+        // The block's BN columns are handled in TN chunks of 64.  Per chunk: stage 1, H = relu(acc + bias) -> LDS, k-major for the second product
+        // (k = the chunk's 64 columns: rows 0..31 in As, 32..63 in Bs; every read of the main loop is behind its last barrier); stage 2, wave w ->
+        // rows 16 TM w .. 16 TM (w + 1) - 1, NT = ceil(no / 16) column tiles, 16 k-steps of v_mfma_f32_16x16x4_f32 accumulating over the chunks.
+        constexpr int NT = (EPI == EPI_RELU_OUT) ? 2 : 4, NOP = 16 * NT, W2U = 64 * NOP / 256;     // column tiles, padded columns, W2 elements per thread and chunk
+        __shared__ float W2s[64][NOP + 1];
         typedef float f32x4_ __attribute__((ext_vector_type(4)));
-        f32x4_ o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+        float* Hlo = &As[0][0][0]; float* Hhi = &Bs[0][0][0];                      // each 32 x (BM + 4) floats
         const int c16 = lane & 15, q4 = lane >> 4;
+        f32x4_ o[TM][NT];
 #pragma unroll
-        for (int s2 = 0; s2 < 16; ++s2) {
-            const int k = 4 * s2 + q4;
-            const float a = (k < 32 ? Hlo[k * (BM + 4) + wave * 16 + c16] : Hhi[(k - 32) * (BM + 4) + wave * 16 + c16]);
-            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, W2s[k][c16], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, W2s[k][16 + c16], o1, 0, 0, 0);
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) o[i][ct] = f32x4_{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ch = 0; ch < TN; ++ch) {
+            float w2r[W2U];                                                        // the chunk's slice of the output weights: all loads in flight at once,
+#pragma unroll
+            for (int u = 0; u < W2U; ++u) {                                        // behind the LDS traffic of stage 1
+                const int e = tid + 256 * u, k = e / NOP, jj = e % NOP;
+                w2r[u] = (jj < ep.no) ? ep.w2[(size_t)head * ep.strideW2 + (size_t)(n0 + ch * 64 + k) * ep.no + jj] : 0.0f;
+            }
+            if (ch > 0) __syncthreads();                                           // stage 2 of the previous chunk has read Hs / W2s
+            if (TN == 1 || wn == ch) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int nl = (TN == 1 ? wn * 32 : j * 32) + (lane & 31);
+                    const float bv = ep.bias[(size_t)head * ep.strideBias + n0 + ch * 64 + nl];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        float* dst = (nl < 32 ? Hlo + nl * (BM + 4) : Hhi + (nl - 32) * (BM + 4)) + wm * 32 * TM + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dst[(r & 3) + 8 * (r >> 2)] = fmaxf(acc[i][j][r] + bv, 0.0f);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < W2U; ++u) { const int e = tid + 256 * u; W2s[e / NOP][e % NOP] = w2r[u]; }
+            __syncthreads();
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {
+                const int k = 4 * s2 + q4;
+                const float* hrow = (k < 32 ? Hlo + k * (BM + 4) : Hhi + (k - 32) * (BM + 4)) + wave * 16 * TM + c16;
+                float av[TM];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) av[i] = hrow[16 * i];
+#pragma unroll
+                for (int ct = 0; ct < NT; ++ct) {
+                    const float bw = W2s[k][16 * ct + c16];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) o[i][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bw, o[i][ct], 0, 0, 0);
+                }
+            }
         }
         float* P = ep.part + ((size_t)blockIdx.x * gridDim.z + head) * ep.stridePart;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {                                                // D layout: row 4 q + r, col c
-            const int row = m0 + wave * 16 + 4 * q4 + r;
-            if (row < M) {
-                if (c16 < ep.no) P[(size_t)row * ep.no + c16] = o0[r];
-                if (16 + c16 < ep.no) P[(size_t)row * ep.no + 16 + c16] = o1[r];
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                                            // D layout: row 4 q + r, col c
+                const int row = m0 + wave * 16 * TM + 16 * i + 4 * q4 + r;
+                if (row < M) {
+#pragma unroll
+                    for (int ct = 0; ct < NT; ++ct) if (16 * ct + c16 < ep.no) P[(size_t)row * ep.no + 16 * ct + c16] = o[i][ct][r];
+                }
             }
-        }
         return;
     }
     // epilogue: C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -276,21 +308,28 @@ static inline void gemm_auto(const float* A, long long sA, int lda, const float*
     else gemm_mfma_launch<1, 1, EPI, TA, TB>(A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, heads, ep, st);
 }
 
-// Hidden layer + skinny output layer in one launch (EPI_RELU_OUT) when gemm_auto would pick 64x64 tiles for the hidden layer anyway.
-static inline bool gemm_fused_out_applicable(int M, int N, int heads, int no) {
+// Hidden layer + skinny (<= 64 column) output layer in one launch (EPI_RELU_OUT), on the square tile shape gemm_auto would pick for the hidden
+// layer: 64x64 (small batches: C0-params-file, C2, C3 shapes) or 128x128 (C4).  Returns the tile factor (1 or 2), 0 if not applicable.
+static inline int gemm_fused_out_tile(int M, int N, int heads, int no) {
     auto blocks = [&](int tm, int tn) { return (long long)((M + 64 * tm - 1) / (64 * tm)) * ((N + 64 * tn - 1) / (64 * tn)) * heads; };
-    return no <= 32 && (N % 64) == 0 && blocks(2, 1) < 2048 && blocks(1, 2) < 2048;       // same rule as gemm_auto -> <1, 1>
+    if (no > 64) return 0;
+    if (M > 64 && N > 64 && (N % 128) == 0 && blocks(2, 2) >= 2048) return 2;                 // same rule as gemm_auto -> <2, 2>
+    if ((N % 64) == 0 && blocks(2, 1) < 2048 && blocks(1, 2) < 2048) return 1;                 // -> <1, 1>
+    return 0;
 }
-static inline size_t gemm_fused_out_part_floats(int M, int N, int heads, int no) { return (size_t)(N / 64) * heads * ((((size_t)M * no) + 3) & ~(size_t)3); }
-// part receives N/64 partials per head ({splits, stridePart} reported through defer, same convention as gemm_skinny_bias)
-static inline void gemm_relu_fused_out(const float* A, long long sA, int lda, const float* W, long long sW, int ldw, const float* bias, long long sBias,
+static inline size_t gemm_fused_out_part_floats(int M, int N, int heads, int no, int tile) { return (size_t)(N / (64 * tile)) * heads * ((((size_t)M * no) + 3) & ~(size_t)3); }
+// part receives N / (64 tile) partials per head ({splits, stridePart} as reported by gemm_skinny_bias's defer)
+static inline void gemm_relu_fused_out(int tile, const float* A, long long sA, int lda, const float* W, long long sW, int ldw, const float* bias, long long sBias,
                                        const float* W2, long long sW2, int no, int M, int N, int Kd, int heads, float* part, hipStream_t st, int* splits,
                                        long long* stridePart) {
     GemmEpi ep = {};
     ep.bias = bias; ep.strideBias = sBias; ep.w2 = W2; ep.strideW2 = sW2; ep.no = no;
     ep.part = part; ep.stridePart = (((long long)M * no) + 3) & ~3LL;
-    gemm_mfma_launch<1, 1, EPI_RELU_OUT, false, false>(A, sA, lda, W, sW, ldw, nullptr, 0, N, M, N, Kd, heads, ep, st);
-    *splits = N / 64; *stridePart = ep.stridePart;
+    if (tile == 2 && no <= 32) gemm_mfma_launch<2, 2, EPI_RELU_OUT, false, false>(A, sA, lda, W, sW, ldw, nullptr, 0, N, M, N, Kd, heads, ep, st);
+    else if (tile == 2) gemm_mfma_launch<2, 2, EPI_RELU_OUT64, false, false>(A, sA, lda, W, sW, ldw, nullptr, 0, N, M, N, Kd, heads, ep, st);
+    else if (no <= 32) gemm_mfma_launch<1, 1, EPI_RELU_OUT, false, false>(A, sA, lda, W, sW, ldw, nullptr, 0, N, M, N, Kd, heads, ep, st);
+    else gemm_mfma_launch<1, 1, EPI_RELU_OUT64, false, false>(A, sA, lda, W, sW, ldw, nullptr, 0, N, M, N, Kd, heads, ep, st);
+    *splits = N / (64 * tile); *stridePart = ep.stridePart;
 }
 
 // ---- skinny output layers (N <= 64 columns, long contraction): C[h] = bias[h] + A[h] . W[h] as split-K partials + an ordered reduce ----

@@ -383,9 +383,10 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
     for (int l = 0; l < L; ++l) nP = std::max(nP, up4(skinny_part_floats(B, pd.dyn.dims[l + 1], pd.dyn.dims[l], K)));
     // last hidden layer + output layer as ONE launch when the hidden layer runs on 64x64 tiles anyway (C0-params-file, C2, C3 shapes): its
     // activations (K x B x width floats: 51 MB at C3) are then neither written nor read back; k_big_post adds the width/64 partials
-    const bool fuse_out = L >= 2 && pd.dyn.act[L - 2] == METRPO_ACT_RELU && pd.dyn.act[L - 1] == METRPO_ACT_IDENTITY && getenv("METRPO_NO_FUSED_OUT") == nullptr &&
-                          gemm_fused_out_applicable(B, pd.dyn.dims[L - 1], K, pd.ns);
-    if (fuse_out) nP = std::max(nP, up4(gemm_fused_out_part_floats(B, pd.dyn.dims[L - 1], K, pd.ns)));
+    const int fuse_tile = (L >= 2 && pd.dyn.act[L - 2] == METRPO_ACT_RELU && pd.dyn.act[L - 1] == METRPO_ACT_IDENTITY && getenv("METRPO_NO_FUSED_OUT") == nullptr)
+                              ? gemm_fused_out_tile(B, pd.dyn.dims[L - 1], K, pd.ns) : 0;
+    const bool fuse_out = fuse_tile > 0;
+    if (fuse_out) nP = std::max(nP, up4(gemm_fused_out_part_floats(B, pd.dyn.dims[L - 1], K, pd.ns, fuse_tile)));
     const big_pre_mfma_t pre_mfma = big_pre_mfma_select(pd);
     // policies without an MFMA pre-kernel: GEMM chain over the batch from B = 1024 up (METRPO_PRE_GEMM=1 forces it, =0 forbids it: tests)
     const char* pg_env = getenv("METRPO_PRE_GEMM");
@@ -435,7 +436,7 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
             const float* bl = c->d_dyn + pd.dyn.b_off[l];
             if (fuse_out && l == L - 2) {
                 const float* W2 = c->d_dyn + pd.dyn.w_off[L - 1];
-                gemm_relu_fused_out(in, sIn, ldin, Wl, pd.dyn.n_params, N, bl, pd.dyn.n_params, W2, pd.dyn.n_params, pd.ns, B, N, Kd, K, bs.PART, st,
+                gemm_relu_fused_out(fuse_tile, in, sIn, ldin, Wl, pd.dyn.n_params, N, bl, pd.dyn.n_params, W2, pd.dyn.n_params, pd.ns, B, N, Kd, K, bs.PART, st,
                                     &bs.out_splits, &bs.out_stride);
                 bs.out_bias = c->d_dyn + pd.dyn.b_off[L - 1]; bs.out_bias_stride = pd.dyn.n_params;
                 break;

@@ -496,3 +496,25 @@ def test_gemm_rollout_wide_policy_gemm_prestep(draws, monkeypatch):
         np.testing.assert_allclose(cpu(gemm.mean), orc['mean'], rtol=2e-5, atol=1e-5)
         np.testing.assert_allclose(cpu(gemm.act), orc['act'], rtol=2e-5, atol=1e-5)
         np.testing.assert_allclose(cpu(gemm.rew), orc['rew'], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize('env,K,B,hidden', [('humanoid', 16, 4096, (512, 512)),      # 128x128 tiles, 45 output columns (3 column tiles)
+                                            ('ant', 4, 300, (128, 256))])            # 64x64 tiles, 29 output columns
+def test_gemm_rollout_fused_output_layer_equals_separate_layers(env, K, B, hidden, monkeypatch):
+    """Step-wise GEMM rollout: the last hidden layer's launch contracts its relu tile with the output weights (EPI_RELU_OUT) instead of
+    writing the activations and running the output layer as its own GEMM.  Same trajectories up to fp32 summation order."""
+    T, H = 4, 3
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, hidden, (32, 32) if env != 'humanoid' else (100, 50, 25), seed=29)
+    assert eng.set_rollout_variant(0) == 3
+    monkeypatch.setenv('METRPO_NO_FUSED_OUT', '1')
+    sep = eng.rollout(B, T, H, 'model_mean', pool, seed=9)
+    ref = {k: cpu(getattr(sep, k)).copy() for k in ('obs', 'act', 'rew')}
+    ref_done = sep.done.clone()
+    monkeypatch.delenv('METRPO_NO_FUSED_OUT')
+    fused = eng.rollout(B, T, H, 'model_mean', pool, seed=9)
+    for k in ref:
+        got = cpu(getattr(fused, k))
+        assert np.isfinite(got).all()
+        np.testing.assert_allclose(got, ref[k], rtol=3e-4, atol=1e-4, err_msg=k)
+    assert torch.equal(fused.done, ref_done)
+    assert float(np.abs(ref['obs'][1] - ref['obs'][0]).max()) > 1e-3                  # the dynamics did move the state
