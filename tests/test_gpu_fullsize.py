@@ -122,3 +122,30 @@ def test_migrating_tiles_equal_whole_tiles(env, H, mode):
     # and a second launch on the same context (hand-over flags are epoch-stamped, not cleared)
     again = eng.rollout(B, T, H, mode, pool_d, seed=11)
     assert torch.equal(again.obs, whole.obs) and torch.equal(again.rew, whole.rew)
+
+
+def test_migrating_schedule_random_shapes_equal_two_per_cu():
+    """Random (B, T, H, env, sam_mode) in the window where tiles migrate between workgroups: bitwise the trajectories of the
+    two-workgroups-per-CU instantiation of the same kernel (test hook 2), which runs every tile on one workgroup from start to end."""
+    import metrpo_amd
+    rs = np.random.RandomState(77)
+    engines = {}
+    for case in range(14):
+        env = ['swimmer', 'hopper', 'snake', 'half_cheetah', 'ant'][case % 5]
+        B = int(rs.randint(4097, 6337)); H = int(rs.randint(3, 40)); T = int(rs.randint(1, 2 * H + 2))
+        mode = ['step_rand', 'eps_rand', 'model_mean', 'model_med', 'model_mean_std', 'one_model'][int(rs.randint(6))]
+        if env not in engines:
+            dm, theta, pdims, pool = O.make_problem(env, K=5, dyn_hidden=(64, 64), pol_hidden=(32, 32), seed=case, n_pool=300, dtype=np.float32)
+            eng = metrpo_amd.Engine(env, 5, (64, 64), (32, 32))
+            eng.set_dynamics_layers(dm.Ws, dm.bs, dm.in_mean, dm.in_std, dm.diff_mean, dm.diff_std)
+            eng.set_policy(theta)
+            engines[env] = (eng, torch.as_tensor(pool, device=eng.device))
+        eng, pool_d = engines[env]
+        if eng.set_rollout_variant(2) != 2:
+            pytest.skip('cooperative kernel not selected')
+        ref = eng.rollout(B, T, H, mode, pool_d, seed=100 + case)
+        ref = {k: getattr(ref, k).clone() for k in ('obs', 'act', 'rew', 'mean', 'done', 'tpath', 'last_obs')}
+        eng.set_rollout_variant(0)
+        got = eng.rollout(B, T, H, mode, pool_d, seed=100 + case)
+        for k, v in ref.items():
+            assert torch.equal(getattr(got, k), v), (case, env, B, T, H, mode, k)
