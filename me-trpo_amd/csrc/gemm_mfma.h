@@ -9,7 +9,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { EPI_BIAS_ID = 0, EPI_BIAS_RELU = 1, EPI_BIAS_TANH = 2, EPI_RELU_MASK = 3, EPI_ADAM = 4, EPI_PLAIN = 5, EPI_PARTIAL = 6, EPI_DTANH = 7, EPI_RELU_OUT = 8, EPI_RELU_OUT64 = 9 };   // EPI_RELU_OUT: fused skinny layer of <= 32 columns, EPI_RELU_OUT64: <= 64
+enum { EPI_BIAS_ID = 0, EPI_BIAS_RELU = 1, EPI_BIAS_TANH = 2, EPI_RELU_MASK = 3, EPI_ADAM = 4, EPI_PLAIN = 5, EPI_PARTIAL = 6, EPI_DTANH = 7, EPI_RELU_OUT = 8, EPI_RELU_OUT64 = 9, EPI_RELU_OUT48 = 10 };   // fused skinny layer of <= 32 / <= 64 / <= 48 columns
 
 struct GemmEpi {                 // epilogue operands (unused fields may be null)
     const float* bias; long long strideBias;          // EPI_BIAS_*: bias[col]
@@ -177,12 +177,12 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
             }
         }
     }
-    if constexpr (EPI == EPI_RELU_OUT || EPI == EPI_RELU_OUT64) {
+    if constexpr (EPI == EPI_RELU_OUT || EPI == EPI_RELU_OUT64 || EPI == EPI_RELU_OUT48) {
         static_assert(TM == TN, "fused skinny output layer: square block tiles");
         // The block's BN columns are handled in TN chunks of 64.  Per chunk: stage 1, H = relu(acc + bias) -> LDS, k-major for the second product
         // (k = the chunk's 64 columns: rows 0..31 in As, 32..63 in Bs; every read of the main loop is behind its last barrier); stage 2, wave w ->
         // rows 16 TM w .. 16 TM (w + 1) - 1, NT = ceil(no / 16) column tiles, 16 k-steps of v_mfma_f32_16x16x4_f32 accumulating over the chunks.
-        constexpr int NT = (EPI == EPI_RELU_OUT) ? 2 : 4, NOP = 16 * NT, W2U = 64 * NOP / 256;     // column tiles, padded columns, W2 elements per thread and chunk
+        constexpr int NT = (EPI == EPI_RELU_OUT) ? 2 : (EPI == EPI_RELU_OUT48) ? 3 : 4, NOP = 16 * NT, W2U = 64 * NOP / 256;     // column tiles, padded columns, W2 elements per thread and chunk
         __shared__ float W2s[64][NOP + 1];
         typedef float f32x4_ __attribute__((ext_vector_type(4)));
         float* Hlo = &As[0][0][0]; float* Hhi = &Bs[0][0][0];                      // each 32 x (BM + 4) floats
@@ -325,10 +325,10 @@ static inline void gemm_relu_fused_out(int tile, const float* A, long long sA, i
     GemmEpi ep = {};
     ep.bias = bias; ep.strideBias = sBias; ep.w2 = W2; ep.strideW2 = sW2; ep.no = no;
     ep.part = part; ep.stridePart = (((long long)M * no) + 3) & ~3LL;
-    if (tile == 2 && no <= 32) gemm_mfma_launch<2, 2, EPI_RELU_OUT, false, false>(A, sA, lda, W, sW, ldw, nullptr, 0, N, M, N, Kd, heads, ep, st);
-    else if (tile == 2) gemm_mfma_launch<2, 2, EPI_RELU_OUT64, false, false>(A, sA, lda, W, sW, ldw, nullptr, 0, N, M, N, Kd, heads, ep, st);
-    else if (no <= 32) gemm_mfma_launch<1, 1, EPI_RELU_OUT, false, false>(A, sA, lda, W, sW, ldw, nullptr, 0, N, M, N, Kd, heads, ep, st);
-    else gemm_mfma_launch<1, 1, EPI_RELU_OUT64, false, false>(A, sA, lda, W, sW, ldw, nullptr, 0, N, M, N, Kd, heads, ep, st);
+#define FUSED_OUT_LAUNCH(T_, E_) gemm_mfma_launch<T_, T_, E_, false, false>(A, sA, lda, W, sW, ldw, nullptr, 0, N, M, N, Kd, heads, ep, st)
+    if (tile == 2) { if (no <= 32) FUSED_OUT_LAUNCH(2, EPI_RELU_OUT); else if (no <= 48) FUSED_OUT_LAUNCH(2, EPI_RELU_OUT48); else FUSED_OUT_LAUNCH(2, EPI_RELU_OUT64); }
+    else { if (no <= 32) FUSED_OUT_LAUNCH(1, EPI_RELU_OUT); else if (no <= 48) FUSED_OUT_LAUNCH(1, EPI_RELU_OUT48); else FUSED_OUT_LAUNCH(1, EPI_RELU_OUT64); }
+#undef FUSED_OUT_LAUNCH
     *splits = N / (64 * tile); *stridePart = ep.stridePart;
 }
 
