@@ -627,9 +627,11 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
 
 // -------------------------------------------------------------------------------------------------
 typedef void (*coop_kernel_t)(RolloutK, const float*, const float*, const float*);
-struct CoopEntry { int env, K; coop_kernel_t kern[2][2]; int lds_floats; };     // kern[one workgroup per CU][draws supplied]
+template <int ENV> static constexpr bool coop_two_per_cu_spills() { return EnvDim<ENV>::NS > 16; }   // see the launch rule below
+struct CoopEntry { int env, K; coop_kernel_t kern[2][2]; int lds_floats; bool always_one; double pair, rem_slope; };     // kern[one workgroup per CU][draws supplied]
 #define CENTRY(ENVID, KK) {ENVID, KK, {{k_rollout_coop<ENVID, KK, false, false>, k_rollout_coop<ENVID, KK, false, true>}, \
-                                       {k_rollout_coop<ENVID, KK, true, false>, k_rollout_coop<ENVID, KK, true, true>}}, Coop<ENVID, KK>::TOTAL}
+                                       {k_rollout_coop<ENVID, KK, true, false>, k_rollout_coop<ENVID, KK, true, true>}}, Coop<ENVID, KK>::TOTAL, coop_two_per_cu_spills<ENVID>(), \
+                                       (ENVID == METRPO_ENV_SWIMMER) ? 1.50 : (ENVID == METRPO_ENV_SNAKE) ? 1.58 : 1.65, (ENVID == METRPO_ENV_SWIMMER) ? 0.0 : 1.0}
 static const CoopEntry kCoop[] = {
     CENTRY(METRPO_ENV_SWIMMER, 5), CENTRY(METRPO_ENV_HALF_CHEETAH, 5), CENTRY(METRPO_ENV_HOPPER, 5),
     CENTRY(METRPO_ENV_SNAKE, 5), CENTRY(METRPO_ENV_ANT, 5),
@@ -645,17 +647,29 @@ int coop_select_config(metrpo_ctx* c) {
 }
 
 // Launch rule.  tiles <= n_sm: one workgroup per tile, each alone on its CU (spill-free instantiation with the whole register file).
-// n_sm < tiles <= MIG_RATIO x n_sm (the shipped B = 5000: 313 tiles on 256 CUs): still ONE workgroup per CU, and the tiles x T
-// tile-steps are dealt out evenly with tiles migrating between two workgroups once (see the kernel) -- co-residency would leave 57
-// CUs with two tiles setting the wall time while 199 idle half of it.  Beyond: two co-resident workgroups per CU (more throughput per
-// CU than one tile at a time once every CU has two).
-static constexpr double MIG_RATIO = 1.55;
+// More tiles: either ONE workgroup per CU with the tiles x T tile-steps dealt out evenly (tiles migrate between workgroups once, see the
+// kernel), or two co-resident workgroups per CU working through the tiles in rounds of 2 n_sm.  Measured (tools/mig_sweep*.py): a tile-step
+// costs x1 alone on a CU and `pair` x1 per PAIR-step when two share it (1.50 swimmer, 1.58 snake, 1.65 hopper: the two-per-CU instantiations of
+// the latter spill a little), so the first takes tiles / n_sm units of T x1 and the second `pair` per full round plus, for <= n_sm left-over
+// tiles, 1 (swimmer) up to `pair` (the others: the left-overs start next to still-running neighbours); the cheaper one is launched.  That is
+// the migrating schedule for the shipped B = 5000 (313 tiles on 256 CUs: 1.22 vs 1.50 -- co-residency would leave 57 CUs with two tiles
+// setting the wall time while 199 idle half of it), co-residency at 2 or 4 tiles per CU, the migrating schedule again at 2.4.  Envs with more
+// than 16 state dims (half-cheetah, Ant) always run one workgroup per CU: their two-per-CU instantiation spills 100+ registers and is
+// 1.6-2 x slower per tile-step.
 int launch_rollout_coop(metrpo_ctx* c, int idx, const RolloutK& r_in, hipStream_t st) {
     const CoopEntry& en = kCoop[idx];
     const size_t sh = sizeof(float) * (size_t)en.lds_floats;
     const int tiles = (r_in.B + 15) / 16;
     RolloutK r = r_in;
-    const bool one = tiles <= (int)(MIG_RATIO * c->n_sm) && c->rollout_variant != 2;
+    bool one = tiles <= c->n_sm || en.always_one;
+    if (!one) {
+        const long long slots = 2LL * c->n_sm, rounds = tiles / slots, rest = tiles % slots;
+        const double t_one = (double)tiles / c->n_sm;
+        const double t_two = en.pair * rounds + (rest == 0 ? 0.0 : rest <= c->n_sm ? 1.0 + en.rem_slope * (en.pair - 1.0) * rest / c->n_sm : en.pair);
+        one = t_one < t_two;
+    }
+    if (const char* ex = getenv("METRPO_COOP_MODE")) one = (ex[0] == '1') || (one && ex[0] != '2');     // launch-rule experiments only: 1 / 2 workgroups per CU
+    if (c->rollout_variant == 2) one = false;
     const int grid = one ? (tiles < c->n_sm ? tiles : c->n_sm) : tiles;
     if (one && tiles > grid) {                                           // hand-over slots: flag[tiles] | ts[16 tiles] | model[16 tiles] | obs[16 tiles][ns]
         const int ns = c->pd.ns;
