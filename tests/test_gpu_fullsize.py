@@ -149,3 +149,32 @@ def test_migrating_schedule_random_shapes_equal_two_per_cu():
         got = eng.rollout(B, T, H, mode, pool_d, seed=100 + case)
         for k, v in ref.items():
             assert torch.equal(getattr(got, k), v), (case, env, B, T, H, mode, k)
+
+
+def test_chunked_ant_sampling_on_migrating_schedule_equals_two_per_cu():
+    """Early-terminating env (Ant, 2x64 nets) at n_envs = 5000: obtain_samples rolls in chunks that continue from the last state and stop
+    at the reference's step-granular rule; every chunk launch runs the migrating one-workgroup-per-CU schedule.  Same samples, bitwise,
+    as with the two-workgroups-per-CU instantiation (test hook 2), whose tiles never change workgroup."""
+    import metrpo_amd
+    env, K, B, H = 'ant', 5, 5000, 40
+    dm, theta, pdims, pool = O.make_problem(env, K=K, dyn_hidden=(64, 64), pol_hidden=(32, 32), seed=2, n_pool=2048, dtype=np.float32)
+    pool[::3, 2] = 0.21; dm.diff_mean[2] = -0.02                          # some paths fall early
+    outs = []
+    for variant in (2, 0):
+        eng = metrpo_amd.Engine(env, K, (64, 64), (32, 32))
+        eng.set_dynamics_layers(dm.Ws, dm.bs, dm.in_mean, dm.in_std, dm.diff_mean, dm.diff_std)
+        policy = metrpo_amd.GaussianMLPPolicy(eng, init_std=1.0, seed=0)
+        eng.set_policy(theta)
+        if eng.set_rollout_variant(variant) != 2:
+            pytest.skip('cooperative kernel not selected')
+        nne = metrpo_amd.NeuralNetEnv(env=metrpo_amd.InitStatePool(pool, dm.na), inner_env=None, cost_np=env, dynamics_in=None,
+                                      dynamics_outs=eng, sam_mode='step_rand')
+        algo = metrpo_amd.TRPO(env=nne, policy=policy, baseline=metrpo_amd.LinearFeatureBaseline(), batch_size=B * H, max_path_length=H,
+                               discount=0.99, gae_lambda=0.97, step_size=0.01, sampler_args=dict(n_envs=B), seed=5)
+        algo.start_worker()
+        tr = algo.obtain_samples(0).traj
+        outs.append({k: getattr(tr, k).clone() for k in ('obs', 'act', 'rew', 'done', 'tpath')})
+        assert int((tr.done.bool() & (tr.tpath < H - 1)).sum()) > 0       # early terminations happened
+        assert tr.T > H                                                   # more than one chunk
+    for k in outs[0]:
+        assert outs[0][k].shape == outs[1][k].shape and torch.equal(outs[0][k], outs[1][k]), k
