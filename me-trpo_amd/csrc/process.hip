@@ -305,6 +305,140 @@ __global__ void __launch_bounds__(1024) k_gram_final(const double* __restrict__ 
     }
 }
 
+// Same sums for WIDE feature sets (5 to 8 column blocks: Humanoid's 114 features + the return column): the NFB (NFB + 1) / 2 upper-triangle
+// 16 x 16 blocks do not fit one wave's registers in float64, so a BLOCK works on one 16-sample tile at a time: its 256 threads evaluate the
+// tile's 16 x M feature values once into LDS ([k-step][q][feature], double-buffered, the next tile's raw inputs loaded a tile ahead), and every
+// wave runs the MFMAs of its quarter of the block pairs on LDS operands and keeps those blocks' float64 accumulators.  The generic k_gram
+// (thread per sample pair in LDS) needed 77 ms per iteration at C4.
+template <int NFB>
+__global__ void __launch_bounds__(256) k_gram_mfma_wide(const float* __restrict__ obs, const float* __restrict__ ret,
+                                                        const int32_t* __restrict__ tpath, const uint8_t* __restrict__ valid,
+                                                        long long N, int ns, double* __restrict__ part) {
+    constexpr int M = NFB * 16, NPAIR = NFB * (NFB + 1) / 2, NPW = (NPAIR + 3) / 4, NV = (16 * M + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) double red[];      // epilogue: [M * M]; main loop: float FT[2][4][4][M] in the same memory
+    float* FT = (float*)red;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
+    const int F = 2 * ns + 4;
+    // this wave's block pairs (a <= b), enumerated row-major over the upper triangle: p = wave, wave + 4, ...
+    int pa[NPW], pb[NPW];
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+        int p = wave + 4 * j, a = 0;
+        if (p >= NPAIR) { pa[j] = -1; pb[j] = -1; continue; }
+        while (p >= NFB - a) { p -= NFB - a; ++a; }
+        pa[j] = a; pb[j] = a + p;
+    }
+    double acc[NPW][4];
+#pragma unroll
+    for (int j = 0; j < NPW; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[j][r] = 0.0;
+    const long long ntiles = (N + 15) / 16;
+    // element v of the tile handled by this thread: sample sl = e / M (0..15), feature f = e % M, e = tid + 256 v
+    struct Raw { float o[NV]; float rv[NV]; int tp[NV]; int ok[NV]; };
+    auto fetch = [&](long long tile, Raw& in) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int e = tid + 256 * v, sl = e / M, f = e % M;
+            const long long n = tile * 16 + sl;
+            const bool inr = e < 16 * M && tile < ntiles && n < N;
+            const long long nc = inr ? n : 0;
+            const int fo = (f < ns) ? f : ((f < 2 * ns) ? f - ns : 0);
+            in.ok[v] = inr ? ((valid == nullptr) ? 1 : (int)valid[nc]) : 0;
+            in.tp[v] = tpath[nc]; in.rv[v] = ret[nc]; in.o[v] = obs[nc * ns + fo];
+        }
+    };
+    auto publish = [&](const Raw& in, float* dst) {                  // dst[k-step s][q][feature]: sample sl = 4 s + q
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int e = tid + 256 * v, sl = e / M, f = e % M;
+            if (e >= 16 * M) continue;
+            const float al = (float)in.tp[v] / 100.0f, o = fminf(fmaxf(in.o[v], -10.f), 10.f);
+            const int kq = f - 2 * ns;
+            float x = (f < ns) ? o : o * o;
+            x = (kq == 0) ? al : x;
+            x = (kq == 1) ? al * al : x;
+            x = (kq == 2) ? al * al * al : x;
+            x = (kq == 3) ? 1.0f : x;
+            x = (f == F) ? in.rv[v] : x;
+            x = (f > F) ? 0.0f : x;
+            dst[((sl >> 2) * 4 + (sl & 3)) * M + f] = in.ok[v] ? x : 0.0f;
+        }
+    };
+    Raw nxt;
+    long long tile = blockIdx.x;
+    fetch(tile, nxt);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    int buf = 0;
+    if (tile < ntiles) publish(nxt, FT);
+    fetch(tile + gridDim.x, nxt);
+    __syncthreads();
+    for (; tile < ntiles; tile += gridDim.x) {
+        const float* cur = FT + buf * 16 * M;
+        f32x4 g[NPW];
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) g[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const float* row = cur + (s4 * 4 + q) * M + c;
+#pragma unroll
+            for (int j = 0; j < NPW; ++j)
+                if (pa[j] >= 0) g[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(row[16 * pa[j]], row[16 * pb[j]], g[j], 0, 0, 0);
+        }
+        if (tile + gridDim.x < ntiles) publish(nxt, FT + (buf ^ 1) * 16 * M);      // the other buffer: its readers passed the barrier below one tile ago
+        fetch(tile + 2LL * gridDim.x, nxt);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < NPW; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[j][r] += (double)g[j][r];
+        __syncthreads();
+        buf ^= 1;
+    }
+    __syncthreads();
+    // epilogue: every block pair is owned by exactly one wave -> write it (and its mirror image) into the M x M matrix, then the compact row
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+        if (pa[j] < 0) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                                   // D layout: row 4 q + r of block a, col c of block b
+            const int i = 16 * pa[j] + 4 * q + r, jj = 16 * pb[j] + c;
+            red[i * M + jj] = acc[j][r];
+            if (pa[j] != pb[j]) red[jj * M + i] = acc[j][r];
+        }
+    }
+    __syncthreads();
+    const int nout = F * F + F;
+    double* out = part + (size_t)blockIdx.x * nout;
+    for (int p = tid; p < nout; p += 256) {
+        const int i = (p < F * F) ? p / F : p - F * F, j = (p < F * F) ? p % F : F;
+        out[p] = red[i * M + j];
+    }
+}
+
+template <int NFB>
+static int launch_gram_mfma_wide(metrpo_ctx* c, const float* obs, const float* ret, const int32_t* tpath, const uint8_t* valid,
+                                 int64_t N, double* AtA, double* Aty, hipStream_t st) {
+    constexpr int M = NFB * 16;
+    const int F = 2 * c->pd.ns + 4;
+    const long long tiles = (N + 15) / 16;
+    const int g = (int)std::max<long long>(1, std::min<long long>(tiles, (long long)c->n_sm * 2));
+    const size_t need = (size_t)g * (F * F + F);
+    if (need > c->gram_cap) {
+        if (c->d_gram_part) HIP_TRY(c, hipFree(c->d_gram_part));
+        c->d_gram_part = nullptr; c->gram_cap = 0;
+        HIP_TRY(c, hipMalloc(&c->d_gram_part, need * sizeof(double)));
+        c->gram_cap = need;
+    }
+    const size_t sh = sizeof(double) * M * M;                         // >= the 2 x 16 x M floats of the main loop
+    if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_gram_mfma_wide<NFB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    hipLaunchKernelGGL(k_gram_mfma_wide<NFB>, dim3(g), dim3(256), sh, st, obs, ret, tpath, valid, (long long)N, c->pd.ns, c->d_gram_part);
+    const int nout = F * F + F;
+    hipLaunchKernelGGL(k_gram_final, dim3((nout + 15) / 16), dim3(1024), 0, st, c->d_gram_part, g, M, F, AtA, Aty);
+    HIP_TRY(c, hipGetLastError());
+    return METRPO_OK;
+}
+
 template <int NFB>
 static int launch_gram_mfma(metrpo_ctx* c, const float* obs, const float* ret, const int32_t* tpath, const uint8_t* valid,
                             int64_t N, double* AtA, double* Aty, hipStream_t st) {
@@ -364,6 +498,10 @@ int launch_gram(metrpo_ctx* c, const float* obs, const float* ret, const int32_t
     if (nfb <= 2) return launch_gram_mfma<2>(c, obs, ret, tpath, valid, N, AtA, Aty, st);
     if (nfb == 3) return launch_gram_mfma<3>(c, obs, ret, tpath, valid, N, AtA, Aty, st);
     if (nfb == 4) return launch_gram_mfma<4>(c, obs, ret, tpath, valid, N, AtA, Aty, st);
+    if (nfb == 5) return launch_gram_mfma_wide<5>(c, obs, ret, tpath, valid, N, AtA, Aty, st);
+    if (nfb == 6) return launch_gram_mfma_wide<6>(c, obs, ret, tpath, valid, N, AtA, Aty, st);
+    if (nfb == 7) return launch_gram_mfma_wide<7>(c, obs, ret, tpath, valid, N, AtA, Aty, st);
+    if (nfb == 8) return launch_gram_mfma_wide<8>(c, obs, ret, tpath, valid, N, AtA, Aty, st);
     const int bs = 256;
     const size_t sh = sizeof(double) * GRAM_TILE * (F + 1);
     const int grid = (int)std::min<int64_t>((N + GRAM_TILE - 1) / GRAM_TILE, (int64_t)c->n_sm * 4);

@@ -518,3 +518,29 @@ def test_gemm_rollout_fused_output_layer_equals_separate_layers(env, K, B, hidde
         np.testing.assert_allclose(got, ref[k], rtol=3e-4, atol=1e-4, err_msg=k)
     assert torch.equal(fused.done, ref_done)
     assert float(np.abs(ref['obs'][1] - ref['obs'][0]).max()) > 1e-3                  # the dynamics did move the state
+
+
+def test_wide_feature_baseline_gram_humanoid():
+    """114 features + the return column = 8 column blocks: the block-cooperative MFMA Gram kernel (process.hip k_gram_mfma_wide) vs float64 NumPy
+    on the oracle's feature matrix, at a sample count that is not a multiple of the tile or the grid."""
+    env, K, B, T, H = 'humanoid', 3, 333, 9, 4
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (64, 64), (32, 32), seed=19)
+    traj = eng.rollout(B, T, H, 'step_rand', pool, seed=4)
+    adv, ret, valid, stats = eng.gae(traj, None, 0.99, 0.95)
+    AtA, Aty = eng.baseline_gram(traj.obs, ret, traj.tpath, valid)
+    tr = dict(obs=cpu(traj.obs), act=cpu(traj.act), rew=cpu(traj.rew), mean=cpu(traj.mean), done=cpu(traj.done).astype(bool), tpath=cpu(traj.tpath))
+    paths = Hh.paths_from_timemajor(tr)
+    F = np.concatenate([O.LinearFeatureBaselineOracle.features(p) for p in paths])
+    tb = np.array([x for p in paths for x in p['_tb']])
+    y = cpu(ret)[tb[:, 0], tb[:, 1]]
+    nf = 2 * dm.ns + 4
+    assert F.shape[1] == nf == 114 and len(F) == int(cpu(valid).sum())
+    G = F.T @ F
+    scale = np.sqrt(np.outer(np.diag(G), np.diag(G)))
+    assert (np.abs(cpu(AtA) - G) <= 2e-6 * scale + 1e-9).all()
+    np.testing.assert_allclose(cpu(AtA), cpu(AtA).T, rtol=0, atol=0)               # mirrored blocks
+    assert (np.abs(cpu(Aty) - F.T @ y) <= 2e-6 * np.sqrt(np.diag(G) * (y @ y)) + 1e-6).all()
+    # accumulates (+=) into the caller's buffers like the narrow kernels: a second call doubles the sums
+    out = torch.cat([AtA.reshape(-1), Aty]).clone()
+    eng.baseline_gram(traj.obs, ret, traj.tpath, valid, out=out)
+    np.testing.assert_allclose(cpu(out[:nf * nf]).reshape(nf, nf), 2 * cpu(AtA), rtol=1e-12)
