@@ -55,6 +55,7 @@ __global__ void k_big_pre(ProblemDesc pd, RolloutK r, int t, const float* __rest
         r.obs[tb * ns + i] = s;
         if (i >= pd.n_drop) st.X[(size_t)b * st.ldx + i - pd.n_drop] = (s - in_mean[i]) / in_std[i];       // training.py:228,146-151
     }
+    for (int j = pd.nin; j < st.ldx; ++j) st.X[(size_t)b * st.ldx + j] = 0.0f;                     // pad columns of the 16-byte aligned rows (layer 0 contracts over ldx)
     for (int d0 = 0; d0 < na; d0 += 2) {
         float z[2] = {0.f, 0.f};
         if (!r.determ && r.eps == nullptr) {
@@ -160,6 +161,7 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
     const float* __restrict__ log_std = theta + C::pLS;
     // state part of the normalised, dropped input: lane (c, q) writes its dims 4q .. (every 16th column block)
     for (int i = q; i < NS; i += 4) if (i >= NDROP) st.X[(size_t)b * st.ldx + i - NDROP] = (ST[c * NS + i] - in_mean[i]) / in_std[i];     // training.py:228,146-151
+    if (q == 0) for (int j = C::NIN; j < st.ldx; ++j) st.X[(size_t)b * st.ldx + j] = 0.0f;            // pad columns of the 16-byte aligned rows (layer 0 contracts over ldx)
     // action dims 4q .. 4q+3 of this lane = Philox chunks 2q, 2q+1 (chunk 0 = the step block), exactly as k_big_pre
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -428,7 +430,9 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
         const float* in = bs.X; long long sIn = 0; int ldin = bs.ldx;
         float* bufs[2] = {bs.HA, bs.HB};
         for (int l = 0; l < L; ++l) {
-            const int Kd = pd.dyn.dims[l], N = pd.dyn.dims[l + 1];
+            // layer 0 contracts over the PADDED input row (X's pad columns are 0, the weight rows they meet are the first bias entries that follow
+            // W0 in the resident layout: finite x 0): a contraction length that is a multiple of 4 takes the GEMM's aligned load path
+            const int Kd = (l == 0 && L > 1) ? bs.ldx : pd.dyn.dims[l], N = pd.dyn.dims[l + 1];
             const bool lastl = (l == L - 1);
             float* out = lastl ? bs.OUT : bufs[l & 1];
             const long long sOut = (long long)B * N;
