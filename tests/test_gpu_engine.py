@@ -544,3 +544,30 @@ def test_wide_feature_baseline_gram_humanoid():
     out = torch.cat([AtA.reshape(-1), Aty]).clone()
     eng.baseline_gram(traj.obs, ret, traj.tpath, valid, out=out)
     np.testing.assert_allclose(cpu(out[:nf * nf]).reshape(nf, nf), 2 * cpu(AtA), rtol=1e-12)
+
+
+def test_gemm_rollout_random_shapes_vs_generic_kernel():
+    """Random (env, K, hidden widths, B, sam_mode) on the step-wise GEMM rollout -- widths that are and are not multiples of 64 (fused vs separate
+    output layer), 2 and 3 hidden layers, MFMA / block / GEMM pre-step -- against the thread-per-env generic kernel with the same supplied draws."""
+    rs = np.random.RandomState(1234)
+    envs = ['swimmer', 'half_cheetah', 'ant', 'hopper', 'snake', 'humanoid']
+    for case in range(8):
+        env = envs[case % len(envs)]
+        K = int(rs.randint(1, 6))
+        nl = 2 if case % 3 else 3
+        hidden = tuple(int(rs.choice([128, 160, 192, 256, 320])) for _ in range(nl))
+        B = int(rs.randint(20, 400)); H = int(rs.randint(2, 6)); T = int(rs.randint(2, 2 * H + 1))
+        mode = ['step_rand', 'eps_rand', 'model_mean', 'model_med', 'one_model'][int(rs.randint(5))]
+        pol = (100, 50, 25) if env == 'humanoid' else (32, 32)
+        eng, dm, theta, pdims, pool = Hh.make_engine(env, K, hidden, pol, seed=300 + case)
+        assert eng.set_rollout_variant(0) == 3
+        dr = Hh.draws(np.random.RandomState(case), K, B, T, dm.ns, dm.na, len(pool))
+        dr32 = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in dr.items()}
+        dr32.pop('sel_noise', None)
+        got = eng.rollout(B, T, H, mode, pool, **dr32)
+        ref = eng.rollout(B, T, H, mode, pool, force_generic=True, **dr32)
+        msg = str((case, env, K, hidden, B, T, H, mode))
+        assert torch.equal(got.tpath, ref.tpath) and torch.equal(got.done, ref.done), msg
+        np.testing.assert_allclose(cpu(got.mean), cpu(ref.mean), rtol=2e-3, atol=2e-3, err_msg=msg)
+        np.testing.assert_allclose(cpu(got.obs), cpu(ref.obs), rtol=5e-3, atol=5e-3, err_msg=msg)
+        np.testing.assert_allclose(cpu(got.rew), cpu(ref.rew), rtol=5e-3, atol=5e-3, err_msg=msg)
