@@ -14,6 +14,9 @@ struct DgState {
     float *S, *X, *U, *MU, *OUT, *G, *DZa, *DZb, *LAM, *DONES, *PART;
     float* H[MAXL];
     double* ACC;
+    // forward sweep: output layer left as partials (split-K, or one per 64 / 128-column block of the last hidden layer when that layer's launch
+    // contracts its relu tile with the output weights, gemm_mfma.h EPI_RELU_OUT); k_dg_post adds them and the bias.  0 splits: OUT holds the layer.
+    int out_splits; long long out_stride; const float* out_bias; long long out_bias_stride;
 };
 
 // thread = row (k, b): policy forward of the current state, clipped action, pre-clip mean, normalised + dropped dynamics input
@@ -156,16 +159,35 @@ __device__ __forceinline__ float dg_cost(int env, int ns, int na, const float* x
 }
 
 // forward: x' = diff_mean + diff_std * out + x, cost, dones, weights, trajectory
-__global__ void k_dg_post(ProblemDesc pd, int B, int T, int t, double gpow, const float* __restrict__ norm, DgState st, float* __restrict__ XS,
-                          float* __restrict__ WT) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
-    if (b >= B) return;
-    const int ns = pd.ns, na = pd.na, K = pd.K;
+constexpr int DG_POST_ROWS = 32, DG_POST_THREADS = 256;
+__global__ __launch_bounds__(DG_POST_THREADS) void k_dg_post(ProblemDesc pd, int B, int T, int t, double gpow, const float* __restrict__ norm, DgState st,
+                                                             float* __restrict__ XS, float* __restrict__ WT) {
+    // phase 1, all threads: the block's DG_POST_ROWS x ns output-layer values, coalesced (and summed over the partials when the layer was left as
+    // partials), into LDS; phase 2, one thread per row: residual, cost, dones, weights
+    __shared__ float so[DG_POST_ROWS * 65];
+    const int ns = pd.ns, na = pd.na, K = pd.K, k = blockIdx.y;
+    const int b0 = blockIdx.x * DG_POST_ROWS, nr = min(DG_POST_ROWS, B - b0), nel = nr * ns, lds = ns | 1;
+    for (int e = threadIdx.x; e < nel; e += DG_POST_THREADS) {
+        const int r = e / ns, i = e - r * ns;
+        float o;
+        if (st.out_splits == 0) o = st.OUT[((size_t)k * B + b0) * ns + e];
+        else {
+            o = st.out_bias[(size_t)k * st.out_bias_stride + i];
+            const float* part = st.PART + (size_t)k * st.out_stride + (size_t)b0 * ns + e;
+            const size_t sps = (size_t)K * st.out_stride;
+#pragma unroll 4
+            for (int sp = 0; sp < st.out_splits; ++sp) o += part[sp * sps];
+        }
+        so[r * lds + i] = o;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x >= nr) return;
+    const int b = b0 + threadIdx.x;
     const size_t row = (size_t)k * B + b;
     const float* diff_mean = norm + 2 * (ns + na); const float* diff_std = diff_mean + ns;
     float xn[64];                                                   // ns <= 64 enforced by the launcher
     bool fin = true;
-    for (int i = 0; i < ns; ++i) { xn[i] = fmaf(diff_std[i], st.OUT[row * ns + i], diff_mean[i]) + st.S[row * ns + i]; fin = fin && isfinite(xn[i]); }
+    for (int i = 0; i < ns; ++i) { xn[i] = fmaf(diff_std[i], so[threadIdx.x * lds + i], diff_mean[i]) + st.S[row * ns + i]; fin = fin && isfinite(xn[i]); }
     const float c = dg_cost(pd.env, ns, na, xn, st.U + row * na);
     const float dones = st.DONES[row], live = 1.0f - dones;
     if (pd.env == METRPO_ENV_ANT) st.DONES[row] = fmaxf(dones, ((xn[2] >= 0.2f) && (xn[2] <= 1.0f) && fin) ? 0.0f : 1.0f);
@@ -312,6 +334,14 @@ bool det_gemm_applicable(const metrpo_ctx* c) {
     return true;
 }
 
+// defer_out (forward sweeps: nobody reads the last hidden layer or OUT afterwards): the last hidden layer's launch contracts its relu tile with the
+// output weights when the tile shape allows it, otherwise the output layer's split-K partials are left un-reduced; either way k_dg_post adds them
+static int dg_fuse_tile(const metrpo_ctx* c, int B) {
+    const ProblemDesc& pd = c->pd;
+    const int L = pd.dyn.n_layers;
+    if (L < 2 || pd.dyn.act[L - 2] != METRPO_ACT_RELU || pd.dyn.act[L - 1] != METRPO_ACT_IDENTITY || getenv("METRPO_NO_FUSED_OUT") != nullptr) return 0;
+    return gemm_fused_out_tile(B, pd.dyn.dims[L - 1], pd.K, pd.ns);
+}
 static int dg_workspace(metrpo_ctx* c, int B, DgState* s) {
     const ProblemDesc& pd = c->pd;
     const int K = pd.K, L = pd.dyn.n_layers;
@@ -323,6 +353,7 @@ static int dg_workspace(metrpo_ctx* c, int B, DgState* s) {
     const size_t nS = up4(R * pd.ns), nX = up4(R * pd.nin), nU = up4(R * pd.na), nZ = up4(R * maxw), nD = up4(R);
     size_t nP = 0;
     for (int l = 0; l < L; ++l) nP = std::max(nP, up4(skinny_part_floats(B, pd.dyn.dims[l + 1], pd.dyn.dims[l], K)));
+    if (const int ft = dg_fuse_tile(c, B)) nP = std::max(nP, up4(gemm_fused_out_part_floats(B, pd.dyn.dims[L - 1], K, pd.ns, ft)));
     const size_t need = (4 * nS + nX + 2 * nU + nH + 2 * nZ + nD + nP) * sizeof(float) + R * sizeof(double) + 64;
     if (need > c->dg_cap) {
         if (c->d_dg) HIP_TRY(c, hipFree(c->d_dg));
@@ -338,18 +369,27 @@ static int dg_workspace(metrpo_ctx* c, int B, DgState* s) {
     return METRPO_OK;
 }
 
-static void dg_forward_layers(metrpo_ctx* c, const DgState& s, int B, int n_layers_to_run, hipStream_t st) {
+static void dg_forward_layers(metrpo_ctx* c, DgState& s, int B, int n_layers_to_run, bool defer_out, hipStream_t st) {
     const ProblemDesc& pd = c->pd;
     const int K = pd.K, L = pd.dyn.n_layers;
     const float* in = s.X; int ldin = pd.nin;
+    s.out_splits = 0; s.out_stride = 0; s.out_bias = c->d_dyn + pd.dyn.b_off[L - 1]; s.out_bias_stride = pd.dyn.n_params;
+    const int fuse_tile = (defer_out && n_layers_to_run == L) ? dg_fuse_tile(c, B) : 0;
     for (int l = 0; l < n_layers_to_run; ++l) {
         const int Kd = pd.dyn.dims[l], N = pd.dyn.dims[l + 1];
         float* out = (l == L - 1) ? s.OUT : s.H[l];
         GemmEpi ep = {};
         ep.bias = c->d_dyn + pd.dyn.b_off[l]; ep.strideBias = pd.dyn.n_params;
         const float* Wl = c->d_dyn + pd.dyn.w_off[l];
+        if (fuse_tile && l == L - 2) {
+            gemm_relu_fused_out(fuse_tile, in, (long long)B * Kd, ldin, Wl, pd.dyn.n_params, N, ep.bias, ep.strideBias, c->d_dyn + pd.dyn.w_off[L - 1],
+                                pd.dyn.n_params, pd.ns, B, N, Kd, K, s.PART, st, &s.out_splits, &s.out_stride);
+            break;
+        }
+        SkinnyDefer df = {0, 0};
         gemm_skinny_bias(in, (long long)B * Kd, ldin, Wl, pd.dyn.n_params, N, ep.bias, ep.strideBias, out, (long long)B * N, B, N, Kd, K, s.PART, st,
-                         (l == L - 1) ? 0 : 1);
+                         (l == L - 1) ? 0 : 1, (defer_out && l == L - 1) ? &df : nullptr);
+        if (defer_out && l == L - 1) { s.out_splits = df.splits; s.out_stride = df.stridePart; }
         in = out; ldin = N;
     }
 }
@@ -376,8 +416,8 @@ int launch_dg_forward(metrpo_ctx* c, const float* s0, int B, int T, double gamma
     for (int t = 0; t < T; ++t) {
         if (pre_mfma) hipLaunchKernelGGL(pre_mfma, dim3((B + 63) / 64, K), dim3(256), 0, st, pd, B, c->d_theta, c->d_norm, (const float*)nullptr, 0LL, s);
         else hipLaunchKernelGGL(k_dg_pre, dim3((B + pbs - 1) / pbs, K), dim3(pbs), psh, st, pd, B, c->d_theta, c->d_norm, (const float*)nullptr, 0LL, s);
-        dg_forward_layers(c, s, B, L, st);
-        hipLaunchKernelGGL(k_dg_post, dim3((B + 127) / 128, K), dim3(128), 0, st, pd, B, T, t, g, c->d_norm, s, XS, WT);
+        dg_forward_layers(c, s, B, L, true, st);
+        hipLaunchKernelGGL(k_dg_post, dim3((B + DG_POST_ROWS - 1) / DG_POST_ROWS, K), dim3(DG_POST_THREADS), 0, st, pd, B, T, t, g, c->d_norm, s, XS, WT);
         g *= gamma;
     }
     hipLaunchKernelGGL(k_dg_costs, dim3(K), dim3(256), 0, st, B, s.ACC, costs);
@@ -406,7 +446,7 @@ int launch_dg_backward(metrpo_ctx* c, int B, int T, const float* XS, const float
         if (pre_mfma) hipLaunchKernelGGL(pre_mfma, dim3((B + 63) / 64, K), dim3(256), 0, st, pd, B, c->d_theta, c->d_norm, XS + (size_t)t * B * pd.ns, xs_model, s);
         else hipLaunchKernelGGL(k_dg_pre, dim3((B + pbs - 1) / pbs, K), dim3(pbs), psh, st, pd, B, c->d_theta, c->d_norm,
                                 XS + (size_t)t * B * pd.ns, xs_model, s);
-        dg_forward_layers(c, s, B, L - 1, st);                                    // hidden activations only
+        dg_forward_layers(c, s, B, L - 1, false, st);                             // hidden activations only
         hipLaunchKernelGGL(k_dg_mid, dim3((B + 127) / 128, K), dim3(128), 0, st, pd, B, T, t, c->d_norm, XS, WT, s);
         float* dz = s.DZa; float* dzn = s.DZb;
         for (int l = L - 1; l >= 0; --l) {
