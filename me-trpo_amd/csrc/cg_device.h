@@ -21,8 +21,26 @@ struct CgTail {
 // r, p <- g; x <- 0; pf <- (float) g   (krylov.cg prologue)
 __device__ __forceinline__ void cg_init_body(int P, const double* gout, double* x, double* r, double* p, float* pf, double* scal, double* sh);
 
+// wave sum on the DPP path (quad swaps, half-row mirror, row mirror, then the four row totals through readlane, in row order): the
+// __shfl_down ladder is 12 dependent ds_bpermute round trips per float64 sum, ~1 us of every fused CG step
+template <int CTRL> __device__ __forceinline__ double dpp_add_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xF, 0xF, true), hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return v + __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v = dpp_add_f64<0xB1>(v); v = dpp_add_f64<0x4E>(v); v = dpp_add_f64<0x141>(v); v = dpp_add_f64<0x140>(v);
+    const long long b = __double_as_longlong(v);
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int lo = __builtin_amdgcn_readlane((int)b, 16 * r), hi = __builtin_amdgcn_readlane((int)(b >> 32), 16 * r);
+        t += __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    }
+    return t;
+}
 __device__ __forceinline__ double blk_sum(double v, double* sh) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    v = wave_sum_f64(v);
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     __syncthreads();
     if (l == 0) sh[w] = v;
@@ -60,16 +78,32 @@ __device__ __forceinline__ void cg_init_body(int P, const double* gout, double* 
     if (threadIdx.x == 0) { scal[S_RDOTR] = rdotr; scal[S_DONE] = 0.0; scal[S_ITERS] = 0.0; scal[S_LOSS0] = gout[0]; }
 }
 
+// What a CG iteration reads that the Fisher-vector product it follows does NOT write (p, r, x and the two scalars): k_finalize loads these
+// before it waits on the arrival ticket, so the last block's CG step has one global round trip (z) left instead of two dependent ones.
+constexpr int CG_R = 2;              // register-resident fast path: P <= 2 * blockDim (1024 threads)
+struct CgPre { double pv[CG_R], rv[CG_R], xv[CG_R], done, rdotr; bool have; };
+__device__ __forceinline__ void cg_prefetch(const CgTail& t, CgPre& pre) {
+    pre.have = (t.op == 1 && t.P <= CG_R * (int)blockDim.x);
+    if (!pre.have) return;
+    pre.done = t.scal[S_DONE]; pre.rdotr = t.scal[S_RDOTR];
+#pragma unroll
+    for (int j = 0; j < CG_R; ++j) {
+        const int i = threadIdx.x + j * blockDim.x;
+        pre.pv[j] = pre.rv[j] = pre.xv[j] = 0.0;
+        if (i < t.P) { pre.pv[j] = t.p[i]; pre.rv[j] = t.r[i]; pre.xv[j] = t.x[i]; }
+    }
+}
+
 // one krylov.cg iteration after z = f_Ax(p) has been formed (z lacks the reg term: added here)
 __device__ __forceinline__ void cg_step_body(int P, double reg, double tol, int last, double* x, double* r, double* p, double* z,
-                                             float* pf, double* scal, double* sh) {
-    if (scal[S_DONE] != 0.0) {
+                                             float* pf, double* scal, double* sh, const CgPre* pre = nullptr) {
+    const bool pf_ = (pre != nullptr && pre->have);
+    if ((pf_ ? pre->done : scal[S_DONE]) != 0.0) {
         if (last) for (int i = threadIdx.x; i < P; i += blockDim.x) pf[i] = (float)x[i];   // next FVP input is x (step scale)
         return;
     }
-    const double rdotr = scal[S_RDOTR];
+    const double rdotr = pf_ ? pre->rdotr : scal[S_RDOTR];
     // every vector element is read ONCE (one global round trip) and kept in registers across the two reductions: element i = tid + j*blockDim
-    constexpr int CG_R = 2;          // register-resident fast path: P <= 2 * blockDim (stand-alone k_cg_step with 1024 threads)
     if (P <= CG_R * (int)blockDim.x) {
         double pv[CG_R], zv[CG_R], rv[CG_R], xv[CG_R];
         double acc = 0.0;
@@ -77,7 +111,10 @@ __device__ __forceinline__ void cg_step_body(int P, double reg, double tol, int 
         for (int j = 0; j < CG_R; ++j) {
             const int i = threadIdx.x + j * blockDim.x;
             pv[j] = zv[j] = rv[j] = xv[j] = 0.0;
-            if (i < P) { pv[j] = p[i]; zv[j] = z[i] + reg * pv[j]; rv[j] = r[i]; xv[j] = x[i]; acc += pv[j] * zv[j]; }
+            if (i < P) {
+                if (pf_) { pv[j] = pre->pv[j]; rv[j] = pre->rv[j]; xv[j] = pre->xv[j]; } else { pv[j] = p[i]; rv[j] = r[i]; xv[j] = x[i]; }
+                zv[j] = z[i] + reg * pv[j]; acc += pv[j] * zv[j];
+            }
         }
         const double pz = blk_sum(acc, sh);
         const double v = rdotr / pz;
@@ -142,9 +179,9 @@ __device__ __forceinline__ void cg_finish_body(int P, double reg, double max_kl,
 }
 
 // CG tail dispatch shared by k_finalize and the in-kernel reduction of policy_mfma.hip (one block, all threads)
-__device__ __forceinline__ void cg_tail_run(const CgTail& t, double* sh) {
+__device__ __forceinline__ void cg_tail_run(const CgTail& t, double* sh, const CgPre* pre = nullptr) {
     if (t.op == 1) {
-        cg_step_body(t.P, t.reg, t.tol, t.last, t.x, t.r, t.p, t.z, t.pf, t.scal, sh);
+        cg_step_body(t.P, t.reg, t.tol, t.last, t.x, t.r, t.p, t.z, t.pf, t.scal, sh, pre);
         if (t.last && t.implicit_hd) {
             __syncthreads();
             cg_finish_implicit(t.P, t.max_kl, t.x, t.r, t.gout + 1, t.step, t.scal, sh);

@@ -20,10 +20,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef POL_SKIP
 #define POL_SKIP 0              // developer experiments (tools/build_variant.sh): bit mask of tile stages to leave out; results are then meaningless
 #endif
+#ifndef POL_PRIO
+#define POL_PRIO 0
+#endif
 #ifndef NWAVES
 #define NWAVES 8                // waves per block: one block per CU (2 waves per SIMD), the weight image is shared by all 8
 #endif
 constexpr int cdiv_(int a, int b) { return (a + b - 1) / b; }
+// Developer instrumentation (SRC=policy_mfma.hip tools/build_variant.sh ptiming -DPOL_TIMING): s_memtime at the phase boundaries of the
+// cached-activation FVP kernel, waves of workgroup 0, read back with metrpo_debug_pol_phases (tools/pol_phases.py).  Not in the shipped library.
+#ifdef POL_TIMING
+__device__ unsigned long long g_pol_phase[16][8];
+#define PT_MARK(i) { if (MODE_ == MODE_FVPC && blockIdx.x == 0 && lane == 0) g_pol_phase[wave][i] = __builtin_readcyclecounter(); }
+extern "C" int32_t metrpo_debug_pol_phases(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pol_phase), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -1; }
+#else
+#define PT_MARK(i)
+#endif
 
 
 __device__ __forceinline__ void wave_sync_lds() {
@@ -31,8 +43,14 @@ __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ float xsum_q(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
+// sum over the 16 lanes c of a row, on the VALU's DPP path (quad swaps, then half-row and row mirrors: after each step the lanes that are
+// exchanged hold equal partial sums, so this is the xor-1, 2, 4, 8 butterfly bit for bit).  The epilogue runs ~45 of these per wave: as
+// ds_bpermute chains (__shfl_xor) they were 6 us of every launch, measured with tools/pol_phases.py.
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float xsum_c(float v) {
-    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    v = dpp_add<0xB1>(v); v = dpp_add<0x4E>(v); v = dpp_add<0x141>(v); v = dpp_add<0x140>(v);
     return v;
 }
 
@@ -73,31 +91,53 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
     const int c = lane & 15, q = lane >> 4;
     float* IMG = lds;
     float* TL = lds + I::TOTAL + wave * WTL;
-
-    // ---------------- weight fragment image -> LDS (each element written by exactly one thread) ----------------
-    // k.img_map[i] = source index of image element i in theta (bit 30 clear) or in v (bit 30 set), -1 = zero; built once on the
-    // host (pol_image_map).  Map loads, gathers and LDS stores are issued in independent batches of IMG_U per thread: the
-    // prologue costs ~2 L2 round trips instead of one dependent global load per element.
-    {
-        constexpr int IMG_U = 8;
-        for (int i0 = 0; i0 < I::TOTAL; i0 += NWAVES * 64 * IMG_U) {
-            int m[IMG_U]; float w[IMG_U];
+    PT_MARK(0)
+    const long long ntiles = (k.N + 15) / 16;
+    const f32x4* __restrict__ hc = (const f32x4*)k.hcache;
+    // Everything a tile reads from HBM (observations in both layouts, valid flag, cached activations, and for the loss modes the old
+    // distribution / action / advantage) is fetched ONE TILE AHEAD into registers: consumed in the iteration that issued them, the
+    // valid flag and the observation loads each put a full HBM round trip (~2000 cycles) on the wave's critical path, per tile.
+    struct TileIn {
+        float xB[NS_KS]; float xTs[4][NSI]; float ols[4], omu[4], act[4], adv; f32x4 gmv; int vld; f32x4 h[2 * HB];
+    };
+    auto fetch = [&](long long tile, TileIn& in) {
+        const long long n0 = tile * 16, n = n0 + c;
+        const bool inr = tile < ntiles && n < k.N;
 #pragma unroll
-            for (int u = 0; u < IMG_U; ++u) { const int i = i0 + u * NWAVES * 64 + tid; m[u] = (i < I::TOTAL) ? k.img_map[i] : -1; }
+        for (int s = 0; s < NS_KS; ++s) { const int f = 4 * s + q; in.xB[s] = (inr && f < NS) ? k.obs[n * NS + f] : 0.f; }
+        if (MODE != MODE_LOSSKL) {
 #pragma unroll
-            for (int u = 0; u < IMG_U; ++u) {
-                const int i = i0 + u * NWAVES * 64 + tid;
-                bool use = m[u] >= 0;
-                if (MODE != MODE_FVP && (m[u] & 0x40000000)) use = false;                       // tangent tables: FVP only
-                if (MODE == MODE_LOSSKL && i >= I::O_W2B && i < I::O_W2F) use = false;          // back-prop tables unused
-                if (CACHED && i < I::O_W1F) use = false;                                        // W0 forward table unused
-                w[u] = 0.f;
-                if (use) w[u] = (m[u] & 0x40000000) ? v[m[u] & 0x3FFFFFFF] : theta[m[u]];
+            for (int s = 0; s < 4; ++s) {
+                const long long ns_ = n0 + 4 * s + q;
+#pragma unroll
+                for (int ci = 0; ci < NSI; ++ci) { const int f = 16 * ci + c; in.xTs[s][ci] = (tile < ntiles && ns_ < k.N && f < NS) ? k.obs[ns_ * NS + f] : 0.f; }
             }
-#pragma unroll
-            for (int u = 0; u < IMG_U; ++u) { const int i = i0 + u * NWAVES * 64 + tid; if (i < I::TOTAL) IMG[i] = w[u]; }
         }
-    }
+        in.vld = inr ? ((k.valid == nullptr) ? 1 : (int)k.valid[n]) : 0;
+        if (MODE != MODE_FVP) {
+            if (MODE == MODE_GRAD && k.gm != nullptr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) in.gmv[r] = (inr && 4 * q + r < NA) ? k.gm[n * NA + 4 * q + r] : 0.f;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int d = 4 * q + r;
+                    const bool on = inr && d < NA;
+                    in.ols[r] = on ? k.old_ls[(size_t)n * k.ls_stride + d] : 0.f;
+                    in.omu[r] = on ? k.old_mean[n * NA + d] : 0.f;
+                    in.act[r] = on ? k.act[n * NA + d] : 0.f;
+                }
+                in.adv = inr ? k.adv[n] : 0.f;
+            }
+        }
+        if (CACHED) {
+#pragma unroll
+            for (int j = 0; j < 2 * HB; ++j) in.h[j] = (tile < ntiles) ? hc[(tile * (2 * HB) + j) * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    TileIn nxt;
+
+    // per-lane biases / output-layer weights first: their loads are in flight while the image's map -> gather round trips run
     // fragment accessors (this lane's element)
 #define FRAG2(off, row, cb) IMG[(off) + ((row) * 64 + lane) * HB + (cb)]
 #define FRAG1(off, row) IMG[(off) + (row) * 64 + lane]
@@ -143,7 +183,36 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
 #pragma unroll
         for (int d = 0; d < NAV; ++d) { b2l[d] = theta[pb2 + d]; vb2l[d] = (MODE == MODE_FVP) ? v[pb2 + d] : 0.f; }
     }
+    // ---------------- weight fragment image -> LDS (each element written by exactly one thread) ----------------
+    // k.img_map[i] = source index of image element i in theta (bit 30 clear) or in v (bit 30 set), -1 = zero; built once on the
+    // host (pol_image_map).  Map loads, gathers and LDS stores are issued in independent batches of IMG_U per thread: the
+    // prologue costs ~2 L2 round trips instead of one dependent global load per element.
+    {
+        constexpr int IMG_U = 8;
+#pragma unroll
+        for (int i0 = 0; i0 < I::TOTAL; i0 += NWAVES * 64 * IMG_U) {
+            int m[IMG_U]; float w[IMG_U];
+#pragma unroll
+            for (int u = 0; u < IMG_U; ++u) { const int i = i0 + u * NWAVES * 64 + tid; m[u] = (i < I::TOTAL) ? k.img_map[i] : -1; }
+#pragma unroll
+            for (int u = 0; u < IMG_U; ++u) {
+                const int i = i0 + u * NWAVES * 64 + tid;
+                bool use = m[u] >= 0;
+                if (MODE != MODE_FVP && (m[u] & 0x40000000)) use = false;                       // tangent tables: FVP only
+                if (MODE == MODE_LOSSKL && i >= I::O_W2B && i < I::O_W2F) use = false;          // back-prop tables unused
+                if (CACHED && i < I::O_W1F) use = false;                                        // W0 forward table unused
+                w[u] = 0.f;
+                if (use) w[u] = (m[u] & 0x40000000) ? v[m[u] & 0x3FFFFFFF] : theta[m[u]];
+            }
+            // the first tile's loads go out behind the last batch of gathers (vmcnt retires in order: issued any earlier, their HBM round
+            // trip would hold up the map loads' return): they overlap the LDS stores, the barrier and the bias loads
+            if (i0 + NWAVES * 64 * IMG_U >= I::TOTAL) { asm volatile("" ::: "memory"); fetch((long long)blockIdx.x * NWAVES + wave, nxt); asm volatile("" ::: "memory"); }
+#pragma unroll
+            for (int u = 0; u < IMG_U; ++u) { const int i = i0 + u * NWAVES * 64 + tid; if (i < I::TOTAL) IMG[i] = w[u]; }
+        }
+    }
     __syncthreads();
+    PT_MARK(1)
 
     // ---------------- accumulators -------------------------------------------------------------------
     const f32x4 Z4 = {0.f, 0.f, 0.f, 0.f};
@@ -159,57 +228,19 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
     float dls[4] = {0.f, 0.f, 0.f, 0.f};
     float acc0 = 0.f, acc1 = 0.f, accw = 0.f;               // loss, kl, valid weight (per-lane partials)
 
-    const long long ntiles = (k.N + 15) / 16;
-    const f32x4* __restrict__ hc = (const f32x4*)k.hcache;
-    // Everything a tile reads from HBM (observations in both layouts, valid flag, cached activations, and for the loss modes the old
-    // distribution / action / advantage) is fetched ONE TILE AHEAD into registers: consumed in the iteration that issued them, the
-    // valid flag and the observation loads each put a full HBM round trip (~2000 cycles) on the wave's critical path, per tile.
-    struct TileIn {
-        float xB[NS_KS]; float xTs[4][NSI]; float ols[4], omu[4], act[4], adv; f32x4 gmv; int vld; f32x4 h[2 * HB];
-    };
-    auto fetch = [&](long long tile, TileIn& in) {
-        const long long n0 = tile * 16, n = n0 + c;
-        const bool inr = tile < ntiles && n < k.N;
-#pragma unroll
-        for (int s = 0; s < NS_KS; ++s) { const int f = 4 * s + q; in.xB[s] = (inr && f < NS) ? k.obs[n * NS + f] : 0.f; }
-        if (MODE != MODE_LOSSKL) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const long long ns_ = n0 + 4 * s + q;
-#pragma unroll
-                for (int ci = 0; ci < NSI; ++ci) { const int f = 16 * ci + c; in.xTs[s][ci] = (tile < ntiles && ns_ < k.N && f < NS) ? k.obs[ns_ * NS + f] : 0.f; }
-            }
-        }
-        in.vld = inr ? ((k.valid == nullptr) ? 1 : (int)k.valid[n]) : 0;
-        if (MODE != MODE_FVP) {
-            if (MODE == MODE_GRAD && k.gm != nullptr) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) in.gmv[r] = (inr && 4 * q + r < NA) ? k.gm[n * NA + 4 * q + r] : 0.f;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int d = 4 * q + r;
-                    const bool on = inr && d < NA;
-                    in.ols[r] = on ? k.old_ls[(size_t)n * k.ls_stride + d] : 0.f;
-                    in.omu[r] = on ? k.old_mean[n * NA + d] : 0.f;
-                    in.act[r] = on ? k.act[n * NA + d] : 0.f;
-                }
-                in.adv = inr ? k.adv[n] : 0.f;
-            }
-        }
-        if (CACHED) {
-#pragma unroll
-            for (int j = 0; j < 2 * HB; ++j) in.h[j] = (tile < ntiles) ? hc[(tile * (2 * HB) + j) * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    TileIn nxt;
-    fetch((long long)blockIdx.x * NWAVES + wave, nxt);
     // vmcnt(0) HERE: otherwise the wait for these first loads is placed inside the loop, at the top of every iteration, right
     // behind the prefetch of the next tile -- which it then waits for as well
     __builtin_amdgcn_s_waitcnt(0x0F70);
+    PT_MARK(2)
+#if POL_PRIO
+    int pol_it = 0;         // the two waves of a SIMD take turns at issue priority (oldest-first arbitration otherwise lets waves 0-3 finish ~20 % early)
+#endif
     for (long long tile = (long long)blockIdx.x * NWAVES + wave; tile < ntiles; tile += (long long)gridDim.x * NWAVES) {
         const long long n0 = tile * 16, n = n0 + c;
         const bool inr = n < k.N;
+#if POL_PRIO
+        if ((pol_it++ ^ (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
         const TileIn in = nxt;
         fetch(tile + (long long)gridDim.x * NWAVES, nxt);
         asm volatile("" ::: "memory");                      // the loads are issued HERE (left alone, the compiler sinks them to the end of the iteration)
@@ -453,10 +484,14 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
 #undef FRAG1
 
     // ---------------- epilogue: wave partial -> block partial (fixed order) -> global row -------------
+    PT_MARK(3)
     __syncthreads();
+    PT_MARK(4)
     float* RB = lds;                                        // [NWAVES][ROW] (weight image and transpose tiles are dead)
     float* row = RB + wave * ROW;
-    for (int i = lane; i < ROW; i += 64) row[i] = 0.f;
+    // every column of the row is written exactly once below, except the log_std columns outside the gradient mode (zero there); the
+    // loss / KL mode only produces the three scalar columns (and only those are summed and stored)
+    if (MODE != MODE_GRAD && lane < NA) row[pLS + lane] = 0.f;
     wave_sync_lds();
     if (MODE != MODE_LOSSKL) {
 #pragma unroll
@@ -500,13 +535,15 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
         if (lane == 0) { row[P] = a0; row[P + 1] = a1; row[P + 2] = aw; }
     }
     __syncthreads();
+    PT_MARK(5)
     float* out = partials + (size_t)blockIdx.x * ROW;
-    for (int i = tid; i < ROW; i += NWAVES * 64) {            // fixed pairwise order over the waves
+    for (int i = (MODE == MODE_LOSSKL ? P : 0) + tid; i < ROW; i += NWAVES * 64) {            // fixed pairwise order over the waves
         float a = 0.f;
 #pragma unroll
         for (int w = 0; w < NWAVES; w += 4) a += (RB[w * ROW + i] + RB[(w + 1) * ROW + i]) + (RB[(w + 2) * ROW + i] + RB[(w + 3) * ROW + i]);
         out[i] = a;
     }
+    PT_MARK(6)
 }
 
 

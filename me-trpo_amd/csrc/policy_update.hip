@@ -283,6 +283,8 @@ __global__ void __launch_bounds__(1024) k_finalize(ProblemDesc pd, int mode, int
     // s, s+NSL, ... and the slice sums are added in slice order: deterministic.  32 columns = one 128-byte line per row read.
     constexpr int NSL = 1024 / FIN_C;
     __shared__ double sh[NSL][FIN_C + 1];
+    CgPre pre;
+    cg_prefetch(tail, pre);                 // every block (nobody knows yet who arrives last); these vectors are not written by this launch
     const int P = pd.P;
     const int nout = (mode == 0) ? P + 1 : (mode == 1) ? P : 2;
     const int lc = threadIdx.x % FIN_C, sl = threadIdx.x / FIN_C;
@@ -331,7 +333,7 @@ __global__ void __launch_bounds__(1024) k_finalize(ProblemDesc pd, int mode, int
     }
     __syncthreads();
     if (!s_last) return;
-    cg_tail_run(tail, cgsh);
+    cg_tail_run(tail, cgsh, &pre);
     if (threadIdx.x == 0) __hip_atomic_store(tail.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
 }
 
