@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
     constexpr int TS = 20, TILE = 16 * TS;
     constexpr int WTL = (4 * HB + (NA <= 2 ? 0 : 1)) * TILE;   // per-wave transpose tiles: h0, h1, d1, d0 (HB each) and, with the output layer on the MFMA, u
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index in an SGPR: tile indices and base pointers stay scalar
     const int c = lane & 15, q = lane >> 4;
     float* IMG = lds;
     float* TL = lds + I::TOTAL + wave * WTL;
@@ -98,42 +98,65 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
     // distribution / action / advantage) is fetched ONE TILE AHEAD into registers: consumed in the iteration that issued them, the
     // valid flag and the observation loads each put a full HBM round trip (~2000 cycles) on the wave's critical path, per tile.
     struct TileIn {
-        float xB[NS_KS]; float xTs[4][NSI]; float ols[4], omu[4], act[4], adv; f32x4 gmv; int vld; f32x4 h[2 * HB];
+        float xB[NS_KS]; float xTs[4][NSI]; float ols[4], omu[4], act[4], adv; f32x4 gmv; int vld, nrem; f32x4 h[2 * HB];
     };
-    auto fetch = [&](long long tile, TileIn& in) {
-        const long long n0 = tile * 16, n = n0 + c;
-        const bool inr = tile < ntiles && n < k.N;
+    // `tile` is wave-uniform (SGPRs): scalar base pointers + 32-bit lane offsets, and every load is issued unconditionally on a clamped
+    // (always valid) address; what lies outside the batch or in the feature padding is zeroed when the tile is CONSUMED (mask_tile; a
+    // select at fetch time would wait for the load).  As written before (bounds-checked 64-bit per-lane addresses) the fetch was 17
+    // exec-masked branches and ~150 instructions per tile.
+    auto fetch = [&](long long tile_, TileIn& in) {
+        const long long tile = (tile_ < ntiles) ? tile_ : ntiles - 1;
+        const long long n0 = tile * 16;
+        const int nrem = (int)((k.N - n0 < 16) ? k.N - n0 : 16);            // samples of this tile that exist (>= 1)
+        in.nrem = nrem;
+        const int cl = (c < nrem) ? c : nrem - 1;
+        const float* __restrict__ ob = k.obs + n0 * NS;
 #pragma unroll
-        for (int s = 0; s < NS_KS; ++s) { const int f = 4 * s + q; in.xB[s] = (inr && f < NS) ? k.obs[n * NS + f] : 0.f; }
+        for (int s = 0; s < NS_KS; ++s) { const int f = 4 * s + q; in.xB[s] = ob[cl * NS + ((f < NS) ? f : NS - 1)]; }
         if (MODE != MODE_LOSSKL) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const long long ns_ = n0 + 4 * s + q;
+                const int sl = 4 * s + q, slc = (sl < nrem) ? sl : nrem - 1;
 #pragma unroll
-                for (int ci = 0; ci < NSI; ++ci) { const int f = 16 * ci + c; in.xTs[s][ci] = (tile < ntiles && ns_ < k.N && f < NS) ? k.obs[ns_ * NS + f] : 0.f; }
+                for (int ci = 0; ci < NSI; ++ci) { const int f = 16 * ci + c; in.xTs[s][ci] = ob[slc * NS + ((f < NS) ? f : NS - 1)]; }
             }
         }
-        in.vld = inr ? ((k.valid == nullptr) ? 1 : (int)k.valid[n]) : 0;
+        in.vld = (k.valid == nullptr) ? 1 : (int)k.valid[n0 + cl];
         if (MODE != MODE_FVP) {
+            const long long nl = n0 + cl;
             if (MODE == MODE_GRAD && k.gm != nullptr) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) in.gmv[r] = (inr && 4 * q + r < NA) ? k.gm[n * NA + 4 * q + r] : 0.f;
+                for (int r = 0; r < 4; ++r) { const int d = 4 * q + r; in.gmv[r] = k.gm[nl * NA + ((d < NA) ? d : NA - 1)]; }
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int d = 4 * q + r;
-                    const bool on = inr && d < NA;
-                    in.ols[r] = on ? k.old_ls[(size_t)n * k.ls_stride + d] : 0.f;
-                    in.omu[r] = on ? k.old_mean[n * NA + d] : 0.f;
-                    in.act[r] = on ? k.act[n * NA + d] : 0.f;
+                    const int d = 4 * q + r, dc = (d < NA) ? d : NA - 1;
+                    in.ols[r] = k.old_ls[(size_t)nl * k.ls_stride + dc]; in.omu[r] = k.old_mean[nl * NA + dc]; in.act[r] = k.act[nl * NA + dc];
                 }
-                in.adv = inr ? k.adv[n] : 0.f;
+                in.adv = k.adv[nl];
             }
         }
         if (CACHED) {
+            const f32x4* __restrict__ hb_ = hc + tile * (2 * HB) * 64;
 #pragma unroll
-            for (int j = 0; j < 2 * HB; ++j) in.h[j] = (tile < ntiles) ? hc[(tile * (2 * HB) + j) * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 2 * HB; ++j) in.h[j] = hb_[j * 64 + lane];
         }
+    };
+    auto mask_tile = [&](TileIn& in) {
+        // feature padding of the B-operand observations (k rows f >= NS meet zero weights, but 0 x garbage must stay 0)
+#pragma unroll
+        for (int s = 0; s < NS_KS; ++s) if (4 * s + 3 >= NS && 4 * s + q >= NS) in.xB[s] = 0.f;
+        if (in.nrem == 16) return;                          // wave-uniform: only the batch's last tile is partial
+        const bool inr = c < in.nrem;
+#pragma unroll
+        for (int s = 0; s < NS_KS; ++s) if (!inr) in.xB[s] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int ci = 0; ci < NSI; ++ci) if (4 * s + q >= in.nrem) in.xTs[s][ci] = 0.f;
+        if (!inr) { in.vld = 0; in.adv = 0.f; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (!inr) { in.ols[r] = 0.f; in.omu[r] = 0.f; in.act[r] = 0.f; in.gmv[r] = 0.f; }
     };
     TileIn nxt;
 
@@ -241,9 +264,10 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
 #if POL_PRIO
         if ((pol_it++ ^ (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
 #endif
-        const TileIn in = nxt;
+        TileIn in = nxt;
         fetch(tile + (long long)gridDim.x * NWAVES, nxt);
         asm volatile("" ::: "memory");                      // the loads are issued HERE (left alone, the compiler sinks them to the end of the iteration)
+        mask_tile(in);
         const bool ok = inr && in.vld != 0;
         // The tile is processed as a few long MFMA runs with the VALU work of the neighbouring stages placed textually inside them
         // (it issues in the matrix pipe's shadow), and every activation is dropped into its own wave-private transpose tile the
