@@ -15,6 +15,8 @@
 #include "device_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define PKFMA(a, b, c) __builtin_elementwise_fma((a), (b), (c))     // v_pk_fma_f32: both action dims of the VALU output layer per instruction
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define PART_EXTRA 3
 #ifndef POL_SKIP
@@ -190,7 +192,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
     // the weights of its 8 hidden units (D layout) for every action dim; partial sums are combined over the 4 q-lanes of a sample.
     constexpr bool L2V = (NA <= 2);
     constexpr int NAV = L2V ? NA : 1;
-    float w2l[HB][4][NAV], v2l[HB][4][NAV], gw2l[HB][4][NAV], b2l[NAV], vb2l[NAV];
+    float w2l[HB][4][NAV], v2l[HB][4][NAV], gw2l[HB][4][NAV], b2l[NAV], vb2l[NAV], fisher_d[NAV];   // fisher_d: fisher_w by action dim, in every lane
     if (L2V) {
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb)
@@ -204,7 +206,10 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
                     gw2l[cb][r][d] = 0.f;
                 }
 #pragma unroll
-        for (int d = 0; d < NAV; ++d) { b2l[d] = theta[pb2 + d]; vb2l[d] = (MODE == MODE_FVP) ? v[pb2 + d] : 0.f; }
+        for (int d = 0; d < NAV; ++d) {
+            b2l[d] = theta[pb2 + d]; vb2l[d] = (MODE == MODE_FVP) ? v[pb2 + d] : 0.f;
+            fisher_d[d] = 1.0f / (expf(2.f * fmaxf(theta[pLS + d], LOG_MIN_STD)) + 0.5f * KL_EPS);
+        }
     }
     // ---------------- weight fragment image -> LDS (each element written by exactly one thread) ----------------
     // k.img_map[i] = source index of image element i in theta (bit 30 clear) or in v (bit 30 set), -1 = zero; built once on the
@@ -344,6 +349,9 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
         }
 
         f32x4 um = Z4;                                      // d(objective)/d(mean) in D layout [d = 4q+r][sample c]
+        float ual[NAV];                                     // FVP with the VALU output layer: the sample's mean-adjoint, already in all of its lanes
+#pragma unroll
+        for (int d = 0; d < NAV; ++d) ual[d] = 0.f;
         if (MODE == MODE_GRAD && k.gm != nullptr) {         // VJP mode (bptt.hip): the mean-adjoint is an input
 #pragma unroll
             for (int r = 0; r < 4; ++r) um[r] = (ok && 4 * q + r < NA) ? in.gmv[r] : 0.f;
@@ -407,15 +415,31 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
                 for (int r = 0; r < 4; ++r) t1[cb][r] *= fmaf(-h1[cb][r], h1[cb][r], 1.f);
             if (L2V) {
                 m0 = Z4;
-#pragma unroll
-                for (int d = 0; d < NAV; ++d) {
-                    float a = 0.f;
+                float av[NAV];
+                if constexpr (NAV == 2) {
+                    f32x2 a2 = {0.f, 0.f};
 #pragma unroll
                     for (int cb = 0; cb < HB; ++cb)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) a = fmaf(w2l[cb][r][d], t1[cb][r], fmaf(v2l[cb][r][d], h1[cb][r], a));
-                    a = xsum_q(a) + vb2l[d];
+                        for (int r = 0; r < 4; ++r)
+                            a2 = PKFMA((f32x2{w2l[cb][r][0], w2l[cb][r][1]}), (f32x2{t1[cb][r], t1[cb][r]}),
+                                       PKFMA((f32x2{v2l[cb][r][0], v2l[cb][r][1]}), (f32x2{h1[cb][r], h1[cb][r]}), a2));
+                    av[0] = a2[0]; av[1] = a2[1];
+                } else {
+#pragma unroll
+                    for (int d = 0; d < NAV; ++d) {
+                        av[d] = 0.f;
+#pragma unroll
+                        for (int cb = 0; cb < HB; ++cb)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) av[d] = fmaf(w2l[cb][r][d], t1[cb][r], fmaf(v2l[cb][r][d], h1[cb][r], av[d]));
+                    }
+                }
+#pragma unroll
+                for (int d = 0; d < NAV; ++d) {
+                    const float a = xsum_q(av[d]) + vb2l[d];       // the butterfly leaves the same bits in all four q-lanes of the sample
                     if (q == 0) m0[d] = a;
+                    ual[d] = ok ? a * fisher_d[d] * k.inv_n : 0.f;   // = um[d] of the sample's q = 0 lane: no broadcast needed in S5
                 }
             } else {
 #pragma unroll
@@ -433,16 +457,22 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
         if (L2V) {
             float ua[NAV];                                  // the sample's mean-adjoint, broadcast from its q = 0 lane to all 4 lanes
 #pragma unroll
-            for (int d = 0; d < NAV; ++d) ua[d] = __shfl(um[d], c, 64);
+            for (int d = 0; d < NAV; ++d) ua[d] = (MODE == MODE_FVP) ? ual[d] : __shfl(um[d], c, 64);
 #pragma unroll
             for (int cb = 0; cb < HB; ++cb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                    for (int d = 0; d < NAV; ++d) {
-                        d1[cb][r] = fmaf(w2l[cb][r][d], ua[d], d1[cb][r]);
-                        gw2l[cb][r][d] = fmaf(h1[cb][r], ua[d], gw2l[cb][r][d]);      // weight gradient of the output layer, per lane
+                    for (int d = 0; d < NAV; ++d) d1[cb][r] = fmaf(w2l[cb][r][d], ua[d], d1[cb][r]);
+                    // weight gradient of the output layer, per lane
+                    if constexpr (NAV == 2) {
+                        const f32x2 g2 = PKFMA((f32x2{h1[cb][r], h1[cb][r]}), (f32x2{ua[0], ua[1]}), (f32x2{gw2l[cb][r][0], gw2l[cb][r][1]}));
+                        gw2l[cb][r][0] = g2[0]; gw2l[cb][r][1] = g2[1];
+                    } else {
+#pragma unroll
+                        for (int d = 0; d < NAV; ++d) gw2l[cb][r][d] = fmaf(h1[cb][r], ua[d], gw2l[cb][r][d]);
                     }
+                }
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) T_UM[(4 * q + r) * TS + wpos] = um[r];
