@@ -22,13 +22,18 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef POL_SKIP
 #define POL_SKIP 0              // developer experiments (tools/build_variant.sh): bit mask of tile stages to leave out; results are then meaningless
 #endif
-#ifndef POL_PRIO
-#define POL_PRIO 0
+#ifndef POL_SPLIT_R
+// The two waves that share a SIMD do not run at the same speed: the one launched first (waves 0-3 of the block) gets through its tiles ~17 %
+// faster (tools/pol_phases.py: 110k vs 129k cycles for 16 tiles each), and then idles while the other finishes alone.  The tiles of a SIMD's
+// pair are therefore dealt (R+1)/2 : (R-1)/2 in rounds of R (odd); a fixed assignment, so results stay bitwise reproducible.  R = 13 (7 : 6)
+// measured best of {9, 13, 17}: FVP 65.1 -> 63.5 us, gradient 75.1 -> 72.4 us at N = 500 000.  0 = equal shares.
+#define POL_SPLIT_R 13
 #endif
 #ifndef NWAVES
 #define NWAVES 8                // waves per block: one block per CU (2 waves per SIMD), the weight image is shared by all 8
 #endif
 constexpr int cdiv_(int a, int b) { return (a + b - 1) / b; }
+static_assert(POL_SPLIT_R == 0 || (NWAVES == 8 && (POL_SPLIT_R & 1) == 1 && POL_SPLIT_R >= 3), "the uneven deal pairs wave w with wave w + 4");
 // Developer instrumentation (SRC=policy_mfma.hip tools/build_variant.sh ptiming -DPOL_TIMING): s_memtime at the phase boundaries of the
 // cached-activation FVP kernel, waves of workgroup 0, read back with metrpo_debug_pol_phases (tools/pol_phases.py).  Not in the shipped library.
 #ifdef POL_TIMING
@@ -234,7 +239,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
             }
             // the first tile's loads go out behind the last batch of gathers (vmcnt retires in order: issued any earlier, their HBM round
             // trip would hold up the map loads' return): they overlap the LDS stores, the barrier and the bias loads
-            if (i0 + NWAVES * 64 * IMG_U >= I::TOTAL) { asm volatile("" ::: "memory"); fetch((long long)blockIdx.x * NWAVES + wave, nxt); asm volatile("" ::: "memory"); }
+            if (i0 + NWAVES * 64 * IMG_U >= I::TOTAL) { asm volatile("" ::: "memory"); fetch(POL_SPLIT_R ? (long long)blockIdx.x * 4 + (wave & 3) + ((wave < 4) ? 0 : 1) * (long long)gridDim.x * 4 : (long long)blockIdx.x * NWAVES + wave, nxt); asm volatile("" ::: "memory"); }
 #pragma unroll
             for (int u = 0; u < IMG_U; ++u) { const int i = i0 + u * NWAVES * 64 + tid; if (i < I::TOTAL) IMG[i] = w[u]; }
         }
@@ -260,17 +265,21 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
     // behind the prefetch of the next tile -- which it then waits for as well
     __builtin_amdgcn_s_waitcnt(0x0F70);
     PT_MARK(2)
-#if POL_PRIO
-    int pol_it = 0;         // the two waves of a SIMD take turns at issue priority (oldest-first arbitration otherwise lets waves 0-3 finish ~20 % early)
-#endif
+#if POL_SPLIT_R
+    const long long sp_base = (long long)blockIdx.x * 4 + (wave & 3), sp_stride = (long long)gridDim.x * 4;
+    auto sp_next = [&](long long m) { const int ph = (int)(m % POL_SPLIT_R); return (wave < 4) ? ((ph == POL_SPLIT_R - 1) ? m + 1 : m + 2) : ((ph == POL_SPLIT_R - 2) ? m + 3 : m + 2); };
+    for (long long m = (wave < 4) ? 0 : 1, tile = sp_base + m * sp_stride; tile < ntiles; m = sp_next(m), tile = sp_base + m * sp_stride) {
+#else
     for (long long tile = (long long)blockIdx.x * NWAVES + wave; tile < ntiles; tile += (long long)gridDim.x * NWAVES) {
+#endif
         const long long n0 = tile * 16, n = n0 + c;
         const bool inr = n < k.N;
-#if POL_PRIO
-        if ((pol_it++ ^ (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#endif
         TileIn in = nxt;
+#if POL_SPLIT_R
+        fetch(sp_base + sp_next(m) * sp_stride, nxt);
+#else
         fetch(tile + (long long)gridDim.x * NWAVES, nxt);
+#endif
         asm volatile("" ::: "memory");                      // the loads are issued HERE (left alone, the compiler sinks them to the end of the iteration)
         mask_tile(in);
         const bool ok = inr && in.vld != 0;
