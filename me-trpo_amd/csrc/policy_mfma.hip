@@ -101,6 +101,9 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
     PT_MARK(0)
     const long long ntiles = (k.N + 15) / 16;
     const f32x4* __restrict__ hc = (const f32x4*)k.hcache;
+    // a state-independent old log_std (stride 0: the reference's GaussianMLPPolicy) is one value per action dim for the whole batch: its loads
+    // and its two exponentials per sample leave the tile loop (the loss / KL kernel is VALU-bound: 340 instructions per tile, 39 transcendental)
+    const bool ols_const = (MODE != MODE_FVP) && k.ls_stride == 0 && k.old_ls != nullptr;
     // Everything a tile reads from HBM (observations in both layouts, valid flag, cached activations, and for the loss modes the old
     // distribution / action / advantage) is fetched ONE TILE AHEAD into registers: consumed in the iteration that issued them, the
     // valid flag and the observation loads each put a full HBM round trip (~2000 cycles) on the wave's critical path, per tile.
@@ -138,7 +141,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int d = 4 * q + r, dc = (d < NA) ? d : NA - 1;
-                    in.ols[r] = k.old_ls[(size_t)nl * k.ls_stride + dc]; in.omu[r] = k.old_mean[nl * NA + dc]; in.act[r] = k.act[nl * NA + dc];
+                    in.ols[r] = ols_const ? 0.f : k.old_ls[(size_t)nl * k.ls_stride + dc]; in.omu[r] = k.old_mean[nl * NA + dc]; in.act[r] = k.act[nl * NA + dc];
                 }
                 in.adv = k.adv[nl];
             }
@@ -184,6 +187,12 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
     float fisher_w[4];                                      // 1 / (std^2 + eps/2), hoisted out of the tile loop (exp + full-precision division per tile)
 #pragma unroll
     for (int r = 0; r < 4; ++r) fisher_w[r] = 1.0f / (expf(2.f * ls[r]) + 0.5f * KL_EPS);
+    float ols_c[4] = {0.f, 0.f, 0.f, 0.f}, eo_c[4] = {1.f, 1.f, 1.f, 1.f}, os2_c[4] = {1.f, 1.f, 1.f, 1.f};
+    if (ols_const) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * q + r < NA) { ols_c[r] = k.old_ls[4 * q + r]; eo_c[r] = expf(-ols_c[r]); os2_c[r] = expf(2.f * ols_c[r]); }
+    }
     f32x4 vb0f[HB], vb1f[HB], vb2f;
     if (MODE == MODE_FVP) {
 #pragma unroll
@@ -391,12 +400,20 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
             for (int r = 0; r < 4; ++r) {
                 const int d = 4 * q + r;
                 if (d < NA && ok) {
-                    const float ols = in.ols[r], omu = in.omu[r], a = in.act[r];
-                    const float z = (a - mu[r]) * inv_std[r], zo = (a - omu) * expf(-ols);
+                    const float omu = in.omu[r], a = in.act[r];
+                    float ols, eo, os2 = 0.f;
+                    if (ols_const) { ols = ols_c[r]; eo = eo_c[r]; os2 = os2_c[r]; }          // wave-uniform branch
+                    else {
+                        ols = in.ols[r];
+                        asm volatile("" : "+v"(ols));                                          // keeps the exponentials on this side of the branch
+                        eo = expf(-ols);
+                        if (MODE == MODE_LOSSKL) os2 = expf(2.f * ols);
+                    }
+                    const float z = (a - mu[r]) * inv_std[r], zo = (a - omu) * eo;
                     llr += (ols - ls[r]) + 0.5f * (zo * zo - z * z);
                     zz[r] = z;
                     if (MODE == MODE_LOSSKL) {
-                        const float s2 = expf(2.f * ls[r]), os2 = expf(2.f * ols), dm = omu - mu[r];
+                        const float s2 = expf(2.f * ls[r]), dm = omu - mu[r];
                         kl += (dm * dm + os2 - s2) / (2.f * s2 + KL_EPS) + ls[r] - ols;
                     }
                 }
