@@ -4,6 +4,9 @@
 // agent-scope release/acquire as in the guide's inter-workgroup recipe) runs the step itself and saves a launch.
 #pragma once
 #include "metrpo_internal.h"
+#ifndef CG_MARK
+#define CG_MARK(i)
+#endif
 
 enum { S_RDOTR = 0, S_DONE = 1, S_BETA = 2, S_XHX = 3, S_ITERS = 4, S_LOSS0 = 5 };   // S_LOSS0: surrogate loss at theta (copy of gout[0]: one read-back fetches scal | lk)
 
@@ -116,12 +119,15 @@ __device__ __forceinline__ void cg_step_body(int P, double reg, double tol, int 
                 zv[j] = z[i] + reg * pv[j]; acc += pv[j] * zv[j];
             }
         }
+        CG_MARK(5)
         const double pz = blk_sum(acc, sh);
+        CG_MARK(6)
         const double v = rdotr / pz;
         acc = 0.0;
 #pragma unroll
         for (int j = 0; j < CG_R; ++j) { xv[j] += v * pv[j]; rv[j] -= v * zv[j]; acc += rv[j] * rv[j]; }
         const double newrdotr = blk_sum(acc, sh);
+        CG_MARK(7)
         const double mu = newrdotr / rdotr;
 #pragma unroll
         for (int j = 0; j < CG_R; ++j) {

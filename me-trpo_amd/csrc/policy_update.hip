@@ -11,6 +11,10 @@
 // that lanes holding different units hit different LDS banks).  Each block accumulates into its own
 // row of a global partial buffer; k_finalize sums rows in block order -> bitwise reproducible.
 #include "device_common.h"
+#ifdef FIN_TIMING
+__device__ unsigned long long g_fin_phase[64][8];
+#define CG_MARK(i) { if (threadIdx.x == 0) g_fin_phase[blockIdx.x][i] = __builtin_readcyclecounter(); }
+#endif
 #include "cg_device.h"
 
 
@@ -276,6 +280,12 @@ __global__ void __launch_bounds__(PT) k_loss_kl(ProblemDesc pd, PolK k, const fl
 // mode 1: fvp  -> out[p] = Hv[p] for the mean net; log_std rows get c(s) * v_ls * weight (column P+2)
 // mode 2: loss/kl -> out[0], out[1] from columns (lk_col, lk_col+1)
 #define FIN_C 32
+#ifdef FIN_TIMING      // developer instrumentation (SRC=policy_update.hip tools/build_variant.sh ftiming -DFIN_TIMING; tools/fin_phases.py)
+#define FT_MARK(i) { if (threadIdx.x == 0 && tail.op == 1) g_fin_phase[blockIdx.x][i] = __builtin_readcyclecounter(); }
+extern "C" int32_t metrpo_debug_fin_phases(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fin_phase), sizeof(unsigned long long) * 512) == hipSuccess ? 0 : -1; }
+#else
+#define FT_MARK(i)
+#endif
 __global__ void __launch_bounds__(1024) k_finalize(ProblemDesc pd, int mode, int nrows, int stride, int lk_col,
                                                    const float* __restrict__ partials, const float* __restrict__ theta,
                                                    const double* __restrict__ v, double* __restrict__ out, CgTail tail) {
@@ -283,6 +293,7 @@ __global__ void __launch_bounds__(1024) k_finalize(ProblemDesc pd, int mode, int
     // s, s+NSL, ... and the slice sums are added in slice order: deterministic.  32 columns = one 128-byte line per row read.
     constexpr int NSL = 1024 / FIN_C;
     __shared__ double sh[NSL][FIN_C + 1];
+    FT_MARK(0)
     CgPre pre;
     cg_prefetch(tail, pre);                 // every block (nobody knows yet who arrives last); these vectors are not written by this launch
     const int P = pd.P;
@@ -304,6 +315,7 @@ __global__ void __launch_bounds__(1024) k_finalize(ProblemDesc pd, int mode, int
         }
         for (; b < nrows; b += NSL) a += (double)partials[(size_t)b * stride + col];
     }
+    FT_MARK(1)
     sh[sl][lc] = a;
     __syncthreads();
     if (sl == 0 && p < nout) {
@@ -322,8 +334,10 @@ __global__ void __launch_bounds__(1024) k_finalize(ProblemDesc pd, int mode, int
     // ---- fused CG tail: the last block to arrive owns the complete `out` vector and runs the vector step ----
     __shared__ unsigned int s_last;
     __shared__ double cgsh[16];
+    FT_MARK(2)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    FT_MARK(3)
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -332,6 +346,7 @@ __global__ void __launch_bounds__(1024) k_finalize(ProblemDesc pd, int mode, int
         if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
+    FT_MARK(4)
     if (!s_last) return;
     cg_tail_run(tail, cgsh, &pre);
     if (threadIdx.x == 0) __hip_atomic_store(tail.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
