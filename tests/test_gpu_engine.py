@@ -296,6 +296,29 @@ def test_loss_grad_fvp_losskl_parity(env, pol_hidden, N, use_mfma):
     assert abs(lk0[1]) < 1e-7 and abs(lk0[0] - loss) < 1e-6
 
 
+def test_policy_kernels_many_tiles_per_wave_and_both_log_std_forms():
+    """N large enough that every wave of the MFMA kernels walks through several rounds of its 7 : 6 tile deal (policy_mfma.hip POL_SPLIT_R) and
+    ends on a partial tile; gradient / FVP / loss-KL against the oracle, and the broadcast (stride 0, hoisted exponentials) and per-sample
+    forms of the old log_std bit for bit."""
+    N = 300007
+    eng, th, pdims, obs, act, adv, om, ols = _update_problem('swimmer', N)
+    assert eng.set_update_path(True)
+    rows, bcast = eng.make_batch(obs, act, adv, om, ols), eng.make_batch(obs, act, adv, om, ols[0])
+    out = eng.loss_grad(rows).clone()
+    assert torch.equal(out, eng.loss_grad(bcast))
+    loss, g = O.surrogate_loss_grad(th, pdims, obs, act, adv, om, ols)
+    out = cpu(out)
+    assert abs(out[0] - loss) <= 1e-5 * max(1.0, abs(loss)) and rel_l2(out[1:], g) <= 5e-5
+    v = np.random.RandomState(1).randn(eng.P)
+    assert rel_l2(cpu(eng.fvp(rows, v)), O.fisher_vector_product(th, pdims, obs, v, reg_coeff=0.0)) <= 1e-4
+    th2 = (th + np.random.RandomState(2).randn(th.size) * 0.02).astype(np.float32)
+    lk = eng.loss_kl(rows, th2).clone()
+    assert torch.equal(lk, eng.loss_kl(bcast, th2))
+    l2, k2 = O.surrogate_loss_kl(th2.astype(np.float64), pdims, obs, act, adv, om, ols)
+    lk = cpu(lk)
+    assert abs(lk[0] - l2) <= 1e-5 * max(1.0, abs(l2)) and abs(lk[1] - k2) <= max(1e-7, 1e-4 * k2)
+
+
 def test_update_is_bitwise_reproducible():
     eng, th, pdims, obs, act, adv, om, ols = _update_problem(N=4000)
     batch = eng.make_batch(obs, act, adv, om, ols)
