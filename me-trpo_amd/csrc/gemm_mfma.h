@@ -8,6 +8,9 @@
 #include "device_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef GEMM_XCD_SWIZZLE
+#define GEMM_XCD_SWIZZLE 1
+#endif
 
 enum { EPI_BIAS_ID = 0, EPI_BIAS_RELU = 1, EPI_BIAS_TANH = 2, EPI_RELU_MASK = 3, EPI_ADAM = 4, EPI_PLAIN = 5, EPI_PARTIAL = 6, EPI_DTANH = 7, EPI_RELU_OUT = 8, EPI_RELU_OUT64 = 9, EPI_RELU_OUT48 = 10 };   // fused skinny layer of <= 32 / <= 64 / <= 48 columns
 
@@ -33,21 +36,32 @@ template <int TM, int TN, int EPI, bool TA, bool TB, bool AL>
 __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, long long strideA, int lda,
                                                    const float* __restrict__ W, long long strideW, int ldw,
                                                    float* __restrict__ C, long long strideC, int ldc, int M, int N, int Kd, GemmEpi ep) {
-    constexpr int BM = 64 * TM, BN = 64 * TN, BK = 16;
+    constexpr int BM = 64 * TM, BN = 64 * TN, BK = 16;     // BK = 32 for the 64x64 tile (half the barriers, half the resident blocks): C3 step 0.204 -> 0.218 ms, not kept
     __shared__ __attribute__((aligned(16))) float As[2][BK][BM + 4];     // As[k][m]
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + 4];     // Bs[k][n]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    int head = blockIdx.z, kbeg = 0, kend = Kd;
+    // XCD-aware tile order: the dispatcher deals workgroups round-robin over the 8 XCDs (each with its own 4 MB L2), so in launch order the
+    // column blocks that share an A row panel land on 8 different L2s and every one of them fetches the panel from beyond L2.  Remapped, each
+    // XCD works through a CONTIGUOUS run of the logical tile order (column block fastest, then row block, then head): the panel is fetched
+    // once per XCD and the head's weights stay in that L2.  Bijective for any workgroup count; a placement hint only, never a correctness matter.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (GEMM_XCD_SWIZZLE) {
+        const unsigned gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * gridDim.z;
+        const unsigned L = bx + gx * (by + gy * bz), xcd = L & 7u, q8 = nwg >> 3, r8 = nwg & 7u;
+        const unsigned t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (L >> 3);
+        bx = (int)(t % gx); by = (int)((t / gx) % gy); bz = (int)(t / (gx * gy));
+    }
+    int head = bz, kbeg = 0, kend = Kd;
     if (EPI == EPI_PARTIAL) {
-        const int sp = blockIdx.z % ep.splits;
-        head = blockIdx.z / ep.splits;
+        const int sp = bz % ep.splits;
+        head = bz / ep.splits;
         kbeg = sp * ep.kchunk; kend = min(Kd, kbeg + ep.kchunk);
         C = ep.part + ((size_t)sp * (gridDim.z / ep.splits) + head) * ep.stridePart;
     } else {
         C += (size_t)head * strideC;
     }
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = by * BM, n0 = bx * BN;
     A += (size_t)head * strideA; W += (size_t)head * strideW;
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -129,7 +143,7 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
     };
 
     const int nk = (kend - kbeg + BK - 1) / BK;
-    const bool colsum = (EPI == EPI_PARTIAL && blockIdx.y == 0) || (EPI == EPI_ADAM && blockIdx.y == 0 && ep.bvec != nullptr);
+    const bool colsum = (EPI == EPI_PARTIAL && by == 0) || (EPI == EPI_ADAM && by == 0 && ep.bvec != nullptr);
     float csum = 0.0f;                                           // thread (tid % BN, tid / BN): column sum over its k slice
     constexpr int CS_S = 256 / BN, CS_K = BK / CS_S;             // k slices per tile, rows per slice
     load_tiles(kbeg);
@@ -232,7 +246,7 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
                 }
             }
         }
-        float* P = ep.part + ((size_t)blockIdx.x * gridDim.z + head) * ep.stridePart;
+        float* P = ep.part + ((size_t)bx * gridDim.z + head) * ep.stridePart;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
