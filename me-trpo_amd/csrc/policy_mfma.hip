@@ -3,7 +3,8 @@
 // product, loss + mean-KL.  Same arithmetic as policy_update.hip (algos/npo.py:68-75 graph; [rllab]
 // DiagonalGaussian / PerlmutterHvp), mapped to v_mfma_f32_16x16x4_f32 (exact f32 fmaf chains):
 //
-//   * a wave owns tiles of 16 samples and keeps ALL weight fragments in registers;
+//   * a wave owns tiles of 16 samples; weight fragments come from an LDS image the block builds once (the compiler keeps what fits in
+//     registers and re-reads the rest per tile);
 //   * forward, tangent-forward and back-prop run TRANSPOSED (H^T[unit][sample] = W^T X^T): the D
 //     fragment of one layer is the B operand of the next when the k-steps are enumerated (cb, r)
 //     (same trick as rollout_mfma.hip), so these chains never leave registers;
@@ -68,7 +69,7 @@ enum { MODE_GRAD = 0, MODE_FVP = 1, MODE_LOSSKL = 2, MODE_FVPC = 3 };
 // Cache layout per 16-sample tile: [h0 cb0 | h0 cb1 | .. | h1 cb0 | ..][64 lanes] float4 in the MFMA D layout -- each wave
 // instruction reads or writes 1 KB contiguously.
 
-// LDS weight image, shared by the 4 waves of a block (filled once per block).  Tables with a col-block index store the HB
+// LDS weight image, shared by the NWAVES waves of a block (filled once per block).  Tables with a col-block index store the HB
 // col-block fragments of one k-step adjacently per lane, so one ds_read_b64 (HB = 2) feeds both MFMAs of that k-step.
 template <int NS, int NA, int PH>
 struct PolImg {
