@@ -9,8 +9,9 @@
 //     fragment of one layer is the B operand of the next when the k-steps are enumerated (cb, r)
 //     (same trick as rollout_mfma.hip), so these chains never leave registers;
 //   * the weight gradients  G[i][j] = sum_n a[i][n] d[j][n]  contract over SAMPLES, i.e. over the lane
-//     index of the D fragments, so a and d take one 16x16 transpose through LDS (sample order permuted so that
-//     the contracting side reads 16 bytes at a time) and G accumulates in MFMA accumulators across all tiles of the wave;
+//     index of the D fragments, so h0, h1 and the layer-1 deltas take one 16x16 transpose through LDS (read back 16 bytes at a time), the
+//     layer-0 deltas are produced in that orientation directly (MFMA with swapped operands), and G accumulates in MFMA accumulators
+//     across all tiles of the wave;
 //   * waves -> block partial (LDS, fixed order) -> global partial row -> k_finalize (fixed order,
 //     float64): bitwise reproducible.
 #include "device_common.h"
@@ -89,11 +90,12 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
     constexpr int NS_KS = I::NS_KS, NSI = cdiv_(NS, 16), HB = I::HB, KK = I::KK;
     constexpr int pW0 = 0, pb0 = NS * PH, pW1 = pb0 + PH, pb1 = pW1 + PH * PH, pW2 = pb1 + PH, pb2 = pW2 + PH * NA,
                   pLS = pb2 + NA, P = pLS + NA, ROW = P + PART_EXTRA;
-    // transpose tile T[unit][sample position]: sample n sits at position 4 (n & 3) + (n >> 2), so the four samples 4s + q (s = 0..3) that lane
-    // q contracts in S7 are CONTIGUOUS: one ds_read_b128 per tile and array instead of four scalar reads (S7's LDS reads were 11 of an
-    // FVP's 70 us).  Row stride 20 floats keeps the 16-byte reads aligned (2-way bank conflicts on both sides).
+    // transpose tile T[unit][sample]: k-step s of S7 contracts, in lane (unit, q), sample 4q + s, so a lane's four samples are CONTIGUOUS:
+    // one ds_read_b128 per tile and array instead of four scalar reads (S7's LDS reads were 11 of an FVP's 70 us).  The same sample <-> k-step
+    // assignment is what an MFMA with swapped operands produces (S6), so the layer-0 deltas need no tile at all.  Row stride 20 floats keeps
+    // the 16-byte reads aligned (2-way bank conflicts on both sides).
     constexpr int TS = 20, TILE = 16 * TS;
-    constexpr int WTL = (4 * HB + (NA <= 2 ? 0 : 1)) * TILE;   // per-wave transpose tiles: h0, h1, d1, d0 (HB each) and, with the output layer on the MFMA, u
+    constexpr int WTL = (3 * HB + (NA <= 2 ? 0 : 1)) * TILE;   // per-wave transpose tiles: h0, h1, d1 (HB each) and, with the output layer on the MFMA, u
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index in an SGPR: tile indices and base pointers stay scalar
     const int c = lane & 15, q = lane >> 4;
@@ -127,7 +129,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
         if (MODE != MODE_LOSSKL) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const int sl = 4 * s + q, slc = (sl < nrem) ? sl : nrem - 1;
+                const int sl = 4 * q + s, slc = (sl < nrem) ? sl : nrem - 1;     // lane q holds samples 4q .. 4q+3 (k-step s of S7 covers samples 4q+s)
 #pragma unroll
                 for (int ci = 0; ci < NSI; ++ci) { const int f = 16 * ci + c; in.xTs[s][ci] = ob[slc * NS + ((f < NS) ? f : NS - 1)]; }
             }
@@ -164,7 +166,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int ci = 0; ci < NSI; ++ci) if (4 * s + q >= in.nrem) in.xTs[s][ci] = 0.f;
+            for (int ci = 0; ci < NSI; ++ci) if (4 * q + s >= in.nrem) in.xTs[s][ci] = 0.f;
         if (!inr) { in.vld = 0; in.adv = 0.f; }
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (!inr) { in.ols[r] = 0.f; in.omu[r] = 0.f; in.act[r] = 0.f; in.gmv[r] = 0.f; }
@@ -297,9 +299,9 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
         // (it issues in the matrix pipe's shadow), and every activation is dropped into its own wave-private transpose tile the
         // moment it exists, so the three sample-contracted weight-gradient products run as ONE run after a single LDS sync.
         const float (&xB)[NS_KS] = in.xB;
-        const float (&xTs)[4][NSI] = in.xTs;                // observations transposed ([feature 16ci + c][sample 4s + q]) for S7
-        const int wpos = 4 * (c & 3) + (c >> 2);            // this lane's sample in the permuted row order
-        float* T_H0 = TL, *T_H1 = TL + HB * TILE, *T_D1 = TL + 2 * HB * TILE, *T_D0 = TL + 3 * HB * TILE, *T_UM = TL + 4 * HB * TILE;
+        const float (&xTs)[4][NSI] = in.xTs;                // observations transposed ([feature 16ci + c][sample 4q + s]) for S7
+        const int wpos = c;                                 // T[unit][sample]: lane (unit, q) of S7 reads its samples 4q .. 4q+3 as one 16-byte word
+        float* T_H0 = TL, *T_H1 = TL + HB * TILE, *T_D1 = TL + 2 * HB * TILE, *T_UM = TL + 3 * HB * TILE;
         // ---- S1: layer 0, forward and (FVP) tangent  ------------------------------------------------------
         f32x4 h0[HB], h1[HB], t0[HB], t1[HB];
         if (CACHED) {
@@ -478,7 +480,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
             if (ok && q == 0) accw += k.inv_n;
         }
         // ---- S5/S6: back-prop (transposed chain); deltas go straight into their transpose tiles ---------------------
-        f32x4 d1[HB], d0[HB];
+        f32x4 d1[HB], d0n[HB];                              // d0n: layer-0 deltas in the OTHER orientation, [sample 4q+r][unit c] (see S6)
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb) d1[cb] = Z4;
         if (L2V) {
@@ -512,29 +514,34 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
         }
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb) {
-            d0[cb] = Z4;
+            d0n[cb] = Z4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { d1[cb][r] *= fmaf(-h1[cb][r], h1[cb][r], 1.f); T_D1[cb * TILE + (4 * q + r) * TS + wpos] = d1[cb][r]; }
         }
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-            for (int cb = 0; cb < HB; ++cb) { if (POL_SKIP & 4) d0[cb][2] += d1[kk >> 2][kk & 3]; else d0[cb] = MFMA16(FRAG2(I::O_W1B, kk, cb), d1[kk >> 2][kk & 3], d0[cb]); }
-#pragma unroll
-        for (int cb = 0; cb < HB; ++cb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { d0[cb][r] *= fmaf(-h0[cb][r], h0[cb][r], 1.f); T_D0[cb * TILE + (4 * q + r) * TS + wpos] = d0[cb][r]; }
+            for (int cb = 0; cb < HB; ++cb) { if (POL_SKIP & 4) d0n[cb][2] += d1[kk >> 2][kk & 3]; else d0n[cb] = MFMA16(d1[kk >> 2][kk & 3], FRAG2(I::O_W1B, kk, cb), d0n[cb]); }
+        // S6 with the operands SWAPPED (A = the delta fragment, B = the very weight fragment the transposed chain uses as A): the product comes
+        // out as D[sample 4q+r][unit c] -- units on the lane axis, which is what the sample-contracted products of S7 take as an operand.  The
+        // layer-0 deltas therefore never go through LDS; their tanh' factor comes from the h0 tile S7 reads anyway (same orientation).
         gb2 += um;
 #pragma unroll
-        for (int cb = 0; cb < HB; ++cb) { gb1[cb] += d1[cb]; gb0[cb] += d0[cb]; }
+        for (int cb = 0; cb < HB; ++cb) gb1[cb] += d1[cb];
         // ---- S7: weight gradients G[i][j] += sum_n a[i][n] d[j][n] as one MFMA run ------------------------------------
-        // D fragment [unit 16cb+4q+r][sample c] -> T[unit][sample]; k-step s of the MFMA covers samples 4s+q
+        // D fragment [unit 16cb+4q+r][sample c] -> T[unit][sample]; k-step s of the MFMA covers samples 4q+s
         wave_sync_lds();
-        f32x4 a1v[HB], a0v[HB], b1v[HB], b0v[HB], buv = Z4;
+        f32x4 a1v[HB], a0v[HB], b1v[HB], buv = Z4;
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb) {
             a1v[cb] = *(const f32x4*)&T_H1[cb * TILE + c * TS + 4 * q]; a0v[cb] = *(const f32x4*)&T_H0[cb * TILE + c * TS + 4 * q];
-            b1v[cb] = *(const f32x4*)&T_D1[cb * TILE + c * TS + 4 * q]; b0v[cb] = *(const f32x4*)&T_D0[cb * TILE + c * TS + 4 * q];
+            b1v[cb] = *(const f32x4*)&T_D1[cb * TILE + c * TS + 4 * q];
+        }
+#pragma unroll
+        for (int cb = 0; cb < HB; ++cb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d0n[cb][r] *= fmaf(-a0v[cb][r], a0v[cb][r], 1.f);
+            gb0[cb] += d0n[cb];
         }
         if (!L2V) buv = *(const f32x4*)&T_UM[c * TS + 4 * q];
 #pragma unroll
@@ -542,7 +549,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
             const float bu = buv[s];
             float a1_[HB], a0_[HB], b1_[HB], b0_[HB], xT[NSI];
 #pragma unroll
-            for (int cb = 0; cb < HB; ++cb) { a1_[cb] = a1v[cb][s]; a0_[cb] = a0v[cb][s]; b1_[cb] = b1v[cb][s]; b0_[cb] = b0v[cb][s]; }
+            for (int cb = 0; cb < HB; ++cb) { a1_[cb] = a1v[cb][s]; a0_[cb] = a0v[cb][s]; b1_[cb] = b1v[cb][s]; b0_[cb] = d0n[cb][s]; }
 #pragma unroll
             for (int ci = 0; ci < NSI; ++ci) xT[ci] = xTs[s][ci];
             if (POL_SKIP & 1) { gW1[0][0][0] += a0_[0] + b1_[0] + a1_[0] + b0_[0] + xT[0] + a0_[HB - 1] + b1_[HB - 1] + a1_[HB - 1] + b0_[HB - 1] + bu; continue; }
@@ -600,9 +607,16 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
             }
 #pragma unroll
             for (int cb = 0; cb < HB; ++cb) {
-                const float s0 = xsum_c(gb0[cb][r]), s1 = xsum_c(gb1[cb][r]);
+                const float s1 = xsum_c(gb1[cb][r]);
                 const int u = 16 * cb + 4 * q + r;
-                if (c == 0 && u < PH) { row[pb0 + u] = s0; row[pb1 + u] = s1; }
+                if (c == 0 && u < PH) row[pb1 + u] = s1;
+            }
+            if (r == 0) {                                   // layer-0 bias gradient: accumulated as [sample 4q+r][unit c] -> sum over r, then over the q-lanes
+#pragma unroll
+                for (int cb = 0; cb < HB; ++cb) {
+                    const float s0 = xsum_q((gb0[cb][0] + gb0[cb][1]) + (gb0[cb][2] + gb0[cb][3]));
+                    if (q == 0 && 16 * cb + c < PH) row[pb0 + 16 * cb + c] = s0;
+                }
             }
             const float s2 = xsum_c(gb2[r]), sl = xsum_c(dls[r]);
             if (c == 0 && 4 * q + r < NA) {
@@ -664,7 +678,7 @@ typedef void (*pol_kernel_t)(PolK, const float*, const float*, float*);
 struct PolEntry { int ns, na, ph; pol_kernel_t kern[4]; int lds_floats, lds_floats_eval; void (*build_map)(std::vector<int>&); };
 template <int NS, int NA, int PH> constexpr int pol_lds() {
     constexpr int HB = cdiv_(PH, 16);
-    constexpr int a = PolImg<NS, NA, PH>::TOTAL + NWAVES * (4 * HB + (NA <= 2 ? 0 : 1)) * 16 * 20;      // 20 = TS of the kernel's transpose tiles
+    constexpr int a = PolImg<NS, NA, PH>::TOTAL + NWAVES * (3 * HB + (NA <= 2 ? 0 : 1)) * 16 * 20;      // 20 = TS of the kernel's transpose tiles
     constexpr int P = NS * PH + PH + PH * PH + PH + PH * NA + NA + NA;
     constexpr int b = NWAVES * (P + PART_EXTRA);
     return a > b ? a : b;
