@@ -26,8 +26,12 @@ __global__ void k_baseline_predict(const float* __restrict__ obs, const int32_t*
         V[n] = baseline_value(obs + n * ns, ns, tpath[n], coeffs);
 }
 
-#define GAE_CHUNK 10
-#define GAE_NW 4          // wavefronts per 64-env tile = time chunks scanned concurrently
+#ifndef GAE_CHUNK
+#define GAE_CHUNK 7
+#endif
+#ifndef GAE_NW
+#define GAE_NW 8          // wavefronts per 64-env tile = time chunks scanned concurrently (4 x 10-step batches: 15.1 us at C1, 8 x 7: 12.9, 16 x 7: 15.6)
+#endif
 
 // One reverse pass over the steps [t_lo, t_hi) of env column b, starting from the carry (a_next, v_next, r_next, complete) of step t_hi:
 // the arithmetic of samplers/base.py:57-64 in float64.  WRITE = false only returns the carry at t_lo (chunk aggregate).
@@ -74,7 +78,7 @@ __device__ __forceinline__ void gae_chunk_pass(const double* __restrict__ V, con
 //   combine after one barrier every wave composes the aggregates of the later chunks (<= GAE_NW-1 fused multiply-adds per env);
 //   pass 2  every wave rescans its chunk from its true carry with exactly the float64 arithmetic of the sequential scan and writes
 //           adv / ret / valid (equal to a single sequential pass up to float64 rounding of the composed carry).
-// The dependent chain per env is 2*T/GAE_NW steps instead of T, and 4x as many waves are in flight.
+// The dependent chain per env is 2*T/GAE_NW steps instead of T, and GAE_NW times as many waves are in flight.
 __global__ void __launch_bounds__(64 * GAE_NW) k_gae(const double* __restrict__ V, const float* __restrict__ rew, const uint8_t* __restrict__ done,
                                                       int T, int B, double gamma, double lam, float* __restrict__ adv, float* __restrict__ ret,
                                                       uint8_t* __restrict__ valid, double* __restrict__ stats) {

@@ -15,7 +15,7 @@ try:
         if not db:
             print(name, 'no trace'); continue
         rows = sqlite3.connect(db[0]).execute("select name, count(*), avg(end-start) from kernels group by name order by sum(end-start) desc").fetchall()
-        pick = [(n, c, a) for n, c, a in rows if 'k_policy_mfma' in n or 'k_finalize' in n or 'k_rollout' in n]
+        pick = [(n, c, a) for n, c, a in rows if any(k in n for k in (os.environ.get('VK_KERNELS') or 'k_policy_mfma,k_finalize,k_rollout').split(','))]
         print('%-8s ' % name + '  '.join('%s x%d %.1f us' % (n.split('(')[0].replace('void ', '')[:34], c, a / 1e3) for n, c, a in pick), flush=True)
         shutil.rmtree(d, ignore_errors=True)
 finally:
