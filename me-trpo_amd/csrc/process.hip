@@ -10,9 +10,17 @@
 __device__ __forceinline__ double baseline_value(const float* __restrict__ obs_row, int ns, int tpath,
                                                  const double* __restrict__ coeffs) {
     double v = 0.0;
-    for (int i = 0; i < ns; ++i) {
-        const double o = fmin(fmax((double)obs_row[i], -10.0), 10.0);
-        v += coeffs[i] * o + coeffs[ns + i] * o * o;
+    for (int i0 = 0; i0 < ns; i0 += 8) {                 // 8 observation loads in flight, then the (ordered) float64 sum: the one-load-per-iteration
+        float ob[8];                                     // form of this loop was a chain of ns dependent HBM round trips per sample
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ob[u] = (i0 + u < ns) ? obs_row[i0 + u] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + u < ns) {
+                const double o = fmin(fmax((double)ob[u], -10.0), 10.0);
+                v += coeffs[i0 + u] * o + coeffs[ns + i0 + u] * o * o;
+            }
+        }
     }
     const double al = (double)tpath / 100.0;
     v += coeffs[2 * ns] * al + coeffs[2 * ns + 1] * al * al + coeffs[2 * ns + 2] * al * al * al + coeffs[2 * ns + 3];
