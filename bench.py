@@ -142,6 +142,13 @@ def main():
     upd_flops = (3 + 4 * n_hvp + n_ls) * f_pol * N_local
     upd_achieved = upd_flops / (upd_ms * 1e-3) / 1e12
     variant = eng.rollout_path()
+    upd_traffic, upd_traffic_src = None, None                   # HBM bytes per policy update (all of its launches), from the OFFLINE per-sample PMC figures
+    upath = os.path.join(REPO, 'profiles', 'r02_update_traffic.json')
+    if args.config in ('C0', 'C0p', 'C1') and eng.update_path(int(N_local)) == 'mfma' and os.path.exists(upath):
+        bps = json.load(open(upath)).get('hbm_bytes_per_sample', {})
+        if all(k in bps for k in ('fvp', 'grad', 'losskl')):
+            upd_traffic = float(N_local) * (n_hvp * bps['fvp'] + bps['grad'] + n_ls * bps['losskl'])
+            upd_traffic_src = 'profiles/r02_update_traffic.json (rocprofv3 --pmc bytes per sample of each kernel, offline, x this run\'s launch counts)'
     traffic, traffic_src = None, None                           # HBM bytes per rollout launch: rocprofv3 PMC, measured OFFLINE (profiles/)
     tpath = os.path.join(REPO, 'profiles', 'r02_rollout_traffic.json')
     if args.config == 'C1' and variant == 2 and os.path.exists(tpath):
@@ -165,7 +172,8 @@ def main():
                      "update": {"kernel": "policy update (1 gradient + %d Fisher-vector products + %d line-search evaluations, N=%d)"
                                           % (n_hvp, n_ls, int(N_local)),
                                 "path": eng.update_path(int(N_local)),
-                                "ms": upd_ms, "achieved": upd_achieved, "peak": PEAK_F32, "unit": "TFLOP/s", "frac": upd_achieved / PEAK_F32}},
+                                "ms": upd_ms, "achieved": upd_achieved, "peak": PEAK_F32, "unit": "TFLOP/s", "frac": upd_achieved / PEAK_F32,
+                                "traffic": upd_traffic, "traffic_source": upd_traffic_src}},
     }
     if comm.world > 1:                                          # latency of the exchanges of the path: P and 2 float64 values
         lat = {}
