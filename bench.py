@@ -89,7 +89,7 @@ def main():
     init = metrpo_amd.InitStatePool(synthetic.make_pool(env), na)
     nne = metrpo_amd.NeuralNetEnv(env=init, inner_env=None, cost_np=env, dynamics_in=None, dynamics_outs=eng,
                                   sam_mode='step_rand')
-    algo = metrpo_amd.TRPO(env=nne, policy=policy, baseline=baseline, batch_size=B * H, max_path_length=H,
+    algo = metrpo_amd.TRPO(env=nne, policy=policy, baseline=baseline, batch_size=cfg.get('batch_size', B * H), max_path_length=H,
                            discount=1.0, step_size=0.01, sampler_args=dict(n_envs=B), comm=comm, seed=0)
     rccl_in_ctx = False                       # N > 1 over RCCL: the ctx owns the communicator, all-reduces issued from C
     if comm.world > 1 and os.environ.get('METRPO_BENCH_NO_CTX_COMM', '0') != '1':

@@ -29,6 +29,7 @@ struct ProblemDesc {
     int P;                             // policy params incl. log_std
 };
 
+#define METRPO_MAX_PAR_ROUNDS 8
 struct metrpo_ctx {
     int device;
     metrpo_dims dims;
@@ -76,6 +77,7 @@ struct metrpo_ctx {
     size_t train_cap;
     void* d_big;         // workspace of the GEMM step-wise rollout (rollout_gemm.hip)
     size_t big_cap;
+    hipStream_t side_stream[METRPO_MAX_PAR_ROUNDS - 1]; hipEvent_t ev_fork, ev_join[METRPO_MAX_PAR_ROUNDS - 1]; int side_ready;   // rollout_gemm.hip: independent rounds of a small-batch rollout run concurrently
     double* h_pinned;    // pinned host scratch for the per-trial read-back
     int n_sm;            // CU count
     std::string err;

@@ -8,6 +8,7 @@
 //     k_big_post   lane per (env, dim): de-normalise + residual, sam_mode selection over the K heads, reward, done, reset
 // The weights are streamed from L2/HBM every step (K x 1-9 MB): the tile shape gives >= 128-fold reuse per fetched
 // weight, which keeps the kernel MFMA-bound (AI ~ 60 flop/B at B = 2500).
+#include <thread>
 #include "gemm_mfma.h"
 #include "mfma_common.h"
 
@@ -373,7 +374,8 @@ bool gemm_path_applicable(const metrpo_ctx* c) {
     return pd.dyn.n_layers >= 2 && minw >= 128;
 }
 
-int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t st) {
+// One chunk of the step loop on stream `st`.  ws == nullptr: only report the workspace size (bytes, 256-aligned) through *need_out.
+static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t st, char* ws, size_t* need_out) {
     const ProblemDesc& pd = c->pd;
     const int B = a->B, K = pd.K, L = pd.dyn.n_layers;
     int maxh = 0;
@@ -394,15 +396,11 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
     const char* pg_env = getenv("METRPO_PRE_GEMM");
     const bool pre_gemm = !pre_mfma && ((pg_env && pg_env[0] == '1') || (!(pg_env && pg_env[0] == '0') && B >= 1024));
     const size_t nPol = pre_gemm ? up4((size_t)B * pd.pol.max_width) : 0;
-    const size_t need = (nS + nX + nU + 2 * nH + nO + nP + 2 * nPol) * sizeof(float) + 2 * (size_t)B * sizeof(int) + 256;
-    if (need > c->big_cap) {
-        if (c->d_big) HIP_TRY(c, hipFree(c->d_big));
-        c->d_big = nullptr; c->big_cap = 0;
-        HIP_TRY(c, hipMalloc(&c->d_big, need));
-        c->big_cap = need;
-    }
+    const size_t need = ((nS + nX + nU + 2 * nH + nO + nP + 2 * nPol) * sizeof(float) + 2 * (size_t)B * sizeof(int) + 511) & ~(size_t)255;
+    if (need_out) *need_out = need;
+    if (ws == nullptr) return METRPO_OK;
     BigState bs = {};
-    float* p = (float*)c->d_big;
+    float* p = (float*)ws;
     bs.S = p; p += nS; bs.X = p; p += nX; bs.U = p; p += nU; bs.HA = p; p += nH; bs.HB = p; p += nH; bs.OUT = p; p += nO; bs.PART = nP ? p : nullptr; p += nP; bs.PA = p; p += nPol; bs.PB = p; p += nPol;
     bs.ts = (int*)p; bs.cur_model = bs.ts + B;
     bs.ldx = (pd.nin + 3) & ~3;
@@ -454,5 +452,96 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
         else hipLaunchKernelGGL(k_big_post<64>, dim3((B + 3) / 4), dim3(256), 0, st, pd, r, t, c->d_norm, bs);
     }
     HIP_TRY(c, hipGetLastError());
+    return METRPO_OK;
+}
+
+
+// Reset states of rounds 1 .. R-1 of a rollout whose envs only end at the horizon: what k_big_post's reset branch at step round * H - 1 produces
+// (pool row and next model from that step's draw, env_helpers.py:585-595), without running the steps before it.
+__global__ void k_round_init(ProblemDesc pd, RolloutK r, int R, float* __restrict__ init_obs, int32_t* __restrict__ init_ts, int32_t* __restrict__ init_model) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ns = pd.ns;
+    if (idx >= (long long)(R - 1) * r.B * ns) return;
+    const int i = (int)(idx % ns), b = (int)((idx / ns) % r.B), round = 1 + (int)(idx / ((long long)ns * r.B));
+    const uint4 dstep = rng_draw(r.seed, r.stream_offset + (uint64_t)b, r.t0 + round * r.H - 1, RNG_STEP, 0);
+    const int row = rng_index(dstep.w, r.n_pool);
+    const size_t o = (size_t)(round - 1) * r.B + b;
+    init_obs[o * ns + i] = r.pool[(size_t)row * ns + i];
+    if (i == 0) { init_ts[o] = 0; init_model[o] = rng_index16(dstep.z, pd.K); }
+}
+
+// Step-wise rollout of a large dynamics ensemble.  The R = T / H rounds of a horizon-terminated rollout that starts from a reset are
+// independent given the counter-based draws (every env is reset at the same steps, and its reset state is a function of that step's
+// draw alone), and at the reference's own batch size (B = 100: params-*.json) a round is a chain of ~3 us launches that leaves most of the
+// chip idle: the rounds then run CONCURRENTLY, one per stream, each as a continuation chunk (t0 = round * H) on its own workspace, and
+// produce bit for bit what the sequential loop does.
+int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t st) {
+    const ProblemDesc& pd = c->pd;
+    const int B = a->B, H = a->H;
+    const int R = (H > 0 && a->T % H == 0) ? a->T / H : 1;
+    const bool par = R >= 2 && R <= METRPO_MAX_PAR_ROUNDS && pd.env != METRPO_ENV_ANT && (long long)pd.K * B <= 8192 &&
+                     a->t0 == 0 && a->d_init_obs == nullptr && a->d_stop == nullptr && a->d_eps == nullptr && a->d_model_idx == nullptr &&
+                     a->d_sel_noise == nullptr && a->d_reset_idx == nullptr && a->d_reset_model == nullptr && getenv("METRPO_SEQ_ROUNDS") == nullptr;
+    size_t need1 = 0;
+    {
+        metrpo_rollout_args probe = *a;
+        if (par) probe.T = H;
+        const int rc = rollout_gemm_chunk(c, &probe, st, nullptr, &need1);
+        if (rc != METRPO_OK) return rc;
+    }
+    const size_t init_bytes = par ? (((size_t)(R - 1) * B * (pd.ns * sizeof(float) + 2 * sizeof(int32_t)) + 255) & ~(size_t)255) : 0;
+    const size_t need = (par ? (size_t)R * need1 : need1) + init_bytes;
+    if (need > c->big_cap) {
+        if (c->d_big) HIP_TRY(c, hipFree(c->d_big));
+        c->d_big = nullptr; c->big_cap = 0;
+        HIP_TRY(c, hipMalloc(&c->d_big, need));
+        c->big_cap = need;
+    }
+    if (!par) return rollout_gemm_chunk(c, a, st, (char*)c->d_big, nullptr);
+    if (!c->side_ready) {
+        for (int i = 0; i < METRPO_MAX_PAR_ROUNDS - 1; ++i) {
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->side_stream[i], hipStreamNonBlocking));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+        }
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        c->side_ready = 1;
+    }
+    char* base = (char*)c->d_big;
+    float* init_obs = (float*)(base + (size_t)R * need1);
+    int32_t* init_ts = (int32_t*)(init_obs + (size_t)(R - 1) * B * pd.ns);
+    int32_t* init_model = init_ts + (size_t)(R - 1) * B;
+    const RolloutK rk = make_rollout_k(a);
+    const long long n_init = (long long)(R - 1) * B * pd.ns;
+    hipLaunchKernelGGL(k_round_init, dim3((unsigned)((n_init + 255) / 256)), dim3(256), 0, st, pd, rk, R, init_obs, init_ts, init_model);
+    HIP_TRY(c, hipEventRecord(c->ev_fork, st));
+    // At these sizes the step loop is bound by the HOST's launch rate (~3 us per launch, 4 launches per step: the GPU is waiting), so every
+    // round is enqueued by its own host thread; round 0 by the caller's, on the caller's stream.
+    auto run_round = [&](int round) -> int {
+        metrpo_rollout_args ar = *a;
+        const size_t rows = (size_t)round * H * B;
+        ar.T = H; ar.t0 = round * H;
+        ar.d_obs = a->d_obs + rows * pd.ns; ar.d_act = a->d_act + rows * pd.na; ar.d_mean = a->d_mean + rows * pd.na;
+        ar.d_rew = a->d_rew + rows; ar.d_done = a->d_done + rows; ar.d_tpath = a->d_tpath + rows;
+        if (round != R - 1) { ar.d_last_obs = nullptr; ar.d_last_ts = nullptr; ar.d_last_model = nullptr; }
+        if (round > 0) {
+            ar.d_init_obs = init_obs + (size_t)(round - 1) * B * pd.ns; ar.d_init_ts = init_ts + (size_t)(round - 1) * B; ar.d_init_model = init_model + (size_t)(round - 1) * B;
+        }
+        hipStream_t rs = (round == 0) ? st : c->side_stream[round - 1];
+        if (round > 0) {
+            if (hipSetDevice(c->device) != hipSuccess) return METRPO_EHIP;                 // a fresh host thread has no current device
+            if (hipStreamWaitEvent(rs, c->ev_fork, 0) != hipSuccess) return METRPO_EHIP;
+        }
+        const int rc = rollout_gemm_chunk(c, &ar, rs, base + (size_t)round * need1, nullptr);
+        if (rc != METRPO_OK) return rc;
+        if (round > 0 && hipEventRecord(c->ev_join[round - 1], rs) != hipSuccess) return METRPO_EHIP;
+        return METRPO_OK;
+    };
+    int rcs[METRPO_MAX_PAR_ROUNDS] = {0};
+    std::thread workers[METRPO_MAX_PAR_ROUNDS - 1];
+    for (int round = 1; round < R; ++round) workers[round - 1] = std::thread([&, round] { rcs[round] = run_round(round); });
+    rcs[0] = run_round(0);
+    for (int round = 1; round < R; ++round) workers[round - 1].join();
+    for (int round = 0; round < R; ++round) if (rcs[round] != METRPO_OK) return (c->err.empty() ? set_err(c, rcs[round], "concurrent rollout round failed") : rcs[round]);
+    for (int round = 1; round < R; ++round) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join[round - 1], 0));
     return METRPO_OK;
 }

@@ -594,3 +594,20 @@ def test_gemm_rollout_random_shapes_vs_generic_kernel():
         np.testing.assert_allclose(cpu(got.mean), cpu(ref.mean), rtol=2e-3, atol=2e-3, err_msg=msg)
         np.testing.assert_allclose(cpu(got.obs), cpu(ref.obs), rtol=5e-3, atol=5e-3, err_msg=msg)
         np.testing.assert_allclose(cpu(got.rew), cpu(ref.rew), rtol=5e-3, atol=5e-3, err_msg=msg)
+
+
+@pytest.mark.parametrize('env,K,hidden,B,H,R,mode', [('swimmer', 5, (512, 512), 100, 6, 3, 'step_rand'), ('half_cheetah', 3, (256, 192), 77, 4, 5, 'eps_rand'),
+                                                      ('hopper', 2, (128, 128, 128), 50, 5, 2, 'model_mean_std'), ('swimmer', 5, (512, 512), 100, 3, 8, 'model_med')])
+def test_gemm_rollout_concurrent_rounds_equal_sequential_rounds(env, K, hidden, B, H, R, mode, monkeypatch):
+    """Small-batch rollouts of horizon-terminated envs run their T / H rounds concurrently (one stream per round, reset states of the later
+    rounds computed from the draws of the step before them, rollout_gemm.hip): bit for bit the sequential step loop, production draws."""
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, hidden, (32, 32), seed=77)
+    assert eng.set_rollout_variant(0) == 3
+    T = R * H
+    par = eng.rollout(B, T, H, mode, pool, seed=5)
+    par = [x.clone() for x in (par.obs, par.act, par.mean, par.rew, par.done, par.tpath, par.last_obs)]
+    monkeypatch.setenv('METRPO_SEQ_ROUNDS', '1')
+    seq = eng.rollout(B, T, H, mode, pool, seed=5)
+    for a, b in zip(par, (seq.obs, seq.act, seq.mean, seq.rew, seq.done, seq.tpath, seq.last_obs)):
+        assert torch.equal(a, b)
+    assert int(seq.done.sum()) == R * B and bool(seq.done[H - 1::H].all())
