@@ -11,7 +11,14 @@ runs the other BASELINE configs at their per-GPU share (B / gpus the config is q
 all K heads evaluated per env-step as the reference does (env_helpers.py:612).  B is per GPU (weak scaling); the only
 cross-rank traffic is the small sum all-reduces of parallel.py.
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched under torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process is one rank; invoked
+plainly, bench.py re-executes itself under `python -m torch.distributed.run --nproc-per-node N` on 127.0.0.1 and rank 0 prints the
+one JSON line.  The sum all-reduces of the path go through libmetrpo.so's one-shot direct all-reduce (peer-mapped receive regions
+over xGMI; comm.hip), RCCL from C if that is unavailable, torch.distributed as the last resort -- `allreduce_us.transport` says
+which.  On a box with fewer GPUs than ranks the ranks share the devices over gloo (`oversubscribed`: a functional run, not a
+scaling measurement).
 """
 import argparse
 import json
@@ -48,14 +55,49 @@ def cpu_baseline_block(env, K, dyn_hidden, pol_hidden, B, H):
     block = {"value": cb['units'] / cb['seconds'], "unit": "env-steps/s", "cores": 1, "kind": "port",
              "sample": "one full iteration (obtain_samples+process_samples+optimize_policy) at B=%d, H=%d (N=%d samples), float32 "
                        "NumPy, 1 thread; breakdown_s=%s" % (B, H, B * H, {k: round(v, 3) for k, v in cb['breakdown'].items()})}
-    ncpu = multiprocessing.cpu_count()
     try:
-        ca = cpu_baseline.run_iteration(env, K, dyn_hidden, pol_hidden, B=B, H=max(10, H // 4), seed=0)       # BLAS free to use every core
-        block["all_cores"] = {"value": ca['units'] / ca['seconds'], "unit": "env-steps/s", "cores": ncpu,
-                              "sample": "same iteration at H=%d with the BLAS thread pool unrestricted (%d hardware threads)" % (max(10, H // 4), ncpu)}
+        block["all_cores"] = cpu_all_cores_block(env, K, dyn_hidden, pol_hidden, B=B, H=max(10, H // 4))
     except Exception as e:
-        block["all_cores"] = {"value": None, "cores": ncpu, "sample": "failed: %r" % (e,)}
+        block["all_cores"] = {"value": None, "cores": multiprocessing.cpu_count(), "sample": "failed: %r" % (e,)}
     return block
+
+
+def cpu_all_cores_block(env, K, dyn_hidden, pol_hidden, B, H):
+    """All host cores the way the path itself shards: one single-threaded process per B-shard (no BLAS pool oversubscription),
+    all started together; throughput = total units / slowest shard.  The cross-shard sums of the update are NOT exchanged (each
+    shard optimises on its own samples), so this is an upper bound for a sharded CPU run."""
+    import multiprocessing
+    import subprocess
+    ncpu = multiprocessing.cpu_count()
+    nproc = max(1, min(ncpu // 2 if ncpu >= 4 else ncpu, B // 8))       # physical cores (SMT siblings share the FP pipes)
+    Bs = [B // nproc + (1 if i < B % nproc else 0) for i in range(nproc)]
+    env_ = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1', PYTHONPATH=REPO)
+    procs = [subprocess.Popen([sys.executable, '-m', 'oracle.cpu_baseline', env, str(K), ','.join(map(str, dyn_hidden)),
+                               ','.join(map(str, pol_hidden)), str(b), str(H), str(i)], stdout=subprocess.PIPE, env=env_, cwd=REPO)
+             for i, b in enumerate(Bs)]
+    secs, units = [], 0
+    for pr in procs:
+        out, _ = pr.communicate(timeout=600)
+        rec = json.loads(out.decode().strip().splitlines()[-1])
+        secs.append(rec['seconds']); units += rec['units']
+    return {"value": units / max(secs), "unit": "env-steps/s", "cores": nproc,
+            "sample": "%d single-threaded processes, each one full iteration on its B-shard (%d..%d envs, H=%d), started together; "
+                      "total units / slowest shard (%.2f s); %d hardware threads on the host" % (nproc, min(Bs), max(Bs), H, max(secs), ncpu)}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run ... bench.py <same flags>`."""
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')           # dmabuf IPC (RCCL and the one-shot transport both need it)
+    os.environ.setdefault('OMP_NUM_THREADS', '4')
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
 
 
 def main():
@@ -67,15 +109,22 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-H', type=int, default=100, help='horizon of the bounded CPU-baseline sample')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(args)
 
     import metrpo_amd
     from metrpo_amd import synthetic
     # test hooks (tests/test_gpu_api.py): METRPO_BENCH_BACKEND=gloo + METRPO_BENCH_DEVICE=0 run N ranks on ONE GPU so the
     # multi-rank control flow (collectives, barriers, max-over-ranks timing) is exercised on a 1-GPU box
-    comm = metrpo_amd.Comm.init_from_env(os.environ.get('METRPO_BENCH_BACKEND', 'nccl'))
-    assert comm.world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    dev = int(os.environ.get('METRPO_BENCH_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+    n_dev = torch.cuda.device_count()
+    oversub = args.gpus > n_dev                               # fewer devices than ranks: share them (RCCL refuses that; gloo + IPC works)
+    backend = os.environ.get('METRPO_BENCH_BACKEND', 'gloo' if oversub else 'nccl')
+    dev = int(os.environ.get('METRPO_BENCH_DEVICE', int(os.environ.get('LOCAL_RANK', '0')) % max(n_dev, 1)))
     torch.cuda.set_device(dev)
+    if backend == 'nccl':
+        os.environ['LOCAL_RANK'] = str(dev)
+    comm = metrpo_amd.Comm.init_from_env(backend)
+    assert comm.world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (comm.world, args.gpus)
 
     cfg = synthetic.CONFIGS[args.config]
     env, K, H = cfg['env'], cfg['K'], cfg['H']
@@ -91,20 +140,22 @@ def main():
                                   sam_mode='step_rand')
     algo = metrpo_amd.TRPO(env=nne, policy=policy, baseline=baseline, batch_size=cfg.get('batch_size', B * H), max_path_length=H,
                            discount=1.0, step_size=0.01, sampler_args=dict(n_envs=B), comm=comm, seed=0)
-    rccl_in_ctx = False                       # N > 1 over RCCL: the ctx owns the communicator, all-reduces issued from C
+    transport = False                         # N > 1: all-reduces issued from C (one-shot exchange over peer-mapped regions, else RCCL)
     if comm.world > 1 and os.environ.get('METRPO_BENCH_NO_CTX_COMM', '0') != '1':
         try:
-            rccl_in_ctx = bool(comm.attach_engine(eng))
+            transport = comm.attach_engine(eng)
         except Exception as e:                # never lose the multi-GPU line: fall back to torch.distributed through the host callback
-            sys.stderr.write('rank %d: ctx-owned RCCL communicator unavailable (%r); using the torch.distributed callback\n' % (comm.rank, e))
+            sys.stderr.write('rank %d: ctx-owned transport unavailable (%r); using the torch.distributed callback\n' % (comm.rank, e))
             comm.engine = None
     algo.defer_baseline_fit = True            # host solve of the 24x24 baseline system overlaps the next rollout
     algo.reuse_trajectory_buffers = True      # one set of [T,B,.] tensors, overwritten every iteration
 
-    ev_roll, ev_upd, steps_run, n_valid = [], [], [], []
+    ev_roll, ev_upd, ev_iter, steps_run, n_valid = [], [], [], [], []
 
     def step(j, timed):
         algo.rollout_events = ev_roll if timed else None      # HIP events recorded around the rollout launch(es) themselves
+        if timed:
+            ei = torch.cuda.Event(enable_timing=True); ei.record(); ev_iter.append(ei)
         algo.start_worker()
         paths = algo.obtain_samples(j)
         samples = algo.process_samples(j, paths)
@@ -122,11 +173,14 @@ def main():
     t0 = time.perf_counter()
     for j in range(args.steps):
         step(args.warmup + j, True)
+    ei = torch.cuda.Event(enable_timing=True); ei.record(); ev_iter.append(ei)
     comm.barrier(); torch.cuda.synchronize()
-    dt = comm.max_float(time.perf_counter() - t0, device='cuda')
+    dt = comm.max_float(time.perf_counter() - t0, device='cuda' if backend == 'nccl' else 'cpu')
+    side = 'cuda' if backend == 'nccl' else 'cpu'             # where the bench's own bookkeeping reductions live
+    iter_ms = [a.elapsed_time(b) for a, b in zip(ev_iter[:-1], ev_iter[1:])]        # per-iteration times on the stream (median of >= 20)
 
-    roll_ms = comm.max_float(float(np.mean([a.elapsed_time(b) for a, b in ev_roll])) if ev_roll else float('nan'), device='cuda')
-    upd_ms = comm.max_float(float(np.mean([a.elapsed_time(b) for a, b in ev_upd])), device='cuda')
+    roll_ms = comm.max_float(float(np.mean([a.elapsed_time(b) for a, b in ev_roll])) if ev_roll else float('nan'), device=side)
+    upd_ms = comm.max_float(float(np.mean([a.elapsed_time(b) for a, b in ev_upd])), device=side)
     T_mean = float(np.mean(steps_run))                          # env steps per rollout (= H except for early-terminating Ant)
     units_per_step = K * B * T_mean * comm.world
     ms_per_step = dt / args.steps * 1e3
@@ -141,26 +195,32 @@ def main():
     N_local = float(np.mean(n_valid)) / comm.world
     upd_flops = (3 + 4 * n_hvp + n_ls) * f_pol * N_local
     upd_achieved = upd_flops / (upd_ms * 1e-3) / 1e12
+    # the same update by the work the kernels EXECUTE: inside a CG solve the Fisher-vector products read the hidden activations the
+    # gradient kernel cached (policy_mfma.hip MODE_FVPC) and skip the forward pass: tangent + back-prop + weight gradient = 3 x forward
+    fvp_mult = 3 if eng.update_path(int(N_local)) == 'mfma' else 4
+    upd_exec = (3 + fvp_mult * n_hvp + n_ls) * f_pol * N_local / (upd_ms * 1e-3) / 1e12
     variant = eng.rollout_path()
     upd_traffic, upd_traffic_src = None, None                   # HBM bytes per policy update (all of its launches), from the OFFLINE per-sample PMC figures
-    upath = os.path.join(REPO, 'profiles', 'r02_update_traffic.json')
+    upath = next((q for q in (os.path.join(REPO, 'profiles', r + '_update_traffic.json') for r in ('r03', 'r02')) if os.path.exists(q)), '')
     if args.config in ('C0', 'C0p', 'C1') and eng.update_path(int(N_local)) == 'mfma' and os.path.exists(upath):
         bps = json.load(open(upath)).get('hbm_bytes_per_sample', {})
         if all(k in bps for k in ('fvp', 'grad', 'losskl')):
             upd_traffic = float(N_local) * (n_hvp * bps['fvp'] + bps['grad'] + n_ls * bps['losskl'])
-            upd_traffic_src = 'profiles/r02_update_traffic.json (rocprofv3 --pmc bytes per sample of each kernel, offline, x this run\'s launch counts)'
+            upd_traffic_src = 'profiles/' + os.path.basename(upath) + ' (rocprofv3 --pmc bytes per sample of each kernel, offline, x this run\'s launch counts)'
     traffic, traffic_src = None, None                           # HBM bytes per rollout launch: rocprofv3 PMC, measured OFFLINE (profiles/)
-    tpath = os.path.join(REPO, 'profiles', 'r02_rollout_traffic.json')
+    tpath = next((q for q in (os.path.join(REPO, 'profiles', r + '_rollout_traffic.json') for r in ('r03', 'r02')) if os.path.exists(q)), '')
     if args.config == 'C1' and variant == 2 and os.path.exists(tpath):
         traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
-        traffic_src = 'profiles/r02_rollout_traffic.json (rocprofv3 --pmc, offline run of the same launch)'
+        traffic_src = 'profiles/' + os.path.basename(tpath) + ' (rocprofv3 --pmc, offline run of the same launch)'
     out = {
         "metric": "imagined env-steps/sec (KxBxH) over the full TRPO iteration", "value": units_per_step / (dt / args.steps),
         "unit": "env-steps/s", "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "ms_per_step_median": comm.max_float(float(np.median(iter_ms)), device=side), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s rollout+GAE+TRPO: env=%s K=%d dyn=%s policy=%s B=%d/GPU (config B=%d on %d GPUs) H=%d sam_mode=step_rand "
-                               "all-K-heads-evaluated max_kl=0.01 cg_iters=10; env steps per rollout %.1f"
+                               "all-K-heads-evaluated max_kl=0.01 cg_iters=10; env steps per rollout %.1f; defer_baseline_fit=1 (the host solve of the baseline's "
+                               "normal equations overlaps the next rollout and lands before the next process_samples) reuse_trajectory_buffers=1 (one set of "
+                               "[T,B,.] tensors overwritten every iteration)"
                                % (args.config, env, K, list(cfg['dyn_hidden']), list(cfg['pol_hidden']), B, cfg['B'], cfg['gpus'], H, T_mean),
                    "parallelism": "B-sharded x%d, sum all-reduce of g/FVP/scalars" % comm.world},
         "trpo_iter_ms": ms_per_step,
@@ -172,12 +232,25 @@ def main():
                      "update": {"kernel": "policy update (1 gradient + %d Fisher-vector products + %d line-search evaluations, N=%d)"
                                           % (n_hvp, n_ls, int(N_local)),
                                 "path": eng.update_path(int(N_local)),
-                                "ms": upd_ms, "achieved": upd_achieved, "peak": PEAK_F32, "unit": "TFLOP/s", "frac": upd_achieved / PEAK_F32,
+                                "ms": upd_ms, "achieved": upd_exec, "peak": PEAK_F32, "unit": "TFLOP/s", "frac": upd_exec / PEAK_F32,
+                                "flop_count": "executed: gradient 3 x, Fisher-vector product %d x, evaluation 1 x the forward FLOPs per sample" % fvp_mult,
+                                "achieved_survey_8d": upd_achieved, "frac_survey_8d": upd_achieved / PEAK_F32,
                                 "traffic": upd_traffic, "traffic_source": upd_traffic_src}},
     }
-    if comm.world > 1:                                          # latency of the exchanges of the path: P and 2 float64 values
+    if comm.rank == 0:
+        try:                                                    # measured peaks of THIS device next to the nominal denominators
+            mf, hb = eng.probe_peaks()
+            out["roofline"]["measured_peaks"] = {"f32_mfma_tflops": mf, "hbm_copy_gbs": hb, "frac_of_measured": achieved / mf,
+                                                 "note": "register-resident v_mfma_f32_32x32x2_f32 issue loop / 1 GiB streaming copy (csrc/probe.hip); "
+                                                         "`frac` keeps the nominal peak (the stricter denominator)"}
+        except Exception as e:
+            out["roofline"]["measured_peaks"] = {"error": repr(e)}
+    out["n_devices"] = n_dev
+    if oversub:
+        out["oversubscribed"] = "%d ranks share %d device(s): functional run of the sharded path, not a scaling measurement" % (comm.world, n_dev)
+    if comm.world > 1:                                          # latency of the exchanges of the path: 1+P, P and 2 float64 values
         lat = {}
-        for n_el in (eng.P, 2):
+        for n_el in (eng.P + 1, eng.P, 2):
             buf = torch.zeros(n_el, dtype=torch.float64, device='cuda')
             for _ in range(10):
                 comm.allreduce_sum_(buf)
@@ -187,9 +260,11 @@ def main():
             for _ in range(100):
                 comm.allreduce_sum_(buf)
             e1.record(); torch.cuda.synchronize()
-            lat["%d_f64" % n_el] = comm.max_float(e0.elapsed_time(e1) * 10.0, device='cuda')     # us per all-reduce
-        out["allreduce_us"] = dict(lat, transport="rccl-in-ctx (ncclAllReduce issued by libmetrpo.so)" if rccl_in_ctx
-                                   else "torch.distributed %s via host callback" % os.environ.get('METRPO_BENCH_BACKEND', 'nccl'))
+            lat["%d_f64" % n_el] = comm.max_float(e0.elapsed_time(e1) * 10.0, device=side)     # us per all-reduce (stand-alone kernel; inside the update it rides in k_finalize)
+        out["allreduce_us"] = dict(lat, transport={'one-shot': "one-shot direct all-reduce over peer-mapped receive regions (libmetrpo.so, comm.hip)",
+                                                   'rccl': "rccl-in-ctx (ncclAllReduce issued by libmetrpo.so)"}.get(
+                                                       transport, "torch.distributed %s via host callback" % backend),
+                                   one_shot_error=getattr(comm, 'one_shot_error', None))
     if comm.rank == 0 and comm.world == 1 and not args.no_cpu_baseline:
         try:
             # bounded sample: ~10-30 s of 1-thread CPU work (about 0.4 TFLOP of dynamics forwards), same per-step structure

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define METRPO_ABI_VERSION 2
+#define METRPO_ABI_VERSION 3
 #define METRPO_MAX_LAYERS 6      /* hidden layers per MLP */
 
 typedef struct metrpo_ctx metrpo_ctx;
@@ -234,6 +234,27 @@ int32_t metrpo_comm_init(metrpo_ctx* ctx, const void* id /* METRPO_COMM_ID_BYTES
 int32_t metrpo_comm_destroy(metrpo_ctx* ctx);
 /* in-place sum over the ranks of the attached communicator, stream-ordered (advantage statistics, baseline normal equations) */
 int32_t metrpo_allreduce_sum_f64(metrpo_ctx* ctx, double* d_buf, int64_t count, void* stream);
+
+/* One-shot direct all-reduce (SURVEY.md 8e "collective choice on xGMI"): the exchanges above are latency-bound, and xGMI connects
+ * every pair of GPUs directly, so each rank writes its vector straight into a slot of every peer's receive region (device memory
+ * exported with hipIpcGetMemHandle and mapped by the peers) and adds the slots of its own region in rank order -- one fabric
+ * traversal, deterministic, bit-identical on every rank, no host in the loop.  Inside metrpo_trpo_update the exchange rides in the
+ * tail of the kernel that reduces the per-block partial rows, in front of the CG vector step.  Takes precedence over an RCCL
+ * communicator when both are attached.  World size <= 8 (one node); the ranks may also share one GPU (tests).
+ *   every rank: metrpo_comm_ipc_export(ctx, blob) -> all-gather the blobs by any side channel (Comm.attach_engine: torch.distributed)
+ *   every rank: metrpo_comm_ipc_attach(ctx, blobs[world], world, rank)
+ * A rank that never arrives makes the waiting kernels give up after METRPO_XCHG_TIMEOUT_MS (default 20 000) and the next
+ * metrpo_trpo_update / metrpo_comm_check returns METRPO_EHIP instead of hanging the GPU. */
+#define METRPO_COMM_IPC_BLOB_BYTES 128
+int32_t metrpo_comm_ipc_export(metrpo_ctx* ctx, void* blob_out /* METRPO_COMM_IPC_BLOB_BYTES */);
+int32_t metrpo_comm_ipc_attach(metrpo_ctx* ctx, const void* blobs /* world x METRPO_COMM_IPC_BLOB_BYTES */, int32_t world, int32_t rank);
+int32_t metrpo_comm_ipc_detach(metrpo_ctx* ctx);
+/* time limit of a waiting exchange kernel from now on (attach sets METRPO_XCHG_TIMEOUT_MS or 20 000) */
+int32_t metrpo_comm_set_timeout_ms(metrpo_ctx* ctx, int64_t ms);
+/* 0 = single rank, 1 = RCCL communicator, 2 = one-shot direct all-reduce */
+int32_t metrpo_comm_transport(const metrpo_ctx* ctx);
+/* synchronises `stream`; METRPO_EHIP if an exchange timed out since the transport was attached */
+int32_t metrpo_comm_check(metrpo_ctx* ctx, void* stream);
 
 /* all-reduce(sum) hook for sharded runs WITHOUT an attached communicator (e.g. a gloo group in the CPU-side tests; takes
  * precedence over the communicator when both are given): called on the host while enqueuing, must reduce `count`

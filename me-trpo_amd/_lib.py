@@ -78,6 +78,12 @@ SYMBOLS = {
     'metrpo_comm_init': (_I, [_P, _P, _I, _I]),
     'metrpo_comm_destroy': (_I, [_P]),
     'metrpo_allreduce_sum_f64': (_I, [_P, _P, _L, _P]),
+    'metrpo_comm_ipc_export': (_I, [_P, _P]),
+    'metrpo_comm_ipc_attach': (_I, [_P, _P, _I, _I]),
+    'metrpo_comm_ipc_detach': (_I, [_P]),
+    'metrpo_comm_set_timeout_ms': (_I, [_P, _L]),
+    'metrpo_comm_transport': (_I, [_P]),
+    'metrpo_comm_check': (_I, [_P, _P]),
     'metrpo_sampler_progress': (_I, [_P, _P, _P, _I, _I, _I, _L, _P, _P, _P, _P]),
     'metrpo_validation_cost': (_I, [_P, _P, _I, _I, _D, _P, _P]),
     'metrpo_gae': (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _D, _D, _P, _P, _P, _P, _P]),
@@ -106,6 +112,7 @@ EXTRA_SYMBOLS = {
     'metrpo_update_path': (_I, [_P, _L]),
     'metrpo_set_rollout_variant': (_I, [_P, _I]),
     'metrpo_set_det_path': (_I, [_P, _I]),
+    'metrpo_probe_peaks': (_I, [_P, _P, _P]),
 }
 
 
@@ -118,7 +125,7 @@ def load():
         for name, (res, args) in table.items():
             fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
             fn.restype, fn.argtypes = res, args
-    if lib.metrpo_abi_version() != 2:
+    if lib.metrpo_abi_version() != 3:
         raise ImportError("libmetrpo.so ABI version mismatch")
     return lib
 

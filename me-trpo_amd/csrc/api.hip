@@ -60,7 +60,7 @@ static CgView cg_view(metrpo_ctx* c) {
     const int P = c->pd.P;
     CgView v;
     v.gout = c->d_cg; v.x = v.gout + 1 + P; v.r = v.x + P; v.p = v.r + P; v.z = v.p + P; v.step = v.z + P;
-    v.scal = v.step + P; v.lk = v.scal + 8;
+    v.scal = v.step + P; v.lk = v.scal + 8;      // lk directly behind scal[8]: run_trpo_update reads scal | lk back as ONE 10-double copy
     return v;
 }
 
@@ -130,6 +130,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
         return METRPO_EHIP;
     }
     if (hipMemset(c->d_dyn, 0, sizeof(float) * (size_t)pd.K * pd.dyn.n_params) != hipSuccess) { c->err = "hipMemset failed"; return METRPO_EHIP; }
+    if (hipMemset(c->d_cg, 0, sizeof(double) * ncg) != hipSuccess) { c->err = "hipMemset failed"; return METRPO_EHIP; }   // scal[S_COMMERR] starts clear
     if (hipMemset(c->d_ticket, 0, sizeof(unsigned int)) != hipSuccess) { c->err = "hipMemset failed"; return METRPO_EHIP; }   // the reductions' arrival counter resets itself
     c->mfma_cfg = mfma_select_config(c);
     c->pol_mfma = policy_mfma_select(pd);
@@ -143,6 +144,8 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
 extern "C" int32_t metrpo_destroy(metrpo_ctx* c) {
     if (!c) return METRPO_ENULL;
     if (c->nccl_comm) (void)metrpo_comm_destroy(c);
+    (void)metrpo_comm_ipc_detach(c);
+    if (c->xg_region) (void)hipFree(c->xg_region);
     void* bufs[] = {c->d_dyn, c->d_norm, c->d_theta, c->d_vf, c->d_theta_try, c->d_cg, c->d_valbuf, c->d_partials,
                     c->d_dyn_img, c->d_pol_img, c->d_vbuf, c->d_gram_part, c->d_big, c->d_ticket, c->d_hcache, c->d_mig, c->d_pg, c->d_adam, c->d_train, c->d_bptt, c->d_pol_adam, c->d_detpart, c->d_dg};
     for (void* p : bufs) if (p) (void)hipFree(p);
@@ -452,15 +455,26 @@ int run_trpo_update(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_para
     // sum over ranks: the caller's callback if given, else the RCCL communicator attached to the ctx (comm.hip), else single rank
 #define AR(buf, n) do { if (pr->allreduce) { if ((rc = pr->allreduce(pr->allreduce_user, (buf), (n), (void*)st)) != 0) \
                                                  return set_err(c, METRPO_EINVAL, "allreduce callback failed"); } \
-                        else if (c->nccl_comm) { if ((rc = comm_allreduce_f64(c, (buf), (n), st)) != 0) return rc; } } while (0)
+                        else if (xg_fused) { /* summed in the tail of the reduction that produced buf */ } \
+                        else if (c->nccl_comm || xg) { if ((rc = comm_allreduce_f64(c, (buf), (n), st)) != 0) return rc; } } while (0)
     // krylov.cg with every vector step fused into the tail of the kernel that produced its input (no all-reduce in between) or
     // as stand-alone one-block kernels after the caller's all-reduce.  The step scale needs d.(H d): by default it is taken
     // from the CG recurrence (cg_device.h: A x = g - r), explicit_final_hvp = 1 spends the extra FVP rllab spends.
-    const bool fused = (pr->allreduce == nullptr && c->nccl_comm == nullptr);
+    // Sharded over a peer-mapped transport (comm.hip, one-shot exchange): the reductions of the update kernels add the ranks' shares in
+    // their own tail (xg_fuse), so the update keeps its single-rank launch sequence -- CG vector steps included.  The GEMM path
+    // (policy_gemm.hip) has its own reduction kernels: there the exchange is the stand-alone one-shot kernel between them and the CG step.
+    const bool xg = (pr->allreduce == nullptr && c->xg_world > 1);
+    const bool xg_fused = xg && !policy_gemm_applicable(c, b->N);
+    const bool fused = (pr->allreduce == nullptr && ((c->nccl_comm == nullptr && !xg) || xg_fused));
+    c->xg_fuse = xg_fused ? 1 : 0;
+    struct FuseOff { metrpo_ctx* c; ~FuseOff() { c->xg_fuse = 0; } } fuse_off{c};
     const int implicit_hd = pr->explicit_final_hvp ? 0 : 1;
     CgTail tl; tl.P = P; tl.last = 0; tl.implicit_hd = implicit_hd; tl.reg = pr->reg_coeff; tl.tol = pr->residual_tol; tl.max_kl = pr->max_kl;
     tl.x = v.x; tl.r = v.r; tl.p = v.p; tl.z = v.z; tl.step = v.step; tl.scal = v.scal; tl.gout = v.gout; tl.pf = c->d_vf; tl.ticket = c->d_ticket;
     tl.op = 3;
+    // the arrival counter of the fused tails resets itself, but a launch that failed half-way would leave it non-zero and silently
+    // disable every later tail: 4 bytes of memset per update are cheap insurance
+    HIP_TRY(c, hipMemsetAsync(c->d_ticket, 0, sizeof(unsigned int), st));
     c->hcache_on = 1;                    // the gradient kernel publishes tanh activations, the CG products of this solve reuse them
     struct CacheOff { metrpo_ctx* c; ~CacheOff() { c->hcache_on = 0; } } cache_off{c};
     if ((rc = launch_loss_grad(c, b, v.gout, st, fused ? &tl : nullptr))) return rc;
@@ -502,6 +516,7 @@ int run_trpo_update(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_para
         AR(v.lk, 2);
         HIP_TRY(c, hipMemcpyAsync(c->h_pinned, v.scal, sizeof(double) * 10, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
+        if (c->h_pinned[S_COMMERR] != 0.0) return set_err(c, METRPO_EHIP, "trpo_update: one-shot all-reduce timed out (a rank did not arrive)");
         if (first) { loss_before = c->h_pinned[S_LOSS0]; first = false; }
         loss = c->h_pinned[8]; kl = c->h_pinned[9];
         if (loss < loss_before && kl <= pr->max_kl) break;

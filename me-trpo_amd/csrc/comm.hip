@@ -6,6 +6,9 @@
 #include <dlfcn.h>
 #include <link.h>
 #include <cstring>
+#include <cstdlib>
+#include <algorithm>
+#include <unistd.h>
 #include <rccl/rccl.h>
 #include "metrpo_internal.h"
 
@@ -78,7 +81,152 @@ extern "C" int32_t metrpo_comm_destroy(metrpo_ctx* c) {
     return METRPO_OK;
 }
 
+// ---- one-shot direct all-reduce over peer-mapped receive regions (xchg_device.h) ---------------------------------------------
+// Bootstrap (any side channel carries the blobs; Comm.attach_engine uses a torch.distributed all_gather):
+//   every rank:  metrpo_comm_ipc_export(ctx, blob)          allocates + zeroes the local receive region, returns its IPC handle
+//   all-gather the blobs
+//   every rank:  metrpo_comm_ipc_attach(ctx, blobs, G, r)   maps the G-1 peer regions (hipIpcOpenMemHandle)
+// The ranks may sit on different GPUs of one node (stores cross xGMI) or share one GPU (what the 1-GPU test boxes can run).
+namespace {
+struct IpcBlob {                       // METRPO_COMM_IPC_BLOB_BYTES
+    hipIpcMemHandle_t handle;          // 64 bytes
+    int32_t device, cap, magic, pid;
+    char pad[METRPO_COMM_IPC_BLOB_BYTES - sizeof(hipIpcMemHandle_t) - 16];
+};
+static_assert(sizeof(IpcBlob) == METRPO_COMM_IPC_BLOB_BYTES, "blob size");
+constexpr int32_t IPC_MAGIC = 0x58474d49;          // "XGMI"
+constexpr int XG_CAP = 16384;                      // float64 elements per exchange: Humanoid's [F*F+F] = 13 110, P = 12 492
+
+size_t region_bytes(int cap) { return (size_t)2 * XCHG_MAX_WORLD * cap * 2 * sizeof(unsigned long long); }
+
+__global__ void k_xchg_allreduce(XchgK x, double* __restrict__ buf, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    xchg_push(x, i, buf[i]);
+    buf[i] = xchg_pull_sum(x, i);
+}
+}  // namespace
+
+XchgK xchg_next(metrpo_ctx* c) {
+    XchgK x = {};
+    if (c->xg_world <= 1) return x;
+    x.world = c->xg_world; x.rank = c->xg_rank; x.cap = c->xg_cap; x.seq = ++c->xg_seq;
+    if (x.seq == 0) x.seq = c->xg_seq = 2;          // wrapped after 2^32 exchanges: 0 is the stamp of untouched slots; keep the parity sequence (…, 0xffffffff (odd), 2 (even))
+    for (int q = 0; q < XCHG_MAX_WORLD; ++q) x.peer[q] = (unsigned long long*)c->xg_peer[q];
+    x.err = comm_err_cell(c); x.timeout_ticks = c->xg_timeout;
+    return x;
+}
+
+extern "C" int32_t metrpo_comm_ipc_export(metrpo_ctx* c, void* blob_out) {
+    if (!c) return METRPO_ENULL;
+    if (!blob_out) return set_err(c, METRPO_ENULL, "comm_ipc_export: blob is NULL");
+    if (c->xg_world > 0) return set_err(c, METRPO_ESTATE, "comm_ipc_export: a peer mapping is attached (metrpo_comm_ipc_detach first)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->xg_region) {
+        // fine-grained / uncached device memory: peer writes must become visible to polling loads without a kernel boundary
+        void* p = nullptr;
+        if (hipExtMallocWithFlags(&p, region_bytes(XG_CAP), hipDeviceMallocUncached) != hipSuccess) {
+            (void)hipGetLastError(); p = nullptr;
+            if (hipExtMallocWithFlags(&p, region_bytes(XG_CAP), hipDeviceMallocFinegrained) != hipSuccess) {
+                (void)hipGetLastError(); p = nullptr;
+                HIP_TRY(c, hipMalloc(&p, region_bytes(XG_CAP)));
+            }
+        }
+        c->xg_region = p; c->xg_cap = XG_CAP;
+    }
+    HIP_TRY(c, hipMemset(c->xg_region, 0, region_bytes(c->xg_cap)));
+    HIP_TRY(c, hipMemset(comm_err_cell(c), 0, sizeof(double)));
+    HIP_TRY(c, hipDeviceSynchronize());
+    IpcBlob b;
+    std::memset(&b, 0, sizeof(b));
+    HIP_TRY(c, hipIpcGetMemHandle(&b.handle, c->xg_region));
+    b.device = c->device; b.cap = c->xg_cap; b.magic = IPC_MAGIC; b.pid = (int32_t)getpid();
+    std::memcpy(blob_out, &b, sizeof(b));
+    return METRPO_OK;
+}
+
+extern "C" int32_t metrpo_comm_ipc_attach(metrpo_ctx* c, const void* blobs, int32_t world, int32_t rank) {
+    if (!c) return METRPO_ENULL;
+    if (!blobs) return set_err(c, METRPO_ENULL, "comm_ipc_attach: blobs is NULL");
+    if (world < 1 || world > XCHG_MAX_WORLD || rank < 0 || rank >= world) return set_err(c, METRPO_EINVAL, "comm_ipc_attach: bad world / rank (at most 8 ranks: one node)");
+    if (!c->xg_region) return set_err(c, METRPO_ESTATE, "comm_ipc_attach: call metrpo_comm_ipc_export first");
+    if (c->xg_world > 0) return set_err(c, METRPO_ESTATE, "comm_ipc_attach: already attached");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const IpcBlob* bl = static_cast<const IpcBlob*>(blobs);
+    for (int q = 0; q < world; ++q)
+        if (bl[q].magic != IPC_MAGIC || bl[q].cap != c->xg_cap) return set_err(c, METRPO_EINVAL, "comm_ipc_attach: malformed blob");
+    for (int q = 0; q < world; ++q)                   // hipIpcOpenMemHandle refuses handles of the calling process
+        if (q != rank && bl[q].pid == (int32_t)getpid()) return set_err(c, METRPO_EUNSUPPORTED, "comm_ipc_attach: two ranks in one process");
+    for (int q = 0; q < XCHG_MAX_WORLD; ++q) c->xg_peer[q] = nullptr;
+    for (int q = 0; q < world; ++q) {
+        if (q == rank) { c->xg_peer[q] = c->xg_region; continue; }
+        if (bl[q].device != c->device) {             // peer on another GPU of the node: direct access over xGMI
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, c->device, bl[q].device) == hipSuccess && can) {
+                const hipError_t e = hipDeviceEnablePeerAccess(bl[q].device, 0);
+                if (e != hipSuccess) (void)hipGetLastError();        // already enabled is fine; a real failure shows up in the open below
+            } else (void)hipGetLastError();
+        }
+        void* p = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&p, bl[q].handle, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            for (int j = 0; j < q; ++j) if (j != rank && c->xg_peer[j]) (void)hipIpcCloseMemHandle(c->xg_peer[j]);
+            for (int j = 0; j < XCHG_MAX_WORLD; ++j) c->xg_peer[j] = nullptr;
+            return set_err(c, METRPO_EHIP, std::string("hipIpcOpenMemHandle (rank ") + std::to_string(q) + "): " + hipGetErrorString(e));
+        }
+        c->xg_peer[q] = p;
+    }
+    c->xg_world = world; c->xg_rank = rank; c->xg_seq = 0; c->xg_fuse = 0;
+    long long ms = 20000;
+    if (const char* t = getenv("METRPO_XCHG_TIMEOUT_MS")) { const long long v = atoll(t); if (v > 0) ms = v; }
+    c->xg_timeout = (unsigned long long)ms * 100000ull;       // wall_clock64: 100 MHz
+    return METRPO_OK;
+}
+
+extern "C" int32_t metrpo_comm_ipc_detach(metrpo_ctx* c) {
+    if (!c) return METRPO_ENULL;
+    if (c->xg_world > 0) {
+        (void)hipSetDevice(c->device);
+        (void)hipDeviceSynchronize();
+        for (int q = 0; q < c->xg_world; ++q) if (q != c->xg_rank && c->xg_peer[q]) (void)hipIpcCloseMemHandle(c->xg_peer[q]);
+    }
+    for (int q = 0; q < XCHG_MAX_WORLD; ++q) c->xg_peer[q] = nullptr;
+    c->xg_world = 0; c->xg_rank = 0; c->xg_fuse = 0;
+    return METRPO_OK;
+}
+
+extern "C" int32_t metrpo_comm_set_timeout_ms(metrpo_ctx* c, int64_t ms) {
+    if (!c) return METRPO_ENULL;
+    if (ms <= 0) return set_err(c, METRPO_EINVAL, "comm_set_timeout_ms: must be positive");
+    c->xg_timeout = (unsigned long long)ms * 100000ull;
+    return METRPO_OK;
+}
+
+// 0 = single rank, 1 = RCCL communicator, 2 = one-shot direct all-reduce over peer-mapped regions
+extern "C" int32_t metrpo_comm_transport(const metrpo_ctx* c) {
+    if (!c) return METRPO_ENULL;
+    return c->xg_world > 1 ? 2 : (c->nccl_comm ? 1 : 0);
+}
+
+// synchronises `stream` and reports whether any exchange so far ran into its time limit (a rank that never arrived)
+extern "C" int32_t metrpo_comm_check(metrpo_ctx* c, void* stream) {
+    if (!c) return METRPO_ENULL;
+    HIP_TRY(c, hipMemcpyAsync(c->h_pinned + 15, comm_err_cell(c), sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(c, hipStreamSynchronize((hipStream_t)stream));
+    if (c->h_pinned[15] != 0.0) return set_err(c, METRPO_EHIP, "one-shot all-reduce: a rank did not arrive within the time limit (METRPO_XCHG_TIMEOUT_MS)");
+    return METRPO_OK;
+}
+
 int comm_allreduce_f64(metrpo_ctx* c, double* buf, long long count, hipStream_t st) {
+    if (c->xg_world > 1) {
+        for (long long off = 0; off < count; off += c->xg_cap) {           // vectors longer than a slot go in slot-sized pieces
+            const int n = (int)std::min<long long>(c->xg_cap, count - off);
+            hipLaunchKernelGGL(k_xchg_allreduce, dim3((n + 255) / 256), dim3(256), 0, st, xchg_next(c), buf + off, n);
+        }
+        HIP_TRY(c, hipGetLastError());
+        return METRPO_OK;
+    }
     if (!c->nccl_comm) return set_err(c, METRPO_ESTATE, "all-reduce: no communicator attached (metrpo_comm_init)");
     const ncclResult_t r = g_rccl.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, (ncclComm_t)c->nccl_comm, st);
     if (r != ncclSuccess) return set_err(c, METRPO_EHIP, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <string>
 #include "metrpo.h"
+#include "xchg_device.h"
 
 #define MAXL (METRPO_MAX_LAYERS + 1)   // weight layers per MLP (hidden + output)
 #define WAVE 64
@@ -69,6 +70,10 @@ struct metrpo_ctx {
     float* d_hcache; size_t hcache_cap; int hcache_on;   // activation cache of one CG solve (policy_mfma.hip MODE_FVPC)
     void* d_mig; int mig_cap, mig_epoch;            // rollout_coop.hip: hand-over slots of migrating tiles (flag | ts | model | obs per tile)
     void* nccl_comm; int comm_world, comm_rank;   // comm.hip: RCCL communicator attached by metrpo_comm_init (NULL: single rank)
+    // comm.hip: one-shot direct all-reduce (xchg_device.h).  xg_region = this rank's receive region (IPC-exported), xg_peer[q] = rank q's
+    // region as mapped here; xg_seq counts the exchanges issued so far (identical on every rank: SPMD); xg_fuse is raised by
+    // run_trpo_update while the reductions of the update kernels carry the exchange in their own tail
+    void* xg_region; void* xg_peer[XCHG_MAX_WORLD]; int xg_world, xg_rank, xg_cap, xg_fuse; unsigned int xg_seq; unsigned long long xg_timeout;
     int pol_path;        // 1 auto (fused MFMA kernels where the shape has them, GEMM path for large N otherwise), 0 generic forced, 2 GEMM path forced
     void* d_pg; size_t pg_cap; long long pg_fwd_rows; const float* pg_fwd_obs;   // policy_gemm.hip workspace + validity of its cached forward pass
     void* d_adam;        // Adam moments [2][K][Pd] + loss accumulators (dyn_train.hip)
@@ -169,6 +174,11 @@ int launch_gram(metrpo_ctx*, const float*, const float*, const int32_t*, const u
                 hipStream_t);
 int launch_loss_grad(metrpo_ctx*, const metrpo_batch*, double*, hipStream_t, const CgTail* tail = nullptr);
 int comm_allreduce_f64(metrpo_ctx*, double* buf, long long count, hipStream_t);
+// descriptor of the NEXT one-shot exchange (advances the sequence number); world = 0 when no peer-mapped transport is attached
+XchgK xchg_next(metrpo_ctx*);
+static inline XchgK xchg_none() { XchgK x = {}; return x; }
+// scal[S_COMMERR] of the CG workspace (gout[1+P] | x r p z step [5P] | scal[8] | lk[2]): sticky error cell of the exchanges
+static inline double* comm_err_cell(metrpo_ctx* c) { return c->d_cg + (size_t)(1 + c->pd.P) + 5 * (size_t)c->pd.P + 6; }
 bool policy_gemm_applicable(const metrpo_ctx*, long long N);
 int policy_gemm_run(metrpo_ctx*, int mode, const metrpo_batch*, const PolK&, const float* theta, const float* vf, const double* v64, double* out,
                     const CgTail* tail, hipStream_t);

@@ -288,7 +288,7 @@ extern "C" int32_t metrpo_debug_fin_phases(unsigned long long* out) { return hip
 #endif
 __global__ void __launch_bounds__(1024) k_finalize(ProblemDesc pd, int mode, int nrows, int stride, int lk_col,
                                                    const float* __restrict__ partials, const float* __restrict__ theta,
-                                                   const double* __restrict__ v, double* __restrict__ out, CgTail tail) {
+                                                   const double* __restrict__ v, double* __restrict__ out, CgTail tail, XchgK xc) {
     // block = FIN_C output columns x (1024 / FIN_C) row slices (latency-bound sum: many small blocks); slice s adds rows
     // s, s+NSL, ... and the slice sums are added in slice order: deterministic.  32 columns = one 128-byte line per row read.
     constexpr int NSL = 1024 / FIN_C;
@@ -329,9 +329,11 @@ __global__ void __launch_bounds__(1024) k_finalize(ProblemDesc pd, int mode, int
             t = (raw > (double)LOG_MIN_STD) ? c * v[p] * t : 0.0;
         }
         out[p] = t;
+        if (xc.world > 1) xchg_push(xc, p, t);                // sharded run: this rank's share goes straight into every rank's receive slot
     }
-    if (tail.op == 0) return;
-    // ---- fused CG tail: the last block to arrive owns the complete `out` vector and runs the vector step ----
+    if (tail.op == 0 && xc.world <= 1) return;
+    // ---- fused tail: the last block to arrive owns the complete `out` vector: it adds the ranks' shares (one-shot exchange,
+    //      xchg_device.h; the packets of the other blocks have been under way since they were produced) and runs the CG vector step ----
     __shared__ unsigned int s_last;
     __shared__ double cgsh[16];
     FT_MARK(2)
@@ -348,7 +350,11 @@ __global__ void __launch_bounds__(1024) k_finalize(ProblemDesc pd, int mode, int
     __syncthreads();
     FT_MARK(4)
     if (!s_last) return;
-    cg_tail_run(tail, cgsh, &pre);
+    if (xc.world > 1) {
+        for (int i = threadIdx.x; i < nout; i += blockDim.x) out[i] = xchg_pull_sum(xc, i);
+        __syncthreads();
+    }
+    if (tail.op != 0) cg_tail_run(tail, cgsh, &pre);
     if (threadIdx.x == 0) __hip_atomic_store(tail.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
 }
 
@@ -384,9 +390,11 @@ static int fill_polk(metrpo_ctx* c, const metrpo_batch* b, PolK* k, bool need_ta
 static void finalize(metrpo_ctx* c, int mode, int nrows, int stride, int lk_col, const double* v, double* out, hipStream_t st,
                      const CgTail* tail = nullptr) {
     const int nout = (mode == 0) ? c->pd.P + 1 : (mode == 1) ? c->pd.P : 2;
-    CgTail none; none.op = 0; none.ticket = nullptr;
+    CgTail none; none.op = 0; none.ticket = c->d_ticket;
+    // inside a fused update of a sharded run (run_trpo_update raises xg_fuse) the reduction carries the cross-rank sum in its tail
+    const XchgK xc = (c->xg_fuse && c->xg_world > 1) ? xchg_next(c) : xchg_none();
     hipLaunchKernelGGL(k_finalize, dim3((nout + FIN_C - 1) / FIN_C), dim3(1024), 0, st, c->pd, mode, nrows, stride, lk_col,
-                       c->d_partials, c->d_theta, v, out, tail ? *tail : none);
+                       c->d_partials, c->d_theta, v, out, tail ? *tail : none, xc);
 }
 
 // generic kernels: pick the largest sample tile (threads per block) whose LDS columns fit

@@ -1,0 +1,63 @@
+// Measured peaks for the roofline denominators (SURVEY.md 8d "measured peak"): a register-resident f32 MFMA issue loop and a
+// streaming copy, on the device the ctx lives on.  Diagnostics hook (not part of include/metrpo.h); bench.py prints the two numbers
+// beside the nominal ones of MI355X_MICROARCH.md -- `frac` keeps the nominal peak, the stricter denominator.
+#include "metrpo_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ void __launch_bounds__(256) k_probe_mfma(float* out, int iters) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) for (int i = 0; i < 16; ++i) acc[j][i] = 0.0f;
+    float a = 1.0f + threadIdx.x * 1e-6f, b = 1.0f - threadIdx.x * 1e-6f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+        }
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) for (int i = 0; i < 16; ++i) s += acc[j][i];
+    if (s == 12345.678f) out[0] = s;                 // keeps the chain alive, never true
+}
+
+__global__ void __launch_bounds__(256) k_probe_copy(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// out[0] = dense f32 MFMA TFLOP/s (v_mfma_f32_32x32x2_f32, 8 waves per CU, 4 independent accumulators per wave)
+// out[1] = HBM GB/s of a 1 GiB streaming copy (read + write bytes)
+extern "C" int32_t metrpo_probe_peaks(metrpo_ctx* c, double* out, void* stream) {
+    if (!c || !out) return METRPO_ENULL;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipEvent_t e0, e1;
+    HIP_TRY(c, hipEventCreate(&e0)); HIP_TRY(c, hipEventCreate(&e1));
+    float* d = nullptr;
+    const size_t bytes = (size_t)1 << 30;
+    HIP_TRY(c, hipMalloc(&d, 2 * bytes));
+    HIP_TRY(c, hipMemsetAsync(d, 0, 2 * bytes, st));
+    const int iters = 4096, blocks = c->n_sm * 2;
+    float ms = 0.0f;
+    hipLaunchKernelGGL(k_probe_mfma, dim3(blocks), dim3(256), 0, st, d, 64);       // warm-up
+    HIP_TRY(c, hipEventRecord(e0, st));
+    hipLaunchKernelGGL(k_probe_mfma, dim3(blocks), dim3(256), 0, st, d, iters);
+    HIP_TRY(c, hipEventRecord(e1, st));
+    HIP_TRY(c, hipEventSynchronize(e1));
+    HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
+    out[0] = (double)blocks * 4 /*waves*/ * iters * 16 /*MFMAs*/ * (2.0 * 32 * 32 * 2) / (ms * 1e-3) / 1e12;
+    const size_t n4 = bytes / sizeof(float4);
+    hipLaunchKernelGGL(k_probe_copy, dim3(c->n_sm * 8), dim3(256), 0, st, (const float4*)d, (float4*)((char*)d + bytes), n4);
+    HIP_TRY(c, hipEventRecord(e0, st));
+    for (int r = 0; r < 4; ++r)
+        hipLaunchKernelGGL(k_probe_copy, dim3(c->n_sm * 8), dim3(256), 0, st, (const float4*)d, (float4*)((char*)d + bytes), n4);
+    HIP_TRY(c, hipEventRecord(e1, st));
+    HIP_TRY(c, hipEventSynchronize(e1));
+    HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
+    out[1] = 4.0 * 2.0 * (double)bytes / (ms * 1e-3) / 1e9;
+    (void)hipFree(d); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    HIP_TRY(c, hipGetLastError());
+    return METRPO_OK;
+}

@@ -112,11 +112,50 @@ class Engine(object):
         self._chk(lib.metrpo_comm_destroy(self._ctx))
         self.comm_world = 0
 
+    # ---- one-shot direct all-reduce over peer-mapped receive regions (comm.hip / xchg_device.h)
+    IPC_BLOB_BYTES = 128
+
+    def comm_ipc_export(self):
+        """Allocate + zero this rank's receive region; -> 128 opaque bytes (IPC handle) to all-gather over the ranks."""
+        buf = C.create_string_buffer(self.IPC_BLOB_BYTES)
+        with torch.cuda.device(self.device):
+            self._chk(lib.metrpo_comm_ipc_export(self._ctx, buf))
+        return buf.raw
+
+    def comm_ipc_attach(self, blobs, world, rank):
+        """blobs: the ranks' export blobs concatenated in rank order.  Maps the peers' regions; from then on the sum all-reduces of the
+        path are one-shot exchanges issued by libmetrpo.so (inside metrpo_trpo_update: in the tail of the reduction kernels)."""
+        assert len(blobs) == self.IPC_BLOB_BYTES * int(world)
+        with torch.cuda.device(self.device):
+            self._chk(lib.metrpo_comm_ipc_attach(self._ctx, C.c_char_p(blobs), int(world), int(rank)))
+        self.comm_world = int(world)
+
+    def comm_ipc_detach(self):
+        self._chk(lib.metrpo_comm_ipc_detach(self._ctx))
+        if not lib.metrpo_comm_transport(self._ctx):
+            self.comm_world = 0
+
+    def comm_set_timeout_ms(self, ms):
+        self._chk(lib.metrpo_comm_set_timeout_ms(self._ctx, int(ms)))
+
+    def comm_transport(self):
+        return {0: None, 1: 'rccl', 2: 'one-shot'}[int(lib.metrpo_comm_transport(self._ctx))]
+
+    def comm_check(self):
+        """Synchronise and raise if an exchange timed out (a rank that never arrived)."""
+        self._chk(lib.metrpo_comm_check(self._ctx, self._stream()))
+
     def allreduce_sum_(self, t):
         """In-place sum of a float64 device tensor over the ranks of the attached communicator (stream-ordered)."""
         assert t.dtype == torch.float64 and t.is_cuda and t.is_contiguous()
         self._chk(lib.metrpo_allreduce_sum_f64(self._ctx, _ptr(t), t.numel(), self._stream()))
         return t
+
+    def probe_peaks(self):
+        """Measured (f32 MFMA TFLOP/s, HBM copy GB/s) of this device: register-resident MFMA issue loop, 1 GiB streaming copy."""
+        out = (C.c_double * 2)()
+        self._chk(lib.metrpo_probe_peaks(self._ctx, out, self._stream()))
+        return float(out[0]), float(out[1])
 
     def update_path(self, N):
         """Kernel family the policy update of an N-sample batch runs on: 'mfma' (fused), 'gemm' or 'generic'."""

@@ -31,18 +31,80 @@ class Comm(object):
             torch.distributed.init_process_group(backend=backend)
         return Comm()
 
-    def attach_engine(self, engine):
-        """Bootstrap an RCCL communicator INSIDE the engine's ctx (rank 0's unique id is broadcast through torch.distributed
-        once): from then on the float64 sum all-reduces of the path go through libmetrpo.so itself -- metrpo_trpo_update issues
-        them from C with no host callback in the CG loop, and allreduce_sum_ below uses the same communicator."""
-        if self.dist is None or self.dist.get_backend(self.group) != 'nccl':
-            return False                                     # gloo (CPU-side tests): keep the torch.distributed callback path
-        uid = torch.zeros(128, dtype=torch.uint8, device=engine.device)
-        if self.rank == 0:
-            uid.copy_(torch.frombuffer(bytearray(engine.comm_unique_id()), dtype=torch.uint8))
-        self.dist.broadcast(uid, src=0, group=self.group)
-        engine.comm_init(bytes(uid.cpu().numpy().tobytes()), self.world, self.rank)
-        self.engine = engine
+    def attach_engine(self, engine, transport=None):
+        """Move the float64 sum all-reduces of the path into libmetrpo.so (no Python and no host callback inside the CG loop).
+        transport (default: env METRPO_COMM, else 'auto'):
+          'one-shot'  peer-mapped receive regions, every rank writes its vector into every peer's slot and adds the slots in rank
+                      order (the exchanges are latency-bound, xGMI is point-to-point); works over any backend because
+                      only 128-byte IPC handles travel through torch.distributed;
+          'rccl'      an RCCL communicator owned by the ctx (ncclAllReduce issued from C); needs the nccl backend;
+          'auto'      one-shot, verified by a test exchange; RCCL if that is unavailable; else the torch.distributed callback.
+        Returns the transport in use ('one-shot', 'rccl') or False."""
+        if self.dist is None or self.world < 2:
+            return False
+        transport = transport or os.environ.get('METRPO_COMM', 'auto')
+        self.engine = None
+        if transport in ('auto', 'one-shot'):
+            if self._attach_one_shot(engine):
+                self.engine = engine
+                return 'one-shot'
+            if transport == 'one-shot':
+                raise RuntimeError('one-shot all-reduce transport unavailable')
+        if transport in ('auto', 'rccl') and self.dist.get_backend(self.group) == 'nccl':
+            uid = torch.zeros(128, dtype=torch.uint8, device=engine.device)
+            if self.rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(engine.comm_unique_id()), dtype=torch.uint8))
+            self.dist.broadcast(uid, src=0, group=self.group)
+            engine.comm_init(bytes(uid.cpu().numpy().tobytes()), self.world, self.rank)
+            self.engine = engine
+            return 'rccl'
+        return False                                         # gloo without IPC: keep the torch.distributed callback path
+
+    def _all_ok(self, ok, device):
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+        return bool(t.item())
+
+    def _attach_one_shot(self, engine):
+        """Collective.  Every step's outcome is agreed on by all ranks, so either everybody ends up attached or nobody does."""
+        side = engine.device if self.dist.get_backend(self.group) == 'nccl' else torch.device('cpu')
+        if self.world > 8:
+            return False
+        try:
+            blob, ok = engine.comm_ipc_export(), True
+        except Exception as e:                               # noqa: BLE001 -- any failure just means "use the next transport"
+            blob, ok, self.one_shot_error = bytes(engine.IPC_BLOB_BYTES), False, repr(e)
+        mine = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(side)
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine, group=self.group)
+        if not self._all_ok(ok, side):
+            return False
+        blobs = b''.join(bytes(p.cpu().numpy().tobytes()) for p in parts)
+        try:
+            engine.comm_ipc_attach(blobs, self.world, self.rank)
+        except Exception as e:                               # noqa: BLE001
+            ok, self.one_shot_error = False, repr(e)
+        if not self._all_ok(ok, side):
+            if ok:
+                engine.comm_ipc_detach()
+            return False
+        # test exchange with a short time limit: rank r contributes (r + 1) * [1, 2, ..., n]
+        n = engine.P + 1
+        try:
+            engine.comm_set_timeout_ms(3000)
+            ramp = torch.arange(1, n + 1, dtype=torch.float64, device=engine.device)
+            probe = ramp * (self.rank + 1)
+            self.dist.barrier(group=self.group)
+            engine.allreduce_sum_(probe)
+            engine.allreduce_sum_(probe)                     # both slot parities
+            engine.comm_check()
+            ok = bool(torch.equal(probe, ramp * (self.world * (self.world + 1) // 2) * self.world))
+            engine.comm_set_timeout_ms(int(os.environ.get('METRPO_XCHG_TIMEOUT_MS', '20000')))
+        except Exception as e:                               # noqa: BLE001
+            ok, self.one_shot_error = False, repr(e)
+        if not self._all_ok(ok, side):
+            engine.comm_ipc_detach()
+            return False
         return True
 
     def allreduce_sum_(self, t):

@@ -39,3 +39,12 @@ def run_iteration(env='swimmer', K=5, dyn_hidden=(64, 64), pol_hidden=(32, 32), 
                         f32(samples['agent_infos']['mean']), f32(samples['agent_infos']['log_std']))
     t['optimize_policy'] = time.perf_counter() - t0
     return dict(units=K * B * H, seconds=sum(t.values()), breakdown=t, accepted=bool(out['accepted']))
+
+
+if __name__ == '__main__':
+    # worker of bench.py's all-cores leg: python -m oracle.cpu_baseline env K dyn_hidden pol_hidden B H seed -> one JSON line
+    import json
+    import sys
+    env, K, dh, ph, B, H, seed = sys.argv[1:8]
+    r = run_iteration(env, int(K), tuple(int(x) for x in dh.split(',')), tuple(int(x) for x in ph.split(',')), B=int(B), H=int(H), seed=int(seed))
+    print(json.dumps({'units': r['units'], 'seconds': r['seconds']}))

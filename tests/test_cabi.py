@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(_lib.lib, n), "libmetrpo.so does not export %s" % n
         assert n in _lib.SYMBOLS, "%s is declared in metrpo.h but not bound in _lib.SYMBOLS" % n
     assert set(_lib.SYMBOLS) == set(names)
-    assert _lib.lib.metrpo_abi_version() == 2
+    assert _lib.lib.metrpo_abi_version() == 3
 
 
 def test_struct_layouts_match_header():

@@ -1,0 +1,117 @@
+"""One-shot direct all-reduce (comm.hip / xchg_device.h): G processes on ONE GPU map each other's receive regions
+through hipIpcGetMemHandle and run the sharded TRPO update with the exchange in the tail of the reduction kernels.  The reference has
+no counterpart (single process, utils.py:229-232); the contract is theta(G ranks x N/G samples) == theta(1 rank x N samples) within
+SURVEY 8d's tolerances, and bit-identical vectors on all ranks."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
+
+
+def _launch(world, out_file, path, port, extra_env=None, n_updates=1):
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'tests', '_multi_rank_oneshot.py'), out_file, path, str(n_updates)]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', **(extra_env or {}))
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+
+
+@pytest.mark.parametrize('path,world', [('mfma', 4), ('gemm', 4), ('generic', 2), ('mfma', 8)])
+def test_ranks_on_one_gpu_equal_one_rank(path, world, tmp_path):
+    from test_gpu_engine import _update_problem
+    out_file = str(tmp_path / 'ranks.npz')
+    res = _launch(world, out_file, path, 29531 + world)
+    assert res.returncode == 0, (res.stdout[-1500:] + res.stderr[-3000:])
+    many = np.load(out_file)
+    eng, th, pdims, obs, act, adv, om, ols = _update_problem(N=6000, seed=29)
+    eng.set_update_path({'mfma': True, 'generic': False, 'gemm': 'gemm'}[path])
+    one = eng.trpo_update(eng.make_batch(obs, act, adv, om, ols), want_vectors=True)
+    # float32 partial sums over different sample groupings: 1e-7-relative differences in g, amplified by 10 CG iterations in d
+    # (g rel-L2 1e-5, d rel-L2 1e-3)
+    np.testing.assert_allclose(many['g'], cpu(one['g']), rtol=0, atol=2e-6 * np.abs(cpu(one['g'])).max())
+    rel = np.linalg.norm(many['d'] - cpu(one['d'])) / np.linalg.norm(cpu(one['d']))
+    assert rel < 1e-3
+    assert abs(float(many['loss_before']) - one['loss_before']) < 1e-6
+    assert abs(float(many['beta']) - one['beta']) < 1e-3 * one['beta'] and int(many['n_backtrack']) == one['n_backtrack']
+    assert bool(many['accepted']) and one['accepted']
+    step = np.abs(cpu(eng.get_policy()) - th).max()
+    np.testing.assert_allclose(many['theta'], cpu(eng.get_policy()), rtol=0, atol=2e-3 * step + 1e-7)
+
+
+def test_missing_rank_times_out_instead_of_hanging():
+    """A rank whose peers never send must come back with METRPO_EHIP after the time limit -- not spin forever on the GPU.  One process,
+    two contexts: ctx A exports its region, ctx B's blob stands in for the absent peer (a region nobody writes to ... but hipIpcOpenMemHandle
+    refuses handles of the own process, so the attach itself must fail cleanly; the time-out is exercised by the 2-process variant below)."""
+    import torch
+    import metrpo_amd
+    from test_gpu_engine import _update_problem
+    eng = _update_problem(N=500, seed=3)[0]
+    blob = eng.comm_ipc_export()
+    with pytest.raises(metrpo_amd._lib.MetrpoError, match='two ranks in one process'):
+        eng.comm_ipc_attach(blob + blob, 2, 0)
+    assert eng.comm_transport() is None
+    # world size 1 attach is a no-op transport: updates stay on the single-rank path
+    eng.comm_ipc_attach(blob, 1, 0)
+    assert eng.comm_transport() is None
+    eng.comm_ipc_detach()
+    t = torch.ones(3, dtype=torch.float64, device='cuda')
+    with pytest.raises(metrpo_amd._lib.MetrpoError, match='no communicator'):
+        eng.allreduce_sum_(t)
+
+
+def test_absent_peer_reports_timeout(tmp_path):
+    """Two processes attach; rank 1 then leaves without ever exchanging.  Rank 0's exchange must give up after METRPO_XCHG_TIMEOUT_MS and
+    surface METRPO_EHIP through comm_check / trpo_update."""
+    script = tmp_path / 'absent.py'
+    script.write_text('''
+import os, sys, time
+import torch, torch.distributed as dist
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import metrpo_amd
+from test_gpu_engine import _update_problem
+dist.init_process_group("gloo"); rank = dist.get_rank(); torch.cuda.set_device(0)
+eng = _update_problem(N=500, seed=3)[0]
+comm = metrpo_amd.Comm()
+assert comm.attach_engine(eng, transport="one-shot") == "one-shot"
+eng.comm_set_timeout_ms(500)
+dist.barrier()
+if rank == 0:
+    t0 = time.time()
+    eng.allreduce_sum_(torch.ones(4, dtype=torch.float64, device="cuda"))
+    try:
+        eng.comm_check(); print("NO-ERROR")
+    except metrpo_amd._lib.MetrpoError as e:
+        print("TIMED-OUT %%.2f %%s" %% (time.time() - t0, e))
+dist.barrier()
+''' % (ROOT, ROOT))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29547', str(script)]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, MASTER_ADDR='127.0.0.1'), cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    assert 'TIMED-OUT' in res.stdout and 'did not arrive' in res.stdout, res.stdout[-2000:]
+
+
+def test_bench_self_launches_for_n_gpus():
+    """`python bench.py --gpus 4` the way the driver invokes `--gpus 1` (plain python, no launcher, no WORLD_SIZE): bench.py re-executes
+    itself under torch.distributed.run; on this 1-GPU box the 4 ranks share cuda:0 (gloo for the bookkeeping, the one-shot transport
+    for the path's all-reduces) and rank 0 prints ONE JSON line with n_gpus = 4."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--steps', '3', '--warmup', '1'],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 4 and rec['steps'] == 3 and rec['scaling'] == 'weak' and rec['value'] > 0
+    assert 'one-shot' in rec['allreduce_us']['transport'], rec['allreduce_us']
+    assert 'oversubscribed' in rec and 'cpu_baseline' not in rec
+    assert abs(rec['value'] - 4 * 5 * 5000 * 100 / (rec['ms_per_step'] * 1e-3)) / rec['value'] < 1e-9
