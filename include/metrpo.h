@@ -253,7 +253,8 @@ int32_t metrpo_comm_ipc_detach(metrpo_ctx* ctx);
 int32_t metrpo_comm_set_timeout_ms(metrpo_ctx* ctx, int64_t ms);
 /* 0 = single rank, 1 = RCCL communicator, 2 = one-shot direct all-reduce */
 int32_t metrpo_comm_transport(const metrpo_ctx* ctx);
-/* synchronises `stream`; METRPO_EHIP if an exchange timed out since the transport was attached */
+/* synchronises `stream`; METRPO_EHIP if an exchange timed out since the transport was attached, or if a tile hand-over of the
+ * cooperative rollout kernel gave up waiting (both are sticky device-side error cells, also checked by metrpo_trpo_update) */
 int32_t metrpo_comm_check(metrpo_ctx* ctx, void* stream);
 
 /* all-reduce(sum) hook for sharded runs WITHOUT an attached communicator (e.g. a gloo group in the CPU-side tests; takes

@@ -9,6 +9,7 @@ unchanged:
 from .optimizer import ConjugateGradientOptimizer
 from .parallel import Comm
 from .sampler import VectorizedSampler
+from .tracing import PhaseTimers
 
 
 class BatchPolopt(object):
@@ -26,7 +27,11 @@ class BatchPolopt(object):
         self.kwargs = kwargs
         self.engine = policy.engine
         self.comm = comm or Comm()
+        # Sharded runs: `batch_size` and the sampler's n_envs are PER RANK (the job collects world x batch_size samples; weak
+        # scaling).  The stop rule of early-terminating envs (sampler._obtain_until_enough) is applied by every rank to its own
+        # envs against this per-rank batch_size -- divide by comm.world beforehand for a fixed global batch.
         self.seed = seed
+        self.timers = PhaseTimers()          # rollout / process / policy_opt GPU times (tracing.py); off until .enable()
         assert not force_batch_sampler, "BatchSampler is unreachable on this path (batch_polopt.py:86-90)"
         if sampler_cls is None:
             assert self.policy.vectorized
@@ -43,10 +48,12 @@ class BatchPolopt(object):
         self.sampler.shutdown_worker()
 
     def obtain_samples(self, itr, determ=False, **kw):
-        return self.sampler.obtain_samples(itr, determ, **kw)
+        with self.timers.phase('rollout'):
+            return self.sampler.obtain_samples(itr, determ, **kw)
 
     def process_samples(self, itr, paths):
-        return self.sampler.process_samples(itr, paths)
+        with self.timers.phase('process'):
+            return self.sampler.process_samples(itr, paths)
 
     def init_opt(self):
         raise NotImplementedError
@@ -78,7 +85,8 @@ class NPO(BatchPolopt):
         batch = self.engine.make_batch(samples_data["observations"], samples_data["actions"], samples_data["advantages"],
                                        agent_infos["mean"], agent_infos["log_std"], valid=samples_data.get("valids"),
                                        n_global=samples_data.get("n_valid_global"))
-        self.optimizer.optimize(self.engine, batch, comm=self.comm)
+        with self.timers.phase('policy_opt'):
+            self.optimizer.optimize(self.engine, batch, comm=self.comm)
         if hasattr(self.sampler, 'finish_baseline_fit') and not getattr(self, 'defer_baseline_fit', False):
             self.sampler.finish_baseline_fit()
         return dict()

@@ -2,13 +2,17 @@
 // dispatch to the kernels, and the host driver of one TRPO update.
 #include "metrpo_internal.h"
 #include "cg_device.h"
+#include "trace.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <new>
 
+// serialised: the concurrent rounds of rollout_gemm.hip enqueue from several host threads and may fail together
+static std::mutex g_err_mutex;
 int set_err(metrpo_ctx* c, int code, const std::string& msg) {
-    if (c) c->err = msg;
+    if (c) { std::lock_guard<std::mutex> lock(g_err_mutex); c->err = msg; }
     return code;
 }
 
@@ -229,6 +233,7 @@ extern "C" int32_t metrpo_step(metrpo_ctx* c, const float* s, const float* a, in
 }
 
 extern "C" int32_t metrpo_rollout(metrpo_ctx* c, const metrpo_rollout_args* a, void* stream) {
+    TraceRange trace_("metrpo:rollout (obtain_samples: policy + env)");
     if (!c) return METRPO_ENULL;
     if (!a) return set_err(c, METRPO_ENULL, "rollout: args NULL");
     NEED_DYN(c); NEED_POL(c);
@@ -293,6 +298,7 @@ extern "C" int32_t metrpo_set_update_path(metrpo_ctx* c, int32_t use_mfma) {
 
 extern "C" int32_t metrpo_validation_cost(metrpo_ctx* c, const float* s0, int32_t Bv, int32_t T, double gamma,
                                           double* costs, void* stream) {
+    TraceRange trace_("metrpo:validation_cost");
     if (!c) return METRPO_ENULL;
     NEED_DYN(c); NEED_POL(c);
     if (!s0 || !costs) return set_err(c, METRPO_ENULL, "validation_cost: NULL pointer");
@@ -303,6 +309,7 @@ extern "C" int32_t metrpo_validation_cost(metrpo_ctx* c, const float* s0, int32_
 extern "C" int32_t metrpo_gae(metrpo_ctx* c, const float* obs, const float* rew, const uint8_t* done,
                               const int32_t* tpath, int32_t T, int32_t B, const double* coeffs, double gamma, double lam,
                               float* adv, float* ret, uint8_t* valid, double* stats, void* stream) {
+    TraceRange trace_("metrpo:process_samples:gae");
     if (!c) return METRPO_ENULL;
     if (!obs || !rew || !done || !tpath || !adv || !ret || !valid || !stats) return set_err(c, METRPO_ENULL, "gae: NULL pointer");
     if (T < 0 || B < 0) return set_err(c, METRPO_EINVAL, "gae: bad T/B");
@@ -312,6 +319,7 @@ extern "C" int32_t metrpo_gae(metrpo_ctx* c, const float* obs, const float* rew,
 
 extern "C" int32_t metrpo_center_advantages(metrpo_ctx* c, float* adv, const uint8_t* valid, int64_t N,
                                             const double* stats, void* stream) {
+    TraceRange trace_("metrpo:process_samples:center");
     if (!c) return METRPO_ENULL;
     if (!adv || !stats) return set_err(c, METRPO_ENULL, "center: NULL pointer");
     if (N <= 0) return METRPO_OK;
@@ -320,6 +328,7 @@ extern "C" int32_t metrpo_center_advantages(metrpo_ctx* c, float* adv, const uin
 
 extern "C" int32_t metrpo_baseline_gram(metrpo_ctx* c, const float* obs, const float* ret, const int32_t* tpath,
                                         const uint8_t* valid, int64_t N, double* AtA, double* Aty, void* stream) {
+    TraceRange trace_("metrpo:process_samples:baseline_gram");
     if (!c) return METRPO_ENULL;
     if (!obs || !ret || !tpath || !AtA || !Aty) return set_err(c, METRPO_ENULL, "gram: NULL pointer");
     if (N <= 0) return METRPO_OK;
@@ -357,6 +366,7 @@ extern "C" int32_t metrpo_dyn_train_reset(metrpo_ctx* c, void* stream) {
 
 extern "C" int32_t metrpo_dyn_train_step(metrpo_ctx* c, const float* x, const float* y, const metrpo_train_params* tp, double* loss_out,
                                          void* stream) {
+    TraceRange trace_("metrpo:dyn_train_step");
     if (!c) return METRPO_ENULL;
     NEED_DYN(c);
     if (!x || !y || !tp) return set_err(c, METRPO_ENULL, "dyn_train_step: NULL pointer");
@@ -517,6 +527,7 @@ int run_trpo_update(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_para
         HIP_TRY(c, hipMemcpyAsync(c->h_pinned, v.scal, sizeof(double) * 10, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
         if (c->h_pinned[S_COMMERR] != 0.0) return set_err(c, METRPO_EHIP, "trpo_update: one-shot all-reduce timed out (a rank did not arrive)");
+        if (c->h_pinned[S_ROLLERR] != 0.0) return set_err(c, METRPO_EHIP, "rollout: a migrating tile's hand-over timed out (producer workgroup never ran); trajectories are invalid");
         if (first) { loss_before = c->h_pinned[S_LOSS0]; first = false; }
         loss = c->h_pinned[8]; kl = c->h_pinned[9];
         if (loss < loss_before && kl <= pr->max_kl) break;
@@ -543,6 +554,7 @@ int run_trpo_update(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_para
 
 extern "C" int32_t metrpo_trpo_update(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_params* pr,
                                       metrpo_trpo_diag* diag, double* g_out, double* dir_out, void* stream) {
+    TraceRange trace_("metrpo:trpo_update (optimize_policy)");
     if (!c) return METRPO_ENULL;
     NEED_POL(c);
     if (!b || !pr) return set_err(c, METRPO_ENULL, "trpo_update: NULL pointer");
@@ -553,6 +565,7 @@ extern "C" int32_t metrpo_trpo_update(metrpo_ctx* c, const metrpo_batch* b, cons
 // ---- BPTT policy update -----------------------------------------------------------------------
 extern "C" int32_t metrpo_bptt_grad(metrpo_ctx* c, const float* init, int32_t B, int32_t T, double gamma, double* costs, double* grad,
                                     void* stream) {
+    TraceRange trace_("metrpo:bptt_grad");
     if (!c) return METRPO_ENULL;
     NEED_DYN(c); NEED_POL(c);
     if (B <= 0 || T <= 0) return set_err(c, METRPO_EINVAL, "bptt_grad: B and T must be positive");

@@ -8,7 +8,7 @@
 #define CG_MARK(i)
 #endif
 
-enum { S_RDOTR = 0, S_DONE = 1, S_BETA = 2, S_XHX = 3, S_ITERS = 4, S_LOSS0 = 5, S_COMMERR = 6 };   // S_COMMERR: sticky time-out cell of the one-shot exchanges (xchg_device.h)
+enum { S_RDOTR = 0, S_DONE = 1, S_BETA = 2, S_XHX = 3, S_ITERS = 4, S_LOSS0 = 5, S_COMMERR = 6, S_ROLLERR = 7 };   // S_COMMERR: sticky time-out cell of the one-shot exchanges (xchg_device.h)
 //   // S_LOSS0: surrogate loss at theta (copy of gout[0]: one read-back fetches scal | lk)
 
 struct CgTail {

@@ -102,7 +102,7 @@ struct RolloutK {          // device-side copy of metrpo_rollout_args (plain poi
     int t0; const float* init_obs; const int32_t* init_ts; const int32_t* init_model;
     int32_t* last_ts; int32_t* last_model; const int32_t* stop;
     // tile migration of the cooperative kernel (rollout_coop.hip; ctx-owned hand-over slots, NULL elsewhere)
-    int32_t* mig_flag; float* mig_obs; int32_t* mig_ts; int32_t* mig_model; int mig_epoch;
+    int32_t* mig_flag; float* mig_obs; int32_t* mig_ts; int32_t* mig_model; int mig_epoch; double* mig_err;
 };
 
 static inline RolloutK make_rollout_k(const metrpo_rollout_args* a) {
@@ -114,7 +114,7 @@ static inline RolloutK make_rollout_k(const metrpo_rollout_args* a) {
     r.done = a->d_done; r.tpath = a->d_tpath; r.last_obs = a->d_last_obs;
     r.t0 = a->t0; r.init_obs = a->d_init_obs; r.init_ts = a->d_init_ts; r.init_model = a->d_init_model;
     r.last_ts = a->d_last_ts; r.last_model = a->d_last_model; r.stop = a->d_stop;
-    r.mig_flag = nullptr; r.mig_obs = nullptr; r.mig_ts = nullptr; r.mig_model = nullptr; r.mig_epoch = 0;
+    r.mig_flag = nullptr; r.mig_obs = nullptr; r.mig_ts = nullptr; r.mig_model = nullptr; r.mig_epoch = 0; r.mig_err = nullptr;
     return r;
 }
 

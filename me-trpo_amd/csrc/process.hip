@@ -27,13 +27,6 @@ __device__ __forceinline__ double baseline_value(const float* __restrict__ obs_r
     return v;
 }
 
-// V[n] for every sample in parallel (the scan then needs 3 scalars per step instead of a feature row)
-__global__ void k_baseline_predict(const float* __restrict__ obs, const int32_t* __restrict__ tpath, long long N, int ns,
-                                   const double* __restrict__ coeffs, double* __restrict__ V) {
-    for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (long long)gridDim.x * blockDim.x)
-        V[n] = baseline_value(obs + n * ns, ns, tpath[n], coeffs);
-}
-
 #ifndef GAE_CHUNK
 #define GAE_CHUNK 7
 #endif
@@ -87,9 +80,49 @@ __device__ __forceinline__ void gae_chunk_pass(const double* __restrict__ V, con
 //   pass 2  every wave rescans its chunk from its true carry with exactly the float64 arithmetic of the sequential scan and writes
 //           adv / ret / valid (equal to a single sequential pass up to float64 rounding of the composed carry).
 // The dependent chain per env is 2*T/GAE_NW steps instead of T, and GAE_NW times as many waves are in flight.
-__global__ void __launch_bounds__(64 * GAE_NW) k_gae(const double* __restrict__ V, const float* __restrict__ rew, const uint8_t* __restrict__ done,
+// Phase 0 (fused baseline.predict, samplers/base.py:55): the value V[t][b] = features(obs[t][b], tpath) . coeffs of every sample of the
+// tile is formed by the same block before the scan -- wave w takes the steps t = w, w + GAE_NW, ...; the 64 x ns observation block of a
+// step is ONE contiguous run of the time-major tensor, read with coalesced loads (the block of the wave's NEXT step is already in flight),
+// turned through a wave-private LDS buffer so that every lane ends up with its own env's row, evaluated in float64 and kept in the ctx's
+// V buffer for the two scan passes (L2-resident: written and read by the same workgroup).  As a separate thread-per-sample kernel this
+// read rows of ns floats at a stride of ns floats per lane: 0.26 TB/s on Ant (560 us at the C3 share, 10x the scan itself).
+// NS = compile-time ns of the six envs (register-resident prefetch), NS = 0: any ns (no prefetch).
+template <int NS>
+__global__ void __launch_bounds__(64 * GAE_NW) k_gae(const float* __restrict__ obs, const int32_t* __restrict__ tpath, const double* __restrict__ coeffs,
+                                                      int ns_rt, double* __restrict__ V, const float* __restrict__ rew, const uint8_t* __restrict__ done,
                                                       int T, int B, double gamma, double lam, float* __restrict__ adv, float* __restrict__ ret,
                                                       uint8_t* __restrict__ valid, double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) float stage[];      // [GAE_NW][64 * ns]
+    if (coeffs != nullptr) {
+        const int ns = NS ? NS : ns_rt;
+        const int lane0 = threadIdx.x & 63, w0 = threadIdx.x >> 6;
+        const int b0 = blockIdx.x * 64, nv = min(64, B - b0);
+        float* S = stage + (size_t)w0 * 64 * ns;
+        constexpr int NR = NS ? NS : 1;
+        float cur[NR], nxt[NR];
+        auto load = [&](int t, float (&r)[NR]) {
+            const float* __restrict__ src = obs + ((size_t)t * B + b0) * NS;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) { const int e = i * 64 + lane0; r[i] = (e < nv * NS) ? src[e] : 0.0f; }
+        };
+        if (NS && w0 < T) load(w0, nxt);
+        for (int t = w0; t < T; t += GAE_NW) {
+            if (NS) {
+#pragma unroll
+                for (int i = 0; i < NR; ++i) cur[i] = nxt[i];
+                if (t + GAE_NW < T) load(t + GAE_NW, nxt);
+#pragma unroll
+                for (int i = 0; i < NR; ++i) S[i * 64 + lane0] = cur[i];
+            } else {
+                const float* __restrict__ src = obs + ((size_t)t * B + b0) * ns;
+                for (int e = lane0; e < nv * ns; e += 64) S[e] = src[e];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+            if (lane0 < nv) V[(size_t)t * B + b0 + lane0] = baseline_value(S + lane0 * ns, ns, tpath[(size_t)t * B + b0 + lane0], coeffs);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();                             // every wave's V rows are visible to the whole workgroup from here on
+    } else V = nullptr;
     __shared__ double red[16];
     __shared__ double agg[GAE_NW][5][64];           // per chunk and env: A0, G0, v_first, CA, CG   (carry-out = A0 + CA*E_in, G0 + CG*r_in)
     __shared__ uint8_t cut[GAE_NW][64];             // a done inside the chunk: the carry-in does not reach the chunk's first step
@@ -487,10 +520,19 @@ int launch_gae(metrpo_ctx* c, const float* obs, const float* rew, const uint8_t*
             c->vbuf_cap = (size_t)N;
         }
         V = c->d_vbuf;
-        const int g = (int)std::min<long long>((N + 255) / 256, (long long)c->n_sm * 8);
-        hipLaunchKernelGGL(k_baseline_predict, dim3(g), dim3(256), 0, st, obs, tpath, N, c->pd.ns, coeffs, V);
     }
-    hipLaunchKernelGGL(k_gae, dim3((B + 63) / 64), dim3(64 * GAE_NW), 0, st, V, rew, done, T, B, gamma, lam, adv, ret, valid, stats);
+    const int ns = c->pd.ns;
+    const size_t sh = (coeffs != nullptr) ? sizeof(float) * GAE_NW * 64 * (size_t)ns : 0;
+#define GAE_LAUNCH(NSV) do { \
+        if (sh > 48 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_gae<NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)); \
+        hipLaunchKernelGGL(k_gae<NSV>, dim3((B + 63) / 64), dim3(64 * GAE_NW), sh, st, obs, tpath, coeffs, ns, V, rew, done, T, B, gamma, lam, adv, ret, valid, stats); } while (0)
+    if (sh + 24 * 1024 > 160 * 1024) return set_err(c, METRPO_EUNSUPPORTED, "gae: observation too wide for the staging buffer");
+    switch (ns) {                                    // the six envs' widths get the register-prefetching instantiation
+    case 10: GAE_LAUNCH(10); break; case 11: GAE_LAUNCH(11); break; case 14: GAE_LAUNCH(14); break;
+    case 18: GAE_LAUNCH(18); break; case 29: GAE_LAUNCH(29); break; case 55: GAE_LAUNCH(55); break;
+    default: GAE_LAUNCH(0);
+    }
+#undef GAE_LAUNCH
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;
 }

@@ -199,7 +199,18 @@ __global__ void __launch_bounds__(256, ONE ? 1 : 2) k_rollout_coop(RolloutK r, c
     const bool resume = r.init_obs != nullptr;
     int cur_model = 0, ts = 0;
     if (ONE && t_begin > 0) {
-        if (tid == 0) while (__hip_atomic_load(&r.mig_flag[tile], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != r.mig_epoch) __builtin_amdgcn_s_sleep(4);
+        // The producer is the previous workgroup, which runs this very piece FIRST and waits for nobody; workgroups are dispatched in
+        // ascending order per XCD, so the smallest unfinished workgroup is always resident and the chain cannot deadlock.  Should the
+        // platform ever break that assumption (CU masks, partition modes), the wait gives up after ~2 s of wall clock and raises the
+        // ctx's sticky error cell (reported by the next metrpo_trpo_update / metrpo_comm_check) instead of hanging the GPU.
+        if (tid == 0) {
+            unsigned long long t0 = 0; int spins = 0;
+            while (__hip_atomic_load(&r.mig_flag[tile], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != r.mig_epoch) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins == 4096) t0 = wall_clock64();
+                if (spins > 4096 && (spins & 1023) == 0 && wall_clock64() - t0 > 200000000ull) { if (r.mig_err) *r.mig_err = 1.0; break; }
+            }
+        }
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         cur_model = r.mig_model[b]; ts = r.mig_ts[b];
@@ -684,6 +695,7 @@ int launch_rollout_coop(metrpo_ctx* c, int idx, const RolloutK& r_in, hipStream_
         r.mig_flag = base; r.mig_ts = base + c->mig_cap; r.mig_model = base + 17 * (size_t)c->mig_cap;
         r.mig_obs = (float*)(base + 33 * (size_t)c->mig_cap);
         r.mig_epoch = ++c->mig_epoch;
+        r.mig_err = comm_err_cell(c) + 1;                                // scal[S_ROLLERR]
     }
     const bool draws = r.eps || r.model_idx || r.sel_noise || r.reset_idx || r.reset_model;
     const coop_kernel_t kern = en.kern[one ? 1 : 0][draws ? 1 : 0];

@@ -537,11 +537,23 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
         return METRPO_OK;
     };
     int rcs[METRPO_MAX_PAR_ROUNDS] = {0};
+    bool threaded[METRPO_MAX_PAR_ROUNDS] = {false};
     std::thread workers[METRPO_MAX_PAR_ROUNDS - 1];
-    for (int round = 1; round < R; ++round) workers[round - 1] = std::thread([&, round] { rcs[round] = run_round(round); });
+    for (int round = 1; round < R; ++round) {
+        try { workers[round - 1] = std::thread([&, round] { rcs[round] = run_round(round); }); threaded[round] = true; }
+        catch (...) { threaded[round] = false; }                  // no thread to be had (std::system_error must not cross the C ABI): enqueue it here
+    }
     rcs[0] = run_round(0);
-    for (int round = 1; round < R; ++round) workers[round - 1].join();
-    for (int round = 0; round < R; ++round) if (rcs[round] != METRPO_OK) return (c->err.empty() ? set_err(c, rcs[round], "concurrent rollout round failed") : rcs[round]);
-    for (int round = 1; round < R; ++round) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join[round - 1], 0));
+    for (int round = 1; round < R; ++round) { if (threaded[round]) workers[round - 1].join(); else rcs[round] = run_round(round); }
+    // The caller's stream joins EVERY round that was started, failed ones included: their side streams may still be writing the
+    // trajectory tensors and the shared workspace, and the next call must not race with them.  A round that failed before it
+    // recorded its join event is drained on the host instead.
+    int first_bad = METRPO_OK;
+    for (int round = 0; round < R; ++round) if (rcs[round] != METRPO_OK && first_bad == METRPO_OK) first_bad = rcs[round];
+    for (int round = 1; round < R; ++round) {
+        if (rcs[round] == METRPO_OK) { if (hipStreamWaitEvent(st, c->ev_join[round - 1], 0) != hipSuccess && first_bad == METRPO_OK) first_bad = METRPO_EHIP; }
+        else (void)hipStreamSynchronize(c->side_stream[round - 1]);
+    }
+    if (first_bad != METRPO_OK) { (void)hipGetLastError(); return first_bad; }       // c->err holds the failing round's message (set_err is serialised)
     return METRPO_OK;
 }

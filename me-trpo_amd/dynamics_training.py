@@ -37,6 +37,9 @@ class data_collection(object):
         if self._xs is None:
             self._xs = torch.empty(self.max_size, x.shape[1], dtype=torch.float32, device=x.device)
             self._ys = torch.empty(self.max_size, y.shape[1], dtype=torch.float32, device=y.device)
+        elif x.shape[1] != self._xs.shape[1] or y.shape[1] != self._ys.shape[1]:
+            raise AssertionError("feature width changed: buffer holds (%d, %d) columns, got (%d, %d)"
+                                 % (self._xs.shape[1], self._ys.shape[1], x.shape[1], y.shape[1]))
 
     def _append(self, x, y):
         """Write rows after the newest sample; returns how many of the OLDEST logical rows (of old + new) fell out."""
@@ -66,13 +69,22 @@ class data_collection(object):
         phys = self._physical(logical)
         return self._xs.index_select(0, phys), self._ys.index_select(0, phys)
 
+    # .x / .y: the buffer's rows in logical order, as READ-ONLY snapshots (the reference exposes its arrays; writing through these
+    # would not reach the ring once it has wrapped).  While the oldest row is physical row 0 they are views (no copy).
+    def _logical(self, store):
+        if store is None:
+            return None
+        if self._head == 0:
+            return store[:self.n_data]
+        return store.index_select(0, self._physical(np.arange(self.n_data)))
+
     @property
     def x(self):
-        return None if self._xs is None else self._rows(np.arange(self.n_data))[0]
+        return self._logical(self._xs)
 
     @property
     def y(self):
-        return None if self._ys is None else self._rows(np.arange(self.n_data))[1]
+        return self._logical(self._ys)
 
     def _fresh_mapping(self, is_shuffled):
         self.idx_mapping = list(range(self.n_data))
@@ -181,36 +193,45 @@ def trajectories_to_pairs(Os, As):
     return x_all, y_all
 
 
+def _split_plan(total, n_scopes, shared, split_ratio):
+    """Row ranges [lo, hi) of the (possibly shuffled) sample order that go to each scope's validation and training buffers.
+    shared: every scope gets the same split (validation = the first round(ratio * total) rows); otherwise the order is cut into
+    n_scopes consecutive (validation, training) pairs of int(ratio * total / n) and int(total / n - validation) rows."""
+    if shared:
+        cut = round(split_ratio * total)
+        return [((0, cut), (cut, total))] * n_scopes, total
+    n_val = int(split_ratio * total / n_scopes)
+    n_trn = int(total / n_scopes - n_val)
+    plan, at = [], 0
+    for _ in range(n_scopes):
+        plan.append(((at, at + n_val), (at + n_val, at + n_val + n_trn)))
+        at += n_val + n_trn
+    return plan, at
+
+
 def add_rollouts(x_all, y_all, dynamics_data, dynamics_validation, splitting_mode, use_same_dataset, split_ratio, input_rms=None,
                  output_rms=None):
-    """The post-simulator half of collect_data (model_based_rl.py:813-852): np.random.shuffle of the indices in "triplet"
-    mode, per-scope validation / training split, RunningMeanStd fed from the training part (shared-dataset branch only,
-    as in the reference).  The simulator half (sample_trajectories) stays with the caller -- it needs MuJoCo."""
-    x_all, y_all = np.asarray(x_all), np.asarray(y_all)
-    indices = list(range(len(x_all)))
-    if splitting_mode == "triplet":
-        np.random.shuffle(indices)
-    elif splitting_mode != "trajectory":
+    """What collect_data does with the simulator's samples (model_based_rl.py:813-852): one np.random.shuffle of the sample
+    order in "triplet" mode (none in "trajectory" mode), a validation / training cut per scope, and -- in the shared-dataset
+    branch only, as in the reference -- the running normalisers fed from the training rows (inputs, and output minus state).
+    The simulator call itself (sample_trajectories) stays with the caller: it needs MuJoCo."""
+    if splitting_mode not in ("trajectory", "triplet"):
         raise AssertionError("splitting_mode must be 'trajectory' or 'triplet'")
-    cur_i, total = 0, len(x_all)
-    n_scopes = len(dynamics_data.keys())
-    for scope in dynamics_data.keys():
-        if use_same_dataset:
-            n = round(split_ratio * total)
-            dynamics_validation[scope].add_data(x_all[indices[:n], :], y_all[indices[:n], :])
-            dynamics_data[scope].add_data(x_all[indices[n:], :], y_all[indices[n:], :])
-            cur_i = len(indices)
-            if input_rms is not None:
-                input_rms.update(x_all[indices[n:], :])
-                output_rms.update(y_all[indices[n:], :] - x_all[indices[n:], :y_all.shape[1]])
-        else:
-            n = int(split_ratio * total / n_scopes)
-            dynamics_validation[scope].add_data(x_all[indices[cur_i:cur_i + n], :], y_all[indices[cur_i:cur_i + n], :])
-            cur_i += n
-            m = int(total / n_scopes - n)
-            dynamics_data[scope].add_data(x_all[indices[cur_i:cur_i + m], :], y_all[indices[cur_i:cur_i + m], :])
-            cur_i += m
-    assert cur_i == total, "sample count must split evenly over the scopes (model_based_rl.py:852)"
+    x_all, y_all = np.asarray(x_all), np.asarray(y_all)
+    total = len(x_all)
+    order = np.arange(total)
+    if splitting_mode == "triplet":
+        np.random.shuffle(order)
+    scopes = list(dynamics_data.keys())
+    plan, consumed = _split_plan(total, len(scopes), bool(use_same_dataset), split_ratio)
+    assert consumed == total, "sample count must split evenly over the scopes (model_based_rl.py:852)"
+    for scope, ((v_lo, v_hi), (t_lo, t_hi)) in zip(scopes, plan):
+        val_rows, trn_rows = order[v_lo:v_hi], order[t_lo:t_hi]
+        dynamics_validation[scope].add_data(x_all[val_rows], y_all[val_rows])
+        dynamics_data[scope].add_data(x_all[trn_rows], y_all[trn_rows])
+        if use_same_dataset and input_rms is not None:
+            input_rms.update(x_all[trn_rows])
+            output_rms.update(y_all[trn_rows] - x_all[trn_rows, :y_all.shape[1]])
 
 
 def push_normalizers(engine, input_rms, diff_rms):
@@ -232,62 +253,81 @@ def xavier_reinitialize(engine, seed=None):
         engine.set_dynamics_model(k, params[k])
 
 
+class _BestPerModel(object):
+    """Per-model best-validation bookkeeping of optimize_models, on device tensors: the lowest validation loss each of the K models
+    has reached, the parameters it had then (the reference's per-model tf.train.Saver, model_based_rl.py:927-930, 1002-1004) and the
+    update count at which that happened."""
+
+    def __init__(self, engine, first_losses):
+        self.engine = engine
+        self.params = engine.get_dynamics().clone()                        # [K, P_dyn]
+        self.loss = first_losses.clone()                                   # [K] float64
+        self.when = torch.zeros(engine.K, dtype=torch.int64, device=first_losses.device)
+
+    def offer(self, update, losses):
+        """Keep the models that improved; returns nothing (no host sync)."""
+        better = losses < self.loss
+        self.loss = torch.where(better, losses, self.loss)
+        self.params = torch.where(better[:, None], self.engine.get_dynamics(), self.params)
+        self.when = torch.where(better, torch.full_like(self.when, update), self.when)
+
+    def restore(self):
+        """recover_weights (model_based_rl.py:871-878): every model goes back to its own best parameters."""
+        for k in range(self.engine.K):
+            self.engine.set_dynamics_model(k, self.params[k])
+
+
 def optimize_models(engine, dynamics_data, dynamics_validation, learning_rate, batch_size=1000, max_passes=2000, log_every=5,
                     num_passes_threshold=25, reinitialize=False, sample_mode='random', reg_constant=0.0, init_seed=None, logger=None):
-    """model_based_rl.py:881-1051 for one scope.  learning_rate = {"scratch":..., "refine":...}; returns the reference's
-    bookkeeping (training/validation losses, best index) plus '# model updates'."""
+    """One scope of model_based_rl.py:881-1051.  Every model trains on its own slice of each K * batch_size draw (Adam on the
+    prediction loss, SGD on the regulariser: dyn_train.hip); every `log_every` passes the K validation losses are evaluated, each
+    model keeps the parameters of its own best validation loss, and training stops once no model has improved for
+    `num_passes_threshold` passes -- after one switch from the "scratch" to the smaller "refine" learning rate (restarting from the
+    best parameters) when the ensemble was re-initialised.  Returns the reference's bookkeeping plus the number of updates."""
+    if sample_mode not in ('random', 'next_batch'):
+        raise AssertionError("sample_mode must be 'random' or 'next_batch'")
     K = engine.K
-    lr = learning_rate
+    rate = learning_rate["scratch"] if reinitialize else learning_rate["refine"]
+    may_refine = bool(reinitialize) and learning_rate["scratch"] > learning_rate["refine"]
     if reinitialize:
-        cur_lr = lr["scratch"]
         xavier_reinitialize(engine, init_seed)
-    else:
-        cur_lr = lr["refine"]
-    engine.train_reset()                                                   # dynamics_adam_init
-    snapshot = engine.get_dynamics().clone()                               # savers[scope][i].save(...), :927-930
-    x_val, y_val = dynamics_validation.x, dynamics_validation.y           # np.tile(val, n_models): every model sees all of it
-    min_validation_losses = engine.eval_losses(x_val, y_val, reg_constant).cpu().numpy()
-    min_sum_validation_loss = float(np.sum(min_validation_losses))
-    recover_indices, refine_idx, best_j = np.zeros(K), -1, 0
-    training_losses, validation_losses = [], []
-    iter_const = dynamics_data.n_data / batch_size
-    max_iters = int(max_passes * iter_const)
-    log_every_it = max(1, int(log_every * iter_const))
-    num_iters_threshold = int(num_passes_threshold * iter_const)
-    j = 0
-    for j in range(1, max_iters + 1):
+    engine.train_reset()
+    x_val, y_val = dynamics_validation.x, dynamics_validation.y           # every model is validated on all of it
+    best = _BestPerModel(engine, engine.eval_losses(x_val, y_val, reg_constant))
+    best_sum, best_sum_at = float(best.loss.sum().item()), 0
+    updates_per_pass = dynamics_data.n_data / batch_size
+    n_updates_max = int(max_passes * updates_per_pass)
+    eval_period = max(1, int(log_every * updates_per_pass))
+    patience = int(num_passes_threshold * updates_per_pass)
+    refined_at = -1
+    history_train, history_val = [], []
+    done = 0
+    for done in range(1, n_updates_max + 1):
         if sample_mode == 'next_batch':
-            x_batch, y_batch = dynamics_data.get_next_batch(batch_size * K, is_shuffled=False)
+            xb, yb = dynamics_data.get_next_batch(batch_size * K, is_shuffled=False)
         else:
-            assert sample_mode == 'random'
-            x_batch, y_batch = dynamics_data.sample(batch_size * K)
-        want = (j % log_every_it == 0)
-        tl = engine.train_step(x_batch, y_batch, batch_size, cur_lr, reg_constant, want_loss=want)
-        if want:                                                           # validation and logging, :974-1031
-            training_losses.append(float(tl.sum().item()))
-            _validation_losses = engine.eval_losses(x_val, y_val, reg_constant).cpu().numpy()
-            validation_loss = float(np.sum(_validation_losses))
-            validation_losses.append(validation_loss)
-            if logger:
-                logger('iter %d train %.5f val %.5f' % (j, training_losses[-1], validation_loss))
-            if min_sum_validation_loss > validation_loss:
-                min_sum_validation_loss, best_j = validation_loss, j
-            to_update = min_validation_losses > _validation_losses
-            min_validation_losses[to_update] = _validation_losses[to_update]
-            if to_update.any():
-                cur = engine.get_dynamics()
-                for i in np.nonzero(to_update)[0]:
-                    snapshot[i].copy_(cur[i])                              # per-model saver, :1002-1004
-                    recover_indices[i] = j
-            if j - max(np.amax(recover_indices), refine_idx) >= num_iters_threshold:
-                if reinitialize and refine_idx < 0 and lr["scratch"] > lr["refine"]:
-                    for i in range(K):                                     # recover_weights, then refine with the smaller rate
-                        engine.set_dynamics_model(i, snapshot[i])
-                    cur_lr, refine_idx = lr["refine"], j
-                    continue
-                break
-    for i in range(K):                                                     # recover_weights (:1034), :871-878
-        engine.set_dynamics_model(i, snapshot[i])
-    return {'training_losses': training_losses, 'validation_losses': validation_losses, 'best_index': best_j,
-            'n_model_updates': j, 'min_sum_validation_loss': min_sum_validation_loss,
-            'min_validation_losses': min_validation_losses, 'recover_indices': recover_indices}
+            xb, yb = dynamics_data.sample(batch_size * K)
+        evaluate = (done % eval_period == 0)
+        train_losses = engine.train_step(xb, yb, batch_size, rate, reg_constant, want_loss=evaluate)
+        if not evaluate:
+            continue
+        val_losses = engine.eval_losses(x_val, y_val, reg_constant)
+        best.offer(done, val_losses)
+        # one read-back per evaluation: summed training loss, summed validation loss, update count of the latest improvement
+        t_sum, v_sum, latest = (float(v) for v in torch.stack([train_losses.sum(), val_losses.sum(), best.when.max().double()]).cpu())
+        history_train.append(t_sum); history_val.append(v_sum)
+        if logger:
+            logger('iter %d train %.5f val %.5f' % (done, t_sum, v_sum))
+        if v_sum < best_sum:
+            best_sum, best_sum_at = v_sum, done
+        if done - max(latest, refined_at) < patience:
+            continue
+        if may_refine and refined_at < 0:                                  # stalled at the scratch rate: best parameters, smaller rate
+            best.restore()
+            rate, refined_at = learning_rate["refine"], done
+            continue
+        break
+    best.restore()
+    return {'training_losses': history_train, 'validation_losses': history_val, 'best_index': best_sum_at,
+            'n_model_updates': done, 'min_sum_validation_loss': best_sum,
+            'min_validation_losses': best.loss.cpu().numpy(), 'recover_indices': best.when.cpu().numpy().astype(np.float64)}

@@ -174,7 +174,7 @@ class VectorizedSampler(BaseSampler):
         T_first = max(1, -(-batch // B))
         T_max = T_first + H
         chunk = max(1, int(getattr(algo, 'sampler_chunk', max(8, H // 8))))
-        key = (B, T_max, H)
+        key = (B, T_max, H, chunk)                     # chunk sizes the per-step count buffer below
         if getattr(self, '_ant_key', None) != key or not getattr(algo, 'reuse_trajectory_buffers', False):
             self._ant_buf, self._ant_key = eng.alloc_trajectory(B, T_max, H), key
             self._ant_state = (torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev))
