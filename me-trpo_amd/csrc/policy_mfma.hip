@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
 #pragma unroll
             for (int cb = 0; cb < HB; ++cb)
 #pragma unroll
-                for (int r = 0; r < ((POL_SKIP & 8) ? 0 : 4); ++r) T_H1[cb * TILE + (4 * q + r) * TS + wpos] = h1[cb][r];
+                for (int r = 0; r < (((POL_SKIP & 8) || NA <= 2) ? 0 : 4); ++r) T_H1[cb * TILE + (4 * q + r) * TS + wpos] = h1[cb][r];     // only the MFMA output layer (na > 2) reads it back
         }
         if (MODE == MODE_GRAD && k.hcache != nullptr) {     // publish the activations for the FVPs of this update
             f32x4* hw = (f32x4*)k.hcache + (size_t)tile * (2 * HB) * 64 + lane;
