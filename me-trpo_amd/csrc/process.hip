@@ -105,8 +105,13 @@ __global__ void __launch_bounds__(64 * GAE_NW) k_gae(const float* __restrict__ o
 #pragma unroll
             for (int i = 0; i < NR; ++i) { const int e = i * 64 + lane0; r[i] = (e < nv * NS) ? src[e] : 0.0f; }
         };
-        if (NS && w0 < T) load(w0, nxt);
+        // the step's path-time index travels with its observation block (consumed one iteration after it was requested, like the block)
+        int tp_cur = 0, tp_nxt = 0;
+        auto load_tp = [&](int t) { return (lane0 < nv) ? tpath[(size_t)t * B + b0 + lane0] : 0; };
+        if (w0 < T) { if (NS) load(w0, nxt); tp_nxt = load_tp(w0); }
         for (int t = w0; t < T; t += GAE_NW) {
+            tp_cur = tp_nxt;
+            if (t + GAE_NW < T) tp_nxt = load_tp(t + GAE_NW);
             if (NS) {
 #pragma unroll
                 for (int i = 0; i < NR; ++i) cur[i] = nxt[i];
@@ -118,7 +123,7 @@ __global__ void __launch_bounds__(64 * GAE_NW) k_gae(const float* __restrict__ o
                 for (int e = lane0; e < nv * ns; e += 64) S[e] = src[e];
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
-            if (lane0 < nv) V[(size_t)t * B + b0 + lane0] = baseline_value(S + lane0 * ns, ns, tpath[(size_t)t * B + b0 + lane0], coeffs);
+            if (lane0 < nv) V[(size_t)t * B + b0 + lane0] = baseline_value(S + lane0 * ns, ns, tp_cur, coeffs);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();                             // every wave's V rows are visible to the whole workgroup from here on

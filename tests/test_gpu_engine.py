@@ -611,3 +611,66 @@ def test_gemm_rollout_concurrent_rounds_equal_sequential_rounds(env, K, hidden, 
     for a, b in zip(par, (seq.obs, seq.act, seq.mean, seq.rew, seq.done, seq.tpath, seq.last_obs)):
         assert torch.equal(a, b)
     assert int(seq.done.sum()) == R * B and bool(seq.done[H - 1::H].all())
+
+
+@pytest.mark.parametrize('env,B,T', [('swimmer', 70, 13), ('half_cheetah', 130, 9), ('hopper', 64, 17), ('snake', 33, 8), ('humanoid', 65, 11), ('ant', 200, 5)])
+def test_gae_fused_baseline_predict_every_state_width(env, B, T):
+    """baseline.predict (samplers/base.py:55) is evaluated inside the GAE kernel from coalesced, LDS-transposed observation blocks
+    (k_gae<ns>, one instantiation per env): every state width, partial 64-env blocks, horizons that are not a multiple of the 8 time
+    chunks -- advantages / returns against the oracle's per-path scan with the same coefficients."""
+    from metrpo_amd.engine import Trajectory
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, 2, (64, 64), (32, 32) if env != 'humanoid' else (100, 50, 25), seed=3)
+    rs = np.random.RandomState(B + T)
+    H = 4
+    obs = rs.randn(T, B, dm.ns).astype(np.float32) * 3.0           # some entries beyond the +-10 clip of the features
+    obs[rs.rand(T, B, dm.ns) < 0.02] *= 5.0
+    rew = rs.randn(T, B).astype(np.float32)
+    tpath = np.zeros((T, B), np.int32); done = np.zeros((T, B), np.uint8)
+    ts = np.zeros(B, np.int32)
+    for t in range(T):
+        tpath[t] = ts
+        ts += 1
+        dn = (ts >= H) | (rs.rand(B) < 0.1)
+        done[t] = dn
+        ts[dn] = 0
+    dev = eng.device
+    traj = Trajectory(torch.as_tensor(obs, device=dev), torch.zeros(T, B, dm.na, device=dev), torch.as_tensor(rew, device=dev),
+                      torch.zeros(T, B, dm.na, device=dev), torch.as_tensor(done, device=dev), torch.as_tensor(tpath, device=dev),
+                      torch.zeros(B, dm.ns, device=dev), B, T, H)
+    coeffs = rs.randn(2 * dm.ns + 4) * 0.05
+    adv, ret, valid, stats = eng.gae(traj, coeffs, 0.99, 0.95)
+    tr = dict(obs=obs, act=np.zeros((T, B, dm.na), np.float32), rew=rew, mean=np.zeros((T, B, dm.na), np.float32), done=done.astype(bool), tpath=tpath)
+    paths = Hh.paths_from_timemajor(tr)
+    base = O.LinearFeatureBaselineOracle(); base._coeffs = coeffs
+    samples = O.process_samples(paths, base, 0.99, 0.95, center_adv=False)
+    tt, bb = np.array([x for p in paths for x in p['_tb']]).T
+    np.testing.assert_allclose(cpu(ret)[tt, bb], samples['returns'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(cpu(adv)[tt, bb], samples['advantages'], rtol=1e-5, atol=5e-5)
+    adv2 = eng.gae(traj, coeffs, 0.99, 0.95)[0]
+    assert torch.equal(adv, adv2)                                  # bitwise repeatable
+
+
+def test_phase_timers_and_trace_ranges():
+    """the reference accounts policy / env / process time in VectorizedSampler.obtain_samples (vectorized_sampler.py:54-56,106)
+    and policy_opt_time in the outer loop (model_based_rl.py:694).  Here: HIP-event timers on the algo (no synchronisation in the loop) and
+    roctx ranges inside libmetrpo.so (exercised by every entry point; must be harmless without a profiler attached)."""
+    import metrpo_amd
+    from metrpo_amd import synthetic
+    env, K, B, H = 'swimmer', 5, 256, 20
+    eng = metrpo_amd.Engine(env, K, (64, 64), (32, 32))
+    Ws, bs, norm = synthetic.make_dynamics(env, K, (64, 64), seed=0)
+    eng.set_dynamics_layers(Ws, bs, norm['in_mean'], norm['in_std'], norm['diff_mean'], norm['diff_std'])
+    policy = metrpo_amd.GaussianMLPPolicy(eng, init_std=1.0, seed=0)
+    nne = metrpo_amd.NeuralNetEnv(env=metrpo_amd.InitStatePool(synthetic.make_pool(env), 2), inner_env=None, cost_np=env, dynamics_in=None,
+                                  dynamics_outs=eng, sam_mode='step_rand')
+    algo = metrpo_amd.TRPO(env=nne, policy=policy, baseline=metrpo_amd.LinearFeatureBaseline(), batch_size=B * H, max_path_length=H,
+                           discount=0.99, step_size=0.01, sampler_args=dict(n_envs=B))
+    assert algo.timers.summary() == {'rollout_ms': None, 'process_ms': None, 'policy_opt_ms': None, 'n': 0}     # off by default
+    algo.timers.enable()
+    for j in range(4):
+        algo.start_worker()
+        paths = algo.obtain_samples(j)
+        algo.optimize_policy(j, algo.process_samples(j, paths))
+    s = algo.timers.summary()
+    assert s['n'] == 4 and all(0.0 < s[k] < 50.0 for k in ('rollout_ms', 'process_ms', 'policy_opt_ms')), s
+    assert len(algo.timers.times_ms('rollout')) == 4
