@@ -457,8 +457,19 @@ __global__ void k_try_theta(int P, double ratio, const float* __restrict__ prev,
     if (i < P) cur[i] = (float)((double)prev[i] - ratio * step[i]);     // cur_param = prev_param - ratio * flat_descent_step
 }
 
+static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_params* pr, metrpo_trpo_diag* diag,
+                                double* g_out, double* dir_out, hipStream_t st);
+// The arrival counter of the fused tails (d_ticket) resets itself in the last block of every reduction, so a completed update leaves it
+// at zero.  An update that FAILED half-way (a launch error, a time-out) may not: it is cleared on the error path, where the cost of a
+// 4-byte memset does not matter -- a stale count would silently disable every later CG tail.
 int run_trpo_update(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_params* pr, metrpo_trpo_diag* diag,
                     double* g_out, double* dir_out, hipStream_t st) {
+    const int rc = run_trpo_update_impl(c, b, pr, diag, g_out, dir_out, st);
+    if (rc != METRPO_OK) { (void)hipGetLastError(); (void)hipMemsetAsync(c->d_ticket, 0, sizeof(unsigned int), st); }
+    return rc;
+}
+static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_params* pr, metrpo_trpo_diag* diag,
+                                double* g_out, double* dir_out, hipStream_t st) {
     const int P = c->pd.P;
     CgView v = cg_view(c);
     int rc;
@@ -482,9 +493,6 @@ int run_trpo_update(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_para
     CgTail tl; tl.P = P; tl.last = 0; tl.implicit_hd = implicit_hd; tl.reg = pr->reg_coeff; tl.tol = pr->residual_tol; tl.max_kl = pr->max_kl;
     tl.x = v.x; tl.r = v.r; tl.p = v.p; tl.z = v.z; tl.step = v.step; tl.scal = v.scal; tl.gout = v.gout; tl.pf = c->d_vf; tl.ticket = c->d_ticket;
     tl.op = 3;
-    // the arrival counter of the fused tails resets itself, but a launch that failed half-way would leave it non-zero and silently
-    // disable every later tail: 4 bytes of memset per update are cheap insurance
-    HIP_TRY(c, hipMemsetAsync(c->d_ticket, 0, sizeof(unsigned int), st));
     c->hcache_on = 1;                    // the gradient kernel publishes tanh activations, the CG products of this solve reuse them
     struct CacheOff { metrpo_ctx* c; ~CacheOff() { c->hcache_on = 0; } } cache_off{c};
     if ((rc = launch_loss_grad(c, b, v.gout, st, fused ? &tl : nullptr))) return rc;
