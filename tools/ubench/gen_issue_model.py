@@ -43,7 +43,7 @@ def body(nv10, lds, vmem):
     if lds or vmem: L.append('s_waitcnt vmcnt(0) lgkmcnt(0)')
     return L
 
-def body_clustered(K, nv, lds, vmem, rot, wreads=0):
+def body_clustered(K, nv, lds, vmem, rot, wreads=0, avgpr=True, waits=False):
     """K phases per tile, each = a run of 78/K MFMAs then a run of nv/K VALU (+ the phase's share of DS / VMEM); rot: start with the VALU run"""
     chains = []
     chains += ['v[%d:%d]' % (4 * (g % 2), 4 * (g % 2) + 3) for g in range(6)]
@@ -57,7 +57,9 @@ def body_clustered(K, nv, lds, vmem, rot, wreads=0):
         M = []
         while g < 78 * (k + 1) // K:
             if wreads and g % 3 == 0 and g // 3 < wreads: M.append('ds_read_b64 v[%d:%d], v57 offset:%d' % (24 + 2 * ((g // 3) % 16), 25 + 2 * ((g // 3) % 16), 512 * (g // 3)))
-            M.append('v_mfma_f32_16x16x4_f32 %s, a%d, v%d, %s' % (chains[g], 32 + g % 54, 24 + g % 32, chains[g])); g += 1
+            if wreads and waits and g % 4 == 2 and g // 3 < wreads: M.append('s_waitcnt lgkmcnt(0)')
+            M.append(('v_mfma_f32_16x16x4_f32 %s, a%d, v%d, %s' % (chains[g], 32 + g % 54, 24 + g % 32, chains[g])) if avgpr else
+                     ('v_mfma_f32_16x16x4_f32 %s, v%d, v%d, %s' % (chains[g], 24 + (g + 7) % 32, 24 + g % 32, chains[g]))); g += 1
         V = []
         while vdone < nv * (k + 1) // K:
             r = 64 + (vdone % 4) + 4 * ((vdone // 4) % 8)
@@ -90,6 +92,8 @@ kernels.append(('k_cl2_w', 'clustered K=1, 2 waves/SIMD, 26 ds_read_b64 inside t
 kernels.append(('k_cl2_w3', 'clustered K=3, 2 waves/SIMD, 26 ds_read_b64 inside the MFMA runs', 512, body_clustered(3, 230, 1, 1, False, 26), body_clustered(3, 230, 1, 1, False, 26)))
 kernels.append(('k_cl2_v300', 'clustered K=1, 2 waves/SIMD, 300 VALU', 512, body_clustered(1, 300, 1, 1, False), body_clustered(1, 300, 1, 1, False)))
 kernels.append(('k_cl2_v300w', 'clustered K=1, 2 waves/SIMD, 300 VALU, 26 ds_read_b64 in the MFMA run', 512, body_clustered(1, 300, 1, 1, False, 26), body_clustered(1, 300, 1, 1, False, 26)))
+kernels.append(('k_cl2_va', 'clustered K=2, 2 waves/SIMD, A operands in VGPRs, 26 reads in runs', 512, body_clustered(2, 230, 1, 1, False, 26, False), body_clustered(2, 230, 1, 1, False, 26, False)))
+kernels.append(('k_cl2_vaw', 'clustered K=2, 2 waves/SIMD, A in VGPRs, reads in runs + lgkmcnt(0) waits', 512, body_clustered(2, 230, 1, 1, False, 26, False, True), body_clustered(2, 230, 1, 1, False, 26, False, True)))
 for K in (1, 3):
     kernels.append(('k_cl_%d' % K, 'clustered K=%d (230 VALU, lds, vmem), 1 wave/SIMD' % K, 256, body_clustered(K, 230, 1, 1, False), None))
     kernels.append(('k_cl2_%d' % K, 'clustered K=%d, 2 waves/SIMD same phase' % K, 512, body_clustered(K, 230, 1, 1, False), body_clustered(K, 230, 1, 1, False)))
