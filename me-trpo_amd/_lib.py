@@ -112,6 +112,7 @@ EXTRA_SYMBOLS = {
     'metrpo_update_path': (_I, [_P, _L]),
     'metrpo_set_rollout_variant': (_I, [_P, _I]),
     'metrpo_set_det_path': (_I, [_P, _I]),
+    'metrpo_last_rollout_kernel': (_I, [_P]),
     'metrpo_probe_peaks': (_I, [_P, _P, _P]),
 }
 

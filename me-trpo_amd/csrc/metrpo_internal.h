@@ -82,6 +82,8 @@ struct metrpo_ctx {
     size_t train_cap;
     void* d_big;         // workspace of the GEMM step-wise rollout (rollout_gemm.hip)
     size_t big_cap;
+    void* d_res; size_t res_cap; unsigned int res_seq;   // rollout_resident.hip: uncached exchange region (abort cell | X packets | P packets) and the step stamps issued so far
+    int last_rollout_kernel;                              // which kernel family the last metrpo_rollout ran on: 0 generic, 1 head-per-wave MFMA, 2 cooperative MFMA, 3 step-wise GEMM, 4 resident
     hipStream_t side_stream[METRPO_MAX_PAR_ROUNDS - 1]; hipEvent_t ev_fork, ev_join[METRPO_MAX_PAR_ROUNDS - 1]; int side_ready;   // rollout_gemm.hip: independent rounds of a small-batch rollout run concurrently
     double* h_pinned;    // pinned host scratch for the per-trial read-back
     int n_sm;            // CU count
@@ -146,6 +148,7 @@ int launch_step(metrpo_ctx*, const float*, const float*, int, int, const int32_t
 int launch_rollout_generic(metrpo_ctx*, const metrpo_rollout_args*, hipStream_t);
 bool gemm_path_applicable(const metrpo_ctx*);
 int launch_rollout_gemm(metrpo_ctx*, const metrpo_rollout_args*, hipStream_t);
+int launch_rollout_resident(metrpo_ctx*, const metrpo_rollout_args*, hipStream_t);   // METRPO_EUNSUPPORTED: not a shape / call of the resident kernel
 int launch_bptt_grad(metrpo_ctx*, const float* init, int B, int T, double gamma, double* costs, double* grad, hipStream_t);
 int launch_policy_adam(metrpo_ctx*, const double* grad, double lr, double b1, double b2, double eps, double clip_val, bool reset, hipStream_t);
 int det_mfma_select(const metrpo_ctx*);

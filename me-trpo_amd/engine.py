@@ -79,7 +79,8 @@ class Engine(object):
             self._ctx = None
 
     def set_rollout_variant(self, v):
-        """Test hook: 0 = fastest rollout kernel available, 1 = head-per-wave MFMA kernel, 2 = cooperative kernel in its
+        """Test hook: 0 = fastest rollout kernel available, 1 = head-per-wave MFMA kernel (for large nets: the step-wise
+        GEMM path even where the resident kernel applies), 2 = cooperative kernel in its
         two-workgroups-per-CU instantiation at any batch size.  Returns the variant that
         will run: 3 step-wise GEMM (large nets), 2 cooperative-heads MFMA, 1 head-per-wave MFMA, 0 generic."""
         self._variant = int(v)
@@ -282,6 +283,12 @@ class Engine(object):
     def rollout_path(self):
         """3 step-wise GEMM (large nets), 2 cooperative-heads MFMA, 1 head-per-wave MFMA, 0 generic (current selection)."""
         return int(lib.metrpo_set_rollout_variant(self._ctx, int(getattr(self, '_variant', 0))))
+
+    def last_rollout_kernel(self):
+        """Kernel family the last rollout() of this engine ran on: 'generic', 'mfma-head-per-wave', 'mfma-cooperative', 'gemm-stepwise',
+        'resident' (whole time loop in one launch, rollout_resident.hip); None before the first rollout."""
+        k = int(lib.metrpo_last_rollout_kernel(self._ctx))
+        return {0: 'generic', 1: 'mfma-head-per-wave', 2: 'mfma-cooperative', 3: 'gemm-stepwise', 4: 'resident'}.get(k)
 
     def alloc_trajectory(self, B, T, H):
         dev, f = self.device, torch.float32

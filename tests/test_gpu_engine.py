@@ -602,9 +602,10 @@ def test_gemm_rollout_concurrent_rounds_equal_sequential_rounds(env, K, hidden, 
     """Small-batch rollouts of horizon-terminated envs run their T / H rounds concurrently (one stream per round, reset states of the later
     rounds computed from the draws of the step before them, rollout_gemm.hip): bit for bit the sequential step loop, production draws."""
     eng, dm, theta, pdims, pool = Hh.make_engine(env, K, hidden, (32, 32), seed=77)
-    assert eng.set_rollout_variant(0) == 3
+    assert eng.set_rollout_variant(1) == 3                          # 1: stay on the step-wise path where the resident kernel would take over (test_gpu_resident.py)
     T = R * H
     par = eng.rollout(B, T, H, mode, pool, seed=5)
+    assert eng.last_rollout_kernel() == 'gemm-stepwise'
     par = [x.clone() for x in (par.obs, par.act, par.mean, par.rew, par.done, par.tpath, par.last_obs)]
     monkeypatch.setenv('METRPO_SEQ_ROUNDS', '1')
     seq = eng.rollout(B, T, H, mode, pool, seed=5)

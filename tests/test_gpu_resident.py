@@ -1,0 +1,126 @@
+"""Resident rollout kernel (rollout_resident.hip): the whole time loop of a small-batch rollout of a 2 x 512 dynamics ensemble in ONE
+launch -- the shape of the reference's own params-swimmer.json (K = 5, B = 100, three rounds of 200 steps).  Reference path:
+samplers/vectorized_sampler.py:45-116, env_helpers.py:597-635, training.py:218-269.  Checked against the CPU oracle (supplied draws,
+teacher-forced), against the step-wise GEMM path (production draws) and against itself across its launch shapes."""
+import numpy as np
+import pytest
+import torch
+
+import helpers as Hh
+
+pytestmark = pytest.mark.gpu
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
+
+
+def _fields(tr):
+    return [x.clone() for x in (tr.obs, tr.act, tr.mean, tr.rew, tr.done, tr.tpath, tr.last_obs)]
+
+
+@pytest.mark.parametrize('env,K,B,T,H,mode', [('swimmer', 5, 100, 12, 12, 'step_rand'),       # params-swimmer.json network and batch
+                                               ('swimmer', 5, 128, 9, 4, 'eps_rand'),         # 8 full env tiles, resets inside the call
+                                               ('swimmer', 3, 5, 7, 7, 'one_model'),          # one partial tile
+                                               ('hopper', 5, 37, 8, 8, 'step_rand'),
+                                               ('snake', 4, 50, 8, 5, 'eps_rand'),
+                                               ('half_cheetah', 5, 77, 6, 6, 'step_rand')])   # ns = 18: two output-dim tiles, 6 input k-steps
+def test_resident_rollout_against_oracle(env, K, B, T, H, mode):
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (512, 512), (32, 32), seed=61)
+    th = theta.astype(np.float32).astype(np.float64)
+    pool32 = pool.astype(np.float32).astype(np.float64)
+    dr = Hh.draws(np.random.RandomState(8), K, B, T, dm.ns, dm.na, len(pool))
+    dr32 = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in dr.items()}
+    traj = eng.rollout(B, T, H, mode, pool, **dr32)
+    assert eng.last_rollout_kernel() == 'resident'
+    drf = {k: (v.astype(np.float64) if v.dtype == np.float32 else v) for k, v in dr32.items()}
+    ref = Hh.oracle_rollout(dm, th, pdims, env, pool32, drf, B, T, H, mode, teacher_obs=cpu(traj.obs))
+    tol = dict(rtol=1e-4, atol=5e-5)                                 # 512-wide fp32 sums in a fixed, different order
+    np.testing.assert_allclose(cpu(traj.mean), ref['mean'], **tol)
+    np.testing.assert_allclose(cpu(traj.act), ref['act'], **tol)
+    np.testing.assert_allclose(cpu(traj.rew), ref['rew'], **tol)
+    dn = cpu(traj.done).astype(bool)
+    assert np.array_equal(dn, ref['done'].astype(bool)) and np.array_equal(cpu(traj.tpath), ref['tpath'])
+    for t in range(T - 1):
+        np.testing.assert_allclose(cpu(traj.obs[t + 1])[~dn[t]], ref['next'][t][~dn[t]], **tol)
+        if dn[t].any():                                              # reset rows come straight from the pool
+            np.testing.assert_array_equal(cpu(traj.obs[t + 1])[dn[t]], pool.astype(np.float32)[dr['reset_idx'][t + 1][dn[t]]])
+    # and the step-wise GEMM path on the same draws (its own summation order)
+    eng.set_rollout_variant(1)
+    stepwise = eng.rollout(B, T, H, mode, pool, **dr32)
+    assert eng.last_rollout_kernel() == 'gemm-stepwise'
+    np.testing.assert_allclose(cpu(traj.obs), cpu(stepwise.obs), rtol=2e-3, atol=2e-3)
+    assert torch.equal(traj.done, stepwise.done) and torch.equal(traj.tpath, stepwise.tpath)
+
+
+@pytest.mark.parametrize('K,B,H,R,ws', [(5, 100, 7, 3, 32),        # params-file layout: 240 compute workgroups, rounds side by side
+                                        (5, 100, 3, 8, 32),        # more rounds than fit at once: round groups, one launch each
+                                        (2, 40, 5, 2, 16)])        # narrow slices with the rounds side by side
+def test_resident_rounds_side_by_side_equal_sequential_rounds(K, B, H, R, ws, monkeypatch):
+    """Production draws: the R rounds of a horizon-terminated rollout run side by side (every round from the reset its predecessor's last
+    step draws) -- bit for bit the single-round-at-a-time loop at the same slice width (a lone round would otherwise take the narrower
+    slices: other partial sums), and within float32 summation order of the step-wise GEMM path."""
+    eng, dm, theta, pdims, pool = Hh.make_engine('swimmer', K, (512, 512), (32, 32), seed=77)
+    T = R * H
+    monkeypatch.setenv('METRPO_RESIDENT_WS', str(ws))
+    par = eng.rollout(B, T, H, 'step_rand', pool, seed=5)
+    assert eng.last_rollout_kernel() == 'resident'
+    par = _fields(par)
+    monkeypatch.setenv('METRPO_SEQ_ROUNDS', '1')
+    seq = eng.rollout(B, T, H, 'step_rand', pool, seed=5)
+    assert eng.last_rollout_kernel() == 'resident'
+    for a, b in zip(par, _fields(seq)):
+        assert torch.equal(a, b)
+    assert int(seq.done.sum()) == R * B and bool(seq.done[H - 1::H].all())
+    eng.set_rollout_variant(1)
+    gm = eng.rollout(B, T, H, 'step_rand', pool, seed=5)
+    assert eng.last_rollout_kernel() == 'gemm-stepwise'
+    assert torch.equal(par[4], gm.done) and torch.equal(par[5], gm.tpath)
+    np.testing.assert_array_equal(cpu(par[0][::H]), cpu(gm.obs[::H]))                     # reset states: same pool rows
+    np.testing.assert_allclose(cpu(par[0]), cpu(gm.obs), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(cpu(par[3]), cpu(gm.rew), rtol=2e-3, atol=2e-3)
+
+
+def test_resident_chunked_continuation_equals_one_call():
+    """A rollout cut into chunks (t0, resume, last_state: the sampler's step-granular stop rule) gives the trajectory of the single call."""
+    eng, dm, theta, pdims, pool = Hh.make_engine('swimmer', 5, (512, 512), (32, 32), seed=13)
+    B, T, H = 70, 12, 5
+    whole = eng.rollout(B, T, H, 'eps_rand', pool, seed=9)
+    assert eng.last_rollout_kernel() == 'resident'
+    whole = _fields(whole)
+    dev = eng.device
+    lts, lmd = torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)
+    parts, resume, t0 = [], None, 0
+    stop = torch.zeros(1, dtype=torch.int32, device=dev)
+    for Tc in (5, 4, 3):
+        tr = eng.rollout(B, Tc, H, 'eps_rand', pool, seed=9, t0=t0, resume=resume, last_state=(lts, lmd), stop=stop)
+        assert eng.last_rollout_kernel() == 'resident'
+        parts.append(_fields(tr))
+        resume = (tr.last_obs.clone(), lts.clone(), lmd.clone())
+        t0 += Tc
+    for i in range(6):
+        assert torch.equal(torch.cat([p[i] for p in parts], 0), whole[i])
+    assert torch.equal(parts[-1][6], whole[6])
+    # a raised stop flag turns the launch into a no-op
+    stop.fill_(1)
+    sentinel = eng.alloc_trajectory(B, 3, H)
+    sentinel.rew.fill_(-7.0)
+    eng.rollout(B, 3, H, 'eps_rand', pool, seed=9, t0=t0, resume=resume, last_state=(lts, lmd), stop=stop, out=sentinel)
+    assert bool((sentinel.rew == -7.0).all())
+
+
+def test_resident_kernel_scope():
+    """Shapes and modes outside the kernel's table stay on the step-wise GEMM path."""
+    eng, dm, theta, pdims, pool = Hh.make_engine('swimmer', 5, (512, 512), (32, 32), seed=3)
+    eng.rollout(129, 4, 4, 'step_rand', pool, seed=1)
+    assert eng.last_rollout_kernel() == 'gemm-stepwise'
+    eng.rollout(64, 4, 4, 'model_med', pool, seed=1)
+    assert eng.last_rollout_kernel() == 'gemm-stepwise'
+    eng.rollout(64, 4, 4, 'step_rand', pool, seed=1)
+    assert eng.last_rollout_kernel() == 'resident'
+    eng2 = Hh.make_engine('swimmer', 5, (256, 256), (32, 32), seed=3)[0]
+    eng2.rollout(64, 4, 4, 'step_rand', pool, seed=1)
+    assert eng2.last_rollout_kernel() == 'gemm-stepwise'
+    eng3 = Hh.make_engine('swimmer', 5, (64, 64), (32, 32), seed=3)[0]
+    eng3.rollout(64, 4, 4, 'step_rand', pool, seed=1)
+    assert eng3.last_rollout_kernel() == 'mfma-cooperative'
