@@ -225,7 +225,7 @@ def main():
                    "parallelism": "B-sharded x%d, sum all-reduce of g/FVP/scalars" % comm.world},
         "trpo_iter_ms": ms_per_step,
         "rollout": {"ms": roll_ms, "env_steps_per_s": units_per_step / (roll_ms * 1e-3),
-                    "kernel": {3: "gemm-stepwise", 2: "mfma-cooperative", 1: "mfma-head-per-wave", 0: "generic"}[variant]},
+                    "kernel": eng.last_rollout_kernel() or {3: "gemm-stepwise", 2: "mfma-cooperative", 1: "mfma-head-per-wave", 0: "generic"}[variant]},
         "roofline": {"bound": "mfma", "kernel": "rollout", "achieved": achieved, "peak": PEAK_F32, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_F32, "traffic": traffic, "traffic_source": traffic_src,
                      "hbm_frac_unfused_88B": (K * B * T_mean * (2 * ns + na) * 4) / (roll_ms * 1e-3) / PEAK_HBM,

@@ -19,6 +19,24 @@
 // Everything else (B > 128, other widths, Ant-sized inputs, model_mean_std / model_med, chunks with a stop flag) stays on rollout_gemm.hip.
 #include "mfma_common.h"
 
+// Developer instrumentation (SRC=rollout_resident.hip tools/build_variant.sh restiming -DRES_TIMING): shader-clock sums per phase of the
+// waves of compute workgroup 0 and of the first post workgroup, read back with metrpo_debug_resident_phases (tools/resident_phases.py).
+#ifdef RES_TIMING
+__device__ unsigned long long g_res_phase[2][8][8];
+__device__ unsigned long long g_res_wall[4][256];     // wall clock (100 MHz) of tile (round 0, tile 0): X pushed | X seen by workgroup 0 | P pushed by workgroup 0 | P complete at the post wave
+#define RT_WALL(i, cond) { if ((cond) && lane == 0 && tau < 256) g_res_wall[i][tau] = wall_clock64(); }
+extern "C" int32_t metrpo_debug_resident_wall(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_res_wall), sizeof(unsigned long long) * 1024) == hipSuccess ? 0 : -1; }
+#define RT_DECL unsigned long long rt_t = __builtin_readcyclecounter(); unsigned long long rt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RT_MARK(i) { const unsigned long long n_ = __builtin_readcyclecounter(); rt_acc[i] += n_ - rt_t; rt_t = n_; }
+#define RT_DUMP(role, first) { if (lane == 0 && (int)blockIdx.x == (first)) for (int i_ = 0; i_ < 8; ++i_) g_res_phase[role][wave][i_] = rt_acc[i_]; }
+extern "C" int32_t metrpo_debug_resident_phases(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_res_phase), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -1; }
+#else
+#define RT_DECL
+#define RT_MARK(i)
+#define RT_DUMP(role, first)
+#define RT_WALL(i, cond)
+#endif
+
 struct ResidentK {
     int R, round0, rounds_total, NT, NSL, U, PW, steps;   // rounds of this launch, first round, env tiles, slices, compute blocks, post waves per block, steps per round
     unsigned int seq0;                                    // packets of local step tau carry seq0 + tau + 1
@@ -49,116 +67,177 @@ struct ResSpin {
 };
 
 // ---- compute role ---------------------------------------------------------------------------------------------------------------------
+// true once a packet stamped for step `seq` (or, for a unit nobody is waiting for, a later one) has landed
+__device__ __forceinline__ bool res_fresh(unsigned long long pk, unsigned int seq) { return (int)((unsigned int)(pk >> 32) - seq) >= 0; }
+
+// A compute workgroup = 4 PRODUCER waves (one per SIMD) + 4 FINISHER waves.  Producer kappa owns a quarter of the hidden-0 units
+// (16 j-tiles / 4) and keeps the matching MFMA fragments of W0 and of the workgroup's W1 slice in REGISTERS for the whole rollout; it
+// walks the env tiles of the round in order: input packets of tile t (prefetched during tile t-1) -> J/4 x (NIN_KS + 4 MT) MFMAs in eight
+// independent accumulator chains -> its partial pre-activations of the slice's hidden-1 units for tile t into LDS, stamped.  No barrier:
+// the four SIMDs run one uninterrupted matrix-instruction stream each, and a tile's hand-over latency (partial sums out, next input
+// in: ~5 us) passes while the CU works on the round's other tiles.  Finisher i serves tiles t = i (mod 4): waits for the four stamps,
+// adds the quarters in order, bias + ReLU, output-layer MFMAs with the slice's W2 rows, packets out.
 template <int NS, int NIN, int DH, int WS>
 __device__ __forceinline__ void resident_compute(const ProblemDesc& pd, const ResidentK& z, const float* __restrict__ dyn, float* lds) {
-    constexpr int NIN_KS = cdiv(NIN, 4), KS4 = cdiv(NIN_KS, 4), J = DH / 16, MT = WS / 16, OUT_CB = cdiv(NS, 16), NSP = 16 * OUT_CB;
-    constexpr int O_W1 = 0, O_W2 = O_W1 + J * KS4 * 256, O_W3 = O_W2 + MT * J * 256, O_B1 = O_W3 + OUT_CB * MT * 256, O_B2 = O_B1 + DH;
+    constexpr int NIN_KS = cdiv(NIN, 4), J = DH / 16, JQ = J / 4, MT = WS / 16, OUT_CB = cdiv(NS, 16), NSP = 16 * OUT_CB;
+    constexpr int O_B1 = 0, O_STAMP = O_B1 + DH, O_PART = O_STAMP + 32;          // floats: b0 | stamps [8 tiles][4 producers] | partials [tile][producer][mt][lane] f32x4
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
-    const int K = pd.K, NSL = z.NSL;
+    const int K = pd.K, NSL = z.NSL, NT = z.NT;
     const int u = blockIdx.x, rho = u / (K * NSL), k = (u / NSL) % K, sl = u % NSL, col0 = sl * WS;
     const float* __restrict__ W = dyn + (size_t)k * pd.dyn.n_params;
     const float* __restrict__ W0 = W + pd.dyn.w_off[0];
     const float* __restrict__ W1 = W + pd.dyn.w_off[1];
     const float* __restrict__ W2 = W + pd.dyn.w_off[2];
-    // fragment images.  MFMA16(a, b, acc): a = A[m = lane & 15][k = lane >> 4], b = B[k = lane >> 4][n = lane & 15], acc[r] = D[4 (lane >> 4) + r][n]:
-    // a layer's output register r of lane (c, q) is unit 4q + r of its 16-unit tile, i.e. exactly the B operand of k-slot q of the
-    // next layer's MFMA number r -- so the next layer's A fragments are stored in that order and nothing is ever transposed.
-    for (int i = tid; i < J * KS4 * 256; i += 512) {                 // [j][g][lane][e]: W0[input 4 (4g + e) + q][unit 16 j + c]
-        const int e = i & 3, ln = (i >> 2) & 63, g = (i >> 8) % KS4, j = i / (256 * KS4);
-        const int in = 4 * (4 * g + e) + (ln >> 4);
-        lds[O_W1 + i] = (in < NIN) ? W0[(size_t)in * DH + 16 * j + (ln & 15)] : 0.0f;
-    }
-    for (int i = tid; i < MT * J * 256; i += 512) {                  // [mt][j][lane][r]: W1[unit 16 j + 4q + r][column col0 + 16 mt + c]
-        const int r = i & 3, ln = (i >> 2) & 63, j = (i >> 8) % J, mt = i / (256 * J);
-        lds[O_W2 + i] = W1[(size_t)(16 * j + 4 * (ln >> 4) + r) * DH + col0 + 16 * mt + (ln & 15)];
-    }
-    for (int i = tid; i < OUT_CB * MT * 256; i += 512) {             // [ocb][mt][lane][r]: W2[unit col0 + 16 mt + 4q + r][dim 16 ocb + c]
-        const int r = i & 3, ln = (i >> 2) & 63, mt = (i >> 8) % MT, ocb = i / (256 * MT);
-        const int dim = 16 * ocb + (ln & 15);
-        lds[O_W3 + i] = (dim < NS) ? W2[(size_t)(col0 + 16 * mt + 4 * (ln >> 4) + r) * NS + dim] : 0.0f;
-    }
     for (int i = tid; i < DH; i += 512) lds[O_B1 + i] = W[pd.dyn.b_off[0] + i];
-    for (int i = tid; i < WS; i += 512) lds[O_B2 + i] = W[pd.dyn.b_off[1] + col0 + i];
+    if (tid < 32) ((unsigned int*)lds)[O_STAMP + tid] = z.seq0;                  // stamps of this launch start at seq0 + 1
     __syncthreads();
-    if (wave >= z.NT) return;
-    const unsigned long long* xp = z.X + ((size_t)(rho * z.NT + wave) * (4 * NIN_KS)) * 16 + c;
-    unsigned long long* pp = z.P + ((((size_t)(rho * z.NT + wave) * K + k) * NSL + sl) * NSP) * 16 + c;
-    const f32x4* W1I = (const f32x4*)(lds + O_W1) + lane;
-    const f32x4* W2I = (const f32x4*)(lds + O_W2) + lane;
-    const f32x4* W3I = (const f32x4*)(lds + O_W3) + lane;
+    // MFMA16(a, b, acc): a = A[m = lane & 15][k = lane >> 4], b = B[k = lane >> 4][n = lane & 15], acc[r] = D[4 (lane >> 4) + r][n]: output register r
+    // of lane (c, q) is unit 4q + r of its 16-unit tile = the B operand of k-slot q of the next layer's MFMA number r, so the next
+    // layer's A fragments are gathered in that order and nothing is ever transposed.
+    if (wave < 4) {
+        const int kap = wave;
+        float w0f[JQ][NIN_KS], w1f[MT][JQ][4];
+#pragma unroll
+        for (int jj = 0; jj < JQ; ++jj) {
+            const int j = kap * JQ + jj;
+#pragma unroll
+            for (int kk = 0; kk < NIN_KS; ++kk) { const int in = 4 * kk + q; w0f[jj][kk] = (in < NIN) ? W0[(size_t)in * DH + 16 * j + c] : 0.0f; }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w1f[mt][jj][r] = W1[(size_t)(16 * j + 4 * q + r) * DH + col0 + 16 * mt + c];
+        }
+        const unsigned long long* xbase = z.X + ((size_t)(rho * NT) * (4 * NIN_KS)) * 16 + c;
+        unsigned long long pk[NIN_KS];
+        auto fetch = [&](int t) {
+#pragma unroll
+            for (int kk = 0; kk < NIN_KS; ++kk) pk[kk] = res_ld(xbase + ((size_t)t * (4 * NIN_KS) + 4 * kk + q) * 16);
+        };
+        fetch(0);
+        RT_DECL
+        for (int tau = 0; tau < z.steps; ++tau) {
+            const unsigned int seq = z.seq0 + (unsigned int)tau + 1u;
+            for (int t = 0; t < NT; ++t) {
+                float x[NIN_KS];
+                {
+                    ResSpin sp;
+                    for (;;) {
+                        bool ok = true;
+#pragma unroll
+                        for (int kk = 0; kk < NIN_KS; ++kk) { ok = ok && res_fresh(pk[kk], seq); x[kk] = __uint_as_float((unsigned int)pk[kk]); }
+                        if (__all(ok)) break;
+                        if (sp.give_up(z)) return;
+                        fetch(t);
+                    }
+                }
+                RT_MARK(0)
+                RT_WALL(1, blockIdx.x == 0 && wave == 0 && t == 0)
+                fetch((t + 1 < NT) ? t + 1 : 0);                          // next tile's input (stamped for the next step after the last tile): in flight during this tile's MFMAs
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 a2[MT][4];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a2[mt][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                auto layer0 = [&](int jj) {
+                    f32x4 h = *(const f32x4*)&lds[O_B1 + 16 * (kap * JQ + jj) + 4 * q];
+#pragma unroll
+                    for (int kk = 0; kk < NIN_KS; ++kk) h = MFMA16(w0f[jj][kk], x[kk], h);
+                    return h;
+                };
+                f32x4 hn = layer0(0);
+#pragma unroll
+                for (int jj = 0; jj < JQ; ++jj) {
+                    f32x4 h;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[r] = relu1(hn[r]);
+                    if (jj + 1 < JQ) hn = layer0(jj + 1);                 // the next tile's short dependent chain sits between this tile's independent MFMAs
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) a2[mt][r] = MFMA16(w1f[mt][jj][r], h[r], a2[mt][r]);
+                }
+                f32x4* part = (f32x4*)(lds + O_PART) + ((size_t)(t * 4 + kap) * MT) * 64 + lane;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) part[mt * 64] = (a2[mt][0] + a2[mt][1]) + (a2[mt][2] + a2[mt][3]);
+                if (lane == 0) __hip_atomic_store((unsigned int*)lds + O_STAMP + t * 4 + kap, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                RT_MARK(1)
+            }
+        }
+        RT_DUMP(0, 0)
+        return;
+    }
+    // ---- finishers
+    const int fi = wave - 4;
+    float w2f[OUT_CB][MT][4];
+    f32x4 b1f[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            b1f[mt][r] = W[pd.dyn.b_off[1] + col0 + 16 * mt + 4 * q + r];
+#pragma unroll
+            for (int ocb = 0; ocb < OUT_CB; ++ocb) { const int dim = 16 * ocb + c; w2f[ocb][mt][r] = (dim < NS) ? W2[(size_t)(col0 + 16 * mt + 4 * q + r) * NS + dim] : 0.0f; }
+        }
+    }
+    RT_DECL
     for (int tau = 0; tau < z.steps; ++tau) {
         const unsigned int seq = z.seq0 + (unsigned int)tau + 1u;
-        float x[NIN_KS];
-        {
-            ResSpin sp;
-            for (;;) {
-                unsigned long long pk[NIN_KS];
-                bool ok = true;
-#pragma unroll
-                for (int kk = 0; kk < NIN_KS; ++kk) pk[kk] = res_ld(xp + (4 * kk + q) * 16);
-#pragma unroll
-                for (int kk = 0; kk < NIN_KS; ++kk) { ok = ok && ((unsigned int)(pk[kk] >> 32) == seq); x[kk] = __uint_as_float((unsigned int)pk[kk]); }
-                if (__all(ok)) break;
-                if (sp.give_up(z)) return;
+        for (int t = fi; t < NT; t += 4) {
+            {
+                ResSpin sp;
+                for (;;) {
+                    const unsigned int st = __hip_atomic_load((const unsigned int*)lds + O_STAMP + t * 4 + (lane & 3), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (__all((int)(st - seq) >= 0)) break;
+                    if (sp.give_up(z)) return;
+                }
             }
-        }
-        f32x4 a2[MT][2];
+            RT_MARK(0)
+            const f32x4* part = (const f32x4*)(lds + O_PART) + ((size_t)(t * 4) * MT) * 64 + lane;
+            f32x4 o[OUT_CB];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) { a2[mt][0] = *(const f32x4*)&lds[O_B2 + 16 * mt + 4 * q]; a2[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        auto layer0 = [&](int j) {
-            f32x4 h = *(const f32x4*)&lds[O_B1 + 16 * j + 4 * q];
-#pragma unroll
-            for (int g = 0; g < KS4; ++g) {
-                const f32x4 wf = W1I[(j * KS4 + g) * 64];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) if (4 * g + e < NIN_KS) h = MFMA16(wf[e], x[4 * g + e], h);
-            }
-            return h;
-        };
-        f32x4 hn = layer0(0);
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-            f32x4 h;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = relu1(hn[r]);
-            if (j + 1 < J) hn = layer0(j + 1);                        // the next tile's short dependent chain sits between this tile's independent MFMAs
+            for (int ocb = 0; ocb < OUT_CB; ++ocb) o[ocb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const f32x4 wf = W2I[(mt * J + j) * 64];
+                f32x4 h2 = b1f[mt];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a2[mt][j & 1] = MFMA16(wf[r], h[r], a2[mt][j & 1]);
+                for (int kp = 0; kp < 4; ++kp) h2 += part[(kp * MT + mt) * 64];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h2[r] = relu1(h2[r]);
+#pragma unroll
+                for (int ocb = 0; ocb < OUT_CB; ++ocb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[ocb] = MFMA16(w2f[ocb][mt][r], h2[r], o[ocb]);
             }
+            unsigned long long* pp = z.P + ((((size_t)(rho * NT + t) * K + k) * NSL + sl) * NSP) * 16 + c;
+#pragma unroll
+            for (int ocb = 0; ocb < OUT_CB; ++ocb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int dim = 16 * ocb + 4 * q + r; if (dim < NS) res_st(pp + dim * 16, seq, o[ocb][r]); }
+            RT_MARK(1)
+            RT_WALL(2, blockIdx.x == 0 && t == 0)
         }
-        f32x4 o[OUT_CB];
-#pragma unroll
-        for (int ocb = 0; ocb < OUT_CB; ++ocb) o[ocb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            f32x4 h2;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h2[r] = relu1(a2[mt][0][r] + a2[mt][1][r]);
-#pragma unroll
-            for (int ocb = 0; ocb < OUT_CB; ++ocb) {
-                const f32x4 wf = W3I[(ocb * MT + mt) * 64];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[ocb] = MFMA16(wf[r], h2[r], o[ocb]);
-            }
-        }
-#pragma unroll
-        for (int ocb = 0; ocb < OUT_CB; ++ocb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const int dim = 16 * ocb + 4 * q + r; if (dim < NS) res_st(pp + dim * 16, seq, o[ocb][r]); }
     }
+    RT_DUMP(0, 0)
 }
 
 // ---- post role ------------------------------------------------------------------------------------------------------------------------
+// value held by lane q of an env's four lanes out of (a0, a1, a2, a3)
+__device__ __forceinline__ float sel4(int q, float a0, float a1, float a2, float a3) { return (q & 2) ? ((q & 1) ? a3 : a2) : ((q & 1) ? a1 : a0); }
+
+// The four lanes (c, q = 0..3) of env c hold the env's whole state in registers (the same values): nothing on the path from "last partial
+// sum arrived" to "next input pushed" goes through memory except the 16 x NA clipped / normalised actions (LDS).  Everything that does not
+// feed the next input -- Philox blocks and Box-Muller of the NEXT step, the reset row, head choice, output-layer bias, trajectory stores --
+// is issued while the compute workgroups are busy with the step.
 template <int ENV>
 __device__ __forceinline__ void resident_post(const ProblemDesc& pd, const RolloutK& r, const ResidentK& z, const float* __restrict__ dyn,
                                               const float* __restrict__ theta, const float* __restrict__ norm, float* lds) {
+    static_assert(ENV != METRPO_ENV_ANT && ENV != METRPO_ENV_HUMANOID, "horizon-terminated envs only");
     using C = Cfg<ENV, 64, 32>;
-    constexpr int NS = C::NS, NA = C::NA, NDROP = C::NDROP, NIN = C::NIN, PH = 32, NS_KS = C::NS_KS, NIN_KS = C::NIN_KS, OUT_CB = C::OUT_CB, NSP = C::NSP;
+    constexpr int NS = C::NS, NA = C::NA, NDROP = C::NDROP, NIN = C::NIN, PH = 32, NS_KS = C::NS_KS, NIN_KS = C::NIN_KS, NSP = C::NSP;
     constexpr int O_PF1 = NS_KS * 2 * 64, O_PF2 = O_PF1 + 16 * 64, O_B0 = O_PF2 + 8 * 64, O_B1 = O_B0 + 32, O_B2 = O_B1 + 32, IMG = ((O_B2 + 16 + 3) / 4) * 4;
-    constexpr int PW_LDS = 2 * 16 * NS + 2 * 16 * NA;
+    constexpr int PW_LDS = 2 * 16 * NA;
+    constexpr int DCH = (NS <= 12) ? NS : (NS + 1) / 2;               // output dims per batch of partial-sum loads (4 slices x DCH packets in flight per lane)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
     for (int i = tid; i < IMG; i += 512) {                            // policy fragment image (layout of k_big_pre_mfma, rollout_gemm.hip)
         float w = 0.0f;
@@ -176,7 +255,7 @@ __device__ __forceinline__ void resident_post(const ProblemDesc& pd, const Rollo
     if (wave >= z.PW || g >= z.R * z.NT) return;
     const int rho = g / z.NT, w = g % z.NT, round = z.round0 + rho;
     const int K = pd.K, NSL = z.NSL, B = r.B;
-    float* ST = lds + IMG + wave * PW_LDS; float* NX = ST + 16 * NS; float* UA = NX + 16 * NS; float* XA = UA + 16 * NA;
+    float* UA = lds + IMG + wave * PW_LDS; float* XA = UA + 16 * NA;
     const int b0 = w * 16, b = b0 + c;
     const bool active = b < B;
     const int bc = active ? b : 0;
@@ -184,10 +263,25 @@ __device__ __forceinline__ void resident_post(const ProblemDesc& pd, const Rollo
     const float* in_mean = norm; const float* in_std = norm + (NS + NA);
     const float* diff_mean = norm + 2 * (NS + NA); const float* diff_std = diff_mean + NS;
     const float* __restrict__ log_std = theta + C::pLS;
-    const int lim = min(16, max(0, B - b0)) * NS;
     unsigned long long* xp = z.X + ((size_t)(rho * z.NT + w) * (4 * NIN_KS)) * 16 + c;
     const unsigned long long* pbase = z.P + ((size_t)(rho * z.NT + w) * K) * NSL * NSP * 16 + c;
-    // ---- state at the first step of this round (every lane of an env computes the env's scalars redundantly: no broadcast needed)
+    // per-lane constants: normaliser of X element 4 kk + q, sigma and normaliser of action dims 4q .. 4q+3, de-normaliser of every state dim
+    float xm[NIN_KS], xr[NIN_KS], sig[4], am[4], ar[4], dmn[NS], dsd[NS];
+#pragma unroll
+    for (int kk = 0; kk < NIN_KS; ++kk) {
+        const int f = 4 * kk + q, src = (f < NS - NDROP) ? f + NDROP : NS + (f - (NS - NDROP));
+        xm[kk] = (f < NIN) ? in_mean[src] : 0.0f; xr[kk] = (f < NIN) ? 1.0f / in_std[src] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int d = 4 * q + j;
+        sig[j] = (d < NA) ? __expf(fmaxf(log_std[d], LOG_MIN_STD)) : 0.0f;
+        am[j] = (d < NA) ? in_mean[NS + d] : 0.0f; ar[j] = (d < NA) ? 1.0f / in_std[NS + d] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { dmn[i] = diff_mean[i]; dsd[i] = diff_std[i]; }
+    // ---- state at the first step of this round
+    float s[NS];
     int ts = 0, cur_model = 0;
     {
         int row = 0;
@@ -203,21 +297,39 @@ __device__ __forceinline__ void resident_post(const ProblemDesc& pd, const Rollo
             row = (r.reset_idx != nullptr) ? r.reset_idx[rb] : rng_index(dp.w, r.n_pool);
             cur_model = (r.reset_model != nullptr) ? r.reset_model[rb] : rng_index16(dp.z, K);
         }
-        for (int i = q; i < NS; i += 4)
-            ST[c * NS + i] = !active ? 0.0f : (row < 0 ? r.init_obs[(size_t)bc * NS + i] : r.pool[(size_t)row * NS + i]);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) s[i] = !active ? 0.0f : (row < 0 ? r.init_obs[(size_t)bc * NS + i] : r.pool[(size_t)row * NS + i]);
     }
-    wave_lds_sync();
+    // draws of a step: the step's Philox block (head choice, reset row / model) and the policy noise of this lane's action dims
+    uint4 dstep; float zn[4];
+    auto draw = [&](int t_loc) {
+        const size_t tb = (size_t)t_loc * B + bc;
+        dstep = rng_draw(r.seed, genv, r.t0 + t_loc, RNG_STEP, 0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int d0 = 4 * q + 2 * h;
+            zn[2 * h] = 0.0f; zn[2 * h + 1] = 0.0f;
+            if (d0 >= NA || r.determ) continue;
+            if (r.eps != nullptr) { zn[2 * h] = r.eps[tb * NA + d0]; if (d0 + 1 < NA) zn[2 * h + 1] = r.eps[tb * NA + d0 + 1]; }
+            else {
+                const uint4 blk = (d0 == 0) ? dstep : rng_draw(r.seed, genv, r.t0 + t_loc, RNG_STEP, d0 >> 1);
+                normal2(blk.x, blk.y, zn[2 * h], zn[2 * h + 1]);
+            }
+        }
+    };
+    draw(round * z.steps);
+    RT_DECL
     for (int tau = 0; tau < z.steps; ++tau) {
         const unsigned int seq = z.seq0 + (unsigned int)tau + 1u;
         const int t_loc = round * z.steps + tau;                      // row of the trajectory tensors; draws are keyed by r.t0 + t_loc
         const size_t tb = (size_t)t_loc * B + bc;
-        // ---- policy.get_actions (MFMA chain of k_big_pre_mfma)
+        // ---- policy.get_actions (MFMA chain of k_big_pre_mfma; input k-slot q of step s_ = state dim 4 s_ + q)
         f32x4 p0[2], p1[2];
         p0[0] = *(const f32x4*)&lds[O_B0 + 4 * q]; p0[1] = *(const f32x4*)&lds[O_B0 + 16 + 4 * q];
 #pragma unroll
         for (int s_ = 0; s_ < NS_KS; ++s_) {
-            const int f = 4 * s_ + q;
-            const float xs = (f < NS) ? ST[c * NS + f] : 0.0f;
+            const float xs = sel4(q, s[4 * s_], (4 * s_ + 1 < NS) ? s[(4 * s_ + 1 < NS) ? 4 * s_ + 1 : 0] : 0.0f, (4 * s_ + 2 < NS) ? s[(4 * s_ + 2 < NS) ? 4 * s_ + 2 : 0] : 0.0f,
+                                  (4 * s_ + 3 < NS) ? s[(4 * s_ + 3 < NS) ? 4 * s_ + 3 : 0] : 0.0f);
             p0[0] = MFMA16(lds[(s_ * 2 + 0) * 64 + lane], xs, p0[0]);
             p0[1] = MFMA16(lds[(s_ * 2 + 1) * 64 + lane], xs, p0[1]);
         }
@@ -242,122 +354,120 @@ __device__ __forceinline__ void resident_post(const ProblemDesc& pd, const Rollo
             m1 = MFMA16(lds[O_PF2 + (kk + 1) * 64 + lane], p1[(kk + 1) >> 2][(kk + 1) & 3], m1);
         }
         const f32x4 mu = m0 + m1;
-        // ---- actions: lane (c, q) owns action dims 4q .. 4q+3 = Philox chunks 2q, 2q+1 (chunk 0 = the step block), as k_big_pre_mfma
-        const uint4 dstep = rng_draw(r.seed, genv, r.t0 + t_loc, RNG_STEP, 0);
+        // ---- actions of dims 4q .. 4q+3 (env_helpers.py:599 clip; training.py:228,146-151 normalisation)
+        float av[4];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int d0 = 4 * q + 2 * h;
-            if (d0 >= NA) continue;
-            float zz[2] = {0.f, 0.f};
-            if (!r.determ && r.eps == nullptr) {
-                const uint4 blk = (d0 == 0) ? dstep : rng_draw(r.seed, genv, r.t0 + t_loc, RNG_STEP, d0 >> 1);
-                normal2(blk.x, blk.y, zz[0], zz[1]);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int d = d0 + j;
-                if (d >= NA) continue;
-                const float m = mu[2 * h + j];
-                float a = m;
-                if (!r.determ) a = fmaf((r.eps != nullptr) ? r.eps[tb * NA + d] : zz[j], __expf(fmaxf(log_std[d], LOG_MIN_STD)), m);
-                if (active) { r.act[tb * NA + d] = a; r.mean[tb * NA + d] = m; }
-                const float ac = fminf(fmaxf(a, -1.0f), 1.0f);            // env_helpers.py:599
-                UA[c * NA + d] = ac;
-                XA[c * NA + d] = (ac - in_mean[NS + d]) / in_std[NS + d];
-            }
+        for (int j = 0; j < 4; ++j) {
+            const int d = 4 * q + j;
+            if (d >= NA) continue;
+            av[j] = r.determ ? mu[j] : fmaf(zn[j], sig[j], mu[j]);
+            const float ac = fminf(fmaxf(av[j], -1.0f), 1.0f);
+            UA[c * NA + d] = ac;
+            XA[c * NA + d] = (ac - am[j]) * ar[j];
         }
         wave_lds_sync();
-        // ---- normalised, dropped input of the dynamics nets (training.py:228,146-151) -> X packets: element 4 kk + q of env c
 #pragma unroll
         for (int kk = 0; kk < NIN_KS; ++kk) {
-            const int f = 4 * kk + q;
-            float v = 0.0f;
-            if (active && f < NS - NDROP) v = (ST[c * NS + f + NDROP] - in_mean[f + NDROP]) / in_std[f + NDROP];
-            else if (active && f < NIN) v = XA[c * NA + f - (NS - NDROP)];
+            const int f = 4 * kk + q;                                 // X element of this lane: state dim f + NDROP, then the action dims
+            constexpr int NSD = NS - NDROP;
+            auto sd = [&](int e) { const int i = 4 * kk + e + NDROP; return (4 * kk + e < NSD) ? s[(i < NS) ? i : 0] : 0.0f; };
+            float v = sel4(q, sd(0), sd(1), sd(2), sd(3));
+            if (f >= NSD && f < NIN) v = XA[c * NA + f - NSD]; else v = (v - xm[kk]) * xr[kk];
+            if (!active || f >= NIN) v = 0.0f;
             res_st(xp + f * 16, seq, v);
         }
-        if (lim > 0) { const size_t base = ((size_t)t_loc * B + b0) * NS; for (int i = lane; i < lim; i += 64) r.obs[base + i] = ST[i]; }
-        // ---- which head this env follows this step (env_helpers.py:617-634)
-        int sel = cur_model;
+        RT_MARK(0)
+        RT_WALL(0, g == 0)
+        // ---- off the critical path (the compute workgroups are busy with the step now)
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int d = 4 * q + j; if (d < NA) { r.act[tb * NA + d] = av[j]; r.mean[tb * NA + d] = mu[j]; } }
+#pragma unroll
+            for (int i = 0; i < NS; ++i) if ((i & 3) == q) r.obs[tb * NS + i] = s[i];
+        }
+        int sel = cur_model;                                          // which head this env follows this step (env_helpers.py:617-634)
         if (r.sam_mode == METRPO_SAM_STEP_RAND) sel = (r.model_idx != nullptr) ? r.model_idx[tb] : rng_index(dstep.z, K);
         if (r.sam_mode == METRPO_SAM_ONE_MODEL) sel = 0;
-        // ---- output layer of head `sel`: bias + the slices' partial sums in slice order, dims 16 ocb + 4q + rr of env c
+        const int ts_new = ts + 1;
+        const bool dn = ts_new >= r.H;                                // env_helpers.py:603-604 (no state-dependent termination in these envs)
+        float prow[NS];
+        int next_model = cur_model;
+        if (dn) {                                                     // reset (env_helpers.py:585-595): row and model from this step's block
+            const size_t rb = (size_t)(t_loc + 1) * B + bc;
+            const int row = (r.reset_idx != nullptr) ? r.reset_idx[rb] : rng_index(dstep.w, r.n_pool);
+            next_model = (r.reset_model != nullptr) ? r.reset_model[rb] : rng_index16(dstep.z, K);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) prow[i] = r.pool[(size_t)row * NS + i];
+        }
+        float su2 = 0.0f;
+#pragma unroll
+        for (int d = 0; d < NA; ++d) { const float a = UA[c * NA + d]; su2 = fmaf(a, a, su2); }
         const float* __restrict__ b2 = dyn + (size_t)sel * pd.dyn.n_params + pd.dyn.b_off[2];
+        float bias[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) bias[i] = b2[i];
+        if (tau + 1 < z.steps) draw(t_loc + 1);                        // next step's block and noise
+        // ---- output layer of head `sel`: lane q adds slices q, q + 4, ... in slice order, then the four lanes' sums are added (fixed tree)
         const unsigned long long* pq = pbase + (size_t)sel * NSL * NSP * 16;
-        float outv[OUT_CB][4];
+        float out[NS];
+        RT_MARK(1)
         {
             ResSpin sp;
             for (;;) {
                 bool ok = true;
 #pragma unroll
-                for (int ocb = 0; ocb < OUT_CB; ++ocb)
+                for (int i = 0; i < NS; ++i) out[i] = 0.0f;
+                if (active) {
+                    for (int s0 = 0; s0 < NSL; s0 += 16) {
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const int dim = 16 * ocb + 4 * q + rr;
-                        float acc = (dim < NS) ? b2[dim] : 0.0f;
-                        if (active && dim < NS) {
-                            for (int s0 = 0; s0 < NSL; s0 += 8) {
-                                unsigned long long pk[8];
+                        for (int d0 = 0; d0 < NS; d0 += DCH) {
+                            unsigned long long pk[4][DCH];
 #pragma unroll
-                                for (int s1 = 0; s1 < 8; ++s1) pk[s1] = (s0 + s1 < NSL) ? res_ld(pq + ((size_t)(s0 + s1) * NSP + dim) * 16) : 0ull;
+                            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                                for (int s1 = 0; s1 < 8; ++s1)
-                                    if (s0 + s1 < NSL) { ok = ok && ((unsigned int)(pk[s1] >> 32) == seq); acc += __uint_as_float((unsigned int)pk[s1]); }
-                            }
+                                for (int i = 0; i < DCH; ++i) if (d0 + i < NS) pk[j][i] = res_ld(pq + ((size_t)(s0 + 4 * j + q) * NSP + d0 + i) * 16);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                for (int i = 0; i < DCH; ++i)
+                                    if (d0 + i < NS) { ok = ok && res_fresh(pk[j][i], seq); out[d0 + i] += __uint_as_float((unsigned int)pk[j][i]); }
                         }
-                        outv[ocb][rr] = acc;
                     }
+                }
                 if (__all(ok)) break;
                 if (sp.give_up(z)) return;
             }
         }
-        // ---- de-normalise + residual (training.py:257)
+        RT_MARK(2)
+        RT_WALL(3, g == 0)
+        // ---- de-normalise + residual (training.py:257), reward (env_helpers.py:601)
+        float v[NS];
 #pragma unroll
-        for (int ocb = 0; ocb < OUT_CB; ++ocb)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int dim = 16 * ocb + 4 * q + rr;
-                if (dim < NS) NX[c * NS + dim] = fmaf(diff_std[dim], outv[ocb][rr], diff_mean[dim]) + ST[c * NS + dim];
-            }
-        wave_lds_sync();
-        // ---- reward (env_helpers.py:601), done (:603-604), reset (:585-595); per-env scalars on every lane of the env
-        const float* xn = NX + c * NS;
-        float su2 = 0.0f;
-#pragma unroll
-        for (int d = 0; d < NA; ++d) { const float a = UA[c * NA + d]; su2 = fmaf(a, a, su2); }
+        for (int i = 0; i < NS; ++i) v[i] = fmaf(dsd[i], xor_sum(out[i]) + bias[i], dmn[i]) + s[i];
         float cost = 0.0f;
-        if constexpr (ENV == METRPO_ENV_SWIMMER) cost = -(xn[5] - 1e-2f * (su2 / (float)NA));
-        else if constexpr (ENV == METRPO_ENV_HALF_CHEETAH) cost = -fminf(fmaxf(xn[9] - 1e-1f * 0.5f * su2, -10.0f), 10.0f);
-        else if constexpr (ENV == METRPO_ENV_ANT) cost = -(xn[15] - 1e-2f * 0.5f * su2 + 0.05f);
+        if constexpr (ENV == METRPO_ENV_SWIMMER) cost = -(v[5] - 1e-2f * (su2 / (float)NA));
+        else if constexpr (ENV == METRPO_ENV_HALF_CHEETAH) cost = -fminf(fmaxf(v[9] - 1e-1f * 0.5f * su2, -10.0f), 10.0f);
         else if constexpr (ENV == METRPO_ENV_HOPPER) {
             float pen = 0.0f;
-            for (int j = 2; j < NS; ++j) pen += fmaxf(fabsf(xn[j]) - 100.0f, 0.0f);
-            cost = -(xn[5] - 0.01f * 0.5f * su2 - 10.0f * fmaxf(0.45f - xn[0], 0.0f) - 10.0f * fmaxf(fabsf(xn[1]) - 0.2f, 0.0f) - pen);
-        } else if constexpr (ENV == METRPO_ENV_SNAKE) cost = -(xn[7] - 1e-2f * 0.5f * su2);
-        bool dn = false;
-        if constexpr (ENV == METRPO_ENV_ANT) {
-            bool fin = true;
-            for (int j = 0; j < NS; ++j) fin = fin && isfinite(xn[j]);
-            dn = !((xn[2] >= 0.2f) && (xn[2] <= 1.0f) && fin);
-        }
-        int ts_new = ts + 1;
-        dn = dn || (ts_new >= r.H);
+#pragma unroll
+            for (int j = 2; j < NS; ++j) pen += fmaxf(fabsf(v[j]) - 100.0f, 0.0f);
+            cost = -(v[5] - 0.01f * 0.5f * su2 - 10.0f * fmaxf(0.45f - v[0], 0.0f) - 10.0f * fmaxf(fabsf(v[1]) - 0.2f, 0.0f) - pen);
+        } else if constexpr (ENV == METRPO_ENV_SNAKE) cost = -(v[7] - 1e-2f * 0.5f * su2);
         if (active && q == 0) { r.rew[tb] = -cost; r.done[tb] = dn ? 1 : 0; r.tpath[tb] = ts_new - 1; }
-        int row = -1;
-        if (dn) {
-            const size_t rb = (size_t)(t_loc + 1) * B + bc;
-            row = (r.reset_idx != nullptr) ? r.reset_idx[rb] : rng_index(dstep.w, r.n_pool);
-            cur_model = (r.reset_model != nullptr) ? r.reset_model[rb] : rng_index16(dstep.z, K);
-            ts_new = 0;
-        }
-        ts = ts_new;
-        for (int i = q; i < NS; i += 4) ST[c * NS + i] = !active ? 0.0f : (row >= 0 ? r.pool[(size_t)row * NS + i] : NX[c * NS + i]);
-        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < NS; ++i) s[i] = !active ? 0.0f : (dn ? prow[i] : v[i]);
+        ts = dn ? 0 : ts_new;
+        cur_model = next_model;
         if (round == z.rounds_total - 1 && tau == z.steps - 1 && active) {
-            if (r.last_obs != nullptr) for (int i = q; i < NS; i += 4) r.last_obs[(size_t)b * NS + i] = ST[c * NS + i];
+            if (r.last_obs != nullptr) {
+#pragma unroll
+                for (int i = 0; i < NS; ++i) if ((i & 3) == q) r.last_obs[(size_t)b * NS + i] = s[i];
+            }
             if (q == 0) { if (r.last_ts != nullptr) r.last_ts[b] = ts; if (r.last_model != nullptr) r.last_model[b] = cur_model; }
         }
+        RT_MARK(3)
     }
+    RT_DUMP(1, z.U)
 }
 
 template <int ENV, int DH, int WS>
@@ -373,9 +483,9 @@ __global__ void __launch_bounds__(512) k_rollout_resident(ProblemDesc pd, Rollou
 // ---- host side --------------------------------------------------------------------------------------------------------------------------
 template <int ENV, int DH, int WS> static size_t resident_lds_bytes() {
     using C = Cfg<ENV, 64, 32>;
-    constexpr int NIN_KS = C::NIN_KS, KS4 = cdiv(NIN_KS, 4), J = DH / 16, MT = WS / 16;
-    const size_t comp = (size_t)(J * KS4 * 256 + MT * J * 256 + C::OUT_CB * MT * 256 + DH + WS) * sizeof(float);
-    const size_t post = (size_t)((C::NS_KS * 2 + 24) * 64 + 84 + 8 * (2 * 16 * C::NS + 2 * 16 * C::NA)) * sizeof(float);
+    constexpr int MT = WS / 16;
+    const size_t comp = (size_t)(DH + 32 + 8 * 4 * MT * 256) * sizeof(float);
+    const size_t post = (size_t)((C::NS_KS * 2 + 24) * 64 + 84 + 8 * (2 * 16 * C::NA)) * sizeof(float);
     return std::max(comp, post);
 }
 typedef void (*resident_kernel_t)(ProblemDesc, RolloutK, ResidentK, const float*, const float*, const float*);
@@ -439,7 +549,9 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
     if (need > c->res_cap) {
         if (c->d_res) HIP_TRY(c, hipFree(c->d_res));
         c->d_res = nullptr; c->res_cap = 0;
-        HIP_TRY(c, hipExtMallocWithFlags(&c->d_res, need, hipDeviceMallocUncached));
+        const char* mem_env = getenv("METRPO_RESIDENT_MEM");              // experiment hook: 1 ordinary device memory, 2 fine-grained, else uncached
+        if (mem_env && mem_env[0] == '1') HIP_TRY(c, hipMalloc(&c->d_res, need));
+        else HIP_TRY(c, hipExtMallocWithFlags(&c->d_res, need, (mem_env && mem_env[0] == '2') ? hipDeviceMallocFinegrained : hipDeviceMallocUncached));
         HIP_TRY(c, hipMemsetAsync(c->d_res, 0, need, st));
         c->res_cap = need; c->res_seq = 0;
     }
