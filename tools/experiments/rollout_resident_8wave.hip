@@ -70,17 +70,18 @@ struct ResSpin {
 // true once a packet stamped for step `seq` (or, for a unit nobody is waiting for, a later one) has landed
 __device__ __forceinline__ bool res_fresh(unsigned long long pk, unsigned int seq) { return (int)((unsigned int)(pk >> 32) - seq) >= 0; }
 
-// A compute workgroup = 4 PRODUCER waves (one per SIMD) + 4 FINISHER waves.  Producer kappa owns a quarter of the hidden-0 units
-// (16 j-tiles / 4) and keeps the matching MFMA fragments of W0 and of the workgroup's W1 slice in REGISTERS for the whole rollout; it
-// walks the env tiles of the round in order: input packets of tile t (prefetched during tile t-1) -> J/4 x (NIN_KS + 4 MT) MFMAs in eight
-// independent accumulator chains -> its partial pre-activations of the slice's hidden-1 units for tile t into LDS, stamped.  No barrier:
-// the four SIMDs run one uninterrupted matrix-instruction stream each, and a tile's hand-over latency (partial sums out, next input
-// in: ~5 us) passes while the CU works on the round's other tiles.  Finisher i serves tiles t = i (mod 4): waits for the four stamps,
-// adds the quarters in order, bias + ReLU, output-layer MFMAs with the slice's W2 rows, packets out.
+// A compute workgroup = 8 waves, two per SIMD.  Wave w owns an eighth of the hidden-0 units (J/8 j-tiles) and keeps the matching MFMA
+// fragments of W0 and of the workgroup's W1 slice in REGISTERS for the whole rollout; it walks the env tiles of the round in order: input
+// packets of tile t (requested while tile t-1 is being worked on) -> J/8 x (NIN_KS + 4 MT) MFMAs in independent accumulator chains -> its
+// partial pre-activations of the slice's hidden-1 units for tile t into LDS, stamped.  No barrier anywhere: each SIMD runs two matrix-
+// instruction streams that fill each other's gaps, and a tile's hand-over latency (partial sums out, next input in: ~5 us) passes while the
+// CU works on the round's other tiles.  Wave t also FINISHES env tile t: once the eight stamps of the step are there (checked after each
+// of its own tiles, never waited for unless its next input is late), it adds the eighths in order, bias + ReLU, output-layer MFMAs with the
+// slice's W2 rows, packets out.
 template <int NS, int NIN, int DH, int WS>
 __device__ __forceinline__ void resident_compute(const ProblemDesc& pd, const ResidentK& z, const float* __restrict__ dyn, float* lds) {
-    constexpr int NIN_KS = cdiv(NIN + 1, 4), J = DH / 16, JQ = J / 4, MT = WS / 16, OUT_CB = cdiv(NS, 16), NSP = 16 * OUT_CB;      // NIN + 1: the bias rides as one more input
-    constexpr int O_STAMP = 0, O_PART = O_STAMP + 32;          // floats: stamps [8 tiles][4 producers] | partials [tile][producer][mt][lane] f32x4
+    constexpr int NIN_KS = cdiv(NIN + 1, 4), J = DH / 16, JQ = J / 8, MT = WS / 16, OUT_CB = cdiv(NS, 16), NSP = 16 * OUT_CB;      // NIN + 1: the bias rides as one more input
+    constexpr int O_STAMP = 0, O_PART = O_STAMP + 64;                          // floats: stamps [8 tiles][8 waves] | partials [tile][wave][mt][lane] f32x4
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
     const int K = pd.K, NSL = z.NSL, NT = z.NT;
     const int u = blockIdx.x, rho = u / (K * NSL), k = (u / NSL) % K, sl = u % NSL, col0 = sl * WS;
@@ -88,166 +89,137 @@ __device__ __forceinline__ void resident_compute(const ProblemDesc& pd, const Re
     const float* __restrict__ W0 = W + pd.dyn.w_off[0];
     const float* __restrict__ W1 = W + pd.dyn.w_off[1];
     const float* __restrict__ W2 = W + pd.dyn.w_off[2];
-    if (tid < 32) ((unsigned int*)lds)[O_STAMP + tid] = z.seq0;                  // stamps of this launch start at seq0 + 1
+    if (tid < 64) ((unsigned int*)lds)[O_STAMP + tid] = z.seq0;                  // stamps of this launch start at seq0 + 1
     __syncthreads();
     // MFMA16(a, b, acc): a = A[m = lane & 15][k = lane >> 4], b = B[k = lane >> 4][n = lane & 15], acc[r] = D[4 (lane >> 4) + r][n]: output register r
     // of lane (c, q) is unit 4q + r of its 16-unit tile = the B operand of k-slot q of the next layer's MFMA number r, so the next
     // layer's A fragments are gathered in that order and nothing is ever transposed.
-    if (wave < 4) {
-        const int kap = wave;
+    const int kap = wave;
 #ifdef RES_TIMING
-        unsigned long long rt_stale = 0;
+    unsigned long long rt_stale = 0;
 #endif
-        float w0f[JQ][NIN_KS], w1f[MT][JQ][4];
-#pragma unroll
-        for (int jj = 0; jj < JQ; ++jj) {
-            const int j = kap * JQ + jj;
-#pragma unroll
-            for (int kk = 0; kk < NIN_KS; ++kk) {                      // input slot NIN carries the constant 1 (post wave): its weight row is the bias
-                const int in = 4 * kk + q;
-                w0f[jj][kk] = (in < NIN) ? W0[(size_t)in * DH + 16 * j + c] : (in == NIN ? W[pd.dyn.b_off[0] + 16 * j + c] : 0.0f);
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) w1f[mt][jj][r] = W1[(size_t)(16 * j + 4 * q + r) * DH + col0 + 16 * mt + c];
-        }
-        const unsigned long long* xbase = z.X + ((size_t)(rho * NT) * (4 * NIN_KS)) * 16 + c;
-        unsigned long long pk[NIN_KS];
-        auto fetch = [&](int t) {
-#pragma unroll
-            for (int kk = 0; kk < NIN_KS; ++kk) pk[kk] = res_ld(xbase + ((size_t)t * (4 * NIN_KS) + 4 * kk + q) * 16);
-        };
-        // hidden-0 tiles of this producer for the env tile whose input is in pk (waits for it): JQ independent chains of NIN_KS MFMAs
-        auto layer0 = [&](f32x4 (&h)[JQ], int t, unsigned int seq, auto&& flush) -> bool {
-            float x[NIN_KS];
-            ResSpin sp;
-            for (;;) {
-                bool ok = true;
-#pragma unroll
-                for (int kk = 0; kk < NIN_KS; ++kk) { ok = ok && res_fresh(pk[kk], seq); x[kk] = __uint_as_float((unsigned int)pk[kk]); }
-                if (__all(ok)) break;
-                flush();                                                // the input is late: it may be waiting for the very tile whose hand-over is still pending here
-                if (sp.give_up(z)) return false;
-                fetch(t);
-            }
-#ifdef RES_TIMING
-            if (sp.spins > 0) rt_stale += 1;
-#endif
-            fetch((t + 1 < NT) ? t + 1 : 0);                            // the next tile's input (after the last tile: stamped for the next step) is in flight during this tile's MFMAs
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int jj = 0; jj < JQ; ++jj) h[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < NIN_KS; ++kk)
-#pragma unroll
-                for (int jj = 0; jj < JQ; ++jj) h[jj] = MFMA16(w0f[jj][kk], x[kk], h[jj]);
-            return true;
-        };
-        // this producer's quarter of the slice's hidden-1 pre-activations: 4 MT independent chains over its JQ x 4 k-steps
-        auto layer1 = [&](f32x4 (&a2)[MT][4], f32x4 (&h)[JQ]) {
-#pragma unroll
-            for (int jj = 0; jj < JQ; ++jj)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float hr = relu1(h[jj][r]);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) a2[mt][r] = (jj == 0) ? MFMA16(w1f[mt][jj][r], hr, (f32x4{0.f, 0.f, 0.f, 0.f})) : MFMA16(w1f[mt][jj][r], hr, a2[mt][r]);
-                }
-        };
-        // partial sums of env tile t out to the finisher (LDS operations of one wave complete in issue order: the stamp lands after the data)
-        auto hand_over = [&](f32x4 (&a2)[MT][4], int t, unsigned int seq) {
-            f32x4* part = (f32x4*)(lds + O_PART) + ((size_t)(t * 4 + kap) * MT) * 64 + lane;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) part[mt * 64] = (a2[mt][0] + a2[mt][1]) + (a2[mt][2] + a2[mt][3]);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            if (lane == 0) __hip_atomic_store((unsigned int*)lds + O_STAMP + t * 4 + kap, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        };
-        fetch(0);
-        RT_DECL
-        // flattened (step, tile) sequence, two tiles per trip on alternating accumulator sets: the tail of a tile (chain drain, sums, LDS
-        // write) is issued after the NEXT tile's hidden-0 MFMAs, so the matrix pipe does not idle between tiles
-        const int total = z.steps * NT;
-        f32x4 accA[MT][4], accB[MT][4], h[JQ];
-        int tA = 0, tB = 0; unsigned int sA = z.seq0 + 1u, sB = sA;
-        bool pendA = false, pendB = false;
-        int t = 0; unsigned int seq = z.seq0 + 1u;
-        auto advance = [&]() { if (++t == NT) { t = 0; ++seq; } };
-        auto flushA = [&]() { if (pendA) { hand_over(accA, tA, sA); pendA = false; } };
-        auto flushB = [&]() { if (pendB) { hand_over(accB, tB, sB); pendB = false; } };
-        for (int it = 0; it < total; it += 2) {
-            if (!layer0(h, t, seq, flushB)) return;
-            RT_MARK(0)
-            RT_WALL(1, blockIdx.x == 0 && wave == 0 && t == 0, (int)(seq - z.seq0) - 1)
-            flushB();
-            layer1(accA, h);
-            tA = t; sA = seq; pendA = true; advance();
-            if (it + 1 < total) {
-                if (!layer0(h, t, seq, flushA)) return;
-                flushA();
-                layer1(accB, h);
-                tB = t; sB = seq; pendB = true; advance();
-            }
-            RT_MARK(1)
-        }
-        flushA(); flushB();
-#ifdef RES_TIMING
-        rt_acc[2] = rt_stale;
-#endif
-        RT_DUMP(0, 0)
-        return;
-    }
-    // ---- finishers
-    const int fi = wave - 4;
-    float w2f[OUT_CB][MT][4];
+    float w0f[JQ][NIN_KS], w1f[MT][JQ][4], w2f[OUT_CB][MT][4];
     f32x4 b1f[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    for (int jj = 0; jj < JQ; ++jj) {
+        const int j = kap * JQ + jj;
+#pragma unroll
+        for (int kk = 0; kk < NIN_KS; ++kk) {                          // input slot NIN carries the constant 1 (post wave): its weight row is the bias
+            const int in = 4 * kk + q;
+            w0f[jj][kk] = (in < NIN) ? W0[(size_t)in * DH + 16 * j + c] : (in == NIN ? W[pd.dyn.b_off[0] + 16 * j + c] : 0.0f);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w1f[mt][jj][r] = W1[(size_t)(16 * j + 4 * q + r) * DH + col0 + 16 * mt + c];
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             b1f[mt][r] = W[pd.dyn.b_off[1] + col0 + 16 * mt + 4 * q + r];
 #pragma unroll
             for (int ocb = 0; ocb < OUT_CB; ++ocb) { const int dim = 16 * ocb + c; w2f[ocb][mt][r] = (dim < NS) ? W2[(size_t)(col0 + 16 * mt + 4 * q + r) * NS + dim] : 0.0f; }
         }
-    }
-    RT_DECL
-    for (int tau = 0; tau < z.steps; ++tau) {
-        const unsigned int seq = z.seq0 + (unsigned int)tau + 1u;
-        for (int t = fi; t < NT; t += 4) {
-            {
-                ResSpin sp;
-                for (;;) {
-                    const unsigned int st = __hip_atomic_load((const unsigned int*)lds + O_STAMP + t * 4 + (lane & 3), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (__all((int)(st - seq) >= 0)) break;
-                    if (sp.give_up(z)) return;
-                }
-            }
-            RT_MARK(0)
-            const f32x4* part = (const f32x4*)(lds + O_PART) + ((size_t)(t * 4) * MT) * 64 + lane;
-            f32x4 o[OUT_CB];
+    const unsigned long long* xbase = z.X + ((size_t)(rho * NT) * (4 * NIN_KS)) * 16 + c;
+    unsigned long long pk[NIN_KS];
+    auto fetch = [&](int t) {
 #pragma unroll
-            for (int ocb = 0; ocb < OUT_CB; ++ocb) o[ocb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kk = 0; kk < NIN_KS; ++kk) pk[kk] = res_ld(xbase + ((size_t)t * (4 * NIN_KS) + 4 * kk + q) * 16);
+    };
+    // ---- finishing env tile `wave` of step stamp fS: pending from this wave's own hand-over of that tile until the other seven have landed
+    bool fin_pending = false; unsigned int fS = 0;
+    auto try_finish = [&]() {
+        if (!fin_pending) return;
+        const unsigned int st = __hip_atomic_load((const unsigned int*)lds + O_STAMP + wave * 8 + (lane & 7), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!__all((int)(st - fS) >= 0)) return;
+        fin_pending = false;
+        const f32x4* part = (const f32x4*)(lds + O_PART) + ((size_t)(wave * 8) * MT) * 64 + lane;
+        f32x4 o[OUT_CB][MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                f32x4 h2 = b1f[mt];
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x4 h2 = b1f[mt];
 #pragma unroll
-                for (int kp = 0; kp < 4; ++kp) h2 += part[(kp * MT + mt) * 64];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) h2[r] = relu1(h2[r]);
-#pragma unroll
-                for (int ocb = 0; ocb < OUT_CB; ++ocb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[ocb] = MFMA16(w2f[ocb][mt][r], h2[r], o[ocb]);
-            }
-            unsigned long long* pp = z.P + ((((size_t)(rho * NT + t) * K + k) * NSL + sl) * NSP) * 16 + c;
+            for (int kp = 0; kp < 8; ++kp) h2 += part[(kp * MT + mt) * 64];
 #pragma unroll
             for (int ocb = 0; ocb < OUT_CB; ++ocb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const int dim = 16 * ocb + 4 * q + r; if (dim < NS) res_st(pp + dim * 16, seq, o[ocb][r]); }
-            RT_MARK(1)
-            RT_WALL(2, blockIdx.x == 0 && t == 0, tau)
+                for (int r = 0; r < 4; ++r) {
+                    const float hr = relu1(h2[r]);
+                    o[ocb][mt] = (r == 0) ? MFMA16(w2f[ocb][mt][r], hr, (f32x4{0.f, 0.f, 0.f, 0.f})) : MFMA16(w2f[ocb][mt][r], hr, o[ocb][mt]);
+                }
         }
+        unsigned long long* pp = z.P + ((((size_t)(rho * NT + wave) * K + k) * NSL + sl) * NSP) * 16 + c;
+#pragma unroll
+        for (int ocb = 0; ocb < OUT_CB; ++ocb) {
+            f32x4 ov = o[ocb][0];
+#pragma unroll
+            for (int mt = 1; mt < MT; ++mt) ov += o[ocb][mt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int dim = 16 * ocb + 4 * q + r; if (dim < NS) res_st(pp + dim * 16, fS, ov[r]); }
+        }
+        RT_WALL(2, blockIdx.x == 0 && wave == 0, (int)(fS - z.seq0) - 1)
+    };
+    fetch(0);
+    RT_DECL
+    int t = 0; unsigned int seq = z.seq0 + 1u;
+    const int total = z.steps * NT;
+    for (int it = 0; it < total; ++it) {
+        // ---- input of tile t (waits for it; a pending finish goes first: the late input may be waiting for exactly that tile)
+        float x[NIN_KS];
+        {
+            ResSpin sp;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int kk = 0; kk < NIN_KS; ++kk) { ok = ok && res_fresh(pk[kk], seq); x[kk] = __uint_as_float((unsigned int)pk[kk]); }
+                if (__all(ok)) break;
+                try_finish();
+                if (sp.give_up(z)) return;
+                fetch(t);
+            }
+#ifdef RES_TIMING
+            if (sp.spins > 0) rt_stale += 1;
+#endif
+        }
+        RT_MARK(0)
+        RT_WALL(1, blockIdx.x == 0 && wave == 0 && t == 0, (int)(seq - z.seq0) - 1)
+        fetch((t + 1 < NT) ? t + 1 : 0);                                // the next tile's input (after the last tile: stamped for the next step) is in flight during this tile's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- hidden-0 tiles of this wave: JQ independent chains of NIN_KS MFMAs; then its eighth of the slice's hidden-1 pre-activations
+        f32x4 h[JQ], a2[MT][4];
+#pragma unroll
+        for (int jj = 0; jj < JQ; ++jj) h[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < NIN_KS; ++kk)
+#pragma unroll
+            for (int jj = 0; jj < JQ; ++jj) h[jj] = MFMA16(w0f[jj][kk], x[kk], h[jj]);
+#pragma unroll
+        for (int jj = 0; jj < JQ; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float hr = relu1(h[jj][r]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a2[mt][r] = (jj == 0) ? MFMA16(w1f[mt][jj][r], hr, (f32x4{0.f, 0.f, 0.f, 0.f})) : MFMA16(w1f[mt][jj][r], hr, a2[mt][r]);
+            }
+        // ---- partial sums out (LDS operations of one wave complete in issue order: the stamp lands after the data)
+        f32x4* part = (f32x4*)(lds + O_PART) + ((size_t)(t * 8 + kap) * MT) * 64 + lane;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) part[mt * 64] = (a2[mt][0] + a2[mt][1]) + (a2[mt][2] + a2[mt][3]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (lane == 0) __hip_atomic_store((unsigned int*)lds + O_STAMP + t * 8 + kap, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (t == wave) { fin_pending = true; fS = seq; }
+        try_finish();
+        RT_MARK(1)
+        if (++t == NT) { t = 0; ++seq; }
     }
+    {
+        ResSpin sp;
+        while (fin_pending) { try_finish(); if (fin_pending && sp.give_up(z)) return; }
+    }
+#ifdef RES_TIMING
+    rt_acc[2] = rt_stale;
+#endif
     RT_DUMP(0, 0)
 }
 
@@ -515,7 +487,7 @@ __global__ void __launch_bounds__(512) k_rollout_resident(ProblemDesc pd, Rollou
 template <int ENV, int DH, int WS> static size_t resident_lds_bytes() {
     using C = Cfg<ENV, 64, 32>;
     constexpr int MT = WS / 16;
-    const size_t comp = (size_t)(32 + 8 * 4 * MT * 256) * sizeof(float);
+    const size_t comp = (size_t)(64 + 8 * 8 * MT * 256) * sizeof(float);
     const size_t post = (size_t)((C::NS_KS * 2 + 24) * 64 + 84 + 8 * (2 * 16 * C::NA)) * sizeof(float);
     return std::max(comp, post);
 }

@@ -30,10 +30,10 @@ for R in (3, 1):
     buf = (C.c_ulonglong * 128)()
     if not hasattr(lib, 'metrpo_debug_resident_phases') or lib.metrpo_debug_resident_phases(buf) != 0:
         continue
-    for role, names in ((0, ['producers 0-3: wait for X | finishers 4-7: wait for partials', 'producers: MFMA burst + partial write | finishers: sum, layer 2, push']), (1, ['policy + action + X push', 'obs row + head choice', 'wait for P + sum', 'residual, reward, reset'])):
+    for role, names in ((0, ['producers 0-3: wait for X | finishers 4-7: wait for partials', 'producers: MFMA bursts + hand-over | finishers: sum, layer 2, push', 'producers: tiles per step whose requested input was late']), (1, ['policy + action + X push', 'obs row + head choice', 'wait for P + sum', 'residual, reward, reset'])):
         print('  %s workgroup, cycles per step per wave:' % ('compute' if role == 0 else 'first post'))
         for i, nme in enumerate(names):
-            print('    %-34s %s' % (nme, ' '.join('%6.0f' % (buf[role * 64 + w * 8 + i] / H) for w in range(8))))
+            print('    %-34s %s' % (nme, ' '.join('%7.1f' % (buf[role * 64 + w * 8 + i] / H) for w in range(8))))
     wall = (C.c_ulonglong * 1024)()
     if hasattr(lib, 'metrpo_debug_resident_wall') and lib.metrpo_debug_resident_wall(wall) == 0:
         import numpy as np
