@@ -119,6 +119,8 @@ def main():
     n_dev = torch.cuda.device_count()
     oversub = args.gpus > n_dev                               # fewer devices than ranks: share them (RCCL refuses that; gloo + IPC works)
     backend = os.environ.get('METRPO_BENCH_BACKEND', 'gloo' if oversub else 'nccl')
+    if oversub:
+        os.environ['METRPO_NO_RESIDENT'] = '1'                # the resident rollout kernel needs its whole grid on the chip at once: not with several ranks per device
     dev = int(os.environ.get('METRPO_BENCH_DEVICE', int(os.environ.get('LOCAL_RANK', '0')) % max(n_dev, 1)))
     torch.cuda.set_device(dev)
     if backend == 'nccl':
