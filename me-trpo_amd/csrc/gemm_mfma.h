@@ -11,6 +11,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef GEMM_XCD_SWIZZLE
 #define GEMM_XCD_SWIZZLE 1
 #endif
+#ifndef GEMM_A_KMAJOR
+#define GEMM_A_KMAJOR 1
+#endif
 
 enum { EPI_BIAS_ID = 0, EPI_BIAS_RELU = 1, EPI_BIAS_TANH = 2, EPI_RELU_MASK = 3, EPI_ADAM = 4, EPI_PLAIN = 5, EPI_PARTIAL = 6, EPI_DTANH = 7, EPI_RELU_OUT = 8, EPI_RELU_OUT64 = 9, EPI_RELU_OUT48 = 10 };   // fused skinny layer of <= 32 / <= 64 / <= 48 columns
 
@@ -37,7 +40,14 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
                                                    const float* __restrict__ W, long long strideW, int ldw,
                                                    float* __restrict__ C, long long strideC, int ldc, int M, int N, int Kd, GemmEpi ep) {
     constexpr int BM = 64 * TM, BN = 64 * TN, BK = 16;     // BK = 32 for the 64x64 tile (half the barriers, half the resident blocks): C3 step 0.204 -> 0.218 ms, not kept
-    __shared__ __attribute__((aligned(16))) float As[2][BK][BM + 4];     // As[k][m]
+    // A tile in LDS.  Row-major A (the forward layers: !TA) with aligned rows keeps its k-contiguous quads: As[m][k] (row stride BK + 4 floats: the
+    // 16 lanes of a b128 pass hit 16 disjoint bank groups), written by ONE ds_write_b128 per staged quad instead of four scattered b32 stores and
+    // read by one ds_read_b128 per four MFMA steps -- slot lk of step 4 h + e then contracts k = 8 h + 4 lk + e, and the B operand reads that row.
+    // Measured (bench.py --config): 128x128 tiles +1.8 % (C4 5.14 -> 5.05 s); 64x64 tiles -3 % (C3 160 -> 165 ms: eight MFMAs per k-tile and wave do not
+    // cover the longer b128 latency), so only the large tile takes it.
+    constexpr bool AKM = GEMM_A_KMAJOR && !TA && AL && TM * TN == 4;
+    constexpr int AS_ROWS = AKM ? BM : BK, AS_COLS = AKM ? BK + 4 : BM + 4;
+    __shared__ __attribute__((aligned(16))) float As[2][AS_ROWS][AS_COLS];   // As[k][m], or As[m][k] (AKM)
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + 4];     // Bs[k][n]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -124,7 +134,8 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
 #pragma unroll
             for (int p = 0; p < SA_P; ++p) {
                 const int kq = (tid & 3) * 4, m = (tid >> 2) + p * 64;
-                As[buf][kq + 0][m] = ra[p].x; As[buf][kq + 1][m] = ra[p].y; As[buf][kq + 2][m] = ra[p].z; As[buf][kq + 3][m] = ra[p].w;
+                if constexpr (AKM) *(float4*)&As[buf][m][kq] = ra[p];
+                else { As[buf][kq + 0][m] = ra[p].x; As[buf][kq + 1][m] = ra[p].y; As[buf][kq + 2][m] = ra[p].z; As[buf][kq + 3][m] = ra[p].w; }
             }
         } else {
 #pragma unroll
@@ -153,6 +164,26 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
         const int buf = kt & 1;
         if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);              // global loads of the next tile fly under the MFMAs
         const int li = lane & 31, lk = lane >> 5;
+        if constexpr (AKM) {
+#pragma unroll
+            for (int h8 = 0; h8 < BK / 8; ++h8) {
+                float4 a4[TM];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a4[i] = *(const float4*)&As[buf][wm * 32 * TM + i * 32 + li][8 * h8 + 4 * lk];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float bf[TN];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bf[j] = Bs[buf][8 * h8 + 4 * lk + e][wn * 32 * TN + j * 32 + li];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const float af = (e == 0) ? a4[i].x : (e == 1) ? a4[i].y : (e == 2) ? a4[i].z : a4[i].w;
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float af[TM], bf[TN];
@@ -164,6 +195,7 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
         }
         if (colsum) {
 #pragma unroll
@@ -200,6 +232,7 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
         __shared__ float W2s[64][NOP + 1];
         typedef float f32x4_ __attribute__((ext_vector_type(4)));
         float* Hlo = &As[0][0][0]; float* Hhi = &Bs[0][0][0];                      // each 32 x (BM + 4) floats
+        static_assert(2 * AS_ROWS * AS_COLS >= 32 * (BM + 4), "A tile too small for the fused output layer's staging");
         const int c16 = lane & 15, q4 = lane >> 4;
         f32x4_ o[TM][NT];
 #pragma unroll
