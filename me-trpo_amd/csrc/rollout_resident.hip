@@ -67,7 +67,10 @@ struct ResSpin {
 };
 
 // ---- compute role ---------------------------------------------------------------------------------------------------------------------
-// true once a packet stamped for step `seq` (or, for a unit nobody is waiting for, a later one) has landed
+// true once a packet stamped for step `seq` has landed -- or a LATER one.  Later stamps only ever meet a reader nobody waits for: the post wave
+// releases the input of step tau + 1 of a tile when the partial sums of the heads its 16 envs SELECTED at step tau are in, so a workgroup of a head
+// no env of the tile selected may still be on step tau when its input slot (or its producers' LDS partials) already carries tau + 1.  It then
+// computes on what it finds -- a result nobody reads -- and catches up; an exact-match test would leave it waiting for a stamp that is gone.
 __device__ __forceinline__ bool res_fresh(unsigned long long pk, unsigned int seq) { return (int)((unsigned int)(pk >> 32) - seq) >= 0; }
 
 // A compute workgroup = 4 PRODUCER waves (one per SIMD) + 4 FINISHER waves.  Producer kappa owns a quarter of the hidden-0 units
@@ -580,9 +583,7 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
     if (need > c->res_cap) {
         if (c->d_res) HIP_TRY(c, hipFree(c->d_res));
         c->d_res = nullptr; c->res_cap = 0;
-        const char* mem_env = getenv("METRPO_RESIDENT_MEM");              // experiment hook: 1 ordinary device memory, 2 fine-grained, else uncached
-        if (mem_env && mem_env[0] == '1') HIP_TRY(c, hipMalloc(&c->d_res, need));
-        else HIP_TRY(c, hipExtMallocWithFlags(&c->d_res, need, (mem_env && mem_env[0] == '2') ? hipDeviceMallocFinegrained : hipDeviceMallocUncached));
+        HIP_TRY(c, hipExtMallocWithFlags(&c->d_res, need, hipDeviceMallocUncached));     // (ordinary and fine-grained device memory measured the same: the hop is the fabric round trip)
         HIP_TRY(c, hipMemsetAsync(c->d_res, 0, need, st));
         c->res_cap = need; c->res_seq = 0;
     }
