@@ -214,6 +214,10 @@ def main():
     if args.config == 'C1' and variant == 2 and os.path.exists(tpath):
         traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
         traffic_src = 'profiles/' + os.path.basename(tpath) + ' (rocprofv3 --pmc, offline run of the same launch)'
+    rpath = os.path.join(REPO, 'profiles', 'r03_resident_traffic.json')
+    if args.config == 'C0p' and eng.last_rollout_kernel() == 'resident' and os.path.exists(rpath):
+        traffic = json.load(open(rpath)).get('hbm_bytes_per_launch')
+        traffic_src = 'profiles/r03_resident_traffic.json (rocprofv3 --pmc, offline run of the same launch; mostly the uncached step hand-over packets)'
     out = {
         "metric": "imagined env-steps/sec (KxBxH) over the full TRPO iteration", "value": units_per_step / (dt / args.steps),
         "unit": "env-steps/s", "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup,
