@@ -24,7 +24,9 @@ def _fields(tr):
                                                ('swimmer', 3, 5, 7, 7, 'one_model'),          # one partial tile
                                                ('hopper', 5, 37, 8, 8, 'step_rand'),
                                                ('snake', 4, 50, 8, 5, 'eps_rand'),
-                                               ('half_cheetah', 5, 77, 6, 6, 'step_rand')])   # ns = 18: two output-dim tiles, 6 input k-steps
+                                               ('half_cheetah', 5, 77, 6, 6, 'step_rand'),    # ns = 18: two output-dim tiles, 6 input k-steps
+                                               ('swimmer', 5, 100, 12, 4, 'step_rand'),       # T = 3 H: the three rounds side by side, every reset from the supplied draws
+                                               ('hopper', 3, 1, 3, 1, 'eps_rand')])           # one env, every step ends an episode
 def test_resident_rollout_against_oracle(env, K, B, T, H, mode):
     eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (512, 512), (32, 32), seed=61)
     th = theta.astype(np.float32).astype(np.float64)
@@ -79,6 +81,26 @@ def test_resident_rounds_side_by_side_equal_sequential_rounds(K, B, H, R, ws, mo
     np.testing.assert_array_equal(cpu(par[0][::H]), cpu(gm.obs[::H]))                     # reset states: same pool rows
     np.testing.assert_allclose(cpu(par[0]), cpu(gm.obs), rtol=2e-3, atol=2e-3)
     np.testing.assert_allclose(cpu(par[3]), cpu(gm.rew), rtol=2e-3, atol=2e-3)
+
+
+def test_resident_deterministic_policy_and_repeatability():
+    """determ=True follows the policy mean (no noise draws); two launches with the same seed are bit-identical at the params-file size (600 steps:
+    the packets of the second launch carry later stamps on the same slots), a different seed is a different trajectory."""
+    eng, dm, theta, pdims, pool = Hh.make_engine('swimmer', 5, (512, 512), (32, 32), seed=21)
+    B, H, R = 100, 200, 3
+    a = _fields(eng.rollout(B, R * H, H, 'step_rand', pool, seed=4))
+    assert eng.last_rollout_kernel() == 'resident'
+    b = _fields(eng.rollout(B, R * H, H, 'step_rand', pool, seed=4))
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    c = _fields(eng.rollout(B, R * H, H, 'step_rand', pool, seed=5))
+    assert not torch.equal(a[1], c[1])
+    assert bool(torch.isfinite(a[0]).all()) and bool(torch.isfinite(a[3]).all())
+    assert int(a[4].sum()) == R * B and bool(a[4][H - 1::H].all()) and int(a[5].max()) == H - 1
+    d = eng.rollout(B, 8, 8, 'step_rand', pool, seed=4, determ=True)
+    assert eng.last_rollout_kernel() == 'resident'
+    assert torch.equal(d.act, d.mean)
+    np.testing.assert_array_equal(cpu(d.obs[0]), cpu(a[0][0]))                               # same reset draws as the noisy rollout of that seed
 
 
 def test_resident_chunked_continuation_equals_one_call():
