@@ -102,7 +102,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     if (!c) return METRPO_EINVAL;
     c->device = device; c->dims = *d;
     c->d_dyn = c->d_norm = c->d_theta = nullptr; c->have_dyn = c->have_pol = false;
-    c->d_dyn_img = c->d_pol_img = nullptr; c->pol_img_idx = -1;
+    c->d_dyn_img = c->d_pol_img = nullptr; c->pol_img_idx = -1; c->d_pol_imgval = nullptr; c->d_pol_vpos = nullptr; c->img_live = 0;
     c->d_bptt = nullptr; c->bptt_cap = 0; c->det_cfg = -1; c->d_detpart = nullptr; c->detpart_cap = 0; c->det_gemm = 0; c->d_dg = nullptr; c->dg_cap = 0; c->vjp_gm = nullptr; c->d_pol_adam = nullptr; c->pol_adam_t = 0; c->mfma_cfg = -1; c->pol_mfma = -1; c->coop_cfg = -1; c->rollout_variant = 0;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_cg = nullptr; c->d_vf = nullptr; c->d_theta_try = nullptr;
     c->d_valbuf = nullptr; c->h_pinned = nullptr; c->n_sm = 256;
@@ -151,7 +151,7 @@ extern "C" int32_t metrpo_destroy(metrpo_ctx* c) {
     (void)metrpo_comm_ipc_detach(c);
     if (c->xg_region) (void)hipFree(c->xg_region);
     void* bufs[] = {c->d_dyn, c->d_norm, c->d_theta, c->d_vf, c->d_theta_try, c->d_cg, c->d_valbuf, c->d_partials,
-                    c->d_dyn_img, c->d_pol_img, c->d_vbuf, c->d_gram_part, c->d_big, c->d_res, c->d_ticket, c->d_hcache, c->d_mig, c->d_pg, c->d_adam, c->d_train, c->d_bptt, c->d_pol_adam, c->d_detpart, c->d_dg};
+                    c->d_dyn_img, c->d_pol_img, c->d_pol_imgval, c->d_pol_vpos, c->d_vbuf, c->d_gram_part, c->d_big, c->d_res, c->d_ticket, c->d_hcache, c->d_mig, c->d_pg, c->d_adam, c->d_train, c->d_bptt, c->d_pol_adam, c->d_detpart, c->d_dg};
     for (void* p : bufs) if (p) (void)hipFree(p);
     if (c->side_ready) {
         for (int i = 0; i < METRPO_MAX_PAR_ROUNDS - 1; ++i) { (void)hipStreamDestroy(c->side_stream[i]); (void)hipEventDestroy(c->ev_join[i]); }
@@ -438,7 +438,7 @@ extern "C" int32_t metrpo_rms_accumulate(metrpo_ctx* c, const float* x, int64_t 
 // ------------------------------------------------------------------------------------------------
 __global__ void k_cg_init(int P, const double* __restrict__ gout, double* x, double* r, double* p, float* pf, double* scal) {
     __shared__ double sh[16];
-    cg_init_body(P, gout, x, r, p, pf, scal, sh);
+    cg_init_body(P, gout, x, r, p, PfOut{pf, nullptr, nullptr}, scal, sh);
 }
 
 __global__ void k_cg_step(CgTail t, int) {
@@ -503,7 +503,14 @@ static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metr
     tl.x = v.x; tl.r = v.r; tl.p = v.p; tl.z = v.z; tl.step = v.step; tl.scal = v.scal; tl.gout = v.gout; tl.pf = c->d_vf; tl.ticket = c->d_ticket;
     tl.op = 3;
     c->hcache_on = 1;                    // the gradient kernel publishes tanh activations, the CG products of this solve reuse them
-    struct CacheOff { metrpo_ctx* c; ~CacheOff() { c->hcache_on = 0; } } cache_off{c};
+    // ... and, when every CG vector comes out of a fused tail, its weight-fragment image; the tails add the tangent entries (policy_mfma.hip)
+    c->img_live = (fused && c->pol_mfma >= 0 && !policy_gemm_applicable(c, b->N) && getenv("METRPO_NO_IMGVAL") == nullptr) ? 1 : 0;
+    struct CacheOff { metrpo_ctx* c; ~CacheOff() { c->hcache_on = 0; c->img_live = 0; } } cache_off{c};
+    tl.vpos = nullptr; tl.imgval = nullptr;
+    if (c->img_live) {
+        if ((rc = policy_mfma_image_buffers(c))) return rc;
+        tl.vpos = c->d_pol_vpos; tl.imgval = c->d_pol_imgval;
+    }
     if ((rc = launch_loss_grad(c, b, v.gout, st, fused ? &tl : nullptr))) return rc;
     if (!fused) {
         AR(v.gout, 1 + P);

@@ -19,11 +19,17 @@ struct CgTail {
     double *x, *r, *p, *z, *step, *scal;
     const double* gout;     // [1 + P]: loss, gradient (b of the solve)
     float* pf;
+    const int* vpos; float* imgval;   // non-NULL: every pf element with an image position (policy_mfma.hip tangent tables) is also stored there
     unsigned int* ticket;   // zero at allocation; the last block of every reduction resets it
 };
 
+// float copy of the next FVP input, element i; mirrored into the weight-fragment image the cached-activation FVP copies (see CgTail::vpos)
+struct PfOut {
+    float* pf; const int* vpos; float* imgval;
+    __device__ __forceinline__ void put(int i, float v) const { pf[i] = v; if (vpos != nullptr) { const int q = vpos[i]; if (q >= 0) imgval[q] = v; } }
+};
 // r, p <- g; x <- 0; pf <- (float) g   (krylov.cg prologue)
-__device__ __forceinline__ void cg_init_body(int P, const double* gout, double* x, double* r, double* p, float* pf, double* scal, double* sh);
+__device__ __forceinline__ void cg_init_body(int P, const double* gout, double* x, double* r, double* p, PfOut pf, double* scal, double* sh);
 
 // wave sum on the DPP path (quad swaps, half-row mirror, row mirror, then the four row totals through readlane, in row order): the
 // __shfl_down ladder is 12 dependent ds_bpermute round trips per float64 sum, ~1 us of every fused CG step
@@ -71,11 +77,11 @@ __device__ __forceinline__ void cg_finish_implicit(int P, double max_kl, const d
     if (threadIdx.x == 0) { scal[S_BETA] = beta; scal[S_XHX] = xhx; }
 }
 
-__device__ __forceinline__ void cg_init_body(int P, const double* gout, double* x, double* r, double* p, float* pf, double* scal, double* sh) {
+__device__ __forceinline__ void cg_init_body(int P, const double* gout, double* x, double* r, double* p, PfOut pf, double* scal, double* sh) {
     double acc = 0.0;
     for (int i = threadIdx.x; i < P; i += blockDim.x) {
         const double g = gout[1 + i];
-        x[i] = 0.0; r[i] = g; p[i] = g; pf[i] = (float)g;
+        x[i] = 0.0; r[i] = g; p[i] = g; pf.put(i, (float)g);
         acc += g * g;
     }
     const double rdotr = blk_sum(acc, sh);
@@ -100,10 +106,10 @@ __device__ __forceinline__ void cg_prefetch(const CgTail& t, CgPre& pre) {
 
 // one krylov.cg iteration after z = f_Ax(p) has been formed (z lacks the reg term: added here)
 __device__ __forceinline__ void cg_step_body(int P, double reg, double tol, int last, double* x, double* r, double* p, double* z,
-                                             float* pf, double* scal, double* sh, const CgPre* pre = nullptr) {
+                                             PfOut pf, double* scal, double* sh, const CgPre* pre = nullptr) {
     const bool pf_ = (pre != nullptr && pre->have);
     if ((pf_ ? pre->done : scal[S_DONE]) != 0.0) {
-        if (last) for (int i = threadIdx.x; i < P; i += blockDim.x) pf[i] = (float)x[i];   // next FVP input is x (step scale)
+        if (last) for (int i = threadIdx.x; i < P; i += blockDim.x) pf.put(i, (float)x[i]);   // next FVP input is x (step scale)
         return;
     }
     const double rdotr = pf_ ? pre->rdotr : scal[S_RDOTR];
@@ -136,7 +142,7 @@ __device__ __forceinline__ void cg_step_body(int P, double reg, double tol, int 
             if (i < P) {
                 const double pn = rv[j] + mu * pv[j];
                 z[i] = zv[j]; x[i] = xv[j]; r[i] = rv[j]; p[i] = pn;
-                pf[i] = last ? (float)xv[j] : (float)pn;
+                pf.put(i, last ? (float)xv[j] : (float)pn);
             }
         }
         __syncthreads();
@@ -163,7 +169,7 @@ __device__ __forceinline__ void cg_step_body(int P, double reg, double tol, int 
     for (int i = threadIdx.x; i < P; i += blockDim.x) {
         const double pn = r[i] + mu * p[i];
         p[i] = pn;
-        pf[i] = last ? (float)x[i] : (float)pn;       // float copy of the next FVP input
+        pf.put(i, last ? (float)x[i] : (float)pn);       // float copy of the next FVP input
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -188,11 +194,11 @@ __device__ __forceinline__ void cg_finish_body(int P, double reg, double max_kl,
 // CG tail dispatch shared by k_finalize and the in-kernel reduction of policy_mfma.hip (one block, all threads)
 __device__ __forceinline__ void cg_tail_run(const CgTail& t, double* sh, const CgPre* pre = nullptr) {
     if (t.op == 1) {
-        cg_step_body(t.P, t.reg, t.tol, t.last, t.x, t.r, t.p, t.z, t.pf, t.scal, sh, pre);
+        cg_step_body(t.P, t.reg, t.tol, t.last, t.x, t.r, t.p, t.z, PfOut{t.pf, t.vpos, t.imgval}, t.scal, sh, pre);
         if (t.last && t.implicit_hd) {
             __syncthreads();
             cg_finish_implicit(t.P, t.max_kl, t.x, t.r, t.gout + 1, t.step, t.scal, sh);
         }
     } else if (t.op == 2) cg_finish_body(t.P, t.reg, t.max_kl, t.x, t.z, t.step, t.scal, sh);
-    else if (t.op == 3) cg_init_body(t.P, t.gout, t.x, t.r, t.p, t.pf, t.scal, sh);
+    else if (t.op == 3) cg_init_body(t.P, t.gout, t.x, t.r, t.p, PfOut{t.pf, t.vpos, t.imgval}, t.scal, sh);
 }

@@ -43,6 +43,10 @@ struct metrpo_ctx {
     float* d_dyn_img;    // per-model register image, see rollout_mfma.hip
     float* d_pol_img;    // (int32 payload) gather map of the policy weight-fragment image, see policy_mfma.hip
     int pol_img_idx;     // table index the map was built for (-1: none)
+    // image VALUES of one CG solve (policy_mfma.hip): [weight entries of theta, written by the gradient kernel's block 0 | tangent entries of the
+    // current CG vector, written by the fused CG tails through d_pol_vpos (theta index -> image position, -1: none)].  img_live is raised by
+    // run_trpo_update while both writers are on the launch sequence; the cached-activation FVP then copies the image instead of gathering it.
+    float* d_pol_imgval; int* d_pol_vpos; int img_live;
     // --- BPTT (bptt.hip) ---
     void* d_bptt; size_t bptt_cap;      // XS | WT | GM | gout | costs
     const float* vjp_gm;                // set around the VJP launch of the gradient kernels
@@ -125,10 +129,12 @@ struct PolK {
     int ls_stride; const uint8_t* valid; long long N; float inv_n;
     const float* gm;         // non-NULL: VJP mode of the gradient kernels (bptt.hip): d objective / d mean [N][na] supplied, no loss terms
     const int* img_map;      // policy_mfma.hip: gather map of the LDS weight-fragment image (built once per ctx on the host)
+    float* imgval;           // policy_mfma.hip: non-NULL while metrpo_ctx::img_live -- gradient kernel: block 0 publishes its image here; MODE_FVPC: the image to copy
     float* hcache;           // policy_mfma.hip: hidden activations of (theta, batch): written by the gradient kernel, read by MODE_FVPC
 };
 
 int policy_mfma_select(const ProblemDesc& pd);
+int policy_mfma_image_buffers(metrpo_ctx*);   // gather map, its inverse for the tangent entries and the image-value buffer of ctx->pol_mfma (idempotent)
 struct CgTail;
 int policy_mfma_launch(metrpo_ctx*, int idx, int mode, const metrpo_batch*, const float* theta, const float* v,
                        float* partials, int nblocks, hipStream_t);

@@ -232,7 +232,21 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
     // k.img_map[i] = source index of image element i in theta (bit 30 clear) or in v (bit 30 set), -1 = zero; built once on the
     // host (pol_image_map).  Map loads, gathers and LDS stores are issued in independent batches of IMG_U per thread: the
     // prologue costs ~2 L2 round trips instead of one dependent global load per element.
-    {
+    const long long first_tile = POL_SPLIT_R ? (long long)blockIdx.x * 4 + (wave & 3) + ((wave < 4) ? 0 : 1) * (long long)gridDim.x * 4 : (long long)blockIdx.x * NWAVES + wave;
+    if (CACHED && k.imgval != nullptr) {
+        // inside a fused CG solve the image already exists in global memory, element for element (weight entries: published by block 0 of the
+        // gradient kernel of this theta; tangent entries: stored by the CG tail that produced this product's input vector): one coalesced copy
+        // = one L2 round trip, instead of the map loads and the gathers that depend on them (9 k of the kernel's 130 k cycles at N = 500 000)
+        static_assert(I::TOTAL % 4 == 0, "image tables are multiples of 64 floats");
+        constexpr int NQ = I::TOTAL / 4, NIT = cdiv_(NQ, NWAVES * 64);
+        float4 w4[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) { const int i = it * NWAVES * 64 + tid; w4[it] = (i < NQ) ? ((const float4*)k.imgval)[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+        asm volatile("" ::: "memory");
+        fetch(first_tile, nxt);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) { const int i = it * NWAVES * 64 + tid; if (i < NQ) ((float4*)IMG)[i] = w4[it]; }
+    } else {
         constexpr int IMG_U = 8;
 #pragma unroll
         for (int i0 = 0; i0 < I::TOTAL; i0 += NWAVES * 64 * IMG_U) {
@@ -257,6 +271,9 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
         }
     }
     __syncthreads();
+    if (MODE_ == MODE_GRAD && k.imgval != nullptr && blockIdx.x == 0) {      // publish the image of this theta for the CG products that follow (tangent entries: zero here, the CG tails fill them)
+        for (int i = tid; i < I::TOTAL; i += NWAVES * 64) k.imgval[i] = IMG[i];
+    }
     PT_MARK(1)
 
     // ---------------- accumulators -------------------------------------------------------------------
@@ -705,6 +722,34 @@ int policy_mfma_select(const ProblemDesc& pd) {
     return -1;
 }
 
+// gather map of ctx->pol_mfma's weight-fragment image, its inverse over the tangent entries (theta index -> image position) and the buffer
+// the image VALUES of a CG solve are kept in (metrpo_ctx::d_pol_imgval); built on first use
+int policy_mfma_image_buffers(metrpo_ctx* c) {
+    const int idx = c->pol_mfma;
+    if (idx < 0) return set_err(c, METRPO_EUNSUPPORTED, "no MFMA policy kernels for this shape");
+    if (c->pol_img_idx == idx) return METRPO_OK;
+    const PolEntry& en = kPol[idx];
+    std::vector<int> map;
+    en.build_map(map);
+    std::vector<int> vpos((size_t)c->pd.P, -1);
+    for (size_t i = 0; i < map.size(); ++i)
+        if (map[i] >= 0 && (map[i] & 0x40000000)) {
+            const int j = map[i] & 0x3FFFFFFF;
+            if (j >= c->pd.P || vpos[j] != -1) return set_err(c, METRPO_EINVAL, "policy image map: tangent entry out of range or stored twice");
+            vpos[j] = (int)i;
+        }
+    for (void** q : {(void**)&c->d_pol_img, (void**)&c->d_pol_vpos, (void**)&c->d_pol_imgval}) if (*q) { HIP_TRY(c, hipFree(*q)); *q = nullptr; }
+    c->pol_img_idx = -1;
+    HIP_TRY(c, hipMalloc(&c->d_pol_img, sizeof(int) * map.size()));
+    HIP_TRY(c, hipMemcpy(c->d_pol_img, map.data(), sizeof(int) * map.size(), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMalloc(&c->d_pol_vpos, sizeof(int) * vpos.size()));
+    HIP_TRY(c, hipMemcpy(c->d_pol_vpos, vpos.data(), sizeof(int) * vpos.size(), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMalloc(&c->d_pol_imgval, sizeof(float) * map.size()));
+    HIP_TRY(c, hipMemset(c->d_pol_imgval, 0, sizeof(float) * map.size()));
+    c->pol_img_idx = idx;
+    return METRPO_OK;
+}
+
 // launches mode `mode`; per-block rows of P+3 floats land in `partials`; returns the block count via *nblocks
 int policy_mfma_launch(metrpo_ctx* c, int idx, int mode, const metrpo_batch* b, const float* theta, const float* v,
                        float* partials, int nblocks, hipStream_t st) {
@@ -712,17 +757,11 @@ int policy_mfma_launch(metrpo_ctx* c, int idx, int mode, const metrpo_batch* b, 
     PolK k;
     k.obs = b->d_obs; k.act = b->d_act; k.adv = b->d_adv; k.old_mean = b->d_old_mean; k.old_ls = b->d_old_log_std;
     k.ls_stride = b->old_log_std_stride; k.valid = b->d_valid; k.N = b->N; k.inv_n = (float)b->inv_n_global;
-    if (c->pol_img_idx != idx) {                            // first launch for this table entry: upload the gather map
-        std::vector<int> map;
-        en.build_map(map);
-        if (c->d_pol_img) { HIP_TRY(c, hipFree(c->d_pol_img)); c->d_pol_img = nullptr; }
-        HIP_TRY(c, hipMalloc(&c->d_pol_img, sizeof(int) * map.size()));
-        HIP_TRY(c, hipMemcpy(c->d_pol_img, map.data(), sizeof(int) * map.size(), hipMemcpyHostToDevice));
-        c->pol_img_idx = idx;
-    }
+    { const int rc = policy_mfma_image_buffers(c); if (rc) return rc; }
     k.img_map = (const int*)c->d_pol_img;
     k.gm = c->vjp_gm;
     k.hcache = nullptr;
+    k.imgval = (c->img_live && c->hcache_on && k.gm == nullptr && (mode == MODE_GRAD || mode == MODE_FVP)) ? c->d_pol_imgval : nullptr;
     if (c->hcache_on && (mode == MODE_GRAD || mode == MODE_FVP) && k.gm == nullptr) {      // set by run_trpo_update around one CG solve
         const size_t need = (size_t)((b->N + 15) / 16) * 2 * (size_t)cdiv_(en.ph, 16) * 64 * 4;
         if (need > c->hcache_cap) {

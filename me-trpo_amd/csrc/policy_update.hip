@@ -383,14 +383,14 @@ static int fill_polk(metrpo_ctx* c, const metrpo_batch* b, PolK* k, bool need_ta
         return set_err(c, METRPO_ENULL, "batch pointer is NULL");
     k->obs = b->d_obs; k->act = b->d_act; k->adv = b->d_adv; k->old_mean = b->d_old_mean; k->old_ls = b->d_old_log_std;
     k->ls_stride = b->old_log_std_stride; k->valid = b->d_valid; k->N = b->N; k->inv_n = (float)b->inv_n_global;
-    k->gm = nullptr; k->img_map = nullptr; k->hcache = nullptr;
+    k->gm = nullptr; k->img_map = nullptr; k->hcache = nullptr; k->imgval = nullptr;
     return METRPO_OK;
 }
 
 static void finalize(metrpo_ctx* c, int mode, int nrows, int stride, int lk_col, const double* v, double* out, hipStream_t st,
                      const CgTail* tail = nullptr) {
     const int nout = (mode == 0) ? c->pd.P + 1 : (mode == 1) ? c->pd.P : 2;
-    CgTail none; none.op = 0; none.ticket = c->d_ticket;
+    CgTail none; none.op = 0; none.ticket = c->d_ticket; none.vpos = nullptr; none.imgval = nullptr;
     // inside a fused update of a sharded run (run_trpo_update raises xg_fuse) the reduction carries the cross-rank sum in its tail
     const XchgK xc = (c->xg_fuse && c->xg_world > 1) ? xchg_next(c) : xchg_none();
     hipLaunchKernelGGL(k_finalize, dim3((nout + FIN_C - 1) / FIN_C), dim3(1024), 0, st, c->pd, mode, nrows, stride, lk_col,
