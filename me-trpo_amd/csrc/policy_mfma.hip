@@ -31,11 +31,17 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // measured best of {9, 13, 17}: FVP 65.1 -> 63.5 us, gradient 75.1 -> 72.4 us at N = 500 000.  0 = equal shares.
 #define POL_SPLIT_R 13
 #endif
+#ifndef POL_SPLIT_R_FVP
+// The cached-activation FVP and the loss / KL evaluation are lighter per tile and the gap between the two waves of a SIMD is wider there (102 k vs
+// 115 k cycles at 7 : 6): 4 : 3 measured best of {5, 7, 9, 11, 13} (FVP 63.5 -> 62.2 us, evaluation 34.4 -> 32.8 us under the kernel tracer; the
+// gradient kernel keeps 7 : 6, 71.5 vs 72.0).
+#define POL_SPLIT_R_FVP 7
+#endif
 #ifndef NWAVES
 #define NWAVES 8                // waves per block: one block per CU (2 waves per SIMD), the weight image is shared by all 8
 #endif
 constexpr int cdiv_(int a, int b) { return (a + b - 1) / b; }
-static_assert(POL_SPLIT_R == 0 || (NWAVES == 8 && (POL_SPLIT_R & 1) == 1 && POL_SPLIT_R >= 3), "the uneven deal pairs wave w with wave w + 4");
+static_assert(POL_SPLIT_R == 0 || (NWAVES == 8 && (POL_SPLIT_R & 1) == 1 && POL_SPLIT_R >= 3 && (POL_SPLIT_R_FVP & 1) == 1 && POL_SPLIT_R_FVP >= 3), "the uneven deal pairs wave w with wave w + 4");
 // Developer instrumentation (SRC=policy_mfma.hip tools/build_variant.sh ptiming -DPOL_TIMING): s_memtime at the phase boundaries of the
 // cached-activation FVP kernel, waves of workgroup 0, read back with metrpo_debug_pol_phases (tools/pol_phases.py).  Not in the shipped library.
 #ifdef POL_TIMING
@@ -232,7 +238,8 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
     // k.img_map[i] = source index of image element i in theta (bit 30 clear) or in v (bit 30 set), -1 = zero; built once on the
     // host (pol_image_map).  Map loads, gathers and LDS stores are issued in independent batches of IMG_U per thread: the
     // prologue costs ~2 L2 round trips instead of one dependent global load per element.
-    const long long first_tile = POL_SPLIT_R ? (long long)blockIdx.x * 4 + (wave & 3) + ((wave < 4) ? 0 : 1) * (long long)gridDim.x * 4 : (long long)blockIdx.x * NWAVES + wave;
+    constexpr int SPL = POL_SPLIT_R ? ((MODE_ == MODE_GRAD || MODE_ == MODE_FVP) ? POL_SPLIT_R : POL_SPLIT_R_FVP) : 0;      // rounds of the uneven tile deal (0: equal shares)
+    const long long first_tile = SPL ? (long long)blockIdx.x * 4 + (wave & 3) + ((wave < 4) ? 0 : 1) * (long long)gridDim.x * 4 : (long long)blockIdx.x * NWAVES + wave;
     if (CACHED && k.imgval != nullptr) {
         // inside a fused CG solve the image already exists in global memory, element for element (weight entries: published by block 0 of the
         // gradient kernel of this theta; tangent entries: stored by the CG tail that produced this product's input vector): one coalesced copy
@@ -265,7 +272,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
             }
             // the first tile's loads go out behind the last batch of gathers (vmcnt retires in order: issued any earlier, their HBM round
             // trip would hold up the map loads' return): they overlap the LDS stores, the barrier and the bias loads
-            if (i0 + NWAVES * 64 * IMG_U >= I::TOTAL) { asm volatile("" ::: "memory"); fetch(POL_SPLIT_R ? (long long)blockIdx.x * 4 + (wave & 3) + ((wave < 4) ? 0 : 1) * (long long)gridDim.x * 4 : (long long)blockIdx.x * NWAVES + wave, nxt); asm volatile("" ::: "memory"); }
+            if (i0 + NWAVES * 64 * IMG_U >= I::TOTAL) { asm volatile("" ::: "memory"); fetch(first_tile, nxt); asm volatile("" ::: "memory"); }
 #pragma unroll
             for (int u = 0; u < IMG_U; ++u) { const int i = i0 + u * NWAVES * 64 + tid; if (i < I::TOTAL) IMG[i] = w[u]; }
         }
@@ -294,21 +301,16 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
     // behind the prefetch of the next tile -- which it then waits for as well
     __builtin_amdgcn_s_waitcnt(0x0F70);
     PT_MARK(2)
-#if POL_SPLIT_R
-    const long long sp_base = (long long)blockIdx.x * 4 + (wave & 3), sp_stride = (long long)gridDim.x * 4;
-    auto sp_next = [&](long long m) { const int ph = (int)(m % POL_SPLIT_R); return (wave < 4) ? ((ph == POL_SPLIT_R - 1) ? m + 1 : m + 2) : ((ph == POL_SPLIT_R - 2) ? m + 3 : m + 2); };
-    for (long long m = (wave < 4) ? 0 : 1, tile = sp_base + m * sp_stride; tile < ntiles; m = sp_next(m), tile = sp_base + m * sp_stride) {
-#else
-    for (long long tile = (long long)blockIdx.x * NWAVES + wave; tile < ntiles; tile += (long long)gridDim.x * NWAVES) {
-#endif
+    const long long sp_base = SPL ? (long long)blockIdx.x * 4 + (wave & 3) : (long long)blockIdx.x * NWAVES + wave, sp_stride = (long long)gridDim.x * (SPL ? 4 : NWAVES);
+    auto sp_next = [&](long long m) -> long long {
+        if constexpr (SPL == 0) return m + 1;
+        else { const int ph = (int)(m % SPL); return (wave < 4) ? ((ph == SPL - 1) ? m + 1 : m + 2) : ((ph == SPL - 2) ? m + 3 : m + 2); }
+    };
+    for (long long m = (SPL && wave >= 4) ? 1 : 0, tile = sp_base + m * sp_stride; tile < ntiles; m = sp_next(m), tile = sp_base + m * sp_stride) {
         const long long n0 = tile * 16, n = n0 + c;
         const bool inr = n < k.N;
         TileIn in = nxt;
-#if POL_SPLIT_R
         fetch(sp_base + sp_next(m) * sp_stride, nxt);
-#else
-        fetch(tile + (long long)gridDim.x * NWAVES, nxt);
-#endif
         asm volatile("" ::: "memory");                      // the loads are issued HERE (left alone, the compiler sinks them to the end of the iteration)
         mask_tile(in);
         const bool ok = inr && in.vld != 0;
