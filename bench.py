@@ -103,8 +103,8 @@ def self_launch(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=10)          # the first ~8 iterations after start-up run 5-10 % slow (clocks, allocator): 3 warm-up steps left two of them in a 20-step mean
     ap.add_argument('--config', default='C1')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-H', type=int, default=100, help='horizon of the bounded CPU-baseline sample')
