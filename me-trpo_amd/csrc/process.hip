@@ -87,12 +87,12 @@ __device__ __forceinline__ void gae_chunk_pass(const double* __restrict__ V, con
 // V buffer for the two scan passes (L2-resident: written and read by the same workgroup).  As a separate thread-per-sample kernel this
 // read rows of ns floats at a stride of ns floats per lane: 0.26 TB/s on Ant (560 us at the C3 share, 10x the scan itself).
 // NS = compile-time ns of the six envs (register-resident prefetch), NS = 0: any ns (no prefetch).
-template <int NS>
-__global__ void __launch_bounds__(64 * GAE_NW) k_gae(const float* __restrict__ obs, const int32_t* __restrict__ tpath, const double* __restrict__ coeffs,
+template <int NS, int NW>
+__global__ void __launch_bounds__(64 * NW) k_gae(const float* __restrict__ obs, const int32_t* __restrict__ tpath, const double* __restrict__ coeffs,
                                                       int ns_rt, double* __restrict__ V, const float* __restrict__ rew, const uint8_t* __restrict__ done,
                                                       int T, int B, double gamma, double lam, float* __restrict__ adv, float* __restrict__ ret,
                                                       uint8_t* __restrict__ valid, double* __restrict__ stats) {
-    extern __shared__ __attribute__((aligned(16))) float stage[];      // [GAE_NW][64 * ns]
+    extern __shared__ __attribute__((aligned(16))) float stage[];      // [NW][64 * ns]
     if (coeffs != nullptr) {
         const int ns = NS ? NS : ns_rt;
         const int lane0 = threadIdx.x & 63, w0 = threadIdx.x >> 6;
@@ -109,13 +109,13 @@ __global__ void __launch_bounds__(64 * GAE_NW) k_gae(const float* __restrict__ o
         int tp_cur = 0, tp_nxt = 0;
         auto load_tp = [&](int t) { return (lane0 < nv) ? tpath[(size_t)t * B + b0 + lane0] : 0; };
         if (w0 < T) { if (NS) load(w0, nxt); tp_nxt = load_tp(w0); }
-        for (int t = w0; t < T; t += GAE_NW) {
+        for (int t = w0; t < T; t += NW) {
             tp_cur = tp_nxt;
-            if (t + GAE_NW < T) tp_nxt = load_tp(t + GAE_NW);
+            if (t + NW < T) tp_nxt = load_tp(t + NW);
             if (NS) {
 #pragma unroll
                 for (int i = 0; i < NR; ++i) cur[i] = nxt[i];
-                if (t + GAE_NW < T) load(t + GAE_NW, nxt);
+                if (t + NW < T) load(t + NW, nxt);
 #pragma unroll
                 for (int i = 0; i < NR; ++i) S[i * 64 + lane0] = cur[i];
             } else {
@@ -129,11 +129,11 @@ __global__ void __launch_bounds__(64 * GAE_NW) k_gae(const float* __restrict__ o
         __syncthreads();                             // every wave's V rows are visible to the whole workgroup from here on
     } else V = nullptr;
     __shared__ double red[16];
-    __shared__ double agg[GAE_NW][5][64];           // per chunk and env: A0, G0, v_first, CA, CG   (carry-out = A0 + CA*E_in, G0 + CG*r_in)
-    __shared__ uint8_t cut[GAE_NW][64];             // a done inside the chunk: the carry-in does not reach the chunk's first step
+    __shared__ double agg[NW][5][64];           // per chunk and env: A0, G0, v_first, CA, CG   (carry-out = A0 + CA*E_in, G0 + CG*r_in)
+    __shared__ uint8_t cut[NW][64];             // a done inside the chunk: the carry-in does not reach the chunk's first step
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int b = blockIdx.x * 64 + lane;
-    const int Tc = (T + GAE_NW - 1) / GAE_NW;
+    const int Tc = (T + NW - 1) / NW;
     const int t_lo = min(T, w * Tc), t_hi = min(T, (w + 1) * Tc);
     const bool act = b < B;
     double s1 = 0.0, s2 = 0.0, cnt = 0.0;
@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(64 * GAE_NW) k_gae(const float* __restrict__ o
     __syncthreads();
     // combine: carry entering chunk w = carry-out of chunk w+1 (which in turn depends on the carry entering it, ...), from the last chunk down
     double a_in = 0.0, v_in = 0.0, r_in = 0.0; bool c_in = false;
-    for (int j = GAE_NW - 1; j > w; --j) {
+    for (int j = NW - 1; j > w; --j) {
         const int lo = min(T, j * Tc), hi = min(T, (j + 1) * Tc);
         if (hi <= lo) continue;                          // empty chunk: the carry passes through
         const double E = gamma * v_in + gamma * lam * a_in;
@@ -527,16 +527,24 @@ int launch_gae(metrpo_ctx* c, const float* obs, const float* rew, const uint8_t*
         V = c->d_vbuf;
     }
     const int ns = c->pd.ns;
-    const size_t sh = (coeffs != nullptr) ? sizeof(float) * GAE_NW * 64 * (size_t)ns : 0;
-#define GAE_LAUNCH(NSV) do { \
-        if (sh > 48 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_gae<NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)); \
-        hipLaunchKernelGGL(k_gae<NSV>, dim3((B + 63) / 64), dim3(64 * GAE_NW), sh, st, obs, tpath, coeffs, ns, V, rew, done, T, B, gamma, lam, adv, ret, valid, stats); } while (0)
-    if (sh + 24 * 1024 > 160 * 1024) return set_err(c, METRPO_EUNSUPPORTED, "gae: observation too wide for the staging buffer");
+    // few env columns and a long horizon (the params-file batches: B = 100, T = 600): the grid is 2 workgroups and the kernel is the
+    // dependent chain of one wave's steps -- 16 time chunks instead of 8 shorten it (84 -> 67 us at C0-params-file); at C1 (79 workgroups) 8 is faster
+    const bool wide = (B <= 256 && T >= 128 && ns <= 18);
+    const int nw = wide ? 16 : GAE_NW;
+    const size_t sh = (coeffs != nullptr) ? sizeof(float) * nw * 64 * (size_t)ns : 0;
+#define GAE_LAUNCH_NW(NSV, NWV) do { \
+        if (sh > 48 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_gae<NSV, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)); \
+        hipLaunchKernelGGL((k_gae<NSV, NWV>), dim3((B + 63) / 64), dim3(64 * NWV), sh, st, obs, tpath, coeffs, ns, V, rew, done, T, B, gamma, lam, adv, ret, valid, stats); } while (0)
+#define GAE_LAUNCH(NSV) do { if (wide) GAE_LAUNCH_NW(NSV, 16); else GAE_LAUNCH_NW(NSV, GAE_NW); } while (0)
+#define GAE_LAUNCH8(NSV) GAE_LAUNCH_NW(NSV, GAE_NW)
+    if (sh + 48 * 1024 > 160 * 1024) return set_err(c, METRPO_EUNSUPPORTED, "gae: observation too wide for the staging buffer");
     switch (ns) {                                    // the six envs' widths get the register-prefetching instantiation
     case 10: GAE_LAUNCH(10); break; case 11: GAE_LAUNCH(11); break; case 14: GAE_LAUNCH(14); break;
-    case 18: GAE_LAUNCH(18); break; case 29: GAE_LAUNCH(29); break; case 55: GAE_LAUNCH(55); break;
-    default: GAE_LAUNCH(0);
+    case 18: GAE_LAUNCH(18); break; case 29: GAE_LAUNCH8(29); break; case 55: GAE_LAUNCH8(55); break;
+    default: GAE_LAUNCH8(0);
     }
+#undef GAE_LAUNCH8
+#undef GAE_LAUNCH_NW
 #undef GAE_LAUNCH
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;
