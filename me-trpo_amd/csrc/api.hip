@@ -106,7 +106,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     c->d_bptt = nullptr; c->bptt_cap = 0; c->det_cfg = -1; c->d_detpart = nullptr; c->detpart_cap = 0; c->det_gemm = 0; c->d_dg = nullptr; c->dg_cap = 0; c->vjp_gm = nullptr; c->d_pol_adam = nullptr; c->pol_adam_t = 0; c->mfma_cfg = -1; c->pol_mfma = -1; c->coop_cfg = -1; c->rollout_variant = 0;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_cg = nullptr; c->d_vf = nullptr; c->d_theta_try = nullptr;
     c->d_valbuf = nullptr; c->h_pinned = nullptr; c->n_sm = 256;
-    c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0; c->d_res = nullptr; c->res_cap = 0; c->res_seq = 0; c->last_rollout_kernel = -1; c->side_ready = 0; c->d_ticket = nullptr; c->d_hcache = nullptr; c->hcache_cap = 0; c->hcache_on = 0; c->d_mig = nullptr; c->mig_cap = 0; c->mig_epoch = 0; c->nccl_comm = nullptr; c->comm_world = 0; c->comm_rank = 0; c->pol_path = 1; c->d_pg = nullptr; c->pg_cap = 0; c->pg_fwd_rows = -1; c->pg_fwd_obs = nullptr; c->d_adam = nullptr; c->adam_t = 0; c->d_train = nullptr; c->train_cap = 0;
+    c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0; c->d_res = nullptr; c->res_cap = 0; c->res_seq = 0; c->res_failed = 0; c->last_rollout_kernel = -1; c->side_ready = 0; c->d_ticket = nullptr; c->d_hcache = nullptr; c->hcache_cap = 0; c->hcache_on = 0; c->d_mig = nullptr; c->mig_cap = 0; c->mig_epoch = 0; c->nccl_comm = nullptr; c->comm_world = 0; c->comm_rank = 0; c->pol_path = 1; c->d_pg = nullptr; c->pg_cap = 0; c->pg_fwd_rows = -1; c->pg_fwd_obs = nullptr; c->d_adam = nullptr; c->adam_t = 0; c->d_train = nullptr; c->train_cap = 0;
     ProblemDesc& pd = c->pd;
     pd.env = d->env; pd.ns = d->ns; pd.na = d->na; pd.K = d->n_models; pd.n_drop = d->n_drop;
     pd.nin = d->ns + d->na - d->n_drop;
@@ -551,7 +551,7 @@ static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metr
         HIP_TRY(c, hipMemcpyAsync(c->h_pinned, v.scal, sizeof(double) * 10, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
         if (c->h_pinned[S_COMMERR] != 0.0) return set_err(c, METRPO_EHIP, "trpo_update: one-shot all-reduce timed out (a rank did not arrive)");
-        if (c->h_pinned[S_ROLLERR] != 0.0) return set_err(c, METRPO_EHIP, "rollout: a migrating tile's hand-over timed out (producer workgroup never ran); trajectories are invalid");
+        if (c->h_pinned[S_ROLLERR] != 0.0) return rollout_error_seen(c, st);
         if (first) { loss_before = c->h_pinned[S_LOSS0]; first = false; }
         loss = c->h_pinned[8]; kl = c->h_pinned[9];
         if (loss < loss_before && kl <= pr->max_kl) break;

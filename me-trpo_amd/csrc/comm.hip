@@ -214,7 +214,7 @@ extern "C" int32_t metrpo_comm_check(metrpo_ctx* c, void* stream) {
     if (!c) return METRPO_ENULL;
     HIP_TRY(c, hipMemcpyAsync(c->h_pinned + 14, comm_err_cell(c), 2 * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(c, hipStreamSynchronize((hipStream_t)stream));
-    if (c->h_pinned[15] != 0.0) return set_err(c, METRPO_EHIP, "rollout: a migrating tile's hand-over timed out (producer workgroup never ran)");
+    if (c->h_pinned[15] != 0.0) return rollout_error_seen(c, (hipStream_t)stream);
     if (c->h_pinned[14] != 0.0) return set_err(c, METRPO_EHIP, "one-shot all-reduce: a rank did not arrive within the time limit (METRPO_XCHG_TIMEOUT_MS)");
     return METRPO_OK;
 }

@@ -87,6 +87,7 @@ struct metrpo_ctx {
     void* d_big;         // workspace of the GEMM step-wise rollout (rollout_gemm.hip)
     size_t big_cap;
     void* d_res; size_t res_cap; unsigned int res_seq;   // rollout_resident.hip: uncached exchange region (abort cell | X packets | P packets) and the step stamps issued so far
+    int res_failed;                                       // a resident launch gave up (its grid was not co-resident): this context stays on the step-wise path from then on
     int last_rollout_kernel;                              // which kernel family the last metrpo_rollout ran on: 0 generic, 1 head-per-wave MFMA, 2 cooperative MFMA, 3 step-wise GEMM, 4 resident
     hipStream_t side_stream[METRPO_MAX_PAR_ROUNDS - 1]; hipEvent_t ev_fork, ev_join[METRPO_MAX_PAR_ROUNDS - 1]; int side_ready;   // rollout_gemm.hip: independent rounds of a small-batch rollout run concurrently
     double* h_pinned;    // pinned host scratch for the per-trial read-back
@@ -188,6 +189,16 @@ XchgK xchg_next(metrpo_ctx*);
 static inline XchgK xchg_none() { XchgK x = {}; return x; }
 // scal[S_COMMERR] of the CG workspace (gout[1+P] | x r p z step [5P] | scal[8] | lk[2]): sticky error cell of the exchanges
 static inline double* comm_err_cell(metrpo_ctx* c) { return c->d_cg + (size_t)(1 + c->pd.P) + 5 * (size_t)c->pd.P + 6; }
+// A rollout kernel reported a timed-out hand-over (scal[S_ROLLERR]): the trajectories of that launch are invalid.  The cell is cleared so the
+// context can go on, and the resident kernel -- the one whose hand-overs need every workgroup of its grid on the chip at once -- is retired.
+static inline int rollout_error_seen(metrpo_ctx* c, hipStream_t st) {
+    (void)hipMemsetAsync(comm_err_cell(c) + 1, 0, sizeof(double), st);
+    const bool was_resident = (c->last_rollout_kernel == 4);
+    if (was_resident) c->res_failed = 1;
+    return set_err(c, METRPO_EHIP, was_resident ? "rollout: the resident kernel's hand-over timed out (a workgroup of its grid never ran: is another process using this GPU?); "
+                                                  "the trajectories of that launch are invalid, later rollouts of this context use the step-wise path"
+                                                : "rollout: a migrating tile's hand-over timed out (producer workgroup never ran); trajectories are invalid");
+}
 bool policy_gemm_applicable(const metrpo_ctx*, long long N);
 int policy_gemm_run(metrpo_ctx*, int mode, const metrpo_batch*, const PolK&, const float* theta, const float* vf, const double* v64, double* out,
                     const CgTail* tail, hipStream_t);

@@ -40,6 +40,7 @@ extern "C" int32_t metrpo_debug_resident_phases(unsigned long long* out) { retur
 struct ResidentK {
     int R, round0, rounds_total, NT, NSL, U, PW, steps;   // rounds of this launch, first round, env tiles, slices, compute blocks, post waves per block, steps per round
     unsigned int seq0;                                    // packets of local step tau carry seq0 + tau + 1
+    int skip_block;                                       // test hook (METRPO_RESIDENT_TEST_SKIP): this workgroup behaves as if it had never been scheduled; -1 otherwise
     unsigned long long* X; unsigned long long* P; unsigned int* abort_cell;
     double* err;
 };
@@ -510,6 +511,7 @@ __global__ void __launch_bounds__(512) k_rollout_resident(ProblemDesc pd, Rollou
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using C = Cfg<ENV, 64, 32>;
     if (r.stop != nullptr && *r.stop != 0) return;                   // the sampling loop already ended (metrpo_sampler_progress); uniform over the grid
+    if ((int)blockIdx.x == z.skip_block) return;
     if ((int)blockIdx.x < z.U) resident_compute<C::NS, C::NIN, DH, WS>(pd, z, dyn, lds);
     else resident_post<ENV>(pd, r, z, dyn, theta, norm, lds);
 }
@@ -537,7 +539,7 @@ static const ResidentEntry* resident_table(int* n) {
 // METRPO_EUNSUPPORTED: this shape / call stays on the step-wise path (rollout_gemm.hip)
 int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t st) {
     const ProblemDesc& pd = c->pd;
-    if (c->rollout_variant == 1 || getenv("METRPO_NO_RESIDENT") != nullptr) return METRPO_EUNSUPPORTED;
+    if (c->rollout_variant == 1 || c->res_failed || getenv("METRPO_NO_RESIDENT") != nullptr) return METRPO_EUNSUPPORTED;
     if (pd.dyn.n_layers != 3 || pd.dyn.dims[1] != pd.dyn.dims[2] || pd.dyn.act[0] != METRPO_ACT_RELU || pd.dyn.act[1] != METRPO_ACT_RELU ||
         pd.dyn.act[2] != METRPO_ACT_IDENTITY) return METRPO_EUNSUPPORTED;
     if (pd.pol.n_layers != 3 || pd.pol.dims[1] != 32 || pd.pol.dims[2] != 32 || pd.pol.act[0] != METRPO_ACT_TANH || pd.pol.act[1] != METRPO_ACT_TANH)
@@ -597,6 +599,8 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
         ResidentK z;
         z.R = Rg; z.round0 = round0; z.rounds_total = R; z.NT = NT; z.NSL = NSL; z.U = Rg * K * NSL; z.PW = PW; z.steps = steps;
         z.seq0 = c->res_seq; c->res_seq += (unsigned int)steps + 1u;
+        z.skip_block = -1;
+        if (const char* sk = getenv("METRPO_RESIDENT_TEST_SKIP")) z.skip_block = atoi(sk);
         z.abort_cell = (unsigned int*)c->d_res;
         z.X = (unsigned long long*)c->d_res + 32; z.P = z.X + nX;
         z.err = comm_err_cell(c) + 1;                               // scal[S_ROLLERR]

@@ -146,3 +146,29 @@ def test_resident_kernel_scope():
     eng3 = Hh.make_engine('swimmer', 5, (64, 64), (32, 32), seed=3)[0]
     eng3.rollout(64, 4, 4, 'step_rand', pool, seed=1)
     assert eng3.last_rollout_kernel() == 'mfma-cooperative'
+
+
+def test_resident_missing_workgroup_times_out_and_context_recovers(monkeypatch):
+    """A workgroup of the grid that never runs (here: told to leave at once; in the field: another process holding CUs) must not hang the GPU:
+    the waiting waves give up after 2 s, the launch ends, the next check of the context reports it, and from then on the context rolls out on the
+    step-wise path -- with results that match a context that never tried."""
+    import time
+    import metrpo_amd
+    eng, dm, theta, pdims, pool = Hh.make_engine('swimmer', 5, (512, 512), (32, 32), seed=33)
+    B, T, H = 64, 6, 6
+    monkeypatch.setenv('METRPO_RESIDENT_TEST_SKIP', '3')
+    t0 = time.time()
+    eng.rollout(B, T, H, 'step_rand', pool, seed=2)
+    assert eng.last_rollout_kernel() == 'resident'
+    with pytest.raises(metrpo_amd._lib.MetrpoError, match="resident kernel's hand-over timed out"):
+        eng.comm_check()
+    assert 1.5 < time.time() - t0 < 20.0
+    monkeypatch.delenv('METRPO_RESIDENT_TEST_SKIP')
+    again = eng.rollout(B, T, H, 'step_rand', pool, seed=2)
+    assert eng.last_rollout_kernel() == 'gemm-stepwise'
+    eng.comm_check()                                                     # the error cell was cleared: the context is usable
+    ref_eng = Hh.make_engine('swimmer', 5, (512, 512), (32, 32), seed=33)[0]
+    ref_eng.set_rollout_variant(1)
+    ref = ref_eng.rollout(B, T, H, 'step_rand', pool, seed=2)
+    for a, b in zip(_fields(again), _fields(ref)):
+        assert torch.equal(a, b)
