@@ -1,22 +1,24 @@
 // Resident rollout for SMALL batches of 2 x 512 dynamics ensembles (the reference's own params-swimmer.json: K = 5, B = 100 envs,
-// three rounds of 200 steps): the whole time loop in ONE launch, weights resident in LDS, the steps chained through 8-byte packets.
+// three rounds of 200 steps): the whole time loop in ONE launch, weights resident in registers, the steps chained through 8-byte packets.
 // Same reference path as the other rollout kernels (samplers/vectorized_sampler.py:45-116, env_helpers.py:597-635, training.py:218-269).
 //
 // Why: at B = 100 a step of the step-wise GEMM path (rollout_gemm.hip) is four dependent launches of 4-19 us that each re-read the
 // weights from L2 and leave most CUs idle; 600 steps take 9 ms whatever the launch mechanism.  Here
-//   * a COMPUTE workgroup owns (round, model k, slice of WS hidden-2 units): W0 (all of it), its W1 columns and its W2 rows sit in
-//     LDS as MFMA fragments for the whole rollout (100 KB).  Wave w owns env tile w (16 envs): per step it recomputes hidden layer 0
-//     for its tile (DH/16 x NIN_KS MFMAs -- cheaper than fetching the activations from another CU), contracts it with the slice
-//     (WS/16 x DH/4 MFMAs, the layer-0 results feeding the next MFMA from registers) and emits the slice's contribution to the
-//     output layer: [ns x 16 envs] partial sums;
+//   * a COMPUTE workgroup owns (round, model k, slice of WS hidden-1 units).  Its 4 PRODUCER waves (one per SIMD) keep a quarter each of W0
+//     and of the slice's W1 columns as MFMA fragments in registers for the whole rollout and walk the round's env tiles (16 envs each): per
+//     tile they recompute their quarter of hidden layer 0 (cheaper than fetching 512 activations per env from another CU every step) and
+//     contract it with the slice -- one uninterrupted matrix-instruction stream per SIMD; its 4 FINISHER waves add the quarters, apply
+//     bias + ReLU and emit the slice's contribution to the output layer: [ns x 16 envs] partial sums (resident_compute);
 //   * a POST wave owns (round, env tile): policy forward (the MFMA chain of k_big_pre_mfma), action noise, normalised input -> X
 //     packets; then it adds the DH/WS partials of each env's selected model in slice order, applies the residual, reward, done,
-//     reset, and writes the trajectory rows.  R x ceil(B/16) post waves on the CUs the compute grid leaves free;
+//     reset, and writes the trajectory rows.  R x ceil(B/16) post waves on the CUs the compute grid leaves free (resident_post);
 //   * hand-over in both directions by {32 data bits | 32-bit step stamp} packets in an uncached exchange region (agent-scope relaxed
-//     8-byte stores / loads: no fence, no flag, no grid barrier; xchg_device.h uses the same idea between GPUs).  A wave only waits
-//     for ITS tile, so the two waves of a SIMD drift apart and one computes while the other waits for its hand-over.
+//     8-byte stores / loads: no fence, no flag, no grid barrier; xchg_device.h uses the same idea between GPUs).  Nobody waits for
+//     more than ITS tile: a tile's round trip (partial sums out, next input in: ~6 us) passes while the CU works on the round's other tiles.
 // All K heads are evaluated every step (as the reference's graph does); only simple sampling modes (step_rand / eps_rand / one_model).
-// Everything else (B > 128, other widths, Ant-sized inputs, model_mean_std / model_med, chunks with a stop flag) stays on rollout_gemm.hip.
+// Everything else (B > 128, other widths, Ant, model_mean_std / model_med) stays on rollout_gemm.hip.  The grid must be resident as a whole:
+// every wait is bounded (2 s), a launch that gives up is reported by the next metrpo_trpo_update / metrpo_comm_check and retires the kernel
+// for its context (metrpo_internal.h: rollout_error_seen).
 #include "mfma_common.h"
 
 // Developer instrumentation (SRC=rollout_resident.hip tools/build_variant.sh restiming -DRES_TIMING): shader-clock sums per phase of the
