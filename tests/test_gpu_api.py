@@ -13,9 +13,9 @@ def cpu(t):
     return t.detach().cpu().numpy().astype(np.float64)
 
 
-def build_algo(env='swimmer', K=5, B=64, H=10, batch=None, sam_mode='step_rand', seed=0, gamma=0.99, lam=0.95):
+def build_algo(env='swimmer', K=5, B=64, H=10, batch=None, sam_mode='step_rand', seed=0, gamma=0.99, lam=0.95, dyn_hidden=(64, 64)):
     import metrpo_amd
-    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (64, 64), (32, 32), seed=seed)
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, dyn_hidden, (32, 32), seed=seed)
     policy = metrpo_amd.GaussianMLPPolicy(eng, init_std=1.0, seed=seed)
     eng.set_policy(theta)
     init = metrpo_amd.InitStatePool(pool, dm.na)
@@ -125,6 +125,39 @@ def test_sampler_process_samples_pipeline(env, batch):
     np.testing.assert_allclose(feat_pred(algo.baseline.coeffs), feat_pred(base._coeffs), rtol=0,
                                atol=2e-3 * max(1.0, np.abs(feat_pred(base._coeffs)).max()))
     assert not np.allclose(algo.baseline.coeffs, prev)
+
+
+def test_params_file_shape_iteration_on_the_resident_kernel():
+    """The reference's own params-swimmer.json shape (K = 5, 2 x 512 nets, 100 envs, several rounds per batch) through the host interface:
+    obtain_samples lands on the resident rollout kernel (all rounds in one launch), the list-of-paths view, process_samples and the
+    TRPO step behave as on the other kernels."""
+    B, H, batch = 100, 10, 2500                                              # -> 3 rounds of 100 envs x 10 steps
+    algo, eng, dm, theta, pdims, pool = build_algo('swimmer', B=B, H=H, batch=batch, dyn_hidden=(512, 512))
+    prev = np.random.RandomState(3).randn(2 * dm.ns + 4) * 0.05
+    algo.baseline.set_param_values(prev.copy())
+    algo.start_worker()
+    paths = algo.obtain_samples(0)
+    assert eng.last_rollout_kernel() == 'resident'
+    assert paths.traj.T == 3 * H
+    plist = paths.to_paths()
+    assert len(plist) == 3 * B and all(len(p['rewards']) == H for p in plist)
+    samples = algo.process_samples(0, paths)
+    base = O.LinearFeatureBaselineOracle(); base._coeffs = prev.copy()
+    ref = O.process_samples([dict(p) for p in plist], base, algo.discount, algo.gae_lambda, center_adv=True)
+    v = cpu(samples['valids']).astype(bool)
+    assert v.sum() == len(ref['advantages']) == samples['n_valid_global'] == 3 * B * H
+    srt = lambda ret, adv: tuple(x[np.lexsort((adv, ret))] for x in (ret, adv))
+    gr, ga = srt(cpu(samples['returns'])[v], cpu(samples['advantages'])[v])
+    rr, ra = srt(ref['returns'], ref['advantages'])
+    np.testing.assert_allclose(gr, rr, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ga, ra, rtol=1e-4, atol=2e-4)
+    assert algo.optimize_policy(0, samples) == dict()
+    d = algo.optimizer.last_diag
+    assert np.isfinite(d['loss_before']) and (not d['accepted'] or (d['kl'] <= 0.01 and d['loss'] < d['loss_before']))
+    # the next iteration rolls out under the updated policy, again in one launch
+    algo.start_worker()
+    paths2 = algo.obtain_samples(1)
+    assert eng.last_rollout_kernel() == 'resident' and not torch.equal(paths2.traj.act, paths.traj.act) if d['accepted'] else True
 
 
 def test_trpo_iteration_and_early_stopping_loop():
