@@ -169,6 +169,15 @@ def main():
             e1.record(); ev_upd.append((e0, e1))
             steps_run.append(paths.traj.T); n_valid.append(samples['n_valid_global'])
 
+    # The host meets the device once per iteration (the line search reads its trial back), so a stop-the-world pass of Python's cyclic
+    # collector lands 1:1 on an iteration: one 2.2-2.4 ms iteration in every 20-step run (per-iteration events).  The iteration allocates no
+    # reference cycles worth collecting; the collector is paused from before the warm-up steps to the end of the timed region
+    # (what Python's own `timeit` does by default; METRPO_BENCH_GC=1 leaves it on) -- collecting right before the timed region would leave the GPU idle for tens of ms and the first
+    # iterations after an idle gap run 10-30 % slow.
+    import gc
+    gc_was = gc.isenabled()
+    if os.environ.get('METRPO_BENCH_GC') != '1':
+        gc.collect(); gc.disable()
     for j in range(args.warmup):
         step(j, False)
     comm.barrier(); torch.cuda.synchronize()
@@ -178,6 +187,8 @@ def main():
     ei = torch.cuda.Event(enable_timing=True); ei.record(); ev_iter.append(ei)
     comm.barrier(); torch.cuda.synchronize()
     dt = comm.max_float(time.perf_counter() - t0, device='cuda' if backend == 'nccl' else 'cpu')
+    if gc_was:
+        gc.enable()
     side = 'cuda' if backend == 'nccl' else 'cpu'             # where the bench's own bookkeeping reductions live
     iter_ms = [a.elapsed_time(b) for a, b in zip(ev_iter[:-1], ev_iter[1:])]        # per-iteration times on the stream (median of >= 20)
 
