@@ -291,6 +291,22 @@ typedef struct {                 /* host-side diagnostics of one optimize() call
 int32_t metrpo_trpo_update(metrpo_ctx* ctx, const metrpo_batch* batch, const metrpo_trpo_params* params,
                            metrpo_trpo_diag* diag, double* d_g_out, double* d_dir_out, void* stream);
 
+/* The same optimize() call (algos/npo.py:111) in two halves, for callers that want to keep enqueuing (the next iteration's
+ * obtain_samples, model_based_rl.py:1171-1180) while the line search is being decided.
+ *   _begin  gradient, CG solve and the first `spec_trials` (>= 1) trials of the backtracking loop; the loop's break test and the
+ *           acceptance rule that follows it are evaluated ON THE DEVICE in the tail of each trial's reduction, an accepted trial's
+ *           theta becomes the ctx policy at once, later speculative trials leave without work.  Does NOT synchronise; `batch`
+ *           must stay valid until _end.  Launches that follow on `stream` see theta_new if one of these trials was accepted.
+ *   _end    waits for _begin's work (not for what was enqueued after it), fills `diag`, and -- only if the search did not stop
+ *           within the speculative trials -- runs trials spec_trials, spec_trials+1, ... exactly as metrpo_trpo_update does.
+ *           *late_out (may be NULL) = 1 if the policy changed inside _end (accepted at one of those later trials): work enqueued
+ *           between the two calls used theta_prev and has to be redone by the caller; 0 otherwise.
+ * Results are those of metrpo_trpo_update bit for bit.  With a host all-reduce callback, an RCCL transport or the GEMM update path
+ * the accept test cannot run on the device: _begin then performs the whole update synchronously and _end returns its diagnostics. */
+int32_t metrpo_trpo_update_begin(metrpo_ctx* ctx, const metrpo_batch* batch, const metrpo_trpo_params* params, int32_t spec_trials,
+                                 double* d_g_out, double* d_dir_out, void* stream);
+int32_t metrpo_trpo_update_end(metrpo_ctx* ctx, metrpo_trpo_diag* diag, int32_t* late_out, void* stream);
+
 /* ---- "next" rows of the scope table: ensemble dynamics training + normaliser statistics ---- */
 typedef struct {
     double lr;                   /* dynamics_opt_params.learning_rate["scratch"|"refine"] (model_based_rl.py:905-918)      */

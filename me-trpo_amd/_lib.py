@@ -93,6 +93,8 @@ SYMBOLS = {
     'metrpo_fvp': (_I, [_P, C.POINTER(Batch), _P, _P, _P]),
     'metrpo_loss_kl': (_I, [_P, C.POINTER(Batch), _P, _P, _P]),
     'metrpo_trpo_update': (_I, [_P, C.POINTER(Batch), C.POINTER(TrpoParams), C.POINTER(TrpoDiag), _P, _P, _P]),
+    'metrpo_trpo_update_begin': (_I, [_P, C.POINTER(Batch), C.POINTER(TrpoParams), _I, _P, _P, _P]),
+    'metrpo_trpo_update_end': (_I, [_P, C.POINTER(TrpoDiag), C.POINTER(C.c_int32), _P]),
     'metrpo_dyn_train_reset': (_I, [_P, _P]),
     'metrpo_dyn_train_step': (_I, [_P, _P, _P, C.POINTER(TrainParams), _P, _P]),
     'metrpo_dyn_eval_losses': (_I, [_P, _P, _P, _L, _D, _P, _P]),

@@ -49,7 +49,16 @@ class BatchPolopt(object):
 
     def obtain_samples(self, itr, determ=False, **kw):
         with self.timers.phase('rollout'):
-            return self.sampler.obtain_samples(itr, determ, **kw)
+            paths = self.sampler.obtain_samples(itr, determ, **kw)
+            # async_line_search: the previous optimize_policy only ENQUEUED its update (the accept test of the first line-search trials
+            # runs on the device), so the rollout above went out without the host waiting for it.  Now the update is closed; in the rare
+            # case that it was accepted at a later trial than the speculative ones, the policy changed after the rollout was enqueued
+            # and the rollout is repeated -- results are those of the synchronous order, always.
+            opt = getattr(self, 'optimizer', None)
+            if opt is not None and getattr(opt, 'pending', False):
+                if opt.finish().get('late'):
+                    paths = self.sampler.obtain_samples(itr, determ, **kw)
+            return paths
 
     def process_samples(self, itr, paths):
         with self.timers.phase('process'):
@@ -86,7 +95,8 @@ class NPO(BatchPolopt):
                                        agent_infos["mean"], agent_infos["log_std"], valid=samples_data.get("valids"),
                                        n_global=samples_data.get("n_valid_global"))
         with self.timers.phase('policy_opt'):
-            self.optimizer.optimize(self.engine, batch, comm=self.comm)
+            # async_line_search (off by default: the reference decides every trial on the host): see obtain_samples
+            self.optimizer.optimize(self.engine, batch, comm=self.comm, defer=bool(getattr(self, 'async_line_search', False)))
         if hasattr(self.sampler, 'finish_baseline_fit') and not getattr(self, 'defer_baseline_fit', False):
             self.sampler.finish_baseline_fit()
         return dict()

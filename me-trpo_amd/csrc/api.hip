@@ -1,6 +1,9 @@
 // C-ABI entry points of libmetrpo.so (include/metrpo.h): context management, argument checking,
 // dispatch to the kernels, and the host driver of one TRPO update.
 #include "metrpo_internal.h"
+#include <atomic>
+#include <chrono>
+#include <cstring>
 #include "cg_device.h"
 #include "trace.h"
 #include <algorithm>
@@ -58,13 +61,14 @@ static bool build_net(NetDesc* n, int n_in, const int32_t* hidden, const int32_t
     return true;
 }
 
-// CG workspace layout (doubles): gout[1+P] | x[P] | r[P] | p[P] | z[P] | step[P] | scal[8] | lk[2]
-struct CgView { double *gout, *x, *r, *p, *z, *step, *scal, *lk; };
+// CG workspace layout (doubles): gout[1+P] | x[P] | r[P] | p[P] | z[P] | step[P] | scal[8] | lk[2] | ls[4]
+struct CgView { double *gout, *x, *r, *p, *z, *step, *scal, *lk, *ls; };
 static CgView cg_view(metrpo_ctx* c) {
     const int P = c->pd.P;
     CgView v;
     v.gout = c->d_cg; v.x = v.gout + 1 + P; v.r = v.x + P; v.p = v.r + P; v.z = v.p + P; v.step = v.z + P;
-    v.scal = v.step + P; v.lk = v.scal + 8;      // lk directly behind scal[8]: run_trpo_update reads scal | lk back as ONE 10-double copy
+    v.scal = v.step + P; v.lk = v.scal + 8;      // lk directly behind scal[8], ls behind lk: run_trpo_update reads scal | lk | ls back as ONE 14-double copy
+    v.ls = v.lk + 2;                             // device-side line-search state (cg_device.h: CgTail::ls)
     return v;
 }
 
@@ -103,10 +107,10 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     c->device = device; c->dims = *d;
     c->d_dyn = c->d_norm = c->d_theta = nullptr; c->have_dyn = c->have_pol = false;
     c->d_dyn_img = c->d_pol_img = nullptr; c->pol_img_idx = -1; c->d_pol_imgval = nullptr; c->d_pol_vpos = nullptr; c->img_live = 0;
-    c->d_bptt = nullptr; c->bptt_cap = 0; c->det_cfg = -1; c->d_detpart = nullptr; c->detpart_cap = 0; c->det_gemm = 0; c->d_dg = nullptr; c->dg_cap = 0; c->vjp_gm = nullptr; c->d_pol_adam = nullptr; c->pol_adam_t = 0; c->mfma_cfg = -1; c->pol_mfma = -1; c->coop_cfg = -1; c->rollout_variant = 0;
+    c->d_bptt = nullptr; c->bptt_cap = 0; c->det_cfg = -1; c->d_detpart = nullptr; c->detpart_cap = 0; c->det_gemm = 0; c->d_dg = nullptr; c->dg_cap = 0; c->vjp_gm = nullptr; c->ls_skip = nullptr; c->d_pol_adam = nullptr; c->pol_adam_t = 0; c->mfma_cfg = -1; c->pol_mfma = -1; c->coop_cfg = -1; c->rollout_variant = 0;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_cg = nullptr; c->d_vf = nullptr; c->d_theta_try = nullptr;
     c->d_valbuf = nullptr; c->h_pinned = nullptr; c->n_sm = 256;
-    c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0; c->d_res = nullptr; c->res_cap = 0; c->res_seq = 0; c->res_failed = 0; c->last_rollout_kernel = -1; c->side_ready = 0; c->d_ticket = nullptr; c->d_hcache = nullptr; c->hcache_cap = 0; c->hcache_on = 0; c->d_mig = nullptr; c->mig_cap = 0; c->mig_epoch = 0; c->nccl_comm = nullptr; c->comm_world = 0; c->comm_rank = 0; c->pol_path = 1; c->d_pg = nullptr; c->pg_cap = 0; c->pg_fwd_rows = -1; c->pg_fwd_obs = nullptr; c->d_adam = nullptr; c->adam_t = 0; c->d_train = nullptr; c->train_cap = 0;
+    c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0; c->d_res = nullptr; c->res_cap = 0; c->res_seq = 0; c->res_failed = 0; c->last_rollout_kernel = -1; c->upd_pending = 0; c->upd_spec = 0; c->h_upd = nullptr; c->upd_stamp = 0; c->side_ready = 0; c->d_ticket = nullptr; c->d_hcache = nullptr; c->hcache_cap = 0; c->hcache_on = 0; c->d_mig = nullptr; c->mig_cap = 0; c->mig_epoch = 0; c->nccl_comm = nullptr; c->comm_world = 0; c->comm_rank = 0; c->pol_path = 1; c->d_pg = nullptr; c->pg_cap = 0; c->pg_fwd_rows = -1; c->pg_fwd_obs = nullptr; c->d_adam = nullptr; c->adam_t = 0; c->d_train = nullptr; c->train_cap = 0;
     ProblemDesc& pd = c->pd;
     pd.env = d->env; pd.ns = d->ns; pd.na = d->na; pd.K = d->n_models; pd.n_drop = d->n_drop;
     pd.nin = d->ns + d->na - d->n_drop;
@@ -120,7 +124,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     if (hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return METRPO_EHIP; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_sm = prop.multiProcessorCount;
-    const size_t ncg = (size_t)(1 + pd.P) + 5 * (size_t)pd.P + 8 + 2;
+    const size_t ncg = (size_t)(1 + pd.P) + 5 * (size_t)pd.P + 8 + 2 + 4;
     if (hipMalloc(&c->d_dyn, sizeof(float) * (size_t)pd.K * pd.dyn.n_params) != hipSuccess ||
         hipMalloc(&c->d_norm, sizeof(float) * (2 * (pd.ns + pd.na) + 2 * pd.ns)) != hipSuccess ||
         hipMalloc(&c->d_theta, sizeof(float) * pd.P) != hipSuccess ||
@@ -158,6 +162,7 @@ extern "C" int32_t metrpo_destroy(metrpo_ctx* c) {
         (void)hipEventDestroy(c->ev_fork);
     }
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->h_upd) (void)hipHostFree(c->h_upd);
     delete c;
     return METRPO_OK;
 }
@@ -456,29 +461,47 @@ __global__ void k_cg_finish(int P, double reg, double max_kl, const double* x, d
     cg_finish_body(P, reg, max_kl, x, z, step, scal, sh);
 }
 
+// the update's outcome (scal[8] | lk[2] | ls[4]) into pinned host memory, then the stamp the host is polling for (one wave: program order + fence)
+__global__ void k_ls_publish(const double* __restrict__ src, double* dst, unsigned long long stamp) {
+    if (threadIdx.x < 14) __hip_atomic_store(dst + threadIdx.x, src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    if (threadIdx.x == 0) __hip_atomic_store((unsigned long long*)(dst + 16), stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_ls_reset(double* ls) { if (threadIdx.x == 0) { ls[0] = -1.0; ls[1] = NAN; ls[2] = NAN; ls[3] = 0.0; } }
 __global__ void k_zero_f(float* p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0.0f;
 }
 
-__global__ void k_try_theta(int P, double ratio, const float* __restrict__ prev, const double* __restrict__ step, float* cur) {
+__global__ void k_try_theta(int P, double ratio, const float* __restrict__ prev, const double* __restrict__ step, float* cur, const double* __restrict__ ls) {
+    if (ls != nullptr && ls[0] >= 0.0) return;                      // speculative trial after the search stopped: cur must keep the accepted theta's source
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < P) cur[i] = (float)((double)prev[i] - ratio * step[i]);     // cur_param = prev_param - ratio * flat_descent_step
 }
 
+// phase: 0 = the whole update with the line search decided on the host (one synchronisation per trial, as the reference does);
+//        1 = metrpo_trpo_update_begin: solve + the first `spec` line-search trials enqueued with the accept test on the DEVICE (ls_decide), no
+//            synchronisation; 2 = metrpo_trpo_update_end: fetch the outcome, continue on the host from trial `spec` if the search has not stopped
 static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_params* pr, metrpo_trpo_diag* diag,
-                                double* g_out, double* dir_out, hipStream_t st);
+                                double* g_out, double* dir_out, hipStream_t st, int phase, int spec);
 // The arrival counter of the fused tails (d_ticket) resets itself in the last block of every reduction, so a completed update leaves it
 // at zero.  An update that FAILED half-way (a launch error, a time-out) may not: it is cleared on the error path, where the cost of a
 // 4-byte memset does not matter -- a stale count would silently disable every later CG tail.
 int run_trpo_update(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_params* pr, metrpo_trpo_diag* diag,
-                    double* g_out, double* dir_out, hipStream_t st) {
-    const int rc = run_trpo_update_impl(c, b, pr, diag, g_out, dir_out, st);
-    if (rc != METRPO_OK) { (void)hipGetLastError(); (void)hipMemsetAsync(c->d_ticket, 0, sizeof(unsigned int), st); }
+                    double* g_out, double* dir_out, hipStream_t st, int phase, int spec) {
+    const int rc = run_trpo_update_impl(c, b, pr, diag, g_out, dir_out, st, phase, spec);
+    if (rc != METRPO_OK) { (void)hipGetLastError(); (void)hipMemsetAsync(c->d_ticket, 0, sizeof(unsigned int), st); c->upd_pending = 0; }
     return rc;
 }
+// Can this update's line search be decided on the device?  Needs the single-launch-sequence update (no host callback / stand-alone
+// all-reduce between a reduction and its consumer) on the fused MFMA or generic kernels; the GEMM path has its own reductions.
+static bool device_line_search_ok(const metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_params* pr) {
+    const bool xg = (pr->allreduce == nullptr && c->xg_world > 1);
+    const bool fused = (pr->allreduce == nullptr && ((c->nccl_comm == nullptr && !xg) || (xg && !policy_gemm_applicable(c, b->N))));
+    return fused && !policy_gemm_applicable(c, b->N) && getenv("METRPO_NO_DEVICE_LINESEARCH") == nullptr;
+}
 static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_params* pr, metrpo_trpo_diag* diag,
-                                double* g_out, double* dir_out, hipStream_t st) {
+                                double* g_out, double* dir_out, hipStream_t st, int phase, int spec) {
     const int P = c->pd.P;
     CgView v = cg_view(c);
     int rc;
@@ -501,12 +524,13 @@ static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metr
     const int implicit_hd = pr->explicit_final_hvp ? 0 : 1;
     CgTail tl; tl.P = P; tl.last = 0; tl.implicit_hd = implicit_hd; tl.reg = pr->reg_coeff; tl.tol = pr->residual_tol; tl.max_kl = pr->max_kl;
     tl.x = v.x; tl.r = v.r; tl.p = v.p; tl.z = v.z; tl.step = v.step; tl.scal = v.scal; tl.gout = v.gout; tl.pf = c->d_vf; tl.ticket = c->d_ticket;
+    tl.vpos = nullptr; tl.imgval = nullptr; tl.ls = nullptr; tl.lk = nullptr; tl.th = nullptr; tl.th_try = nullptr; tl.trial = 0; tl.accept_violation = 0;
+    if (phase != 2) {
     tl.op = 3;
     c->hcache_on = 1;                    // the gradient kernel publishes tanh activations, the CG products of this solve reuse them
     // ... and, when every CG vector comes out of a fused tail, its weight-fragment image; the tails add the tangent entries (policy_mfma.hip)
     c->img_live = (fused && c->pol_mfma >= 0 && !policy_gemm_applicable(c, b->N) && getenv("METRPO_NO_IMGVAL") == nullptr) ? 1 : 0;
     struct CacheOff { metrpo_ctx* c; ~CacheOff() { c->hcache_on = 0; c->img_live = 0; } } cache_off{c};
-    tl.vpos = nullptr; tl.imgval = nullptr;
     if (c->img_live) {
         if ((rc = policy_mfma_image_buffers(c))) return rc;
         tl.vpos = c->d_pol_vpos; tl.imgval = c->d_pol_imgval;
@@ -536,16 +560,59 @@ static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metr
             hipLaunchKernelGGL(k_cg_finish, dim3(1), dim3(1024), 0, st, P, pr->reg_coeff, pr->max_kl, v.x, v.z, v.step, v.scal);
         }
     }
+    tl.vpos = nullptr; tl.imgval = nullptr;
     if (g_out) HIP_TRY(c, hipMemcpyAsync(g_out, v.gout + 1, sizeof(double) * P, hipMemcpyDeviceToDevice, st));
     if (dir_out) HIP_TRY(c, hipMemcpyAsync(dir_out, v.x, sizeof(double) * P, hipMemcpyDeviceToDevice, st));
-    // read-backs: ONE copy per line-search trial fetches scal[8] | lk[2] (loss at theta, beta, CG iterations, trial loss and KL)
+    }
+    const int nspec = std::min(spec, (int)pr->max_backtracks);
+    if (phase == 1) {
+        // ---- the first `nspec` trials of the backtracking line search, each one's accept test in the tail of its own reduction (ls_decide): an
+        //      accepted trial's theta is in place when the caller's next launch reads it; trials after the one that stopped the search leave at once
+        hipLaunchKernelGGL(k_ls_reset, dim3(1), dim3(64), 0, st, v.ls);
+        for (int n = 0; n < nspec; ++n) {
+            const double ratio = std::pow(pr->backtrack_ratio, (double)n);
+            hipLaunchKernelGGL(k_try_theta, dim3((P + 255) / 256), dim3(256), 0, st, P, ratio, c->d_theta, v.step, c->d_theta_try, (const double*)v.ls);
+            CgTail dt = tl;
+            dt.op = 4; dt.ls = v.ls; dt.lk = v.lk; dt.th = c->d_theta; dt.th_try = c->d_theta_try; dt.trial = n; dt.accept_violation = pr->accept_violation;
+            if ((rc = launch_loss_kl(c, b, c->d_theta_try, v.lk, st, &dt))) return rc;
+        }
+        if (c->mfma_cfg >= 0 && (rc = mfma_prepare_policy(c, st))) return rc;      // of whatever theta the trials left in place
+        if (!c->h_upd) { HIP_TRY(c, hipHostMalloc((void**)&c->h_upd, sizeof(double) * 17)); memset(c->h_upd, 0, sizeof(double) * 17); }
+        c->upd_stamp += 1;                                          // _end waits for THIS stamp, not for what the caller enqueues after _begin
+        hipLaunchKernelGGL(k_ls_publish, dim3(1), dim3(64), 0, st, (const double*)v.scal, c->h_upd, c->upd_stamp);
+        HIP_TRY(c, hipGetLastError());
+        c->upd_pending = 1; c->upd_spec = nspec; c->upd_batch = *b; c->upd_params = *pr;
+        return METRPO_OK;
+    }
+    // read-backs: ONE copy per line-search trial fetches scal[8] | lk[2] | ls[4] (loss at theta, beta, CG iterations, trial loss and KL)
     double loss = NAN, kl = NAN, loss_before = NAN;
-    int n_iter = 0;
-    bool first = true;
-    for (int n = 0; n < pr->max_backtracks; ++n) {
+    int n_iter = 0, n_start = 0;
+    bool first = true, stopped = false, taken = false;
+    if (phase == 2) {
+        {   // the outcome _begin's last kernel published (a busy wait: this thread has nothing else to do, and a blocking wait costs 10-20 us to wake)
+            volatile unsigned long long* stamp = (volatile unsigned long long*)(c->h_upd + 16);
+            const auto t0 = std::chrono::steady_clock::now();
+            long spins = 0;
+            while (*stamp != c->upd_stamp) {
+                if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+                    HIP_TRY(c, hipStreamSynchronize(st));         // surfaces a device fault; a healthy stream has published by now
+                    if (*stamp != c->upd_stamp) return set_err(c, METRPO_EHIP, "trpo_update_end: the update's outcome never arrived");
+                }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            for (int i = 0; i < 14; ++i) c->h_pinned[i] = c->h_upd[i];
+        }
+        if (c->h_pinned[S_COMMERR] != 0.0) return set_err(c, METRPO_EHIP, "trpo_update: one-shot all-reduce timed out (a rank did not arrive)");
+        if (c->h_pinned[S_ROLLERR] != 0.0) return rollout_error_seen(c, st);
+        loss_before = c->h_pinned[S_LOSS0]; first = false;
+        loss = c->h_pinned[11]; kl = c->h_pinned[12];
+        n_start = nspec; n_iter = nspec > 0 ? nspec - 1 : 0;
+        if (c->h_pinned[10] >= 0.0) { stopped = true; n_iter = (int)c->h_pinned[10]; taken = c->h_pinned[13] != 0.0; }
+    }
+    for (int n = n_start; n < pr->max_backtracks && !stopped; ++n) {
         n_iter = n;
         const double ratio = std::pow(pr->backtrack_ratio, (double)n);
-        hipLaunchKernelGGL(k_try_theta, dim3((P + 255) / 256), dim3(256), 0, st, P, ratio, c->d_theta, v.step, c->d_theta_try);
+        hipLaunchKernelGGL(k_try_theta, dim3((P + 255) / 256), dim3(256), 0, st, P, ratio, c->d_theta, v.step, c->d_theta_try, (const double*)nullptr);
         if ((rc = launch_loss_kl(c, b, c->d_theta_try, v.lk, st))) return rc;
         AR(v.lk, 2);
         HIP_TRY(c, hipMemcpyAsync(c->h_pinned, v.scal, sizeof(double) * 10, hipMemcpyDeviceToHost, st));
@@ -562,7 +629,8 @@ static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metr
     }
     bool accepted = true;
     if ((std::isnan(loss) || std::isnan(kl) || loss >= loss_before || kl >= pr->max_kl) && !pr->accept_violation) accepted = false;
-    if (accepted) {
+    if (stopped) accepted = taken;                               // decided on the device: an accepted trial's theta is already the policy
+    else if (accepted) {
         std::swap(c->d_theta, c->d_theta_try);               // both ctx-owned, every launch takes c->d_theta afresh: no copy
         if (c->mfma_cfg >= 0 && (rc = mfma_prepare_policy(c, st))) return rc;
     }
@@ -583,7 +651,46 @@ extern "C" int32_t metrpo_trpo_update(metrpo_ctx* c, const metrpo_batch* b, cons
     NEED_POL(c);
     if (!b || !pr) return set_err(c, METRPO_ENULL, "trpo_update: NULL pointer");
     if (pr->cg_iters < 0 || pr->max_backtracks < 1) return set_err(c, METRPO_EINVAL, "trpo_update: bad cg_iters/max_backtracks");
-    return run_trpo_update(c, b, pr, diag, g_out, dir_out, (hipStream_t)stream);
+    if (c->upd_pending) return set_err(c, METRPO_ESTATE, "trpo_update: an update begun with metrpo_trpo_update_begin is still open (call metrpo_trpo_update_end)");
+    return run_trpo_update(c, b, pr, diag, g_out, dir_out, (hipStream_t)stream, 0, 0);
+}
+
+// The same update in two halves, so that the host can go on enqueuing work (the next rollout) while the line search is being decided: _begin
+// launches gradient, CG solve and the first `spec_trials` trials of the backtracking search with the accept test on the device and returns
+// WITHOUT synchronising; launches that follow it on the stream see the accepted trial's theta (or theta_prev).  _end synchronises, reports the
+// diagnostics and -- only if none of the speculative trials stopped the search -- runs the remaining trials the ordinary way.  If the returned
+// *late_out is 1, the policy changed inside _end: work enqueued in between used theta_prev and must be redone.
+// Where the accept test cannot run on the device (host all-reduce callback, RCCL transport, GEMM update path) _begin does the whole update
+// synchronously and _end only hands out the stored diagnostics.  d_g_out / d_dir_out as in metrpo_trpo_update.
+extern "C" int32_t metrpo_trpo_update_begin(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_params* pr, int32_t spec_trials,
+                                            double* g_out, double* dir_out, void* stream) {
+    TraceRange trace_("metrpo:trpo_update_begin (optimize_policy, line search decided on the device)");
+    if (!c) return METRPO_ENULL;
+    NEED_POL(c);
+    if (!b || !pr) return set_err(c, METRPO_ENULL, "trpo_update_begin: NULL pointer");
+    if (pr->cg_iters < 0 || pr->max_backtracks < 1 || spec_trials < 1) return set_err(c, METRPO_EINVAL, "trpo_update_begin: bad cg_iters / max_backtracks / spec_trials");
+    if (c->upd_pending) return set_err(c, METRPO_ESTATE, "trpo_update_begin: the previous update is still open (call metrpo_trpo_update_end)");
+    if (!device_line_search_ok(c, b, pr)) {
+        const int rc = run_trpo_update(c, b, pr, &c->upd_diag, g_out, dir_out, (hipStream_t)stream, 0, 0);
+        if (rc == METRPO_OK) { c->upd_pending = 2; c->upd_spec = pr->max_backtracks; }      // complete: _end hands out upd_diag
+        return rc;
+    }
+    return run_trpo_update(c, b, pr, nullptr, g_out, dir_out, (hipStream_t)stream, 1, spec_trials);
+}
+extern "C" int32_t metrpo_trpo_update_end(metrpo_ctx* c, metrpo_trpo_diag* diag, int32_t* late_out, void* stream) {
+    TraceRange trace_("metrpo:trpo_update_end");
+    if (!c) return METRPO_ENULL;
+    if (late_out) *late_out = 0;
+    if (!c->upd_pending) return set_err(c, METRPO_ESTATE, "trpo_update_end: no update is open");
+    if (c->upd_pending == 2) { if (diag) *diag = c->upd_diag; c->upd_pending = 0; return METRPO_OK; }
+    metrpo_trpo_diag d = {};
+    const int rc = run_trpo_update(c, &c->upd_batch, &c->upd_params, &d, nullptr, nullptr, (hipStream_t)stream, 2, c->upd_spec);
+    c->upd_pending = 0;
+    if (rc == METRPO_OK) {
+        if (diag) *diag = d;
+        if (late_out) *late_out = (d.accepted && d.n_backtrack >= c->upd_spec) ? 1 : 0;
+    }
+    return rc;
 }
 
 // ---- BPTT policy update -----------------------------------------------------------------------

@@ -12,7 +12,8 @@ enum { S_RDOTR = 0, S_DONE = 1, S_BETA = 2, S_XHX = 3, S_ITERS = 4, S_LOSS0 = 5,
 //   // S_LOSS0: surrogate loss at theta (copy of gout[0]: one read-back fetches scal | lk)
 
 struct CgTail {
-    int op;                 // 0 none, 1 = CG iteration, 2 = step-size finish from an explicit H.d, 3 = CG initialisation from the gradient
+    int op;                 // 0 none, 1 = CG iteration, 2 = step-size finish from an explicit H.d, 3 = CG initialisation from the gradient,
+                            // 4 = accept test of one line-search trial (ls_decide)
     int P, last;            // last: final CG iteration; with `implicit_hd` it also finishes (step = beta * x) from the CG recurrence
     int implicit_hd;
     double reg, tol, max_kl;
@@ -21,6 +22,11 @@ struct CgTail {
     float* pf;
     const int* vpos; float* imgval;   // non-NULL: every pf element with an image position (policy_mfma.hip tangent tables) is also stored there
     unsigned int* ticket;   // zero at allocation; the last block of every reduction resets it
+    // op 4 (metrpo_trpo_update_begin: speculative line-search trials decided on the device)
+    double* ls;             // [4]: index of the trial the search stopped at (-1: none yet) | its loss | its KL | 1 = its theta was taken
+    const double* lk;       // [2]: loss, KL of this trial (the reduction's own output)
+    float* th; const float* th_try;
+    int trial, accept_violation;
 };
 
 // float copy of the next FVP input, element i; mirrored into the weight-fragment image the cached-activation FVP copies (see CgTail::vpos)
@@ -191,6 +197,19 @@ __device__ __forceinline__ void cg_finish_body(int P, double reg, double max_kl,
     if (threadIdx.x == 0) { scal[S_BETA] = beta; scal[S_XHX] = xhx; }
 }
 
+// One pass of ConjugateGradientOptimizer.optimize's backtracking loop, decided where the numbers are: the loop's break test
+// (loss < loss_before and kl <= max_kl) and, when it breaks, the acceptance rule that follows the loop (rejects a NaN, loss >= loss_before or
+// kl >= max_kl unless accept_violation) -- an accepted trial's theta replaces the policy at once.  Later speculative trials see ls[0] >= 0
+// and leave without doing anything.  One block, all threads; lk was written by this block (a barrier lies in between).
+__device__ __forceinline__ void ls_decide(const CgTail& t) {
+    const double loss = t.lk[0], kl = t.lk[1], lb = t.scal[S_LOSS0];
+    if (loss < lb && kl <= t.max_kl) {
+        const bool acc = !(isnan(loss) || isnan(kl) || loss >= lb || kl >= t.max_kl) || t.accept_violation != 0;
+        if (acc) for (int i = threadIdx.x; i < t.P; i += blockDim.x) t.th[i] = t.th_try[i];
+        if (threadIdx.x == 0) { t.ls[0] = (double)t.trial; t.ls[1] = loss; t.ls[2] = kl; t.ls[3] = acc ? 1.0 : 0.0; }
+    } else if (threadIdx.x == 0) { t.ls[1] = loss; t.ls[2] = kl; }
+}
+
 // CG tail dispatch shared by k_finalize and the in-kernel reduction of policy_mfma.hip (one block, all threads)
 __device__ __forceinline__ void cg_tail_run(const CgTail& t, double* sh, const CgPre* pre = nullptr) {
     if (t.op == 1) {
@@ -201,4 +220,5 @@ __device__ __forceinline__ void cg_tail_run(const CgTail& t, double* sh, const C
         }
     } else if (t.op == 2) cg_finish_body(t.P, t.reg, t.max_kl, t.x, t.z, t.step, t.scal, sh);
     else if (t.op == 3) cg_init_body(t.P, t.gout, t.x, t.r, t.p, PfOut{t.pf, t.vpos, t.imgval}, t.scal, sh);
+    else if (t.op == 4) ls_decide(t);
 }

@@ -50,6 +50,7 @@ struct metrpo_ctx {
     // --- BPTT (bptt.hip) ---
     void* d_bptt; size_t bptt_cap;      // XS | WT | GM | gout | costs
     const float* vjp_gm;                // set around the VJP launch of the gradient kernels
+    const double* ls_skip;              // set around a speculative line-search evaluation (PolK::skip of the fused MFMA kernels)
     void* d_pol_adam; int pol_adam_t;   // Adam moments of the policy parameters + segment table
     int det_cfg;                        // bptt_mfma.hip table index (-1: generic sweeps / generic validation kernel)
     double* d_detpart; size_t detpart_cap;   // per-tile cost partials of the MFMA forward sweep
@@ -88,7 +89,13 @@ struct metrpo_ctx {
     size_t big_cap;
     void* d_res; size_t res_cap; unsigned int res_seq;   // rollout_resident.hip: uncached exchange region (abort cell | X packets | P packets) and the step stamps issued so far
     int res_failed;                                       // a resident launch gave up (its grid was not co-resident): this context stays on the step-wise path from then on
-    int last_rollout_kernel;                              // which kernel family the last metrpo_rollout ran on: 0 generic, 1 head-per-wave MFMA, 2 cooperative MFMA, 3 step-wise GEMM, 4 resident
+    int last_rollout_kernel;
+    // metrpo_trpo_update_begin / _end: an update whose line search is still undecided on the host
+    // metrpo_trpo_update_begin's outcome lands in pinned host memory straight from its last kernel (k_ls_publish: scal | lk | ls, then a
+    // stamp); _end polls the stamp (no copy engine, no event, no blocking wait to wake up from).  Publishing from a side stream behind a device-scope
+    // event was measured too: the second queue costs the update 35 us, more than the 15 us gap in front of the next rollout it removes.
+    double* h_upd; unsigned long long upd_stamp;
+    int upd_pending, upd_spec; metrpo_batch upd_batch; metrpo_trpo_params upd_params; metrpo_trpo_diag upd_diag;                              // which kernel family the last metrpo_rollout ran on: 0 generic, 1 head-per-wave MFMA, 2 cooperative MFMA, 3 step-wise GEMM, 4 resident
     hipStream_t side_stream[METRPO_MAX_PAR_ROUNDS - 1]; hipEvent_t ev_fork, ev_join[METRPO_MAX_PAR_ROUNDS - 1]; int side_ready;   // rollout_gemm.hip: independent rounds of a small-batch rollout run concurrently
     double* h_pinned;    // pinned host scratch for the per-trial read-back
     int n_sm;            // CU count
@@ -130,6 +137,7 @@ struct PolK {
     int ls_stride; const uint8_t* valid; long long N; float inv_n;
     const float* gm;         // non-NULL: VJP mode of the gradient kernels (bptt.hip): d objective / d mean [N][na] supplied, no loss terms
     const int* img_map;      // policy_mfma.hip: gather map of the LDS weight-fragment image (built once per ctx on the host)
+    const double* skip;      // non-NULL: a line-search trial that leaves at once when skip[0] >= 0 (the search already stopped: CgTail::ls)
     float* imgval;           // policy_mfma.hip: non-NULL while metrpo_ctx::img_live -- gradient kernel: block 0 publishes its image here; MODE_FVPC: the image to copy
     float* hcache;           // policy_mfma.hip: hidden activations of (theta, batch): written by the gradient kernel, read by MODE_FVPC
 };
@@ -207,6 +215,6 @@ int launch_fvp(metrpo_ctx*, const metrpo_batch*, const double*, double*, hipStre
 int launch_fvp_f32(metrpo_ctx*, const metrpo_batch*, const float* vf, const double* v, double* hv, hipStream_t);
 // FVP + reduction + (in the reduction kernel's last block) the CG vector step described by `tail`
 int launch_fvp_tail(metrpo_ctx*, const metrpo_batch*, const float* vf, const double* v, double* hv, const CgTail* tail, hipStream_t);
-int launch_loss_kl(metrpo_ctx*, const metrpo_batch*, const float*, double*, hipStream_t);
+int launch_loss_kl(metrpo_ctx*, const metrpo_batch*, const float*, double*, hipStream_t, const CgTail* decide = nullptr);   // decide: op 4 tail (device-side accept test)
 int run_trpo_update(metrpo_ctx*, const metrpo_batch*, const metrpo_trpo_params*, metrpo_trpo_diag*, double*,
-                    double*, hipStream_t);
+                    double*, hipStream_t, int phase = 0, int spec = 0);

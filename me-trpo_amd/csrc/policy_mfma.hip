@@ -105,6 +105,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index in an SGPR: tile indices and base pointers stay scalar
     const int c = lane & 15, q = lane >> 4;
+    if (MODE_ == MODE_LOSSKL && k.skip != nullptr && k.skip[0] >= 0.0) return;      // speculative line-search trial after the search stopped
     float* IMG = lds;
     float* TL = lds + I::TOTAL + wave * WTL;
     PT_MARK(0)
@@ -762,6 +763,7 @@ int policy_mfma_launch(metrpo_ctx* c, int idx, int mode, const metrpo_batch* b, 
     { const int rc = policy_mfma_image_buffers(c); if (rc) return rc; }
     k.img_map = (const int*)c->d_pol_img;
     k.gm = c->vjp_gm;
+    k.skip = c->ls_skip;
     k.hcache = nullptr;
     k.imgval = (c->img_live && c->hcache_on && k.gm == nullptr && (mode == MODE_GRAD || mode == MODE_FVP)) ? c->d_pol_imgval : nullptr;
     if (c->hcache_on && (mode == MODE_GRAD || mode == MODE_FVP) && k.gm == nullptr) {      // set by run_trpo_update around one CG solve

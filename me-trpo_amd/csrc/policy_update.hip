@@ -244,6 +244,7 @@ __global__ void __launch_bounds__(PT) k_loss_kl(ProblemDesc pd, PolK k, const fl
     constexpr int PLD = PT + 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ double red[16];
+    if (k.skip != nullptr && k.skip[0] >= 0.0) return;        // speculative line-search trial after the search stopped
     const NetDesc& net = pd.pol;
     const int tid = threadIdx.x, ns = pd.ns, na = pd.na;
     float* S = lds;
@@ -293,6 +294,11 @@ __global__ void __launch_bounds__(1024) k_finalize(ProblemDesc pd, int mode, int
     // s, s+NSL, ... and the slice sums are added in slice order: deterministic.  32 columns = one 128-byte line per row read.
     constexpr int NSL = 1024 / FIN_C;
     __shared__ double sh[NSL][FIN_C + 1];
+    if (tail.op == 4 && tail.ls[0] >= 0.0) {                  // speculative line-search trial after the search stopped (every block reads the same cell)
+        // a sharded run keeps its exchanges in step: the slot protocol (xchg_device.h) counts on every sequence number being used by every rank
+        if (xc.world > 1 && blockIdx.x == 0 && threadIdx.x < 2) { xchg_push(xc, (int)threadIdx.x, 0.0); (void)xchg_pull_sum(xc, (int)threadIdx.x); }
+        return;
+    }
     FT_MARK(0)
     CgPre pre;
     cg_prefetch(tail, pre);                 // every block (nobody knows yet who arrives last); these vectors are not written by this launch
@@ -383,14 +389,14 @@ static int fill_polk(metrpo_ctx* c, const metrpo_batch* b, PolK* k, bool need_ta
         return set_err(c, METRPO_ENULL, "batch pointer is NULL");
     k->obs = b->d_obs; k->act = b->d_act; k->adv = b->d_adv; k->old_mean = b->d_old_mean; k->old_ls = b->d_old_log_std;
     k->ls_stride = b->old_log_std_stride; k->valid = b->d_valid; k->N = b->N; k->inv_n = (float)b->inv_n_global;
-    k->gm = nullptr; k->img_map = nullptr; k->hcache = nullptr; k->imgval = nullptr;
+    k->gm = nullptr; k->img_map = nullptr; k->hcache = nullptr; k->imgval = nullptr; k->skip = nullptr;
     return METRPO_OK;
 }
 
 static void finalize(metrpo_ctx* c, int mode, int nrows, int stride, int lk_col, const double* v, double* out, hipStream_t st,
                      const CgTail* tail = nullptr) {
     const int nout = (mode == 0) ? c->pd.P + 1 : (mode == 1) ? c->pd.P : 2;
-    CgTail none; none.op = 0; none.ticket = c->d_ticket; none.vpos = nullptr; none.imgval = nullptr;
+    CgTail none; none.op = 0; none.ticket = c->d_ticket; none.vpos = nullptr; none.imgval = nullptr; none.ls = nullptr;
     // inside a fused update of a sharded run (run_trpo_update raises xg_fuse) the reduction carries the cross-rank sum in its tail
     const XchgK xc = (c->xg_fuse && c->xg_world > 1) ? xchg_next(c) : xchg_none();
     hipLaunchKernelGGL(k_finalize, dim3((nout + FIN_C - 1) / FIN_C), dim3(1024), 0, st, c->pd, mode, nrows, stride, lk_col,
@@ -435,7 +441,10 @@ static int run_mode(metrpo_ctx* c, int mode, const metrpo_batch* b, const PolK& 
         const int g = (int)std::max<long long>(1, std::min<long long>((tiles + 7) / 8, (long long)c->n_sm * (mode == 2 ? 2 : 1)));
         int rc = ensure_partials(c, g); if (rc) return rc;
         *nrows = g; *stride = P + PART_EXTRA; *lk_col = P;
-        return policy_mfma_launch(c, c->pol_mfma, mode, b, theta, vf, c->d_partials, g, st);
+        c->ls_skip = k.skip;
+        rc = policy_mfma_launch(c, c->pol_mfma, mode, b, theta, vf, c->d_partials, g, st);
+        c->ls_skip = nullptr;
+        return rc;
     }
     *stride = (mode == 2) ? 2 : P + PART_EXTRA; *lk_col = 0;
     int rc = launch_generic<128>(c, mode, k, theta, vf, nrows, st);
@@ -499,12 +508,16 @@ int launch_fvp_tail(metrpo_ctx* c, const metrpo_batch* b, const float* vf, const
     return METRPO_OK;
 }
 
-int launch_loss_kl(metrpo_ctx* c, const metrpo_batch* b, const float* theta, double* out, hipStream_t st) {
+int launch_loss_kl(metrpo_ctx* c, const metrpo_batch* b, const float* theta, double* out, hipStream_t st, const CgTail* decide) {
     PolK k; int rc = fill_polk(c, b, &k, true); if (rc) return rc;
-    if (policy_gemm_applicable(c, b->N)) return policy_gemm_run(c, 2, b, k, theta ? theta : c->d_theta, nullptr, nullptr, out, nullptr, st);
+    if (policy_gemm_applicable(c, b->N)) {
+        if (decide) return set_err(c, METRPO_EUNSUPPORTED, "device-side line search: not on the GEMM update path");
+        return policy_gemm_run(c, 2, b, k, theta ? theta : c->d_theta, nullptr, nullptr, out, nullptr, st);
+    }
+    if (decide) k.skip = decide->ls;
     int nrows, stride, lk;
     if ((rc = run_mode(c, 2, b, k, theta ? theta : c->d_theta, nullptr, &nrows, &stride, &lk, st))) return rc;
-    finalize(c, 2, nrows, stride, lk, nullptr, out, st);
+    finalize(c, 2, nrows, stride, lk, nullptr, out, st, decide);
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;
 }

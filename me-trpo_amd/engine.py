@@ -388,8 +388,9 @@ class Engine(object):
         return out
 
     def trpo_update(self, batch, max_kl=0.01, cg_iters=10, reg_coeff=1e-5, backtrack_ratio=0.8, max_backtracks=15,
-                    accept_violation=False, residual_tol=1e-10, allreduce=None, want_vectors=False, explicit_final_hvp=False):
-        """One ConjugateGradientOptimizer.optimize; `allreduce(tensor_f64)` reduces in place across ranks."""
+                    accept_violation=False, residual_tol=1e-10, allreduce=None, want_vectors=False, explicit_final_hvp=False, spec_trials=0):
+        """One ConjugateGradientOptimizer.optimize; `allreduce(tensor_f64)` reduces in place across ranks.  spec_trials = S > 0: only
+        enqueue it, with the first S line-search trials decided on the device (no synchronisation; see trpo_update_end)."""
         p = _lib.TrpoParams()
         p.max_kl, p.cg_iters, p.reg_coeff, p.backtrack_ratio = max_kl, cg_iters, reg_coeff, backtrack_ratio
         p.max_backtracks, p.accept_violation, p.residual_tol = max_backtracks, int(accept_violation), residual_tol
@@ -413,10 +414,33 @@ class Engine(object):
         g = d = None
         if want_vectors:
             g = torch.empty(self.P, dtype=torch.float64, device=self.device); d = torch.empty_like(g)
+        if spec_trials:
+            # first half only (metrpo_trpo_update_begin): no synchronisation; trpo_update_end() returns the diagnostics
+            self._chk(lib.metrpo_trpo_update_begin(self._ctx, C.byref(batch), C.byref(p), int(spec_trials), _ptr(g), _ptr(d), self._stream()))
+            self._upd_open = (batch, p, g, d, int(spec_trials))              # keeps the batch struct and the output tensors alive until _end
+            return None
         self._chk(lib.metrpo_trpo_update(self._ctx, C.byref(batch), C.byref(p), C.byref(diag), _ptr(g), _ptr(d), self._stream()))
         out = dict(loss_before=diag.loss_before, loss=diag.loss, kl=diag.kl, beta=diag.beta,
                    n_backtrack=diag.n_backtrack, accepted=bool(diag.accepted), cg_iters_run=diag.cg_iters_run)
         if want_vectors:
+            out['g'], out['d'] = g, d
+        return out
+
+    def trpo_update_end(self):
+        """Second half of trpo_update(..., spec_trials=S): waits for the update (not for launches enqueued after it) and returns its
+        diagnostics; 'late' is True when the policy changed inside this call (accepted at a trial >= S): work enqueued since the first
+        half saw the previous policy and must be redone."""
+        batch, p, g, d, spec = self._upd_open
+        diag = _lib.TrpoDiag()
+        late = C.c_int32(0)
+        try:
+            self._chk(lib.metrpo_trpo_update_end(self._ctx, C.byref(diag), C.byref(late), self._stream()))
+        finally:
+            self._upd_open = None
+        out = dict(loss_before=diag.loss_before, loss=diag.loss, kl=diag.kl, beta=diag.beta,
+                   n_backtrack=diag.n_backtrack, accepted=bool(diag.accepted), cg_iters_run=diag.cg_iters_run)
+        out['late'] = bool(late.value)
+        if g is not None:
             out['g'], out['d'] = g, d
         return out
 

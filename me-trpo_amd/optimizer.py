@@ -65,7 +65,34 @@ class ConjugateGradientOptimizer(object):
         self._accept_violation, self._fused = accept_violation, fused
         self._max_constraint_val = None
         self._constraint_name = None
-        self.last_diag = None
+        self._last_diag = None
+        self._open = None                    # engine whose update was only enqueued (optimize(..., defer=True)); finish() closes it
+        self.spec_trials = 2                 # line-search trials decided on the device by a deferred update (the first two cover ~95 % of C1's updates)
+
+    @property
+    def pending(self):
+        return self._open is not None
+
+    @property
+    def last_diag(self):
+        """Diagnostics of the last optimize(); closes a deferred update first."""
+        if self._open is not None:
+            self.finish()
+        return self._last_diag
+
+    @last_diag.setter
+    def last_diag(self, d):
+        self._last_diag = d
+
+    def finish(self):
+        """Second half of optimize(..., defer=True): waits for the update, stores and returns its diagnostics.  diag['late'] is True
+        when the policy changed only now (accepted at a later trial than the speculative ones): launches enqueued since optimize()
+        used the previous policy."""
+        if self._open is None:
+            return self._last_diag
+        eng, self._open = self._open, None
+        self._last_diag = eng.trpo_update_end()
+        return self._last_diag
 
     def update_opt(self, loss=None, target=None, leq_constraint=None, inputs=None, extra_inputs=None,
                    constraint_name="constraint", *args, **kwargs):
@@ -91,12 +118,23 @@ class ConjugateGradientOptimizer(object):
         t = comm.allreduce_sum_(t)
         return t.cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
 
-    def optimize(self, engine_or_evaluator, batch=None, comm=None):
+    def optimize(self, engine_or_evaluator, batch=None, comm=None, defer=False):
+        """defer=True (fused form only): enqueue the update with its first `spec_trials` line-search trials decided on the device and
+        return at once (None); finish() / last_diag complete it.  The caller may enqueue the next rollout in between (algos.BatchPolopt)."""
         comm = comm or Comm()
+        if self._open is not None:
+            self.finish()
         if self._fused and batch is not None:
             # ranks > 1: the ctx's own RCCL communicator when one is attached (all-reduces issued from C), else a host callback
             need = comm.world > 1 or comm.always_reduce
             ar = (lambda t: comm.allreduce_sum_(t)) if (need and not getattr(engine_or_evaluator, 'comm_world', 0)) else None
+            if defer and ar is None:
+                engine_or_evaluator.trpo_update(
+                    batch, max_kl=self._max_constraint_val, cg_iters=self._cg_iters, reg_coeff=self._reg_coeff,
+                    backtrack_ratio=self._backtrack_ratio, max_backtracks=self._max_backtracks,
+                    accept_violation=self._accept_violation, spec_trials=self.spec_trials)
+                self._open = engine_or_evaluator
+                return None
             self.last_diag = engine_or_evaluator.trpo_update(
                 batch, max_kl=self._max_constraint_val, cg_iters=self._cg_iters, reg_coeff=self._reg_coeff,
                 backtrack_ratio=self._backtrack_ratio, max_backtracks=self._max_backtracks,

@@ -64,6 +64,18 @@ def main(out_path, path, n_updates):
     theta = eng.get_policy().double()
     for t in (theta, out['g'], out['d']):
         assert same_on_all_ranks(t, world), "ranks ended with different vectors"
+    # ---- the same update in two halves (metrpo_trpo_update_begin / _end): three speculative line-search trials decided on the device, the
+    #      ones after the accepted trial leave at once but keep the exchange sequence in step -- same theta, bit for bit, and the protocol lives on
+    eng.set_policy(th)
+    assert eng.trpo_update(batch, spec_trials=3) is None
+    late = eng.trpo_update_end()
+    assert late['n_backtrack'] == out['n_backtrack'] and late['accepted'] == out['accepted'] and late['loss'] == out['loss'] and late['kl'] == out['kl']
+    if n_updates == 1:
+        assert torch.equal(eng.get_policy().double(), theta), "two-halves update differs from the one-call update"
+    assert same_on_all_ranks(eng.get_policy(), world)
+    probe = comm.allreduce_sum_(torch.full((5,), float(rank + 1), dtype=torch.float64, device='cuda'))
+    assert torch.equal(probe.cpu(), torch.full((5,), world * (world + 1) / 2.0, dtype=torch.float64))
+    eng.comm_check()
     if rank == 0:
         np.savez(out_path, theta=theta.cpu().numpy(), g=out['g'].cpu().numpy(), d=out['d'].cpu().numpy(), beta=out['beta'],
                  n_backtrack=out['n_backtrack'], accepted=out['accepted'], loss=out['loss'], kl=out['kl'],

@@ -675,3 +675,56 @@ def test_phase_timers_and_trace_ranges():
     s = algo.timers.summary()
     assert s['n'] == 4 and all(0.0 < s[k] < 50.0 for k in ('rollout_ms', 'process_ms', 'policy_opt_ms')), s
     assert len(algo.timers.times_ms('rollout')) == 4
+
+
+@pytest.mark.parametrize('use_mfma', [True, False, 'gemm'])
+def test_trpo_update_in_two_halves_equals_one_call(use_mfma):
+    """metrpo_trpo_update_begin / _end (line-search accept test on the device for the first S trials, no host synchronisation in the first
+    half) against metrpo_trpo_update: theta, loss, KL, trial index and acceptance bit for bit, for S below, at and above the accepted trial
+    ('late' = the policy changed inside the second half); the GEMM path falls back to the synchronous update inside the first half."""
+    import metrpo_amd
+    eng, th, pdims, obs, act, adv, om, ols = _update_problem(N=6000, seed=29)
+    eng.set_update_path(use_mfma)
+    for scale in (1.0, 40.0):                                   # different step sizes -> different numbers of backtracks
+        batch = eng.make_batch(obs, act, adv * scale, om, ols)
+        eng.set_policy(th)
+        ref = eng.trpo_update(batch, want_vectors=True)
+        th_ref = eng.get_policy().clone()
+        for S in (1, 2, 4):
+            eng.set_policy(th)
+            assert eng.trpo_update(batch, want_vectors=True, spec_trials=S) is None
+            with pytest.raises(metrpo_amd._lib.MetrpoError, match='still open'):
+                eng.trpo_update(batch)
+            out = eng.trpo_update_end()
+            assert torch.equal(eng.get_policy(), th_ref), (scale, S)
+            for key in ('loss_before', 'loss', 'kl', 'beta', 'n_backtrack', 'accepted', 'cg_iters_run'):
+                assert out[key] == ref[key], (key, scale, S)
+            assert torch.equal(out['g'], ref['g']) and torch.equal(out['d'], ref['d'])
+            assert out['late'] == (use_mfma != 'gemm' and ref['accepted'] and ref['n_backtrack'] >= S)
+    with pytest.raises(metrpo_amd._lib.MetrpoError, match='no update is open'):
+        eng._upd_open = (batch, None, None, None, 1); eng.trpo_update_end()
+
+
+def test_deferred_optimizer_closes_after_the_next_rollout():
+    """algos.async_line_search: optimize_policy only enqueues the update; the next obtain_samples enqueues its rollout and THEN closes it.
+    Three iterations give the policy and the trajectories of the synchronous order (same seeds), whatever the trial the search stops at."""
+    from test_gpu_api import build_algo
+    outs = []
+    for mode in (False, True):
+        algo, eng, dm, theta, pdims, pool = build_algo('swimmer', B=128, H=20, gamma=1.0, lam=1.0)
+        algo.async_line_search = mode
+        algo.optimizer.spec_trials = 1                           # forces the late path (and the repeated rollout) whenever trial 0 is rejected
+        acts = []
+        for j in range(3):
+            algo.start_worker()
+            paths = algo.obtain_samples(j)
+            acts.append(paths.traj.act.clone())
+            samples = algo.process_samples(j, paths)
+            algo.optimize_policy(j, samples)
+        assert algo.optimizer.pending == mode
+        d = algo.optimizer.last_diag
+        assert not algo.optimizer.pending and d['accepted']
+        outs.append((eng.get_policy().clone(), acts))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)
