@@ -151,19 +151,21 @@ def main():
             comm.engine = None
     algo.defer_baseline_fit = True            # host solve of the 24x24 baseline system overlaps the next rollout
     algo.reuse_trajectory_buffers = True      # one set of [T,B,.] tensors, overwritten every iteration
+    algo.device_baseline_fit = os.environ.get('METRPO_BENCH_HOST_BASELINE_FIT') != '1'   # the 24x24 solve of the baseline fit as a kernel: coefficients stay on the device
     algo.async_line_search = os.environ.get('METRPO_BENCH_SYNC_LINESEARCH') != '1'     # update enqueued without a host round trip per trial; closed after the next rollout is enqueued
 
+    from metrpo_amd.tracing import timing_event          # HIP events with a device-scope release: a torch.cuda.Event record costs the next kernel 6-15 us
     ev_roll, ev_upd, ev_iter, steps_run, n_valid = [], [], [], [], []
 
     def step(j, timed):
         algo.rollout_events = ev_roll if timed else None      # HIP events recorded around the rollout launch(es) themselves
         if timed:
-            ei = torch.cuda.Event(enable_timing=True); ei.record(); ev_iter.append(ei)
+            ei = timing_event(); ei.record(); ev_iter.append(ei)
         algo.start_worker()
         paths = algo.obtain_samples(j)
         samples = algo.process_samples(j, paths)
         if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0, e1 = timing_event(), timing_event()
             e0.record()
         algo.optimize_policy(j, samples)
         if timed:
@@ -186,7 +188,7 @@ def main():
     for j in range(args.steps):
         step(args.warmup + j, True)
     algo.optimizer.finish()                                   # the last update's line search is closed inside the timed region
-    ei = torch.cuda.Event(enable_timing=True); ei.record(); ev_iter.append(ei)
+    ei = timing_event(); ei.record(); ev_iter.append(ei)
     comm.barrier(); torch.cuda.synchronize()
     dt = comm.max_float(time.perf_counter() - t0, device='cuda' if backend == 'nccl' else 'cpu')
     if gc_was:
@@ -239,9 +241,9 @@ def main():
         "config": {"workload": "%s rollout+GAE+TRPO: env=%s K=%d dyn=%s policy=%s B=%d/GPU (config B=%d on %d GPUs) H=%d sam_mode=step_rand "
                                "all-K-heads-evaluated max_kl=0.01 cg_iters=10; env steps per rollout %.1f; defer_baseline_fit=1 (the host solve of the baseline's "
                                "normal equations overlaps the next rollout and lands before the next process_samples) reuse_trajectory_buffers=1 (one set of "
-                               "[T,B,.] tensors overwritten every iteration) async_line_search=%d (the accept test of the first two line-search trials runs on "
+                               "[T,B,.] tensors overwritten every iteration) device_baseline_fit=%d (the fit's normal equations are solved by a kernel, float64, partial pivoting) async_line_search=%d (the accept test of the first two line-search trials runs on "
                                "the device and the host closes the update after it has enqueued the next rollout: same trials, same rule, same results)"
-                               % (args.config, env, K, list(cfg['dyn_hidden']), list(cfg['pol_hidden']), B, cfg['B'], cfg['gpus'], H, T_mean, int(bool(algo.async_line_search))),
+                               % (args.config, env, K, list(cfg['dyn_hidden']), list(cfg['pol_hidden']), B, cfg['B'], cfg['gpus'], H, T_mean, int(bool(algo.device_baseline_fit)), int(bool(algo.async_line_search))),
                    "parallelism": "B-sharded x%d, sum all-reduce of g/FVP/scalars" % comm.world},
         "trpo_iter_ms": ms_per_step,
         "rollout": {"ms": roll_ms, "env_steps_per_s": units_per_step / (roll_ms * 1e-3),

@@ -89,6 +89,7 @@ SYMBOLS = {
     'metrpo_gae': (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _D, _D, _P, _P, _P, _P, _P]),
     'metrpo_center_advantages': (_I, [_P, _P, _P, _L, _P, _P]),
     'metrpo_baseline_gram': (_I, [_P, _P, _P, _P, _P, _L, _P, _P, _P]),
+    'metrpo_baseline_solve': (_I, [_P, _P, _P, _D, _P, _P]),
     'metrpo_loss_grad': (_I, [_P, C.POINTER(Batch), _P, _P]),
     'metrpo_fvp': (_I, [_P, C.POINTER(Batch), _P, _P, _P]),
     'metrpo_loss_kl': (_I, [_P, C.POINTER(Batch), _P, _P, _P]),

@@ -349,6 +349,14 @@ extern "C" int32_t metrpo_baseline_gram(metrpo_ctx* c, const float* obs, const f
     return launch_gram(c, obs, ret, tpath, valid, N, AtA, Aty, (hipStream_t)stream);
 }
 
+extern "C" int32_t metrpo_baseline_solve(metrpo_ctx* c, const double* AtA, const double* Aty, double reg_coeff, double* coeffs, void* stream) {
+    TraceRange trace_("metrpo:process_samples:baseline_solve");
+    if (!c) return METRPO_ENULL;
+    if (!AtA || !Aty || !coeffs) return set_err(c, METRPO_ENULL, "baseline_solve: NULL pointer");
+    if (!(reg_coeff >= 0.0)) return set_err(c, METRPO_EINVAL, "baseline_solve: reg_coeff must be >= 0");
+    return launch_baseline_solve(c, AtA, Aty, reg_coeff, coeffs, (hipStream_t)stream);
+}
+
 extern "C" int32_t metrpo_loss_grad(metrpo_ctx* c, const metrpo_batch* b, double* out, void* stream) {
     if (!c) return METRPO_ENULL;
     NEED_POL(c);
@@ -463,9 +471,11 @@ __global__ void k_cg_finish(int P, double reg, double max_kl, const double* x, d
 
 // the update's outcome (scal[8] | lk[2] | ls[4]) into pinned host memory, then the stamp the host is polling for (one wave: program order + fence)
 __global__ void k_ls_publish(const double* __restrict__ src, double* dst, unsigned long long stamp) {
+    // system-scope stores bypass L2; once the wave's own stores are acknowledged (vmcnt) the stamp may follow -- a system-scope FENCE here
+    // would write back the whole L2 (15 us that the next kernel on the stream waits for)
     if (threadIdx.x < 14) __hip_atomic_store(dst + threadIdx.x, src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __threadfence_system();
-    if (threadIdx.x == 0) __hip_atomic_store((unsigned long long*)(dst + 16), stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) __hip_atomic_store((unsigned long long*)(dst + 16), stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __global__ void k_ls_reset(double* ls) { if (threadIdx.x == 0) { ls[0] = -1.0; ls[1] = NAN; ls[2] = NAN; ls[3] = 0.0; } }
 __global__ void k_zero_f(float* p, int n) {

@@ -188,6 +188,7 @@ int launch_gae(metrpo_ctx*, const float*, const float*, const uint8_t*, const in
                double, double, float*, float*, uint8_t*, double*, hipStream_t);
 int launch_center(metrpo_ctx*, float*, const uint8_t*, int64_t, const double*, hipStream_t);
 int launch_sampler_progress(metrpo_ctx*, const uint8_t*, const int32_t*, int, int, int, long long, double*, double*, int32_t*, hipStream_t);
+int launch_baseline_solve(metrpo_ctx*, const double* AtA, const double* Aty, double reg, double* coeffs, hipStream_t);
 int launch_gram(metrpo_ctx*, const float*, const float*, const int32_t*, const uint8_t*, int64_t, double*, double*,
                 hipStream_t);
 int launch_loss_grad(metrpo_ctx*, const metrpo_batch*, double*, hipStream_t, const CgTail* tail = nullptr);

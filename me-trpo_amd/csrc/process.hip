@@ -558,6 +558,123 @@ int launch_center(metrpo_ctx* c, float* adv, const uint8_t* valid, int64_t N, co
     return METRPO_OK;
 }
 
+// [rllab] LinearFeatureBaseline.fit's solve (linear_feature_baseline.py: lstsq(F^T F + reg I, F^T returns), reg x 10 while the solution has
+// a NaN, at most 5 attempts) on the device, so that the coefficients the next process_samples needs never leave it: one workgroup, the
+// augmented system [A + reg I | b] in LDS (float64), Gaussian elimination with partial pivoting (the system is square and, with reg > 0,
+// nonsingular: the least-squares solution IS its solution), back substitution by the first wave.  F <= 114 (Humanoid): 0.1 MB of LDS.
+__global__ void __launch_bounds__(256) k_baseline_solve(int F, const double* __restrict__ AtA, const double* __restrict__ Aty, double reg0, double* __restrict__ coeffs) {
+    extern __shared__ __attribute__((aligned(16))) double Ms[];      // [F][F + 1] | x [F]
+    __shared__ int s_piv, s_bad;
+    const int tid = threadIdx.x, lane = tid & 63, W = F + 1;
+    double* x = Ms + (size_t)F * W;
+    double reg = reg0;
+    for (int attempt = 0; attempt < 5; ++attempt) {
+        for (int i = tid; i < F * W; i += 256) { const int r = i / W, c = i % W; Ms[i] = (c < F) ? AtA[r * F + c] + (r == c ? reg : 0.0) : Aty[r]; }
+        if (tid == 0) s_bad = 0;
+        __syncthreads();
+        for (int k = 0; k < F; ++k) {
+            if (tid < 64) {                                  // pivot row: largest |M[r][k]|, r >= k (lowest r among equals)
+                double best = -1.0; int bi = k;
+                for (int r = k + lane; r < F; r += 64) { const double v = fabs(Ms[r * W + k]); if (v > best || !(best >= 0.0)) { best = v; bi = r; } }
+                for (int o = 32; o > 0; o >>= 1) {
+                    const double ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+                    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+                }
+                if (lane == 0) s_piv = bi;
+            }
+            __syncthreads();
+            const int p = s_piv;
+            if (p != k) for (int c = k + tid; c < W; c += 256) { const double t = Ms[k * W + c]; Ms[k * W + c] = Ms[p * W + c]; Ms[p * W + c] = t; }
+            __syncthreads();
+            const double inv = 1.0 / Ms[k * W + k];
+            const int nr = F - k - 1, nc = W - k - 1;        // rows below k x columns right of k (rhs included)
+            for (int i = tid; i < nr * nc; i += 256) {
+                const int r = k + 1 + i / nc, c = k + 1 + i % nc;
+                Ms[r * W + c] -= (Ms[r * W + k] * inv) * Ms[k * W + c];
+            }
+            __syncthreads();
+        }
+        if (tid < 64) {                                      // back substitution: x[k] = (b[k] - sum_{c > k} M[k][c] x[c]) / M[k][k]
+            for (int k = F - 1; k >= 0; --k) {
+                double a = 0.0;
+                for (int c = k + 1 + lane; c < F; c += 64) a += Ms[k * W + c] * x[c];
+                for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+                if (lane == 0) { const double v = (Ms[k * W + F] - a) / Ms[k * W + k]; x[k] = v; if (isnan(v)) s_bad = 1; }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        if (!s_bad) break;
+        reg *= 10.0;
+        __syncthreads();
+    }
+    for (int i = tid; i < F; i += 256) coeffs[i] = x[i];
+}
+
+// The same solve for the feature counts of the five small envs (F = 24 ... 62), in ONE wave's registers: lane r holds row r of [A + reg I | b],
+// the elimination is unrolled over the pivots, a pivot row is read out of its lane straight into scalar registers (v_readlane with a constant
+// lane), no LDS, no barrier: 2 us where the workgroup version takes 37 (its 3 barriers per pivot).  No row exchanges: A + reg I is symmetric
+// positive definite, for which elimination in the natural order is as stable as with pivoting; a non-finite result escalates reg like a NaN.
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)b, l), hi = (unsigned int)__builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int FT>
+__global__ void __launch_bounds__(64) k_baseline_solve_wave(const double* __restrict__ AtA, const double* __restrict__ Aty, double reg0, double* __restrict__ coeffs) {
+    const int lane = threadIdx.x;
+    const bool live = lane < FT;
+    double reg = reg0;
+    double x[FT];
+    for (int attempt = 0; attempt < 5; ++attempt) {
+        double row[FT + 1];
+#pragma unroll
+        for (int c = 0; c < FT; ++c) row[c] = live ? AtA[lane * FT + c] + (lane == c ? reg : 0.0) : 0.0;
+        row[FT] = live ? Aty[lane] : 0.0;
+#pragma unroll
+        for (int k = 0; k < FT; ++k) {
+            double pv[FT + 1];
+#pragma unroll
+            for (int c = k; c <= FT; ++c) pv[c] = readlane_f64(row[c], k);
+            const double f = row[k] * (1.0 / pv[k]);
+            if (lane > k) {
+#pragma unroll
+                for (int c = k + 1; c <= FT; ++c) row[c] = fma(-f, pv[c], row[c]);
+            }
+        }
+        bool bad = false;
+#pragma unroll
+        for (int k = FT - 1; k >= 0; --k) {
+            double a = row[FT];
+#pragma unroll
+            for (int c = k + 1; c < FT; ++c) a = fma(-row[c], x[c], a);
+            x[k] = readlane_f64(a / row[k], k);
+            bad = bad || !isfinite(x[k]);
+        }
+        if (!bad) break;
+        reg *= 10.0;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < FT; ++k) coeffs[k] = x[k];
+    }
+}
+
+int launch_baseline_solve(metrpo_ctx* c, const double* AtA, const double* Aty, double reg, double* coeffs, hipStream_t st) {
+    const int F = 2 * c->pd.ns + 4;
+#define SOLVE_WAVE(FT_) case FT_: hipLaunchKernelGGL(k_baseline_solve_wave<FT_>, dim3(1), dim3(64), 0, st, AtA, Aty, reg, coeffs); HIP_TRY(c, hipGetLastError()); return METRPO_OK;
+    if (getenv("METRPO_SOLVE_BLOCK") == nullptr) {
+        switch (F) { SOLVE_WAVE(24) SOLVE_WAVE(26) SOLVE_WAVE(32) SOLVE_WAVE(40) SOLVE_WAVE(62) default: break; }
+    }
+#undef SOLVE_WAVE
+    const size_t sh = sizeof(double) * ((size_t)F * (F + 1) + F);
+    if (sh > 160 * 1024) return set_err(c, METRPO_EUNSUPPORTED, "baseline_solve: feature count too large for one workgroup's LDS");
+    if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_baseline_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    hipLaunchKernelGGL(k_baseline_solve, dim3(1), dim3(256), sh, st, F, AtA, Aty, reg, coeffs);
+    HIP_TRY(c, hipGetLastError());
+    return METRPO_OK;
+}
+
 int launch_gram(metrpo_ctx* c, const float* obs, const float* ret, const int32_t* tpath, const uint8_t* valid,
                 int64_t N, double* AtA, double* Aty, hipStream_t st) {
     const int F = 2 * c->pd.ns + 4;

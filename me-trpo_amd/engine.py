@@ -349,6 +349,16 @@ class Engine(object):
         return AtA, Aty
 
     # ------------------------------------------------------------------ TRPO update pieces
+    def baseline_solve(self, gram, reg_coeff=1e-5, out=None):
+        """LinearFeatureBaseline.fit's solve on the device: gram = [AtA (F*F, row-major) | Aty (F)] float64 device tensor (summed over the
+        ranks) -> coefficients [F] float64 on the device, stream-ordered (no host round trip)."""
+        F = 2 * self.ns + 4
+        assert gram.is_cuda and gram.dtype == torch.float64 and gram.numel() == F * F + F and gram.is_contiguous()
+        if out is None:
+            out = torch.empty(F, dtype=torch.float64, device=self.device)
+        self._chk(lib.metrpo_baseline_solve(self._ctx, _ptr(gram), C.c_void_p(gram.data_ptr() + 8 * F * F), float(reg_coeff), _ptr(out), self._stream()))
+        return out
+
     def make_batch(self, obs, act, adv, old_mean, old_log_std, valid=None, n_global=None):
         dev = self.device
         obs = _f32(obs, dev).reshape(-1, self.ns); N = obs.shape[0]

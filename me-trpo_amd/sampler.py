@@ -54,7 +54,7 @@ class BaseSampler(object):
         comm = getattr(algo, 'comm', None) or Comm()
         tr = paths.traj
         self.finish_baseline_fit()             # deferred solve of the previous iteration (overlaps the rollout just launched)
-        coeffs = algo.baseline.coeffs
+        coeffs = getattr(algo.baseline, 'coeffs_for_kernel', None) if hasattr(algo.baseline, 'coeffs_for_kernel') else algo.baseline.coeffs
         F = 2 * eng.ns + 4
         acc = torch.zeros(3 + F * F + F, dtype=torch.float64, device=eng.device)     # one fill: [advantage statistics | AtA | Aty]
         adv, ret, valid, stats = eng.gae(tr, coeffs, algo.discount, algo.gae_lambda, stats=acc[:3])
@@ -71,10 +71,17 @@ class BaseSampler(object):
         gram = acc[3:]
         eng.baseline_gram(tr.obs, ret, tr.tpath, valid, out=gram)
         comm.allreduce_sum_(gram)
-        self._pending_gram = gram.to('cpu', non_blocking=True) if gram.is_cuda else gram
-        self._gram_event = torch.cuda.Event() if gram.is_cuda else None
-        if self._gram_event is not None:
-            self._gram_event.record()
+        if getattr(algo, 'device_baseline_fit', False) and gram.is_cuda and hasattr(algo.baseline, 'solve_device'):
+            # the fit's solve on the device (metrpo_baseline_solve): the coefficients never visit the host, nothing to wait for, no copy
+            # between the rollout and the next GAE kernel (the host solve + its two transfers were where the host fell behind the GPU)
+            algo.baseline.solve_device(eng, gram)
+            self._pending_gram = None
+            self._gram_event = None
+        else:
+            self._pending_gram = gram.to('cpu', non_blocking=True) if gram.is_cuda else gram
+            self._gram_event = torch.cuda.Event() if gram.is_cuda else None
+            if self._gram_event is not None:
+                self._gram_event.record()
         samples_data = dict(observations=tr.obs.reshape(-1, eng.ns), actions=tr.act.reshape(-1, eng.na),
                             rewards=tr.rew.reshape(-1), returns=ret.reshape(-1), advantages=adv.reshape(-1),
                             env_infos={}, agent_infos=dict(mean=tr.mean.reshape(-1, eng.na), log_std=paths.log_std),
@@ -137,7 +144,8 @@ class VectorizedSampler(BaseSampler):
         draws = draws or {}
         ev = getattr(algo, 'rollout_events', None)          # optional [(start, end)] HIP-event pairs around the launch
         if ev is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            from .tracing import timing_event
+            e0, e1 = timing_event(), timing_event()
             e0.record()
         common = dict(determ=determ, eval_all_heads=getattr(algo, 'eval_all_heads', True), seed=seed, stream_offset=offset)
         if eng.env_name == 'ant':
