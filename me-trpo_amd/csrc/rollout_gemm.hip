@@ -557,3 +557,4 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
     if (first_bad != METRPO_OK) { (void)hipGetLastError(); return first_bad; }       // c->err holds the failing round's message (set_err is serialised)
     return METRPO_OK;
 }
+

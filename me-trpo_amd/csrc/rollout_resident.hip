@@ -587,7 +587,14 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
     if (need > c->res_cap) {
         if (c->d_res) HIP_TRY(c, hipFree(c->d_res));
         c->d_res = nullptr; c->res_cap = 0;
-        HIP_TRY(c, hipExtMallocWithFlags(&c->d_res, need, hipDeviceMallocUncached));     // (ordinary and fine-grained device memory measured the same: the hop is the fabric round trip)
+        // ORDINARY device memory.  The packets only ever move through agent-scope atomics (L2-served, never L1), so the memory type buys nothing:
+        // uncached, fine-grained and ordinary memory all measure 2.73 ms at the params-file shape.  It is ordinary memory because a region that was
+        // allocated hipDeviceMallocUncached and later hipFree'd can come back from hipMalloc as somebody's ordinary buffer with lines of its old
+        // life still sitting in one XCD's L2: seen as a step-wise rollout (rollout_gemm.hip) of a LATER engine reading two stale cache lines of
+        // its fresh workspace, gone after evicting the L2s (tests/test_gpu_resident.py::test_stepwise_workspace_after_freed_resident_regions).
+        // METRPO_RES_UNCACHED=1 brings the uncached flavour back (reproducing the above).
+        if (getenv("METRPO_RES_UNCACHED") != nullptr) HIP_TRY(c, hipExtMallocWithFlags(&c->d_res, need, hipDeviceMallocUncached));
+        else HIP_TRY(c, hipMalloc(&c->d_res, need));
         HIP_TRY(c, hipMemsetAsync(c->d_res, 0, need, st));
         c->res_cap = need; c->res_seq = 0;
     }

@@ -51,8 +51,39 @@ def test_resident_rollout_against_oracle(env, K, B, T, H, mode):
     eng.set_rollout_variant(1)
     stepwise = eng.rollout(B, T, H, mode, pool, **dr32)
     assert eng.last_rollout_kernel() == 'gemm-stepwise'
-    np.testing.assert_allclose(cpu(traj.obs), cpu(stepwise.obs), rtol=2e-3, atol=2e-3)
+    generic = eng.rollout(B, T, H, mode, pool, force_generic=True, **dr32)        # thread-per-env kernel: a third, independent summation order
+    np.testing.assert_allclose(cpu(traj.obs), cpu(generic.obs), rtol=2e-3, atol=2e-3, err_msg='resident kernel vs generic kernel')
+    dd = np.abs(cpu(stepwise.obs) - cpu(generic.obs)); badi = np.argwhere(dd > 2e-3)
+    info = ''
+    if len(badi):
+        t0 = badi[:, 0].min(); e_bad = sorted(set(badi[:, 1]))
+        info = ' first bad step %d, envs %s, act diff at t0-1 %.3g, mean diff %.3g, model_idx at t0-1 %s, done at t0-1 %s' % (
+            t0, e_bad, np.abs(cpu(stepwise.act)[t0 - 1] - cpu(generic.act)[t0 - 1]).max(), np.abs(cpu(stepwise.mean)[t0 - 1] - cpu(generic.mean)[t0 - 1]).max(),
+            dr['model_idx'][t0 - 1][e_bad].tolist(), cpu(stepwise.done)[t0 - 1][e_bad].tolist())
+    np.testing.assert_allclose(cpu(stepwise.obs), cpu(generic.obs), rtol=2e-3, atol=2e-3, err_msg='step-wise GEMM path vs generic kernel' + info)
     assert torch.equal(traj.done, stepwise.done) and torch.equal(traj.tpath, stepwise.tpath)
+
+
+def test_stepwise_workspace_after_freed_resident_regions():
+    """Engines come and go (every one allocates and frees the resident kernel's packet region), each followed by a step-wise rollout on a
+    freshly allocated workspace: all three kernels agree every time.  (With the packet region in hipDeviceMallocUncached memory a later
+    engine's workspace could land on a freed region and read two stale cache lines of it: envs 32-36 of 37 off by 0.1 from step 1 on.)"""
+    import gc
+    for rep in range(6):
+        eng, dm, theta, pdims, pool = Hh.make_engine('hopper', 5, (512, 512), (32, 32), seed=61 + rep)
+        B, T, H = 37 + 3 * rep, 8, 8
+        dr = Hh.draws(np.random.RandomState(8 + rep), 5, B, T, dm.ns, dm.na, len(pool))
+        dr32 = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in dr.items()}
+        res = eng.rollout(B, T, H, 'step_rand', pool, **dr32)
+        assert eng.last_rollout_kernel() == 'resident'
+        eng.set_rollout_variant(1)
+        stepwise = eng.rollout(B, T, H, 'step_rand', pool, **dr32)
+        assert eng.last_rollout_kernel() == 'gemm-stepwise'
+        generic = eng.rollout(B, T, H, 'step_rand', pool, force_generic=True, **dr32)
+        np.testing.assert_allclose(cpu(res.obs), cpu(generic.obs), rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(cpu(stepwise.obs), cpu(generic.obs), rtol=2e-3, atol=2e-3)
+        del eng, res, stepwise, generic
+        gc.collect()
 
 
 @pytest.mark.parametrize('K,B,H,R,ws', [(5, 100, 7, 3, 32),        # params-file layout: 240 compute workgroups, rounds side by side
