@@ -110,7 +110,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     c->d_bptt = nullptr; c->bptt_cap = 0; c->det_cfg = -1; c->d_detpart = nullptr; c->detpart_cap = 0; c->det_gemm = 0; c->d_dg = nullptr; c->dg_cap = 0; c->vjp_gm = nullptr; c->ls_skip = nullptr; c->d_pol_adam = nullptr; c->pol_adam_t = 0; c->mfma_cfg = -1; c->pol_mfma = -1; c->coop_cfg = -1; c->rollout_variant = 0;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_cg = nullptr; c->d_vf = nullptr; c->d_theta_try = nullptr;
     c->d_valbuf = nullptr; c->h_pinned = nullptr; c->n_sm = 256;
-    c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0; c->d_res = nullptr; c->res_cap = 0; c->res_seq = 0; c->res_failed = 0; c->last_rollout_kernel = -1; c->upd_pending = 0; c->upd_spec = 0; c->h_upd = nullptr; c->upd_stamp = 0; c->side_ready = 0; c->d_ticket = nullptr; c->d_hcache = nullptr; c->hcache_cap = 0; c->hcache_on = 0; c->d_mig = nullptr; c->mig_cap = 0; c->mig_epoch = 0; c->nccl_comm = nullptr; c->comm_world = 0; c->comm_rank = 0; c->pol_path = 1; c->d_pg = nullptr; c->pg_cap = 0; c->pg_fwd_rows = -1; c->pg_fwd_obs = nullptr; c->d_adam = nullptr; c->adam_t = 0; c->d_train = nullptr; c->train_cap = 0;
+    c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gae_part = nullptr; c->gae_part_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0; c->d_res = nullptr; c->res_cap = 0; c->res_seq = 0; c->res_failed = 0; c->last_rollout_kernel = -1; c->upd_pending = 0; c->upd_spec = 0; c->h_upd = nullptr; c->upd_stamp = 0; c->side_ready = 0; c->d_ticket = nullptr; c->d_hcache = nullptr; c->hcache_cap = 0; c->hcache_on = 0; c->d_mig = nullptr; c->mig_cap = 0; c->mig_epoch = 0; c->nccl_comm = nullptr; c->comm_world = 0; c->comm_rank = 0; c->pol_path = 1; c->d_pg = nullptr; c->pg_cap = 0; c->pg_fwd_rows = -1; c->pg_fwd_obs = nullptr; c->d_adam = nullptr; c->adam_t = 0; c->d_train = nullptr; c->train_cap = 0;
     ProblemDesc& pd = c->pd;
     pd.env = d->env; pd.ns = d->ns; pd.na = d->na; pd.K = d->n_models; pd.n_drop = d->n_drop;
     pd.nin = d->ns + d->na - d->n_drop;
@@ -155,7 +155,7 @@ extern "C" int32_t metrpo_destroy(metrpo_ctx* c) {
     (void)metrpo_comm_ipc_detach(c);
     if (c->xg_region) (void)hipFree(c->xg_region);
     void* bufs[] = {c->d_dyn, c->d_norm, c->d_theta, c->d_vf, c->d_theta_try, c->d_cg, c->d_valbuf, c->d_partials,
-                    c->d_dyn_img, c->d_pol_img, c->d_pol_imgval, c->d_pol_vpos, c->d_vbuf, c->d_gram_part, c->d_big, c->d_res, c->d_ticket, c->d_hcache, c->d_mig, c->d_pg, c->d_adam, c->d_train, c->d_bptt, c->d_pol_adam, c->d_detpart, c->d_dg};
+                    c->d_dyn_img, c->d_pol_img, c->d_pol_imgval, c->d_pol_vpos, c->d_vbuf, c->d_gae_part, c->d_gram_part, c->d_big, c->d_res, c->d_ticket, c->d_hcache, c->d_mig, c->d_pg, c->d_adam, c->d_train, c->d_bptt, c->d_pol_adam, c->d_detpart, c->d_dg};
     for (void* p : bufs) if (p) (void)hipFree(p);
     if (c->side_ready) {
         for (int i = 0; i < METRPO_MAX_PAR_ROUNDS - 1; ++i) { (void)hipStreamDestroy(c->side_stream[i]); (void)hipEventDestroy(c->ev_join[i]); }
@@ -191,6 +191,7 @@ extern "C" int32_t metrpo_set_dynamics(metrpo_ctx* c, const float* p, const floa
 extern "C" int32_t metrpo_set_policy(metrpo_ctx* c, const float* theta, void* stream) {
     if (!c) return METRPO_ENULL;
     if (!theta) return set_err(c, METRPO_ENULL, "set_policy: NULL pointer");
+    if (c->upd_pending) return set_err(c, METRPO_ESTATE, "set_policy: an update begun with metrpo_trpo_update_begin is still open (metrpo_trpo_update_end decides which theta stands)");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(c, hipMemcpyAsync(c->d_theta, theta, sizeof(float) * c->pd.P, hipMemcpyDeviceToDevice, st));
     c->have_pol = true;
@@ -469,21 +470,18 @@ __global__ void k_cg_finish(int P, double reg, double max_kl, const double* x, d
     cg_finish_body(P, reg, max_kl, x, z, step, scal, sh);
 }
 
-// the update's outcome (scal[8] | lk[2] | ls[4]) into pinned host memory, then the stamp the host is polling for (one wave: program order + fence)
-__global__ void k_ls_publish(const double* __restrict__ src, double* dst, unsigned long long stamp) {
-    // system-scope stores bypass L2; once the wave's own stores are acknowledged (vmcnt) the stamp may follow -- a system-scope FENCE here
-    // would write back the whole L2 (15 us that the next kernel on the stream waits for)
-    if (threadIdx.x < 14) __hip_atomic_store(dst + threadIdx.x, src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0) __hip_atomic_store((unsigned long long*)(dst + 16), stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
+// the update's outcome into pinned host memory as a launch of its own (no speculated trial whose reduction could carry it: cg_device.h ls_publish)
+__global__ void k_ls_publish(const double* __restrict__ src, double* dst, unsigned long long stamp) { ls_publish(src, dst, stamp); }
 __global__ void k_ls_reset(double* ls) { if (threadIdx.x == 0) { ls[0] = -1.0; ls[1] = NAN; ls[2] = NAN; ls[3] = 0.0; } }
 __global__ void k_zero_f(float* p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0.0f;
 }
 
-__global__ void k_try_theta(int P, double ratio, const float* __restrict__ prev, const double* __restrict__ step, float* cur, const double* __restrict__ ls) {
+__global__ void k_try_theta(int P, double ratio, const float* __restrict__ prev, const double* __restrict__ step, float* cur, const double* __restrict__ ls,
+                            double* ls_reset = nullptr) {
+    // trial 0 of a device-decided search also opens it (ls <- "not stopped yet": what k_ls_reset does as a launch of its own); it is never skipped itself
+    if (ls_reset != nullptr && blockIdx.x == 0 && threadIdx.x == 0) { ls_reset[0] = -1.0; ls_reset[1] = NAN; ls_reset[2] = NAN; ls_reset[3] = 0.0; }
     if (ls != nullptr && ls[0] >= 0.0) return;                      // speculative trial after the search stopped: cur must keep the accepted theta's source
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < P) cur[i] = (float)((double)prev[i] - ratio * step[i]);     // cur_param = prev_param - ratio * flat_descent_step
@@ -532,7 +530,7 @@ static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metr
     c->xg_fuse = xg_fused ? 1 : 0;
     struct FuseOff { metrpo_ctx* c; ~FuseOff() { c->xg_fuse = 0; } } fuse_off{c};
     const int implicit_hd = pr->explicit_final_hvp ? 0 : 1;
-    CgTail tl; tl.P = P; tl.last = 0; tl.implicit_hd = implicit_hd; tl.reg = pr->reg_coeff; tl.tol = pr->residual_tol; tl.max_kl = pr->max_kl;
+    CgTail tl; tl.pub_dst = nullptr; tl.pub_stamp = 0; tl.P = P; tl.last = 0; tl.implicit_hd = implicit_hd; tl.reg = pr->reg_coeff; tl.tol = pr->residual_tol; tl.max_kl = pr->max_kl;
     tl.x = v.x; tl.r = v.r; tl.p = v.p; tl.z = v.z; tl.step = v.step; tl.scal = v.scal; tl.gout = v.gout; tl.pf = c->d_vf; tl.ticket = c->d_ticket;
     tl.vpos = nullptr; tl.imgval = nullptr; tl.ls = nullptr; tl.lk = nullptr; tl.th = nullptr; tl.th_try = nullptr; tl.trial = 0; tl.accept_violation = 0;
     if (phase != 2) {
@@ -578,18 +576,21 @@ static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metr
     if (phase == 1) {
         // ---- the first `nspec` trials of the backtracking line search, each one's accept test in the tail of its own reduction (ls_decide): an
         //      accepted trial's theta is in place when the caller's next launch reads it; trials after the one that stopped the search leave at once
-        hipLaunchKernelGGL(k_ls_reset, dim3(1), dim3(64), 0, st, v.ls);
+        if (!c->h_upd) { HIP_TRY(c, hipHostMalloc((void**)&c->h_upd, sizeof(double) * 17)); memset(c->h_upd, 0, sizeof(double) * 17); }
+        c->upd_stamp += 1;                                          // _end waits for THIS stamp, not for what the caller enqueues after _begin
+        if (nspec == 0) hipLaunchKernelGGL(k_ls_reset, dim3(1), dim3(64), 0, st, v.ls);
         for (int n = 0; n < nspec; ++n) {
             const double ratio = std::pow(pr->backtrack_ratio, (double)n);
-            hipLaunchKernelGGL(k_try_theta, dim3((P + 255) / 256), dim3(256), 0, st, P, ratio, c->d_theta, v.step, c->d_theta_try, (const double*)v.ls);
+            // trial 0 opens the search (ls reset rides in its k_try_theta), the last trial's reduction publishes the outcome: no launches of their own
+            hipLaunchKernelGGL(k_try_theta, dim3((P + 255) / 256), dim3(256), 0, st, P, ratio, c->d_theta, v.step, c->d_theta_try,
+                               (n == 0) ? (const double*)nullptr : (const double*)v.ls, (n == 0) ? v.ls : (double*)nullptr);
             CgTail dt = tl;
             dt.op = 4; dt.ls = v.ls; dt.lk = v.lk; dt.th = c->d_theta; dt.th_try = c->d_theta_try; dt.trial = n; dt.accept_violation = pr->accept_violation;
+            if (n == nspec - 1) { dt.pub_dst = c->h_upd; dt.pub_stamp = c->upd_stamp; }
             if ((rc = launch_loss_kl(c, b, c->d_theta_try, v.lk, st, &dt))) return rc;
         }
         if (c->mfma_cfg >= 0 && (rc = mfma_prepare_policy(c, st))) return rc;      // of whatever theta the trials left in place
-        if (!c->h_upd) { HIP_TRY(c, hipHostMalloc((void**)&c->h_upd, sizeof(double) * 17)); memset(c->h_upd, 0, sizeof(double) * 17); }
-        c->upd_stamp += 1;                                          // _end waits for THIS stamp, not for what the caller enqueues after _begin
-        hipLaunchKernelGGL(k_ls_publish, dim3(1), dim3(64), 0, st, (const double*)v.scal, c->h_upd, c->upd_stamp);
+        if (nspec == 0) hipLaunchKernelGGL(k_ls_publish, dim3(1), dim3(64), 0, st, (const double*)v.scal, c->h_upd, c->upd_stamp);
         HIP_TRY(c, hipGetLastError());
         c->upd_pending = 1; c->upd_spec = nspec; c->upd_batch = *b; c->upd_params = *pr;
         return METRPO_OK;
@@ -622,7 +623,7 @@ static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metr
     for (int n = n_start; n < pr->max_backtracks && !stopped; ++n) {
         n_iter = n;
         const double ratio = std::pow(pr->backtrack_ratio, (double)n);
-        hipLaunchKernelGGL(k_try_theta, dim3((P + 255) / 256), dim3(256), 0, st, P, ratio, c->d_theta, v.step, c->d_theta_try, (const double*)nullptr);
+        hipLaunchKernelGGL(k_try_theta, dim3((P + 255) / 256), dim3(256), 0, st, P, ratio, c->d_theta, v.step, c->d_theta_try, (const double*)nullptr, (double*)nullptr);
         if ((rc = launch_loss_kl(c, b, c->d_theta_try, v.lk, st))) return rc;
         AR(v.lk, 2);
         HIP_TRY(c, hipMemcpyAsync(c->h_pinned, v.scal, sizeof(double) * 10, hipMemcpyDeviceToHost, st));

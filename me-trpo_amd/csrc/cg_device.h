@@ -27,6 +27,8 @@ struct CgTail {
     const double* lk;       // [2]: loss, KL of this trial (the reduction's own output)
     float* th; const float* th_try;
     int trial, accept_violation;
+    double* pub_dst;        // non-NULL on the LAST speculated trial: its reduction also publishes scal[8] | lk[2] | ls[4] to pinned host memory,
+    unsigned long long pub_stamp;   // followed by this stamp at pub_dst[16] (ls_publish) -- what k_ls_publish does as a launch of its own
 };
 
 // float copy of the next FVP input, element i; mirrored into the weight-fragment image the cached-activation FVP copies (see CgTail::vpos)
@@ -210,6 +212,16 @@ __device__ __forceinline__ void ls_decide(const CgTail& t) {
     } else if (threadIdx.x == 0) { t.ls[1] = loss; t.ls[2] = kl; }
 }
 
+// The update's outcome (scal[8] | lk[2] | ls[4], contiguous at t.scal) into pinned host memory, then the stamp the host is polling for.  One wave:
+// program order + vmcnt.  System-scope stores bypass L2; once the wave's own stores are acknowledged the stamp may follow -- a system-scope
+// FENCE here would write back the whole L2 (15 us that the next kernel on the stream waits for).  Call behind a __syncthreads().
+__device__ __forceinline__ void ls_publish(const double* __restrict__ src, double* dst, unsigned long long stamp) {
+    if (threadIdx.x >= 64) return;
+    if (threadIdx.x < 14) __hip_atomic_store(dst + threadIdx.x, src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) __hip_atomic_store((unsigned long long*)(dst + 16), stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // CG tail dispatch shared by k_finalize and the in-kernel reduction of policy_mfma.hip (one block, all threads)
 __device__ __forceinline__ void cg_tail_run(const CgTail& t, double* sh, const CgPre* pre = nullptr) {
     if (t.op == 1) {
@@ -220,5 +232,8 @@ __device__ __forceinline__ void cg_tail_run(const CgTail& t, double* sh, const C
         }
     } else if (t.op == 2) cg_finish_body(t.P, t.reg, t.max_kl, t.x, t.z, t.step, t.scal, sh);
     else if (t.op == 3) cg_init_body(t.P, t.gout, t.x, t.r, t.p, PfOut{t.pf, t.vpos, t.imgval}, t.scal, sh);
-    else if (t.op == 4) ls_decide(t);
+    else if (t.op == 4) {
+        ls_decide(t);
+        if (t.pub_dst != nullptr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); ls_publish(t.scal, t.pub_dst, t.pub_stamp); }
+    }
 }

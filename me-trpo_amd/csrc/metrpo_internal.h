@@ -68,6 +68,7 @@ struct metrpo_ctx {
     float* d_theta_try;  // [P] line-search candidate
     double* d_valbuf;    // validation-cost accumulators
     double* d_vbuf;      // [N] baseline predictions for the GAE scan
+    double* d_gae_part; size_t gae_part_cap;   // k_gae: arrival ticket + one (sum adv, sum adv^2, count) triple per workgroup, added in workgroup order
     size_t vbuf_cap;
     double* d_gram_part; // per-block Gram partials (process.hip)
     size_t gram_cap;

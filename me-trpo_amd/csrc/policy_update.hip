@@ -297,6 +297,7 @@ __global__ void __launch_bounds__(1024) k_finalize(ProblemDesc pd, int mode, int
     if (tail.op == 4 && tail.ls[0] >= 0.0) {                  // speculative line-search trial after the search stopped (every block reads the same cell)
         // a sharded run keeps its exchanges in step: the slot protocol (xchg_device.h) counts on every sequence number being used by every rank
         if (xc.world > 1 && blockIdx.x == 0 && threadIdx.x < 2) { xchg_push(xc, (int)threadIdx.x, 0.0); (void)xchg_pull_sum(xc, (int)threadIdx.x); }
+        if (tail.pub_dst != nullptr && blockIdx.x == 0) ls_publish(tail.scal, tail.pub_dst, tail.pub_stamp);      // the search's outcome still has to reach the host
         return;
     }
     FT_MARK(0)
@@ -396,7 +397,7 @@ static int fill_polk(metrpo_ctx* c, const metrpo_batch* b, PolK* k, bool need_ta
 static void finalize(metrpo_ctx* c, int mode, int nrows, int stride, int lk_col, const double* v, double* out, hipStream_t st,
                      const CgTail* tail = nullptr) {
     const int nout = (mode == 0) ? c->pd.P + 1 : (mode == 1) ? c->pd.P : 2;
-    CgTail none; none.op = 0; none.ticket = c->d_ticket; none.vpos = nullptr; none.imgval = nullptr; none.ls = nullptr;
+    CgTail none; none.op = 0; none.ticket = c->d_ticket; none.vpos = nullptr; none.imgval = nullptr; none.ls = nullptr; none.pub_dst = nullptr;
     // inside a fused update of a sharded run (run_trpo_update raises xg_fuse) the reduction carries the cross-rank sum in its tail
     const XchgK xc = (c->xg_fuse && c->xg_world > 1) ? xchg_next(c) : xchg_none();
     hipLaunchKernelGGL(k_finalize, dim3((nout + FIN_C - 1) / FIN_C), dim3(1024), 0, st, c->pd, mode, nrows, stride, lk_col,

@@ -91,7 +91,7 @@ template <int NS, int NW>
 __global__ void __launch_bounds__(64 * NW) k_gae(const float* __restrict__ obs, const int32_t* __restrict__ tpath, const double* __restrict__ coeffs,
                                                       int ns_rt, double* __restrict__ V, const float* __restrict__ rew, const uint8_t* __restrict__ done,
                                                       int T, int B, double gamma, double lam, float* __restrict__ adv, float* __restrict__ ret,
-                                                      uint8_t* __restrict__ valid, double* __restrict__ stats) {
+                                                      uint8_t* __restrict__ valid, double* __restrict__ stats, double* gpart) {
     extern __shared__ __attribute__((aligned(16))) float stage[];      // [NW][64 * ns]
     if (coeffs != nullptr) {
         const int ns = NS ? NS : ns_rt;
@@ -162,7 +162,34 @@ __global__ void __launch_bounds__(64 * NW) k_gae(const float* __restrict__ obs, 
     }
     if (act) gae_chunk_pass<true>(V, rew, done, t_lo, t_hi, B, b, gamma, lam, a_in, v_in, r_in, c_in, adv, ret, valid, s1, s2, cnt);
     const double t1s = block_sum(s1, red), t2s = block_sum(s2, red), t3s = block_sum(cnt, red);
-    if (threadIdx.x == 0) { atomicAdd(&stats[0], t1s); atomicAdd(&stats[1], t2s); atomicAdd(&stats[2], t3s); }
+    // The statistics of the batch = the workgroups' sums added IN WORKGROUP ORDER by whichever workgroup finishes last (float64 atomics would add
+    // them in arrival order: the centred advantages, and with them the whole update, would differ in the last bit from run to run).
+    // gpart = arrival ticket (first 8 bytes; zero at allocation, reset here), then [gridDim.x][3] sums.
+    __shared__ unsigned int s_last;
+    unsigned int* ticket = (unsigned int*)gpart;
+    gpart += 1;
+    if (threadIdx.x == 0) {
+        gpart[3 * blockIdx.x + 0] = t1s; gpart[3 * blockIdx.x + 1] = t2s; gpart[3 * blockIdx.x + 2] = t3s;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (tk == gridDim.x - 1) ? 1u : 0u;
+        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!s_last || threadIdx.x >= 64) return;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;                  // lane l adds workgroups l, l + 64, ...; then a butterfly of fixed shape
+    for (int j = threadIdx.x; j < (int)gridDim.x; j += 64) {
+        a0 += __hip_atomic_load(gpart + 3 * j + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a1 += __hip_atomic_load(gpart + 3 * j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a2 += __hip_atomic_load(gpart + 3 * j + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
+    if (threadIdx.x == 0) {
+        stats[0] += a0; stats[1] += a1; stats[2] += a2;       // ACCUMULATED (metrpo.h): one add per launch, in stream order
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 __global__ void k_center(float* __restrict__ adv, const uint8_t* __restrict__ valid, int64_t N,
@@ -526,6 +553,15 @@ int launch_gae(metrpo_ctx* c, const float* obs, const float* rew, const uint8_t*
         }
         V = c->d_vbuf;
     }
+    const int nblk = (B + 63) / 64;
+    if ((size_t)nblk * 3 + 2 > c->gae_part_cap) {
+        if (c->d_gae_part) HIP_TRY(c, hipFree(c->d_gae_part));
+        c->d_gae_part = nullptr; c->gae_part_cap = 0;
+        const size_t cap = std::max<size_t>((size_t)nblk * 3 + 2, 1024);
+        HIP_TRY(c, hipMalloc(&c->d_gae_part, sizeof(double) * cap));
+        HIP_TRY(c, hipMemsetAsync(c->d_gae_part, 0, sizeof(double) * cap, st));       // the ticket (first word) starts at zero; every launch leaves it there
+        c->gae_part_cap = cap;
+    }
     const int ns = c->pd.ns;
     // few env columns and a long horizon (the params-file batches: B = 100, T = 600): the grid is 2 workgroups and the kernel is the
     // dependent chain of one wave's steps -- 16 time chunks instead of 8 shorten it (84 -> 67 us at C0-params-file); at C1 (79 workgroups) 8 is faster
@@ -534,7 +570,7 @@ int launch_gae(metrpo_ctx* c, const float* obs, const float* rew, const uint8_t*
     const size_t sh = (coeffs != nullptr) ? sizeof(float) * nw * 64 * (size_t)ns : 0;
 #define GAE_LAUNCH_NW(NSV, NWV) do { \
         if (sh > 48 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_gae<NSV, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)); \
-        hipLaunchKernelGGL((k_gae<NSV, NWV>), dim3((B + 63) / 64), dim3(64 * NWV), sh, st, obs, tpath, coeffs, ns, V, rew, done, T, B, gamma, lam, adv, ret, valid, stats); } while (0)
+        hipLaunchKernelGGL((k_gae<NSV, NWV>), dim3((B + 63) / 64), dim3(64 * NWV), sh, st, obs, tpath, coeffs, ns, V, rew, done, T, B, gamma, lam, adv, ret, valid, stats, c->d_gae_part); } while (0)
 #define GAE_LAUNCH(NSV) do { if (wide) GAE_LAUNCH_NW(NSV, 16); else GAE_LAUNCH_NW(NSV, GAE_NW); } while (0)
 #define GAE_LAUNCH8(NSV) GAE_LAUNCH_NW(NSV, GAE_NW)
     if (sh + 48 * 1024 > 160 * 1024) return set_err(c, METRPO_EUNSUPPORTED, "gae: observation too wide for the staging buffer");

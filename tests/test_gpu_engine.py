@@ -200,6 +200,31 @@ def test_rollout_variants_share_rng_stream(env):
     assert all(r.tobytes() in rows for r in cpu(ref.obs)[H].astype(np.float32)[:32])
 
 
+def test_gae_statistics_are_summed_in_a_fixed_order():
+    """sum(adv), sum(adv^2), count come from 79 workgroups (B = 5000): added in workgroup order by the last one to finish, so thirty launches
+    give thirty identical triples whatever order the workgroups finish in, the triple is ACCUMULATED into the caller's buffer (metrpo.h), and a
+    launch with another grid right after uses the same ticket."""
+    eng, dm, theta, pdims, pool = Hh.make_engine('swimmer', 5, (64, 64), (32, 32), seed=3)
+    traj = eng.rollout(5000, 40, 20, 'step_rand', pool, seed=11)
+    coeffs = np.random.RandomState(2).randn(2 * dm.ns + 4) * 0.05
+    first = None
+    for rep in range(30):
+        adv, ret, valid, stats = eng.gae(traj, coeffs, 0.99, 0.95)
+        got = (cpu(stats).tobytes(), cpu(adv).tobytes())
+        first = first or got
+        assert got == first
+    s1 = np.frombuffer(first[0], dtype=np.float64)
+    assert s1[2] == 5000 * 40 and abs(s1[0] - cpu(adv).astype(np.float64).sum()) <= 1e-6 * max(1.0, abs(s1[0]))
+    acc = torch.full((3,), 2.0, dtype=torch.float64, device='cuda')
+    eng.gae(traj, coeffs, 0.99, 0.95, stats=acc)
+    np.testing.assert_array_equal(cpu(acc), s1 + 2.0)
+    small = eng.rollout(70, 12, 6, 'step_rand', pool, seed=12)                   # 2 workgroups after 79
+    a2, r2, v2, st2 = eng.gae(small, coeffs, 0.99, 0.95)
+    assert cpu(st2)[2] == 70 * 12 and abs(cpu(st2)[0] - cpu(a2).astype(np.float64).sum()) <= 1e-9 * max(1.0, abs(cpu(st2)[0]))
+    adv, ret, valid, stats = eng.gae(traj, coeffs, 0.99, 0.95)
+    assert cpu(stats).tobytes() == first[0]
+
+
 @pytest.mark.parametrize('gamma,lam,use_coeffs', [(1.0, 1.0, False), (0.99, 0.95, True), (0.99, 1.0, True)])
 def test_gae_center_gram_parity(gamma, lam, use_coeffs):
     env, K, B, T, H = 'ant', 4, 96, 23, 6
@@ -673,7 +698,7 @@ def test_phase_timers_and_trace_ranges():
         paths = algo.obtain_samples(j)
         algo.optimize_policy(j, algo.process_samples(j, paths))
     s = algo.timers.summary()
-    assert s['n'] == 4 and all(0.0 < s[k] < 50.0 for k in ('rollout_ms', 'process_ms', 'policy_opt_ms')), s
+    assert s['n'] == 4 and all(0.0 < s[k] < 1000.0 for k in ('rollout_ms', 'process_ms', 'policy_opt_ms')), s
     assert len(algo.timers.times_ms('rollout')) == 4
 
 
@@ -722,6 +747,9 @@ def test_deferred_optimizer_closes_after_the_next_rollout():
             samples = algo.process_samples(j, paths)
             algo.optimize_policy(j, samples)
         assert algo.optimizer.pending == mode
+        if mode:                                                 # an open update owns theta: set_policy is refused until it is closed
+            with pytest.raises(Exception, match='still open'):
+                eng.set_policy(theta)
         d = algo.optimizer.last_diag
         assert not algo.optimizer.pending and d['accepted']
         outs.append((eng.get_policy().clone(), acts))
