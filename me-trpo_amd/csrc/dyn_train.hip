@@ -11,7 +11,7 @@
 #include "gemm_mfma.h"
 
 struct TrainWs {             // carved from ctx->d_train
-    float* Xn; float* H[MAXL]; float* OUT; float* dZa; float* dZb; float* part; float* am; float* av; double* loss; size_t rows;
+    float* Xn; float* H[MAXL]; float* OUT; float* dZa; float* dZb; float* part; float* am; float* av; double* loss; double* lpart; size_t rows;
 };
 
 // normalise + drop columns (training.py:228,146-151).  train: model k reads sample b*K + k; eval: every model reads sample b
@@ -33,7 +33,7 @@ __global__ void k_train_prep(ProblemDesc pd, const float* __restrict__ norm, con
 // prediction, loss and d(loss)/d(out): pred = diff_mean + diff_std*out + s (training.py:257)
 __global__ void k_train_out(ProblemDesc pd, const float* __restrict__ norm, const float* __restrict__ x, const float* __restrict__ y,
                             long long n_rows, int rows, int shared, double inv_n, const float* __restrict__ OUT,
-                            float* __restrict__ dZ /* may be null (eval) */, double* __restrict__ loss) {
+                            float* __restrict__ dZ /* may be null (eval) */, double* __restrict__ loss, double* lpart) {
     __shared__ double red[16];
     const int k = blockIdx.y;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -52,7 +52,24 @@ __global__ void k_train_out(ProblemDesc pd, const float* __restrict__ norm, cons
         }
     }
     const double t = block_sum(acc, red);
-    if (threadIdx.x == 0) atomicAdd(&loss[k], t * inv_n);
+    // a model's loss = its workgroups' sums added in workgroup order by whichever of them finishes last (float64 atomics add in arrival order:
+    // the loss the early-stopping comparisons see would differ in the last bit from run to run).  lpart = [K] tickets (8 bytes each, zero when
+    // idle), then [K][gridDim.x] sums.
+    if (threadIdx.x == 0) {
+        unsigned int* ticket = (unsigned int*)(lpart + k);
+        double* sums = lpart + gridDim.y + (size_t)k * gridDim.x;
+        sums[blockIdx.x] = t;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tk == gridDim.x - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            double a = 0.0;
+            for (unsigned int j = 0; j < gridDim.x; ++j) a += __hip_atomic_load(sums + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            loss[k] += a * inv_n;                                   // chunks of an evaluation accumulate in stream order
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // regulariser value: constant * sum_l (l2_loss(W) + l2_loss(b)) per model (training.py:271-282); one block per model
@@ -143,6 +160,16 @@ static int ensure_train_ws(metrpo_ctx* c, int rows, TrainWs* ws) {
         HIP_TRY(c, hipMalloc(&c->d_train, need));
         c->train_cap = need;
     }
+    const size_t nLp = (size_t)K * (1 + (size_t)(rows + 127) / 128);
+    if (nLp > c->train_part_cap) {
+        if (c->d_train_part) HIP_TRY(c, hipFree(c->d_train_part));
+        c->d_train_part = nullptr; c->train_part_cap = 0;
+        const size_t cap = std::max<size_t>(nLp, 2048);
+        HIP_TRY(c, hipMalloc(&c->d_train_part, cap * sizeof(double)));
+        HIP_TRY(c, hipMemset(c->d_train_part, 0, cap * sizeof(double)));          // tickets start at zero; every launch leaves them there
+        c->train_part_cap = cap;
+    }
+    ws->lpart = c->d_train_part;
     float* p = (float*)c->d_train;
     ws->Xn = p; p += nXn;
     for (int l = 1; l < L; ++l) { ws->H[l] = p; p += up4((size_t)K * rows * pd.dyn.dims[l]); }
@@ -185,7 +212,7 @@ int launch_dyn_train_step(metrpo_ctx* c, const float* x, const float* y, const m
     }
     train_forward(c, ws, rows, st);
     hipLaunchKernelGGL(k_train_out, dim3((rows + 127) / 128, K), dim3(128), 0, st, pd, c->d_norm, x, y, n_rows, rows, 0, 1.0 / (double)rows,
-                       ws.OUT, ws.dZa, ws.loss);
+                       ws.OUT, ws.dZa, ws.loss, ws.lpart);
     if (tp->reg_constant != 0.0) hipLaunchKernelGGL(k_reg_loss, dim3(K), dim3(256), 0, st, pd.dyn.n_params, c->d_dyn, tp->reg_constant, ws.loss);
     // Adam step (tf.train.AdamOptimizer: lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t), epsilon outside the correction)
     c->adam_t += 1;
@@ -241,7 +268,7 @@ int launch_dyn_eval_losses(metrpo_ctx* c, const float* x, const float* y, long l
                            rows, 1, ws.Xn);
         train_forward(c, ws, rows, st);
         hipLaunchKernelGGL(k_train_out, dim3((rows + 127) / 128, K), dim3(128), 0, st, pd, c->d_norm, x + r0 * (pd.ns + pd.na), y + r0 * pd.ns,
-                           n - r0, rows, 1, 1.0 / (double)n, ws.OUT, (float*)nullptr, ws.loss);
+                           n - r0, rows, 1, 1.0 / (double)n, ws.OUT, (float*)nullptr, ws.loss, ws.lpart);
     }
     if (reg_constant != 0.0) hipLaunchKernelGGL(k_reg_loss, dim3(K), dim3(256), 0, st, pd.dyn.n_params, c->d_dyn, reg_constant, ws.loss);
     HIP_TRY(c, hipMemcpyAsync(losses, ws.loss, sizeof(double) * K, hipMemcpyDeviceToDevice, st));

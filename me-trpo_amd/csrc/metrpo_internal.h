@@ -85,6 +85,7 @@ struct metrpo_ctx {
     void* d_adam;        // Adam moments [2][K][Pd] + loss accumulators (dyn_train.hip)
     long long adam_t;    // Adam step count
     void* d_train;       // training activation workspace
+    double* d_train_part; size_t train_part_cap;   // k_train_out: per-model arrival tickets + per-workgroup loss sums (added in workgroup order)
     size_t train_cap;
     void* d_big;         // workspace of the GEMM step-wise rollout (rollout_gemm.hip)
     size_t big_cap;
