@@ -257,6 +257,151 @@ __device__ __forceinline__ void resident_compute(const ProblemDesc& pd, const Re
     RT_DUMP(0, 0)
 }
 
+// ---- compute role, 2 x 1024 ensembles (the reference's params-half-cheetah / -hopper / -snake.json) --------------------------------------
+// A slice of WS = 64 hidden-1 units of a 1024-wide layer is 256 fragment registers per lane and the quarter of W0 another 16 NIN_KS: only a
+// wave that owns its SIMD's whole 512-register file can hold them, so the workgroup is the 4 PRODUCER waves alone (__launch_bounds__(256, 1)) and
+// each of them is also the finisher of the env tiles t = its index (mod 4).  At this width a tile is ~11 000 matrix-pipe cycles per SIMD: the
+// drain of the accumulator chains at the end of a tile (2 % of it) needs no second accumulator set, and the finish of a tile (32 MFMAs, W2
+// fragments and b1 from an LDS image) rides behind the producer's next tile.  Hidden layer 0 is evaluated four 16-unit tiles at a time.
+// Packets, stamps, slot layout and the rules about stale stamps are those of resident_compute.
+template <int NS, int NIN, int DH, int WS>
+__device__ __forceinline__ void resident_compute_wide(const ProblemDesc& pd, const ResidentK& z, const float* __restrict__ dyn, float* lds) {
+    constexpr int NIN_KS = cdiv(NIN + 1, 4), J = DH / 16, JQ = J / 4, JB = 4, MT = WS / 16, OUT_CB = cdiv(NS, 16), NSP = 16 * OUT_CB;
+    constexpr int O_STAMP = 0, O_W2 = 32, O_B1 = O_W2 + OUT_CB * MT * 256, O_PART = O_B1 + MT * 256;   // floats: stamps | W2 fragments [ocb][mt][lane][r] | b1 [mt][lane][r] | partials
+    static_assert(JQ % JB == 0, "hidden-0 tiles are taken four at a time");
+    const int tid = threadIdx.x, lane = tid & 63, kap = tid >> 6, c = lane & 15, q = lane >> 4;
+    const int K = pd.K, NSL = z.NSL, NT = z.NT;
+    const int u = blockIdx.x, rho = u / (K * NSL), k = (u / NSL) % K, sl = u % NSL, col0 = sl * WS;
+    const float* __restrict__ W = dyn + (size_t)k * pd.dyn.n_params;
+    const float* __restrict__ W0 = W + pd.dyn.w_off[0];
+    const float* __restrict__ W1 = W + pd.dyn.w_off[1];
+    const float* __restrict__ W2 = W + pd.dyn.w_off[2];
+    if (tid < 32) ((unsigned int*)lds)[O_STAMP + tid] = z.seq0;
+    for (int i = tid; i < OUT_CB * MT * 256; i += 256) {
+        const int r = i & 3, ln = (i >> 2) & 63, mt = (i >> 8) % MT, ocb = i / (256 * MT), dim = 16 * ocb + (ln & 15);
+        lds[O_W2 + i] = (dim < NS) ? W2[(size_t)(col0 + 16 * mt + 4 * (ln >> 4) + r) * NS + dim] : 0.0f;
+    }
+    for (int i = tid; i < MT * 256; i += 256) {
+        const int r = i & 3, ln = (i >> 2) & 63, mt = i >> 8;
+        lds[O_B1 + i] = W[pd.dyn.b_off[1] + col0 + 16 * mt + 4 * (ln >> 4) + r];
+    }
+    __syncthreads();
+    float w0f[JQ][NIN_KS], w1f[MT][JQ][4];
+#pragma unroll
+    for (int jj = 0; jj < JQ; ++jj) {
+        const int j = kap * JQ + jj;
+#pragma unroll
+        for (int kk = 0; kk < NIN_KS; ++kk) {
+            const int in = 4 * kk + q;
+            w0f[jj][kk] = (in < NIN) ? W0[(size_t)in * DH + 16 * j + c] : (in == NIN ? W[pd.dyn.b_off[0] + 16 * j + c] : 0.0f);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // the slice's W1 fragments live in ACCUMULATION registers (the matrix instruction reads its A operand from either file): defined
+                // there, they stay there -- left to itself the allocator parks what does not fit into the 256 architectural registers in the other
+                // half and copies it back before every use, and each of those copies queues behind the matrix instruction in flight
+                const float wv = W1[(size_t)(16 * j + 4 * q + r) * DH + col0 + 16 * mt + c];
+                asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(w1f[mt][jj][r]) : "v"(wv));
+            }
+    }
+    const unsigned long long* xbase = z.X + ((size_t)(rho * NT) * (4 * NIN_KS)) * 16 + c;
+    unsigned long long pk[NIN_KS];
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int kk = 0; kk < NIN_KS; ++kk) pk[kk] = res_ld(xbase + ((size_t)t * (4 * NIN_KS) + 4 * kk + q) * 16);
+    };
+    // ---- finisher duties of this wave: tiles kap, kap + 4 of every step, in order
+    const unsigned int last_seq = z.seq0 + (unsigned int)z.steps;
+    int dt = kap; unsigned int dseq = z.seq0 + 1u;
+    auto try_finish = [&]() -> bool {
+        if (dt >= NT || (int)(dseq - last_seq) > 0) return false;
+        const unsigned int st = __hip_atomic_load((const unsigned int*)lds + O_STAMP + dt * 4 + (lane & 3), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!__all((int)(st - dseq) >= 0)) return false;
+        const f32x4* part = (const f32x4*)(lds + O_PART) + ((size_t)(dt * 4) * MT) * 64 + lane;
+        f32x4 o[OUT_CB];
+#pragma unroll
+        for (int ocb = 0; ocb < OUT_CB; ++ocb) o[ocb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x4 h2 = *(const f32x4*)&lds[O_B1 + (mt * 64 + lane) * 4];
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) h2 += part[(kp * MT + mt) * 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h2[r] = relu1(h2[r]);
+#pragma unroll
+            for (int ocb = 0; ocb < OUT_CB; ++ocb) {
+                const f32x4 w2 = *(const f32x4*)&lds[O_W2 + ((ocb * MT + mt) * 64 + lane) * 4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[ocb] = MFMA16(w2[r], h2[r], o[ocb]);
+            }
+        }
+        unsigned long long* pp = z.P + ((((size_t)(rho * NT + dt) * K + k) * NSL + sl) * NSP) * 16 + c;
+#pragma unroll
+        for (int ocb = 0; ocb < OUT_CB; ++ocb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int dim = 16 * ocb + 4 * q + r; if (dim < NS) res_st(pp + dim * 16, dseq, o[ocb][r]); }
+        dt += 4;
+        if (dt >= NT) { dt = kap; ++dseq; }
+        return true;
+    };
+    fetch(0);
+    int t = 0; unsigned int seq = z.seq0 + 1u;
+    const int total = z.steps * NT;
+    for (int it = 0; it < total; ++it) {
+        float x[NIN_KS];
+        {
+            ResSpin sp;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int kk = 0; kk < NIN_KS; ++kk) { ok = ok && res_fresh(pk[kk], seq); x[kk] = __uint_as_float((unsigned int)pk[kk]); }
+                if (__all(ok)) break;
+                (void)try_finish();                                     // the input may be waiting for the very tile this wave still has to finish
+                if (sp.give_up(z)) return;
+                fetch(t);
+            }
+        }
+        fetch((t + 1 < NT) ? t + 1 : 0);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 a2[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jb = 0; jb < JQ; jb += JB) {                           // (running layer 0 a batch ahead of its consumers measured no faster: 8.64 vs 8.50 ms)
+            f32x4 h[JB];
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj) h[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < NIN_KS; ++kk)
+#pragma unroll
+                for (int jj = 0; jj < JB; ++jj) h[jj] = MFMA16(w0f[jb + jj][kk], x[kk], h[jj]);
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float hr = relu1(h[jj][r]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) a2[mt] = MFMA16(w1f[mt][jb + jj][r], hr, a2[mt]);
+                }
+        }
+        {   // partial sums of env tile t out (LDS operations of one wave complete in issue order: the stamp lands after the data)
+            f32x4* part = (f32x4*)(lds + O_PART) + ((size_t)(t * 4 + kap) * MT) * 64 + lane;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) part[mt * 64] = a2[mt];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            if (lane == 0) __hip_atomic_store((unsigned int*)lds + O_STAMP + t * 4 + kap, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        (void)try_finish();
+        if (++t == NT) { t = 0; ++seq; }
+    }
+    {   // what is left of this wave's duties (the other producers' last hand-overs may still be under way)
+        ResSpin sp;
+        while (dt < NT && (int)(dseq - last_seq) <= 0) { if (!try_finish() && sp.give_up(z)) return; }
+    }
+}
+
 // ---- post role ------------------------------------------------------------------------------------------------------------------------
 // value held by lane q of an env's four lanes out of (a0, a1, a2, a3)
 __device__ __forceinline__ float sel4(int q, float a0, float a1, float a2, float a3) { return (q & 2) ? ((q & 1) ? a3 : a2) : ((q & 1) ? a1 : a0); }
@@ -275,7 +420,7 @@ __device__ __forceinline__ void resident_post(const ProblemDesc& pd, const Rollo
     constexpr int PW_LDS = 2 * 16 * NA;
     constexpr int DCH = (NS <= 12) ? NS : (NS + 1) / 2;               // output dims per batch of partial-sum loads (4 slices x DCH packets in flight per lane)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
-    for (int i = tid; i < IMG; i += 512) {                            // policy fragment image (layout of k_big_pre_mfma, rollout_gemm.hip)
+    for (int i = tid; i < IMG; i += (int)blockDim.x) {                // policy fragment image (layout of k_big_pre_mfma, rollout_gemm.hip)
         float w = 0.0f;
         const int ln = i & 63, cc = ln & 15, qq = ln >> 4;
         if (i < O_PF1) { const int f = i >> 6, s_ = f >> 1, cb = f & 1, in = 4 * s_ + qq; if (in < NS) w = theta[C::pW0 + in * PH + 16 * cb + cc]; }
@@ -518,6 +663,17 @@ __global__ void __launch_bounds__(512) k_rollout_resident(ProblemDesc pd, Rollou
     else resident_post<ENV>(pd, r, z, dyn, theta, norm, lds);
 }
 
+template <int ENV, int DH, int WS>
+__global__ void __launch_bounds__(256, 1) k_rollout_resident_wide(ProblemDesc pd, RolloutK r, ResidentK z, const float* __restrict__ dyn,
+                                                                  const float* __restrict__ theta, const float* __restrict__ norm) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    using C = Cfg<ENV, 64, 32>;
+    if (r.stop != nullptr && *r.stop != 0) return;
+    if ((int)blockIdx.x == z.skip_block) return;
+    if ((int)blockIdx.x < z.U) resident_compute_wide<C::NS, C::NIN, DH, WS>(pd, z, dyn, lds);
+    else resident_post<ENV>(pd, r, z, dyn, theta, norm, lds);
+}
+
 // ---- host side --------------------------------------------------------------------------------------------------------------------------
 template <int ENV, int DH, int WS> static size_t resident_lds_bytes() {
     using C = Cfg<ENV, 64, 32>;
@@ -526,13 +682,23 @@ template <int ENV, int DH, int WS> static size_t resident_lds_bytes() {
     const size_t post = (size_t)((C::NS_KS * 2 + 24) * 64 + 84 + 8 * (2 * 16 * C::NA)) * sizeof(float);
     return std::max(comp, post);
 }
+template <int ENV, int DH, int WS> static size_t resident_lds_bytes_wide() {
+    using C = Cfg<ENV, 64, 32>;
+    constexpr int MT = WS / 16, OUT_CB = (C::NS + 15) / 16;
+    const size_t comp = (size_t)(32 + OUT_CB * MT * 256 + MT * 256 + 8 * 4 * MT * 256) * sizeof(float);
+    const size_t post = (size_t)((C::NS_KS * 2 + 24) * 64 + 84 + 4 * (2 * 16 * C::NA)) * sizeof(float);
+    return std::max(comp, post);
+}
 typedef void (*resident_kernel_t)(ProblemDesc, RolloutK, ResidentK, const float*, const float*, const float*);
-struct ResidentEntry { int env, ns, na, n_drop, dh, ws; resident_kernel_t fn; size_t lds; };
-#define RES_ENTRY(ENV, DH, WS) {ENV, EnvDim<ENV>::NS, EnvDim<ENV>::NA, EnvDim<ENV>::NDROP, DH, WS, k_rollout_resident<ENV, DH, WS>, resident_lds_bytes<ENV, DH, WS>()}
+struct ResidentEntry { int env, ns, na, n_drop, dh, ws, threads; resident_kernel_t fn; size_t lds; };     // threads: 512 = 4 producer + 4 finisher waves, 256 = 4 waves doing both (2 x 1024)
+#define RES_ENTRY(ENV, DH, WS) {ENV, EnvDim<ENV>::NS, EnvDim<ENV>::NA, EnvDim<ENV>::NDROP, DH, WS, 512, k_rollout_resident<ENV, DH, WS>, resident_lds_bytes<ENV, DH, WS>()}
+#define RES_ENTRY_WIDE(ENV, DH, WS) {ENV, EnvDim<ENV>::NS, EnvDim<ENV>::NA, EnvDim<ENV>::NDROP, DH, WS, 256, k_rollout_resident_wide<ENV, DH, WS>, resident_lds_bytes_wide<ENV, DH, WS>()}
 static const ResidentEntry* resident_table(int* n) {
-    static const ResidentEntry tab[] = {
+    static const ResidentEntry tab[] = {                                // per (env, width): narrowest slice first
         RES_ENTRY(METRPO_ENV_SWIMMER, 512, 16), RES_ENTRY(METRPO_ENV_SWIMMER, 512, 32),
         RES_ENTRY(METRPO_ENV_HOPPER, 512, 32), RES_ENTRY(METRPO_ENV_SNAKE, 512, 32), RES_ENTRY(METRPO_ENV_HALF_CHEETAH, 512, 32),
+        RES_ENTRY_WIDE(METRPO_ENV_HOPPER, 1024, 64), RES_ENTRY_WIDE(METRPO_ENV_SNAKE, 1024, 64), RES_ENTRY_WIDE(METRPO_ENV_HALF_CHEETAH, 1024, 64),
+        RES_ENTRY_WIDE(METRPO_ENV_SWIMMER, 1024, 64),
     };
     *n = (int)(sizeof(tab) / sizeof(tab[0]));
     return tab;
@@ -557,29 +723,23 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
     int n = 0;
     const ResidentEntry* tab = resident_table(&n);
     // narrowest slice (most CUs, least work per step) whose grid -- all rounds side by side -- still fits the chip; if even the widest
-    // slice does not fit, the largest divisor of R that does, the remaining rounds as further launches
+    // slice does not fit, as many rounds at a time as do (the last group may be smaller), every group a launch of its own
     const ResidentEntry* pick = nullptr; int Rg = 0, PW = 0;
-    auto fits = [&](int ws, int rg, int* pw_out) {
-        for (int pw = 1; pw <= 8; pw *= 2)
-            if (rg * K * (DH / ws) + (rg * NT + pw - 1) / pw <= c->n_sm) { *pw_out = pw; return true; }
+    auto fits = [&](const ResidentEntry* e, int rg, int* pw_out) {
+        for (int pw = 1; pw <= e->threads / 64; pw *= 2)
+            if (rg * K * (DH / e->ws) + (rg * NT + pw - 1) / pw <= c->n_sm) { *pw_out = pw; return true; }
         return false;
     };
-    auto entry = [&](int ws) -> const ResidentEntry* {
-        for (int i = 0; i < n; ++i)
-            if (tab[i].env == pd.env && tab[i].ns == pd.ns && tab[i].na == pd.na && tab[i].n_drop == pd.n_drop && tab[i].dh == DH && tab[i].ws == ws) return &tab[i];
-        return nullptr;
-    };
+    auto matches = [&](const ResidentEntry& e) { return e.env == pd.env && e.ns == pd.ns && e.na == pd.na && e.n_drop == pd.n_drop && e.dh == DH; };
     const char* ws_env = getenv("METRPO_RESIDENT_WS");                // test hook: pin the slice width (results are bit-identical only at equal widths)
-    for (int ws = 16; ws <= 32 && !pick; ws *= 2) {
-        if (ws_env != nullptr && atoi(ws_env) != ws) continue;
-        const ResidentEntry* e = entry(ws);
-        if (e && fits(ws, R, &PW)) { pick = e; Rg = R; }
+    const ResidentEntry* widest = nullptr;
+    for (int i = 0; i < n && !pick; ++i) {
+        if (!matches(tab[i]) || (ws_env != nullptr && atoi(ws_env) != tab[i].ws)) continue;
+        widest = &tab[i];
+        if (fits(&tab[i], R, &PW)) { pick = &tab[i]; Rg = R; }
     }
-    if (!pick) {
-        const ResidentEntry* e = entry(32);
-        for (int rg = R - 1; e && rg >= 1 && !pick; --rg)
-            if (R % rg == 0 && fits(32, rg, &PW)) { pick = e; Rg = rg; }
-    }
+    for (int rg = R - 1; widest && rg >= 1 && !pick; --rg)
+        if (fits(widest, rg, &PW)) { pick = widest; Rg = rg; }
     if (!pick) return METRPO_EUNSUPPORTED;
     const int NSL = DH / pick->ws, OUT_CB = (pd.ns + 15) / 16, NIN_KS = (pd.nin + 1 + 3) / 4;
     const size_t nX = (size_t)Rg * NT * 4 * NIN_KS * 16, nP = (size_t)Rg * NT * K * NSL * 16 * OUT_CB * 16;
@@ -598,23 +758,24 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
         HIP_TRY(c, hipMemsetAsync(c->d_res, 0, need, st));
         c->res_cap = need; c->res_seq = 0;
     }
-    if ((unsigned long long)c->res_seq + (unsigned long long)(R / Rg) * (steps + 1) >= 0xfffffff0ull) {   // stamps would wrap: start over on a clean region
+    if ((unsigned long long)c->res_seq + (unsigned long long)((R + Rg - 1) / Rg) * (steps + 1) >= 0xfffffff0ull) {   // stamps would wrap: start over on a clean region
         HIP_TRY(c, hipMemsetAsync(c->d_res, 0, c->res_cap, st));
         c->res_seq = 0;
     }
     if (pick->lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)pick->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pick->lds));
     RolloutK rk = make_rollout_k(a);
     for (int round0 = 0; round0 < R; round0 += Rg) {
+        const int rg = std::min(Rg, R - round0);
         ResidentK z;
-        z.R = Rg; z.round0 = round0; z.rounds_total = R; z.NT = NT; z.NSL = NSL; z.U = Rg * K * NSL; z.PW = PW; z.steps = steps;
+        z.R = rg; z.round0 = round0; z.rounds_total = R; z.NT = NT; z.NSL = NSL; z.U = rg * K * NSL; z.PW = PW; z.steps = steps;
         z.seq0 = c->res_seq; c->res_seq += (unsigned int)steps + 1u;
         z.skip_block = -1;
         if (const char* sk = getenv("METRPO_RESIDENT_TEST_SKIP")) z.skip_block = atoi(sk);
         z.abort_cell = (unsigned int*)c->d_res;
         z.X = (unsigned long long*)c->d_res + 32; z.P = z.X + nX;
         z.err = comm_err_cell(c) + 1;                               // scal[S_ROLLERR]
-        const int grid = z.U + (Rg * NT + PW - 1) / PW;
-        hipLaunchKernelGGL(pick->fn, dim3(grid), dim3(512), pick->lds, st, pd, rk, z, c->d_dyn, c->d_theta, c->d_norm);
+        const int grid = z.U + (rg * NT + PW - 1) / PW;
+        hipLaunchKernelGGL(pick->fn, dim3(grid), dim3(pick->threads), pick->lds, st, pd, rk, z, c->d_dyn, c->d_theta, c->d_norm);
     }
     HIP_TRY(c, hipGetLastError());
     c->last_rollout_kernel = 4;
