@@ -37,6 +37,12 @@ template <> struct EnvDim<METRPO_ENV_HOPPER>       { static constexpr int NS = 1
 template <> struct EnvDim<METRPO_ENV_SNAKE>        { static constexpr int NS = 14, NA = 4, NDROP = 2; };
 
 constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+// A value DEFINED in an accumulation register stays there: the matrix instructions read their A operand from either register file, while a value
+// the allocator merely parks in the accumulation half (more than 256 live registers in a one-wave-per-SIMD kernel) is copied back before every
+// use, and each of those copies queues behind the matrix instruction in flight (rollout_resident.hip: 10.2 -> 8.5 ms at 2 x 1024).  Not a
+// general win: the cooperative rollout kernel (94 parked registers, 45 copies per step) got SLOWER with its fragments pinned there (0.430 -> 0.452 ms).
+__device__ __forceinline__ float in_acc_reg(float v) { float a; asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v)); return a; }
+
 constexpr int al4(int a) { return (a + 3) & ~3; }
 
 template <int ENV, int DH, int PH>

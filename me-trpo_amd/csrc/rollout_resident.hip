@@ -302,8 +302,7 @@ __device__ __forceinline__ void resident_compute_wide(const ProblemDesc& pd, con
                 // the slice's W1 fragments live in ACCUMULATION registers (the matrix instruction reads its A operand from either file): defined
                 // there, they stay there -- left to itself the allocator parks what does not fit into the 256 architectural registers in the other
                 // half and copies it back before every use, and each of those copies queues behind the matrix instruction in flight
-                const float wv = W1[(size_t)(16 * j + 4 * q + r) * DH + col0 + 16 * mt + c];
-                asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(w1f[mt][jj][r]) : "v"(wv));
+                w1f[mt][jj][r] = in_acc_reg(W1[(size_t)(16 * j + 4 * q + r) * DH + col0 + 16 * mt + c]);
             }
     }
     const unsigned long long* xbase = z.X + ((size_t)(rho * NT) * (4 * NIN_KS)) * 16 + c;

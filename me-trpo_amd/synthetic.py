@@ -12,6 +12,10 @@ CONFIGS = {
     # envs per GPU (the per-GPU share; weak scaling keeps that share fixed when --gpus differs).
     'C0': dict(env='swimmer', K=5, dyn_hidden=(64, 64), pol_hidden=(32, 32), B=100, H=50, gpus=1),
     'C0p': dict(env='swimmer', K=5, dyn_hidden=(512, 512), pol_hidden=(32, 32), B=100, H=200, gpus=1, batch_size=50000),    # params-swimmer.json shape: trpo.batch_size 50 000 -> 3 rounds of 100 envs x 200 steps
+    # the other params files of the reference with a horizon-terminated env (2 x 1024 nets, T = 100 / 200): 5 / 3 rounds of 100 envs
+    'C0hc': dict(env='half_cheetah', K=5, dyn_hidden=(1024, 1024), pol_hidden=(32, 32), B=100, H=100, gpus=1, batch_size=50000),   # params-half-cheetah.json
+    'C0ho': dict(env='hopper', K=5, dyn_hidden=(1024, 1024), pol_hidden=(32, 32), B=100, H=100, gpus=1, batch_size=50000),          # params-hopper.json
+    'C0sn': dict(env='snake', K=5, dyn_hidden=(1024, 1024), pol_hidden=(32, 32), B=100, H=200, gpus=1, batch_size=50000),           # params-snake.json
     'C1': dict(env='swimmer', K=5, dyn_hidden=(64, 64), pol_hidden=(32, 32), B=5000, H=100, gpus=1),
     'C2': dict(env='half_cheetah', K=5, dyn_hidden=(1024, 1024), pol_hidden=(32, 32), B=10000, H=200, gpus=4),  # params-half-cheetah.json nets
     'C2s': dict(env='half_cheetah', K=5, dyn_hidden=(64, 64), pol_hidden=(32, 32), B=10000, H=200, gpus=4),     # BASELINE leaves the MLP open: 2x64 variant
