@@ -41,6 +41,7 @@ extern "C" int32_t metrpo_debug_resident_phases(unsigned long long* out) { retur
 
 struct ResidentK {
     int R, round0, rounds_total, NT, NSL, U, PW, steps;   // rounds of this launch, first round, env tiles, slices, compute blocks, post waves per block, steps per round
+    int NTC;                                              // 4-wave form: env tiles per workgroup COLUMN (the R * NT tiles of the launch are dealt to U / (K NSL) columns); else = NT
     unsigned int seq0;                                    // packets of local step tau carry seq0 + tau + 1
     int skip_block;                                       // test hook (METRPO_RESIDENT_TEST_SKIP): this workgroup behaves as if it had never been scheduled; -1 otherwise
     unsigned long long* X; unsigned long long* P; unsigned int* abort_cell;
@@ -267,16 +268,22 @@ __device__ __forceinline__ void resident_compute(const ProblemDesc& pd, const Re
 template <int NS, int NIN, int DH, int WS>
 __device__ __forceinline__ void resident_compute_wide(const ProblemDesc& pd, const ResidentK& z, const float* __restrict__ dyn, float* lds) {
     constexpr int NIN_KS = cdiv(NIN + 1, 4), J = DH / 16, JQ = J / 4, JB = 4, MT = WS / 16, OUT_CB = cdiv(NS, 16), NSP = 16 * OUT_CB;
-    constexpr int O_STAMP = 0, O_W2 = 32, O_B1 = O_W2 + OUT_CB * MT * 256, O_PART = O_B1 + MT * 256;   // floats: stamps | W2 fragments [ocb][mt][lane][r] | b1 [mt][lane][r] | partials
+    constexpr int NSLOT = 8;                                   // LDS slots for the tiles' partial sums: tile t of a column uses slot t % 8
+    constexpr int O_STAMP = 0, O_DONE = 32, O_W2 = 48, O_B1 = O_W2 + OUT_CB * MT * 256, O_PART = O_B1 + MT * 256;   // floats: stamps [slot][producer] | consumed [slot] | W2 fragments [ocb][mt][lane][r] | b1 [mt][lane][r] | partials [slot][producer][mt][lane]
     static_assert(JQ % JB == 0, "hidden-0 tiles are taken four at a time");
     const int tid = threadIdx.x, lane = tid & 63, kap = tid >> 6, c = lane & 15, q = lane >> 4;
-    const int K = pd.K, NSL = z.NSL, NT = z.NT;
-    const int u = blockIdx.x, rho = u / (K * NSL), k = (u / NSL) % K, sl = u % NSL, col0 = sl * WS;
+    const int K = pd.K, NSL = z.NSL;
+    const int u = blockIdx.x, col = u / (K * NSL), k = (u / NSL) % K, sl = u % NSL, col0 = sl * WS;
+    // The R * NT env tiles of the launch (tile g = round * NT + tile of the round: what the post waves and the packet slots are indexed by) are
+    // dealt to the workgroup columns in runs of NTC: five rounds of seven tiles are three columns of 12 / 12 / 11, one launch, every CU busy --
+    // instead of 3 + 2 rounds in two launches.  NT below = the tiles of THIS column.
+    const int g0 = col * z.NTC, NT = max(0, min(z.NTC, z.R * z.NT - g0));
+    if (NT == 0) return;
     const float* __restrict__ W = dyn + (size_t)k * pd.dyn.n_params;
     const float* __restrict__ W0 = W + pd.dyn.w_off[0];
     const float* __restrict__ W1 = W + pd.dyn.w_off[1];
     const float* __restrict__ W2 = W + pd.dyn.w_off[2];
-    if (tid < 32) ((unsigned int*)lds)[O_STAMP + tid] = z.seq0;
+    if (tid < 48) ((unsigned int*)lds)[tid] = 0u;               // stamps and consumed marks count the uses of a slot within this launch (1, 2, ...)
     for (int i = tid; i < OUT_CB * MT * 256; i += 256) {
         const int r = i & 3, ln = (i >> 2) & 63, mt = (i >> 8) % MT, ocb = i / (256 * MT), dim = 16 * ocb + (ln & 15);
         lds[O_W2 + i] = (dim < NS) ? W2[(size_t)(col0 + 16 * mt + 4 * (ln >> 4) + r) * NS + dim] : 0.0f;
@@ -305,48 +312,60 @@ __device__ __forceinline__ void resident_compute_wide(const ProblemDesc& pd, con
                 w1f[mt][jj][r] = in_acc_reg(W1[(size_t)(16 * j + 4 * q + r) * DH + col0 + 16 * mt + c]);
             }
     }
-    const unsigned long long* xbase = z.X + ((size_t)(rho * NT) * (4 * NIN_KS)) * 16 + c;
+    const unsigned long long* xbase = z.X + ((size_t)g0 * (4 * NIN_KS)) * 16 + c;
     unsigned long long pk[NIN_KS];
     auto fetch = [&](int t) {
 #pragma unroll
         for (int kk = 0; kk < NIN_KS; ++kk) pk[kk] = res_ld(xbase + ((size_t)t * (4 * NIN_KS) + 4 * kk + q) * 16);
     };
-    // ---- finisher duties of this wave: tiles kap, kap + 4 of every step, in order
-    const unsigned int last_seq = z.seq0 + (unsigned int)z.steps;
-    int dt = kap; unsigned int dseq = z.seq0 + 1u;
+    // A slot serves the tiles t, t + 8, ... of the column, step after step: use number uid(tau, t) = tau * (uses of the slot per step) + t / 8.
+    // Producers stamp a slot with uid + 1 once their quarter is in it, the finisher marks it consumed (uid + 1) once it has read the four
+    // quarters, and a producer writes use n only over a consumed use n - 1: nobody can lap the finisher (every wait below keeps finishing).
+    auto uid_of = [&](int tau, int t) -> unsigned int { const int s_ = t & (NSLOT - 1); return (unsigned int)(tau * ((NT - s_ + NSLOT - 1) / NSLOT) + (t >> 3)); };
+    // ---- finisher duties of this wave: tiles kap, kap + 4, ... of the column, every step, in order
+    int dt = kap, dtau = 0;
     auto try_finish = [&]() -> bool {
-        if (dt >= NT || (int)(dseq - last_seq) > 0) return false;
-        const unsigned int st = __hip_atomic_load((const unsigned int*)lds + O_STAMP + dt * 4 + (lane & 3), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (!__all((int)(st - dseq) >= 0)) return false;
-        const f32x4* part = (const f32x4*)(lds + O_PART) + ((size_t)(dt * 4) * MT) * 64 + lane;
+        if (dt >= NT || dtau >= z.steps) return false;
+        const int s_ = dt & (NSLOT - 1);
+        const unsigned int want = uid_of(dtau, dt) + 1u;
+        const unsigned int st = __hip_atomic_load((const unsigned int*)lds + O_STAMP + s_ * 4 + (lane & 3), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!__all((int)(st - want) >= 0)) return false;
+        const f32x4* part = (const f32x4*)(lds + O_PART) + ((size_t)(s_ * 4) * MT) * 64 + lane;
+        f32x4 h2[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            h2[mt] = *(const f32x4*)&lds[O_B1 + (mt * 64 + lane) * 4];
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) h2[mt] += part[(kp * MT + mt) * 64];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the quarters are in registers: the slot may be overwritten
+        if (lane == 0) __hip_atomic_store((unsigned int*)lds + O_DONE + s_, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         f32x4 o[OUT_CB];
 #pragma unroll
         for (int ocb = 0; ocb < OUT_CB; ++ocb) o[ocb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            f32x4 h2 = *(const f32x4*)&lds[O_B1 + (mt * 64 + lane) * 4];
 #pragma unroll
-            for (int kp = 0; kp < 4; ++kp) h2 += part[(kp * MT + mt) * 64];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h2[r] = relu1(h2[r]);
+            for (int r = 0; r < 4; ++r) h2[mt][r] = relu1(h2[mt][r]);
 #pragma unroll
             for (int ocb = 0; ocb < OUT_CB; ++ocb) {
                 const f32x4 w2 = *(const f32x4*)&lds[O_W2 + ((ocb * MT + mt) * 64 + lane) * 4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[ocb] = MFMA16(w2[r], h2[r], o[ocb]);
+                for (int r = 0; r < 4; ++r) o[ocb] = MFMA16(w2[r], h2[mt][r], o[ocb]);
             }
         }
-        unsigned long long* pp = z.P + ((((size_t)(rho * NT + dt) * K + k) * NSL + sl) * NSP) * 16 + c;
+        const unsigned int dseq = z.seq0 + (unsigned int)dtau + 1u;
+        unsigned long long* pp = z.P + ((((size_t)(g0 + dt) * K + k) * NSL + sl) * NSP) * 16 + c;
 #pragma unroll
         for (int ocb = 0; ocb < OUT_CB; ++ocb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const int dim = 16 * ocb + 4 * q + r; if (dim < NS) res_st(pp + dim * 16, dseq, o[ocb][r]); }
         dt += 4;
-        if (dt >= NT) { dt = kap; ++dseq; }
+        if (dt >= NT) { dt = kap; ++dtau; }
         return true;
     };
     fetch(0);
-    int t = 0; unsigned int seq = z.seq0 + 1u;
+    int t = 0, tau = 0; unsigned int seq = z.seq0 + 1u;
     const int total = z.steps * NT;
     for (int it = 0; it < total; ++it) {
         float x[NIN_KS];
@@ -386,18 +405,26 @@ __device__ __forceinline__ void resident_compute_wide(const ProblemDesc& pd, con
                 }
         }
         {   // partial sums of env tile t out (LDS operations of one wave complete in issue order: the stamp lands after the data)
-            f32x4* part = (f32x4*)(lds + O_PART) + ((size_t)(t * 4 + kap) * MT) * 64 + lane;
+            const int s_ = t & (NSLOT - 1);
+            const unsigned int uid = uid_of(tau, t);
+            if (uid > 0) {                                              // the slot's previous occupant must have been read by its finisher
+                ResSpin sp;
+                while ((int)(__hip_atomic_load((const unsigned int*)lds + O_DONE + s_, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - uid) < 0) {
+                    if (!try_finish() && sp.give_up(z)) return;
+                }
+            }
+            f32x4* part = (f32x4*)(lds + O_PART) + ((size_t)(s_ * 4 + kap) * MT) * 64 + lane;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) part[mt * 64] = a2[mt];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            if (lane == 0) __hip_atomic_store((unsigned int*)lds + O_STAMP + t * 4 + kap, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0) __hip_atomic_store((unsigned int*)lds + O_STAMP + s_ * 4 + kap, uid + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         (void)try_finish();
-        if (++t == NT) { t = 0; ++seq; }
+        if (++t == NT) { t = 0; ++seq; ++tau; }
     }
     {   // what is left of this wave's duties (the other producers' last hand-overs may still be under way)
         ResSpin sp;
-        while (dt < NT && (int)(dseq - last_seq) <= 0) { if (!try_finish() && sp.give_up(z)) return; }
+        while (dt < NT && dtau < z.steps) { if (!try_finish() && sp.give_up(z)) return; }
     }
 }
 
@@ -684,7 +711,7 @@ template <int ENV, int DH, int WS> static size_t resident_lds_bytes() {
 template <int ENV, int DH, int WS> static size_t resident_lds_bytes_wide() {
     using C = Cfg<ENV, 64, 32>;
     constexpr int MT = WS / 16, OUT_CB = (C::NS + 15) / 16;
-    const size_t comp = (size_t)(32 + OUT_CB * MT * 256 + MT * 256 + 8 * 4 * MT * 256) * sizeof(float);
+    const size_t comp = (size_t)(48 + OUT_CB * MT * 256 + MT * 256 + 8 * 4 * MT * 256) * sizeof(float);
     const size_t post = (size_t)((C::NS_KS * 2 + 24) * 64 + 84 + 4 * (2 * 16 * C::NA)) * sizeof(float);
     return std::max(comp, post);
 }
@@ -725,6 +752,10 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
     // slice does not fit, as many rounds at a time as do (the last group may be smaller), every group a launch of its own
     const ResidentEntry* pick = nullptr; int Rg = 0, PW = 0;
     auto fits = [&](const ResidentEntry* e, int rg, int* pw_out) {
+        if (e->threads == 256) {                                        // 4-wave form: the tiles of the rg rounds are dealt to as many workgroup columns as fit -- one is enough
+            *pw_out = 4;
+            return K * (DH / e->ws) + (rg * NT + 3) / 4 <= c->n_sm;
+        }
         for (int pw = 1; pw <= e->threads / 64; pw *= 2)
             if (rg * K * (DH / e->ws) + (rg * NT + pw - 1) / pw <= c->n_sm) { *pw_out = pw; return true; }
         return false;
@@ -766,7 +797,13 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
     for (int round0 = 0; round0 < R; round0 += Rg) {
         const int rg = std::min(Rg, R - round0);
         ResidentK z;
-        z.R = rg; z.round0 = round0; z.rounds_total = R; z.NT = NT; z.NSL = NSL; z.U = rg * K * NSL; z.PW = PW; z.steps = steps;
+        z.R = rg; z.round0 = round0; z.rounds_total = R; z.NT = NT; z.NSL = NSL; z.U = rg * K * NSL; z.PW = PW; z.steps = steps; z.NTC = NT;
+        if (pick->threads == 256) {
+            const int G = rg * NT, post_blocks = (G + PW - 1) / PW;
+            const int ncol = std::max(1, std::min(G, (c->n_sm - post_blocks) / (K * NSL)));
+            z.NTC = (G + ncol - 1) / ncol;
+            z.U = ((G + z.NTC - 1) / z.NTC) * K * NSL;
+        }
         z.seq0 = c->res_seq; c->res_seq += (unsigned int)steps + 1u;
         z.skip_block = -1;
         if (const char* sk = getenv("METRPO_RESIDENT_TEST_SKIP")) z.skip_block = atoi(sk);

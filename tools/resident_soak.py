@@ -6,9 +6,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, metrpo_amd
 from metrpo_amd import synthetic
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
-env, K, B, H, R = 'swimmer', 5, 100, 200, 3
-eng = metrpo_amd.Engine(env, K, (512, 512), (32, 32))
-Ws, bs, norm = synthetic.make_dynamics(env, K, (512, 512), seed=0)
+env, K, B, H, R, hid = 'swimmer', 5, 100, 200, 3, 512
+if len(sys.argv) > 2 and sys.argv[2] == 'wide':            # params-half-cheetah.json shape: the 4-wave workgroups, five rounds dealt to three columns
+    env, H, R, hid = 'half_cheetah', 100, 5, 1024
+eng = metrpo_amd.Engine(env, K, (hid, hid), (32, 32))
+Ws, bs, norm = synthetic.make_dynamics(env, K, (hid, hid), seed=0)
 eng.set_dynamics_layers(Ws, bs, norm['in_mean'], norm['in_std'], norm['diff_mean'], norm['diff_std'])
 eng.set_policy(metrpo_amd.xavier_policy_theta(eng.ns, (32, 32), eng.na))
 pool = torch.as_tensor(synthetic.make_pool(env), device='cuda')
