@@ -760,7 +760,8 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
             if (rg * K * (DH / e->ws) + (rg * NT + pw - 1) / pw <= c->n_sm) { *pw_out = pw; return true; }
         return false;
     };
-    auto matches = [&](const ResidentEntry& e) { return e.env == pd.env && e.ns == pd.ns && e.na == pd.na && e.n_drop == pd.n_drop && e.dh == DH; };
+    // (the post wave adds the slices in batches of 16: DH / ws must be a multiple of 16)
+    auto matches = [&](const ResidentEntry& e) { return e.env == pd.env && e.ns == pd.ns && e.na == pd.na && e.n_drop == pd.n_drop && e.dh == DH && (DH / e.ws) % 16 == 0; };
     const char* ws_env = getenv("METRPO_RESIDENT_WS");                // test hook: pin the slice width (results are bit-identical only at equal widths)
     const ResidentEntry* widest = nullptr;
     for (int i = 0; i < n && !pick; ++i) {
