@@ -268,8 +268,12 @@ __device__ __forceinline__ void resident_compute(const ProblemDesc& pd, const Re
 template <int NS, int NIN, int DH, int WS>
 __device__ __forceinline__ void resident_compute_wide(const ProblemDesc& pd, const ResidentK& z, const float* __restrict__ dyn, float* lds) {
     constexpr int NIN_KS = cdiv(NIN + 1, 4), J = DH / 16, JQ = J / 4, JB = 4, MT = WS / 16, OUT_CB = cdiv(NS, 16), NSP = 16 * OUT_CB;
-    constexpr int NSLOT = 8;                                   // LDS slots for the tiles' partial sums: tile t of a column uses slot t % 8
-    constexpr int O_STAMP = 0, O_DONE = 32, O_W2 = 48, O_B1 = O_W2 + OUT_CB * MT * 256, O_PART = O_B1 + MT * 256;   // floats: stamps [slot][producer] | consumed [slot] | W2 fragments [ocb][mt][lane][r] | b1 [mt][lane][r] | partials [slot][producer][mt][lane]
+    // Wide inputs (Ant: 35 + 1 inputs = 9 k-steps): the W0 fragments of the k-steps beyond the sixth live in an LDS image instead of 16 more
+    // registers each -- with the W1 slice filling the accumulation half, everything else has to fit the 256 architectural registers, and what
+    // does not is spilled to scratch memory inside the tile loop (31 loads per tile, 10 instead of 6 us).  The image takes half of the partial-sum slots' space.
+    constexpr int W0L = (NIN_KS > 6) ? NIN_KS - 6 : 0, W0R = NIN_KS - W0L;
+    constexpr int NSLOT = W0L ? 4 : 8;                         // LDS slots for the tiles' partial sums: tile t of a column uses slot t % NSLOT
+    constexpr int O_STAMP = 0, O_DONE = 32, O_W2 = 48, O_B1 = O_W2 + OUT_CB * MT * 256, O_W0 = O_B1 + MT * 256, O_PART = O_W0 + 4 * JQ * W0L * 64;   // floats: stamps [slot][producer] | consumed [slot] | W2 fragments [ocb][mt][lane][r] | b1 [mt][lane][r] | partials [slot][producer][mt][lane]
     static_assert(JQ % JB == 0, "hidden-0 tiles are taken four at a time");
     const int tid = threadIdx.x, lane = tid & 63, kap = tid >> 6, c = lane & 15, q = lane >> 4;
     const int K = pd.K, NSL = z.NSL;
@@ -292,15 +296,16 @@ __device__ __forceinline__ void resident_compute_wide(const ProblemDesc& pd, con
         const int r = i & 3, ln = (i >> 2) & 63, mt = i >> 8;
         lds[O_B1 + i] = W[pd.dyn.b_off[1] + col0 + 16 * mt + 4 * (ln >> 4) + r];
     }
-    __syncthreads();
-    float w0f[JQ][NIN_KS], w1f[MT][JQ][4];
+    float w0f[JQ][W0R], w1f[MT][JQ][4];
+    float* w0l = lds + O_W0 + (size_t)kap * JQ * W0L * 64 + lane;      // this wave's image: [jj][kk - W0R][lane]
 #pragma unroll
     for (int jj = 0; jj < JQ; ++jj) {
         const int j = kap * JQ + jj;
 #pragma unroll
         for (int kk = 0; kk < NIN_KS; ++kk) {
             const int in = 4 * kk + q;
-            w0f[jj][kk] = (in < NIN) ? W0[(size_t)in * DH + 16 * j + c] : (in == NIN ? W[pd.dyn.b_off[0] + 16 * j + c] : 0.0f);
+            const float w = (in < NIN) ? W0[(size_t)in * DH + 16 * j + c] : (in == NIN ? W[pd.dyn.b_off[0] + 16 * j + c] : 0.0f);
+            if (kk < W0R) w0f[jj][kk < W0R ? kk : 0] = w; else w0l[(jj * W0L + (kk - W0R)) * 64] = w;
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -312,6 +317,7 @@ __device__ __forceinline__ void resident_compute_wide(const ProblemDesc& pd, con
                 w1f[mt][jj][r] = in_acc_reg(W1[(size_t)(16 * j + 4 * q + r) * DH + col0 + 16 * mt + c]);
             }
     }
+    __syncthreads();                                            // stamps, W2 / b1 / W0 images
     const unsigned long long* xbase = z.X + ((size_t)g0 * (4 * NIN_KS)) * 16 + c;
     unsigned long long pk[NIN_KS];
     auto fetch = [&](int t) {
@@ -321,7 +327,7 @@ __device__ __forceinline__ void resident_compute_wide(const ProblemDesc& pd, con
     // A slot serves the tiles t, t + 8, ... of the column, step after step: use number uid(tau, t) = tau * (uses of the slot per step) + t / 8.
     // Producers stamp a slot with uid + 1 once their quarter is in it, the finisher marks it consumed (uid + 1) once it has read the four
     // quarters, and a producer writes use n only over a consumed use n - 1: nobody can lap the finisher (every wait below keeps finishing).
-    auto uid_of = [&](int tau, int t) -> unsigned int { const int s_ = t & (NSLOT - 1); return (unsigned int)(tau * ((NT - s_ + NSLOT - 1) / NSLOT) + (t >> 3)); };
+    auto uid_of = [&](int tau, int t) -> unsigned int { const int s_ = t & (NSLOT - 1); return (unsigned int)(tau * ((NT - s_ + NSLOT - 1) / NSLOT) + t / NSLOT); };
     // ---- finisher duties of this wave: tiles kap, kap + 4, ... of the column, every step, in order
     int dt = kap, dtau = 0;
     auto try_finish = [&]() -> bool {
@@ -394,7 +400,7 @@ __device__ __forceinline__ void resident_compute_wide(const ProblemDesc& pd, con
 #pragma unroll
             for (int kk = 0; kk < NIN_KS; ++kk)
 #pragma unroll
-                for (int jj = 0; jj < JB; ++jj) h[jj] = MFMA16(w0f[jb + jj][kk], x[kk], h[jj]);
+                for (int jj = 0; jj < JB; ++jj) h[jj] = MFMA16((kk < W0R) ? w0f[jb + jj][kk < W0R ? kk : 0] : w0l[((jb + jj) * W0L + (kk - W0R)) * 64], x[kk], h[jj]);
 #pragma unroll
             for (int jj = 0; jj < JB; ++jj)
 #pragma unroll
@@ -419,7 +425,13 @@ __device__ __forceinline__ void resident_compute_wide(const ProblemDesc& pd, con
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             if (lane == 0) __hip_atomic_store((unsigned int*)lds + O_STAMP + s_ * 4 + kap, uid + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        (void)try_finish();
+        if (NT <= 4 && (t & 3) == kap) {
+            // a column of few tiles (one round of 7 tiles over three columns: Ant's chunks, single rounds) comes back to a tile before a finish deferred
+            // behind the next tile's MFMAs has made its way through the post wave: its finisher waits for the other three quarters (the producers run
+            // the same tile at the same time) and finishes at once -- earlier duties first, so nobody it waits for can be waiting for it
+            ResSpin sp;
+            while (dtau < z.steps && (dtau < tau || (dtau == tau && dt <= t))) { if (!try_finish() && sp.give_up(z)) return; }
+        } else (void)try_finish();
         if (++t == NT) { t = 0; ++seq; ++tau; }
     }
     {   // what is left of this wave's duties (the other producers' last hand-overs may still be under way)
@@ -439,7 +451,7 @@ __device__ __forceinline__ float sel4(int q, float a0, float a1, float a2, float
 template <int ENV>
 __device__ __forceinline__ void resident_post(const ProblemDesc& pd, const RolloutK& r, const ResidentK& z, const float* __restrict__ dyn,
                                               const float* __restrict__ theta, const float* __restrict__ norm, float* lds) {
-    static_assert(ENV != METRPO_ENV_ANT && ENV != METRPO_ENV_HUMANOID, "horizon-terminated envs only");
+    static_assert(ENV != METRPO_ENV_HUMANOID, "2 x 32 policies only");
     using C = Cfg<ENV, 64, 32>;
     constexpr int NS = C::NS, NA = C::NA, NDROP = C::NDROP, NIN = C::NIN, PH = 32, NS_KS = C::NS_KS, NIN_KS = cdiv(NIN + 1, 4), NSP = C::NSP;   // X element NIN = 1 (bias input of layer 0)
     constexpr int O_PF1 = NS_KS * 2 * 64, O_PF2 = O_PF1 + 16 * 64, O_B0 = O_PF2 + 8 * 64, O_B1 = O_B0 + 32, O_B2 = O_B1 + 32, IMG = ((O_B2 + 16 + 3) / 4) * 4;
@@ -597,13 +609,16 @@ __device__ __forceinline__ void resident_post(const ProblemDesc& pd, const Rollo
         if (r.sam_mode == METRPO_SAM_STEP_RAND) sel = (r.model_idx != nullptr) ? r.model_idx[tb] : rng_index(dstep.z, K);
         if (r.sam_mode == METRPO_SAM_ONE_MODEL) sel = 0;
         const int ts_new = ts + 1;
-        const bool dn = ts_new >= r.H;                                // env_helpers.py:603-604 (no state-dependent termination in these envs)
+        const bool dn_h = ts_new >= r.H;                              // env_helpers.py:603-604
+        // Ant also ends an episode on the state it reaches (com_ant_env.py is_done): known only when the partial sums are in, so its reset row is
+        // fetched every step, off the critical path like everything here
+        constexpr bool STATE_DONE = (ENV == METRPO_ENV_ANT);
         float prow[NS];
-        int next_model = cur_model;
-        if (dn) {                                                     // reset (env_helpers.py:585-595): row and model from this step's block
+        int reset_model = cur_model;
+        if (dn_h || STATE_DONE) {                                     // reset (env_helpers.py:585-595): row and model from this step's block
             const size_t rb = (size_t)(t_loc + 1) * B + bc;
             const int row = (r.reset_idx != nullptr) ? r.reset_idx[rb] : rng_index(dstep.w, r.n_pool);
-            next_model = (r.reset_model != nullptr) ? r.reset_model[rb] : rng_index16(dstep.z, K);
+            reset_model = (r.reset_model != nullptr) ? r.reset_model[rb] : rng_index16(dstep.z, K);
 #pragma unroll
             for (int i = 0; i < NS; ++i) prow[i] = r.pool[(size_t)row * NS + i];
         }
@@ -661,6 +676,15 @@ __device__ __forceinline__ void resident_post(const ProblemDesc& pd, const Rollo
             for (int j = 2; j < NS; ++j) pen += fmaxf(fabsf(v[j]) - 100.0f, 0.0f);
             cost = -(v[5] - 0.01f * 0.5f * su2 - 10.0f * fmaxf(0.45f - v[0], 0.0f) - 10.0f * fmaxf(fabsf(v[1]) - 0.2f, 0.0f) - pen);
         } else if constexpr (ENV == METRPO_ENV_SNAKE) cost = -(v[7] - 1e-2f * 0.5f * su2);
+        else if constexpr (ENV == METRPO_ENV_ANT) cost = -(v[15] - 1e-2f * 0.5f * su2 + 0.05f);
+        bool dn = dn_h;
+        if constexpr (STATE_DONE) {                                   // not (0.2 <= z <= 1.0 and every state dim finite), as k_big_post
+            bool fin = true;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) fin = fin && isfinite(v[i]);
+            dn = dn_h || !((v[2] >= 0.2f) && (v[2] <= 1.0f) && fin);
+        }
+        const int next_model = dn ? reset_model : cur_model;
         if (active && q == 0) { r.rew[tb] = -cost; r.done[tb] = dn ? 1 : 0; r.tpath[tb] = ts_new - 1; }
 #pragma unroll
         for (int i = 0; i < NS; ++i) s[i] = !active ? 0.0f : (dn ? prow[i] : v[i]);
@@ -710,8 +734,8 @@ template <int ENV, int DH, int WS> static size_t resident_lds_bytes() {
 }
 template <int ENV, int DH, int WS> static size_t resident_lds_bytes_wide() {
     using C = Cfg<ENV, 64, 32>;
-    constexpr int MT = WS / 16, OUT_CB = (C::NS + 15) / 16;
-    const size_t comp = (size_t)(48 + OUT_CB * MT * 256 + MT * 256 + 8 * 4 * MT * 256) * sizeof(float);
+    constexpr int MT = WS / 16, OUT_CB = (C::NS + 15) / 16, NIN_KS = (C::NIN + 1 + 3) / 4, W0L = (NIN_KS > 6) ? NIN_KS - 6 : 0, NSLOT = W0L ? 4 : 8;
+    const size_t comp = (size_t)(48 + OUT_CB * MT * 256 + MT * 256 + 4 * (DH / 64) * W0L * 64 + NSLOT * 4 * MT * 256) * sizeof(float);
     const size_t post = (size_t)((C::NS_KS * 2 + 24) * 64 + 84 + 4 * (2 * 16 * C::NA)) * sizeof(float);
     return std::max(comp, post);
 }
@@ -724,7 +748,7 @@ static const ResidentEntry* resident_table(int* n) {
         RES_ENTRY(METRPO_ENV_SWIMMER, 512, 16), RES_ENTRY(METRPO_ENV_SWIMMER, 512, 32),
         RES_ENTRY(METRPO_ENV_HOPPER, 512, 32), RES_ENTRY(METRPO_ENV_SNAKE, 512, 32), RES_ENTRY(METRPO_ENV_HALF_CHEETAH, 512, 32),
         RES_ENTRY_WIDE(METRPO_ENV_HOPPER, 1024, 64), RES_ENTRY_WIDE(METRPO_ENV_SNAKE, 1024, 64), RES_ENTRY_WIDE(METRPO_ENV_HALF_CHEETAH, 1024, 64),
-        RES_ENTRY_WIDE(METRPO_ENV_SWIMMER, 1024, 64),
+        RES_ENTRY_WIDE(METRPO_ENV_SWIMMER, 1024, 64), RES_ENTRY_WIDE(METRPO_ENV_ANT, 1024, 64),
     };
     *n = (int)(sizeof(tab) / sizeof(tab[0]));
     return tab;

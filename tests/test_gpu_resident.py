@@ -27,12 +27,18 @@ def _fields(tr):
                                                ('snake', 4, 50, 8, 5, 'eps_rand'),
                                                ('half_cheetah', 5, 77, 6, 6, 'step_rand'),    # ns = 18: two output-dim tiles, 6 input k-steps
                                                ('swimmer', 5, 100, 12, 4, 'step_rand'),       # T = 3 H: the three rounds side by side, every reset from the supplied draws
-                                               ('hopper', 3, 1, 3, 1, 'eps_rand')])           # one env, every step ends an episode
+                                               ('hopper', 3, 1, 3, 1, 'eps_rand'),            # one env, every step ends an episode
+                                               ('ant', 5, 100, 10, 6, 'step_rand')])          # params-ant.json network: episodes also end on the state reached
 def test_resident_rollout_against_oracle(env, K, B, T, H, mode, hid):
     """hid = 1024: the 4-wave workgroups of resident_compute_wide (params-half-cheetah / -hopper / -snake.json networks)."""
     if hid == 1024 and (env, B) in (('swimmer', 128), ('hopper', 1)):
         pytest.skip('covered at 512')
+    if hid == 512 and env == 'ant':
+        pytest.skip('no 2 x 512 Ant in the kernel table (no params file has one)')
     eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (hid, hid), (32, 32), seed=61)
+    if env == 'ant':                                                 # some envs start near the lower z bound: state-dependent dones inside the call
+        pool[::3, 2] = 0.21; dm.diff_mean[2] = -0.02
+        eng.set_dynamics_layers(dm.Ws, dm.bs, dm.in_mean, dm.in_std, dm.diff_mean, dm.diff_std)
     th = theta.astype(np.float32).astype(np.float64)
     pool32 = pool.astype(np.float32).astype(np.float64)
     dr = Hh.draws(np.random.RandomState(8), K, B, T, dm.ns, dm.na, len(pool))
@@ -140,9 +146,14 @@ def test_resident_deterministic_policy_and_repeatability():
     np.testing.assert_array_equal(cpu(d.obs[0]), cpu(a[0][0]))                               # same reset draws as the noisy rollout of that seed
 
 
-def test_resident_chunked_continuation_equals_one_call():
-    """A rollout cut into chunks (t0, resume, last_state: the sampler's step-granular stop rule) gives the trajectory of the single call."""
-    eng, dm, theta, pdims, pool = Hh.make_engine('swimmer', 5, (512, 512), (32, 32), seed=13)
+@pytest.mark.parametrize('env,hid', [('swimmer', 512), ('ant', 1024)])
+def test_resident_chunked_continuation_equals_one_call(env, hid):
+    """A rollout cut into chunks (t0, resume, last_state: the sampler's step-granular stop rule) gives the trajectory of the single call.
+    Ant (2 x 1024, the 4-wave workgroups): the env the chunks exist for -- its episodes end on the state, the sampler stops step-granular."""
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, 5, (hid, hid), (32, 32), seed=13)
+    if env == 'ant':
+        pool[::3, 2] = 0.21; dm.diff_mean[2] = -0.02
+        eng.set_dynamics_layers(dm.Ws, dm.bs, dm.in_mean, dm.in_std, dm.diff_mean, dm.diff_std)
     B, T, H = 70, 12, 5
     whole = eng.rollout(B, T, H, 'eps_rand', pool, seed=9)
     assert eng.last_rollout_kernel() == 'resident'
@@ -160,6 +171,9 @@ def test_resident_chunked_continuation_equals_one_call():
     for i in range(6):
         assert torch.equal(torch.cat([p[i] for p in parts], 0), whole[i])
     assert torch.equal(parts[-1][6], whole[6])
+    if env == 'ant':
+        dn = whole[4].bool(); tp = whole[5]
+        assert bool((dn & (tp < H - 1)).any())                        # some episodes ended before the horizon
     # a raised stop flag turns the launch into a no-op
     stop.fill_(1)
     sentinel = eng.alloc_trajectory(B, 3, H)
@@ -183,7 +197,7 @@ def test_resident_kernel_scope():
     eng3 = Hh.make_engine('swimmer', 5, (64, 64), (32, 32), seed=3)[0]
     eng3.rollout(64, 4, 4, 'step_rand', pool, seed=1)
     assert eng3.last_rollout_kernel() == 'mfma-cooperative'
-    # 2 x 1024 (every other params file of the reference): the 4-wave workgroups; Ant (state-dependent termination) stays step-wise
+    # 2 x 1024 (every other params file of the reference with a 2 x 32 policy): the 4-wave workgroups
     eng4, _, _, _, pool4 = Hh.make_engine('hopper', 5, (1024, 1024), (32, 32), seed=3)
     eng4.rollout(100, 10, 5, 'step_rand', pool4, seed=1)
     assert eng4.last_rollout_kernel() == 'resident'
@@ -191,7 +205,10 @@ def test_resident_kernel_scope():
     assert eng4.last_rollout_kernel() == 'gemm-stepwise'
     eng5, _, _, _, pool5 = Hh.make_engine('ant', 5, (1024, 1024), (32, 32), seed=3)
     eng5.rollout(100, 4, 4, 'step_rand', pool5, seed=1)
-    assert eng5.last_rollout_kernel() == 'gemm-stepwise'
+    assert eng5.last_rollout_kernel() == 'resident'                      # Ant too (one round at a time: its episodes end on the state)
+    eng6, _, _, _, pool6 = Hh.make_engine('ant', 5, (512, 512), (32, 32), seed=3)
+    eng6.rollout(100, 4, 4, 'step_rand', pool6, seed=1)
+    assert eng6.last_rollout_kernel() == 'gemm-stepwise'
 
 
 @pytest.mark.parametrize('env,hid', [('swimmer', 512), ('hopper', 1024)])
