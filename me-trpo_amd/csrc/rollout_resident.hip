@@ -1,5 +1,6 @@
-// Resident rollout for SMALL batches of 2 x 512 dynamics ensembles (the reference's own params-swimmer.json: K = 5, B = 100 envs,
-// three rounds of 200 steps): the whole time loop in ONE launch, weights resident in registers, the steps chained through 8-byte packets.
+// Resident rollout for SMALL batches of 2 x 512 and 2 x 1024 dynamics ensembles (the reference's own params files: K = 5, B = 100 envs,
+// 50 000 samples per iteration = three rounds of 200 steps for Swimmer / Snake, five of 100 for HalfCheetah / Hopper, >= 500 steps in chunks
+// for Ant): the whole time loop in ONE launch, weights resident in registers, the steps chained through 8-byte packets.
 // Same reference path as the other rollout kernels (samplers/vectorized_sampler.py:45-116, env_helpers.py:597-635, training.py:218-269).
 //
 // Why: at B = 100 a step of the step-wise GEMM path (rollout_gemm.hip) is four dependent launches of 4-19 us that each re-read the
@@ -16,7 +17,8 @@
 //     8-byte stores / loads: no fence, no flag, no grid barrier; xchg_device.h uses the same idea between GPUs).  Nobody waits for
 //     more than ITS tile: a tile's round trip (partial sums out, next input in: ~6 us) passes while the CU works on the round's other tiles.
 // All K heads are evaluated every step (as the reference's graph does); only simple sampling modes (step_rand / eps_rand / one_model).
-// Everything else (B > 128, other widths, Ant, model_mean_std / model_med) stays on rollout_gemm.hip.  The grid must be resident as a whole:
+// 2 x 1024 nets (every params file but Swimmer's) take the 4-wave form of the compute role, resident_compute_wide below.
+// Everything else (B > 128, other widths, policies other than 2 x 32, model_mean_std / model_med) stays on rollout_gemm.hip.  The grid must be resident as a whole:
 // every wait is bounded (2 s), a launch that gives up is reported by the next metrpo_trpo_update / metrpo_comm_check and retires the kernel
 // for its context (metrpo_internal.h: rollout_error_seen).
 #include "mfma_common.h"
