@@ -126,6 +126,38 @@ def test_resident_rounds_side_by_side_equal_sequential_rounds(K, B, H, R, ws, mo
     np.testing.assert_allclose(cpu(par[3]), cpu(gm.rew), rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize('hid', [512, 1024])
+def test_resident_random_shapes_vs_generic_kernel(hid):
+    """Random (env, K, B, T, H, mode) with production draws: the resident kernel (8-wave form at 2 x 512, 4-wave form at 2 x 1024, whatever deal
+    of rounds / tile columns the launcher picks) against the thread-per-env generic kernel on the same Philox streams -- same dones and
+    path-time indices, states within float32 summation order over the few steps before the trajectories' chaotic drift matters."""
+    rng = np.random.RandomState(1234 + hid)
+    envs = ['swimmer', 'hopper', 'snake', 'half_cheetah'] + (['ant'] if hid == 1024 else [])
+    for case in range(10):
+        env = envs[rng.randint(len(envs))]
+        K = int(rng.randint(1, 6))
+        B = int(rng.choice([1, 15, 16, 17, 33, 64, 100, 127, 128]))
+        H = int(rng.randint(1, 7))
+        R = int(rng.randint(1, 7)) if env != 'ant' else 1
+        T = R * H if rng.rand() < 0.7 else R * H + int(rng.randint(1, 3))      # sometimes a ragged tail: resets inside one launch, no round split
+        mode = ['step_rand', 'eps_rand', 'one_model'][rng.randint(3)]
+        eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (hid, hid), (32, 32), seed=500 + case)
+        res = eng.rollout(B, T, H, mode, pool, seed=case)
+        assert eng.last_rollout_kernel() == 'resident', (env, K, B, T, H, mode)
+        gen = eng.rollout(B, T, H, mode, pool, seed=case, force_generic=True)
+        msg = str((env, K, B, T, H, mode))
+        np.testing.assert_array_equal(cpu(res.obs[0]), cpu(gen.obs[0]), err_msg=msg)
+        if env != 'ant':                                                    # Ant's dones depend on the state: compare them where the states still agree
+            assert torch.equal(res.done, gen.done) and torch.equal(res.tpath, gen.tpath), msg
+        tcmp = min(T, 4)
+        same = np.ones(B, bool)
+        for t in range(1, tcmp):
+            same &= (cpu(res.done[t - 1]) == cpu(gen.done[t - 1]))
+            np.testing.assert_allclose(cpu(res.obs[t])[same], cpu(gen.obs[t])[same], rtol=5e-3, atol=5e-3, err_msg=msg + ' step %d' % t)
+        np.testing.assert_allclose(cpu(res.act[:1]), cpu(gen.act[:1]), rtol=1e-4, atol=1e-5, err_msg=msg)
+        del eng
+
+
 def test_resident_deterministic_policy_and_repeatability():
     """determ=True follows the policy mean (no noise draws); two launches with the same seed are bit-identical at the params-file size (600 steps:
     the packets of the second launch carry later stamps on the same slots), a different seed is a different trajectory."""
