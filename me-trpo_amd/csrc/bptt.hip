@@ -126,7 +126,7 @@ __global__ void k_bptt_forward(ProblemDesc pd, const float* __restrict__ dynp, c
         for (int i = 0; i < ns; ++i) e.S[i * LD + tid] = e.XN[i * LD + tid];
     }
     const double tot = block_sum(acc, red);
-    if (tid == 0) atomicAdd(&costs[model], tot / (double)B);
+    if (tid == 0) costs[(size_t)model * gridDim.x + blockIdx.x] = tot / (double)B;      // one partial per block; added in block order by k_det_cost_reduce
 }
 
 // GM [K][T+1][B][na]: adjoint of the (pre-clip) policy mean for every sample; slice t = T stays zero
@@ -291,9 +291,10 @@ int launch_bptt_grad(metrpo_ctx* c, const float* init, int B, int T, double gamm
         HIP_TRY(c, hipFuncSetAttribute((const void*)k_bptt_forward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         HIP_TRY(c, hipFuncSetAttribute((const void*)k_bptt_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     }
-    HIP_TRY(c, hipMemsetAsync(cst, 0, sizeof(double) * K, st));
     const dim3 grid((B + bs - 1) / bs, K);
-    hipLaunchKernelGGL(k_bptt_forward, grid, dim3(bs), sh, st, pd, c->d_dyn, c->d_theta, c->d_norm, init, B, T, gamma, XS, WT, cst);
+    { const int rcp = ensure_detpart_n(c, (size_t)K * grid.x); if (rcp) return rcp; }
+    hipLaunchKernelGGL(k_bptt_forward, grid, dim3(bs), sh, st, pd, c->d_dyn, c->d_theta, c->d_norm, init, B, T, gamma, XS, WT, c->d_detpart);
+    { const int rcp = launch_det_cost_reduce(c, (int)grid.x, c->d_detpart, cst, st); if (rcp) return rcp; }
     hipLaunchKernelGGL(k_bptt_backward, grid, dim3(bs), sh, st, pd, c->d_dyn, c->d_theta, c->d_norm, B, T, XS, WT, GM);
     HIP_TRY(c, hipGetLastError());
     // policy-parameter gradient: sum over the K (T+1) B samples of J(x)^T gm  (gradient kernels of the TRPO update, mean-adjoint supplied)
@@ -330,8 +331,9 @@ int launch_policy_adam(metrpo_ctx* c, const double* grad, double lr, double b1, 
     return METRPO_OK;
 }
 
-int ensure_detpart(metrpo_ctx* c, int B) {
-    const size_t need = sizeof(double) * (size_t)c->pd.K * (size_t)(4 * ((B + 63) / 64));
+int ensure_detpart(metrpo_ctx* c, int B) { return ensure_detpart_n(c, (size_t)c->pd.K * (size_t)(4 * ((B + 63) / 64))); }
+int ensure_detpart_n(metrpo_ctx* c, size_t n_doubles) {
+    const size_t need = sizeof(double) * n_doubles;
     if (need > c->detpart_cap) {
         if (c->d_detpart) HIP_TRY(c, hipFree(c->d_detpart));
         c->d_detpart = nullptr; c->detpart_cap = 0;

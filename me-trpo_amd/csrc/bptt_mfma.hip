@@ -386,6 +386,13 @@ __global__ void k_det_cost_reduce(int n_part, const double* __restrict__ part, d
     }
 }
 
+// costs[k] = the n_part partials of model k added in index order (also the generic forward kernels' block sums: rollout_generic.hip, bptt.hip)
+int launch_det_cost_reduce(metrpo_ctx* c, int n_part, const double* part, double* costs, hipStream_t st) {
+    hipLaunchKernelGGL(k_det_cost_reduce, dim3(c->pd.K), dim3(64), 0, st, n_part, part, costs);
+    HIP_TRY(c, hipGetLastError());
+    return METRPO_OK;
+}
+
 // -------------------------------------------------------------------------------------------------
 typedef void (*det_kernel_t)(int, int, int, double, const float*, const float*, const float*, const float*, float*, float*, float*, double*);
 struct DetEntry { int env; det_kernel_t fwd, bwd; int lds_floats; };

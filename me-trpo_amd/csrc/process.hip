@@ -203,11 +203,11 @@ __global__ void k_center(float* __restrict__ adv, const uint8_t* __restrict__ va
 }
 
 // Gram matrix: block stages a tile of GS samples' feature rows (double) in LDS, then every thread owns
-// a strided subset of the F*F (+F) outputs and walks the tile.  Per-block results -> double atomics.
+// a strided subset of the F*F (+F) outputs and walks the tile.  Per-block results -> one partial matrix per block (part [gridDim.x][F*F+F]),
+// added in block order by k_gram_final like the MFMA kernels' partials (float64 atomics would add them in arrival order).
 #define GRAM_TILE 64
 __global__ void k_gram(const float* __restrict__ obs, const float* __restrict__ ret, const int32_t* __restrict__ tpath,
-                       const uint8_t* __restrict__ valid, int64_t N, int ns, double* __restrict__ AtA,
-                       double* __restrict__ Aty) {
+                       const uint8_t* __restrict__ valid, int64_t N, int ns, double* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) double feat[];     // [GRAM_TILE][F+1]  (last col = return)
     const int F = 2 * ns + 4, LDF = F + 1;
     const int nout = F * F + F;
@@ -248,10 +248,7 @@ __global__ void k_gram(const float* __restrict__ obs, const float* __restrict__ 
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int p = p0 + u * blockDim.x + threadIdx.x;
-            if (p < nout) {
-                if (p < F * F) atomicAdd(&AtA[p], acc[u]);
-                else atomicAdd(&Aty[p - F * F], acc[u]);
-            }
+            if (p < nout) part[(size_t)blockIdx.x * nout + p] = acc[u];
         }
     }
 }
@@ -725,7 +722,17 @@ int launch_gram(metrpo_ctx* c, const float* obs, const float* ret, const int32_t
     const int bs = 256;
     const size_t sh = sizeof(double) * GRAM_TILE * (F + 1);
     const int grid = (int)std::min<int64_t>((N + GRAM_TILE - 1) / GRAM_TILE, (int64_t)c->n_sm * 4);
-    hipLaunchKernelGGL(k_gram, dim3(grid), dim3(bs), sh, st, obs, ret, tpath, valid, N, c->pd.ns, AtA, Aty);
+    const int nout = F * F + F;
+    const size_t need = (size_t)grid * nout;
+    if (need > c->gram_cap) {
+        if (c->d_gram_part) HIP_TRY(c, hipFree(c->d_gram_part));
+        c->d_gram_part = nullptr; c->gram_cap = 0;
+        HIP_TRY(c, hipMalloc(&c->d_gram_part, sizeof(double) * need));
+        c->gram_cap = need;
+    }
+    if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_gram, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    hipLaunchKernelGGL(k_gram, dim3(grid), dim3(bs), sh, st, obs, ret, tpath, valid, N, c->pd.ns, c->d_gram_part);
+    hipLaunchKernelGGL(k_gram_final, dim3((nout + 15) / 16), dim3(1024), 0, st, c->d_gram_part, grid, 0, F, AtA, Aty);
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;
 }

@@ -280,7 +280,7 @@ __global__ void k_validation(ProblemDesc pd, const float* __restrict__ dynp, con
         for (int i = 0; i < ns; ++i) e.S[i * LD + tid] = e.NEXT[i * LD + tid];
     }
     const double tot = block_sum(acc, red);
-    if (tid == 0) atomicAdd(&costs[model], tot / (double)Bv);
+    if (tid == 0) costs[(size_t)model * gridDim.x + blockIdx.x] = tot / (double)Bv;     // one partial per block; added in block order by k_det_cost_reduce
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -355,9 +355,9 @@ int launch_validation_cost(metrpo_ctx* c, const float* s0, int Bv, int T, double
     int rc = pick_block(c, envbufs_floats(pd, METRPO_SAM_EPS_RAND, 1), Bv, &bs, &sh);
     if (rc) return rc;
     if ((rc = allow_lds(c, k_validation, sh))) return rc;
-    HIP_TRY(c, hipMemsetAsync(costs, 0, sizeof(double) * pd.K, st));
-    hipLaunchKernelGGL(k_validation, dim3((Bv + bs - 1) / bs, pd.K), dim3(bs), sh, st, pd, c->d_dyn, c->d_theta,
-                       c->d_norm, s0, Bv, T, gamma, costs);
-    HIP_TRY(c, hipGetLastError());
-    return METRPO_OK;
+    const int gx = (Bv + bs - 1) / bs;
+    if ((rc = ensure_detpart_n(c, (size_t)pd.K * gx))) return rc;
+    hipLaunchKernelGGL(k_validation, dim3(gx, pd.K), dim3(bs), sh, st, pd, c->d_dyn, c->d_theta,
+                       c->d_norm, s0, Bv, T, gamma, c->d_detpart);
+    return launch_det_cost_reduce(c, gx, c->d_detpart, costs, st);
 }
