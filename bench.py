@@ -239,9 +239,9 @@ def main():
         "ms_per_step": ms_per_step, "ms_per_step_median": comm.max_float(float(np.median(iter_ms)), device=side), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s rollout+GAE+TRPO: env=%s K=%d dyn=%s policy=%s B=%d/GPU (config B=%d on %d GPUs) H=%d sam_mode=step_rand "
-                               "all-K-heads-evaluated max_kl=0.01 cg_iters=10; env steps per rollout %.1f; defer_baseline_fit=1 (the host solve of the baseline's "
-                               "normal equations overlaps the next rollout and lands before the next process_samples) reuse_trajectory_buffers=1 (one set of "
-                               "[T,B,.] tensors overwritten every iteration) device_baseline_fit=%d (the fit's normal equations are solved by a kernel, float64) async_line_search=%d (the accept test of the first two line-search trials runs on "
+                               "all-K-heads-evaluated max_kl=0.01 cg_iters=10; env steps per rollout %.1f; reuse_trajectory_buffers=1 (one set of "
+                               "[T,B,.] tensors overwritten every iteration) device_baseline_fit=%d (1: the fit's normal equations are solved by a kernel, float64, coefficients stay on the device; "
+                               "0: host lstsq deferred behind the next rollout, defer_baseline_fit) async_line_search=%d (the accept test of the first two line-search trials runs on "
                                "the device and the host closes the update after it has enqueued the next rollout: same trials, same rule, same results)"
                                % (args.config, env, K, list(cfg['dyn_hidden']), list(cfg['pol_hidden']), B, cfg['B'], cfg['gpus'], H, T_mean, int(bool(algo.device_baseline_fit)), int(bool(algo.async_line_search))),
                    "parallelism": "B-sharded x%d, sum all-reduce of g/FVP/scalars" % comm.world},
