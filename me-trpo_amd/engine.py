@@ -188,11 +188,13 @@ class Engine(object):
         self.set_dynamics(torch.cat([p.to(torch.float32) for p in parts], dim=1), in_mean, in_std, diff_mean, diff_std)
 
     def set_policy(self, theta):
+        self._close_open_update()
         t = _f32(theta, self.device, (self.P,))
         self._chk(lib.metrpo_set_policy(self._ctx, _ptr(t), self._stream()))
         torch.cuda.current_stream(self.device).synchronize()
 
     def get_policy(self):
+        self._close_open_update()
         out = torch.empty(self.P, dtype=torch.float32, device=self.device)
         self._chk(lib.metrpo_get_policy(self._ctx, _ptr(out), self._stream()))
         return out
@@ -440,6 +442,13 @@ class Engine(object):
         """Second half of trpo_update(..., spec_trials=S): waits for the update (not for launches enqueued after it) and returns its
         diagnostics; 'late' is True when the policy changed inside this call (accepted at a trial >= S): work enqueued since the first
         half saw the previous policy and must be redone."""
+        if getattr(self, '_upd_open', None) is None:
+            # already closed -- by get_policy() / set_policy(), which must not see or overwrite a policy whose search is still open
+            closed = getattr(self, '_upd_closed', None)
+            if closed is None:
+                raise RuntimeError('trpo_update_end: no update is open')
+            self._upd_closed = None
+            return closed
         batch, p, g, d, spec = self._upd_open
         diag = _lib.TrpoDiag()
         late = C.c_int32(0)
@@ -453,6 +462,11 @@ class Engine(object):
         if g is not None:
             out['g'], out['d'] = g, d
         return out
+
+    def _close_open_update(self):
+        """Reading or replacing the policy while an update is only enqueued: close it first (its diagnostics wait for the optimizer's finish())."""
+        if getattr(self, '_upd_open', None) is not None:
+            self._upd_closed = self.trpo_update_end()
 
 
     # ------------------------------------------------------------------ ensemble dynamics training (SURVEY 8f rank 1-2)

@@ -747,11 +747,18 @@ def test_deferred_optimizer_closes_after_the_next_rollout():
             samples = algo.process_samples(j, paths)
             algo.optimize_policy(j, samples)
         assert algo.optimizer.pending == mode
-        if mode:                                                 # an open update owns theta: set_policy is refused until it is closed
-            with pytest.raises(Exception, match='still open'):
-                eng.set_policy(theta)
+        if mode:                                                 # an open update owns theta: the C entry point refuses to replace it ...
+            import ctypes
+            from metrpo_amd import _lib as L
+            tdev = torch.as_tensor(theta, dtype=torch.float32, device='cuda')
+            rc = L.lib.metrpo_set_policy(eng._ctx, ctypes.c_void_p(tdev.data_ptr()), eng._stream())
+            assert rc != 0 and 'still open' in L.lib.metrpo_last_error(eng._ctx).decode()
+            th_now = eng.get_policy()                            # ... and the host class closes the update before it reads (or replaces) the policy
+            assert getattr(eng, '_upd_open', None) is None
         d = algo.optimizer.last_diag
         assert not algo.optimizer.pending and d['accepted']
+        if mode:
+            assert torch.equal(th_now, eng.get_policy())
         outs.append((eng.get_policy().clone(), acts))
     assert torch.equal(outs[0][0], outs[1][0])
     for a, b in zip(outs[0][1], outs[1][1]):
