@@ -5,7 +5,7 @@ One "step" = one iteration of the reference's TRPO loop body (model_based_rl.py:
     algo.start_worker(); paths = algo.obtain_samples(j); samples = algo.process_samples(j, paths)
     algo.optimize_policy(j, samples)
 Default workload = C1, the configuration BASELINE.json quotes the metric on (Swimmer, K=5 models 2x64, policy 2x32,
-B=5000 imagined envs, H=100, step_rand, TRPO max-KL 0.01), synthetic weights / initial states.  `--config C2|C2s|C3|C4|C0|C0p|C0hc|C0ho|C0sn|C0an`
+B=5000 imagined envs, H=100, step_rand, TRPO max-KL 0.01), synthetic weights / initial states.  `--config C2|C2s|C3|C4|C0|C0p|C0hc|C0ho|C0sn|C0an|C0hu`
 runs the other BASELINE configs at their per-GPU share (B / gpus the config is quoted on; me-trpo_amd/synthetic.py).
 `value` = K*B*steps*n_gpus imagined env-steps per second over the WHOLE iteration (rollout + GAE/baseline + TRPO update),
 all K heads evaluated per env-step as the reference does (env_helpers.py:612).  B is per GPU (weak scaling); the only

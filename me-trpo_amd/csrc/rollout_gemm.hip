@@ -392,9 +392,12 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
     const bool fuse_out = fuse_tile > 0;
     if (fuse_out) nP = std::max(nP, up4(gemm_fused_out_part_floats(B, pd.dyn.dims[L - 1], K, pd.ns, fuse_tile)));
     const big_pre_mfma_t pre_mfma = big_pre_mfma_select(pd);
-    // policies without an MFMA pre-kernel: GEMM chain over the batch from B = 1024 up (METRPO_PRE_GEMM=1 forces it, =0 forbids it: tests)
+    // policies without an MFMA pre-kernel: GEMM chain over the batch from B = 1024 up -- and at ANY batch when the policy is large
+    // (k_big_pre walks the weights through scalar loads, one block's time whatever B: 302 us per step for Humanoid's 100-50-25 at B = 100,
+    // the params-humanoid.json shape, against ~40 us for the six small launches of the chain: iteration 77 -> 28 ms)
+    // (METRPO_PRE_GEMM=1 forces it, =0 forbids it: tests)
     const char* pg_env = getenv("METRPO_PRE_GEMM");
-    const bool pre_gemm = !pre_mfma && ((pg_env && pg_env[0] == '1') || (!(pg_env && pg_env[0] == '0') && B >= 1024));
+    const bool pre_gemm = !pre_mfma && ((pg_env && pg_env[0] == '1') || (!(pg_env && pg_env[0] == '0') && (B >= 1024 || pd.pol.n_params >= 4096)));
     const size_t nPol = pre_gemm ? up4((size_t)B * pd.pol.max_width) : 0;
     const size_t need = ((nS + nX + nU + 2 * nH + nO + nP + 2 * nPol) * sizeof(float) + 2 * (size_t)B * sizeof(int) + 511) & ~(size_t)255;
     if (need_out) *need_out = need;

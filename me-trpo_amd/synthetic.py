@@ -17,6 +17,7 @@ CONFIGS = {
     'C0ho': dict(env='hopper', K=5, dyn_hidden=(1024, 1024), pol_hidden=(32, 32), B=100, H=100, gpus=1, batch_size=50000),          # params-hopper.json
     'C0sn': dict(env='snake', K=5, dyn_hidden=(1024, 1024), pol_hidden=(32, 32), B=100, H=200, gpus=1, batch_size=50000),           # params-snake.json
     'C0an': dict(env='ant', K=5, dyn_hidden=(1024, 1024), pol_hidden=(32, 32), B=100, H=100, gpus=1, batch_size=50000),            # params-ant.json (early termination: step-granular stop rule)
+    'C0hu': dict(env='humanoid', K=5, dyn_hidden=(1024, 1024), pol_hidden=(100, 50, 25), B=100, H=100, gpus=1, batch_size=50000),  # params-humanoid.json
     'C1': dict(env='swimmer', K=5, dyn_hidden=(64, 64), pol_hidden=(32, 32), B=5000, H=100, gpus=1),
     'C2': dict(env='half_cheetah', K=5, dyn_hidden=(1024, 1024), pol_hidden=(32, 32), B=10000, H=200, gpus=4),  # params-half-cheetah.json nets
     'C2s': dict(env='half_cheetah', K=5, dyn_hidden=(64, 64), pol_hidden=(32, 32), B=10000, H=200, gpus=4),     # BASELINE leaves the MLP open: 2x64 variant
