@@ -119,7 +119,15 @@ struct RolloutK {          // device-side copy of metrpo_rollout_args (plain poi
     int32_t* last_ts; int32_t* last_model; const int32_t* stop;
     // tile migration of the cooperative kernel (rollout_coop.hip; ctx-owned hand-over slots, NULL elsewhere)
     int32_t* mig_flag; float* mig_obs; int32_t* mig_ts; int32_t* mig_model; int mig_epoch; double* mig_err;
+    // merged rounds of the step-wise path (rollout_gemm.hip): vB > 0 -> the B rows of this launch are vR rounds of vB envs, row b = env b % vB of round
+    // b / vB, whose steps are the rows t + (b / vB) * H of the trajectory tensors (vB envs per row) and of the draw counters
+    int vB, vR;
 };
+// env index within its round (Philox stream, column of the trajectory row) | first step of the env's round | envs per trajectory row
+#define RK_ENV(r, b) ((r).vB ? (b) % (r).vB : (b))
+#define RK_TOFF(r, b) ((r).vB ? ((b) / (r).vB) * (r).H : 0)
+#define RK_STRIDE(r) ((r).vB ? (r).vB : (r).B)
+#define RK_LAST_ROUND(r, b) (!(r).vB || (b) / (r).vB == (r).vR - 1)
 
 static inline RolloutK make_rollout_k(const metrpo_rollout_args* a) {
     RolloutK r;
@@ -131,6 +139,7 @@ static inline RolloutK make_rollout_k(const metrpo_rollout_args* a) {
     r.t0 = a->t0; r.init_obs = a->d_init_obs; r.init_ts = a->d_init_ts; r.init_model = a->d_init_model;
     r.last_ts = a->d_last_ts; r.last_model = a->d_last_model; r.stop = a->d_stop;
     r.mig_flag = nullptr; r.mig_obs = nullptr; r.mig_ts = nullptr; r.mig_model = nullptr; r.mig_epoch = 0; r.mig_err = nullptr;
+    r.vB = 0; r.vR = 0;
     return r;
 }
 

@@ -29,7 +29,8 @@ __global__ void k_big_pre(ProblemDesc pd, RolloutK r, int t, const float* __rest
     const bool active = b < r.B;
     const int ns = pd.ns, na = pd.na;
     float* Sc = lds; float* A = Sc + ns * LD; float* Bq = A + pd.pol.max_width * LD;
-    const uint64_t genv = r.stream_offset + (uint64_t)b;
+    const uint64_t genv = r.stream_offset + (uint64_t)RK_ENV(r, b);
+    const int tt = t + RK_TOFF(r, b);                            // row of the trajectory tensors / draw counter of this env's step
     if (r.stop != nullptr && *r.stop != 0) return;               // the sampling loop already ended (metrpo_sampler_progress)
     if (grp == 0) {
     if (t == 0 && active && r.init_obs != nullptr) {             // continuation of a chunked rollout
@@ -47,10 +48,10 @@ __global__ void k_big_pre(ProblemDesc pd, RolloutK r, int t, const float* __rest
     __syncthreads();
     float* m = mlp_col_groups(pd.pol, theta, Sc, A, Bq, LD, tid, grp, G);
     if (!active || grp != 0) return;
-    const size_t tb = (size_t)t * r.B + b;
+    const size_t tb = (size_t)tt * RK_STRIDE(r) + RK_ENV(r, b);
     const float* __restrict__ log_std = theta + pd.pol.n_params;
     const float* in_mean = norm; const float* in_std = norm + (ns + na);
-    const uint4 dstep = rng_draw(r.seed, genv, r.t0 + t, RNG_STEP, 0);
+    const uint4 dstep = rng_draw(r.seed, genv, r.t0 + tt, RNG_STEP, 0);
     for (int i = 0; i < ns; ++i) {
         const float s = Sc[i * LD + tid];
         r.obs[tb * ns + i] = s;
@@ -60,7 +61,7 @@ __global__ void k_big_pre(ProblemDesc pd, RolloutK r, int t, const float* __rest
     for (int d0 = 0; d0 < na; d0 += 2) {
         float z[2] = {0.f, 0.f};
         if (!r.determ && r.eps == nullptr) {
-            const uint4 blk = (d0 == 0) ? dstep : rng_draw(r.seed, genv, r.t0 + t, RNG_STEP, d0 >> 1);
+            const uint4 blk = (d0 == 0) ? dstep : rng_draw(r.seed, genv, r.t0 + tt, RNG_STEP, d0 >> 1);
             normal2(blk.x, blk.y, z[0], z[1]);
         }
         for (int d = d0; d < min(d0 + 2, na); ++d) {
@@ -110,7 +111,8 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
 #pragma unroll
         for (int it = 0; it < NIT; ++it) { const int i = tid + 256 * it; if (i < IMG) lds[i] = wv[it]; }
     }
-    const uint64_t genv = r.stream_offset + (uint64_t)b;
+    const uint64_t genv = r.stream_offset + (uint64_t)RK_ENV(r, b);
+    const int tt = t + RK_TOFF(r, b);                            // row of the trajectory tensors / draw counter of this env's step
     if (t == 0 && active && q == 0 && r.init_obs != nullptr) {   // continuation of a chunked rollout
         st.cur_model[b] = r.init_model[b]; st.ts[b] = r.init_ts[b];
         for (int i = 0; i < NS; ++i) st.S[(size_t)b * NS + i] = r.init_obs[(size_t)b * NS + i];
@@ -125,7 +127,13 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
     const int lim = min(16, max(0, r.B - b0)) * NS;
     for (int i = lane; i < 16 * NS; i += 64) ST[i] = (i < lim) ? st.S[(size_t)b0 * NS + i] : 0.0f;
     wave_lds_sync();
-    if (lim > 0) { const size_t base = ((size_t)t * r.B + b0) * NS; for (int i = lane; i < lim; i += 64) r.obs[base + i] = ST[i]; }
+    if (lim > 0) {
+        if (r.vB == 0) { const size_t base = ((size_t)t * r.B + b0) * NS; for (int i = lane; i < lim; i += 64) r.obs[base + i] = ST[i]; }
+        else for (int i = lane; i < lim; i += 64) {              // merged rounds: a tile's envs may belong to two rounds
+            const int bi = b0 + i / NS;
+            r.obs[((size_t)(t + RK_TOFF(r, bi)) * r.vB + RK_ENV(r, bi)) * NS + i % NS] = ST[i];
+        }
+    }
     f32x4 p0[2], p1[2];
     p0[0] = *(const f32x4*)&lds[O_B0 + 4 * q]; p0[1] = *(const f32x4*)&lds[O_B0 + 16 + 4 * q];
 #pragma unroll
@@ -157,7 +165,7 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
     }
     const f32x4 mu = m0 + m1;
     if (!active) return;
-    const size_t tb = (size_t)t * r.B + b;
+    const size_t tb = (size_t)tt * RK_STRIDE(r) + RK_ENV(r, b);
     const float* in_mean = norm; const float* in_std = norm + (NS + NA);
     const float* __restrict__ log_std = theta + C::pLS;
     // state part of the normalised, dropped input: lane (c, q) writes its dims 4q .. (every 16th column block)
@@ -170,7 +178,7 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
         if (d0 >= NA) continue;
         float z[2] = {0.f, 0.f};
         if (!r.determ && r.eps == nullptr) {
-            const uint4 blk = rng_draw(r.seed, genv, r.t0 + t, RNG_STEP, d0 >> 1);
+            const uint4 blk = rng_draw(r.seed, genv, r.t0 + tt, RNG_STEP, d0 >> 1);
             normal2(blk.x, blk.y, z[0], z[1]);
         }
 #pragma unroll
@@ -203,14 +211,14 @@ __global__ void __launch_bounds__(256) k_big_pre_gather(ProblemDesc pd, RolloutK
             s = r.init_obs[(size_t)b * ns + i];
             if (i == 0) { st.cur_model[b] = r.init_model[b]; st.ts[b] = r.init_ts[b]; }
         } else {                                                  // env_helpers.py:585-595
-            const uint4 d0 = rng_draw(r.seed, r.stream_offset + (uint64_t)b, 0, RNG_RESET, 0);
+            const uint4 d0 = rng_draw(r.seed, r.stream_offset + (uint64_t)RK_ENV(r, b), 0, RNG_RESET, 0);
             const int row = (r.reset_idx != nullptr) ? r.reset_idx[b] : rng_index(d0.x, r.n_pool);
             s = r.pool[(size_t)row * ns + i];
             if (i == 0) { st.cur_model[b] = (r.reset_model != nullptr) ? r.reset_model[b] : rng_index(d0.y, pd.K); st.ts[b] = 0; }
         }
         st.S[(size_t)b * ns + i] = s;
     } else s = st.S[(size_t)b * ns + i];
-    r.obs[((size_t)t * r.B + b) * ns + i] = s;
+    r.obs[((size_t)(t + RK_TOFF(r, b)) * RK_STRIDE(r) + RK_ENV(r, b)) * ns + i] = s;
     const float* in_mean = norm; const float* in_std = norm + (ns + na);
     if (i >= pd.n_drop) st.X[(size_t)b * st.ldx + i - pd.n_drop] = (s - in_mean[i]) / in_std[i];       // training.py:228,146-151
     if (i == 0) for (int j = pd.nin; j < st.ldx; ++j) st.X[(size_t)b * st.ldx + j] = 0.0f;              // pad columns of the 16-byte aligned rows
@@ -222,12 +230,13 @@ __global__ void __launch_bounds__(256) k_big_pre_action(ProblemDesc pd, RolloutK
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)r.B * npair || (r.stop != nullptr && *r.stop != 0)) return;
     const int b = (int)(idx / npair), d0 = 2 * (int)(idx % npair);
-    const size_t tb = (size_t)t * r.B + b;
+    const int tt = t + RK_TOFF(r, b);
+    const size_t tb = (size_t)tt * RK_STRIDE(r) + RK_ENV(r, b);
     const float* __restrict__ log_std = theta + pd.pol.n_params;
     const float* in_mean = norm; const float* in_std = norm + (ns + na);
     float z[2] = {0.f, 0.f};
     if (!r.determ && r.eps == nullptr) {
-        const uint4 blk = rng_draw(r.seed, r.stream_offset + (uint64_t)b, r.t0 + t, RNG_STEP, d0 >> 1);
+        const uint4 blk = rng_draw(r.seed, r.stream_offset + (uint64_t)RK_ENV(r, b), r.t0 + tt, RNG_STEP, d0 >> 1);
         normal2(blk.x, blk.y, z[0], z[1]);
     }
     for (int d = d0; d < min(d0 + 2, na); ++d) {
@@ -266,10 +275,11 @@ __global__ void __launch_bounds__(256) k_big_post(ProblemDesc pd, RolloutK r, in
     const int ns = pd.ns, na = pd.na, K = pd.K;
     const bool env_ok = b < r.B, on = env_ok && i < ns;
     const int bc = env_ok ? b : 0, ic = (i < ns) ? i : 0;
-    const size_t tb = (size_t)t * r.B + bc;
-    const uint64_t genv = r.stream_offset + (uint64_t)bc;
+    const int tt = t + RK_TOFF(r, bc);                           // row of the trajectory tensors / draw counter of this env's step
+    const size_t tb = (size_t)tt * RK_STRIDE(r) + RK_ENV(r, bc);
+    const uint64_t genv = r.stream_offset + (uint64_t)RK_ENV(r, bc);
     const float* diff_mean = norm + 2 * (ns + na); const float* diff_std = diff_mean + ns;
-    const uint4 dstep = rng_draw(r.seed, genv, r.t0 + t, RNG_STEP, 0);
+    const uint4 dstep = rng_draw(r.seed, genv, r.t0 + tt, RNG_STEP, 0);
     int sel = st.cur_model[bc];
     if (r.sam_mode == METRPO_SAM_STEP_RAND) sel = (r.model_idx != nullptr) ? r.model_idx[tb] : rng_index(dstep.z, K);
     if (r.sam_mode == METRPO_SAM_ONE_MODEL) sel = 0;
@@ -301,7 +311,7 @@ __global__ void __launch_bounds__(256) k_big_post(ProblemDesc pd, RolloutK r, in
             float z4[4];
             float nz;
             if (r.sel_noise != nullptr) nz = r.sel_noise[tb * ns + ic];
-            else { normal4(rng_draw(r.seed, genv, r.t0 + t, RNG_SELNOISE, ic >> 2), z4); nz = z4[ic & 3]; }
+            else { normal4(rng_draw(r.seed, genv, r.t0 + tt, RNG_SELNOISE, ic >> 2), z4); nz = z4[ic & 3]; }
             v = fmaf(nz, sqrtf(var / (float)K), m);
         } else if (r.sam_mode == METRPO_SAM_MODEL_MED) {
             const int r_lo = (K - 1) / 2, r_hi = K / 2;
@@ -350,9 +360,10 @@ __global__ void __launch_bounds__(256) k_big_post(ProblemDesc pd, RolloutK r, in
     }
     if (on) S[i] = s_new;
     if (env_ok && i == 0) { st.ts[b] = ts; if (dn) st.cur_model[b] = cur; }
-    if (t == r.T - 1) {
-        if (on && r.last_obs != nullptr) r.last_obs[(size_t)b * ns + i] = s_new;
-        if (env_ok && i == 0) { if (r.last_ts != nullptr) r.last_ts[b] = ts; if (r.last_model != nullptr) r.last_model[b] = cur; }
+    if (t == r.T - 1 && RK_LAST_ROUND(r, bc)) {
+        const int be = RK_ENV(r, bc);
+        if (on && r.last_obs != nullptr) r.last_obs[(size_t)be * ns + i] = s_new;
+        if (env_ok && i == 0) { if (r.last_ts != nullptr) r.last_ts[be] = ts; if (r.last_model != nullptr) r.last_model[be] = cur; }
     }
 }
 
@@ -375,7 +386,7 @@ bool gemm_path_applicable(const metrpo_ctx* c) {
 }
 
 // One chunk of the step loop on stream `st`.  ws == nullptr: only report the workspace size (bytes, 256-aligned) through *need_out.
-static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t st, char* ws, size_t* need_out) {
+static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t st, char* ws, size_t* need_out, int vB = 0, int vR = 0) {
     const ProblemDesc& pd = c->pd;
     const int B = a->B, K = pd.K, L = pd.dyn.n_layers;
     int maxh = 0;
@@ -408,6 +419,7 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
     bs.ts = (int*)p; bs.cur_model = bs.ts + B;
     bs.ldx = (pd.nin + 3) & ~3;
     RolloutK r = make_rollout_k(a);
+    r.vB = vB; r.vR = vR;                                    // merged rounds: a->B = vR * vB rows, a->T = H steps (launch_rollout_gemm)
     const int pbs = 256;                                     // 64 envs x 4 output groups
     const size_t psh = (size_t)(pd.ns + 2 * pd.pol.max_width) * 64 * sizeof(float);
     if (psh > 160 * 1024) return set_err(c, METRPO_EUNSUPPORTED, "policy too wide for k_big_pre");
@@ -473,6 +485,26 @@ __global__ void k_round_init(ProblemDesc pd, RolloutK r, int R, float* __restric
     if (i == 0) { init_ts[o] = 0; init_model[o] = rng_index16(dstep.z, pd.K); }
 }
 
+// Merged rounds: the start states of ALL R rounds, [R][B] -- round 0 from the reset draw of vec_env.reset() (env_helpers.py:585-595, as the
+// pre-kernels' own t = 0 branch), rounds 1 .. R-1 as k_round_init.
+__global__ void k_round_init_all(ProblemDesc pd, RolloutK r, int R, int Bv, float* __restrict__ init_obs, int32_t* __restrict__ init_ts, int32_t* __restrict__ init_model) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ns = pd.ns;
+    if (idx >= (long long)R * Bv * ns) return;
+    const int i = (int)(idx % ns), b = (int)((idx / ns) % Bv), round = (int)(idx / ((long long)ns * Bv));
+    int row, model;
+    if (round == 0) {
+        const uint4 d0 = rng_draw(r.seed, r.stream_offset + (uint64_t)b, 0, RNG_RESET, 0);
+        row = rng_index(d0.x, r.n_pool); model = rng_index(d0.y, pd.K);
+    } else {
+        const uint4 dstep = rng_draw(r.seed, r.stream_offset + (uint64_t)b, r.t0 + round * r.H - 1, RNG_STEP, 0);
+        row = rng_index(dstep.w, r.n_pool); model = rng_index16(dstep.z, pd.K);
+    }
+    const size_t o = (size_t)round * Bv + b;
+    init_obs[o * ns + i] = r.pool[(size_t)row * ns + i];
+    if (i == 0) { init_ts[o] = 0; init_model[o] = model; }
+}
+
 // Step-wise rollout of a large dynamics ensemble.  The R = T / H rounds of a horizon-terminated rollout that starts from a reset are
 // independent given the counter-based draws (every env is reset at the same steps, and its reset state is a function of that step's
 // draw alone), and at the reference's own batch size (B = 100: params-*.json) a round is a chain of ~3 us launches that leaves most of the
@@ -485,20 +517,39 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
     const bool par = R >= 2 && R <= METRPO_MAX_PAR_ROUNDS && pd.env != METRPO_ENV_ANT && (long long)pd.K * B <= 8192 &&
                      a->t0 == 0 && a->d_init_obs == nullptr && a->d_stop == nullptr && a->d_eps == nullptr && a->d_model_idx == nullptr &&
                      a->d_sel_noise == nullptr && a->d_reset_idx == nullptr && a->d_reset_model == nullptr && getenv("METRPO_SEQ_ROUNDS") == nullptr;
+    // Small batches (R B <= 1024 rows): the rounds as ONE batch of R B envs stepping H times -- one launch chain instead of R concurrent ones, and
+    // GEMMs over R B rows instead of R GEMMs over B (B = 100 fills 100 of 128 tile rows, 500 fill 500 of 512; params-humanoid.json: 27.7 -> see DESIGN).
+    // Row b of the merged batch = env b % B of round b / B (RolloutK::vB / vR); same draws, same trajectory rows as the round-by-round loop.
+    const bool merged = par && (long long)R * B <= 1024 && getenv("METRPO_NO_MERGED_ROUNDS") == nullptr;
     size_t need1 = 0;
     {
         metrpo_rollout_args probe = *a;
         if (par) probe.T = H;
+        if (merged) probe.B = R * B;
         const int rc = rollout_gemm_chunk(c, &probe, st, nullptr, &need1);
         if (rc != METRPO_OK) return rc;
     }
-    const size_t init_bytes = par ? (((size_t)(R - 1) * B * (pd.ns * sizeof(float) + 2 * sizeof(int32_t)) + 255) & ~(size_t)255) : 0;
-    const size_t need = (par ? (size_t)R * need1 : need1) + init_bytes;
+    const size_t init_rows = merged ? (size_t)R * B : (par ? (size_t)(R - 1) * B : 0);
+    const size_t init_bytes = (init_rows * (pd.ns * sizeof(float) + 2 * sizeof(int32_t)) + 255) & ~(size_t)255;
+    const size_t need = ((par && !merged) ? (size_t)R * need1 : need1) + init_bytes;
     if (need > c->big_cap) {
         if (c->d_big) HIP_TRY(c, hipFree(c->d_big));
         c->d_big = nullptr; c->big_cap = 0;
         HIP_TRY(c, hipMalloc(&c->d_big, need));
         c->big_cap = need;
+    }
+    if (merged) {
+        char* base = (char*)c->d_big;
+        float* init_obs = (float*)(base + need1);
+        int32_t* init_ts = (int32_t*)(init_obs + (size_t)R * B * pd.ns);
+        int32_t* init_model = init_ts + (size_t)R * B;
+        const RolloutK rk = make_rollout_k(a);
+        const long long n_init = (long long)R * B * pd.ns;
+        hipLaunchKernelGGL(k_round_init_all, dim3((unsigned)((n_init + 255) / 256)), dim3(256), 0, st, pd, rk, R, B, init_obs, init_ts, init_model);
+        metrpo_rollout_args am = *a;
+        am.B = R * B; am.T = H;
+        am.d_init_obs = init_obs; am.d_init_ts = init_ts; am.d_init_model = init_model;
+        return rollout_gemm_chunk(c, &am, st, base, nullptr, B, R);
     }
     if (!par) return rollout_gemm_chunk(c, a, st, (char*)c->d_big, nullptr);
     if (!c->side_ready) {

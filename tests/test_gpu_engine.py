@@ -621,13 +621,19 @@ def test_gemm_rollout_random_shapes_vs_generic_kernel():
         np.testing.assert_allclose(cpu(got.rew), cpu(ref.rew), rtol=5e-3, atol=5e-3, err_msg=msg)
 
 
-@pytest.mark.parametrize('env,K,hidden,B,H,R,mode', [('swimmer', 5, (512, 512), 100, 6, 3, 'step_rand'), ('half_cheetah', 3, (256, 192), 77, 4, 5, 'eps_rand'),
-                                                      ('hopper', 2, (128, 128, 128), 50, 5, 2, 'model_mean_std'), ('swimmer', 5, (512, 512), 100, 3, 8, 'model_med')])
-def test_gemm_rollout_concurrent_rounds_equal_sequential_rounds(env, K, hidden, B, H, R, mode, monkeypatch):
-    """Small-batch rollouts of horizon-terminated envs run their T / H rounds concurrently (one stream per round, reset states of the later
-    rounds computed from the draws of the step before them, rollout_gemm.hip): bit for bit the sequential step loop, production draws."""
-    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, hidden, (32, 32), seed=77)
+@pytest.mark.parametrize('merged', [True, False])
+@pytest.mark.parametrize('env,K,hidden,B,H,R,mode,pol', [('swimmer', 5, (512, 512), 100, 6, 3, 'step_rand', (32, 32)), ('half_cheetah', 3, (256, 192), 77, 4, 5, 'eps_rand', (32, 32)),
+                                                          ('hopper', 2, (128, 128, 128), 50, 5, 2, 'model_mean_std', (32, 32)), ('swimmer', 5, (512, 512), 100, 3, 8, 'model_med', (32, 32)),
+                                                          ('humanoid', 3, (256, 256), 37, 4, 5, 'step_rand', (100, 50, 25)),     # wide policy: GEMM pre-step, tiles spanning two rounds
+                                                          ('snake', 2, (128, 128), 20, 3, 4, 'eps_rand', (24, 24))])           # thread-per-env pre-step
+def test_gemm_rollout_concurrent_rounds_equal_sequential_rounds(env, K, hidden, B, H, R, mode, pol, merged, monkeypatch):
+    """Small-batch rollouts of horizon-terminated envs run their T / H rounds side by side (reset states of the later rounds computed from the
+    draws of the step before them, rollout_gemm.hip): as ONE merged batch of R B envs stepping H times (R B <= 1024), or one stream per round
+    (METRPO_NO_MERGED_ROUNDS=1: what larger batches take) -- bit for bit the sequential step loop, production draws."""
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, hidden, pol, seed=77)
     assert eng.set_rollout_variant(1) == 3                          # 1: stay on the step-wise path where the resident kernel would take over (test_gpu_resident.py)
+    if not merged:
+        monkeypatch.setenv('METRPO_NO_MERGED_ROUNDS', '1')
     T = R * H
     par = eng.rollout(B, T, H, mode, pool, seed=5)
     assert eng.last_rollout_kernel() == 'gemm-stepwise'
