@@ -163,7 +163,18 @@ __global__ void __launch_bounds__(256) k_pg_assemble(int mode, PgLay g, int P, i
                                                      const double* __restrict__ hparts, const float* __restrict__ theta, const double* __restrict__ v,
                                                      double* __restrict__ out) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    auto head_sum = [&](int col) { double t = 0.0; for (int b = 0; b < nblk_head; ++b) t += hparts[(size_t)b * 40 + col]; return t; };
+    auto head_sum = [&](int col) {
+        double t = 0.0; int b = 0;
+        for (; b + 8 <= nblk_head; b += 8) {
+            double t8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t8[j] = hparts[(size_t)(b + j) * 40 + col];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t += t8[j];
+        }
+        for (; b < nblk_head; ++b) t += hparts[(size_t)b * 40 + col];
+        return t;
+    };
     if (mode == 2) { if (p < 2) out[p] = head_sum(p); return; }
     if (p == 0 && mode == 0) out[0] = head_sum(0);
     if (p >= P) return;
@@ -185,7 +196,15 @@ __global__ void __launch_bounds__(256) k_pg_assemble(int mode, PgLay g, int P, i
         if (p < g.b_off[l]) { const int q = p - g.w_off[l]; idx = (size_t)(q / dout) * pout + (q % dout); }
         else idx = (size_t)g.dp[l] * pout + (p - g.b_off[l]);                               // column sums follow the M x N partial
         const float* pl = part + g.oPart[l] + idx;
-        for (int s = 0; s < g.splits; ++s) val += (double)pl[(size_t)s * g.part_stride[l]];
+        int s = 0;
+        for (; s + 8 <= g.splits; s += 8) {                    // eight loads in flight, added in split order (one dependent load per split: 90 us at 190 splits)
+            float t8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t8[j] = pl[(size_t)(s + j) * g.part_stride[l]];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) val += (double)t8[j];
+        }
+        for (; s < g.splits; ++s) val += (double)pl[(size_t)s * g.part_stride[l]];
     }
     out[(mode == 0 ? 1 : 0) + p] = val;
 }
