@@ -17,7 +17,8 @@ struct BigState { float* S; int* ts; int* cur_model; float* X; float* U; float* 
                   int ldx;
                   // output layer left as split-K partials (gemm_skinny_bias with defer): k_big_post adds them and the bias
                   int out_splits; long long out_stride; const float* out_bias; long long out_bias_stride;
-                  float* PA; float* PB; };      // policy activations of the GEMM pre-path [B][max policy width]   // ldx: row stride of X = n_in rounded up to 4 floats, so every row is 16-byte aligned for the layer-0 GEMM's loads
+                  float* PA; float* PB;
+                  float* PIMG; };   // k_big_pre_mfma3: the policy's fragment image, built once per launch chain (k_pre_mfma3_image)      // policy activations of the GEMM pre-path [B][max policy width]   // ldx: row stride of X = n_in rounded up to 4 floats, so every row is 16-byte aligned for the layer-0 GEMM's loads
 
 // policy.get_actions + clip + normalise/drop for policies without an MFMA pre-kernel (Humanoid's 100-50-25): a block = 64 envs x G thread
 // groups; the outputs of every policy layer are split over the groups (activations in LDS columns), group 0 owns the env's bookkeeping
@@ -196,6 +197,160 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
     }
 }
 
+// fragment image of a three-hidden-layer tanh policy for k_big_pre_mfma3.  Layer l's k-step kk contracts, in lane (cc, qq), input unit
+// 16 (kk >> 2) + 4 qq + (kk & 3): the D-fragment order of the previous layer's output (register kk & 3 of tile kk >> 2), so nothing is transposed
+// between layers.  [layer-0 fragments | layer 1 | layer 2 | output layer | b0 | b1 | b2 | b3], widths padded to 16 with zeros.
+template <int NS, int NA, int W1, int W2, int W3>
+__global__ void k_pre_mfma3_image(const float* __restrict__ theta, float* __restrict__ img) {
+    constexpr int NS_KS = cdiv(NS, 4), C1 = cdiv(W1, 16), C2 = cdiv(W2, 16), C3 = cdiv(W3, 16), CO = cdiv(NA, 16);
+    constexpr int pW0 = 0, pb0 = NS * W1, pW1 = pb0 + W1, pb1 = pW1 + W1 * W2, pW2 = pb1 + W2, pb2 = pW2 + W2 * W3, pW3 = pb2 + W3, pb3 = pW3 + W3 * NA;
+    constexpr int O_F0 = 0, O_F1 = O_F0 + NS_KS * C1 * 64, O_F2 = O_F1 + 4 * C1 * C2 * 64, O_F3 = O_F2 + 4 * C2 * C3 * 64, O_B0 = O_F3 + 4 * C3 * CO * 64,
+                  O_B1 = O_B0 + 16 * C1, O_B2 = O_B1 + 16 * C2, O_B3 = O_B2 + 16 * C3, IMG = O_B3 + 16 * CO;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= IMG) return;
+    float w = 0.0f;
+    const int ln = i & 63, cc = ln & 15, qq = ln >> 4;
+    if (i < O_F1) { const int f = i >> 6, s_ = f / C1, cb = f % C1, in = 4 * s_ + qq, u = 16 * cb + cc; if (in < NS && u < W1) w = theta[pW0 + in * W1 + u]; }
+    else if (i < O_F2) { const int f = (i - O_F1) >> 6, kk = f / C2, cb = f % C2, in = 16 * (kk >> 2) + 4 * qq + (kk & 3), u = 16 * cb + cc; if (in < W1 && u < W2) w = theta[pW1 + in * W2 + u]; }
+    else if (i < O_F3) { const int f = (i - O_F2) >> 6, kk = f / C3, cb = f % C3, in = 16 * (kk >> 2) + 4 * qq + (kk & 3), u = 16 * cb + cc; if (in < W2 && u < W3) w = theta[pW2 + in * W3 + u]; }
+    else if (i < O_B0) { const int f = (i - O_F3) >> 6, kk = f / CO, cb = f % CO, in = 16 * (kk >> 2) + 4 * qq + (kk & 3), u = 16 * cb + cc; if (in < W3 && u < NA) w = theta[pW3 + in * NA + u]; }
+    else if (i < O_B1) { const int u = i - O_B0; if (u < W1) w = theta[pb0 + u]; }
+    else if (i < O_B2) { const int u = i - O_B1; if (u < W2) w = theta[pb1 + u]; }
+    else if (i < O_B3) { const int u = i - O_B2; if (u < W3) w = theta[pb2 + u]; }
+    else { const int u = i - O_B3; if (u < NA) w = theta[pb3 + u]; }
+    img[i] = w;
+}
+template <int NS, int NA, int W1, int W2, int W3> constexpr int pre_mfma3_image_floats() {
+    return (cdiv(NS, 4) * cdiv(W1, 16) + 4 * cdiv(W1, 16) * cdiv(W2, 16) + 4 * cdiv(W2, 16) * cdiv(W3, 16) + 4 * cdiv(W3, 16) * cdiv(NA, 16)) * 64 +
+           16 * (cdiv(W1, 16) + cdiv(W2, 16) + cdiv(W3, 16) + cdiv(NA, 16));
+}
+
+// MFMA pre-kernel for tanh policies with THREE hidden layers (Humanoid's 100-50-25, params-humanoid.json): the same transposed chain as
+// k_big_pre_mfma, every width padded to whole 16-unit tiles (zero weights, tanh(0) = 0 meets zero rows of the next layer).  One wave per 16-env
+// tile: NS_KS C1 + 4 C1 C2 + 4 C2 C3 + 4 C3 CO matrix instructions (258 for Humanoid) instead of the gather -> four small GEMMs -> action
+// chain of six launches (41 us per step at 500 rows) or the thread-per-env k_big_pre (302 us).  Same draws, same outputs layout.
+template <int NS, int NA, int NDROP, int W1, int W2, int W3>
+__global__ void __launch_bounds__(256) k_big_pre_mfma3(ProblemDesc pd, RolloutK r, int t, const float* __restrict__ theta,
+                                                       const float* __restrict__ norm, BigState st) {
+    constexpr int NS_KS = cdiv(NS, 4), C1 = cdiv(W1, 16), C2 = cdiv(W2, 16), C3 = cdiv(W3, 16), CO = cdiv(NA, 16), NIN = NS - NDROP + NA;
+    constexpr int pLS = NS * W1 + W1 + W1 * W2 + W2 + W2 * W3 + W3 + W3 * NA + NA;      // rllab's flat order [W0, b0, ..., Wout, bout, log_std]
+    constexpr int O_F0 = 0, O_F1 = O_F0 + NS_KS * C1 * 64, O_F2 = O_F1 + 4 * C1 * C2 * 64, O_F3 = O_F2 + 4 * C2 * C3 * 64, O_B0 = O_F3 + 4 * C3 * CO * 64,
+                  O_B1 = O_B0 + 16 * C1, O_B2 = O_B1 + 16 * C2, O_B3 = O_B2 + 16 * C3, IMG = O_B3 + 16 * CO;
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // image, then [4 waves][16 envs][NS] state tiles
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int b0 = (blockIdx.x * 4 + wave) * 16, b = b0 + c;
+    const bool active = b < r.B;
+    float* ST = lds + IMG + wave * 16 * NS;
+    if (r.stop != nullptr && *r.stop != 0) return;
+    // fragment image: built once per launch chain by k_pre_mfma3_image (one element per thread there; filled here element by element it was 65
+    // dependent L2 round trips per thread and step), copied with 16-byte loads
+    static_assert(IMG % 4 == 0, "image tables are multiples of 16 floats");
+    {
+        constexpr int NQ = IMG / 4, NIT = cdiv(NQ, 256);
+        float4 w4[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) { const int i = it * 256 + tid; w4[it] = (i < NQ) ? ((const float4*)st.PIMG)[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) { const int i = it * 256 + tid; if (i < NQ) ((float4*)lds)[i] = w4[it]; }
+    }
+    const uint64_t genv = r.stream_offset + (uint64_t)RK_ENV(r, b);
+    const int tt = t + RK_TOFF(r, b);
+    if (t == 0 && active && q == 0 && r.init_obs != nullptr) {   // continuation of a chunked rollout / merged rounds
+        st.cur_model[b] = r.init_model[b]; st.ts[b] = r.init_ts[b];
+        for (int i = 0; i < NS; ++i) st.S[(size_t)b * NS + i] = r.init_obs[(size_t)b * NS + i];
+    } else if (t == 0 && active && q == 0) {                     // vec_env.reset() (env_helpers.py:585-595)
+        const uint4 d0 = rng_draw(r.seed, genv, 0, RNG_RESET, 0);
+        const int row = (r.reset_idx != nullptr) ? r.reset_idx[b] : rng_index(d0.x, r.n_pool);
+        st.cur_model[b] = (r.reset_model != nullptr) ? r.reset_model[b] : rng_index(d0.y, pd.K);
+        st.ts[b] = 0;
+        for (int i = 0; i < NS; ++i) st.S[(size_t)b * NS + i] = r.pool[(size_t)row * NS + i];
+    }
+    __syncthreads();                                             // image complete; the reset rows of this tile are written by its own wave
+    const int lim = min(16, max(0, r.B - b0)) * NS;
+    for (int i = lane; i < 16 * NS; i += 64) ST[i] = (i < lim) ? st.S[(size_t)b0 * NS + i] : 0.0f;
+    wave_lds_sync();
+    for (int i = lane; i < lim; i += 64) {                       // obs[t] (merged rounds: a tile's envs may belong to two rounds)
+        const int bi = b0 + i / NS;
+        r.obs[((size_t)(t + RK_TOFF(r, bi)) * RK_STRIDE(r) + RK_ENV(r, bi)) * NS + i % NS] = ST[i];
+    }
+    f32x4 p0[C1], p1[C2], p2[C3], mu[CO];
+#pragma unroll
+    for (int cb = 0; cb < C1; ++cb) p0[cb] = *(const f32x4*)&lds[O_B0 + 16 * cb + 4 * q];
+#pragma unroll
+    for (int s_ = 0; s_ < NS_KS; ++s_) {
+        const int f = 4 * s_ + q;
+        const float x = (f < NS) ? ST[c * NS + f] : 0.0f;
+#pragma unroll
+        for (int cb = 0; cb < C1; ++cb) p0[cb] = MFMA16(lds[O_F0 + (s_ * C1 + cb) * 64 + lane], x, p0[cb]);
+    }
+#pragma unroll
+    for (int cb = 0; cb < C1; ++cb)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) p0[cb][rr] = tanh_fast(p0[cb][rr]);
+#pragma unroll
+    for (int cb = 0; cb < C2; ++cb) p1[cb] = *(const f32x4*)&lds[O_B1 + 16 * cb + 4 * q];
+#pragma unroll
+    for (int kk = 0; kk < 4 * C1; ++kk)
+#pragma unroll
+        for (int cb = 0; cb < C2; ++cb) p1[cb] = MFMA16(lds[O_F1 + (kk * C2 + cb) * 64 + lane], p0[kk >> 2][kk & 3], p1[cb]);
+#pragma unroll
+    for (int cb = 0; cb < C2; ++cb)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) p1[cb][rr] = tanh_fast(p1[cb][rr]);
+#pragma unroll
+    for (int cb = 0; cb < C3; ++cb) p2[cb] = *(const f32x4*)&lds[O_B2 + 16 * cb + 4 * q];
+#pragma unroll
+    for (int kk = 0; kk < 4 * C2; ++kk)
+#pragma unroll
+        for (int cb = 0; cb < C3; ++cb) p2[cb] = MFMA16(lds[O_F2 + (kk * C3 + cb) * 64 + lane], p1[kk >> 2][kk & 3], p2[cb]);
+#pragma unroll
+    for (int cb = 0; cb < C3; ++cb)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) p2[cb][rr] = tanh_fast(p2[cb][rr]);
+#pragma unroll
+    for (int cb = 0; cb < CO; ++cb) mu[cb] = *(const f32x4*)&lds[O_B3 + 16 * cb + 4 * q];
+#pragma unroll
+    for (int kk = 0; kk < 4 * C3; ++kk)
+#pragma unroll
+        for (int cb = 0; cb < CO; ++cb) mu[cb] = MFMA16(lds[O_F3 + (kk * CO + cb) * 64 + lane], p2[kk >> 2][kk & 3], mu[cb]);
+    if (!active) return;
+    const size_t tb = (size_t)tt * RK_STRIDE(r) + RK_ENV(r, b);
+    const float* in_mean = norm; const float* in_std = norm + (NS + NA);
+    const float* __restrict__ log_std = theta + pLS;
+    for (int i = q; i < NS; i += 4) if (i >= NDROP) st.X[(size_t)b * st.ldx + i - NDROP] = (ST[c * NS + i] - in_mean[i]) / in_std[i];     // training.py:228,146-151
+    if (q == 0) for (int j = NIN; j < st.ldx; ++j) st.X[(size_t)b * st.ldx + j] = 0.0f;
+    // action dims 16 cb + 4 q .. + 3 of this lane = Philox chunks (dim >> 1) of the step (chunk 0 = the step block), exactly as k_big_pre
+#pragma unroll
+    for (int cb = 0; cb < CO; ++cb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int d0 = 16 * cb + 4 * q + 2 * h;
+            if (d0 >= NA) continue;
+            float z[2] = {0.f, 0.f};
+            if (!r.determ && r.eps == nullptr) {
+                const uint4 blk = rng_draw(r.seed, genv, r.t0 + tt, RNG_STEP, d0 >> 1);
+                normal2(blk.x, blk.y, z[0], z[1]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int d = d0 + j;
+                if (d >= NA) continue;
+                const float m = mu[cb][2 * h + j];
+                float a = m;
+                if (!r.determ) a = fmaf((r.eps != nullptr) ? r.eps[tb * NA + d] : z[j], __expf(fmaxf(log_std[d], LOG_MIN_STD)), m);
+                r.act[tb * NA + d] = a; r.mean[tb * NA + d] = m;
+                const float ac = fminf(fmaxf(a, -1.0f), 1.0f);          // env_helpers.py:599
+                st.U[(size_t)b * NA + d] = ac;
+                st.X[(size_t)b * st.ldx + (NS - NDROP) + d] = (ac - in_mean[NS + d]) / in_std[NS + d];
+            }
+        }
+}
+template <int NS, int NA, int NDROP, int W1, int W2, int W3> constexpr size_t big_pre_mfma3_lds() {
+    constexpr int NS_KS = cdiv(NS, 4), C1 = cdiv(W1, 16), C2 = cdiv(W2, 16), C3 = cdiv(W3, 16), CO = cdiv(NA, 16);
+    return sizeof(float) * (size_t)((NS_KS * C1 + 4 * C1 * C2 + 4 * C2 * C3 + 4 * C3 * CO) * 64 + 16 * (C1 + C2 + C3 + CO) + 4 * 16 * NS);
+}
+
 // ---- pre-step for policies without an MFMA pre-kernel at LARGE batch (Humanoid's 100-50-25 at B = 6250): the policy layers run as GEMMs over
 // the batch (k_gemm_mfma, tanh epilogue) between a gather kernel and an action kernel.  k_big_pre walks the three dense layers on 64-env
 // blocks with weights through scalar loads: 0.31 ms per step at C4 for 140 MFLOP.
@@ -251,7 +406,13 @@ __global__ void __launch_bounds__(256) k_big_pre_action(ProblemDesc pd, RolloutK
 }
 
 typedef void (*big_pre_mfma_t)(ProblemDesc, RolloutK, int, const float*, const float*, BigState);
-static big_pre_mfma_t big_pre_mfma_select(const ProblemDesc& pd) {
+static big_pre_mfma_t big_pre_mfma_select(const ProblemDesc& pd, size_t* dyn_lds) {
+    *dyn_lds = 0;
+    if (pd.env == METRPO_ENV_HUMANOID && pd.ns == 55 && pd.na == 21 && pd.n_drop == 0 && pd.pol.n_layers == 4 && pd.pol.dims[1] == 100 && pd.pol.dims[2] == 50 &&
+        pd.pol.dims[3] == 25 && pd.pol.act[0] == METRPO_ACT_TANH && pd.pol.act[1] == METRPO_ACT_TANH && pd.pol.act[2] == METRPO_ACT_TANH && getenv("METRPO_NO_PRE_MFMA3") == nullptr) {
+        *dyn_lds = big_pre_mfma3_lds<55, 21, 0, 100, 50, 25>();
+        return k_big_pre_mfma3<55, 21, 0, 100, 50, 25>;
+    }
     if (pd.pol.n_layers != 3 || pd.pol.dims[1] != 32 || pd.pol.dims[2] != 32 || pd.pol.act[0] != METRPO_ACT_TANH) return nullptr;
     switch (pd.env) {
     case METRPO_ENV_SWIMMER: return (pd.ns == 10 && pd.na == 2 && pd.n_drop == 2) ? k_big_pre_mfma<METRPO_ENV_SWIMMER> : nullptr;
@@ -402,7 +563,8 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
                               ? gemm_fused_out_tile(B, pd.dyn.dims[L - 1], K, pd.ns) : 0;
     const bool fuse_out = fuse_tile > 0;
     if (fuse_out) nP = std::max(nP, up4(gemm_fused_out_part_floats(B, pd.dyn.dims[L - 1], K, pd.ns, fuse_tile)));
-    const big_pre_mfma_t pre_mfma = big_pre_mfma_select(pd);
+    size_t pre_lds = 0;
+    const big_pre_mfma_t pre_mfma = big_pre_mfma_select(pd, &pre_lds);
     // policies without an MFMA pre-kernel: GEMM chain over the batch from B = 1024 up -- and at ANY batch when the policy is large
     // (k_big_pre walks the weights through scalar loads, one block's time whatever B: 302 us per step for Humanoid's 100-50-25 at B = 100,
     // the params-humanoid.json shape, against ~40 us for the six small launches of the chain: iteration 77 -> 28 ms)
@@ -410,13 +572,15 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
     const char* pg_env = getenv("METRPO_PRE_GEMM");
     const bool pre_gemm = !pre_mfma && ((pg_env && pg_env[0] == '1') || (!(pg_env && pg_env[0] == '0') && (B >= 1024 || pd.pol.n_params >= 4096)));
     const size_t nPol = pre_gemm ? up4((size_t)B * pd.pol.max_width) : 0;
-    const size_t need = ((nS + nX + nU + 2 * nH + nO + nP + 2 * nPol) * sizeof(float) + 2 * (size_t)B * sizeof(int) + 511) & ~(size_t)255;
+    const size_t nPimg = pre_lds ? up4((size_t)pre_mfma3_image_floats<55, 21, 100, 50, 25>()) : 0;      // the only three-hidden-layer instantiation (big_pre_mfma_select)
+    const size_t need = ((nS + nX + nU + 2 * nH + nO + nP + 2 * nPol + nPimg) * sizeof(float) + 2 * (size_t)B * sizeof(int) + 511) & ~(size_t)255;
     if (need_out) *need_out = need;
     if (ws == nullptr) return METRPO_OK;
     BigState bs = {};
     float* p = (float*)ws;
-    bs.S = p; p += nS; bs.X = p; p += nX; bs.U = p; p += nU; bs.HA = p; p += nH; bs.HB = p; p += nH; bs.OUT = p; p += nO; bs.PART = nP ? p : nullptr; p += nP; bs.PA = p; p += nPol; bs.PB = p; p += nPol;
+    bs.S = p; p += nS; bs.X = p; p += nX; bs.U = p; p += nU; bs.HA = p; p += nH; bs.HB = p; p += nH; bs.OUT = p; p += nO; bs.PART = nP ? p : nullptr; p += nP; bs.PA = p; p += nPol; bs.PB = p; p += nPol; bs.PIMG = nPimg ? p : nullptr; p += nPimg;
     bs.ts = (int*)p; bs.cur_model = bs.ts + B;
+    if (nPimg) hipLaunchKernelGGL((k_pre_mfma3_image<55, 21, 100, 50, 25>), dim3((unsigned)((nPimg + 255) / 256)), dim3(256), 0, st, c->d_theta, bs.PIMG);
     bs.ldx = (pd.nin + 3) & ~3;
     RolloutK r = make_rollout_k(a);
     r.vB = vB; r.vR = vR;                                    // merged rounds: a->B = vR * vB rows, a->T = H steps (launch_rollout_gemm)
@@ -424,8 +588,9 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
     const size_t psh = (size_t)(pd.ns + 2 * pd.pol.max_width) * 64 * sizeof(float);
     if (psh > 160 * 1024) return set_err(c, METRPO_EUNSUPPORTED, "policy too wide for k_big_pre");
     if (psh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_big_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psh));
+    if (pre_mfma && pre_lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)pre_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pre_lds));
     for (int t = 0; t < a->T; ++t) {
-        if (pre_mfma) hipLaunchKernelGGL(pre_mfma, dim3((B + 63) / 64), dim3(256), 0, st, pd, r, t, c->d_theta, c->d_norm, bs);
+        if (pre_mfma) hipLaunchKernelGGL(pre_mfma, dim3((B + 63) / 64), dim3(256), pre_lds, st, pd, r, t, c->d_theta, c->d_norm, bs);
         else if (pre_gemm) {
             hipLaunchKernelGGL(k_big_pre_gather, dim3((unsigned)(((long long)B * pd.ns + 255) / 256)), dim3(256), 0, st, pd, r, t, c->d_norm, bs);
             const float* pin = bs.S; int ldp = pd.ns;
