@@ -220,7 +220,9 @@ __global__ void k_pg_tail(CgTail t) {
 bool policy_gemm_applicable(const metrpo_ctx* c, long long N) {
     if (c->pol_path == 2) return true;                       // forced (test hook)
     if (c->pol_path == 0) return false;                      // generic forced
-    return c->pol_mfma < 0 && N >= 8192;                     // no fused kernel for this shape and enough rows to fill GEMM tiles
+    // no fused kernel for this shape, and either enough rows to fill GEMM tiles or a policy large enough that the generic kernels' per-launch cost
+    // (thread-per-parameter phases: 1.2 ms per launch for Humanoid's 12 275 weights, whatever N) exceeds the whole GEMM-path update (1.4 ms at N = 64)
+    return c->pol_mfma < 0 && (N >= 8192 || c->pd.pol.n_params >= 4096);
 }
 
 static int pg_ensure(metrpo_ctx* c, const PgLay& g, long long N, PgBufs* B) {
