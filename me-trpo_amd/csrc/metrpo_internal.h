@@ -183,6 +183,7 @@ int launch_det_backward(metrpo_ctx*, int idx, int B, int T, const float* XS, con
 int ensure_detpart(metrpo_ctx*, int B);
 int ensure_detpart_n(metrpo_ctx*, size_t n_doubles);
 int launch_det_cost_reduce(metrpo_ctx*, int n_part, const double* part, double* costs, hipStream_t);
+int launch_validation_resident(metrpo_ctx*, const float* s0, int Bv, int T, double gamma, double* costs, hipStream_t);   // rollout_resident.hip; METRPO_EUNSUPPORTED: not this shape
 bool det_gemm_applicable(const metrpo_ctx*);
 int launch_dg_forward(metrpo_ctx*, const float* s0, int B, int T, double gamma, float* XS, float* WT, double* costs, hipStream_t);
 int launch_dg_backward(metrpo_ctx*, int B, int T, const float* XS, const float* WT, float* GM, hipStream_t);

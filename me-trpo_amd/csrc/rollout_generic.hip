@@ -350,7 +350,13 @@ int launch_validation_cost(metrpo_ctx* c, const float* s0, int Bv, int T, double
         const int rc0 = ensure_detpart(c, Bv); if (rc0) return rc0;
         return launch_det_forward(c, c->det_cfg, s0, Bv, T, gamma, nullptr, nullptr, c->d_detpart, costs, st);
     }
-    if (c->det_gemm) return launch_dg_forward(c, s0, Bv, T, gamma, nullptr, nullptr, costs, st);      // large nets: GEMM-path sweep (det_gemm.hip)
+    if (c->det_gemm) {                                       // large nets: the resident kernel's validation mode where its table has the shape, else the GEMM-path sweep (det_gemm.hip)
+        if (getenv("METRPO_NO_RESIDENT_VALIDATION") == nullptr) {
+            const int rcr = launch_validation_resident(c, s0, Bv, T, gamma, costs, st);
+            if (rcr != METRPO_EUNSUPPORTED) return rcr;
+        }
+        return launch_dg_forward(c, s0, Bv, T, gamma, nullptr, nullptr, costs, st);
+    }
     int bs; size_t sh;
     int rc = pick_block(c, envbufs_floats(pd, METRPO_SAM_EPS_RAND, 1), Bv, &bs, &sh);
     if (rc) return rc;

@@ -43,6 +43,8 @@ extern "C" int32_t metrpo_debug_resident_phases(unsigned long long* out) { retur
 
 struct ResidentK {
     int R, round0, rounds_total, NT, NSL, U, PW, steps;   // rounds of this launch, first round, env tiles, slices, compute blocks, post waves per block, steps per round
+    int part_stride, part_off, Btot;                      // validation-cost mode in batch chunks: det_part[m * part_stride + part_off + tile], costs are means over Btot envs
+    int det, NTM; float gamma; const float* s0; double* det_part;   // validation-cost mode (metrpo_validation_cost): tiles per model, discount, start states [B][ns], per-(model, tile) cost sums
     int NTC;                                              // 4-wave form: env tiles per workgroup COLUMN (the R * NT tiles of the launch are dealt to U / (K NSL) columns); else = NT
     unsigned int seq0;                                    // packets of local step tau carry seq0 + tau + 1
     int skip_block;                                       // test hook (METRPO_RESIDENT_TEST_SKIP): this workgroup behaves as if it had never been scheduled; -1 otherwise
@@ -283,7 +285,10 @@ __device__ __forceinline__ void resident_compute_wide(const ProblemDesc& pd, con
     // The R * NT env tiles of the launch (tile g = round * NT + tile of the round: what the post waves and the packet slots are indexed by) are
     // dealt to the workgroup columns in runs of NTC: five rounds of seven tiles are three columns of 12 / 12 / 11, one launch, every CU busy --
     // instead of 3 + 2 rounds in two launches.  NT below = the tiles of THIS column.
-    const int g0 = col * z.NTC, NT = max(0, min(z.NTC, z.R * z.NT - g0));
+    // Validation-cost mode (z.det): tile g = model * NTM + tile of the batch belongs to ONE model -- the workgroups of model k deal model k's NTM tiles
+    // to their columns and never see the others'.
+    const int g0 = z.det ? k * z.NTM + col * z.NTC : col * z.NTC;
+    const int NT = z.det ? max(0, min(z.NTC, z.NTM - col * z.NTC)) : max(0, min(z.NTC, z.R * z.NT - g0));
     if (NT == 0) return;
     const float* __restrict__ W = dyn + (size_t)k * pd.dyn.n_params;
     const float* __restrict__ W0 = W + pd.dyn.w_off[0];
@@ -704,6 +709,182 @@ __device__ __forceinline__ void resident_post(const ProblemDesc& pd, const Rollo
     RT_DUMP(1, z.U)
 }
 
+// ---- post role of the validation-cost mode (build_policy_graph's forward, model_based_rl.py:106-151: what k_validation / k_det_mfma compute) ---------
+// Wave = (model m, env tile): deterministic policy (action = clipped mean), next state from head m only, cost of the state reached, Ant's sticky
+// dones mask (cost x (1 - dones), then dones |= is_done), sum_t gamma^t cost per env; no draws, no resets, no trajectory rows.  The tile's
+// sum over its envs / B goes to det_part[m * NTM + tile]; k_det_cost_reduce adds a model's tiles in order.
+template <int ENV>
+__device__ __forceinline__ void resident_post_det(const ProblemDesc& pd, const ResidentK& z, int B, const float* __restrict__ dyn,
+                                                  const float* __restrict__ theta, const float* __restrict__ norm, float* lds) {
+    using C = Cfg<ENV, 64, 32>;
+    constexpr int NS = C::NS, NA = C::NA, NDROP = C::NDROP, NIN = C::NIN, PH = 32, NS_KS = C::NS_KS, NIN_KS = cdiv(NIN + 1, 4), NSP = C::NSP;
+    constexpr int O_PF1 = NS_KS * 2 * 64, O_PF2 = O_PF1 + 16 * 64, O_B0 = O_PF2 + 8 * 64, O_B1 = O_B0 + 32, O_B2 = O_B1 + 32, IMG = ((O_B2 + 16 + 3) / 4) * 4;
+    constexpr int PW_LDS = 2 * 16 * NA;
+    constexpr int DCH = (NS <= 12) ? NS : (NS + 1) / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
+    for (int i = tid; i < IMG; i += (int)blockDim.x) {                // policy fragment image (layout of k_big_pre_mfma, rollout_gemm.hip)
+        float w = 0.0f;
+        const int ln = i & 63, cc = ln & 15, qq = ln >> 4;
+        if (i < O_PF1) { const int f = i >> 6, s_ = f >> 1, cb = f & 1, in = 4 * s_ + qq; if (in < NS) w = theta[C::pW0 + in * PH + 16 * cb + cc]; }
+        else if (i < O_PF2) { const int f = (i - O_PF1) >> 6, kk = f >> 1, cb = f & 1; w = theta[C::pW1 + (16 * (kk >> 2) + 4 * qq + (kk & 3)) * PH + 16 * cb + cc]; }
+        else if (i < O_B0) { const int kk = (i - O_PF2) >> 6; if (cc < NA) w = theta[C::pW2 + (16 * (kk >> 2) + 4 * qq + (kk & 3)) * NA + cc]; }
+        else if (i < O_B1) w = theta[C::pb0 + (i - O_B0)];
+        else if (i < O_B2) w = theta[C::pb1 + (i - O_B1)];
+        else { const int d = i - O_B2; if (d < NA) w = theta[C::pb2 + d]; }
+        lds[i] = w;
+    }
+    __syncthreads();
+    const int g = ((int)blockIdx.x - z.U) * z.PW + wave;
+    const int K = pd.K, NSL = z.NSL;
+    if (wave >= z.PW || g >= K * z.NTM) return;
+    const int m = g / z.NTM, w = g % z.NTM;
+    float* UA = lds + IMG + wave * PW_LDS; float* XA = UA + 16 * NA;
+    const int b = w * 16 + c;
+    const bool active = b < B;
+    const int bc = active ? b : 0;
+    const float* in_mean = norm; const float* in_std = norm + (NS + NA);
+    const float* diff_mean = norm + 2 * (NS + NA); const float* diff_std = diff_mean + NS;
+    unsigned long long* xp = z.X + ((size_t)g * (4 * NIN_KS)) * 16 + c;
+    const unsigned long long* pq = z.P + (((size_t)g * K + m) * NSL) * NSP * 16 + c;
+    float xm[NIN_KS], xr[NIN_KS], am[4], ar[4], dmn[NS], dsd[NS], bias[NS];
+#pragma unroll
+    for (int kk = 0; kk < NIN_KS; ++kk) {
+        const int f = 4 * kk + q, src = (f < NS - NDROP) ? f + NDROP : NS + (f - (NS - NDROP));
+        xm[kk] = (f < NIN) ? in_mean[src] : 0.0f; xr[kk] = (f < NIN) ? 1.0f / in_std[src] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int d = 4 * q + j; am[j] = (d < NA) ? in_mean[NS + d] : 0.0f; ar[j] = (d < NA) ? 1.0f / in_std[NS + d] : 0.0f; }
+    const float* __restrict__ b2 = dyn + (size_t)m * pd.dyn.n_params + pd.dyn.b_off[2];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { dmn[i] = diff_mean[i]; dsd[i] = diff_std[i]; bias[i] = b2[i]; }
+    float s[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) s[i] = active ? z.s0[(size_t)bc * NS + i] : 0.0f;
+    double acc = 0.0, gpow = 1.0;
+    float dones = 0.0f;
+    for (int tau = 0; tau < z.steps; ++tau) {
+        const unsigned int seq = z.seq0 + (unsigned int)tau + 1u;
+        f32x4 p0[2], p1[2];
+        p0[0] = *(const f32x4*)&lds[O_B0 + 4 * q]; p0[1] = *(const f32x4*)&lds[O_B0 + 16 + 4 * q];
+#pragma unroll
+        for (int s_ = 0; s_ < NS_KS; ++s_) {
+            const float xs = sel4(q, s[4 * s_], (4 * s_ + 1 < NS) ? s[(4 * s_ + 1 < NS) ? 4 * s_ + 1 : 0] : 0.0f, (4 * s_ + 2 < NS) ? s[(4 * s_ + 2 < NS) ? 4 * s_ + 2 : 0] : 0.0f,
+                                  (4 * s_ + 3 < NS) ? s[(4 * s_ + 3 < NS) ? 4 * s_ + 3 : 0] : 0.0f);
+            p0[0] = MFMA16(lds[(s_ * 2 + 0) * 64 + lane], xs, p0[0]);
+            p0[1] = MFMA16(lds[(s_ * 2 + 1) * 64 + lane], xs, p0[1]);
+        }
+        p1[0] = *(const f32x4*)&lds[O_B1 + 4 * q]; p1[1] = *(const f32x4*)&lds[O_B1 + 16 + 4 * q];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) p0[cb][rr] = tanh_fast(p0[cb][rr]);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            p1[0] = MFMA16(lds[O_PF1 + (kk * 2 + 0) * 64 + lane], p0[kk >> 2][kk & 3], p1[0]);
+            p1[1] = MFMA16(lds[O_PF1 + (kk * 2 + 1) * 64 + lane], p0[kk >> 2][kk & 3], p1[1]);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) p1[cb][rr] = tanh_fast(p1[cb][rr]);
+        f32x4 m0 = *(const f32x4*)&lds[O_B2 + 4 * q], m1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 8; kk += 2) {
+            m0 = MFMA16(lds[O_PF2 + kk * 64 + lane], p1[kk >> 2][kk & 3], m0);
+            m1 = MFMA16(lds[O_PF2 + (kk + 1) * 64 + lane], p1[(kk + 1) >> 2][(kk + 1) & 3], m1);
+        }
+        const f32x4 mu = m0 + m1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int d = 4 * q + j;
+            if (d >= NA) continue;
+            const float ac = fminf(fmaxf(mu[j], -1.0f), 1.0f);        // model_based_rl.py:128
+            UA[c * NA + d] = ac;
+            XA[c * NA + d] = (ac - am[j]) * ar[j];
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int kk = 0; kk < NIN_KS; ++kk) {
+            const int f = 4 * kk + q;
+            constexpr int NSD = NS - NDROP;
+            auto sd = [&](int e) { const int i = 4 * kk + e + NDROP; return (4 * kk + e < NSD) ? s[(i < NS) ? i : 0] : 0.0f; };
+            float v = sel4(q, sd(0), sd(1), sd(2), sd(3));
+            if (f >= NSD && f < NIN) v = XA[c * NA + f - NSD]; else v = (v - xm[kk]) * xr[kk];
+            if (!active || f > NIN) v = 0.0f;
+            else if (f == NIN) v = 1.0f;
+            res_st(xp + f * 16, seq, v);
+        }
+        float su2 = 0.0f;
+#pragma unroll
+        for (int d = 0; d < NA; ++d) { const float a = UA[c * NA + d]; su2 = fmaf(a, a, su2); }
+        float out[NS];
+        {
+            ResSpin sp;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) out[i] = 0.0f;
+                if (active) {
+                    for (int s0_ = 0; s0_ < NSL; s0_ += 16) {
+#pragma unroll
+                        for (int d0 = 0; d0 < NS; d0 += DCH) {
+                            unsigned long long pk[4][DCH];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                for (int i = 0; i < DCH; ++i) if (d0 + i < NS) pk[j][i] = res_ld(pq + ((size_t)(s0_ + 4 * j + q) * NSP + d0 + i) * 16);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                for (int i = 0; i < DCH; ++i)
+                                    if (d0 + i < NS) { ok = ok && res_fresh(pk[j][i], seq); out[d0 + i] += __uint_as_float((unsigned int)pk[j][i]); }
+                        }
+                    }
+                }
+                if (__all(ok)) break;
+                if (sp.give_up(z)) return;
+            }
+        }
+        float v[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) v[i] = fmaf(dsd[i], xor_sum(out[i]) + bias[i], dmn[i]) + s[i];
+        float cost = 0.0f;
+        if constexpr (ENV == METRPO_ENV_SWIMMER) cost = -(v[5] - 1e-2f * (su2 / (float)NA));
+        else if constexpr (ENV == METRPO_ENV_HALF_CHEETAH) cost = -fminf(fmaxf(v[9] - 1e-1f * 0.5f * su2, -10.0f), 10.0f);
+        else if constexpr (ENV == METRPO_ENV_HOPPER) {
+            float pen = 0.0f;
+#pragma unroll
+            for (int j = 2; j < NS; ++j) pen += fmaxf(fabsf(v[j]) - 100.0f, 0.0f);
+            cost = -(v[5] - 0.01f * 0.5f * su2 - 10.0f * fmaxf(0.45f - v[0], 0.0f) - 10.0f * fmaxf(fabsf(v[1]) - 0.2f, 0.0f) - pen);
+        } else if constexpr (ENV == METRPO_ENV_SNAKE) cost = -(v[7] - 1e-2f * 0.5f * su2);
+        else if constexpr (ENV == METRPO_ENV_ANT) {                   // cost_tf(..., dones) then the dones update (model_based_rl.py:134-137)
+            cost = -(v[15] - 1e-2f * 0.5f * su2 + 0.05f) * (1.0f - dones);
+            bool fin = true;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) fin = fin && isfinite(v[i]);
+            dones = fmaxf(dones, ((v[2] >= 0.2f) && (v[2] <= 1.0f) && fin) ? 0.0f : 1.0f);
+        }
+        if (active) acc += gpow * (double)cost;
+        gpow *= (double)z.gamma;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) s[i] = active ? v[i] : 0.0f;
+    }
+    // the tile's sum over its envs (lanes q = 0 hold one env each; fixed butterfly over the 16 c-lanes), / B
+    double t = (q == 0 && active) ? acc : 0.0;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    if (lane == 0) z.det_part[(size_t)m * z.part_stride + z.part_off + w] = t / (double)z.Btot;
+}
+
+template <int ENV, int DH, int WS>
+__global__ void __launch_bounds__(256, 1) k_validation_resident(ProblemDesc pd, int B, ResidentK z, const float* __restrict__ dyn,
+                                                                const float* __restrict__ theta, const float* __restrict__ norm) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    using C = Cfg<ENV, 64, 32>;
+    if ((int)blockIdx.x < z.U) resident_compute_wide<C::NS, C::NIN, DH, WS>(pd, z, dyn, lds);
+    else resident_post_det<ENV>(pd, z, B, dyn, theta, norm, lds);
+}
+
 template <int ENV, int DH, int WS>
 __global__ void __launch_bounds__(512) k_rollout_resident(ProblemDesc pd, RolloutK r, ResidentK z, const float* __restrict__ dyn,
                                                           const float* __restrict__ theta, const float* __restrict__ norm) {
@@ -825,6 +1006,7 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
         const int rg = std::min(Rg, R - round0);
         ResidentK z;
         z.R = rg; z.round0 = round0; z.rounds_total = R; z.NT = NT; z.NSL = NSL; z.U = rg * K * NSL; z.PW = PW; z.steps = steps; z.NTC = NT;
+        z.det = 0; z.NTM = 0; z.gamma = 1.0f; z.s0 = nullptr; z.det_part = nullptr; z.part_stride = 0; z.part_off = 0; z.Btot = 0;
         if (pick->threads == 256) {
             const int G = rg * NT, post_blocks = (G + PW - 1) / PW;
             const int ncol = std::max(1, std::min(G, (c->n_sm - post_blocks) / (K * NSL)));
@@ -843,4 +1025,78 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
     HIP_TRY(c, hipGetLastError());
     c->last_rollout_kernel = 4;
     return METRPO_OK;
+}
+
+// ---- validation costs (metrpo_validation_cost) on the resident kernel's 4-wave form ------------------------------------------------------------
+typedef void (*resident_val_kernel_t)(ProblemDesc, int, ResidentK, const float*, const float*, const float*);
+struct ResidentValEntry { int env, ns, na, n_drop, dh, ws; resident_val_kernel_t fn; size_t lds; };
+#define RES_VAL_ENTRY(ENV, DH, WS) {ENV, EnvDim<ENV>::NS, EnvDim<ENV>::NA, EnvDim<ENV>::NDROP, DH, WS, k_validation_resident<ENV, DH, WS>, resident_lds_bytes_wide<ENV, DH, WS>()}
+// METRPO_EUNSUPPORTED: this shape stays on the step-wise sweep (det_gemm.hip)
+int launch_validation_resident(metrpo_ctx* c, const float* s0, int Bv, int T, double gamma, double* costs, hipStream_t st) {
+    static const ResidentValEntry tab[] = {
+        RES_VAL_ENTRY(METRPO_ENV_SWIMMER, 512, 32), RES_VAL_ENTRY(METRPO_ENV_HOPPER, 512, 32), RES_VAL_ENTRY(METRPO_ENV_SNAKE, 512, 32), RES_VAL_ENTRY(METRPO_ENV_HALF_CHEETAH, 512, 32),
+        RES_VAL_ENTRY(METRPO_ENV_SWIMMER, 1024, 64), RES_VAL_ENTRY(METRPO_ENV_HOPPER, 1024, 64), RES_VAL_ENTRY(METRPO_ENV_SNAKE, 1024, 64), RES_VAL_ENTRY(METRPO_ENV_HALF_CHEETAH, 1024, 64),
+        RES_VAL_ENTRY(METRPO_ENV_ANT, 1024, 64),
+    };
+    const ProblemDesc& pd = c->pd;
+    if (c->res_failed || getenv("METRPO_NO_RESIDENT") != nullptr || T <= 0) return METRPO_EUNSUPPORTED;
+    if (pd.dyn.n_layers != 3 || pd.dyn.dims[1] != pd.dyn.dims[2] || pd.dyn.act[0] != METRPO_ACT_RELU || pd.dyn.act[1] != METRPO_ACT_RELU ||
+        pd.dyn.act[2] != METRPO_ACT_IDENTITY) return METRPO_EUNSUPPORTED;
+    if (pd.pol.n_layers != 3 || pd.pol.dims[1] != 32 || pd.pol.dims[2] != 32 || pd.pol.act[0] != METRPO_ACT_TANH || pd.pol.act[1] != METRPO_ACT_TANH)
+        return METRPO_EUNSUPPORTED;
+    const int K = pd.K, DH = pd.dyn.dims[1];
+    const ResidentValEntry* e = nullptr;
+    for (const ResidentValEntry& x : tab)
+        if (x.env == pd.env && x.ns == pd.ns && x.na == pd.na && x.n_drop == pd.n_drop && x.dh == DH) { e = &x; break; }
+    if (!e) return METRPO_EUNSUPPORTED;
+    // model k's workgroups (K x DH / ws of them per column) deal the batch's env tiles to as many columns as fit next to the post workgroups (one wave
+    // per (model, tile), four per workgroup).  The batch goes in nb chunks, one launch each: fewer tiles per launch need fewer post workgroups and
+    // leave room for a third column -- 500 envs: one launch = 2 columns of 16 tiles per step, three launches = 3 x (3 columns of 4).
+    const int NSL = DH / e->ws, PW = 4;
+    // Cost of a step (us): a column's tiles at the measured tile time (1.5 at 2 x 512 / 32-unit slices, 6.1 at 2 x 1024 / 64), but never less than a
+    // tile's round trip through the post wave (8), per chunk; plus the launch's prologue (~60 us: weight fragments, LDS images) spread over the T steps.
+    int nb = 0, NTM = 0, NTC = 0, cols = 0;
+    double best = 1e30;
+    const double t_tile = (DH >= 1024) ? 6.1 : 1.5, t_trip = 8.0, t_launch = 60.0;
+    for (int n = 1; n <= 8; ++n) {
+        const int bc = (Bv + n - 1) / n, ntm = (bc + 15) / 16, post = (K * ntm + PW - 1) / PW;
+        const int ncol = std::min(ntm, (c->n_sm - post) / (K * NSL));
+        if (ncol < 1) continue;
+        const int ntc = (ntm + ncol - 1) / ncol;
+        const double cost = n * (std::max(ntc * t_tile, t_trip) + t_launch / T);
+        if (cost < best - 1e-9) { best = cost; nb = n; NTM = ntm; NTC = ntc; cols = (ntm + ntc - 1) / ntc; }
+    }
+    if (nb == 0) return METRPO_EUNSUPPORTED;
+    const int Bc = (Bv + nb - 1) / nb, G = K * NTM, post_blocks = (G + PW - 1) / PW;
+    const int OUT_CB = (pd.ns + 15) / 16, NIN_KS = (pd.nin + 1 + 3) / 4;
+    const size_t nX = (size_t)G * 4 * NIN_KS * 16, nP = (size_t)G * K * NSL * 16 * OUT_CB * 16;
+    const size_t need = (nX + nP + 32) * sizeof(unsigned long long);
+    if (need > c->res_cap) {
+        if (c->d_res) HIP_TRY(c, hipFree(c->d_res));
+        c->d_res = nullptr; c->res_cap = 0;
+        HIP_TRY(c, hipMalloc(&c->d_res, need));                      // ordinary device memory: see launch_rollout_resident
+        HIP_TRY(c, hipMemsetAsync(c->d_res, 0, need, st));
+        c->res_cap = need; c->res_seq = 0;
+    }
+    if ((unsigned long long)c->res_seq + (unsigned long long)nb * (T + 1) >= 0xfffffff0ull) {
+        HIP_TRY(c, hipMemsetAsync(c->d_res, 0, c->res_cap, st));
+        c->res_seq = 0;
+    }
+    { const int rc = ensure_detpart_n(c, (size_t)K * nb * NTM); if (rc) return rc; }
+    if (e->lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)e->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds));
+    for (int ch = 0; ch < nb; ++ch) {
+        const int b_lo = ch * Bc, bn = std::min(Bc, Bv - b_lo);
+        ResidentK z;
+        z.R = 1; z.round0 = 0; z.rounds_total = 1; z.NT = NTM; z.NSL = NSL; z.U = cols * K * NSL; z.PW = PW; z.steps = T; z.NTC = NTC;
+        z.det = 1; z.NTM = NTM; z.gamma = (float)gamma; z.s0 = s0 + (size_t)b_lo * pd.ns; z.det_part = c->d_detpart;
+        z.part_stride = nb * NTM; z.part_off = ch * NTM; z.Btot = Bv;
+        z.seq0 = c->res_seq; c->res_seq += (unsigned int)T + 1u;
+        z.skip_block = -1;
+        z.abort_cell = (unsigned int*)c->d_res;
+        z.X = (unsigned long long*)c->d_res + 32; z.P = z.X + nX;
+        z.err = comm_err_cell(c) + 1;
+        hipLaunchKernelGGL(e->fn, dim3(z.U + post_blocks), dim3(256), e->lds, st, pd, std::max(bn, 0), z, c->d_dyn, c->d_theta, c->d_norm);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return launch_det_cost_reduce(c, nb * NTM, c->d_detpart, costs, st);
 }

@@ -268,3 +268,31 @@ def test_resident_missing_workgroup_times_out_and_context_recovers(env, hid, mon
     ref = ref_eng.rollout(B, T, H, 'step_rand', pool, seed=2)
     for a, b in zip(_fields(again), _fields(ref)):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('env,hid,K,Bv,T,gamma', [('swimmer', 512, 5, 500, 12, 1.0),        # params-swimmer.json's validation batch: 160 tiles, two columns per model
+                                                  ('half_cheetah', 1024, 5, 500, 8, 0.99),
+                                                  ('ant', 1024, 3, 77, 15, 0.97),           # sticky dones mask, a partial last tile
+                                                  ('hopper', 512, 2, 16, 9, 1.0),           # one tile per model
+                                                  ('snake', 1024, 4, 1, 5, 0.9)])           # one env
+def test_resident_validation_costs_against_oracle_and_the_stepwise_sweep(env, hid, K, Bv, T, gamma, monkeypatch):
+    """metrpo_validation_cost (build_policy_graph's forward, model_based_rl.py:106-151) in the resident kernel's validation mode: model k's
+    workgroups deal ITS env tiles to their columns, the post wave of (model, tile) follows the deterministic policy under that one model and
+    sums gamma^t cost.  Against the oracle and against the step-wise GEMM sweep (det_gemm.hip) it replaces for these shapes."""
+    from oracle import metrpo_oracle as O
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (hid, hid), (32, 32), seed=31, n_pool=512)
+    if env == 'ant':
+        pool[::3, 2] = 0.25; dm.diff_mean[2] = -0.01
+        eng.set_dynamics_layers(dm.Ws, dm.bs, dm.in_mean, dm.in_std, dm.diff_mean, dm.diff_std)
+    s0 = pool[:Bv].astype(np.float32)
+    got = cpu(eng.validation_cost(s0, T, gamma))
+    eng.comm_check()                                                      # no hand-over timed out
+    monkeypatch.setenv('METRPO_NO_RESIDENT_VALIDATION', '1')
+    sweep = cpu(eng.validation_cost(s0, T, gamma))
+    monkeypatch.delenv('METRPO_NO_RESIDENT_VALIDATION')
+    ref = O.validation_costs(dm, theta.astype(np.float32).astype(np.float64), pdims, env, s0.astype(np.float64), T, gamma)
+    np.testing.assert_allclose(got, ref, rtol=5e-4, atol=5e-4)
+    np.testing.assert_allclose(got, sweep, rtol=5e-4, atol=5e-4)
+    assert not np.array_equal(got, sweep)                                 # two different kernels did run (their float32 sums differ in the last bits)
+    again = cpu(eng.validation_cost(s0, T, gamma))
+    np.testing.assert_array_equal(got, again)                             # bitwise repeatable
