@@ -713,7 +713,7 @@ __device__ __forceinline__ void resident_post(const ProblemDesc& pd, const Rollo
 // Wave = (model m, env tile): deterministic policy (action = clipped mean), next state from head m only, cost of the state reached, Ant's sticky
 // dones mask (cost x (1 - dones), then dones |= is_done), sum_t gamma^t cost per env; no draws, no resets, no trajectory rows.  The tile's
 // sum over its envs / B goes to det_part[m * NTM + tile]; k_det_cost_reduce adds a model's tiles in order.
-template <int ENV>
+template <int ENV, int NTW>
 __device__ __forceinline__ void resident_post_det(const ProblemDesc& pd, const ResidentK& z, int B, const float* __restrict__ dyn,
                                                   const float* __restrict__ theta, const float* __restrict__ norm, float* lds) {
     using C = Cfg<ENV, 64, 32>;
@@ -734,42 +734,51 @@ __device__ __forceinline__ void resident_post_det(const ProblemDesc& pd, const R
         lds[i] = w;
     }
     __syncthreads();
-    const int g = ((int)blockIdx.x - z.U) * z.PW + wave;
-    const int K = pd.K, NSL = z.NSL;
-    if (wave >= z.PW || g >= K * z.NTM) return;
-    const int m = g / z.NTM, w = g % z.NTM;
-    float* UA = lds + IMG + wave * PW_LDS; float* XA = UA + 16 * NA;
-    const int b = w * 16 + c;
-    const bool active = b < B;
-    const int bc = active ? b : 0;
+    // a wave serves NTW tiles (fewer post workgroups leave room for another column of compute workgroups): g_j = (wave index) * NTW + j
+    const int wv = ((int)blockIdx.x - z.U) * z.PW + wave;
+    const int K = pd.K, NSL = z.NSL, G = K * z.NTM;
+    if (wave >= z.PW || wv * NTW >= G) return;
     const float* in_mean = norm; const float* in_std = norm + (NS + NA);
     const float* diff_mean = norm + 2 * (NS + NA); const float* diff_std = diff_mean + NS;
-    unsigned long long* xp = z.X + ((size_t)g * (4 * NIN_KS)) * 16 + c;
-    const unsigned long long* pq = z.P + (((size_t)g * K + m) * NSL) * NSP * 16 + c;
-    float xm[NIN_KS], xr[NIN_KS], am[4], ar[4], dmn[NS], dsd[NS], bias[NS];
+    float xm[NIN_KS], xr[NIN_KS], am[4], ar[4], dmn[NS], dsd[NS];
 #pragma unroll
     for (int kk = 0; kk < NIN_KS; ++kk) {
         const int f = 4 * kk + q, src = (f < NS - NDROP) ? f + NDROP : NS + (f - (NS - NDROP));
         xm[kk] = (f < NIN) ? in_mean[src] : 0.0f; xr[kk] = (f < NIN) ? 1.0f / in_std[src] : 0.0f;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const int d = 4 * q + j; am[j] = (d < NA) ? in_mean[NS + d] : 0.0f; ar[j] = (d < NA) ? 1.0f / in_std[NS + d] : 0.0f; }
-    const float* __restrict__ b2 = dyn + (size_t)m * pd.dyn.n_params + pd.dyn.b_off[2];
+    for (int jj = 0; jj < 4; ++jj) { const int d = 4 * q + jj; am[jj] = (d < NA) ? in_mean[NS + d] : 0.0f; ar[jj] = (d < NA) ? 1.0f / in_std[NS + d] : 0.0f; }
 #pragma unroll
-    for (int i = 0; i < NS; ++i) { dmn[i] = diff_mean[i]; dsd[i] = diff_std[i]; bias[i] = b2[i]; }
-    float s[NS];
+    for (int i = 0; i < NS; ++i) { dmn[i] = diff_mean[i]; dsd[i] = diff_std[i]; }
+    int gt[NTW], mt_[NTW]; bool live[NTW], active[NTW];
+    float s[NTW][NS], su2[NTW], dones[NTW];
+    double acc[NTW];
 #pragma unroll
-    for (int i = 0; i < NS; ++i) s[i] = active ? z.s0[(size_t)bc * NS + i] : 0.0f;
-    double acc = 0.0, gpow = 1.0;
-    float dones = 0.0f;
+    for (int j = 0; j < NTW; ++j) {
+        gt[j] = wv * NTW + j; live[j] = gt[j] < G;
+        const int gc = live[j] ? gt[j] : 0;
+        mt_[j] = gc / z.NTM;
+        const int b = (gc % z.NTM) * 16 + c;
+        active[j] = live[j] && b < B;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) s[j][i] = active[j] ? z.s0[(size_t)b * NS + i] : 0.0f;
+        acc[j] = 0.0; dones[j] = 0.0f; su2[j] = 0.0f;
+    }
+    float* UAw = lds + IMG + wave * NTW * PW_LDS;
+    double gpow = 1.0;
     for (int tau = 0; tau < z.steps; ++tau) {
         const unsigned int seq = z.seq0 + (unsigned int)tau + 1u;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+        if (!live[j]) continue;
+        float* UA = UAw + j * PW_LDS; float* XA = UA + 16 * NA;
+        unsigned long long* xp = z.X + ((size_t)gt[j] * (4 * NIN_KS)) * 16 + c;
         f32x4 p0[2], p1[2];
         p0[0] = *(const f32x4*)&lds[O_B0 + 4 * q]; p0[1] = *(const f32x4*)&lds[O_B0 + 16 + 4 * q];
 #pragma unroll
         for (int s_ = 0; s_ < NS_KS; ++s_) {
-            const float xs = sel4(q, s[4 * s_], (4 * s_ + 1 < NS) ? s[(4 * s_ + 1 < NS) ? 4 * s_ + 1 : 0] : 0.0f, (4 * s_ + 2 < NS) ? s[(4 * s_ + 2 < NS) ? 4 * s_ + 2 : 0] : 0.0f,
-                                  (4 * s_ + 3 < NS) ? s[(4 * s_ + 3 < NS) ? 4 * s_ + 3 : 0] : 0.0f);
+            const float xs = sel4(q, s[j][4 * s_], (4 * s_ + 1 < NS) ? s[j][(4 * s_ + 1 < NS) ? 4 * s_ + 1 : 0] : 0.0f, (4 * s_ + 2 < NS) ? s[j][(4 * s_ + 2 < NS) ? 4 * s_ + 2 : 0] : 0.0f,
+                                  (4 * s_ + 3 < NS) ? s[j][(4 * s_ + 3 < NS) ? 4 * s_ + 3 : 0] : 0.0f);
             p0[0] = MFMA16(lds[(s_ * 2 + 0) * 64 + lane], xs, p0[0]);
             p0[1] = MFMA16(lds[(s_ * 2 + 1) * 64 + lane], xs, p0[1]);
         }
@@ -795,28 +804,36 @@ __device__ __forceinline__ void resident_post_det(const ProblemDesc& pd, const R
         }
         const f32x4 mu = m0 + m1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int d = 4 * q + j;
+        for (int jj = 0; jj < 4; ++jj) {
+            const int d = 4 * q + jj;
             if (d >= NA) continue;
-            const float ac = fminf(fmaxf(mu[j], -1.0f), 1.0f);        // model_based_rl.py:128
+            const float ac = fminf(fmaxf(mu[jj], -1.0f), 1.0f);       // model_based_rl.py:128
             UA[c * NA + d] = ac;
-            XA[c * NA + d] = (ac - am[j]) * ar[j];
+            XA[c * NA + d] = (ac - am[jj]) * ar[jj];
         }
         wave_lds_sync();
 #pragma unroll
         for (int kk = 0; kk < NIN_KS; ++kk) {
             const int f = 4 * kk + q;
             constexpr int NSD = NS - NDROP;
-            auto sd = [&](int e) { const int i = 4 * kk + e + NDROP; return (4 * kk + e < NSD) ? s[(i < NS) ? i : 0] : 0.0f; };
+            auto sd = [&](int e) { const int i = 4 * kk + e + NDROP; return (4 * kk + e < NSD) ? s[j][(i < NS) ? i : 0] : 0.0f; };
             float v = sel4(q, sd(0), sd(1), sd(2), sd(3));
             if (f >= NSD && f < NIN) v = XA[c * NA + f - NSD]; else v = (v - xm[kk]) * xr[kk];
-            if (!active || f > NIN) v = 0.0f;
+            if (!active[j] || f > NIN) v = 0.0f;
             else if (f == NIN) v = 1.0f;
             res_st(xp + f * 16, seq, v);
         }
-        float su2 = 0.0f;
+        float su = 0.0f;
 #pragma unroll
-        for (int d = 0; d < NA; ++d) { const float a = UA[c * NA + d]; su2 = fmaf(a, a, su2); }
+        for (int d = 0; d < NA; ++d) { const float a = UA[c * NA + d]; su = fmaf(a, a, su); }
+        su2[j] = su;
+        }
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+        if (!live[j]) continue;
+        const int m = mt_[j];
+        const unsigned long long* pq = z.P + (((size_t)gt[j] * K + m) * NSL) * NSP * 16 + c;
+        const float* __restrict__ b2 = dyn + (size_t)m * pd.dyn.n_params + pd.dyn.b_off[2];
         float out[NS];
         {
             ResSpin sp;
@@ -824,20 +841,20 @@ __device__ __forceinline__ void resident_post_det(const ProblemDesc& pd, const R
                 bool ok = true;
 #pragma unroll
                 for (int i = 0; i < NS; ++i) out[i] = 0.0f;
-                if (active) {
+                if (active[j]) {
                     for (int s0_ = 0; s0_ < NSL; s0_ += 16) {
 #pragma unroll
                         for (int d0 = 0; d0 < NS; d0 += DCH) {
                             unsigned long long pk[4][DCH];
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
+                            for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                                for (int i = 0; i < DCH; ++i) if (d0 + i < NS) pk[j][i] = res_ld(pq + ((size_t)(s0_ + 4 * j + q) * NSP + d0 + i) * 16);
+                                for (int i = 0; i < DCH; ++i) if (d0 + i < NS) pk[jj][i] = res_ld(pq + ((size_t)(s0_ + 4 * jj + q) * NSP + d0 + i) * 16);
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
+                            for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
                                 for (int i = 0; i < DCH; ++i)
-                                    if (d0 + i < NS) { ok = ok && res_fresh(pk[j][i], seq); out[d0 + i] += __uint_as_float((unsigned int)pk[j][i]); }
+                                    if (d0 + i < NS) { ok = ok && res_fresh(pk[jj][i], seq); out[d0 + i] += __uint_as_float((unsigned int)pk[jj][i]); }
                         }
                     }
                 }
@@ -847,42 +864,47 @@ __device__ __forceinline__ void resident_post_det(const ProblemDesc& pd, const R
         }
         float v[NS];
 #pragma unroll
-        for (int i = 0; i < NS; ++i) v[i] = fmaf(dsd[i], xor_sum(out[i]) + bias[i], dmn[i]) + s[i];
+        for (int i = 0; i < NS; ++i) v[i] = fmaf(dsd[i], xor_sum(out[i]) + b2[i], dmn[i]) + s[j][i];
+        const float su = su2[j];
         float cost = 0.0f;
-        if constexpr (ENV == METRPO_ENV_SWIMMER) cost = -(v[5] - 1e-2f * (su2 / (float)NA));
-        else if constexpr (ENV == METRPO_ENV_HALF_CHEETAH) cost = -fminf(fmaxf(v[9] - 1e-1f * 0.5f * su2, -10.0f), 10.0f);
+        if constexpr (ENV == METRPO_ENV_SWIMMER) cost = -(v[5] - 1e-2f * (su / (float)NA));
+        else if constexpr (ENV == METRPO_ENV_HALF_CHEETAH) cost = -fminf(fmaxf(v[9] - 1e-1f * 0.5f * su, -10.0f), 10.0f);
         else if constexpr (ENV == METRPO_ENV_HOPPER) {
             float pen = 0.0f;
 #pragma unroll
-            for (int j = 2; j < NS; ++j) pen += fmaxf(fabsf(v[j]) - 100.0f, 0.0f);
-            cost = -(v[5] - 0.01f * 0.5f * su2 - 10.0f * fmaxf(0.45f - v[0], 0.0f) - 10.0f * fmaxf(fabsf(v[1]) - 0.2f, 0.0f) - pen);
-        } else if constexpr (ENV == METRPO_ENV_SNAKE) cost = -(v[7] - 1e-2f * 0.5f * su2);
+            for (int jj = 2; jj < NS; ++jj) pen += fmaxf(fabsf(v[jj]) - 100.0f, 0.0f);
+            cost = -(v[5] - 0.01f * 0.5f * su - 10.0f * fmaxf(0.45f - v[0], 0.0f) - 10.0f * fmaxf(fabsf(v[1]) - 0.2f, 0.0f) - pen);
+        } else if constexpr (ENV == METRPO_ENV_SNAKE) cost = -(v[7] - 1e-2f * 0.5f * su);
         else if constexpr (ENV == METRPO_ENV_ANT) {                   // cost_tf(..., dones) then the dones update (model_based_rl.py:134-137)
-            cost = -(v[15] - 1e-2f * 0.5f * su2 + 0.05f) * (1.0f - dones);
+            cost = -(v[15] - 1e-2f * 0.5f * su + 0.05f) * (1.0f - dones[j]);
             bool fin = true;
 #pragma unroll
             for (int i = 0; i < NS; ++i) fin = fin && isfinite(v[i]);
-            dones = fmaxf(dones, ((v[2] >= 0.2f) && (v[2] <= 1.0f) && fin) ? 0.0f : 1.0f);
+            dones[j] = fmaxf(dones[j], ((v[2] >= 0.2f) && (v[2] <= 1.0f) && fin) ? 0.0f : 1.0f);
         }
-        if (active) acc += gpow * (double)cost;
+        if (active[j]) acc[j] += gpow * (double)cost;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) s[j][i] = active[j] ? v[i] : 0.0f;
+        }
         gpow *= (double)z.gamma;
-#pragma unroll
-        for (int i = 0; i < NS; ++i) s[i] = active ? v[i] : 0.0f;
     }
-    // the tile's sum over its envs (lanes q = 0 hold one env each; fixed butterfly over the 16 c-lanes), / B
-    double t = (q == 0 && active) ? acc : 0.0;
+    // a tile's sum over its envs (lanes q = 0 hold one env each; fixed butterfly over the 16 c-lanes), / B
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-    if (lane == 0) z.det_part[(size_t)m * z.part_stride + z.part_off + w] = t / (double)z.Btot;
+    for (int j = 0; j < NTW; ++j) {
+        double t = (q == 0 && active[j]) ? acc[j] : 0.0;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        if (lane == 0 && live[j]) z.det_part[(size_t)mt_[j] * z.part_stride + z.part_off + gt[j] % z.NTM] = t / (double)z.Btot;
+    }
 }
 
-template <int ENV, int DH, int WS>
+template <int ENV, int DH, int WS, int NTW>
 __global__ void __launch_bounds__(256, 1) k_validation_resident(ProblemDesc pd, int B, ResidentK z, const float* __restrict__ dyn,
                                                                 const float* __restrict__ theta, const float* __restrict__ norm) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using C = Cfg<ENV, 64, 32>;
     if ((int)blockIdx.x < z.U) resident_compute_wide<C::NS, C::NIN, DH, WS>(pd, z, dyn, lds);
-    else resident_post_det<ENV>(pd, z, B, dyn, theta, norm, lds);
+    else resident_post_det<ENV, NTW>(pd, z, B, dyn, theta, norm, lds);
 }
 
 template <int ENV, int DH, int WS>
@@ -1029,8 +1051,13 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
 
 // ---- validation costs (metrpo_validation_cost) on the resident kernel's 4-wave form ------------------------------------------------------------
 typedef void (*resident_val_kernel_t)(ProblemDesc, int, ResidentK, const float*, const float*, const float*);
-struct ResidentValEntry { int env, ns, na, n_drop, dh, ws; resident_val_kernel_t fn; size_t lds; };
-#define RES_VAL_ENTRY(ENV, DH, WS) {ENV, EnvDim<ENV>::NS, EnvDim<ENV>::NA, EnvDim<ENV>::NDROP, DH, WS, k_validation_resident<ENV, DH, WS>, resident_lds_bytes_wide<ENV, DH, WS>()}
+struct ResidentValEntry { int env, ns, na, n_drop, dh, ws; resident_val_kernel_t fn[3]; size_t lds; };      // fn[i]: a post wave serves 1 << i tiles
+template <int ENV, int DH, int WS> static size_t resident_val_lds_bytes() {                                 // compute role | post role with four tiles per wave
+    using C = Cfg<ENV, 64, 32>;
+    return std::max(resident_lds_bytes_wide<ENV, DH, WS>(), (size_t)((C::NS_KS * 2 + 24) * 64 + 84 + 4 * 4 * (2 * 16 * C::NA)) * sizeof(float));
+}
+#define RES_VAL_ENTRY(ENV, DH, WS) {ENV, EnvDim<ENV>::NS, EnvDim<ENV>::NA, EnvDim<ENV>::NDROP, DH, WS, \
+    {k_validation_resident<ENV, DH, WS, 1>, k_validation_resident<ENV, DH, WS, 2>, k_validation_resident<ENV, DH, WS, 4>}, resident_val_lds_bytes<ENV, DH, WS>()}
 // METRPO_EUNSUPPORTED: this shape stays on the step-wise sweep (det_gemm.hip)
 int launch_validation_resident(metrpo_ctx* c, const float* s0, int Bv, int T, double gamma, double* costs, hipStream_t st) {
     static const ResidentValEntry tab[] = {
@@ -1053,21 +1080,28 @@ int launch_validation_resident(metrpo_ctx* c, const float* s0, int Bv, int T, do
     // per (model, tile), four per workgroup).  The batch goes in nb chunks, one launch each: fewer tiles per launch need fewer post workgroups and
     // leave room for a third column -- 500 envs: one launch = 2 columns of 16 tiles per step, three launches = 3 x (3 columns of 4).
     const int NSL = DH / e->ws, PW = 4;
-    // Cost of a step (us): a column's tiles at the measured tile time (1.5 at 2 x 512 / 32-unit slices, 6.1 at 2 x 1024 / 64), but never less than a
-    // tile's round trip through the post wave (8), per chunk; plus the launch's prologue (~60 us: weight fragments, LDS images) spread over the T steps.
-    int nb = 0, NTM = 0, NTC = 0, cols = 0;
+    // Cost of a step (us): a column's tiles at the measured tile time (2.0 at 2 x 512 / 32-unit slices, 6.1 at 2 x 1024 / 64), but never less than a
+    // tile's round trip through its post wave (8, plus 3 for every further tile the wave serves first), per chunk; plus the launch's prologue
+    // (~60 us: weight fragments, LDS images) spread over the T steps.  A post wave serving several tiles frees CUs for another column.
+    int nb = 0, NTM = 0, NTC = 0, cols = 0, ntw_i = 0;
     double best = 1e30;
-    const double t_tile = (DH >= 1024) ? 6.1 : 1.5, t_trip = 8.0, t_launch = 60.0;
-    for (int n = 1; n <= 8; ++n) {
-        const int bc = (Bv + n - 1) / n, ntm = (bc + 15) / 16, post = (K * ntm + PW - 1) / PW;
-        const int ncol = std::min(ntm, (c->n_sm - post) / (K * NSL));
-        if (ncol < 1) continue;
-        const int ntc = (ntm + ncol - 1) / ncol;
-        const double cost = n * (std::max(ntc * t_tile, t_trip) + t_launch / T);
-        if (cost < best - 1e-9) { best = cost; nb = n; NTM = ntm; NTC = ntc; cols = (ntm + ntc - 1) / ntc; }
+    const double t_tile = (DH >= 1024) ? 6.1 : 2.0, t_trip = 8.0, t_post = 3.0, t_launch = 60.0;
+    const char* ntw_env = getenv("METRPO_VAL_TILES_PER_WAVE");              // test hook: 1 | 2 | 4
+    for (int wi = 0; wi < 3; ++wi) {
+        const int ntw = 1 << wi;
+        if (ntw_env != nullptr && atoi(ntw_env) != ntw) continue;
+        for (int n = 1; n <= 8; ++n) {
+            const int bc = (Bv + n - 1) / n, ntm = (bc + 15) / 16, post = ((K * ntm + ntw - 1) / ntw + PW - 1) / PW;
+            const int ncol = std::min(ntm, (c->n_sm - post) / (K * NSL));
+            if (ncol < 1) continue;
+            const int ntc = (ntm + ncol - 1) / ncol;
+            const double cost = n * (std::max(std::max(ntc * t_tile, t_trip + (ntw - 1) * t_post), ntw * t_post * 1.5) + t_launch / T);
+            if (cost < best - 1e-9) { best = cost; nb = n; NTM = ntm; NTC = ntc; cols = (ntm + ntc - 1) / ntc; ntw_i = wi; }
+        }
     }
     if (nb == 0) return METRPO_EUNSUPPORTED;
-    const int Bc = (Bv + nb - 1) / nb, G = K * NTM, post_blocks = (G + PW - 1) / PW;
+    const int NTW = 1 << ntw_i;
+    const int Bc = (Bv + nb - 1) / nb, G = K * NTM, post_blocks = ((G + NTW - 1) / NTW + PW - 1) / PW;
     const int OUT_CB = (pd.ns + 15) / 16, NIN_KS = (pd.nin + 1 + 3) / 4;
     const size_t nX = (size_t)G * 4 * NIN_KS * 16, nP = (size_t)G * K * NSL * 16 * OUT_CB * 16;
     const size_t need = (nX + nP + 32) * sizeof(unsigned long long);
@@ -1083,7 +1117,7 @@ int launch_validation_resident(metrpo_ctx* c, const float* s0, int Bv, int T, do
         c->res_seq = 0;
     }
     { const int rc = ensure_detpart_n(c, (size_t)K * nb * NTM); if (rc) return rc; }
-    if (e->lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)e->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds));
+    if (e->lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)e->fn[ntw_i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds));
     for (int ch = 0; ch < nb; ++ch) {
         const int b_lo = ch * Bc, bn = std::min(Bc, Bv - b_lo);
         ResidentK z;
@@ -1095,7 +1129,7 @@ int launch_validation_resident(metrpo_ctx* c, const float* s0, int Bv, int T, do
         z.abort_cell = (unsigned int*)c->d_res;
         z.X = (unsigned long long*)c->d_res + 32; z.P = z.X + nX;
         z.err = comm_err_cell(c) + 1;
-        hipLaunchKernelGGL(e->fn, dim3(z.U + post_blocks), dim3(256), e->lds, st, pd, std::max(bn, 0), z, c->d_dyn, c->d_theta, c->d_norm);
+        hipLaunchKernelGGL(e->fn[ntw_i], dim3(z.U + post_blocks), dim3(256), e->lds, st, pd, std::max(bn, 0), z, c->d_dyn, c->d_theta, c->d_norm);
     }
     HIP_TRY(c, hipGetLastError());
     return launch_det_cost_reduce(c, nb * NTM, c->d_detpart, costs, st);

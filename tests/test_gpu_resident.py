@@ -296,3 +296,7 @@ def test_resident_validation_costs_against_oracle_and_the_stepwise_sweep(env, hi
     assert not np.array_equal(got, sweep)                                 # two different kernels did run (their float32 sums differ in the last bits)
     again = cpu(eng.validation_cost(s0, T, gamma))
     np.testing.assert_array_equal(got, again)                             # bitwise repeatable
+    for ntw in (1, 2, 4):                                                 # tiles per post wave (the launcher picks by a cost model): same sums whatever the deal
+        monkeypatch.setenv('METRPO_VAL_TILES_PER_WAVE', str(ntw))
+        np.testing.assert_allclose(cpu(eng.validation_cost(s0, T, gamma)), got, rtol=1e-6, atol=1e-6)
+    eng.comm_check()
