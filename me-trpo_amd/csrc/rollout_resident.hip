@@ -1087,10 +1087,12 @@ int launch_validation_resident(metrpo_ctx* c, const float* s0, int Bv, int T, do
     double best = 1e30;
     const double t_tile = (DH >= 1024) ? 6.1 : 2.0, t_trip = 8.0, t_post = 3.0, t_launch = 60.0;
     const char* ntw_env = getenv("METRPO_VAL_TILES_PER_WAVE");              // test hook: 1 | 2 | 4
+    const char* chunks_env = getenv("METRPO_VAL_CHUNKS");                   // test hook: number of batch chunks (launches), 1 .. 8
     for (int wi = 0; wi < 3; ++wi) {
         const int ntw = 1 << wi;
         if (ntw_env != nullptr && atoi(ntw_env) != ntw) continue;
         for (int n = 1; n <= 8; ++n) {
+            if (chunks_env != nullptr && atoi(chunks_env) != n) continue;
             const int bc = (Bv + n - 1) / n, ntm = (bc + 15) / 16, post = ((K * ntm + ntw - 1) / ntw + PW - 1) / PW;
             const int ncol = std::min(ntm, (c->n_sm - post) / (K * NSL));
             if (ncol < 1) continue;

@@ -299,4 +299,9 @@ def test_resident_validation_costs_against_oracle_and_the_stepwise_sweep(env, hi
     for ntw in (1, 2, 4):                                                 # tiles per post wave (the launcher picks by a cost model): same sums whatever the deal
         monkeypatch.setenv('METRPO_VAL_TILES_PER_WAVE', str(ntw))
         np.testing.assert_allclose(cpu(eng.validation_cost(s0, T, gamma)), got, rtol=1e-6, atol=1e-6)
+    monkeypatch.delenv('METRPO_VAL_TILES_PER_WAVE')
+    for nb in (2, 3, 5):                                                  # the batch in chunks (one launch each; the last one ragged)
+        if Bv >= nb:
+            monkeypatch.setenv('METRPO_VAL_CHUNKS', str(nb))
+            np.testing.assert_allclose(cpu(eng.validation_cost(s0, T, gamma)), got, rtol=1e-6, atol=1e-6)
     eng.comm_check()
