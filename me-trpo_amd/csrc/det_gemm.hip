@@ -9,9 +9,11 @@
 //                  mean-adjoint output, policy input VJP)
 #include "gemm_mfma.h"
 #include "mfma_common.h"
+#include "policy_chain3.h"
 
 struct DgState {
     float *S, *X, *U, *MU, *OUT, *G, *DZa, *DZb, *LAM, *DONES, *PART;
+    float* PIMG;                        // k_dg_pre_mfma3: the policy's fragment image (policy_chain3.h), built at the start of a sweep
     float* H[MAXL];
     double* ACC;
     // forward sweep: output layer left as partials (split-K, or one per 64 / 128-column block of the last hidden layer when that layer's launch
@@ -127,8 +129,59 @@ __global__ void __launch_bounds__(256) k_dg_pre_mfma(ProblemDesc pd, int B, cons
     }
 }
 
+// MFMA variant of k_dg_pre for three-hidden-layer tanh policies (Humanoid's 100-50-25; policy_chain3.h): the thread-per-row k_dg_pre walks that
+// policy's 12 275 weights through scalar loads, 253 us per step whatever the batch -- 70 % of a validation-cost evaluation at the
+// params-humanoid.json shape.  grid = (ceil(B/64), K) blocks of 4 waves, dynamic LDS = image + state tiles.
+template <int NS, int NA, int NDROP, int W1, int W2, int W3>
+__global__ void __launch_bounds__(256) k_dg_pre_mfma3(ProblemDesc pd, int B, const float* __restrict__ theta, const float* __restrict__ norm,
+                                                      const float* __restrict__ xs_t, long long xs_model_stride, DgState st) {
+    using PC = P3<NS, NA, W1, W2, W3>;
+    constexpr int CO = PC::CO, IMG = PC::IMG, NIN = NS - NDROP + NA;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int k = blockIdx.y;
+    const int b0 = (blockIdx.x * 4 + wave) * 16, b = b0 + c;
+    const bool active = b < B;
+    float* ST = lds + IMG + wave * 16 * NS;
+    PC::load_image(lds, st.PIMG, tid);
+    const size_t row0 = (size_t)k * B + b0;
+    const float* src = (xs_t != nullptr) ? xs_t + (size_t)k * xs_model_stride + (size_t)b0 * NS : st.S + row0 * NS;
+    const int lim = min(16, max(0, B - b0)) * NS;
+    for (int i = lane; i < 16 * NS; i += 64) {
+        const float v = (i < lim) ? src[i] : 0.0f;
+        ST[i] = v;
+        if (xs_t != nullptr && i < lim) st.S[row0 * NS + i] = v;
+    }
+    __syncthreads();
+    f32x4 mu[CO];
+    PC::forward(lds, ST, lane, c, q, mu);
+    if (!active) return;
+    const size_t row = (size_t)k * B + b;
+    const float* in_mean = norm; const float* in_std = norm + (NS + NA);
+    for (int i = q; i < NS; i += 4) if (i >= NDROP) st.X[row * NIN + i - NDROP] = (ST[c * NS + i] - in_mean[i]) / in_std[i];
+#pragma unroll
+    for (int cb = 0; cb < CO; ++cb)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int d = 16 * cb + 4 * q + rr;
+            if (d < NA) {
+                const float ac = fminf(fmaxf(mu[cb][rr], -1.0f), 1.0f);                       // model_based_rl.py:128
+                st.MU[row * NA + d] = mu[cb][rr]; st.U[row * NA + d] = ac;
+                st.X[row * NIN + (NS - NDROP) + d] = (ac - in_mean[NS + d]) / in_std[NS + d];
+            }
+        }
+}
+
 typedef void (*dg_pre_mfma_t)(ProblemDesc, int, const float*, const float*, const float*, long long, DgState);
-static dg_pre_mfma_t dg_pre_mfma_select(const ProblemDesc& pd) {
+static dg_pre_mfma_t dg_pre_mfma_select(const ProblemDesc& pd, size_t* dyn_lds = nullptr) {
+    if (dyn_lds) *dyn_lds = 0;
+    if (dyn_lds && pd.env == METRPO_ENV_HUMANOID && pd.ns == 55 && pd.na == 21 && pd.n_drop == 0 && pd.pol.n_layers == 4 && pd.pol.dims[1] == 100 &&
+        pd.pol.dims[2] == 50 && pd.pol.dims[3] == 25 && pd.pol.act[0] == METRPO_ACT_TANH && pd.pol.act[1] == METRPO_ACT_TANH && pd.pol.act[2] == METRPO_ACT_TANH &&
+        getenv("METRPO_NO_PRE_MFMA3") == nullptr) {
+        *dyn_lds = sizeof(float) * (size_t)(P3<55, 21, 100, 50, 25>::IMG + 4 * 16 * 55);
+        return k_dg_pre_mfma3<55, 21, 0, 100, 50, 25>;
+    }
     if (pd.pol.n_layers != 3 || pd.pol.dims[1] != 32 || pd.pol.dims[2] != 32 || pd.pol.act[0] != METRPO_ACT_TANH) return nullptr;
     switch (pd.env) {
     case METRPO_ENV_SWIMMER: return (pd.ns == 10 && pd.na == 2 && pd.n_drop == 2) ? k_dg_pre_mfma<METRPO_ENV_SWIMMER> : nullptr;
@@ -354,7 +407,8 @@ static int dg_workspace(metrpo_ctx* c, int B, DgState* s) {
     size_t nP = 0;
     for (int l = 0; l < L; ++l) nP = std::max(nP, up4(skinny_part_floats(B, pd.dyn.dims[l + 1], pd.dyn.dims[l], K)));
     if (const int ft = dg_fuse_tile(c, B)) nP = std::max(nP, up4(gemm_fused_out_part_floats(B, pd.dyn.dims[L - 1], K, pd.ns, ft)));
-    const size_t need = (4 * nS + nX + 2 * nU + nH + 2 * nZ + nD + nP) * sizeof(float) + R * sizeof(double) + 64;
+    const size_t nPimg = up4((size_t)pre_mfma3_image_floats<55, 21, 100, 50, 25>());     // the one three-hidden-layer policy with an MFMA pre-step (dg_pre_mfma_select): 67 KB
+    const size_t need = (4 * nS + nX + 2 * nU + nH + 2 * nZ + nD + nP + nPimg) * sizeof(float) + R * sizeof(double) + 64;
     if (need > c->dg_cap) {
         if (c->d_dg) HIP_TRY(c, hipFree(c->d_dg));
         c->d_dg = nullptr; c->dg_cap = 0;
@@ -364,7 +418,7 @@ static int dg_workspace(metrpo_ctx* c, int B, DgState* s) {
     float* p = (float*)c->d_dg;
     s->S = p; p += nS; s->OUT = p; p += nS; s->G = p; p += nS; s->LAM = p; p += nS; s->X = p; p += nX; s->U = p; p += nU; s->MU = p; p += nU;
     for (int l = 1; l < L; ++l) { s->H[l - 1] = p; p += up4(R * pd.dyn.dims[l]); }
-    s->DZa = p; p += nZ; s->DZb = p; p += nZ; s->DONES = p; p += nD; s->PART = nP ? p : nullptr; p += nP;
+    s->DZa = p; p += nZ; s->DZb = p; p += nZ; s->DONES = p; p += nD; s->PART = nP ? p : nullptr; p += nP; s->PIMG = p; p += nPimg;
     s->ACC = (double*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
     return METRPO_OK;
 }
@@ -412,9 +466,14 @@ int launch_dg_forward(metrpo_ctx* c, const float* s0, int B, int T, double gamma
     if (psh > 160 * 1024) return set_err(c, METRPO_EUNSUPPORTED, "policy too wide for k_dg_pre");
     if (psh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_dg_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psh));
     double g = 1.0;
-    const dg_pre_mfma_t pre_mfma = dg_pre_mfma_select(pd);
+    size_t pre_lds = 0;
+    const dg_pre_mfma_t pre_mfma = dg_pre_mfma_select(pd, &pre_lds);
+    if (pre_lds) {
+        hipLaunchKernelGGL((k_pre_mfma3_image<55, 21, 100, 50, 25>), dim3((unsigned)((P3<55, 21, 100, 50, 25>::IMG + 255) / 256)), dim3(256), 0, st, c->d_theta, s.PIMG);
+        if (pre_lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)pre_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pre_lds));
+    }
     for (int t = 0; t < T; ++t) {
-        if (pre_mfma) hipLaunchKernelGGL(pre_mfma, dim3((B + 63) / 64, K), dim3(256), 0, st, pd, B, c->d_theta, c->d_norm, (const float*)nullptr, 0LL, s);
+        if (pre_mfma) hipLaunchKernelGGL(pre_mfma, dim3((B + 63) / 64, K), dim3(256), pre_lds, st, pd, B, c->d_theta, c->d_norm, (const float*)nullptr, 0LL, s);
         else hipLaunchKernelGGL(k_dg_pre, dim3((B + pbs - 1) / pbs, K), dim3(pbs), psh, st, pd, B, c->d_theta, c->d_norm, (const float*)nullptr, 0LL, s);
         dg_forward_layers(c, s, B, L, true, st);
         hipLaunchKernelGGL(k_dg_post, dim3((B + DG_POST_ROWS - 1) / DG_POST_ROWS, K), dim3(DG_POST_THREADS), 0, st, pd, B, T, t, g, c->d_norm, s, XS, WT);
@@ -441,9 +500,14 @@ int launch_dg_backward(metrpo_ctx* c, int B, int T, const float* XS, const float
     if (psh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_dg_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psh));
     if (bsh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_dg_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bsh));
     const long long xs_model = (long long)(T + 1) * B * pd.ns;
-    const dg_pre_mfma_t pre_mfma = dg_pre_mfma_select(pd);
+    size_t pre_lds = 0;
+    const dg_pre_mfma_t pre_mfma = dg_pre_mfma_select(pd, &pre_lds);
+    if (pre_lds) {
+        hipLaunchKernelGGL((k_pre_mfma3_image<55, 21, 100, 50, 25>), dim3((unsigned)((P3<55, 21, 100, 50, 25>::IMG + 255) / 256)), dim3(256), 0, st, c->d_theta, s.PIMG);
+        if (pre_lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)pre_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pre_lds));
+    }
     for (int t = T - 1; t >= 0; --t) {
-        if (pre_mfma) hipLaunchKernelGGL(pre_mfma, dim3((B + 63) / 64, K), dim3(256), 0, st, pd, B, c->d_theta, c->d_norm, XS + (size_t)t * B * pd.ns, xs_model, s);
+        if (pre_mfma) hipLaunchKernelGGL(pre_mfma, dim3((B + 63) / 64, K), dim3(256), pre_lds, st, pd, B, c->d_theta, c->d_norm, XS + (size_t)t * B * pd.ns, xs_model, s);
         else hipLaunchKernelGGL(k_dg_pre, dim3((B + pbs - 1) / pbs, K), dim3(pbs), psh, st, pd, B, c->d_theta, c->d_norm,
                                 XS + (size_t)t * B * pd.ns, xs_model, s);
         dg_forward_layers(c, s, B, L - 1, false, st);                             // hidden activations only

@@ -11,6 +11,7 @@
 #include <thread>
 #include "gemm_mfma.h"
 #include "mfma_common.h"
+#include "policy_chain3.h"
 
 // ------------------------------------------------------------------------------------------------
 struct BigState { float* S; int* ts; int* cur_model; float* X; float* U; float* HA; float* HB; float* OUT; float* PART;
@@ -197,34 +198,6 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
     }
 }
 
-// fragment image of a three-hidden-layer tanh policy for k_big_pre_mfma3.  Layer l's k-step kk contracts, in lane (cc, qq), input unit
-// 16 (kk >> 2) + 4 qq + (kk & 3): the D-fragment order of the previous layer's output (register kk & 3 of tile kk >> 2), so nothing is transposed
-// between layers.  [layer-0 fragments | layer 1 | layer 2 | output layer | b0 | b1 | b2 | b3], widths padded to 16 with zeros.
-template <int NS, int NA, int W1, int W2, int W3>
-__global__ void k_pre_mfma3_image(const float* __restrict__ theta, float* __restrict__ img) {
-    constexpr int NS_KS = cdiv(NS, 4), C1 = cdiv(W1, 16), C2 = cdiv(W2, 16), C3 = cdiv(W3, 16), CO = cdiv(NA, 16);
-    constexpr int pW0 = 0, pb0 = NS * W1, pW1 = pb0 + W1, pb1 = pW1 + W1 * W2, pW2 = pb1 + W2, pb2 = pW2 + W2 * W3, pW3 = pb2 + W3, pb3 = pW3 + W3 * NA;
-    constexpr int O_F0 = 0, O_F1 = O_F0 + NS_KS * C1 * 64, O_F2 = O_F1 + 4 * C1 * C2 * 64, O_F3 = O_F2 + 4 * C2 * C3 * 64, O_B0 = O_F3 + 4 * C3 * CO * 64,
-                  O_B1 = O_B0 + 16 * C1, O_B2 = O_B1 + 16 * C2, O_B3 = O_B2 + 16 * C3, IMG = O_B3 + 16 * CO;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= IMG) return;
-    float w = 0.0f;
-    const int ln = i & 63, cc = ln & 15, qq = ln >> 4;
-    if (i < O_F1) { const int f = i >> 6, s_ = f / C1, cb = f % C1, in = 4 * s_ + qq, u = 16 * cb + cc; if (in < NS && u < W1) w = theta[pW0 + in * W1 + u]; }
-    else if (i < O_F2) { const int f = (i - O_F1) >> 6, kk = f / C2, cb = f % C2, in = 16 * (kk >> 2) + 4 * qq + (kk & 3), u = 16 * cb + cc; if (in < W1 && u < W2) w = theta[pW1 + in * W2 + u]; }
-    else if (i < O_F3) { const int f = (i - O_F2) >> 6, kk = f / C3, cb = f % C3, in = 16 * (kk >> 2) + 4 * qq + (kk & 3), u = 16 * cb + cc; if (in < W2 && u < W3) w = theta[pW2 + in * W3 + u]; }
-    else if (i < O_B0) { const int f = (i - O_F3) >> 6, kk = f / CO, cb = f % CO, in = 16 * (kk >> 2) + 4 * qq + (kk & 3), u = 16 * cb + cc; if (in < W3 && u < NA) w = theta[pW3 + in * NA + u]; }
-    else if (i < O_B1) { const int u = i - O_B0; if (u < W1) w = theta[pb0 + u]; }
-    else if (i < O_B2) { const int u = i - O_B1; if (u < W2) w = theta[pb1 + u]; }
-    else if (i < O_B3) { const int u = i - O_B2; if (u < W3) w = theta[pb2 + u]; }
-    else { const int u = i - O_B3; if (u < NA) w = theta[pb3 + u]; }
-    img[i] = w;
-}
-template <int NS, int NA, int W1, int W2, int W3> constexpr int pre_mfma3_image_floats() {
-    return (cdiv(NS, 4) * cdiv(W1, 16) + 4 * cdiv(W1, 16) * cdiv(W2, 16) + 4 * cdiv(W2, 16) * cdiv(W3, 16) + 4 * cdiv(W3, 16) * cdiv(NA, 16)) * 64 +
-           16 * (cdiv(W1, 16) + cdiv(W2, 16) + cdiv(W3, 16) + cdiv(NA, 16));
-}
-
 // MFMA pre-kernel for tanh policies with THREE hidden layers (Humanoid's 100-50-25, params-humanoid.json): the same transposed chain as
 // k_big_pre_mfma, every width padded to whole 16-unit tiles (zero weights, tanh(0) = 0 meets zero rows of the next layer).  One wave per 16-env
 // tile: NS_KS C1 + 4 C1 C2 + 4 C2 C3 + 4 C3 CO matrix instructions (258 for Humanoid) instead of the gather -> four small GEMMs -> action
@@ -232,10 +205,8 @@ template <int NS, int NA, int W1, int W2, int W3> constexpr int pre_mfma3_image_
 template <int NS, int NA, int NDROP, int W1, int W2, int W3>
 __global__ void __launch_bounds__(256) k_big_pre_mfma3(ProblemDesc pd, RolloutK r, int t, const float* __restrict__ theta,
                                                        const float* __restrict__ norm, BigState st) {
-    constexpr int NS_KS = cdiv(NS, 4), C1 = cdiv(W1, 16), C2 = cdiv(W2, 16), C3 = cdiv(W3, 16), CO = cdiv(NA, 16), NIN = NS - NDROP + NA;
-    constexpr int pLS = NS * W1 + W1 + W1 * W2 + W2 + W2 * W3 + W3 + W3 * NA + NA;      // rllab's flat order [W0, b0, ..., Wout, bout, log_std]
-    constexpr int O_F0 = 0, O_F1 = O_F0 + NS_KS * C1 * 64, O_F2 = O_F1 + 4 * C1 * C2 * 64, O_F3 = O_F2 + 4 * C2 * C3 * 64, O_B0 = O_F3 + 4 * C3 * CO * 64,
-                  O_B1 = O_B0 + 16 * C1, O_B2 = O_B1 + 16 * C2, O_B3 = O_B2 + 16 * C3, IMG = O_B3 + 16 * CO;
+    using PC = P3<NS, NA, W1, W2, W3>;
+    constexpr int CO = PC::CO, IMG = PC::IMG, pLS = PC::pLS, NIN = NS - NDROP + NA;
     extern __shared__ __attribute__((aligned(16))) float lds[];       // image, then [4 waves][16 envs][NS] state tiles
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
@@ -243,17 +214,7 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma3(ProblemDesc pd, RolloutK 
     const bool active = b < r.B;
     float* ST = lds + IMG + wave * 16 * NS;
     if (r.stop != nullptr && *r.stop != 0) return;
-    // fragment image: built once per launch chain by k_pre_mfma3_image (one element per thread there; filled here element by element it was 65
-    // dependent L2 round trips per thread and step), copied with 16-byte loads
-    static_assert(IMG % 4 == 0, "image tables are multiples of 16 floats");
-    {
-        constexpr int NQ = IMG / 4, NIT = cdiv(NQ, 256);
-        float4 w4[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) { const int i = it * 256 + tid; w4[it] = (i < NQ) ? ((const float4*)st.PIMG)[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) { const int i = it * 256 + tid; if (i < NQ) ((float4*)lds)[i] = w4[it]; }
-    }
+    PC::load_image(lds, st.PIMG, tid);                           // built once per launch chain (k_pre_mfma3_image)
     const uint64_t genv = r.stream_offset + (uint64_t)RK_ENV(r, b);
     const int tt = t + RK_TOFF(r, b);
     if (t == 0 && active && q == 0 && r.init_obs != nullptr) {   // continuation of a chunked rollout / merged rounds
@@ -274,46 +235,8 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma3(ProblemDesc pd, RolloutK 
         const int bi = b0 + i / NS;
         r.obs[((size_t)(t + RK_TOFF(r, bi)) * RK_STRIDE(r) + RK_ENV(r, bi)) * NS + i % NS] = ST[i];
     }
-    f32x4 p0[C1], p1[C2], p2[C3], mu[CO];
-#pragma unroll
-    for (int cb = 0; cb < C1; ++cb) p0[cb] = *(const f32x4*)&lds[O_B0 + 16 * cb + 4 * q];
-#pragma unroll
-    for (int s_ = 0; s_ < NS_KS; ++s_) {
-        const int f = 4 * s_ + q;
-        const float x = (f < NS) ? ST[c * NS + f] : 0.0f;
-#pragma unroll
-        for (int cb = 0; cb < C1; ++cb) p0[cb] = MFMA16(lds[O_F0 + (s_ * C1 + cb) * 64 + lane], x, p0[cb]);
-    }
-#pragma unroll
-    for (int cb = 0; cb < C1; ++cb)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) p0[cb][rr] = tanh_fast(p0[cb][rr]);
-#pragma unroll
-    for (int cb = 0; cb < C2; ++cb) p1[cb] = *(const f32x4*)&lds[O_B1 + 16 * cb + 4 * q];
-#pragma unroll
-    for (int kk = 0; kk < 4 * C1; ++kk)
-#pragma unroll
-        for (int cb = 0; cb < C2; ++cb) p1[cb] = MFMA16(lds[O_F1 + (kk * C2 + cb) * 64 + lane], p0[kk >> 2][kk & 3], p1[cb]);
-#pragma unroll
-    for (int cb = 0; cb < C2; ++cb)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) p1[cb][rr] = tanh_fast(p1[cb][rr]);
-#pragma unroll
-    for (int cb = 0; cb < C3; ++cb) p2[cb] = *(const f32x4*)&lds[O_B2 + 16 * cb + 4 * q];
-#pragma unroll
-    for (int kk = 0; kk < 4 * C2; ++kk)
-#pragma unroll
-        for (int cb = 0; cb < C3; ++cb) p2[cb] = MFMA16(lds[O_F2 + (kk * C3 + cb) * 64 + lane], p1[kk >> 2][kk & 3], p2[cb]);
-#pragma unroll
-    for (int cb = 0; cb < C3; ++cb)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) p2[cb][rr] = tanh_fast(p2[cb][rr]);
-#pragma unroll
-    for (int cb = 0; cb < CO; ++cb) mu[cb] = *(const f32x4*)&lds[O_B3 + 16 * cb + 4 * q];
-#pragma unroll
-    for (int kk = 0; kk < 4 * C3; ++kk)
-#pragma unroll
-        for (int cb = 0; cb < CO; ++cb) mu[cb] = MFMA16(lds[O_F3 + (kk * CO + cb) * 64 + lane], p2[kk >> 2][kk & 3], mu[cb]);
+    f32x4 mu[CO];
+    PC::forward(lds, ST, lane, c, q, mu);
     if (!active) return;
     const size_t tb = (size_t)tt * RK_STRIDE(r) + RK_ENV(r, b);
     const float* in_mean = norm; const float* in_std = norm + (NS + NA);
@@ -347,8 +270,7 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma3(ProblemDesc pd, RolloutK 
         }
 }
 template <int NS, int NA, int NDROP, int W1, int W2, int W3> constexpr size_t big_pre_mfma3_lds() {
-    constexpr int NS_KS = cdiv(NS, 4), C1 = cdiv(W1, 16), C2 = cdiv(W2, 16), C3 = cdiv(W3, 16), CO = cdiv(NA, 16);
-    return sizeof(float) * (size_t)((NS_KS * C1 + 4 * C1 * C2 + 4 * C2 * C3 + 4 * C3 * CO) * 64 + 16 * (C1 + C2 + C3 + CO) + 4 * 16 * NS);
+    return sizeof(float) * (size_t)(P3<NS, NA, W1, W2, W3>::IMG + 4 * 16 * NS);
 }
 
 // ---- pre-step for policies without an MFMA pre-kernel at LARGE batch (Humanoid's 100-50-25 at B = 6250): the policy layers run as GEMMs over
