@@ -13,7 +13,9 @@
  *  - every pointer named `d_*` is DEVICE memory owned by the caller (e.g. torch `data_ptr()`);
  *    the library never frees or retains it past the call, except the `set_*` calls which COPY.
  *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, calls return
- *    without synchronising unless documented.  One ctx per GPU, one host thread per ctx.
+ *    without synchronising unless documented.  One ctx per GPU, one host thread per ctx, and the
+ *    calls of a ctx on ONE stream at a time (they share ctx-owned workspaces: work of the same ctx
+ *    enqueued on two streams is not ordered against itself).
  *  - all functions return 0 (METRPO_OK) or a negative metrpo_status; no exception or abort
  *    crosses the ABI; metrpo_last_error() gives the message for the last failure on a ctx.
  *  - arithmetic is float32 on device (TF graph dtype of the reference); CG vectors, reductions
