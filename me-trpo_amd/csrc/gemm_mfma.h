@@ -35,7 +35,11 @@ struct GemmEpi {                 // epilogue operands (unused fields may be null
     const float* w2; long long strideW2; int no;
 };
 
-template <int TM, int TN, int EPI, bool TA, bool TB, bool AL>
+// PD = prefetch distance of the global loads in k-tiles (register sets in flight).  1: the next tile's loads fly under this tile's MFMAs -- enough when
+// eight workgroups per CU hide each other's latency.  4 (64x64 tiles only): for launches of a few workgroups per CU (M = 100 .. 1000 rows: the
+// params-file shapes of the training step, the merged-round rollouts and the deterministic sweeps), where a k-tile's eight MFMAs per wave
+// (0.2 us) cannot cover an L2 / HBM round trip and the kernel ran at the latency of one workgroup's 32-64 dependent k-tiles.  Same k order: same sums.
+template <int TM, int TN, int EPI, bool TA, bool TB, bool AL, int PD = 1>
 __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, long long strideA, int lda,
                                                    const float* __restrict__ W, long long strideW, int ldw,
                                                    float* __restrict__ C, long long strideC, int ldc, int M, int N, int Kd, GemmEpi ep) {
@@ -87,7 +91,7 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
     constexpr int DA_R = 256 / (BM / 4), DA_P = BK / DA_R;                 // direct A: rows per pass, passes
     constexpr int DB_R = 256 / (BN / 4), DB_P = BK / DB_R;                 // direct B
     constexpr int NA = TA ? DA_P : SA_P, NB = TB ? SB_P : DB_P;
-    float4 ra[NA], rb[NB];
+    float4 ra[PD][NA], rb[PD][NB];
 
     // AL (host-checked: every base pointer, leading dimension and head stride is a multiple of 4 floats and so are the extents along the
     // contiguous axes): a quad is either fully inside or fully outside -> one predicated 16-byte load, no alignment test, no scalar tail.
@@ -101,54 +105,54 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
         if (have > 3) v.w = src[3];
         return v;
     };
-    auto load_tiles = [&](int k0) {
+    auto load_tiles = [&](int k0, int set) {                       // `set` is a constant wherever this is inlined (unrolled callers)
         if (!TA) {
 #pragma unroll
             for (int p = 0; p < SA_P; ++p) {                       // 4 consecutive lanes read the 4 quads (64 B) of one row
                 const int kq = (tid & 3) * 4, m = m0 + (tid >> 2) + p * 64;
-                ra[p] = (m < M) ? ld4(A + (size_t)m * lda + k0 + kq, kend - (k0 + kq)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                ra[set][p] = (m < M) ? ld4(A + (size_t)m * lda + k0 + kq, kend - (k0 + kq)) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
 #pragma unroll
             for (int p = 0; p < DA_P; ++p) {
                 const int k = k0 + tid / (BM / 4) + p * DA_R, m = m0 + (tid % (BM / 4)) * 4;
-                ra[p] = (k < kend) ? ld4(A + (size_t)k * lda + m, M - m) : make_float4(0.f, 0.f, 0.f, 0.f);
+                ra[set][p] = (k < kend) ? ld4(A + (size_t)k * lda + m, M - m) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         if (!TB) {
 #pragma unroll
             for (int p = 0; p < DB_P; ++p) {
                 const int k = k0 + tid / (BN / 4) + p * DB_R, n = n0 + (tid % (BN / 4)) * 4;
-                rb[p] = (k < kend) ? ld4(W + (size_t)k * ldw + n, N - n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[set][p] = (k < kend) ? ld4(W + (size_t)k * ldw + n, N - n) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
 #pragma unroll
             for (int p = 0; p < SB_P; ++p) {
                 const int kq = (tid & 3) * 4, n = n0 + (tid >> 2) + p * 64;
-                rb[p] = (n < N) ? ld4(W + (size_t)n * ldw + k0 + kq, kend - (k0 + kq)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[set][p] = (n < N) ? ld4(W + (size_t)n * ldw + k0 + kq, kend - (k0 + kq)) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, int set) {
         if (!TA) {
 #pragma unroll
             for (int p = 0; p < SA_P; ++p) {
                 const int kq = (tid & 3) * 4, m = (tid >> 2) + p * 64;
-                if constexpr (AKM) *(float4*)&As[buf][m][kq] = ra[p];
-                else { As[buf][kq + 0][m] = ra[p].x; As[buf][kq + 1][m] = ra[p].y; As[buf][kq + 2][m] = ra[p].z; As[buf][kq + 3][m] = ra[p].w; }
+                if constexpr (AKM) *(float4*)&As[buf][m][kq] = ra[set][p];
+                else { As[buf][kq + 0][m] = ra[set][p].x; As[buf][kq + 1][m] = ra[set][p].y; As[buf][kq + 2][m] = ra[set][p].z; As[buf][kq + 3][m] = ra[set][p].w; }
             }
         } else {
 #pragma unroll
-            for (int p = 0; p < DA_P; ++p) *(float4*)&As[buf][tid / (BM / 4) + p * DA_R][(tid % (BM / 4)) * 4] = ra[p];
+            for (int p = 0; p < DA_P; ++p) *(float4*)&As[buf][tid / (BM / 4) + p * DA_R][(tid % (BM / 4)) * 4] = ra[set][p];
         }
         if (!TB) {
 #pragma unroll
-            for (int p = 0; p < DB_P; ++p) *(float4*)&Bs[buf][tid / (BN / 4) + p * DB_R][(tid % (BN / 4)) * 4] = rb[p];
+            for (int p = 0; p < DB_P; ++p) *(float4*)&Bs[buf][tid / (BN / 4) + p * DB_R][(tid % (BN / 4)) * 4] = rb[set][p];
         } else {
 #pragma unroll
             for (int p = 0; p < SB_P; ++p) {
                 const int kq = (tid & 3) * 4, n = (tid >> 2) + p * 64;
-                Bs[buf][kq + 0][n] = rb[p].x; Bs[buf][kq + 1][n] = rb[p].y; Bs[buf][kq + 2][n] = rb[p].z; Bs[buf][kq + 3][n] = rb[p].w;
+                Bs[buf][kq + 0][n] = rb[set][p].x; Bs[buf][kq + 1][n] = rb[set][p].y; Bs[buf][kq + 2][n] = rb[set][p].z; Bs[buf][kq + 3][n] = rb[set][p].w;
             }
         }
     };
@@ -157,12 +161,19 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
     const bool colsum = (EPI == EPI_PARTIAL && by == 0) || (EPI == EPI_ADAM && by == 0 && ep.bvec != nullptr);
     float csum = 0.0f;                                           // thread (tid % BN, tid / BN): column sum over its k slice
     constexpr int CS_S = 256 / BN, CS_K = BK / CS_S;             // k slices per tile, rows per slice
-    load_tiles(kbeg);
-    store_tiles(0);
+    // register set s holds tile kt with kt % PD == s from its load (issued PD iterations before its use) to its LDS store
+    load_tiles(kbeg, 0);
+    store_tiles(0, 0);
+#pragma unroll
+    for (int u = 1; u < PD; ++u) if (u < nk) load_tiles(kbeg + u * BK, u);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt0 = 0; kt0 < nk; kt0 += PD) {
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+        const int kt = kt0 + u;
+        if (kt >= nk) continue;
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);              // global loads of the next tile fly under the MFMAs
+        if (kt + PD < nk) load_tiles(kbeg + (kt + PD) * BK, u);           // set u = kt % PD is free: tile kt went to LDS an iteration ago; these loads fly under PD tiles' MFMAs
         const int li = lane & 31, lk = lane >> 5;
         if constexpr (AKM) {
 #pragma unroll
@@ -201,8 +212,9 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const float* __restrict__ A, 
 #pragma unroll
             for (int kk = 0; kk < CS_K; ++kk) csum += Bs[buf][(tid / BN) * CS_K + kk][tid % BN];
         }
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        if (kt + 1 < nk) store_tiles(buf ^ 1, (u + 1) % PD);
         __syncthreads();
+    }
     }
     if (colsum) {                                                // bias gradient + Adam (tf.train.AdamOptimizer) for columns n0..n0+BN
         float* red = &As[0][0][0];                               // all MFMA reads of As are behind the last barrier
@@ -334,6 +346,16 @@ static inline void gemm_mfma_launch(const float* A, long long sA, int lda, const
     // contiguous axes: A rows run along Kd (or along M when TA), W rows along N (or along Kd when TB)
     const bool al = m4((long long)(uintptr_t)A >> 2) && (((uintptr_t)A & 15) == 0) && (((uintptr_t)W & 15) == 0) && m4(sA) && m4(sW) && m4(lda) && m4(ldw) &&
                     m4(TA ? M : Kd) && m4(TB ? Kd : N) && (EPI != EPI_PARTIAL || m4(ep.kchunk));
+    // few workgroups per CU and a long contraction: deeper prefetch (see k_gemm_mfma's PD); GEMM_PREFETCH=1 in the environment keeps distance 1 (A/B runs)
+    static const bool pd_off = getenv("GEMM_PREFETCH") != nullptr && getenv("GEMM_PREFETCH")[0] == '1';
+    const long long nblocks = (long long)grid.x * grid.y * grid.z;
+    if constexpr (TM * TN == 1) {
+        if (!pd_off && nblocks <= 1280 && Kd >= 256) {
+            if (al) hipLaunchKernelGGL((k_gemm_mfma<TM, TN, EPI, TA, TB, true, 4>), grid, dim3(256), 0, st, A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, ep);
+            else hipLaunchKernelGGL((k_gemm_mfma<TM, TN, EPI, TA, TB, false, 4>), grid, dim3(256), 0, st, A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, ep);
+            return;
+        }
+    }
     if (al) hipLaunchKernelGGL((k_gemm_mfma<TM, TN, EPI, TA, TB, true>), grid, dim3(256), 0, st, A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, ep);
     else hipLaunchKernelGGL((k_gemm_mfma<TM, TN, EPI, TA, TB, false>), grid, dim3(256), 0, st, A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, ep);
 }
