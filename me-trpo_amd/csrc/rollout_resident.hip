@@ -17,7 +17,9 @@
 //     8-byte stores / loads: no fence, no flag, no grid barrier; xchg_device.h uses the same idea between GPUs).  Nobody waits for
 //     more than ITS tile: a tile's round trip (partial sums out, next input in: ~6 us) passes while the CU works on the round's other tiles.
 // All K heads are evaluated every step (as the reference's graph does); only simple sampling modes (step_rand / eps_rand / one_model).
-// 2 x 1024 nets (every params file but Swimmer's) take the 4-wave form of the compute role, resident_compute_wide below.
+// 2 x 1024 nets (every params file but Swimmer's) take the 4-wave form of the compute role, resident_compute_wide below.  The same form serves
+// metrpo_validation_cost (the per-model validation rollouts of build_policy_graph, model_based_rl.py:106-151) with its own post role:
+// resident_post_det / k_validation_resident / launch_validation_resident at the end of this file.
 // Everything else (B > 128, other widths, policies other than 2 x 32, model_mean_std / model_med) stays on rollout_gemm.hip.  The grid must be resident as a whole:
 // every wait is bounded (2 s), a launch that gives up is reported by the next metrpo_trpo_update / metrpo_comm_check and retires the kernel
 // for its context (metrpo_internal.h: rollout_error_seen).
