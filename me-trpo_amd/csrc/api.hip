@@ -265,7 +265,7 @@ extern "C" int32_t metrpo_rollout(metrpo_ctx* c, const metrpo_rollout_args* a, v
     return launch_rollout_generic(c, a, (hipStream_t)stream);
 }
 // which kernel family the last metrpo_rollout of this context ran on (-1: none yet): 0 generic, 1 head-per-wave MFMA, 2 cooperative MFMA,
-// 3 step-wise GEMM, 4 resident (rollout_resident.hip)
+// 3 step-wise GEMM, 4 resident (rollout_resident.hip), 5 step-wise with the stream-K fused ensemble kernel (mlp_streamk.h)
 extern "C" int32_t metrpo_last_rollout_kernel(const metrpo_ctx* c) { return c ? c->last_rollout_kernel : METRPO_ENULL; }
 
 extern "C" int32_t metrpo_sampler_progress(metrpo_ctx* c, const uint8_t* done, const int32_t* tpath, int32_t T, int32_t B, int32_t t0,

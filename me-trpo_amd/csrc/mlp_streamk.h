@@ -1,0 +1,517 @@
+// Persistent, evenly split ("stream-K") f32 MFMA kernel for the wide layers of the dynamics ensemble (training.py:171-214: h <- relu(h W + b) per
+// hidden layer, identity output layer; all K heads of model_based_rl.py:91-97 in one launch).  Replaces, for layers of >= 256 units, the
+// tile-per-workgroup GEMM of gemm_mfma.h on the step-wise rollout path (rollout_gemm.hip):
+//
+//   * a WAVE owns 16 rows (envs) x 256 columns of the layer's output for the whole contraction: its 16 accumulator tiles of
+//     v_mfma_f32_16x16x4_f32 are computed TRANSPOSED (D[n][m] = sum_k W[k][n] H[m][k]: srcA = weight fragment, srcB = activation), so a lane
+//     holds row m = lane % 16 in every tile and the D fragment of one layer is the srcB operand of the next without leaving registers:
+//         x (global, 16 rows per wave) -> layer 0 (producer: 2 x S0 matrix instructions per 32-unit chunk, bias as one more input row)
+//           -> relu -> main layer (128 matrix instructions per chunk) -> bias + relu -> output layer (64 x OT) -> [rows][<= 64] partial
+//     Only WEIGHTS go through LDS; the activations of a 2-hidden-layer net never touch HBM.
+//   * a workgroup = 8 waves = 128 rows sharing the weight chunks: W1[32 k][256 n] (+ the layer-0 slice of those 32 units) per chunk, copied by
+//     the LDS DMA (global_load_lds_dwordx4: no register round trip, no ds_write) into a ring of FOUR stages, three chunks ahead.  Chunk q + 1 is
+//     complete behind the barrier that ended chunk q - 1, so the first operand reads of a chunk are issued ahead of the barrier in front of it.
+//     Operand reads: one ds_read_b128 per four matrix instructions (a lane's four consecutive columns belong to four different accumulator
+//     tiles), conflict-free without padding, issued one step (16 matrix instructions) ahead of their use.
+//   * the two waves of a SIMD take turns on its matrix pipe (waves 0-3 run at raised priority): per chunk, a wave has 128 matrix instructions
+//     and ~100 instructions of bookkeeping (next copies, next activation rows, the producer).  The PRIORITY wave does its bookkeeping BEHIND its
+//     matrix instructions, the other one IN FRONT of them -- each in the shadow of its partner's matrix phase; with the same order in both, the
+//     two bookkeeping phases coincide behind the barrier and the pipe idles through them (first version of this kernel: 70 % busy).
+//   * the grid is one workgroup per CU and every workgroup gets the same number of chunks, whatever the tile count (200 tiles on 256 CUs at the
+//     C3 share ran 78 % of the chip; 7.8 tiles per CU at C4 lost 2 % to the last round): a workgroup's range of the (tile, chunk) sequence
+//     starts and ends inside tiles.  The piece that BEGINS a tile is computed first and its accumulators are handed to the next workgroup
+//     through HBM (write-through stores + a per-wave flag); the piece that ENDS a tile is computed last, starting from the accumulators the
+//     previous workgroup exported long before -- so every output is still ONE k-ordered fmaf chain, bit for bit what an unsplit tile computes,
+//     and nobody waits for a workgroup that was dispatched after it (no co-residency assumption: a producer never waits before it exports
+//     unless its whole range lies inside one tile, and then only for lower-numbered workgroups).
+//
+// Summation order of one output: chunks of 32 k in order; inside a chunk the steps (j, e) = (0,0) .. (1,3), step (j, e) adding
+// k = 16 j + e + {0, 4, 8, 12} in that order (the four lane groups of the matrix instruction) -- fixed, independent of grid and split.
+#pragma once
+#include <type_traits>
+#include "mfma_common.h"
+
+enum { SK_A_GLOBAL = 0, SK_A_PRODUCER = 1 };      // main layer's input: activations [M][K1] in HBM | computed from x by layer 0 on the fly
+enum { SK_EPI_STORE = 0, SK_EPI_OUT = 1 };        // relu(acc + b1) stored row-major | contracted with the (<= 64 column) output layer, partial per column block
+enum { SKF_ZERO = 1, SKF_IMPORT = 2, SKF_EXPORT = 4, SKF_LAST = 8, SKF_EPI = 16, SKF_EPILAST = 32, SKF_NONE = 64, SKF_NEWTILE = 128 };
+
+struct SkRec;
+struct SkArgs {
+    int M, heads, K1, N;                       // rows per head; main layer W1[K1][N], K1 % 32 == 0, N % 256 == 0
+    const float* A; long long strideA; int lda;   // SK_A_GLOBAL: A[head][M][lda]; SK_A_PRODUCER: x[M][lda], x[n_in] = 1 (bias slot), zeros up to 4 S0
+    const float* W0; long long strideW0;       // SK_A_PRODUCER: layer-0 weights [>= 4 S0 rows][K1] row-major, row n_in = its bias (the resident layout)
+    const float* W1; long long strideW1;
+    const float* b1; long long strideB1;       // SK_EPI_STORE
+    float* C; long long strideC; int ldc;      // SK_EPI_STORE
+    const float* epi;                          // SK_EPI_OUT: images [head][CB][E][SK epi floats] (k_sk_epi_image)
+    float* part; long long stridePart; int ldp;   // SK_EPI_OUT: part[(cb * heads + head) * stridePart + m * ldp + o], ldp = 16 OT
+    float* xacc; unsigned* xflag; unsigned epoch; double* err;   // accumulator hand-over: [grid][8 waves][16 tiles][64 lanes] float4, one flag per (workgroup, wave)
+#ifdef SK_DEBUG                                // tools/ubench/mlp_sk_bench.hip
+    int skip;                                  // leave-one-out timing (results invalid): 1 no LDS-DMA copies, 2 no activation loads, 4 no barrier, 8 no schedule fetch
+    unsigned long long* dbg;                   // non-NULL: per-workgroup {shader cycles, 100 MHz ticks, entries} of the main loop
+    unsigned long long* dbg2;                  // non-NULL: phase stamps (shader clock) of chunks 8 .. 11 of workgroup 0, waves 0 and 4: [wave / 4][chunk - 8][6]
+#endif
+    const int* hdr; const SkRec* recs;         // schedule: entries per workgroup | [grid][sched_cap] records (k_sk_sched)
+    int RB, CB, NCk, L, tiles, sched_cap;      // row blocks of 128, column blocks of 256, chunks per tile, units per tile (chunks + epilogue weight)
+    long long units;
+};
+
+template <int OT> struct SkEpi {
+    static constexpr int E = (OT == 4) ? 2 : 1, UPC = 4 / E;                 // EPI chunks per tile; 64-column groups u per EPI chunk
+    static constexpr int FLOATS = 256 + UPC * 1024 * OT;                      // [b1 part, 256 floats][W2 part]
+};
+template <int AMODE, int EPI, int S0, int OT> struct SkGeom {
+    static constexpr int NI0 = (S0 + 1) / 2;                                  // 1 KB pieces of the layer-0 slice of a chunk
+    static constexpr int W0F = (AMODE == SK_A_PRODUCER) ? NI0 * 256 : 0;
+    static constexpr int B1O = 8192 + W0F;                                    // SK_EPI_STORE: the tile's 256 bias values ride in its last chunk's stage
+    static constexpr int STAGE = (EPI == SK_EPI_STORE) ? B1O + 256 : (W0F > 256 ? 8192 + W0F : 8192 + 256);
+};
+
+__device__ __forceinline__ void sk_glds16(const float* src, float* dst_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
+}
+
+// Image of the epilogue operands of one (head, column block, EPI chunk): b1 in the lane order of the accumulators, the output layer's weights as
+// srcA fragments read by ds_read_b128 (four steps v per read).  One launch per weight version (rollout_gemm.hip: once per launch chain).
+template <int OT>
+__global__ void k_sk_epi_image(const float* __restrict__ b1, long long strideB1, const float* __restrict__ W2, long long strideW2, int no, int N, int heads,
+                               float* __restrict__ img) {
+    using EP = SkEpi<OT>;
+    const int CB = N / 256;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x, tot = (long long)heads * CB * EP::E * EP::FLOATS;
+    if (idx >= tot) return;
+    const int f = (int)(idx % EP::FLOATS), e = (int)((idx / EP::FLOATS) % EP::E), cb = (int)((idx / ((long long)EP::FLOATS * EP::E)) % CB),
+              head = (int)(idx / ((long long)EP::FLOATS * EP::E * CB));
+    float v = 0.0f;
+    if (f < 256) {
+        const int ul = f >> 6, g = (f >> 4) & 3, r = (f >> 2) & 3, vv = f & 3;
+        if (ul < EP::UPC) v = b1[(size_t)head * strideB1 + cb * 256 + 64 * (e * EP::UPC + ul) + 16 * g + 4 * r + vv];
+    } else {
+        int p = f - 256;
+        const int vv = p & 3; p >>= 2;
+        const int i = p & 15; p >>= 4;
+        const int ot = p % OT; p /= OT;
+        const int g = p & 3; p >>= 2;
+        const int r = p & 3, ul = p >> 2;
+        const int n = cb * 256 + 64 * (e * EP::UPC + ul) + 16 * g + 4 * r + vv, o = 16 * ot + i;
+        if (o < no) v = W2[(size_t)head * strideW2 + (size_t)n * no + o];
+    }
+    img[idx] = v;
+}
+
+// One entry of a workgroup's schedule (32 bytes, read with ONE s_load_dwordx8): everything the per-chunk bookkeeping would otherwise derive with
+// integer divisions.  Built by k_sk_sched once per shape into global memory, so that the main kernel reads it through the SCALAR cache: on a SIMD
+// whose older wave is issuing matrix instructions back to back, the younger wave's VECTOR instructions do not issue at all (measured: its ~100
+// instructions of bookkeeping took exactly as long as the partner's 128 MFMAs), while scalar, LDS and memory instructions do.
+struct SkRec { int w; int m0; unsigned offA, offC;          // first half: what the chunk itself and the look-ahead need.  w = chunk | flags << 16; element offsets
+               int w2; unsigned offW1, offW0; int tile; };   // second half: what the LDS-DMA copies need (w2 = w)
+typedef int sk_i32x4 __attribute__((ext_vector_type(4)));
+
+template <int AMODE, int EPI, int S0, int OT>
+__global__ void __launch_bounds__(512) k_sk_sched(const SkArgs a, int* __restrict__ hdr, SkRec* __restrict__ recs) {
+    using EP = SkEpi<OT>;
+    constexpr int E = EP::E;
+    constexpr bool PROD = (AMODE == SK_A_PRODUCER), OUT = (EPI == SK_EPI_OUT);
+    // this workgroup's range of the unit sequence, cut into pieces; entry t of the schedule is computed by thread t
+    const int tid = threadIdx.x;
+    const long long U = a.units;
+    const int G = gridDim.x, b = blockIdx.x, NCk = a.NCk;
+    const long long u0 = U * b / G, u1 = U * (b + 1) / G;
+    auto cut = [&](long long u, int& t, int& o) { t = (int)(u / a.L); o = (int)(u % a.L); if (o >= NCk) { ++t; o = 0; } };
+    int ts, cs, te, ce;
+    cut(u0, ts, cs); cut(u1, te, ce);
+    const int Le = NCk + (OUT ? E : 0);
+    int n_h = 0, nf = 0, tf = ts, n_t = 0;
+    if (ts == te) n_h = ce > cs ? ce - cs : 0;                                 // one piece inside one tile: chunks [cs, ce)
+    else { n_h = ce; tf = ts + (cs > 0 ? 1 : 0); nf = te - tf; n_t = cs > 0 ? (NCk - cs) + (OUT ? E : 0) : 0; }
+    const int nq = n_h + nf * Le + n_t;
+    if (tid == 0) hdr[b] = nq;
+    const int tph = a.CB * a.RB;
+    for (int t = tid; t < nq + 4; t += 512) {
+        SkRec r = {};
+        if (t >= nq) { r.w = r.w2 = (SKF_NONE | SKF_EPI) << 16; r.tile = -1; recs[(size_t)b * a.sched_cap + t] = r; continue; }     // four sentinels behind the last entry
+        int tile, c, fl = 0;                                                   // c: chunk, or EPI chunk index when fl & SKF_EPI
+        if (t < n_h) {                                                         // the piece that begins a tile: first, exported at once
+            tile = te; c = (ts == te ? cs : 0) + t;
+            if (t == 0) fl |= (c == 0) ? SKF_ZERO : SKF_IMPORT;
+            if (t == n_h - 1) fl |= SKF_EXPORT;
+        } else if (t < n_h + nf * Le) {
+            const int tt = t - n_h; tile = tf + tt / Le; c = tt % Le;
+            if (c == 0) fl |= SKF_ZERO;
+            if (c == NCk - 1) fl |= SKF_LAST;
+            if (c >= NCk) { c -= NCk; fl = SKF_EPI | (c == E - 1 ? SKF_EPILAST : 0); }
+        } else {                                                               // the piece that ends a tile: last, continues the previous workgroup's sums
+            const int tt = t - n_h - nf * Le; tile = ts; c = cs + tt;
+            if (tt == 0) fl |= SKF_IMPORT;
+            if (c == NCk - 1) fl |= SKF_LAST;
+            if (c >= NCk) { c -= NCk; fl = SKF_EPI | (c == E - 1 ? SKF_EPILAST : 0); }
+        }
+        const int head = tile / tph, cb = (tile / a.RB) % a.CB, rb = tile % a.RB;
+        if (t == 0 || t == n_h || (t >= n_h && t < n_h + nf * Le && (t - n_h) % Le == 0) || t == n_h + nf * Le) fl |= SKF_NEWTILE;   // first entry of a piece
+        r.w = r.w2 = c | (fl << 16); r.m0 = rb * 128;
+        r.offA = (unsigned)(head * a.strideA) + ((!PROD && !(fl & SKF_EPI)) ? 32u * c : 0u);
+        r.offC = OUT ? (unsigned)(((long long)cb * a.heads + head) * a.stridePart) : (unsigned)(head * a.strideC + cb * 256);
+        if (fl & SKF_EPI) { r.offW1 = (unsigned)(((head * a.CB + cb) * E + c) * EP::FLOATS); r.offW0 = 0; }
+        else {
+            r.offW1 = (unsigned)(head * a.strideW1 + (long long)(32 * c) * a.N + cb * 256);
+            r.offW0 = PROD ? (unsigned)(head * a.strideW0 + 32 * c) : (unsigned)(head * a.strideB1 + cb * 256);
+        }
+        r.tile = tile;
+        recs[(size_t)b * a.sched_cap + t] = r;
+    }
+}
+
+// one 1 KB LDS-DMA piece: lane's 16 bytes at sbase + voff -> LDS lds_addr + 16 lane.  Scalar base + 32-bit lane offset: no vector address
+// arithmetic per piece (hipcc folds a per-lane offset into a 64-bit VGPR base with one v_lshl_add_u64 per piece).  Invisible to hipcc's vmcnt
+// counting: drained by the explicit waits of the chunk loop.  M0 is saved and restored inside the statement.
+__device__ __forceinline__ void sk_glds16_s(unsigned voff, const void* sbase, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+
+template <int AMODE, int EPI, int S0, int OT>
+__global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
+    using EP = SkEpi<OT>;
+    using GE = SkGeom<AMODE, EPI, S0, OT>;
+    constexpr int E = EP::E, UPC = EP::UPC, NI0 = GE::NI0, B1O = GE::B1O, STAGE = GE::STAGE;
+    constexpr bool PROD = (AMODE == SK_A_PRODUCER), OUT = (EPI == SK_EPI_OUT);
+    static_assert(EP::FLOATS <= STAGE || !OUT, "EPI image larger than a ring stage");
+    static_assert(NI0 <= 8, "layer-0 slice: at most 8 one-KB pieces (one per wave)");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const ring = lds;
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nq = a.hdr[blockIdx.x];
+    if (nq == 0) return;
+#ifdef SK_DEBUG
+    if (a.dbg != nullptr && tid == 0) a.dbg[8 * blockIdx.x + 3] = wall_clock64();                  // kernel entry
+#endif
+    struct RecL { int kc, fl, m0; unsigned offA, offC; };                      // the chunk itself / the look-ahead
+    struct RecI { int fl; unsigned offW1, offW0; };                            // its LDS-DMA copies
+    const SkRec* const my_recs = a.recs + (size_t)blockIdx.x * a.sched_cap;
+    auto decL = [](const sk_i32x4& v) { RecL r; r.kc = v[0] & 0xFFFF; r.fl = v[0] >> 16; r.m0 = v[1]; r.offA = (unsigned)v[2]; r.offC = (unsigned)v[3]; return r; };
+    auto decI = [](const sk_i32x4& v) { RecI r; r.fl = v[0] >> 16; r.offW1 = (unsigned)v[1]; r.offW0 = (unsigned)v[2]; return r; };
+    // Schedule entries by scalar loads, load + wait in ONE statement (q <= nq + 3: sentinels behind the last entry).  Left to hipcc the loads sink to
+    // their first use or become vector loads + readfirstlane; issued in one statement and waited for in another, their destination registers
+    // are fair game for a spill BEFORE the data lands (seen with 34 spilled SGPRs: garbage offsets, memory faults).  The ~200 cycles this
+    // statement blocks its wave are the partner wave's to fill: the two halves of the workgroup fetch at different points of the matrix phase.
+    auto fetch2 = [&](int ql, int qi, RecL& rl, RecI& ri) {
+        sk_i32x4 vl, vi;
+        asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx4 %1, %3, 0x10\n\ts_waitcnt lgkmcnt(0)" : "=&s"(vl), "=&s"(vi) : "s"(my_recs + ql), "s"(my_recs + qi));
+        rl = decL(vl); ri = decI(vi);
+    };
+
+    // per-thread constants of the LDS-DMA copies (byte offsets from a scalar base)
+    const unsigned ring_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)ring;
+    const unsigned w1_voff = (unsigned)(wave * a.N + 4 * lane) * 4u;           // row (wave + 8 t) of the chunk, this lane's 16 bytes
+    unsigned w0_voff = 0;                                                      // PROD: piece ii = wave of the layer-0 slice image [s][jt][g][i']
+    if constexpr (PROD) { const int p = (wave % NI0) * 64 + lane, i4 = p & 3, gg = (p >> 2) & 3, jt = (p >> 4) & 1, s = p >> 5; w0_voff = (unsigned)((4 * s + gg) * a.K1 + 16 * jt + 4 * i4) * 4u; }
+    const unsigned lane16 = (unsigned)lane * 16u;
+    // LDS-DMA copies of entry q into ring stage q % 4, as five PIECES per wave (spread over the matrix phase of the chunk that issues them)
+    auto issue_piece = [&](const RecI& r, int q, auto tc) {
+        constexpr int t = decltype(tc)::value;
+        if (r.fl & SKF_NONE) return;
+#ifdef SK_DEBUG
+        if (a.skip & 1) return;
+#endif
+        const unsigned st = ring_lds + (unsigned)((q & 3) * STAGE) * 4u;
+        if (!(r.fl & SKF_EPI)) {
+            if constexpr (t < 4) sk_glds16_s(w1_voff, (const char*)(a.W1 + r.offW1) + (size_t)t * ((size_t)a.N * 32), st + (unsigned)(wave + 8 * t) * 1024u);   // row wave + 8 t
+            else {
+                if constexpr (!OUT) { if ((r.fl & SKF_LAST) && wave == 7) sk_glds16_s(lane16, a.b1 + r.offW0, st + B1O * 4u); }
+                if constexpr (PROD) { if (wave < NI0) sk_glds16_s(w0_voff, a.W0 + r.offW0, st + (8192u + (unsigned)wave * 256u) * 4u); }
+            }
+        } else if constexpr (OUT) {
+            constexpr int NIE = EP::FLOATS / 256;
+            const int ii = wave + 8 * t;
+            if (ii < NIE) sk_glds16_s(lane16, (const char*)(a.epi + r.offW1) + (size_t)ii * 1024, st + (unsigned)ii * 1024u);
+        }
+    };
+    auto issue = [&](const RecI& r, int q) {
+        issue_piece(r, q, std::integral_constant<int, 0>{}); issue_piece(r, q, std::integral_constant<int, 1>{}); issue_piece(r, q, std::integral_constant<int, 2>{});
+        issue_piece(r, q, std::integral_constant<int, 3>{}); issue_piece(r, q, std::integral_constant<int, 4>{});
+    };
+    auto drain_vm = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_waitcnt(0x0F70); };   // the asm copies | the loads hipcc counts
+
+    f32x4 acc[4][4];                                                           // [u][v]: columns 64 u + 16 g + 4 r + v of the block, row i
+    f32x4 oacc[OT];
+    // srcB of a chunk's 8 steps: set q & 1 feeds chunk q; SK_A_GLOBAL fills the other set for chunk q + 1 meanwhile.  (With one set + a copy per chunk the
+    // copy's eight v_mov were, on the SIMD's younger wave, eight waits for a gap in the older wave's matrix stream.)
+    f32x4 hs[2][2];
+    float xr[PROD ? S0 : 1];
+    (void)oacc; (void)xr;
+
+    auto load_x = [&](const RecL& r) {
+        const int m = min(r.m0 + wave * 16 + i, a.M - 1);
+        const float* xp = a.A + r.offA + (size_t)m * a.lda + g;
+#pragma unroll
+        for (int s = 0; s < S0; ++s) xr[s] = xp[4 * s];
+    };
+    unsigned a_voff = 0;                                                       // SK_A_GLOBAL: byte offset of this lane's row quad inside the head's activations, per tile
+    auto set_a_voff = [&](const RecL& r) { a_voff = (unsigned)(min(r.m0 + wave * 16 + i, a.M - 1) * a.lda + 4 * g) * 4u; };
+    auto load_a = [&](const RecL& r, f32x4 (&dst)[2]) {                        // two 16-byte loads, scalar base + lane offset: no vector address arithmetic; waited for by drain_a
+        asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:64" : "=&v"(dst[0]), "=&v"(dst[1]) : "v"(a_voff), "s"(a.A + r.offA) : "memory");
+    };
+    auto drain_a = [&](f32x4 (&dst)[2]) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(dst[0]), "+v"(dst[1]) :: "memory"); };
+    auto produce = [&](int q, f32x4 (&dst)[2]) {                               // layer 0 for the 32 units of chunk q, relu, in srcB layout
+        f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+        const float* w0 = ring + (q & 3) * STAGE + 8192 + lane;
+#pragma unroll
+        for (int s = 0; s < S0; ++s) {
+            d0 = MFMA16(w0[(2 * s) * 64], xr[s], d0);
+            d1 = MFMA16(w0[(2 * s + 1) * 64], xr[s], d1);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { dst[0][r] = relu1(d0[r]); dst[1][r] = relu1(d1[r]); }
+    };
+
+    // srcA operands: one ds_read_b128 = four accumulator tiles of one step.  A chunk is 32 GROUPS of {wait for this group's operand, request the one
+    // four groups ahead, four MFMAs}: two non-matrix instructions in the shadow of four matrix instructions, no vector ALU work at all.  Inline
+    // assembly, because hipcc sinks compiler-visible reads down to their first use (read, wait the whole LDS latency, four MFMAs, read ...); it
+    // therefore does not count them either: the waits are written out (in order, four reads in flight: lgkmcnt(3) = the oldest has landed; scalar
+    // loads in flight can only make that wait stricter).  w[k & 7] feeds group k.
+    f32x4 w[8];
+    const unsigned lane_off = (unsigned)((4 * g) * 256 + 4 * i) * 4u;
+    auto stage_addr = [&](int q) { return ring_lds + (unsigned)((q & 3) * STAGE) * 4u + lane_off; };
+#define SK_WOFF(k) (((16 * ((k) >> 4) + (((k) >> 2) & 3)) * 256 + 64 * ((k) & 3)) * 4)
+    auto first4 = [&](unsigned addr) {                                         // groups 0 .. 3 of a chunk, complete on return
+        asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
+                     : "v"(addr), "i"(SK_WOFF(0)), "i"(SK_WOFF(1)), "i"(SK_WOFF(2)), "i"(SK_WOFF(3)));
+    };
+
+    // ---- prologue: entries 0 .. 2 under way, the first rows loaded ----
+    RecL r0, r1; RecI r3;
+    {
+        RecI i0, i1, i2; RecL dummy;
+        fetch2(0, 0, r0, i0); fetch2(1, 1, r1, i1); fetch2(2, 2, dummy, i2); fetch2(3, 3, dummy, r3);
+        issue(i0, 0); issue(i1, 1); issue(i2, 2);
+    }
+    if constexpr (PROD) load_x(r0);
+    else { set_a_voff(r0); load_a(r0, hs[0]); drain_a(hs[0]); }
+    drain_vm();
+    __syncthreads();
+    first4(stage_addr(0));
+#ifdef SK_DEBUG
+    unsigned long long dbg_c0 = 0, dbg_w0 = 0;
+    if (a.dbg != nullptr) { dbg_c0 = __builtin_readcyclecounter(); dbg_w0 = wall_clock64(); }
+#endif
+
+    auto body = [&](auto par_, const int q) {
+        constexpr int PAR = decltype(par_)::value;
+        f32x4 (&h)[2] = hs[PAR];
+        f32x4 (&hn)[2] = hs[PAR ^ 1];
+        const bool nmain = !(r1.fl & SKF_EPI);
+        const float* st = ring + (q & 3) * STAGE;
+#ifdef SK_DEBUG
+        const bool stamp = a.dbg2 != nullptr && blockIdx.x == 0 && (wave & 3) == 0 && q >= 8 && q < 12;
+        unsigned long long* sp_ = a.dbg2 + ((wave >> 2) * 4 + (q - 8)) * 6;
+#define SK_STAMP(k) do { if (stamp) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) sp_[k] = t_; } } while (0)
+#else
+#define SK_STAMP(k) do { } while (0)
+#endif
+        SK_STAMP(0);
+        // bookkeeping: the vector part here; the schedule entries q + 3 (to copy) and q + 2 (the next look-ahead) are fetched and the copies issued INSIDE the
+        // matrix phase below (scalar + memory instructions: two or three per group of four MFMAs cost nothing)
+        if constexpr (PROD) {
+            if (!(r0.fl & SKF_EPI)) produce(q, h);                             // xr: loaded a chunk ago, drained at that chunk's end
+            if (nmain && (r1.fl & SKF_NEWTILE)) load_x(r1);
+        } else {
+            if (nmain) { if (r1.fl & SKF_NEWTILE) set_a_voff(r1); load_a(r1, hn); }
+        }
+        RecI r4; RecL rn;                                                      // fetched inside the matrix phase: copies of entry q + 4 (issued NEXT chunk), look-ahead q + 2
+        SK_STAMP(1);
+
+        if (!(r0.fl & SKF_EPI)) {
+            if (r0.fl & SKF_ZERO) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (r0.fl & SKF_IMPORT) {                                          // the previous workgroup's partial sums of this tile (exported at its start)
+                const unsigned* fp = a.xflag + (size_t)(blockIdx.x - 1) * 8 + wave;
+                const unsigned long long t0 = wall_clock64();
+                while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (wall_clock64() - t0 > 200000000ull) { if (lane == 0) *a.err = 1.0; break; }      // 2 s at 100 MHz: report, do not hang
+                }
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xacc + ((size_t)(blockIdx.x - 1) * 8 + wave) * 4096), 0, 16384, 0x00020000);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, ((u * 4 + v) * 64 + lane) * 16, 0, 16);   // sc1: served beyond this CU's L1
+                        acc[u][v] = __builtin_bit_cast(f32x4, raw);
+                    }
+                __builtin_amdgcn_s_waitcnt(0x0F70);                            // inside the branch: at the merge point hipcc would otherwise drain the queue on EVERY chunk
+            }
+            {
+                const unsigned cur_a = stage_addr(q), nxt_a = stage_addr(q + 1);
+                auto group = [&](auto kc_) {                                   // operand of group k + 4 (the NEXT chunk's first groups from k = 28 on: its stage is
+                    constexpr int k = decltype(kc_)::value;                    // complete since the barrier that ended chunk q - 1) requested in front of group k's MFMAs
+                    constexpr int j = k >> 4, e = (k >> 2) & 3, u = k & 3;
+                    if constexpr (k < 28)
+                        asm volatile("s_waitcnt lgkmcnt(3)\n\tds_read_b128 %0, %2 offset:%3" : "=&v"(w[(k + 4) & 7]), "+v"(w[k & 7]) : "v"(cur_a), "i"(SK_WOFF(k + 4)));
+                    else if (nmain)
+                        asm volatile("s_waitcnt lgkmcnt(3)\n\tds_read_b128 %0, %2 offset:%3" : "=&v"(w[(k + 4) & 7]), "+v"(w[k & 7]) : "v"(nxt_a), "i"(SK_WOFF(k - 28)));
+                    else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(w[k & 7]) : "i"(31 - k));
+                    __builtin_amdgcn_sched_barrier(0);                         // the MFMAs below stay BEHIND the statement (hipcc hoists register-only instructions past asm)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc[u][v] = MFMA16(w[k & 7][v], h[j][e], acc[u][v]);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+#define SK_G4(b) group(std::integral_constant<int, (b)>{}); group(std::integral_constant<int, (b) + 1>{}); group(std::integral_constant<int, (b) + 2>{}); group(std::integral_constant<int, (b) + 3>{});
+                // the copies of entry q + 3 go out EARLY in the phase (they are drained at its end: issued in its last groups they were waited for, 300-1000
+                // cycles per chunk); the schedule fetch (it blocks its wave ~200 cycles) late, at different points for the two waves of a SIMD
+#define SK_P(t) issue_piece(r3, q + 3, std::integral_constant<int, (t)>{})
+                SK_G4(0)  SK_P(0);
+                SK_G4(4)  SK_P(1);
+                SK_G4(8)  SK_P(2);
+                SK_G4(12) SK_P(3);
+                SK_G4(16) SK_P(4);
+                SK_G4(20) if (wave < 4) fetch2(q + 2, q + 4, rn, r4);
+                SK_G4(24) if (wave >= 4) fetch2(q + 2, q + 4, rn, r4);
+                SK_G4(28)
+                // the next chunk's first operands must be COMPLETE before the loop's back edge: hipcc takes an asm read's destination as written when the
+                // statement ends and may copy those registers where control flow merges (seen: half-landed copies behind an EPI chunk, 1 % errors)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+            }
+            SK_STAMP(2);
+            if (r0.fl & SKF_EXPORT) {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xacc + ((size_t)blockIdx.x * 8 + wave) * 4096), 0, 16384, 0x00020000);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[u][v]), rs, ((u * 4 + v) * 64 + lane) * 16, 0, 16);   // sc1: write-through
+                    }
+                __builtin_amdgcn_s_waitcnt(0x0F70);                            // every storing wave drains before its flag
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(a.xflag + (size_t)blockIdx.x * 8 + wave, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if constexpr (!OUT) {
+                if (r0.fl & SKF_LAST) {
+                    const int m = r0.m0 + wave * 16 + i;
+                    const float* bp = st + B1O + 16 * g;
+                    float* cp = a.C + r0.offC + (size_t)m * a.ldc + 16 * g;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const f32x4 bq = *(const f32x4*)(bp + 64 * u + 4 * r);
+                            f32x4 o;
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) o[v] = relu1(acc[u][v][r] + bq[v]);
+                            if (m < a.M) *(f32x4*)(cp + 64 * u + 4 * r) = o;
+                        }
+                }
+            }
+        } else if constexpr (OUT) {
+            issue(r3, q + 3);
+            fetch2(q + 2, q + 4, rn, r4);
+            if (!(r0.fl & SKF_NONE)) {
+                auto epi_chunk = [&](auto ee) {
+                    constexpr int EE = decltype(ee)::value;
+                    if (EE == 0) {
+#pragma unroll
+                        for (int ot = 0; ot < OT; ++ot) oacc[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int ul = 0; ul < UPC; ++ul) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const f32x4 bq = *(const f32x4*)(st + (ul * 4 + g) * 16 + 4 * r);
+                            f32x4 wf[OT];
+#pragma unroll
+                            for (int ot = 0; ot < OT; ++ot) wf[ot] = *(const f32x4*)(st + 256 + ((((ul * 4 + r) * 4 + g) * OT + ot) * 16 + i) * 4);
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                const float hb = relu1(acc[EE * UPC + ul][v][r] + bq[v]);
+#pragma unroll
+                                for (int ot = 0; ot < OT; ++ot) oacc[ot] = MFMA16(wf[ot][v], hb, oacc[ot]);
+                            }
+                        }
+                    }
+                };
+                if (E == 1 || r0.kc == 0) epi_chunk(std::integral_constant<int, 0>{});
+                else epi_chunk(std::integral_constant<int, E - 1>{});
+                if (r0.fl & SKF_EPILAST) {
+                    const int m = r0.m0 + wave * 16 + i;
+                    float* pp = a.part + r0.offC + (size_t)m * a.ldp + 4 * g;
+                    if (m < a.M) {
+#pragma unroll
+                        for (int ot = 0; ot < OT; ++ot) *(f32x4*)(pp + 16 * ot) = oacc[ot];
+                    }
+                }
+                if (nmain) first4(stage_addr(q + 1));
+            }
+        }
+        SK_STAMP(3);
+        if constexpr (!PROD) drain_a(hn);                                      // (nothing to wait for behind the line below; names the registers the asm loads wrote)
+        drain_vm();                                                            // this wave's copies of entry q + 3 (issued early in the chunk) and its rows: landed long ago
+        SK_STAMP(4);
+#ifdef SK_DEBUG
+        if (!(a.skip & 4))
+#endif
+        __builtin_amdgcn_s_barrier();                                          // entry q + 3 complete in LDS for everybody; everybody is done reading stage q % 4
+        asm volatile("" ::: "memory");
+        SK_STAMP(5);
+        r0 = r1; r1 = rn; r3 = r4;
+    };
+    for (int q = 0; q < nq; q += 2) {                                          // unrolled by two: the register set of the srcB operands alternates
+        body(std::integral_constant<int, 0>{}, q);
+        if (q + 1 < nq) body(std::integral_constant<int, 1>{}, q + 1);
+    }
+#ifdef SK_DEBUG
+    if (a.dbg != nullptr && lane == 0) {                                       // shader cycles and 100 MHz ticks of this workgroup's main loop, its chunk count
+        if (tid == 0) { a.dbg[8 * blockIdx.x] = __builtin_readcyclecounter() - dbg_c0; a.dbg[8 * blockIdx.x + 1] = wall_clock64() - dbg_w0; a.dbg[8 * blockIdx.x + 2] = (unsigned long long)nq;
+                        a.dbg[8 * blockIdx.x + 4] = dbg_w0; }
+        atomicMax(&a.dbg[8 * blockIdx.x + 5], wall_clock64());                 // exit of the last wave
+    }
+#endif
+}
+
+// ---- host side ----
+struct SkPlan { int grid; size_t lds_bytes; size_t xacc_floats; int nflags; size_t sched_bytes; };
+template <int AMODE, int EPI, int S0, int OT>
+static inline SkPlan sk_plan(SkArgs& a, int n_sm, int grid_override = 0) {
+    using GE = SkGeom<AMODE, EPI, S0, OT>;
+    a.RB = (a.M + 127) / 128; a.CB = a.N / 256; a.NCk = a.K1 / 32;
+    a.L = a.NCk + ((EPI == SK_EPI_OUT) ? SkEpi<OT>::E : 1);
+    a.tiles = a.heads * a.CB * a.RB;
+    a.units = (long long)a.tiles * a.L;
+    SkPlan p;
+    p.grid = grid_override > 0 ? grid_override : (a.tiles < n_sm ? a.tiles : n_sm);
+    const long long cap = a.units / p.grid + 2LL * a.L + 8;
+    a.sched_cap = (int)cap;
+    p.lds_bytes = (size_t)4 * GE::STAGE * sizeof(float);
+    p.xacc_floats = (size_t)p.grid * 8 * 4096;
+    p.nflags = p.grid * 8;
+    p.sched_bytes = (size_t)p.grid * cap * sizeof(SkRec) + (((size_t)p.grid * sizeof(int) + 255) & ~(size_t)255);
+    return p;
+}
+// schedule of this shape into `mem` (>= sched_bytes, 256-byte aligned): [hdr (grid ints, padded)][records]; sets a.hdr / a.recs.  Once per shape.
+template <int AMODE, int EPI, int S0, int OT>
+static inline hipError_t sk_build_sched(SkArgs& a, const SkPlan& p, void* mem, hipStream_t st) {
+    int* hdr = (int*)mem;
+    SkRec* recs = (SkRec*)((char*)mem + (((size_t)p.grid * sizeof(int) + 255) & ~(size_t)255));
+    hipLaunchKernelGGL((k_sk_sched<AMODE, EPI, S0, OT>), dim3(p.grid), dim3(512), 0, st, a, hdr, recs);
+    a.hdr = hdr; a.recs = recs;
+    return hipGetLastError();
+}
+template <int AMODE, int EPI, int S0, int OT>
+static inline hipError_t sk_launch(const SkArgs& a, const SkPlan& p, hipStream_t st) {
+    auto kern = k_mlp_sk<AMODE, EPI, S0, OT>;
+    static size_t attr_set = 0;
+    if (p.lds_bytes > attr_set) {
+        const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = p.lds_bytes;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.grid), dim3(512), p.lds_bytes, st, a);
+    return hipGetLastError();
+}

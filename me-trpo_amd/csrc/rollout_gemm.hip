@@ -11,6 +11,7 @@
 #include <thread>
 #include "gemm_mfma.h"
 #include "mfma_common.h"
+#include "mlp_streamk.h"
 #include "policy_chain3.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -18,6 +19,8 @@ struct BigState { float* S; int* ts; int* cur_model; float* X; float* U; float* 
                   int ldx;
                   // output layer left as split-K partials (gemm_skinny_bias with defer): k_big_post adds them and the bias
                   int out_splits; long long out_stride; const float* out_bias; long long out_bias_stride;
+                  int out_ld;      // row stride of a partial (ns; 16 OT on the stream-K path, mlp_streamk.h)
+                  int xone;        // 1: X[nin] = 1 -- the stream-K path's layer-0 producer takes the bias as one more input row
                   float* PA; float* PB;
                   float* PIMG; };   // k_big_pre_mfma3: the policy's fragment image, built once per launch chain (k_pre_mfma3_image)      // policy activations of the GEMM pre-path [B][max policy width]   // ldx: row stride of X = n_in rounded up to 4 floats, so every row is 16-byte aligned for the layer-0 GEMM's loads
 
@@ -59,7 +62,7 @@ __global__ void k_big_pre(ProblemDesc pd, RolloutK r, int t, const float* __rest
         r.obs[tb * ns + i] = s;
         if (i >= pd.n_drop) st.X[(size_t)b * st.ldx + i - pd.n_drop] = (s - in_mean[i]) / in_std[i];       // training.py:228,146-151
     }
-    for (int j = pd.nin; j < st.ldx; ++j) st.X[(size_t)b * st.ldx + j] = 0.0f;                     // pad columns of the 16-byte aligned rows (layer 0 contracts over ldx)
+    for (int j = pd.nin; j < st.ldx; ++j) st.X[(size_t)b * st.ldx + j] = (st.xone && j == pd.nin) ? 1.0f : 0.0f;   // pad columns of the 16-byte aligned rows (layer 0 contracts over ldx)
     for (int d0 = 0; d0 < na; d0 += 2) {
         float z[2] = {0.f, 0.f};
         if (!r.determ && r.eps == nullptr) {
@@ -172,7 +175,7 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
     const float* __restrict__ log_std = theta + C::pLS;
     // state part of the normalised, dropped input: lane (c, q) writes its dims 4q .. (every 16th column block)
     for (int i = q; i < NS; i += 4) if (i >= NDROP) st.X[(size_t)b * st.ldx + i - NDROP] = (ST[c * NS + i] - in_mean[i]) / in_std[i];     // training.py:228,146-151
-    if (q == 0) for (int j = C::NIN; j < st.ldx; ++j) st.X[(size_t)b * st.ldx + j] = 0.0f;            // pad columns of the 16-byte aligned rows (layer 0 contracts over ldx)
+    if (q == 0) for (int j = C::NIN; j < st.ldx; ++j) st.X[(size_t)b * st.ldx + j] = (st.xone && j == C::NIN) ? 1.0f : 0.0f;   // pad columns of the 16-byte aligned rows (layer 0 contracts over ldx)
     // action dims 4q .. 4q+3 of this lane = Philox chunks 2q, 2q+1 (chunk 0 = the step block), exactly as k_big_pre
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -242,7 +245,7 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma3(ProblemDesc pd, RolloutK 
     const float* in_mean = norm; const float* in_std = norm + (NS + NA);
     const float* __restrict__ log_std = theta + pLS;
     for (int i = q; i < NS; i += 4) if (i >= NDROP) st.X[(size_t)b * st.ldx + i - NDROP] = (ST[c * NS + i] - in_mean[i]) / in_std[i];     // training.py:228,146-151
-    if (q == 0) for (int j = NIN; j < st.ldx; ++j) st.X[(size_t)b * st.ldx + j] = 0.0f;
+    if (q == 0) for (int j = NIN; j < st.ldx; ++j) st.X[(size_t)b * st.ldx + j] = (st.xone && j == NIN) ? 1.0f : 0.0f;
     // action dims 16 cb + 4 q .. + 3 of this lane = Philox chunks (dim >> 1) of the step (chunk 0 = the step block), exactly as k_big_pre
 #pragma unroll
     for (int cb = 0; cb < CO; ++cb)
@@ -298,7 +301,7 @@ __global__ void __launch_bounds__(256) k_big_pre_gather(ProblemDesc pd, RolloutK
     r.obs[((size_t)(t + RK_TOFF(r, b)) * RK_STRIDE(r) + RK_ENV(r, b)) * ns + i] = s;
     const float* in_mean = norm; const float* in_std = norm + (ns + na);
     if (i >= pd.n_drop) st.X[(size_t)b * st.ldx + i - pd.n_drop] = (s - in_mean[i]) / in_std[i];       // training.py:228,146-151
-    if (i == 0) for (int j = pd.nin; j < st.ldx; ++j) st.X[(size_t)b * st.ldx + j] = 0.0f;              // pad columns of the 16-byte aligned rows
+    if (i == 0) for (int j = pd.nin; j < st.ldx; ++j) st.X[(size_t)b * st.ldx + j] = (st.xone && j == pd.nin) ? 1.0f : 0.0f;   // pad columns of the 16-byte aligned rows
 }
 // action: a = mu + sigma z (policy noise from the step's Philox blocks), clip, act / mean / U / X action columns; one lane per (env, dim pair)
 __global__ void __launch_bounds__(256) k_big_pre_action(ProblemDesc pd, RolloutK r, int t, const float* __restrict__ theta, const float* __restrict__ norm,
@@ -377,7 +380,7 @@ __global__ void __launch_bounds__(256) k_big_post(ProblemDesc pd, RolloutK r, in
     auto outv = [&](int k) {                                     // output layer of head k, dim i (partials in split order, like k_splitk_bias_reduce)
         if (st.out_splits == 0) return st.OUT[((size_t)k * r.B + bc) * ns + ic];
         float o = st.out_bias[(size_t)k * st.out_bias_stride + ic];
-        for (int sp = 0; sp < st.out_splits; ++sp) o += st.PART[((size_t)sp * K + k) * st.out_stride + (size_t)bc * ns + ic];
+        for (int sp = 0; sp < st.out_splits; ++sp) o += st.PART[((size_t)sp * K + k) * st.out_stride + (size_t)bc * st.out_ld + ic];
         return o;
     };
     auto head = [&](int k) { return fmaf(ds, outv(k), dm) + s_old; };
@@ -460,6 +463,90 @@ static void gemm_launch(int act, const float* A, long long sA, int lda, const fl
     else gemm_auto<EPI_BIAS_ID, false, false>(A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, heads, ep, st);
 }
 
+// ---- stream-K path (mlp_streamk.h) for the shapes with enough tiles to give every CU an equal share: BASELINE's C2 / C3 / C4 ----
+// two hidden layers: ONE launch per step (layer 0 as the main layer's operand producer, output layer in its epilogue);
+// three hidden layers (Humanoid): layer 0 on the tile GEMM, then two launches (layer 1 stored, layer 2 + output layer).
+struct SkVt {
+    SkPlan (*plan)(SkArgs&, int);
+    hipError_t (*sched)(SkArgs&, const SkPlan&, void*, hipStream_t);
+    hipError_t (*launch)(const SkArgs&, const SkPlan&, hipStream_t);
+};
+template <int AMODE, int EPI, int S0, int OT> static SkVt sk_vt() {
+    SkVt v;
+    v.plan = [](SkArgs& a, int n_sm) { return sk_plan<AMODE, EPI, S0, OT>(a, n_sm); };
+    v.sched = [](SkArgs& a, const SkPlan& p, void* mem, hipStream_t st) { return sk_build_sched<AMODE, EPI, S0, OT>(a, p, mem, st); };
+    v.launch = [](const SkArgs& a, const SkPlan& p, hipStream_t st) { return sk_launch<AMODE, EPI, S0, OT>(a, p, st); };
+    return v;
+}
+static bool sk_fused_vt(int S0, int OT, SkVt* v) {          // the (input steps, output tiles) pairs of the six envs: swimmer, hopper, snake, half-cheetah, ant
+    if (S0 == 3 && OT == 1) { *v = sk_vt<SK_A_PRODUCER, SK_EPI_OUT, 3, 1>(); return true; }
+    if (S0 == 4 && OT == 1) { *v = sk_vt<SK_A_PRODUCER, SK_EPI_OUT, 4, 1>(); return true; }
+    if (S0 == 5 && OT == 1) { *v = sk_vt<SK_A_PRODUCER, SK_EPI_OUT, 5, 1>(); return true; }
+    if (S0 == 6 && OT == 2) { *v = sk_vt<SK_A_PRODUCER, SK_EPI_OUT, 6, 2>(); return true; }
+    if (S0 == 9 && OT == 2) { *v = sk_vt<SK_A_PRODUCER, SK_EPI_OUT, 9, 2>(); return true; }
+    return false;
+}
+static bool sk_out_vt(int OT, SkVt* v) {
+    if (OT == 1) { *v = sk_vt<SK_A_GLOBAL, SK_EPI_OUT, 1, 1>(); return true; }
+    if (OT == 2) { *v = sk_vt<SK_A_GLOBAL, SK_EPI_OUT, 1, 2>(); return true; }
+    if (OT == 4) { *v = sk_vt<SK_A_GLOBAL, SK_EPI_OUT, 1, 4>(); return true; }
+    return false;
+}
+static void sk_epi_image(int OT, const float* b1, long long sB1, const float* W2, long long sW2, int no, int N, int heads, float* img, hipStream_t st) {
+    const long long per = (OT == 1) ? SkEpi<1>::FLOATS * SkEpi<1>::E : (OT == 2) ? SkEpi<2>::FLOATS * SkEpi<2>::E : SkEpi<4>::FLOATS * SkEpi<4>::E;
+    const long long tot = (long long)heads * (N / 256) * per;
+    const dim3 grid((unsigned)((tot + 255) / 256));
+    if (OT == 1) hipLaunchKernelGGL(k_sk_epi_image<1>, grid, dim3(256), 0, st, b1, sB1, W2, sW2, no, N, heads, img);
+    else if (OT == 2) hipLaunchKernelGGL(k_sk_epi_image<2>, grid, dim3(256), 0, st, b1, sB1, W2, sW2, no, N, heads, img);
+    else hipLaunchKernelGGL(k_sk_epi_image<4>, grid, dim3(256), 0, st, b1, sB1, W2, sW2, no, N, heads, img);
+}
+static size_t sk_epi_floats(int OT, int N, int heads) {
+    const size_t per = (OT == 1) ? SkEpi<1>::FLOATS * SkEpi<1>::E : (OT == 2) ? SkEpi<2>::FLOATS * SkEpi<2>::E : SkEpi<4>::FLOATS * SkEpi<4>::E;
+    return (size_t)heads * (N / 256) * per;
+}
+struct SkPath {            // mode 0: off; 1: x -> [layer 0 | layer 1 | output layer] in one launch; 2: layer L-3 stored, [layer L-2 | output layer]
+    int mode, S0, OT;
+    SkVt v1, v2; SkArgs a1, a2; SkPlan p1, p2;
+};
+// which path (and its plans) for this context and batch; a1 / a2 carry shapes only (pointers are filled in by rollout_gemm_chunk)
+static SkPath sk_select(const metrpo_ctx* c, int B) {
+    SkPath sp = {};
+    const ProblemDesc& pd = c->pd;
+    const int L = pd.dyn.n_layers, K = pd.K;
+    const char* fe = getenv("METRPO_STREAMK");                               // "1": also below one tile per CU (tests at oracle-sized batches)
+    const bool force = fe != nullptr && fe[0] == '1';
+    if (getenv("METRPO_NO_STREAMK") != nullptr || L < 3 || L > 4 || pd.ns > 64) return sp;
+    for (int l = 0; l < L - 1; ++l) if (pd.dyn.act[l] != METRPO_ACT_RELU) return sp;
+    if (pd.dyn.act[L - 1] != METRPO_ACT_IDENTITY) return sp;
+    const int K1 = pd.dyn.dims[L - 2], N = pd.dyn.dims[L - 1];            // the layer in front of the output layer: [K1 x N]
+    if (K1 % 32 != 0 || N % 256 != 0) return sp;
+    sp.OT = (pd.ns <= 16) ? 1 : (pd.ns <= 32) ? 2 : 4;
+    if (!force && (long long)K * ((B + 127) / 128) * (N / 256) < c->n_sm) return sp;   // fewer tiles than CUs: the tile GEMMs / the resident kernels serve those shapes
+    auto shape = [&](SkArgs& a, int K1_, int N_) { a = SkArgs{}; a.M = B; a.heads = K; a.K1 = K1_; a.N = N_; };
+    if (L == 3) {
+        sp.S0 = (pd.nin + 1 + 3) / 4;
+        if (!sk_fused_vt(sp.S0, sp.OT, &sp.v1)) return sp;
+        shape(sp.a1, K1, N);
+        sp.a1.lda = 4 * sp.S0; sp.a1.ldp = 16 * sp.OT; sp.a1.stridePart = (long long)B * sp.a1.ldp;
+        sp.p1 = sp.v1.plan(sp.a1, c->n_sm);
+        if (sp.p1.lds_bytes > 160 * 1024) return sp;
+        sp.mode = 1;
+    } else {
+        const int K0 = pd.dyn.dims[1], N0 = pd.dyn.dims[2];                  // layer 1: [K0 x N0], N0 == K1
+        if (K0 % 32 != 0 || N0 % 256 != 0 || N0 != K1) return sp;
+        if (!sk_out_vt(sp.OT, &sp.v2)) return sp;
+        sp.v1 = sk_vt<SK_A_GLOBAL, SK_EPI_STORE, 1, 1>();
+        shape(sp.a1, K0, N0); shape(sp.a2, K1, N);
+        sp.a2.ldp = 16 * sp.OT; sp.a2.stridePart = (long long)B * sp.a2.ldp;
+        sp.p1 = sp.v1.plan(sp.a1, c->n_sm); sp.p2 = sp.v2.plan(sp.a2, c->n_sm);
+        if (sp.p1.lds_bytes > 160 * 1024 || sp.p2.lds_bytes > 160 * 1024) return sp;
+        sp.mode = 2;
+    }
+    // element offsets of the schedule records are 32 bits
+    if ((long long)K * pd.dyn.n_params >= (1LL << 31) || (long long)K * B * std::max(K1, N) >= (1LL << 31)) { sp.mode = 0; return sp; }
+    return sp;
+}
+
 bool gemm_path_applicable(const metrpo_ctx* c) {
     const ProblemDesc& pd = c->pd;
     if (pd.ns > 64) return false;
@@ -476,12 +563,24 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
     for (int l = 1; l < L; ++l) maxh = std::max(maxh, pd.dyn.dims[l]);
     // workspace (floats): S, X, U, HA, HB, OUT + ints ts, cur_model
     auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };       // keep every sub-buffer 16-byte aligned
-    const size_t nS = up4((size_t)B * pd.ns), nX = up4((size_t)B * ((pd.nin + 3) & ~3)), nU = up4((size_t)B * pd.na), nH = up4((size_t)K * B * maxh), nO = up4((size_t)K * B * pd.ns);
+    SkPath sk = sk_select(c, B);
+    const int ldx = (sk.mode == 1) ? 4 * sk.S0 : ((pd.nin + 3) & ~3);
+    const size_t nS = up4((size_t)B * pd.ns), nX = up4((size_t)B * ldx), nU = up4((size_t)B * pd.na), nH = (sk.mode == 1) ? 0 : up4((size_t)K * B * maxh), nO = up4((size_t)K * B * pd.ns);
     size_t nP = 0;
     for (int l = 0; l < L; ++l) nP = std::max(nP, up4(skinny_part_floats(B, pd.dyn.dims[l + 1], pd.dyn.dims[l], K)));
+    // stream-K path: output-layer partials per 256-column block, epilogue images, schedules, accumulator hand-over slots + flags
+    const SkArgs& ska = (sk.mode == 2) ? sk.a2 : sk.a1;                      // the launch that carries the output layer
+    size_t nSkImg = 0, nSkSched = 0, nSkX = 0, nSkFlag = 0;
+    if (sk.mode) {
+        nP = std::max(nP, up4((size_t)(ska.N / 256) * K * ska.stridePart));
+        nSkImg = up4(sk_epi_floats(sk.OT, ska.N, K));
+        nSkSched = ((sk.p1.sched_bytes + 255) & ~(size_t)255) / 4 + ((sk.mode == 2 ? sk.p2.sched_bytes + 255 : 0) & ~(size_t)255) / 4 + 64;
+        nSkX = up4(std::max(sk.p1.xacc_floats, sk.mode == 2 ? sk.p2.xacc_floats : (size_t)0));
+        nSkFlag = up4((size_t)std::max(sk.p1.nflags, sk.mode == 2 ? sk.p2.nflags : 0));
+    }
     // last hidden layer + output layer as ONE launch when the hidden layer runs on 64x64 tiles anyway (C0-params-file, C2, C3 shapes): its
     // activations (K x B x width floats: 51 MB at C3) are then neither written nor read back; k_big_post adds the width/64 partials
-    const int fuse_tile = (L >= 2 && pd.dyn.act[L - 2] == METRPO_ACT_RELU && pd.dyn.act[L - 1] == METRPO_ACT_IDENTITY && getenv("METRPO_NO_FUSED_OUT") == nullptr)
+    const int fuse_tile = (!sk.mode && L >= 2 && pd.dyn.act[L - 2] == METRPO_ACT_RELU && pd.dyn.act[L - 1] == METRPO_ACT_IDENTITY && getenv("METRPO_NO_FUSED_OUT") == nullptr)
                               ? gemm_fused_out_tile(B, pd.dyn.dims[L - 1], K, pd.ns) : 0;
     const bool fuse_out = fuse_tile > 0;
     if (fuse_out) nP = std::max(nP, up4(gemm_fused_out_part_floats(B, pd.dyn.dims[L - 1], K, pd.ns, fuse_tile)));
@@ -495,15 +594,48 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
     const bool pre_gemm = !pre_mfma && ((pg_env && pg_env[0] == '1') || (!(pg_env && pg_env[0] == '0') && (B >= 1024 || pd.pol.n_params >= 4096)));
     const size_t nPol = pre_gemm ? up4((size_t)B * pd.pol.max_width) : 0;
     const size_t nPimg = pre_lds ? up4((size_t)pre_mfma3_image_floats<55, 21, 100, 50, 25>()) : 0;      // the only three-hidden-layer instantiation (big_pre_mfma_select)
-    const size_t need = ((nS + nX + nU + 2 * nH + nO + nP + 2 * nPol + nPimg) * sizeof(float) + 2 * (size_t)B * sizeof(int) + 511) & ~(size_t)255;
+    const size_t need = ((nS + nX + nU + 2 * nH + nO + nP + 2 * nPol + nPimg + nSkImg + nSkSched + nSkX + nSkFlag) * sizeof(float) + 2 * (size_t)B * sizeof(int) + 1023) & ~(size_t)255;
     if (need_out) *need_out = need;
     if (ws == nullptr) return METRPO_OK;
     BigState bs = {};
     float* p = (float*)ws;
     bs.S = p; p += nS; bs.X = p; p += nX; bs.U = p; p += nU; bs.HA = p; p += nH; bs.HB = p; p += nH; bs.OUT = p; p += nO; bs.PART = nP ? p : nullptr; p += nP; bs.PA = p; p += nPol; bs.PB = p; p += nPol; bs.PIMG = nPimg ? p : nullptr; p += nPimg;
+    float* sk_img = p; p += nSkImg;
+    char* sk_sched = (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255); p += nSkSched;     // 256-byte aligned inside its (64 floats larger) slot
+    float* sk_xacc = p; p += nSkX;
+    unsigned* sk_flag = (unsigned*)p; p += nSkFlag;
     bs.ts = (int*)p; bs.cur_model = bs.ts + B;
+    bs.out_ld = pd.ns; bs.xone = (sk.mode == 1) ? 1 : 0;
+    if (sk.mode) c->last_rollout_kernel = 5;
+    unsigned sk_epoch = 0;                                   // flags are zeroed below; every launch of this chain takes the next epoch
+    if (sk.mode) {
+        const int Lo = L - 1;                                // output layer
+        HIP_TRY(c, hipMemsetAsync(sk_flag, 0, nSkFlag * sizeof(float), st));
+        sk_epi_image(sk.OT, c->d_dyn + pd.dyn.b_off[Lo - 1], pd.dyn.n_params, c->d_dyn + pd.dyn.w_off[Lo], pd.dyn.n_params, pd.ns, ska.N, K, sk_img, st);
+        SkArgs& o = (sk.mode == 2) ? sk.a2 : sk.a1;
+        o.W1 = c->d_dyn + pd.dyn.w_off[Lo - 1]; o.strideW1 = pd.dyn.n_params;
+        o.epi = sk_img; o.part = bs.PART;
+        if (sk.mode == 1) {
+            o.A = bs.X; o.strideA = 0;
+            o.W0 = c->d_dyn + pd.dyn.w_off[0]; o.strideW0 = pd.dyn.n_params;      // row nin of the resident layout = b0 (X[nin] = 1), the rows behind it meet X's zero pad
+        } else {
+            SkArgs& h = sk.a1;                               // layer 1: relu(HA W1 + b1) -> HB
+            h.A = bs.HA; h.strideA = (long long)B * h.K1; h.lda = h.K1;
+            h.W1 = c->d_dyn + pd.dyn.w_off[1]; h.strideW1 = pd.dyn.n_params; h.b1 = c->d_dyn + pd.dyn.b_off[1]; h.strideB1 = pd.dyn.n_params;
+            h.C = bs.HB; h.strideC = (long long)B * h.N; h.ldc = h.N;
+            o.A = bs.HB; o.strideA = (long long)B * o.K1; o.lda = o.K1;
+        }
+        sk.a1.xacc = sk_xacc; sk.a1.xflag = sk_flag; sk.a1.err = comm_err_cell(c) + 1;      // scal[S_ROLLERR]
+        HIP_TRY(c, sk.v1.sched(sk.a1, sk.p1, sk_sched, st));
+        if (sk.mode == 2) {
+            sk.a2.xacc = sk_xacc; sk.a2.xflag = sk_flag; sk.a2.err = comm_err_cell(c) + 1;
+            HIP_TRY(c, sk.v2.sched(sk.a2, sk.p2, sk_sched + ((sk.p1.sched_bytes + 255) & ~(size_t)255), st));
+        }
+        bs.out_splits = ska.N / 256; bs.out_stride = ska.stridePart; bs.out_ld = ska.ldp;
+        bs.out_bias = c->d_dyn + pd.dyn.b_off[Lo]; bs.out_bias_stride = pd.dyn.n_params;
+    }
     if (nPimg) hipLaunchKernelGGL((k_pre_mfma3_image<55, 21, 100, 50, 25>), dim3((unsigned)((nPimg + 255) / 256)), dim3(256), 0, st, c->d_theta, bs.PIMG);
-    bs.ldx = (pd.nin + 3) & ~3;
+    bs.ldx = ldx;
     RolloutK r = make_rollout_k(a);
     r.vB = vB; r.vR = vR;                                    // merged rounds: a->B = vR * vB rows, a->T = H steps (launch_rollout_gemm)
     const int pbs = 256;                                     // 64 envs x 4 output groups
@@ -529,7 +661,18 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
         else hipLaunchKernelGGL(k_big_pre, dim3((B + 63) / 64), dim3(pbs), psh, st, pd, r, t, c->d_theta, c->d_norm, bs);
         const float* in = bs.X; long long sIn = 0; int ldin = bs.ldx;
         float* bufs[2] = {bs.HA, bs.HB};
-        for (int l = 0; l < L; ++l) {
+        if (sk.mode == 1) {                                  // the whole dynamics ensemble of this step in one launch
+            sk.a1.epoch = ++sk_epoch;
+            HIP_TRY(c, sk.v1.launch(sk.a1, sk.p1, st));
+        } else if (sk.mode == 2) {
+            gemm_launch(METRPO_ACT_RELU, bs.X, 0, bs.ldx, c->d_dyn + pd.dyn.w_off[0], pd.dyn.n_params, pd.dyn.dims[1], c->d_dyn + pd.dyn.b_off[0], pd.dyn.n_params,
+                        bs.HA, (long long)B * pd.dyn.dims[1], pd.dyn.dims[1], B, pd.dyn.dims[1], bs.ldx, K, st);
+            sk.a1.epoch = ++sk_epoch;
+            HIP_TRY(c, sk.v1.launch(sk.a1, sk.p1, st));
+            sk.a2.epoch = ++sk_epoch;
+            HIP_TRY(c, sk.v2.launch(sk.a2, sk.p2, st));
+        }
+        for (int l = 0; l < L && !sk.mode; ++l) {
             // layer 0 contracts over the PADDED input row (X's pad columns are 0, the weight rows they meet are the first bias entries that follow
             // W0 in the resident layout: finite x 0): a contraction length that is a multiple of 4 takes the GEMM's aligned load path
             const int Kd = (l == 0 && L > 1) ? bs.ldx : pd.dyn.dims[l], N = pd.dyn.dims[l + 1];

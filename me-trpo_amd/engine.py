@@ -288,9 +288,10 @@ class Engine(object):
 
     def last_rollout_kernel(self):
         """Kernel family the last rollout() of this engine ran on: 'generic', 'mfma-head-per-wave', 'mfma-cooperative', 'gemm-stepwise',
-        'resident' (whole time loop in one launch, rollout_resident.hip); None before the first rollout."""
+        'resident' (whole time loop in one launch, rollout_resident.hip), 'gemm-streamk' (step-wise, the whole ensemble of a step in one
+        evenly split launch, mlp_streamk.h); None before the first rollout."""
         k = int(lib.metrpo_last_rollout_kernel(self._ctx))
-        return {0: 'generic', 1: 'mfma-head-per-wave', 2: 'mfma-cooperative', 3: 'gemm-stepwise', 4: 'resident'}.get(k)
+        return {0: 'generic', 1: 'mfma-head-per-wave', 2: 'mfma-cooperative', 3: 'gemm-stepwise', 4: 'resident', 5: 'gemm-streamk'}.get(k)
 
     def alloc_trajectory(self, B, T, H):
         dev, f = self.device, torch.float32

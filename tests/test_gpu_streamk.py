@@ -1,0 +1,95 @@
+"""Step-wise rollout on the stream-K fused ensemble kernel (csrc/mlp_streamk.h): the whole dynamics ensemble of a time step in ONE evenly split
+launch (two hidden layers: layer 0 as operand producer, output layer in the epilogue; three hidden layers: two launches).  Reference:
+training.py:171-214,218-269 (the K-head forward), env_helpers.py:597-635 (the step around it).  Every case runs through metrpo_rollout
+(C ABI) with supplied draws and is compared with the float64 oracle teacher-forced on the device's own states, and with the tile-GEMM
+path of the same library on the same draws.
+
+Tolerances: DESIGN.md section 5 table, rows "next state, 512 / 1024-wide nets" (rtol 1e-4, atol 5e-5: sums of 512-1024 fp32 products in a fixed
+order that differs from the oracle's float64 order)."""
+import numpy as np
+import pytest
+import torch
+from oracle import metrpo_oracle as O
+import helpers as Hh
+
+pytestmark = pytest.mark.gpu
+WIDE_TOL = dict(rtol=1e-4, atol=5e-5)
+
+
+def cpu(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def _rollout_vs_oracle(eng, dm, theta, pdims, pool, env, K, B, T, H, sam_mode='step_rand', seed=6):
+    th = theta.astype(np.float32).astype(np.float64)
+    pool32 = pool.astype(np.float32).astype(np.float64)
+    dr = Hh.draws(np.random.RandomState(seed), K, B, T, dm.ns, dm.na, len(pool))
+    dr32 = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in dr.items()}
+    traj = eng.rollout(B, T, H, sam_mode, pool, **dr32)
+    drf = {k: (v.astype(np.float64) if v.dtype == np.float32 else v) for k, v in dr32.items()}
+    ref = Hh.oracle_rollout(dm, th, pdims, env, pool32, drf, B, T, H, sam_mode, teacher_obs=cpu(traj.obs))
+    np.testing.assert_allclose(cpu(traj.mean), ref['mean'], **WIDE_TOL)
+    np.testing.assert_allclose(cpu(traj.rew), ref['rew'], **WIDE_TOL)
+    dn = cpu(traj.done).astype(bool)
+    assert np.array_equal(dn, ref['done'])
+    for t in range(T - 1):
+        np.testing.assert_allclose(cpu(traj.obs[t + 1])[~dn[t]], ref['next'][t][~dn[t]], **WIDE_TOL)
+    return traj, dr32
+
+
+# (env, K, hidden, B): every (input steps, output tiles) instantiation of the fused kernel -- swimmer (3, 1), hopper (4, 1), snake (5, 1),
+# half-cheetah (6, 2), ant (9, 2) -- and the three-hidden-layer form (humanoid: stored layer + (.., 4)); batches that are not multiples of 16 / 128
+SHAPES = [('swimmer', 5, (512, 512), 100), ('hopper', 3, (256, 256), 77), ('snake', 4, (256, 512), 130), ('half_cheetah', 5, (1024, 1024), 48),
+          ('ant', 10, (512, 512), 64), ('ant', 3, (512, 256), 333), ('humanoid', 4, (1024, 1024, 1024), 24), ('humanoid', 2, (256, 512, 256), 150)]
+
+
+@pytest.mark.parametrize('env,K,dh,B', SHAPES)
+def test_streamk_rollout_vs_oracle_and_tile_gemm(env, K, dh, B, monkeypatch):
+    ph = (100, 50, 25) if env == 'humanoid' else (32, 32)
+    T, H = 5, 3
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, dh, ph, seed=71)
+    if env == 'ant':
+        pool[::3, 2] = 0.21; dm.diff_mean[2] = -0.02
+        eng.set_dynamics_layers(dm.Ws, dm.bs, dm.in_mean, dm.in_std, dm.diff_mean, dm.diff_std)
+    monkeypatch.setenv('METRPO_STREAMK', '1')                  # also below one tile per CU
+    eng.set_rollout_variant(1)                                 # large nets: the step-wise path even where the resident kernel applies
+    traj, dr32 = _rollout_vs_oracle(eng, dm, theta, pdims, pool, env, K, B, T, H)
+    assert eng.last_rollout_kernel() == 'gemm-streamk'
+    again = eng.rollout(B, T, H, 'step_rand', pool, **dr32)    # bitwise repeatable
+    assert torch.equal(again.obs, traj.obs) and torch.equal(again.rew, traj.rew)
+    monkeypatch.delenv('METRPO_STREAMK')
+    monkeypatch.setenv('METRPO_NO_STREAMK', '1')
+    tile = eng.rollout(B, T, H, 'step_rand', pool, **dr32)     # free-running for 5 steps: same path structure, states within fp32 rounding of 5 steps
+    assert eng.last_rollout_kernel() == 'gemm-stepwise'
+    assert torch.equal(tile.tpath, traj.tpath) and torch.equal(tile.done, traj.done)
+    np.testing.assert_allclose(cpu(tile.obs), cpu(traj.obs), rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize('sam_mode', list(O.SAM_MODES))
+def test_streamk_rollout_all_sam_modes(sam_mode, monkeypatch):
+    env, K, B, T, H = 'half_cheetah', 4, 70, 6, 3
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (256, 256), (32, 32), seed=61)
+    monkeypatch.setenv('METRPO_STREAMK', '1')
+    eng.set_rollout_variant(1)
+    _rollout_vs_oracle(eng, dm, theta, pdims, pool, env, K, B, T, H, sam_mode=sam_mode)
+    assert eng.last_rollout_kernel() == 'gemm-streamk'
+
+
+def test_streamk_split_tiles_equal_the_oracle_and_do_not_depend_on_the_split():
+    """More tiles than CUs and not a multiple of them: workgroup ranges start and end inside tiles, accumulators are handed over between
+    workgroups.  K = 5 heads x 32 row blocks x 2 column blocks = 320 tiles on the chip's CUs; the rollout picks the path by itself."""
+    env, K, B, T, H = 'ant', 5, 4000, 3, 3
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (512, 512), (32, 32), seed=81)
+    traj, dr32 = _rollout_vs_oracle(eng, dm, theta, pdims, pool, env, K, B, T, H)
+    assert eng.last_rollout_kernel() == 'gemm-streamk'
+    again = eng.rollout(B, T, H, 'step_rand', pool, **dr32)
+    assert torch.equal(again.obs, traj.obs) and torch.equal(again.rew, traj.rew) and torch.equal(again.mean, traj.mean)
+
+
+def test_streamk_three_hidden_layers_split_tiles():
+    env, K, B, T, H = 'humanoid', 6, 1500, 2, 2                # 6 x 12 x 4 = 288 tiles per launch
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (1024, 1024, 1024), (100, 50, 25), seed=83)
+    traj, dr32 = _rollout_vs_oracle(eng, dm, theta, pdims, pool, env, K, B, T, H)
+    assert eng.last_rollout_kernel() == 'gemm-streamk'
+    again = eng.rollout(B, T, H, 'step_rand', pool, **dr32)
+    assert torch.equal(again.obs, traj.obs)
