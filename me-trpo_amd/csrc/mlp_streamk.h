@@ -283,10 +283,13 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
 
     // ---- prologue: entries 0 .. 2 under way, the first rows loaded ----
     RecL r0, r1; RecI r3;
-    {
-        RecI i0, i1, i2; RecL dummy;
-        fetch2(0, 0, r0, i0); fetch2(1, 1, r1, i1); fetch2(2, 2, dummy, i2); fetch2(3, 3, dummy, r3);
-        issue(i0, 0); issue(i1, 1); issue(i2, 2);
+    {   // entries 0 .. 3 by one statement (one wait instead of four scalar-load round trips: the prologue is 3-4 % of a 130 us launch)
+        sk_i32x4 l0, l1, i0, i1, i2, i3;
+        asm volatile("s_load_dwordx4 %0, %6, 0x0\n\ts_load_dwordx4 %1, %6, 0x20\n\ts_load_dwordx4 %2, %6, 0x10\n\ts_load_dwordx4 %3, %6, 0x30\n\t"
+                     "s_load_dwordx4 %4, %6, 0x50\n\ts_load_dwordx4 %5, %6, 0x70\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(l0), "=&s"(l1), "=&s"(i0), "=&s"(i1), "=&s"(i2), "=&s"(i3) : "s"(my_recs));
+        r0 = decL(l0); r1 = decL(l1); r3 = decI(i3);
+        issue(decI(i0), 0); issue(decI(i1), 1); issue(decI(i2), 2);
     }
     if constexpr (PROD) load_x(r0);
     else { set_a_voff(r0); load_a(r0, hs[0]); drain_a(hs[0]); }
@@ -298,6 +301,7 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
     if (a.dbg != nullptr) { dbg_c0 = __builtin_readcyclecounter(); dbg_w0 = wall_clock64(); }
 #endif
 
+    bool export_issued = false, export_pending = false;
     auto body = [&](auto par_, const int q) {
         constexpr int PAR = decltype(par_)::value;
         f32x4 (&h)[2] = hs[PAR];
@@ -389,9 +393,7 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
                         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[u][v]), rs, ((u * 4 + v) * 64 + lane) * 16, 0, 16);   // sc1: write-through
                     }
-                __builtin_amdgcn_s_waitcnt(0x0F70);                            // every storing wave drains before its flag
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_store(a.xflag + (size_t)blockIdx.x * 8 + wave, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                export_issued = true;                                          // not waited for here: the flag follows behind the NEXT chunk's drain
             }
             if constexpr (!OUT) {
                 if (r0.fl & SKF_LAST) {
@@ -451,8 +453,18 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
             }
         }
         SK_STAMP(3);
-        if constexpr (!PROD) drain_a(hn);                                      // (nothing to wait for behind the line below; names the registers the asm loads wrote)
-        drain_vm();                                                            // this wave's copies of entry q + 3 (issued early in the chunk) and its rows: landed long ago
+        if (export_issued) {                                                   // all but the 16 youngest memory operations = the accumulator stores just issued: they fly
+            if constexpr (!PROD) asm volatile("s_waitcnt vmcnt(16)" : "+v"(hn[0]), "+v"(hn[1]) :: "memory");   // under the next chunk, whose drain covers them
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            export_issued = false; export_pending = true;
+        } else {
+            if constexpr (!PROD) drain_a(hn);                                  // (nothing to wait for behind the line below; names the registers the asm loads wrote)
+            drain_vm();                                                        // this wave's copies of entry q + 3 (issued early in the chunk) and its rows: landed long ago
+            if (export_pending) {                                              // every storing wave has drained its stores before its flag
+                if (lane == 0) __hip_atomic_store(a.xflag + (size_t)blockIdx.x * 8 + wave, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                export_pending = false;
+            }
+        }
         SK_STAMP(4);
 #ifdef SK_DEBUG
         if (!(a.skip & 4))
@@ -465,6 +477,10 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
     for (int q = 0; q < nq; q += 2) {                                          // unrolled by two: the register set of the srcB operands alternates
         body(std::integral_constant<int, 0>{}, q);
         if (q + 1 < nq) body(std::integral_constant<int, 1>{}, q + 1);
+    }
+    if (export_pending) {                                                      // the range ended with the exporting piece
+        drain_vm();
+        if (lane == 0) __hip_atomic_store(a.xflag + (size_t)blockIdx.x * 8 + wave, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #ifdef SK_DEBUG
     if (a.dbg != nullptr && lane == 0) {                                       // shader cycles and 100 MHz ticks of this workgroup's main loop, its chunk count

@@ -2,6 +2,8 @@
 """Per-kernel mean of rocprofv3 PMC counters from <prefix>_counter_collection.csv."""
 import sys, pandas as pd
 df = pd.read_csv(sys.argv[1])
+if len(sys.argv) > 3:          # only kernels whose name contains this
+    df = df[df['Kernel_Name'].str.contains(sys.argv[3], regex=False)]
 df['k'] = df['Kernel_Name'].str.slice(0, 48)
 t = df.pivot_table(index='k', columns='Counter_Name', values='Counter_Value', aggfunc='mean')
 n = df.groupby('k')['Dispatch_Id'].nunique().rename('dispatches')
