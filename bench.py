@@ -127,6 +127,16 @@ def main():
         os.environ['LOCAL_RANK'] = str(dev)
     comm = metrpo_amd.Comm.init_from_env(backend)
     assert comm.world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (comm.world, args.gpus)
+    if comm.world > 1 and os.environ.get('METRPO_BENCH_NO_PREFLIGHT') is None:
+        # first contact with a multi-GPU box made cheap (tools/multi_gpu_preflight.py): peer access, the agreed transport, exact sums, bit-identical
+        # theta after one sharded update -- on stderr, before anything is timed; a failure ends the run with its reason instead of a hang or a wrong number
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools'))
+        from multi_gpu_preflight import preflight
+        ok, _rep = preflight(comm.world, comm.rank, dev, latency_table=False, out=lambda *a: print(*a, file=sys.stderr, flush=True))
+        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=('cuda' if backend == 'nccl' else 'cpu'))
+        torch.distributed.all_reduce(okt, op=torch.distributed.ReduceOp.MIN)
+        if int(okt.item()) != 1:
+            sys.exit(3)
 
     cfg = synthetic.CONFIGS[args.config]
     env, K, H = cfg['env'], cfg['K'], cfg['H']

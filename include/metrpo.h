@@ -65,7 +65,10 @@ typedef enum {
 
 typedef enum { METRPO_ACT_IDENTITY = 0, METRPO_ACT_RELU = 1, METRPO_ACT_TANH = 2 } metrpo_act;
 
-/* Static shape of the problem (params/params-<env>.json keys in brackets). */
+/* Static shape of the problem (params/params-<env>.json keys in brackets).
+ * Dynamics-model variant: prediction_type "state_change" only (training.py:257).  "second_derivative" (training.py:259-264), the "*_goal"
+ * types (:265-268) and use_logit_weights (:234-242) have no field here and no kernel behind it: a host reading such a params file must refuse
+ * it by name (me-trpo_amd/engine.py: Engine(prediction_type=..., use_logit_weights=...) raises). */
 typedef struct {
     int32_t env;                              /* metrpo_env                                   */
     int32_t ns, na;                           /* state / action dims                          */

@@ -110,7 +110,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     c->d_bptt = nullptr; c->bptt_cap = 0; c->det_cfg = -1; c->d_detpart = nullptr; c->detpart_cap = 0; c->det_gemm = 0; c->d_dg = nullptr; c->dg_cap = 0; c->vjp_gm = nullptr; c->ls_skip = nullptr; c->d_pol_adam = nullptr; c->pol_adam_t = 0; c->mfma_cfg = -1; c->pol_mfma = -1; c->coop_cfg = -1; c->rollout_variant = 0;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_cg = nullptr; c->d_vf = nullptr; c->d_theta_try = nullptr;
     c->d_valbuf = nullptr; c->h_pinned = nullptr; c->n_sm = 256;
-    c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gae_part = nullptr; c->gae_part_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0; c->d_res = nullptr; c->res_cap = 0; c->res_seq = 0; c->res_failed = 0; c->last_rollout_kernel = -1; c->upd_pending = 0; c->upd_spec = 0; c->h_upd = nullptr; c->upd_stamp = 0; c->side_ready = 0; c->d_ticket = nullptr; c->d_hcache = nullptr; c->hcache_cap = 0; c->hcache_on = 0; c->d_mig = nullptr; c->mig_cap = 0; c->mig_epoch = 0; c->nccl_comm = nullptr; c->comm_world = 0; c->comm_rank = 0; c->pol_path = 1; c->d_pg = nullptr; c->pg_cap = 0; c->pg_fwd_rows = -1; c->pg_fwd_obs = nullptr; c->d_adam = nullptr; c->adam_t = 0; c->d_train = nullptr; c->train_cap = 0; c->d_train_part = nullptr; c->train_part_cap = 0;
+    c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gae_part = nullptr; c->gae_part_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0; c->d_res = nullptr; c->res_cap = 0; c->res_seq = 0; c->res_failed = 0; c->last_rollout_kernel = -1; c->upd_pending = 0; c->upd_spec = 0; c->upd_changed_in_end = 0; c->h_upd = nullptr; c->upd_stamp = 0; c->side_ready = 0; c->d_ticket = nullptr; c->d_hcache = nullptr; c->hcache_cap = 0; c->hcache_on = 0; c->d_mig = nullptr; c->mig_cap = 0; c->mig_epoch = 0; c->nccl_comm = nullptr; c->comm_world = 0; c->comm_rank = 0; c->pol_path = 1; c->d_pg = nullptr; c->pg_cap = 0; c->pg_fwd_rows = -1; c->pg_fwd_obs = nullptr; c->d_adam = nullptr; c->adam_t = 0; c->d_train = nullptr; c->train_cap = 0; c->d_train_part = nullptr; c->train_part_cap = 0;
     ProblemDesc& pd = c->pd;
     pd.env = d->env; pd.ns = d->ns; pd.na = d->na; pd.K = d->n_models; pd.n_drop = d->n_drop;
     pd.nin = d->ns + d->na - d->n_drop;
@@ -505,7 +505,7 @@ int run_trpo_update(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_para
 // all-reduce between a reduction and its consumer) on the fused MFMA or generic kernels; the GEMM path has its own reductions.
 static bool device_line_search_ok(const metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_params* pr) {
     const bool xg = (pr->allreduce == nullptr && c->xg_world > 1);
-    const bool fused = (pr->allreduce == nullptr && ((c->nccl_comm == nullptr && !xg) || (xg && !policy_gemm_applicable(c, b->N))));
+    const bool fused = (pr->allreduce == nullptr && ((c->nccl_comm == nullptr && !xg) || (xg && !policy_gemm_applicable(c, b->N) && c->pd.P + 1 <= c->xg_cap)));
     return fused && !policy_gemm_applicable(c, b->N) && getenv("METRPO_NO_DEVICE_LINESEARCH") == nullptr;
 }
 static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_params* pr, metrpo_trpo_diag* diag,
@@ -525,7 +525,8 @@ static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metr
     // their own tail (xg_fuse), so the update keeps its single-rank launch sequence -- CG vector steps included.  The GEMM path
     // (policy_gemm.hip) has its own reduction kernels: there the exchange is the stand-alone one-shot kernel between them and the CG step.
     const bool xg = (pr->allreduce == nullptr && c->xg_world > 1);
-    const bool xg_fused = xg && !policy_gemm_applicable(c, b->N);
+    // in-tail exchange: per-element packets into ONE slot per source (k_finalize does not split); longer vectors take the stand-alone, chunked exchange
+    const bool xg_fused = xg && !policy_gemm_applicable(c, b->N) && P + 1 <= c->xg_cap;
     const bool fused = (pr->allreduce == nullptr && ((c->nccl_comm == nullptr && !xg) || xg_fused));
     c->xg_fuse = xg_fused ? 1 : 0;
     struct FuseOff { metrpo_ctx* c; ~FuseOff() { c->xg_fuse = 0; } } fuse_off{c};
@@ -613,7 +614,7 @@ static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metr
             std::atomic_thread_fence(std::memory_order_acquire);
             for (int i = 0; i < 14; ++i) c->h_pinned[i] = c->h_upd[i];
         }
-        if (c->h_pinned[S_COMMERR] != 0.0) return set_err(c, METRPO_EHIP, "trpo_update: one-shot all-reduce timed out (a rank did not arrive)");
+        if (c->xg_world > 1 && c->h_pinned[S_COMMERR] != 0.0) return set_err(c, METRPO_EHIP, "trpo_update: one-shot all-reduce timed out (a rank did not arrive)");
         if (c->h_pinned[S_ROLLERR] != 0.0) return rollout_error_seen(c, st);
         loss_before = c->h_pinned[S_LOSS0]; first = false;
         loss = c->h_pinned[11]; kl = c->h_pinned[12];
@@ -628,7 +629,7 @@ static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metr
         AR(v.lk, 2);
         HIP_TRY(c, hipMemcpyAsync(c->h_pinned, v.scal, sizeof(double) * 10, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
-        if (c->h_pinned[S_COMMERR] != 0.0) return set_err(c, METRPO_EHIP, "trpo_update: one-shot all-reduce timed out (a rank did not arrive)");
+        if (c->xg_world > 1 && c->h_pinned[S_COMMERR] != 0.0) return set_err(c, METRPO_EHIP, "trpo_update: one-shot all-reduce timed out (a rank did not arrive)");
         if (c->h_pinned[S_ROLLERR] != 0.0) return rollout_error_seen(c, st);
         if (first) { loss_before = c->h_pinned[S_LOSS0]; first = false; }
         loss = c->h_pinned[8]; kl = c->h_pinned[9];
@@ -644,6 +645,7 @@ static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metr
     else if (accepted) {
         std::swap(c->d_theta, c->d_theta_try);               // both ctx-owned, every launch takes c->d_theta afresh: no copy
         if (c->mfma_cfg >= 0 && (rc = mfma_prepare_policy(c, st))) return rc;
+        c->upd_changed_in_end = (phase == 2) ? 1 : 0;        // theta changed on the HOST side of a two-half update: work enqueued after _begin used theta_prev
     }
     if (diag) {
         diag->loss_before = loss_before; diag->loss = loss; diag->kl = kl;
@@ -695,11 +697,14 @@ extern "C" int32_t metrpo_trpo_update_end(metrpo_ctx* c, metrpo_trpo_diag* diag,
     if (!c->upd_pending) return set_err(c, METRPO_ESTATE, "trpo_update_end: no update is open");
     if (c->upd_pending == 2) { if (diag) *diag = c->upd_diag; c->upd_pending = 0; return METRPO_OK; }
     metrpo_trpo_diag d = {};
+    c->upd_changed_in_end = 0;
     const int rc = run_trpo_update(c, &c->upd_batch, &c->upd_params, &d, nullptr, nullptr, (hipStream_t)stream, 2, c->upd_spec);
     c->upd_pending = 0;
     if (rc == METRPO_OK) {
         if (diag) *diag = d;
-        if (late_out) *late_out = (d.accepted && d.n_backtrack >= c->upd_spec) ? 1 : 0;
+        // not inferred from n_backtrack: with accept_violation and spec_trials >= max_backtracks no trial stops the search, _end still installs the last
+        // trial's theta, and n_backtrack (= spec_trials - 1) is below upd_spec
+        if (late_out) *late_out = c->upd_changed_in_end;
     }
     return rc;
 }

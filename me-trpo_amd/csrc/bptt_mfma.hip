@@ -378,17 +378,21 @@ __global__ void __launch_bounds__(256, 2) k_det_mfma(int K, int B, int T, double
 }
 
 // fixed-order sum of the per-tile cost partials of one model
-__global__ void k_det_cost_reduce(int n_part, const double* __restrict__ part, double* __restrict__ costs) {
+// err (may be NULL): sticky time-out cell of the rollout kernels' hand-overs (scal[S_ROLLERR]).  A resident validation launch whose grid was not
+// co-resident leaves invalid partial sums; callers of metrpo_validation_cost never read that cell (only metrpo_trpo_update / metrpo_comm_check
+// do), so the costs themselves carry the failure: NaN instead of plausible garbage feeding model selection and early stopping.
+__global__ void k_det_cost_reduce(int n_part, const double* __restrict__ part, double* __restrict__ costs, const double* __restrict__ err) {
     if (threadIdx.x == 0) {
         double s = 0.0;
         for (int i = 0; i < n_part; ++i) s += part[(size_t)blockIdx.x * n_part + i];
+        if (err != nullptr && *err != 0.0) s = __builtin_nan("");
         costs[blockIdx.x] = s;
     }
 }
 
 // costs[k] = the n_part partials of model k added in index order (also the generic forward kernels' block sums: rollout_generic.hip, bptt.hip)
 int launch_det_cost_reduce(metrpo_ctx* c, int n_part, const double* part, double* costs, hipStream_t st) {
-    hipLaunchKernelGGL(k_det_cost_reduce, dim3(c->pd.K), dim3(64), 0, st, n_part, part, costs);
+    hipLaunchKernelGGL(k_det_cost_reduce, dim3(c->pd.K), dim3(64), 0, st, n_part, part, costs, (const double*)(c->d_cg ? comm_err_cell(c) + 1 : nullptr));
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;
 }
@@ -420,7 +424,7 @@ int launch_det_forward(metrpo_ctx* c, int idx, const float* s0, int B, int T, do
     const int gx = (B + 63) / 64;
     hipLaunchKernelGGL(en.fwd, dim3(gx, c->pd.K), dim3(256), sh, st, c->pd.K, B, T, gamma, c->d_dyn, c->d_theta, c->d_norm, s0, XS, WT,
                        (float*)nullptr, part);
-    hipLaunchKernelGGL(k_det_cost_reduce, dim3(c->pd.K), dim3(64), 0, st, gx * 4, part, costs);
+    hipLaunchKernelGGL(k_det_cost_reduce, dim3(c->pd.K), dim3(64), 0, st, gx * 4, part, costs, (const double*)nullptr);
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;
 }

@@ -193,6 +193,13 @@ extern "C" int32_t metrpo_comm_ipc_detach(metrpo_ctx* c) {
     }
     for (int q = 0; q < XCHG_MAX_WORLD; ++q) c->xg_peer[q] = nullptr;
     c->xg_world = 0; c->xg_rank = 0; c->xg_fuse = 0;
+    // The time-out cell of the exchanges is sticky by design; it must not outlive the transport that raised it: 'auto' mode detaches after a
+    // timed-out test exchange and goes on over RCCL or the caller's callback, and every later update of this context would report that old time-out.
+    if (c->d_cg) {
+        (void)hipSetDevice(c->device);
+        (void)hipMemset(comm_err_cell(c), 0, sizeof(double));
+        (void)hipDeviceSynchronize();
+    }
     return METRPO_OK;
 }
 

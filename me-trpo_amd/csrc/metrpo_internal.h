@@ -97,7 +97,7 @@ struct metrpo_ctx {
     // stamp); _end polls the stamp (no copy engine, no event, no blocking wait to wake up from).  Publishing from a side stream behind a device-scope
     // event was measured too: the second queue costs the update 35 us, more than the 15 us gap in front of the next rollout it removes.
     double* h_upd; unsigned long long upd_stamp;
-    int upd_pending, upd_spec; metrpo_batch upd_batch; metrpo_trpo_params upd_params; metrpo_trpo_diag upd_diag;                              // which kernel family the last metrpo_rollout ran on: 0 generic, 1 head-per-wave MFMA, 2 cooperative MFMA, 3 step-wise GEMM, 4 resident
+    int upd_pending, upd_spec, upd_changed_in_end; metrpo_batch upd_batch; metrpo_trpo_params upd_params; metrpo_trpo_diag upd_diag;                              // which kernel family the last metrpo_rollout ran on: 0 generic, 1 head-per-wave MFMA, 2 cooperative MFMA, 3 step-wise GEMM, 4 resident
     hipStream_t side_stream[METRPO_MAX_PAR_ROUNDS - 1]; hipEvent_t ev_fork, ev_join[METRPO_MAX_PAR_ROUNDS - 1]; int side_ready;   // rollout_gemm.hip: independent rounds of a small-batch rollout run concurrently
     double* h_pinned;    // pinned host scratch for the per-trial read-back
     int n_sm;            // CU count

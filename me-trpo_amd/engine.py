@@ -41,7 +41,16 @@ class Engine(object):
     """Owns the metrpo_ctx for one (env, ensemble shape, policy shape) on one GPU."""
 
     def __init__(self, env, n_models, dyn_hidden, pol_hidden, ns=None, na=None, n_drop=None, dyn_act='relu',
-                 device=None):
+                 device=None, prediction_type='state_change', use_logit_weights=False):
+        # the dynamics-model variants the reference defines but none of its six-env params files selects have no kernel here: say so by name
+        # instead of silently evaluating the 'state_change' arithmetic (dynamics_model.prediction_type / .use_logit_weights of params-*.json)
+        if prediction_type != 'state_change':
+            raise ValueError("dynamics_model.prediction_type=%r is not implemented: only 'state_change' (training.py:257: s' = diff_mean + diff_std * out + s); "
+                             "'second_derivative' (training.py:259-264) and the '*_goal' variants (training.py:265-268) have no kernel in this library"
+                             % (prediction_type,))
+        if use_logit_weights:
+            raise ValueError("dynamics_model.use_logit_weights=True is not implemented (the sigmoid input gate of training.py:234-242, 212-213); "
+                             "every shipped params file of the six envs sets it to false")
         if not torch.cuda.is_available():
             raise RuntimeError("metrpo_amd needs an AMD GPU (gfx950); there is no CPU fallback")
         self.env_name = env.replace('-', '_')

@@ -27,7 +27,14 @@ class DeviceEvent(object):
     def __init__(self):
         import ctypes as C
         if DeviceEvent._hip is None:
-            DeviceEvent._hip = C.CDLL('libamdhip64.so')
+            h = C.CDLL('libamdhip64.so')
+            vp = C.c_void_p                                   # declared signatures: no reliance on ctypes' default int / pointer marshalling
+            h.hipEventCreateWithFlags.argtypes = [C.POINTER(vp), C.c_uint]; h.hipEventCreateWithFlags.restype = C.c_int
+            h.hipEventRecord.argtypes = [vp, vp]; h.hipEventRecord.restype = C.c_int
+            h.hipEventSynchronize.argtypes = [vp]; h.hipEventSynchronize.restype = C.c_int
+            h.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), vp, vp]; h.hipEventElapsedTime.restype = C.c_int
+            h.hipEventDestroy.argtypes = [vp]; h.hipEventDestroy.restype = C.c_int
+            DeviceEvent._hip = h
         self._C = C
         self._h = C.c_void_p()
         rc = DeviceEvent._hip.hipEventCreateWithFlags(C.byref(self._h), C.c_uint(DeviceEvent.RELEASE_TO_DEVICE))

@@ -99,6 +99,44 @@ dist.barrier()
     assert 'TIMED-OUT' in res.stdout and 'did not arrive' in res.stdout, res.stdout[-2000:]
 
 
+def test_update_works_after_a_timed_out_exchange_and_detach(tmp_path):
+    """What Comm.attach_engine('auto') relies on when its test exchange times out: after metrpo_comm_ipc_detach the context must be usable again --
+    the sticky time-out cell of the one-shot exchange may not make every later metrpo_trpo_update fail (round-3 advisor finding)."""
+    script = tmp_path / 'recover.py'
+    script.write_text('''
+import os, sys
+import torch, torch.distributed as dist
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import metrpo_amd
+from test_gpu_engine import _update_problem
+dist.init_process_group("gloo"); rank = dist.get_rank(); torch.cuda.set_device(0)
+eng, th, pdims, obs, act, adv, om, ols = _update_problem(N=500, seed=3)
+comm = metrpo_amd.Comm()
+assert comm.attach_engine(eng, transport="one-shot") == "one-shot"
+eng.comm_set_timeout_ms(300)
+dist.barrier()
+if rank == 0:
+    eng.allreduce_sum_(torch.ones(4, dtype=torch.float64, device="cuda"))          # rank 1 never joins: times out
+    try:
+        eng.comm_check(); print("NO-ERROR")
+    except metrpo_amd._lib.MetrpoError:
+        print("TIMED-OUT")
+dist.barrier()
+eng.comm_ipc_detach()
+if rank == 0:
+    batch = eng.make_batch(obs, act, adv, om, ols)
+    res = eng.trpo_update(batch)                                                    # single rank now: must not report the old time-out
+    eng.comm_check()
+    print("UPDATE-OK", res["accepted"])
+dist.barrier()
+''' % (ROOT, ROOT))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29549', str(script)]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, MASTER_ADDR='127.0.0.1'), cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    assert 'TIMED-OUT' in res.stdout and 'UPDATE-OK' in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+
+
 def test_bench_self_launches_for_n_gpus():
     """`python bench.py --gpus 4` the way the driver invokes `--gpus 1` (plain python, no launcher, no WORLD_SIZE): bench.py re-executes
     itself under torch.distributed.run; on this 1-GPU box the 4 ranks share cuda:0 (gloo for the bookkeeping, the one-shot transport

@@ -150,3 +150,15 @@ def test_ring_replay_buffer_reproduces_reference_index_stream():
     xs = np.arange(14.0).reshape(7, 2)
     big.add_data(xs[:2], xs[:2]); big.add_data(xs, xs)
     np.testing.assert_array_equal(to_np(big.x), xs[3:]); assert big.n_data == 4 and big.cur_idx == 2 - 5
+
+
+def test_engine_names_the_dynamics_variants_it_does_not_implement():
+    """training.py:234-242 (use_logit_weights) and :259-268 (second_derivative, *_goal prediction types) exist in the reference but no six-env params
+    file selects them and no kernel here evaluates them: the host mirror refuses them BY NAME before touching the device."""
+    import metrpo_amd
+    with pytest.raises(ValueError, match='second_derivative'):
+        metrpo_amd.Engine('swimmer', 5, (64, 64), (32, 32), prediction_type='second_derivative')
+    with pytest.raises(ValueError, match='state_change_goal'):
+        metrpo_amd.Engine('swimmer', 5, (64, 64), (32, 32), prediction_type='state_change_goal')
+    with pytest.raises(ValueError, match='use_logit_weights'):
+        metrpo_amd.Engine('swimmer', 5, (64, 64), (32, 32), use_logit_weights=True)
