@@ -119,8 +119,6 @@ def main():
     n_dev = torch.cuda.device_count()
     oversub = args.gpus > n_dev                               # fewer devices than ranks: share them (RCCL refuses that; gloo + IPC works)
     backend = os.environ.get('METRPO_BENCH_BACKEND', 'gloo' if oversub else 'nccl')
-    if oversub:
-        os.environ['METRPO_NO_RESIDENT'] = '1'                # the resident rollout kernel needs its whole grid on the chip at once: not with several ranks per device
     dev = int(os.environ.get('METRPO_BENCH_DEVICE', int(os.environ.get('LOCAL_RANK', '0')) % max(n_dev, 1)))
     torch.cuda.set_device(dev)
     if backend == 'nccl':
@@ -143,6 +141,8 @@ def main():
     B = cfg['B'] // cfg['gpus']                               # per-GPU share of the config's B (weak scaling keeps it fixed)
     ns, na, n_drop = synthetic.ENV_SPECS[env]
     eng = metrpo_amd.Engine(env, K, cfg['dyn_hidden'], cfg['pol_hidden'], device=dev)
+    if oversub:
+        eng.set_exclusive(False)                              # several ranks per device: no kernel whose workgroups wait on each other inside one launch
     Ws, bs, norm = synthetic.make_dynamics(env, K, cfg['dyn_hidden'], seed=0)
     eng.set_dynamics_layers(Ws, bs, norm['in_mean'], norm['in_std'], norm['diff_mean'], norm['diff_std'])
     policy = metrpo_amd.GaussianMLPPolicy(eng, init_std=1.0, seed=0)

@@ -87,6 +87,12 @@ const char* metrpo_status_string(int32_t status);
 /* ---- context ------------------------------------------------------------------------------ */
 int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_dims* dims);
 int32_t metrpo_destroy(metrpo_ctx* ctx);
+/* exclusive = 0: other compute processes share this GPU (several ranks per device).  Kernels that wait on other workgroups of their own launch
+ * (the resident rollout / validation kernels, the migrating-tile schedule) are then never selected; default 1 (0 when METRPO_NO_RESIDENT is set
+ * in the environment).  With exclusive use they are still only launched when the runtime's occupancy answer times the CUs that actually
+ * schedule this process's waves (a census: CU masks and partitions count) covers their grid.  No reference counterpart: the reference is
+ * single-process and single-session (utils.py:229-232). */
+int32_t metrpo_set_exclusive(metrpo_ctx* ctx, int32_t exclusive);
 const char* metrpo_last_error(const metrpo_ctx* ctx);
 /* floats per dynamics model: [W0 (n_in x h0, row-major), b0, W1, b1, ..., Wout, bout]          */
 int32_t metrpo_dyn_param_count(const metrpo_ctx* ctx);

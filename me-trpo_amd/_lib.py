@@ -104,6 +104,7 @@ SYMBOLS = {
     'metrpo_set_normalizers': (_I, [_P, _P, _P, _P, _P, _P]),
     'metrpo_rms_accumulate': (_I, [_P, _P, _L, _I, _P, _P, _P]),
     'metrpo_bptt_grad': (_I, [_P, _P, _I, _I, _D, _P, _P, _P]),
+    'metrpo_set_exclusive': (_I, [_P, _I]),
     'metrpo_policy_adam_reset': (_I, [_P, _P]),
     'metrpo_policy_adam_step': (_I, [_P, _P, _D, _D, _D, _D, _D, _P]),
 }
@@ -117,6 +118,7 @@ EXTRA_SYMBOLS = {
     'metrpo_set_det_path': (_I, [_P, _I]),
     'metrpo_last_rollout_kernel': (_I, [_P]),
     'metrpo_probe_peaks': (_I, [_P, _P, _P]),
+    'metrpo_schedulable_cus': (_I, [_P, _P]),
 }
 
 

@@ -100,7 +100,9 @@ struct metrpo_ctx {
     int upd_pending, upd_spec, upd_changed_in_end; metrpo_batch upd_batch; metrpo_trpo_params upd_params; metrpo_trpo_diag upd_diag;                              // which kernel family the last metrpo_rollout ran on: 0 generic, 1 head-per-wave MFMA, 2 cooperative MFMA, 3 step-wise GEMM, 4 resident
     hipStream_t side_stream[METRPO_MAX_PAR_ROUNDS - 1]; hipEvent_t ev_fork, ev_join[METRPO_MAX_PAR_ROUNDS - 1]; int side_ready;   // rollout_gemm.hip: independent rounds of a small-batch rollout run concurrently
     double* h_pinned;    // pinned host scratch for the per-trial read-back
-    int n_sm;            // CU count
+    int n_sm;            // CU count (device property)
+    int n_cu_sched;      // CUs that actually ran this process's waves (probe.hip: census; 0 = not measured yet)
+    int exclusive;       // 0: the GPU is shared with other compute processes (metrpo_set_exclusive; METRPO_NO_RESIDENT=1 in the environment means the same)
     std::string err;
 };
 
@@ -173,6 +175,8 @@ int launch_step(metrpo_ctx*, const float*, const float*, int, int, const int32_t
                 uint8_t*, float*, hipStream_t);
 int launch_rollout_generic(metrpo_ctx*, const metrpo_rollout_args*, hipStream_t);
 bool gemm_path_applicable(const metrpo_ctx*);
+int sched_cus(metrpo_ctx*, hipStream_t);
+bool grid_is_coresident(metrpo_ctx*, const void* kernel, int threads, size_t lds, long long grid, hipStream_t);
 int launch_rollout_gemm(metrpo_ctx*, const metrpo_rollout_args*, hipStream_t);
 int launch_rollout_resident(metrpo_ctx*, const metrpo_rollout_args*, hipStream_t);   // METRPO_EUNSUPPORTED: not a shape / call of the resident kernel
 int launch_bptt_grad(metrpo_ctx*, const float* init, int B, int T, double gamma, double* costs, double* grad, hipStream_t);

@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
     if (a.dbg != nullptr) { dbg_c0 = __builtin_readcyclecounter(); dbg_w0 = wall_clock64(); }
 #endif
 
-    bool export_issued = false, export_pending = false;
+    bool export_issued = false;
     auto body = [&](auto par_, const int q) {
         constexpr int PAR = decltype(par_)::value;
         f32x4 (&h)[2] = hs[PAR];
@@ -393,7 +393,7 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
                         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[u][v]), rs, ((u * 4 + v) * 64 + lane) * 16, 0, 16);   // sc1: write-through
                     }
-                export_issued = true;                                          // not waited for here: the flag follows behind the NEXT chunk's drain
+                export_issued = true;                                          // the flag follows behind this chunk's drain (below): no separate wait for the stores
             }
             if constexpr (!OUT) {
                 if (r0.fl & SKF_LAST) {
@@ -453,17 +453,13 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
             }
         }
         SK_STAMP(3);
-        if (export_issued) {                                                   // all but the 16 youngest memory operations = the accumulator stores just issued: they fly
-            if constexpr (!PROD) asm volatile("s_waitcnt vmcnt(16)" : "+v"(hn[0]), "+v"(hn[1]) :: "memory");   // under the next chunk, whose drain covers them
-            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            export_issued = false; export_pending = true;
-        } else {
-            if constexpr (!PROD) drain_a(hn);                                  // (nothing to wait for behind the line below; names the registers the asm loads wrote)
-            drain_vm();                                                        // this wave's copies of entry q + 3 (issued early in the chunk) and its rows: landed long ago
-            if (export_pending) {                                              // every storing wave has drained its stores before its flag
-                if (lane == 0) __hip_atomic_store(a.xflag + (size_t)blockIdx.x * 8 + wave, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                export_pending = false;
-            }
+        if constexpr (!PROD) drain_a(hn);                                      // (nothing to wait for behind the line below; names the registers the asm loads wrote)
+        drain_vm();                                                            // this wave's copies of entry q + 3 (issued early in the chunk) and its rows: landed long ago
+        if (export_issued) {                                                   // ... and its accumulator stores: every storing wave has drained before its flag.  (A counted
+            // wait that left the 16 stores in flight -- vmcnt(16) -- let the barrier pass with LDS-DMA copies still under way: stores and loads do not
+            // retire in one order; seen as a rollout that was not bitwise repeatable at the C4 share.)
+            if (lane == 0) __hip_atomic_store(a.xflag + (size_t)blockIdx.x * 8 + wave, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            export_issued = false;
         }
         SK_STAMP(4);
 #ifdef SK_DEBUG
@@ -478,10 +474,7 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
         body(std::integral_constant<int, 0>{}, q);
         if (q + 1 < nq) body(std::integral_constant<int, 1>{}, q + 1);
     }
-    if (export_pending) {                                                      // the range ended with the exporting piece
-        drain_vm();
-        if (lane == 0) __hip_atomic_store(a.xflag + (size_t)blockIdx.x * 8 + wave, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+
 #ifdef SK_DEBUG
     if (a.dbg != nullptr && lane == 0) {                                       // shader cycles and 100 MHz ticks of this workgroup's main loop, its chunk count
         if (tid == 0) { a.dbg[8 * blockIdx.x] = __builtin_readcyclecounter() - dbg_c0; a.dbg[8 * blockIdx.x + 1] = wall_clock64() - dbg_w0; a.dbg[8 * blockIdx.x + 2] = (unsigned long long)nq;

@@ -61,3 +61,58 @@ extern "C" int32_t metrpo_probe_peaks(metrpo_ctx* c, double* out, void* stream) 
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;
 }
+
+
+// ---- how many CUs actually run this process's waves (CU masks, partitioned devices, reserved CUs: multiProcessorCount does not say) ----
+// Census: 16 single-wave workgroups per nominal CU, each holding 64 KB of LDS (at most two per CU: they must spread) for ~3 us, marks the
+// (XCC, SE, SH, CU) it ran on.  The kernels that exchange data between the workgroups of ONE launch (rollout_resident.hip) need their whole
+// grid on the chip at once; they size their grids by this count instead of trusting the property.
+__global__ void __launch_bounds__(64) k_cu_census(unsigned* __restrict__ seen) {
+    extern __shared__ char census_pad[];
+    if (threadIdx.x == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID: [11:8] CU, [12] SH, [15:13] SE
+        const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID: [3:0]
+        const unsigned key = ((xcc & 0xFu) << 8) | ((hw >> 8) & 0xFFu);
+        atomicOr(&seen[key >> 5], 1u << (key & 31));
+        census_pad[0] = (char)key;                                             // keeps the allocation
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < 300ull) __builtin_amdgcn_s_sleep(16);      // 3 us at 100 MHz
+    }
+}
+// schedulable CUs for launches on `st` (measured once per context; one stream synchronisation)
+int sched_cus(metrpo_ctx* c, hipStream_t st) {
+    if (c->n_cu_sched > 0) return c->n_cu_sched;
+    unsigned* d = nullptr;
+    const int words = 128;                                                      // 12-bit keys
+    if (hipMalloc(&d, words * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return c->n_sm; }
+    unsigned h[words];
+    bool ok = hipMemsetAsync(d, 0, words * sizeof(unsigned), st) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_cu_census, dim3(16 * c->n_sm), dim3(64), 65536, st, d);
+        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    }
+    (void)hipFree(d);
+    if (!ok) { (void)hipGetLastError(); return c->n_sm; }
+    int n = 0;
+    for (int i = 0; i < words; ++i) n += __builtin_popcount(h[i]);
+    c->n_cu_sched = (n > 0 && n <= c->n_sm) ? n : c->n_sm;
+    return c->n_cu_sched;
+}
+// grid <= (workgroups of this kernel the runtime says fit a CU) x (CUs that really schedule our waves); exclusive use of the device as told by the host
+bool grid_is_coresident(metrpo_ctx* c, const void* kernel, int threads, size_t lds, long long grid, hipStream_t st) {
+    if (!c->exclusive) return false;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (per_cu > 1) per_cu -= 1;                                                // the API answers one too many at some SGPR counts (MI355X_MICROARCH.md, residency)
+    return per_cu >= 1 && grid <= (long long)per_cu * sched_cus(c, st);
+}
+extern "C" int32_t metrpo_schedulable_cus(metrpo_ctx* c, void* stream) {
+    if (!c) return METRPO_ENULL;
+    return sched_cus(c, (hipStream_t)stream);
+}
+// exclusive = 0: other compute processes share this GPU -- no kernel that waits on other workgroups of its own launch is selected
+extern "C" int32_t metrpo_set_exclusive(metrpo_ctx* c, int32_t exclusive) {
+    if (!c) return METRPO_ENULL;
+    c->exclusive = exclusive ? 1 : 0;
+    return METRPO_OK;
+}

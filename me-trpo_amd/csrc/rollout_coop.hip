@@ -672,19 +672,22 @@ int launch_rollout_coop(metrpo_ctx* c, int idx, const RolloutK& r_in, hipStream_
     const size_t sh = sizeof(float) * (size_t)en.lds_floats;
     const int tiles = (r_in.B + 15) / 16;
     RolloutK r = r_in;
-    bool one = tiles <= c->n_sm || en.always_one;
+    // CUs that really schedule this process's waves (census, probe.hip): under a CU mask the even tile-step deal is made over THOSE.  The migrating
+    // schedule does not need its grid co-resident to be correct (a tile's producer is a lower-numbered workgroup that waits for nobody), only to be fast.
+    const int n_cu = (tiles > c->n_sm / 2) ? sched_cus(c, st) : c->n_sm;
+    bool one = tiles <= n_cu || en.always_one;
     if (!one) {
-        const long long slots = 2LL * c->n_sm, rounds = tiles / slots, rest = tiles % slots;
-        const double t_one = (double)tiles / c->n_sm;
-        const double t_two = en.pair * rounds + (rest == 0 ? 0.0 : rest <= c->n_sm ? 1.0 + en.rem_slope * (en.pair - 1.0) * rest / c->n_sm : en.pair);
+        const long long slots = 2LL * n_cu, rounds = tiles / slots, rest = tiles % slots;
+        const double t_one = (double)tiles / n_cu;
+        const double t_two = en.pair * rounds + (rest == 0 ? 0.0 : rest <= n_cu ? 1.0 + en.rem_slope * (en.pair - 1.0) * rest / n_cu : en.pair);
         one = t_one < t_two;
     }
     if (const char* ex = getenv("METRPO_COOP_MODE")) one = (ex[0] == '1') || (one && ex[0] != '2');     // launch-rule experiments only: 1 / 2 workgroups per CU
     if (c->rollout_variant == 2) one = false;
     // a GPU shared with other compute processes (METRPO_NO_RESIDENT=1, the switch that also keeps rollout_resident.hip out): the migrating schedule's
     // consumers wait for producer workgroups of their own grid, which other processes' workgroups can keep off the chip until the bounded wait gives up
-    if (one && tiles > c->n_sm && getenv("METRPO_NO_RESIDENT") != nullptr) one = false;
-    const int grid = one ? (tiles < c->n_sm ? tiles : c->n_sm) : tiles;
+    if (one && tiles > n_cu && (!c->exclusive || getenv("METRPO_NO_RESIDENT") != nullptr)) one = false;
+    const int grid = one ? (tiles < n_cu ? tiles : n_cu) : tiles;
     if (one && tiles > grid) {                                           // hand-over slots: flag[tiles] | ts[16 tiles] | model[16 tiles] | obs[16 tiles][ns]
         const int ns = c->pd.ns;
         if (c->mig_cap < tiles) {

@@ -964,13 +964,18 @@ static const ResidentEntry* resident_table(int* n) {
 // METRPO_EUNSUPPORTED: this shape / call stays on the step-wise path (rollout_gemm.hip)
 int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t st) {
     const ProblemDesc& pd = c->pd;
-    if (c->rollout_variant == 1 || c->res_failed || getenv("METRPO_NO_RESIDENT") != nullptr) return METRPO_EUNSUPPORTED;
+    if (c->rollout_variant == 1 || c->res_failed || !c->exclusive || getenv("METRPO_NO_RESIDENT") != nullptr) return METRPO_EUNSUPPORTED;
     if (pd.dyn.n_layers != 3 || pd.dyn.dims[1] != pd.dyn.dims[2] || pd.dyn.act[0] != METRPO_ACT_RELU || pd.dyn.act[1] != METRPO_ACT_RELU ||
         pd.dyn.act[2] != METRPO_ACT_IDENTITY) return METRPO_EUNSUPPORTED;
     if (pd.pol.n_layers != 3 || pd.pol.dims[1] != 32 || pd.pol.dims[2] != 32 || pd.pol.act[0] != METRPO_ACT_TANH || pd.pol.act[1] != METRPO_ACT_TANH)
         return METRPO_EUNSUPPORTED;
     if (!(a->sam_mode == METRPO_SAM_STEP_RAND || a->sam_mode == METRPO_SAM_EPS_RAND || a->sam_mode == METRPO_SAM_ONE_MODEL)) return METRPO_EUNSUPPORTED;
     if (a->B > 128) return METRPO_EUNSUPPORTED;
+    // The compute and post workgroups of a launch wait for each other's packets: the WHOLE grid has to be on the chip at once.  The grid is sized by
+    // the CUs that really schedule this process's waves (a census, not the device property: CU masks, partitions, reserved CUs) and checked
+    // against the runtime's occupancy answer for the kernel picked below -- a launch that would not be co-resident is never issued (it used to burn
+    // its 2 s hand-over bound first and report invalid trajectories); the bounded wait stays as the backstop against another tenant.
+    const int n_cu = sched_cus(c, st);
     const int B = a->B, K = pd.K, H = a->H, DH = pd.dyn.dims[1], NT = (B + 15) / 16;
     // rounds of a horizon-terminated rollout are independent given the counter-based draws (see launch_rollout_gemm): they run side by side
     int R = 1;
@@ -985,10 +990,10 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
     auto fits = [&](const ResidentEntry* e, int rg, int* pw_out) {
         if (e->threads == 256) {                                        // 4-wave form: the tiles of the rg rounds are dealt to as many workgroup columns as fit -- one is enough
             *pw_out = 4;
-            return K * (DH / e->ws) + (rg * NT + 3) / 4 <= c->n_sm;
+            return K * (DH / e->ws) + (rg * NT + 3) / 4 <= n_cu;
         }
         for (int pw = 1; pw <= e->threads / 64; pw *= 2)
-            if (rg * K * (DH / e->ws) + (rg * NT + pw - 1) / pw <= c->n_sm) { *pw_out = pw; return true; }
+            if (rg * K * (DH / e->ws) + (rg * NT + pw - 1) / pw <= n_cu) { *pw_out = pw; return true; }
         return false;
     };
     // (the post wave adds the slices in batches of 16: DH / ws must be a multiple of 16)
@@ -1003,6 +1008,8 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
     for (int rg = R - 1; widest && rg >= 1 && !pick; --rg)
         if (fits(widest, rg, &PW)) { pick = widest; Rg = rg; }
     if (!pick) return METRPO_EUNSUPPORTED;
+    if (pick->lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)pick->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pick->lds));
+    if (!grid_is_coresident(c, (const void*)pick->fn, pick->threads, pick->lds, 1, st)) return METRPO_EUNSUPPORTED;      // >= one workgroup per CU, exclusive device
     const int NSL = DH / pick->ws, OUT_CB = (pd.ns + 15) / 16, NIN_KS = (pd.nin + 1 + 3) / 4;
     const size_t nX = (size_t)Rg * NT * 4 * NIN_KS * 16, nP = (size_t)Rg * NT * K * NSL * 16 * OUT_CB * 16;
     const size_t need = (nX + nP + 32) * sizeof(unsigned long long);
@@ -1033,7 +1040,7 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
         z.det = 0; z.NTM = 0; z.gamma = 1.0f; z.s0 = nullptr; z.det_part = nullptr; z.part_stride = 0; z.part_off = 0; z.Btot = 0;
         if (pick->threads == 256) {
             const int G = rg * NT, post_blocks = (G + PW - 1) / PW;
-            const int ncol = std::max(1, std::min(G, (c->n_sm - post_blocks) / (K * NSL)));
+            const int ncol = std::max(1, std::min(G, (n_cu - post_blocks) / (K * NSL)));
             z.NTC = (G + ncol - 1) / ncol;
             z.U = ((G + z.NTC - 1) / z.NTC) * K * NSL;
         }
@@ -1044,6 +1051,7 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
         z.X = (unsigned long long*)c->d_res + 32; z.P = z.X + nX;
         z.err = comm_err_cell(c) + 1;                               // scal[S_ROLLERR]
         const int grid = z.U + (rg * NT + PW - 1) / PW;
+        if (grid > n_cu) return set_err(c, METRPO_EHIP, "resident rollout: grid larger than the schedulable CUs (launch rule out of step with the census)");
         hipLaunchKernelGGL(pick->fn, dim3(grid), dim3(pick->threads), pick->lds, st, pd, rk, z, c->d_dyn, c->d_theta, c->d_norm);
     }
     HIP_TRY(c, hipGetLastError());
@@ -1068,7 +1076,7 @@ int launch_validation_resident(metrpo_ctx* c, const float* s0, int Bv, int T, do
         RES_VAL_ENTRY(METRPO_ENV_ANT, 1024, 64),
     };
     const ProblemDesc& pd = c->pd;
-    if (c->res_failed || getenv("METRPO_NO_RESIDENT") != nullptr || T <= 0) return METRPO_EUNSUPPORTED;
+    if (c->res_failed || !c->exclusive || getenv("METRPO_NO_RESIDENT") != nullptr || T <= 0) return METRPO_EUNSUPPORTED;
     if (pd.dyn.n_layers != 3 || pd.dyn.dims[1] != pd.dyn.dims[2] || pd.dyn.act[0] != METRPO_ACT_RELU || pd.dyn.act[1] != METRPO_ACT_RELU ||
         pd.dyn.act[2] != METRPO_ACT_IDENTITY) return METRPO_EUNSUPPORTED;
     if (pd.pol.n_layers != 3 || pd.pol.dims[1] != 32 || pd.pol.dims[2] != 32 || pd.pol.act[0] != METRPO_ACT_TANH || pd.pol.act[1] != METRPO_ACT_TANH)
@@ -1082,6 +1090,7 @@ int launch_validation_resident(metrpo_ctx* c, const float* s0, int Bv, int T, do
     // per (model, tile), four per workgroup).  The batch goes in nb chunks, one launch each: fewer tiles per launch need fewer post workgroups and
     // leave room for a third column -- 500 envs: one launch = 2 columns of 16 tiles per step, three launches = 3 x (3 columns of 4).
     const int NSL = DH / e->ws, PW = 4;
+    const int n_cu = sched_cus(c, st);                                      // as in launch_rollout_resident: the grid must be co-resident
     // Cost of a step (us): a column's tiles at the measured tile time (2.0 at 2 x 512 / 32-unit slices, 6.1 at 2 x 1024 / 64), but never less than a
     // tile's round trip through its post wave (8, plus 3 for every further tile the wave serves first), per chunk; plus the launch's prologue
     // (~60 us: weight fragments, LDS images) spread over the T steps.  A post wave serving several tiles frees CUs for another column.
@@ -1096,7 +1105,7 @@ int launch_validation_resident(metrpo_ctx* c, const float* s0, int Bv, int T, do
         for (int n = 1; n <= 8; ++n) {
             if (chunks_env != nullptr && atoi(chunks_env) != n) continue;
             const int bc = (Bv + n - 1) / n, ntm = (bc + 15) / 16, post = ((K * ntm + ntw - 1) / ntw + PW - 1) / PW;
-            const int ncol = std::min(ntm, (c->n_sm - post) / (K * NSL));
+            const int ncol = std::min(ntm, (n_cu - post) / (K * NSL));
             if (ncol < 1) continue;
             const int ntc = (ntm + ncol - 1) / ncol;
             const double cost = n * (std::max(std::max(ntc * t_tile, t_trip + (ntw - 1) * t_post), ntw * t_post * 1.5) + t_launch / T);
@@ -1122,6 +1131,7 @@ int launch_validation_resident(metrpo_ctx* c, const float* s0, int Bv, int T, do
     }
     { const int rc = ensure_detpart_n(c, (size_t)K * nb * NTM); if (rc) return rc; }
     if (e->lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)e->fn[ntw_i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds));
+    if (!grid_is_coresident(c, (const void*)e->fn[ntw_i], 256, e->lds, (long long)cols * K * NSL + post_blocks, st)) return METRPO_EUNSUPPORTED;
     for (int ch = 0; ch < nb; ++ch) {
         const int b_lo = ch * Bc, bn = std::min(Bc, Bv - b_lo);
         ResidentK z;

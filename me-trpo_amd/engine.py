@@ -161,6 +161,15 @@ class Engine(object):
         self._chk(lib.metrpo_allreduce_sum_f64(self._ctx, _ptr(t), t.numel(), self._stream()))
         return t
 
+    def set_exclusive(self, exclusive):
+        """False: other compute processes share this GPU (several ranks per device) -- the kernels whose workgroups wait on each other inside one
+        launch (resident rollout / validation, migrating tiles) are never selected.  Default True."""
+        self._chk(lib.metrpo_set_exclusive(self._ctx, int(bool(exclusive))))
+
+    def schedulable_cus(self):
+        """CUs that actually run this process's waves (a census kernel; CU masks and partitions count), measured once per engine."""
+        return int(lib.metrpo_schedulable_cus(self._ctx, self._stream()))
+
     def probe_peaks(self):
         """Measured (f32 MFMA TFLOP/s, HBM copy GB/s) of this device: register-resident MFMA issue loop, 1 GiB streaming copy."""
         out = (C.c_double * 2)()

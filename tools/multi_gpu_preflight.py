@@ -46,6 +46,8 @@ def preflight(world, rank, device_index, latency_table=True, out=print):
     # 2. transport
     eng = metrpo_amd.Engine('swimmer', 5, (64, 64), (32, 32))
     eng.set_policy(metrpo_amd.xavier_policy_theta(10, (32, 32), 2))
+    if world > n_dev:
+        eng.set_exclusive(False)                             # ranks share devices: no kernel whose workgroups wait on each other inside one launch
     comm = metrpo_amd.Comm()
     if comm.world != world:
         return _fail(rank, 'torch.distributed world size %d != %d' % (comm.world, world)), rep
@@ -128,8 +130,6 @@ if __name__ == '__main__':
         print('[preflight] FAIL: no GPU visible'); sys.exit(2)
     torch.cuda.set_device(local % n_dev)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    if world > n_dev:
-        os.environ.setdefault('METRPO_NO_RESIDENT', '1')
     torch.distributed.init_process_group('nccl' if world <= n_dev else 'gloo')      # RCCL refuses two ranks on one device
     ok, rep = preflight(world, rank, local % n_dev)
     flag = torch.tensor([1 if ok else 0])
