@@ -70,6 +70,12 @@ __device__ __forceinline__ float xsum_c(float v) {
 }
 
 enum { MODE_GRAD = 0, MODE_FVP = 1, MODE_LOSSKL = 2, MODE_FVPC = 3 };
+// POL_H0R = 1 (experiment, round 4): MODE_FVPC reads only h1 from the cache and recomputes h0 (one layer: NS_KS x HB MFMAs + 4 HB tanh per lane): -128 of
+// 302 B per sample from HBM, +8 % MFMAs.  Measured SLOWER at C1 (tools/variant_update.py h0r, twice: update 0.846 vs 0.798 ms = +4.8 us per
+// product): the product is bound by its dependent issue chain, not by HBM; the extra layer + tanh at the head of every tile's chain costs more than the bytes.
+#ifndef POL_H0R
+#define POL_H0R 0
+#endif
 // MODE_FVPC: Fisher-vector product with the hidden activations h0, h1 = tanh(.) read from the cache the gradient kernel of the
 // same (theta, batch) wrote (PolK::hcache) instead of being recomputed: all 10 products of a CG solve share theta and the
 // observations, so the forward pass (22 of the 100 MFMAs of a tile and all 16 tanh per lane) is done once per update, not 11 times.
@@ -159,7 +165,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
         if (CACHED) {
             const f32x4* __restrict__ hb_ = hc + tile * (2 * HB) * 64;
 #pragma unroll
-            for (int j = 0; j < 2 * HB; ++j) in.h[j] = hb_[j * 64 + lane];
+            for (int j = (POL_H0R ? HB : 0); j < 2 * HB; ++j) in.h[j] = hb_[j * 64 + lane];
         }
     };
     auto mask_tile = [&](TileIn& in) {
@@ -267,7 +273,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
                 bool use = m[u] >= 0;
                 if (MODE != MODE_FVP && (m[u] & 0x40000000)) use = false;                       // tangent tables: FVP only
                 if (MODE == MODE_LOSSKL && i >= I::O_W2B && i < I::O_W2F) use = false;          // back-prop tables unused
-                if (CACHED && i < I::O_W1F) use = false;                                        // W0 forward table unused
+                if (CACHED && !POL_H0R && i < I::O_W1F) use = false;                            // W0 forward table unused
                 w[u] = 0.f;
                 if (use) w[u] = (m[u] & 0x40000000) ? v[m[u] & 0x3FFFFFFF] : theta[m[u]];
             }
@@ -324,24 +330,25 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
         float* T_H0 = TL, *T_H1 = TL + HB * TILE, *T_D1 = TL + 2 * HB * TILE, *T_UM = TL + 3 * HB * TILE;
         // ---- S1: layer 0, forward and (FVP) tangent  ------------------------------------------------------
         f32x4 h0[HB], h1[HB], t0[HB], t1[HB];
+        constexpr bool H0C = CACHED && !POL_H0R;            // h0 comes from the cache
         if (CACHED) {
 #pragma unroll
-            for (int cb = 0; cb < HB; ++cb) { h0[cb] = in.h[cb]; h1[cb] = in.h[HB + cb]; }
+            for (int cb = 0; cb < HB; ++cb) { if (H0C) h0[cb] = in.h[cb]; h1[cb] = in.h[HB + cb]; }
         }
 #pragma unroll
-        for (int cb = 0; cb < HB; ++cb) { if (!CACHED) h0[cb] = b0f[cb]; if (MODE == MODE_FVP) t0[cb] = vb0f[cb]; }
+        for (int cb = 0; cb < HB; ++cb) { if (!H0C) h0[cb] = b0f[cb]; if (MODE == MODE_FVP) t0[cb] = vb0f[cb]; }
 #pragma unroll
         for (int s = 0; s < NS_KS; ++s)
 #pragma unroll
             for (int cb = 0; cb < HB; ++cb) {
-                if (!CACHED) h0[cb] = MFMA16(FRAG2(I::O_W0F, s, cb), xB[s], h0[cb]);
+                if (!H0C) h0[cb] = MFMA16(FRAG2(I::O_W0F, s, cb), xB[s], h0[cb]);
                 if (MODE == MODE_FVP) t0[cb] = MFMA16(FRAG2(I::O_V0F, s, cb), xB[s], t0[cb]);
             }
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb) {
             if (!CACHED) h1[cb] = b1f[cb];
             if (MODE == MODE_FVP) t1[cb] = vb1f[cb];
-            if (!CACHED) {
+            if (!H0C) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) h0[cb][r] = tanh_fast(h0[cb][r]);
             }

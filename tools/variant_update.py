@@ -7,7 +7,7 @@ shutil.copy(lib, lib + '.orig')
 try:
     for name in ['shipped'] + sys.argv[1:]:
         shutil.copy(lib + '.orig' if name == 'shipped' else os.path.join(root, 'tools', '_variants', name + '.so'), lib)
-        out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--no-cpu-baseline', '--steps', '10', '--warmup', '2'], capture_output=True, text=True)
+        out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--no-cpu-baseline', '--steps', '60', '--warmup', '15'], capture_output=True, text=True)
         try:
             d = json.loads(out.stdout.strip().splitlines()[-1])
             print('%-10s iteration %.3f ms  rollout %.3f ms  update %.3f ms' % (name, d['ms_per_step'], d['rollout']['ms'], d['roofline']['update']['ms']), flush=True)
