@@ -84,7 +84,13 @@ __global__ void k_big_pre(ProblemDesc pd, RolloutK r, int t, const float* __rest
 // MFMA variant of k_big_pre for the 2x32 tanh policies (every shipped params file except Humanoid): a wave evaluates the policy of a 16-env
 // tile as the transposed MFMA chain of the fused rollout kernels (30 MFMAs) instead of 64 threads walking three dense layers each;
 // identical draws (same Philox blocks) and identical outputs layout.  grid = ceil(B/64) blocks of 4 waves.
-template <int ENV>
+// POST = true (t >= 1): the same launch first CLOSES step t - 1 for its 16 envs -- k_big_post's work (de-normalise + residual, selection over the
+// heads, reward, done, reset; env_helpers.py:597-635) in this kernel's layout: lane (env c, quarter q) owns the state dims 4 q + r and
+// 16 + 4 q + r (one 16-byte read per partial and head), the new state goes straight into the wave's LDS state tile, which is what the policy
+// chain below reads.  One launch per step instead of two between the ensemble kernels: k_big_post(t - 1) + this kernel's own launch and
+// its reload of the state cost ~17 us of a 150 us step at the C3 share.  Same arithmetic in the same order as k_big_post: trajectories are
+// bit for bit those of the two-launch sequence (tests/test_gpu_streamk.py).
+template <int ENV, bool POST>
 __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r, int t, const float* __restrict__ theta,
                                                       const float* __restrict__ norm, BigState st) {
     using C = Cfg<ENV, 64, 32>;
@@ -130,7 +136,140 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
     }
     __syncthreads();                                             // image complete; the reset rows of this tile are written by its own wave
     const int lim = min(16, max(0, r.B - b0)) * NS;
-    for (int i = lane; i < 16 * NS; i += 64) ST[i] = (i < lim) ? st.S[(size_t)b0 * NS + i] : 0.0f;
+    if constexpr (POST) {
+        // ---- close step t - 1 (k_big_post) for this wave's 16 envs ----
+        const int bc = active ? b : max(r.B - 1, 0);
+        const int K = pd.K, tp = t - 1;
+        const int ttp = tp + RK_TOFF(r, bc);
+        const size_t tbp = (size_t)ttp * RK_STRIDE(r) + RK_ENV(r, bc);
+        const float* diff_mean = norm + 2 * (NS + NA); const float* diff_std = diff_mean + NS;
+        const uint4 dstep = rng_draw(r.seed, genv, r.t0 + ttp, RNG_STEP, 0);
+        int sel = st.cur_model[bc];
+        if (r.sam_mode == METRPO_SAM_STEP_RAND) sel = (r.model_idx != nullptr) ? r.model_idx[tbp] : rng_index(dstep.z, K);
+        if (r.sam_mode == METRPO_SAM_ONE_MODEL) sel = 0;
+        const bool simple = (r.sam_mode == METRPO_SAM_STEP_RAND || r.sam_mode == METRPO_SAM_EPS_RAND || r.sam_mode == METRPO_SAM_ONE_MODEL);
+        float su2 = 0.0f;                                        // sum of squared clipped actions in action order (every lane of the env, redundantly)
+        for (int d = 0; d < NA; ++d) { const float a_ = st.U[(size_t)bc * NA + d]; su2 = fmaf(a_, a_, su2); }
+        float vnew[2][4];
+        bool finl = true;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int i0 = 16 * hh + 4 * q;                      // dims i0 .. i0 + 3 (the partial rows are 16 OT floats wide, zero beyond ns)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) vnew[hh][rr] = 0.0f;
+            if (i0 >= NS) continue;
+            auto outv4 = [&](int k, float (&o)[4]) {             // output layer of head k, dims i0 .. i0 + 3: bias, then the partials in split order (k_big_post: outv)
+                if (st.out_splits == 0) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) o[rr] = (i0 + rr < NS) ? st.OUT[((size_t)k * r.B + bc) * NS + i0 + rr] : 0.0f;
+                    return;
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) o[rr] = (i0 + rr < NS) ? st.out_bias[(size_t)k * st.out_bias_stride + i0 + rr] : 0.0f;
+                for (int sp = 0; sp < st.out_splits; ++sp) {
+                    const float* pr_ = st.PART + ((size_t)sp * K + k) * st.out_stride + (size_t)bc * st.out_ld + i0;
+                    if ((st.out_ld & 3) == 0) { const f32x4 p4 = *(const f32x4*)pr_;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) o[rr] += p4[rr]; }
+                    else {
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) if (i0 + rr < NS) o[rr] += pr_[rr];
+                    }
+                }
+            };
+            float so[4], dm_[4], ds_[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) { const int i = min(i0 + rr, NS - 1); so[rr] = st.S[(size_t)bc * NS + i]; dm_[rr] = diff_mean[i]; ds_[rr] = diff_std[i]; }
+            auto head4 = [&](int k, float (&hv)[4]) { float o[4]; outv4(k, o);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) hv[rr] = fmaf(ds_[rr], o[rr], dm_[rr]) + so[rr]; };
+            float v4[4];
+            if (simple) head4(sel, v4);
+            else {
+                float m4[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int k = 0; k < K; ++k) { float h4[4]; head4(k, h4);
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) m4[rr] += h4[rr]; }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) { m4[rr] /= (float)K; v4[rr] = m4[rr]; }
+                if (r.sam_mode == METRPO_SAM_MODEL_MEAN_STD) {
+                    float var4[4] = {0.f, 0.f, 0.f, 0.f};
+                    for (int k = 0; k < K; ++k) { float h4[4]; head4(k, h4);
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) { const float d_ = h4[rr] - m4[rr]; var4[rr] = fmaf(d_, d_, var4[rr]); } }
+                    float z4[4];
+                    if (r.sel_noise == nullptr) normal4(rng_draw(r.seed, genv, r.t0 + ttp, RNG_SELNOISE, i0 >> 2), z4);     // dims i0 .. i0 + 3 = chunk i0 / 4
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const float nz = (r.sel_noise != nullptr) ? r.sel_noise[tbp * NS + min(i0 + rr, NS - 1)] : z4[rr];
+                        v4[rr] = fmaf(nz, sqrtf(var4[rr] / (float)K), m4[rr]);
+                    }
+                } else if (r.sam_mode == METRPO_SAM_MODEL_MED) {
+                    const int r_lo = (K - 1) / 2, r_hi = K / 2;
+                    float lo4[4] = {0.f, 0.f, 0.f, 0.f}, hi4[4] = {0.f, 0.f, 0.f, 0.f};
+                    for (int k = 0; k < K; ++k) {
+                        float xk[4]; head4(k, xk);
+                        int rank[4] = {0, 0, 0, 0};
+                        for (int j = 0; j < K; ++j) { float xj[4]; head4(j, xj);
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) rank[rr] += (xj[rr] < xk[rr]) || (xj[rr] == xk[rr] && j < k); }
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) { if (rank[rr] == r_lo) lo4[rr] = xk[rr]; if (rank[rr] == r_hi) hi4[rr] = xk[rr]; }
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) v4[rr] = 0.5f * (lo4[rr] + hi4[rr]);
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) if (i0 + rr < NS) { vnew[hh][rr] = v4[rr]; finl = finl && isfinite(v4[rr]); ST[c * NS + i0 + rr] = v4[rr]; }
+        }
+        int fin = finl ? 1 : 0;                                  // all-finite over the env's dims: the env's four lanes are c, c + 16, c + 32, c + 48
+        fin &= __shfl_xor(fin, 16, 64); fin &= __shfl_xor(fin, 32, 64);
+        wave_lds_sync();
+        const float* Sv = ST + c * NS;                           // the env's next state, every dim
+        constexpr int ki = (ENV == METRPO_ENV_SWIMMER || ENV == METRPO_ENV_HOPPER) ? 5 : (ENV == METRPO_ENV_HALF_CHEETAH) ? 9 : (ENV == METRPO_ENV_ANT) ? 15 : (ENV == METRPO_ENV_SNAKE) ? 7 : 0;
+        const float key = Sv[ki], h0v = Sv[0], h1v = Sv[1], zc = Sv[2];
+        float pen = 0.0f;
+        if (ENV == METRPO_ENV_HOPPER) for (int j = 2; j < NS; ++j) pen += fmaxf(fabsf(Sv[j]) - 100.0f, 0.0f);
+        float cost = 0.0f;
+        switch (ENV) {
+        case METRPO_ENV_SWIMMER: cost = -(key - 1e-2f * (su2 / (float)NA)); break;
+        case METRPO_ENV_HALF_CHEETAH: cost = -fminf(fmaxf(key - 1e-1f * 0.5f * su2, -10.0f), 10.0f); break;
+        case METRPO_ENV_ANT: cost = -(key - 1e-2f * 0.5f * su2 + 0.05f); break;
+        case METRPO_ENV_HOPPER: cost = -(key - 0.01f * 0.5f * su2 - 10.0f * fmaxf(0.45f - h0v, 0.0f) - 10.0f * fmaxf(fabsf(h1v) - 0.2f, 0.0f) - pen); break;
+        case METRPO_ENV_SNAKE: cost = -(key - 1e-2f * 0.5f * su2); break;
+        }
+        int ts = st.ts[bc] + 1;
+        bool dn = (ENV == METRPO_ENV_ANT) ? !((zc >= 0.2f) && (zc <= 1.0f) && (fin != 0)) : false;
+        dn = dn || (ts >= r.H);
+        int cur = st.cur_model[bc];
+        if (active && q == 0) { r.rew[tbp] = -cost; r.done[tbp] = dn ? 1 : 0; r.tpath[tbp] = ts - 1; }
+        wave_lds_sync();                                         // every lane has read its env's scalars: the reset rows may overwrite the tile
+        if (dn) {                                                // uniform over the env's four lanes
+            const size_t rb = (size_t)(tp + 1) * r.B + bc;
+            const int row = (r.reset_idx != nullptr) ? r.reset_idx[rb] : rng_index(dstep.w, r.n_pool);
+            cur = (r.reset_model != nullptr) ? r.reset_model[rb] : rng_index16(dstep.z, K);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) { const int i = 16 * hh + 4 * q + rr; if (i < NS) { vnew[hh][rr] = r.pool[(size_t)row * NS + i]; ST[c * NS + i] = vnew[hh][rr]; } }
+            ts = 0;
+        }
+        if (active) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) { const int i = 16 * hh + 4 * q + rr; if (i < NS) st.S[(size_t)b * NS + i] = vnew[hh][rr]; }
+            if (q == 0) { st.ts[b] = ts; if (dn) st.cur_model[b] = cur; }
+        } else {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) { const int i = 16 * hh + 4 * q + rr; if (i < NS) ST[c * NS + i] = 0.0f; }       // rows beyond the batch: zeros, as the reload below gives
+        }
+    } else {
+        for (int i = lane; i < 16 * NS; i += 64) ST[i] = (i < lim) ? st.S[(size_t)b0 * NS + i] : 0.0f;
+    }
     wave_lds_sync();
     if (lim > 0) {
         if (r.vB == 0) { const size_t base = ((size_t)t * r.B + b0) * NS; for (int i = lane; i < lim; i += 64) r.obs[base + i] = ST[i]; }
@@ -331,8 +470,9 @@ __global__ void __launch_bounds__(256) k_big_pre_action(ProblemDesc pd, RolloutK
 }
 
 typedef void (*big_pre_mfma_t)(ProblemDesc, RolloutK, int, const float*, const float*, BigState);
-static big_pre_mfma_t big_pre_mfma_select(const ProblemDesc& pd, size_t* dyn_lds) {
+static big_pre_mfma_t big_pre_mfma_select(const ProblemDesc& pd, size_t* dyn_lds, bool post = false) {
     *dyn_lds = 0;
+    if (post && (pd.pol.n_layers != 3 || pd.pol.dims[1] != 32 || pd.pol.dims[2] != 32)) return nullptr;     // the merged form exists for the 2 x 32 policies
     if (pd.env == METRPO_ENV_HUMANOID && pd.ns == 55 && pd.na == 21 && pd.n_drop == 0 && pd.pol.n_layers == 4 && pd.pol.dims[1] == 100 && pd.pol.dims[2] == 50 &&
         pd.pol.dims[3] == 25 && pd.pol.act[0] == METRPO_ACT_TANH && pd.pol.act[1] == METRPO_ACT_TANH && pd.pol.act[2] == METRPO_ACT_TANH && getenv("METRPO_NO_PRE_MFMA3") == nullptr) {
         *dyn_lds = big_pre_mfma3_lds<55, 21, 0, 100, 50, 25>();
@@ -340,11 +480,11 @@ static big_pre_mfma_t big_pre_mfma_select(const ProblemDesc& pd, size_t* dyn_lds
     }
     if (pd.pol.n_layers != 3 || pd.pol.dims[1] != 32 || pd.pol.dims[2] != 32 || pd.pol.act[0] != METRPO_ACT_TANH) return nullptr;
     switch (pd.env) {
-    case METRPO_ENV_SWIMMER: return (pd.ns == 10 && pd.na == 2 && pd.n_drop == 2) ? k_big_pre_mfma<METRPO_ENV_SWIMMER> : nullptr;
-    case METRPO_ENV_HALF_CHEETAH: return (pd.ns == 18 && pd.na == 6 && pd.n_drop == 1) ? k_big_pre_mfma<METRPO_ENV_HALF_CHEETAH> : nullptr;
-    case METRPO_ENV_ANT: return (pd.ns == 29 && pd.na == 8 && pd.n_drop == 2) ? k_big_pre_mfma<METRPO_ENV_ANT> : nullptr;
-    case METRPO_ENV_HOPPER: return (pd.ns == 11 && pd.na == 3 && pd.n_drop == 0) ? k_big_pre_mfma<METRPO_ENV_HOPPER> : nullptr;
-    case METRPO_ENV_SNAKE: return (pd.ns == 14 && pd.na == 4 && pd.n_drop == 2) ? k_big_pre_mfma<METRPO_ENV_SNAKE> : nullptr;
+    case METRPO_ENV_SWIMMER: return (pd.ns == 10 && pd.na == 2 && pd.n_drop == 2) ? (post ? k_big_pre_mfma<METRPO_ENV_SWIMMER, true> : k_big_pre_mfma<METRPO_ENV_SWIMMER, false>) : nullptr;
+    case METRPO_ENV_HALF_CHEETAH: return (pd.ns == 18 && pd.na == 6 && pd.n_drop == 1) ? (post ? k_big_pre_mfma<METRPO_ENV_HALF_CHEETAH, true> : k_big_pre_mfma<METRPO_ENV_HALF_CHEETAH, false>) : nullptr;
+    case METRPO_ENV_ANT: return (pd.ns == 29 && pd.na == 8 && pd.n_drop == 2) ? (post ? k_big_pre_mfma<METRPO_ENV_ANT, true> : k_big_pre_mfma<METRPO_ENV_ANT, false>) : nullptr;
+    case METRPO_ENV_HOPPER: return (pd.ns == 11 && pd.na == 3 && pd.n_drop == 0) ? (post ? k_big_pre_mfma<METRPO_ENV_HOPPER, true> : k_big_pre_mfma<METRPO_ENV_HOPPER, false>) : nullptr;
+    case METRPO_ENV_SNAKE: return (pd.ns == 14 && pd.na == 4 && pd.n_drop == 2) ? (post ? k_big_pre_mfma<METRPO_ENV_SNAKE, true> : k_big_pre_mfma<METRPO_ENV_SNAKE, false>) : nullptr;
     }
     return nullptr;
 }
@@ -586,6 +726,9 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
     if (fuse_out) nP = std::max(nP, up4(gemm_fused_out_part_floats(B, pd.dyn.dims[L - 1], K, pd.ns, fuse_tile)));
     size_t pre_lds = 0;
     const big_pre_mfma_t pre_mfma = big_pre_mfma_select(pd, &pre_lds);
+    // steps t >= 1: k_big_post(t - 1) rides in the pre-step's launch (2 x 32 policies; METRPO_NO_STEP_MERGE=1 keeps the two launches: A/B runs, tests)
+    size_t pre_lds_post = 0;
+    const big_pre_mfma_t pre_post = (pre_mfma && getenv("METRPO_NO_STEP_MERGE") == nullptr) ? big_pre_mfma_select(pd, &pre_lds_post, true) : nullptr;
     // policies without an MFMA pre-kernel: GEMM chain over the batch from B = 1024 up -- and at ANY batch when the policy is large
     // (k_big_pre walks the weights through scalar loads, one block's time whatever B: 302 us per step for Humanoid's 100-50-25 at B = 100,
     // the params-humanoid.json shape, against ~40 us for the six small launches of the chain: iteration 77 -> 28 ms)
@@ -644,7 +787,8 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
     if (psh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_big_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psh));
     if (pre_mfma && pre_lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)pre_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pre_lds));
     for (int t = 0; t < a->T; ++t) {
-        if (pre_mfma) hipLaunchKernelGGL(pre_mfma, dim3((B + 63) / 64), dim3(256), pre_lds, st, pd, r, t, c->d_theta, c->d_norm, bs);
+        if (pre_post && t > 0) hipLaunchKernelGGL(pre_post, dim3((B + 63) / 64), dim3(256), pre_lds_post, st, pd, r, t, c->d_theta, c->d_norm, bs);
+        else if (pre_mfma) hipLaunchKernelGGL(pre_mfma, dim3((B + 63) / 64), dim3(256), pre_lds, st, pd, r, t, c->d_theta, c->d_norm, bs);
         else if (pre_gemm) {
             hipLaunchKernelGGL(k_big_pre_gather, dim3((unsigned)(((long long)B * pd.ns + 255) / 256)), dim3(256), 0, st, pd, r, t, c->d_norm, bs);
             const float* pin = bs.S; int ldp = pd.ns;
@@ -693,6 +837,7 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
             if (lastl) { bs.out_splits = df.splits; bs.out_stride = df.stridePart; bs.out_bias = bl; bs.out_bias_stride = pd.dyn.n_params; }
             in = out; sIn = sOut; ldin = N;
         }
+        if (pre_post && t + 1 < a->T) continue;             // closed by the next step's launch
         if (pd.ns <= 32) hipLaunchKernelGGL(k_big_post<32>, dim3((B + 7) / 8), dim3(256), 0, st, pd, r, t, c->d_norm, bs);
         else hipLaunchKernelGGL(k_big_post<64>, dim3((B + 3) / 4), dim3(256), 0, st, pd, r, t, c->d_norm, bs);
     }
