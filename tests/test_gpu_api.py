@@ -5,6 +5,7 @@ import pytest
 import torch
 from oracle import metrpo_oracle as O
 import helpers as Hh
+import tolerances as TOL
 
 pytestmark = pytest.mark.gpu
 
@@ -50,8 +51,8 @@ def test_vec_env_step_api_matches_reference_restatement():
         np.testing.assert_allclose(first, ref_first, atol=1e-6)
         for t in range(T):
             s, r, d, _ = ref_env.step(actions[t])
-            np.testing.assert_allclose(got[t][0], s, rtol=2e-4, atol=5e-5)
-            np.testing.assert_allclose(got[t][1], r, rtol=2e-4, atol=5e-5)
+            np.testing.assert_allclose(got[t][0], s, **TOL.FREE_RUN)
+            np.testing.assert_allclose(got[t][1], r, **TOL.FREE_RUN)
             assert np.array_equal(got[t][2], d)
             assert np.array_equal(ve.ts, ref_env.ts) or t < T - 1
         assert ve.num_envs == B and got[0][3] == {}
@@ -71,8 +72,8 @@ def test_policy_get_actions_surface():
     np.random.seed(5)
     eps = np.random.normal(size=(7, dm.na))
     ra, rinfo = O.policy_get_actions(theta.astype(np.float32).astype(np.float64), pdims, obs.astype(np.float32).astype(np.float64), eps)
-    np.testing.assert_allclose(a, ra, rtol=1e-5, atol=5e-6)
-    np.testing.assert_allclose(info['mean'], rinfo['mean'], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(a, ra, **TOL.ACTION)
+    np.testing.assert_allclose(info['mean'], rinfo['mean'], **TOL.STEP)
     np.testing.assert_allclose(info['log_std'], rinfo['log_std'], atol=1e-6)
     assert algo.policy.vectorized and not algo.policy.recurrent
     th = algo.policy.get_param_values()
@@ -118,12 +119,12 @@ def test_sampler_process_samples_pipeline(env, batch):
         o = np.lexsort((adv, ret)); return ret[o], adv[o]
     gr, ga = srt(cpu(samples['returns'])[v], cpu(samples['advantages'])[v])
     rr, ra = srt(ref['returns'], ref['advantages'])
-    np.testing.assert_allclose(gr, rr, rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(ga, ra, rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(gr, rr, **TOL.RETURNS)
+    np.testing.assert_allclose(ga, ra, **TOL.ADVANTAGE_CENTRED)
     # baseline refit AFTER the advantages were computed (quirk 8)
     feat_pred = lambda c: np.concatenate([O.LinearFeatureBaselineOracle.features(p) for p in plist]) @ c
     np.testing.assert_allclose(feat_pred(algo.baseline.coeffs), feat_pred(base._coeffs), rtol=0,
-                               atol=2e-3 * max(1.0, np.abs(feat_pred(base._coeffs)).max()))
+                               atol=TOL.BASELINE_FIT * max(1.0, np.abs(feat_pred(base._coeffs)).max()))
     assert not np.allclose(algo.baseline.coeffs, prev)
 
 
@@ -149,8 +150,8 @@ def test_params_file_shape_iteration_on_the_resident_kernel():
     srt = lambda ret, adv: tuple(x[np.lexsort((adv, ret))] for x in (ret, adv))
     gr, ga = srt(cpu(samples['returns'])[v], cpu(samples['advantages'])[v])
     rr, ra = srt(ref['returns'], ref['advantages'])
-    np.testing.assert_allclose(gr, rr, rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(ga, ra, rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(gr, rr, **TOL.RETURNS)
+    np.testing.assert_allclose(ga, ra, **TOL.ADVANTAGE_CENTRED)
     assert algo.optimize_policy(0, samples) == dict()
     d = algo.optimizer.last_diag
     assert np.isfinite(d['loss_before']) and (not d['accepted'] or (d['kl'] <= 0.01 and d['loss'] < d['loss_before']))
@@ -270,13 +271,13 @@ def test_two_ranks_equal_one_rank_fused_update(path, tmp_path):
     assert list(two['calls'][:1]) == [eng.P + 1] and list(two['calls']).count(eng.P) == 10
     # the kernels sum float32 partials over different sample groupings on 1 and 2 ranks: float32-level (1e-7 relative) differences
     # in g, amplified by the 10 CG iterations in d (SURVEY 8d allows rel-L2 1e-3 there)
-    np.testing.assert_allclose(two['g'], cpu(one['g']), rtol=0, atol=2e-6 * np.abs(cpu(one['g'])).max())
+    np.testing.assert_allclose(two['g'], cpu(one['g']), rtol=0, atol=TOL.MULTI_RANK_GRAD * np.abs(cpu(one['g'])).max())
     rel = np.linalg.norm(two['d'] - cpu(one['d'])) / np.linalg.norm(cpu(one['d']))
     assert rel < 1e-3
     assert abs(float(two['beta']) - one['beta']) < 1e-3 * one['beta'] and int(two['n_backtrack']) == one['n_backtrack']
     assert bool(two['accepted']) and one['accepted']
     step = np.abs(cpu(eng.get_policy()) - th).max()
-    np.testing.assert_allclose(two['theta'], cpu(eng.get_policy()), rtol=0, atol=2e-3 * step + 1e-7)
+    np.testing.assert_allclose(two['theta'], cpu(eng.get_policy()), rtol=0, atol=TOL.MULTI_RANK_THETA * step + 1e-7)
 
 
 def test_bench_two_ranks_on_one_gpu():

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 from oracle import metrpo_oracle as O
+import tolerances as TOL
 
 pytestmark = pytest.mark.gpu
 
@@ -63,7 +64,7 @@ def test_full_size_iteration_properties(name):
     t_s, b_s = t_s[keep], b_s[keep]
     xn = tr.obs[t_s + 1, b_s].double().cpu().numpy(); x = tr.obs[t_s, b_s].double().cpu().numpy()
     u = np.clip(tr.act[t_s, b_s].double().cpu().numpy(), -1, 1)
-    np.testing.assert_allclose(tr.rew[t_s, b_s].double().cpu().numpy(), -O.cost_np_vec(env, x, u, xn), rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(tr.rew[t_s, b_s].double().cpu().numpy(), -O.cost_np_vec(env, x, u, xn), **TOL.REWARD)
     assert bool(torch.isfinite(tr.obs).all()) and bool(torch.isfinite(tr.rew).all())
     # --- bitwise repeat of the rollout (same launch counter -> same Philox key)
     algo.sampler._itr_seed -= 1

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 import helpers as Hh
+import tolerances as TOL
 
 pytestmark = pytest.mark.gpu
 
@@ -47,7 +48,7 @@ def test_resident_rollout_against_oracle(env, K, B, T, H, mode, hid):
     assert eng.last_rollout_kernel() == 'resident'
     drf = {k: (v.astype(np.float64) if v.dtype == np.float32 else v) for k, v in dr32.items()}
     ref = Hh.oracle_rollout(dm, th, pdims, env, pool32, drf, B, T, H, mode, teacher_obs=cpu(traj.obs))
-    tol = dict(rtol=1e-4, atol=5e-5) if hid == 512 else dict(rtol=2e-4, atol=1e-4)   # 512- / 1024-wide fp32 sums in a fixed, different order
+    tol = TOL.WIDE                                                   # row 2: 512- / 1024-wide fp32 sums in a fixed, different order
     np.testing.assert_allclose(cpu(traj.mean), ref['mean'], **tol)
     np.testing.assert_allclose(cpu(traj.act), ref['act'], **tol)
     np.testing.assert_allclose(cpu(traj.rew), ref['rew'], **tol)
@@ -62,7 +63,7 @@ def test_resident_rollout_against_oracle(env, K, B, T, H, mode, hid):
     stepwise = eng.rollout(B, T, H, mode, pool, **dr32)
     assert eng.last_rollout_kernel() == 'gemm-stepwise'
     generic = eng.rollout(B, T, H, mode, pool, force_generic=True, **dr32)        # thread-per-env kernel: a third, independent summation order
-    np.testing.assert_allclose(cpu(traj.obs), cpu(generic.obs), rtol=2e-3, atol=2e-3, err_msg='resident kernel vs generic kernel')
+    np.testing.assert_allclose(cpu(traj.obs), cpu(generic.obs), **TOL.CROSS_KERNEL, err_msg='resident kernel vs generic kernel')
     dd = np.abs(cpu(stepwise.obs) - cpu(generic.obs)); badi = np.argwhere(dd > 2e-3)
     info = ''
     if len(badi):
@@ -70,7 +71,7 @@ def test_resident_rollout_against_oracle(env, K, B, T, H, mode, hid):
         info = ' first bad step %d, envs %s, act diff at t0-1 %.3g, mean diff %.3g, model_idx at t0-1 %s, done at t0-1 %s' % (
             t0, e_bad, np.abs(cpu(stepwise.act)[t0 - 1] - cpu(generic.act)[t0 - 1]).max(), np.abs(cpu(stepwise.mean)[t0 - 1] - cpu(generic.mean)[t0 - 1]).max(),
             dr['model_idx'][t0 - 1][e_bad].tolist(), cpu(stepwise.done)[t0 - 1][e_bad].tolist())
-    np.testing.assert_allclose(cpu(stepwise.obs), cpu(generic.obs), rtol=2e-3, atol=2e-3, err_msg='step-wise GEMM path vs generic kernel' + info)
+    np.testing.assert_allclose(cpu(stepwise.obs), cpu(generic.obs), **TOL.CROSS_KERNEL, err_msg='step-wise GEMM path vs generic kernel' + info)
     assert torch.equal(traj.done, stepwise.done) and torch.equal(traj.tpath, stepwise.tpath)
 
 
@@ -90,8 +91,8 @@ def test_stepwise_workspace_after_freed_resident_regions():
         stepwise = eng.rollout(B, T, H, 'step_rand', pool, **dr32)
         assert eng.last_rollout_kernel() == 'gemm-stepwise'
         generic = eng.rollout(B, T, H, 'step_rand', pool, force_generic=True, **dr32)
-        np.testing.assert_allclose(cpu(res.obs), cpu(generic.obs), rtol=2e-3, atol=2e-3)
-        np.testing.assert_allclose(cpu(stepwise.obs), cpu(generic.obs), rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(cpu(res.obs), cpu(generic.obs), **TOL.CROSS_KERNEL)
+        np.testing.assert_allclose(cpu(stepwise.obs), cpu(generic.obs), **TOL.CROSS_KERNEL)
         del eng, res, stepwise, generic
         gc.collect()
 
@@ -122,8 +123,8 @@ def test_resident_rounds_side_by_side_equal_sequential_rounds(K, B, H, R, ws, mo
     assert eng.last_rollout_kernel() == 'gemm-stepwise'
     assert torch.equal(par[4], gm.done) and torch.equal(par[5], gm.tpath)
     np.testing.assert_array_equal(cpu(par[0][::H]), cpu(gm.obs[::H]))                     # reset states: same pool rows
-    np.testing.assert_allclose(cpu(par[0]), cpu(gm.obs), rtol=2e-3, atol=2e-3)
-    np.testing.assert_allclose(cpu(par[3]), cpu(gm.rew), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(cpu(par[0]), cpu(gm.obs), **TOL.CROSS_KERNEL)
+    np.testing.assert_allclose(cpu(par[3]), cpu(gm.rew), **TOL.CROSS_KERNEL)
 
 
 @pytest.mark.parametrize('hid', [512, 1024])
@@ -153,8 +154,8 @@ def test_resident_random_shapes_vs_generic_kernel(hid):
         same = np.ones(B, bool)
         for t in range(1, tcmp):
             same &= (cpu(res.done[t - 1]) == cpu(gen.done[t - 1]))
-            np.testing.assert_allclose(cpu(res.obs[t])[same], cpu(gen.obs[t])[same], rtol=5e-3, atol=5e-3, err_msg=msg + ' step %d' % t)
-        np.testing.assert_allclose(cpu(res.act[:1]), cpu(gen.act[:1]), rtol=1e-4, atol=1e-5, err_msg=msg)
+            np.testing.assert_allclose(cpu(res.obs[t])[same], cpu(gen.obs[t])[same], **TOL.CROSS_KERNEL, err_msg=msg + ' step %d' % t)
+        np.testing.assert_allclose(cpu(res.act[:1]), cpu(gen.act[:1]), **TOL.WIDE, err_msg=msg)
         del eng
 
 
@@ -291,8 +292,8 @@ def test_resident_validation_costs_against_oracle_and_the_stepwise_sweep(env, hi
     sweep = cpu(eng.validation_cost(s0, T, gamma))
     monkeypatch.delenv('METRPO_NO_RESIDENT_VALIDATION')
     ref = O.validation_costs(dm, theta.astype(np.float32).astype(np.float64), pdims, env, s0.astype(np.float64), T, gamma)
-    np.testing.assert_allclose(got, ref, rtol=5e-4, atol=5e-4)
-    np.testing.assert_allclose(got, sweep, rtol=5e-4, atol=5e-4)
+    np.testing.assert_allclose(got, ref, **TOL.VALIDATION_COST)
+    np.testing.assert_allclose(got, sweep, **TOL.VALIDATION_COST)
     assert not np.array_equal(got, sweep)                                 # two different kernels did run (their float32 sums differ in the last bits)
     again = cpu(eng.validation_cost(s0, T, gamma))
     np.testing.assert_array_equal(got, again)                             # bitwise repeatable
@@ -350,7 +351,7 @@ print(json.dumps({"ncu": ncu, "kernel": eng.last_rollout_kernel(), "dt": dt}))
     assert full['kernel'] == 'resident' and full['ncu'] >= 200
     assert masked['ncu'] <= 48 and masked['kernel'] == 'gemm-stepwise', masked
     assert masked['dt'] < 1.0, masked                                                # no 2 s hand-over bound burnt on the way
-    np.testing.assert_allclose(np.load(tmp_path / 'masked.npy'), np.load(tmp_path / 'full.npy'), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(np.load(tmp_path / 'masked.npy'), np.load(tmp_path / 'full.npy'), **TOL.CROSS_KERNEL)
     mid = run('0:0-119', tmp_path / 'mid.npy')                                       # 120 CUs: a resident launch sized for them
     assert mid['ncu'] <= 120 and mid['dt'] < 1.0, mid
-    np.testing.assert_allclose(np.load(tmp_path / 'mid.npy'), np.load(tmp_path / 'full.npy'), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(np.load(tmp_path / 'mid.npy'), np.load(tmp_path / 'full.npy'), **TOL.CROSS_KERNEL)

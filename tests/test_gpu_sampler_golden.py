@@ -8,6 +8,7 @@ import torch
 from conftest import load_golden, dm_from_golden
 from oracle import metrpo_oracle as O
 import helpers as Hh
+import tolerances as TOL
 
 pytestmark = pytest.mark.gpu
 
@@ -63,7 +64,7 @@ def test_reference_sampler_run_through_hip(name, chunk):
     assert len(plist) == int(d['n_paths'])
     assert [len(p['rewards']) for p in plist] == list(d['lengths'])
     cat = lambda k: np.concatenate([p[k] for p in plist])
-    tol = dict(rtol=2e-4, atol=5e-5)                                  # free-running fp32 rollout vs the float64 reference run
+    tol = TOL.LONG_RUN                                                # row 4: free-running fp32 rollout vs the float64 reference run
     np.testing.assert_allclose(cat('observations'), d['observations'], **tol)
     np.testing.assert_allclose(cat('actions'), d['actions'], **tol)
     np.testing.assert_allclose(cat('rewards'), d['rewards'], **tol)
@@ -81,10 +82,10 @@ def test_reference_sampler_run_through_hip(name, chunk):
     order = np.array(order)
     v = cpu(samples['valids']).astype(bool)
     assert v.sum() == len(order) == len(d['s_advantages']) == samples['n_valid_global'] and v[order].all()
-    np.testing.assert_allclose(cpu(samples['returns'])[order], d['s_returns'], rtol=2e-4, atol=1e-4)
-    np.testing.assert_allclose(cpu(samples['advantages'])[order], d['s_advantages'], rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(cpu(samples['returns'])[order], d['s_returns'], **TOL.RETURNS)
+    np.testing.assert_allclose(cpu(samples['advantages'])[order], d['s_advantages'], **TOL.ADVANTAGE_CENTRED)
     np.testing.assert_allclose(cpu(samples['observations'])[order], d['s_observations'], **tol)
     # refitted baseline (base.py:164-167) predicts like the reference's
     F = np.concatenate([O.LinearFeatureBaselineOracle.features(dict(observations=p['observations'], rewards=p['rewards'])) for p in plist])
     ref_pred = F @ d['coeffs_after']
-    np.testing.assert_allclose(F @ algo.baseline.coeffs, ref_pred, rtol=0, atol=5e-3 * max(1.0, np.abs(ref_pred).max()))
+    np.testing.assert_allclose(F @ algo.baseline.coeffs, ref_pred, rtol=0, atol=TOL.BASELINE_FIT * max(1.0, np.abs(ref_pred).max()))

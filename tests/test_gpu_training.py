@@ -6,6 +6,7 @@ from conftest import load_golden
 from oracle import metrpo_oracle as O
 from oracle import dynamics_oracle as D
 import helpers as Hh
+import tolerances as TOL
 
 pytestmark = pytest.mark.gpu
 
@@ -54,7 +55,7 @@ def test_train_steps_match_oracle(env, K, dh, bs, reg):
         xs, ys = D.split_batch(xb, yb, bs, K)
         ref_losses = D.prediction_losses(dm, xs, ys) + np.array([D.regularizer_loss(dm, k, reg) for k in range(K)])
         got = cpu(eng.train_step(xb, yb, bs, 1e-3, reg))
-        np.testing.assert_allclose(got, ref_losses, rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(got, ref_losses, **TOL.DYN_LOSS)
         D.train_step(dm, adam, xb, yb, bs, 1e-3, reg_constant=reg)
     Ws, bs_ = flat_to_layers(cpu(eng.get_dynamics()), dm)
     for l in range(len(dm.Ws)):
@@ -65,7 +66,7 @@ def test_train_steps_match_oracle(env, K, dh, bs, reg):
             err = np.abs(got_ - ref_)
             assert (err > 5e-5).mean() < 1e-3 and err.max() <= 4.4e-3
     xv, yv = data(dm, 777, 9)
-    np.testing.assert_allclose(cpu(eng.eval_losses(xv, yv, reg)), D.validation_losses(dm, xv, yv, reg), rtol=5e-4, atol=1e-6)
+    np.testing.assert_allclose(cpu(eng.eval_losses(xv, yv, reg)), D.validation_losses(dm, xv, yv, reg), **TOL.DYN_EVAL_LOSS)
 
 
 def test_single_step_gradient_direction():
@@ -95,7 +96,7 @@ def test_single_step_gradient_direction():
 def test_eval_losses_chunking_and_model_restore():
     eng, dm, theta, pdims, pool = Hh.make_engine('swimmer', 3, (64, 64), (32, 32), seed=73)
     xv, yv = data(dm, 20000, 11)                       # > one 8192-row pass
-    np.testing.assert_allclose(cpu(eng.eval_losses(xv, yv)), D.validation_losses(dm, xv, yv), rtol=5e-4)
+    np.testing.assert_allclose(cpu(eng.eval_losses(xv, yv)), D.validation_losses(dm, xv, yv), rtol=TOL.DYN_EVAL_LOSS['rtol'])
     snap = eng.get_dynamics().clone()
     eng.train_reset()
     for _ in range(3):
@@ -138,7 +139,7 @@ def test_replay_buffer_and_normalizers_match_reference_semantics():
     dm.diff_mean, dm.diff_std = np.zeros(10), np.ones(10)
     s = pool[:64].astype(np.float32); a = np.zeros((64, 2), np.float32)
     nxt = eng.step(s, a, 'one_model', None, None)[0]
-    np.testing.assert_allclose(cpu(nxt), O.dynamics_forward(dm, 0, s.astype(np.float64), a.astype(np.float64)), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(cpu(nxt), O.dynamics_forward(dm, 0, s.astype(np.float64), a.astype(np.float64)), **TOL.STEP)
 
 
 def test_add_rollouts_matches_reference_collect_data():
