@@ -109,7 +109,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     c->d_dyn_img = c->d_pol_img = nullptr; c->pol_img_idx = -1; c->d_pol_imgval = nullptr; c->d_pol_vpos = nullptr; c->img_live = 0;
     c->d_bptt = nullptr; c->bptt_cap = 0; c->det_cfg = -1; c->d_detpart = nullptr; c->detpart_cap = 0; c->det_gemm = 0; c->d_dg = nullptr; c->dg_cap = 0; c->vjp_gm = nullptr; c->ls_skip = nullptr; c->d_pol_adam = nullptr; c->pol_adam_t = 0; c->mfma_cfg = -1; c->pol_mfma = -1; c->coop_cfg = -1; c->rollout_variant = 0;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_cg = nullptr; c->d_vf = nullptr; c->d_theta_try = nullptr;
-    c->d_valbuf = nullptr; c->h_pinned = nullptr; c->n_sm = 256; c->n_cu_sched = 0; c->exclusive = (getenv("METRPO_NO_RESIDENT") == nullptr) ? 1 : 0;
+    c->d_valbuf = nullptr; c->h_pinned = nullptr; c->n_sm = 256; c->n_cu_sched = 0; c->upd_tiles_per_wave = getenv("METRPO_UPD_TILES_PER_WAVE") ? std::max(1, atoi(getenv("METRPO_UPD_TILES_PER_WAVE"))) : 1; c->exclusive = (getenv("METRPO_NO_RESIDENT") == nullptr) ? 1 : 0;
     c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gae_part = nullptr; c->gae_part_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0; c->d_res = nullptr; c->res_cap = 0; c->res_seq = 0; c->res_failed = 0; c->last_rollout_kernel = -1; c->upd_pending = 0; c->upd_spec = 0; c->upd_changed_in_end = 0; c->h_upd = nullptr; c->upd_stamp = 0; c->side_ready = 0; c->d_ticket = nullptr; c->d_hcache = nullptr; c->hcache_cap = 0; c->hcache_on = 0; c->d_mig = nullptr; c->mig_cap = 0; c->mig_epoch = 0; c->nccl_comm = nullptr; c->comm_world = 0; c->comm_rank = 0; c->pol_path = 1; c->d_pg = nullptr; c->pg_cap = 0; c->pg_fwd_rows = -1; c->pg_fwd_obs = nullptr; c->d_adam = nullptr; c->adam_t = 0; c->d_train = nullptr; c->train_cap = 0; c->d_train_part = nullptr; c->train_part_cap = 0;
     ProblemDesc& pd = c->pd;
     pd.env = d->env; pd.ns = d->ns; pd.na = d->na; pd.K = d->n_models; pd.n_drop = d->n_drop;

@@ -101,6 +101,7 @@ struct metrpo_ctx {
     hipStream_t side_stream[METRPO_MAX_PAR_ROUNDS - 1]; hipEvent_t ev_fork, ev_join[METRPO_MAX_PAR_ROUNDS - 1]; int side_ready;   // rollout_gemm.hip: independent rounds of a small-batch rollout run concurrently
     double* h_pinned;    // pinned host scratch for the per-trial read-back
     int n_sm;            // CU count (device property)
+    int upd_tiles_per_wave;   // MFMA update kernels: at least this many 16-sample tiles per wave before another block is added (METRPO_UPD_TILES_PER_WAVE)
     int n_cu_sched;      // CUs that actually ran this process's waves (probe.hip: census; 0 = not measured yet)
     int exclusive;       // 0: the GPU is shared with other compute processes (metrpo_set_exclusive; METRPO_NO_RESIDENT=1 in the environment means the same)
     std::string err;

@@ -439,7 +439,10 @@ static int run_mode(metrpo_ctx* c, int mode, const metrpo_batch* b, const PolK& 
         // one 8-wave block per CU = 2 waves per SIMD (measured in round 1: 2 and 3 waves per SIMD run at the same speed, 1 and 4
         // are slower) and only n_sm partial rows for k_finalize
         // (the loss + KL evaluation of the line search needs no transpose tiles and half the registers: two blocks per CU)
-        const int g = (int)std::max<long long>(1, std::min<long long>((tiles + 7) / 8, (long long)c->n_sm * (mode == 2 ? 2 : 1)));
+        // small batches (the params files' N = 50 000 - 60 000: 1.5 tiles per wave on a full grid): fewer, fuller blocks -- a launch's fixed cost does not
+        // shrink with the tile count, but k_finalize reads one partial row per block (upd_tiles_per_wave, api.hip)
+        const long long per_block = 8ll * std::max(1, c->upd_tiles_per_wave);
+        const int g = (int)std::max<long long>(1, std::min<long long>((tiles + per_block - 1) / per_block, (long long)c->n_sm * (mode == 2 ? 2 : 1)));
         int rc = ensure_partials(c, g); if (rc) return rc;
         *nrows = g; *stride = P + PART_EXTRA; *lk_col = P;
         c->ls_skip = k.skip;

@@ -31,6 +31,9 @@
 __device__ unsigned long long g_res_phase[2][8][8];
 __device__ unsigned long long g_res_wall[4][256];     // wall clock (100 MHz) of tile (round 0, tile 0): X pushed | X seen by workgroup 0 | P pushed by workgroup 0 | P complete at the post wave
 #define RT_WALL(i, cond, tau_) { if ((cond) && lane == 0 && (tau_) < 256) g_res_wall[i][tau_] = wall_clock64(); }
+__device__ unsigned long long g_res_wmax[2][256];     // latest over ALL workgroups serving tile 0: X seen | P pushed
+#define RT_WMAX(i, cond, tau_) { if ((cond) && lane == 0 && (tau_) < 256) atomicMax(&g_res_wmax[i][tau_], wall_clock64()); }
+extern "C" int32_t metrpo_debug_resident_wmax(unsigned long long* out) { const int rc = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_res_wmax), sizeof(unsigned long long) * 512) == hipSuccess ? 0 : -1; static unsigned long long zero[512]; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_res_wmax), zero, sizeof(zero)); return rc; }
 extern "C" int32_t metrpo_debug_resident_wall(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_res_wall), sizeof(unsigned long long) * 1024) == hipSuccess ? 0 : -1; }
 #define RT_DECL unsigned long long rt_t = __builtin_readcyclecounter(); unsigned long long rt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define RT_MARK(i) { const unsigned long long n_ = __builtin_readcyclecounter(); rt_acc[i] += n_ - rt_t; rt_t = n_; }
@@ -41,6 +44,7 @@ extern "C" int32_t metrpo_debug_resident_phases(unsigned long long* out) { retur
 #define RT_MARK(i)
 #define RT_DUMP(role, first)
 #define RT_WALL(i, cond, tau_)
+#define RT_WMAX(i, cond, tau_)
 #endif
 
 struct ResidentK {
@@ -48,6 +52,8 @@ struct ResidentK {
     int part_stride, part_off, Btot;                      // validation-cost mode in batch chunks: det_part[m * part_stride + part_off + tile], costs are means over Btot envs
     int det, NTM; float gamma; const float* s0; double* det_part;   // validation-cost mode (metrpo_validation_cost): tiles per model, discount, start states [B][ns], per-(model, tile) cost sums
     int NTC;                                              // 4-wave form: env tiles per workgroup COLUMN (the R * NT tiles of the launch are dealt to U / (K NSL) columns); else = NT
+    int sentinel;                                         // post waves wait on one packet per slice before they read a tile's partial sums (resident_post)
+    int rot;                                              // 4-wave form: tile g belongs to column (g + step) mod columns instead of a fixed run (uneven deals of few tiles: Ant's 7 tiles on 3 columns)
     unsigned int seq0;                                    // packets of local step tau carry seq0 + tau + 1
     int skip_block;                                       // test hook (METRPO_RESIDENT_TEST_SKIP): this workgroup behaves as if it had never been scheduled; -1 otherwise
     unsigned long long* X; unsigned long long* P; unsigned int* abort_cell;
@@ -271,7 +277,7 @@ __device__ __forceinline__ void resident_compute(const ProblemDesc& pd, const Re
 // drain of the accumulator chains at the end of a tile (2 % of it) needs no second accumulator set, and the finish of a tile (32 MFMAs, W2
 // fragments and b1 from an LDS image) rides behind the producer's next tile.  Hidden layer 0 is evaluated four 16-unit tiles at a time.
 // Packets, stamps, slot layout and the rules about stale stamps are those of resident_compute.
-template <int NS, int NIN, int DH, int WS>
+template <int NS, int NIN, int DH, int WS, bool ROT = false>
 __device__ __forceinline__ void resident_compute_wide(const ProblemDesc& pd, const ResidentK& z, const float* __restrict__ dyn, float* lds) {
     constexpr int NIN_KS = cdiv(NIN + 1, 4), J = DH / 16, JQ = J / 4, JB = 4, MT = WS / 16, OUT_CB = cdiv(NS, 16), NSP = 16 * OUT_CB;
     // Wide inputs (Ant: 35 + 1 inputs = 9 k-steps): the W0 fragments of the k-steps beyond the sixth live in an LDS image instead of 16 more
@@ -290,7 +296,16 @@ __device__ __forceinline__ void resident_compute_wide(const ProblemDesc& pd, con
     // Validation-cost mode (z.det): tile g = model * NTM + tile of the batch belongs to ONE model -- the workgroups of model k deal model k's NTM tiles
     // to their columns and never see the others'.
     const int g0 = z.det ? k * z.NTM + col * z.NTC : col * z.NTC;
-    const int NT = z.det ? max(0, min(z.NTC, z.NTM - col * z.NTC)) : max(0, min(z.NTC, z.R * z.NT - g0));
+    // ROTATING deal (z.rot; launches of few tiles that do not divide by the columns -- Ant's one round of 7 tiles on 3 columns is 3 / 2 / 2 and the rollout
+    // runs at the pace of the column with 3): tile g is served by column (g + step) mod NCOL, so every column has 3, 2, 2, 3, ... tiles and all of
+    // them the same 7 per three steps.  Every column holds the same weight slices and the packets are indexed by the global tile, so nothing else
+    // moves; local tile t of step tau is global tile first(tau) + t NCOL.
+    constexpr bool rot = ROT;                                    // an instantiation of its own: the fixed deal keeps its constant tile count and addresses
+    const int NCOL = z.U / (K * NSL), G = z.R * z.NT;
+    auto first_at = [&](int tau_) -> int { return ((col - tau_) % NCOL + NCOL) % NCOL; };
+    auto cnt_at = [&](int tau_) -> int { return rot ? (G - first_at(tau_) + NCOL - 1) / NCOL : (z.det ? max(0, min(z.NTC, z.NTM - col * z.NTC)) : max(0, min(z.NTC, G - g0))); };
+    auto g_at = [&](int tau_, int t_) -> int { return rot ? first_at(tau_) + t_ * NCOL : g0 + t_; };
+    int NT = cnt_at(0);                                          // tiles of this column in the current step (constant unless rot)
     if (NT == 0) return;
     const float* __restrict__ W = dyn + (size_t)k * pd.dyn.n_params;
     const float* __restrict__ W0 = W + pd.dyn.w_off[0];
@@ -327,20 +342,31 @@ __device__ __forceinline__ void resident_compute_wide(const ProblemDesc& pd, con
             }
     }
     __syncthreads();                                            // stamps, W2 / b1 / W0 images
-    const unsigned long long* xbase = z.X + ((size_t)g0 * (4 * NIN_KS)) * 16 + c;
+    const unsigned long long* xbase = z.X + c;
     unsigned long long pk[NIN_KS];
-    auto fetch = [&](int t) {
+    auto fetch = [&](int g) {                                    // g: global tile
 #pragma unroll
-        for (int kk = 0; kk < NIN_KS; ++kk) pk[kk] = res_ld(xbase + ((size_t)t * (4 * NIN_KS) + 4 * kk + q) * 16);
+        for (int kk = 0; kk < NIN_KS; ++kk) pk[kk] = res_ld(xbase + ((size_t)g * (4 * NIN_KS) + 4 * kk + q) * 16);
     };
     // A slot serves the tiles t, t + 8, ... of the column, step after step: use number uid(tau, t) = tau * (uses of the slot per step) + t / 8.
     // Producers stamp a slot with uid + 1 once their quarter is in it, the finisher marks it consumed (uid + 1) once it has read the four
     // quarters, and a producer writes use n only over a consumed use n - 1: nobody can lap the finisher (every wait below keeps finishing).
-    auto uid_of = [&](int tau, int t) -> unsigned int { const int s_ = t & (NSLOT - 1); return (unsigned int)(tau * ((NT - s_ + NSLOT - 1) / NSLOT) + t / NSLOT); };
+    // Rotating deal (at most NSLOT tiles per step, slot = local tile): the uses of slot t before step tau = the steps tau' < tau with more than t tiles,
+    // i.e. first(tau') < G - t NCOL; first(.) runs through all residues once per NCOL steps.
+    auto uid_of = [&](int tau, int t) -> unsigned int {
+        const int s_ = t & (NSLOT - 1);
+        if (!rot) return (unsigned int)(tau * ((NT - s_ + NSLOT - 1) / NSLOT) + t / NSLOT);
+        const int lim = G - t * NCOL, full = tau / NCOL, rem = tau - full * NCOL;
+        int n = full * max(0, min(NCOL, lim));
+        for (int j = 0; j < rem; ++j) n += (first_at(j) < lim) ? 1 : 0;
+        return (unsigned int)n;
+    };
     // ---- finisher duties of this wave: tiles kap, kap + 4, ... of the column, every step, in order
     int dt = kap, dtau = 0;
+    auto duty_norm = [&]() { while (dtau < z.steps && dt >= cnt_at(dtau)) { dt = kap; ++dtau; } };      // next (step, local tile = kap mod 4) this wave finishes
     auto try_finish = [&]() -> bool {
-        if (dt >= NT || dtau >= z.steps) return false;
+        duty_norm();
+        if (dtau >= z.steps) return false;
         const int s_ = dt & (NSLOT - 1);
         const unsigned int want = uid_of(dtau, dt) + 1u;
         const unsigned int st = __hip_atomic_load((const unsigned int*)lds + O_STAMP + s_ * 4 + (lane & 3), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -370,20 +396,28 @@ __device__ __forceinline__ void resident_compute_wide(const ProblemDesc& pd, con
             }
         }
         const unsigned int dseq = z.seq0 + (unsigned int)dtau + 1u;
-        unsigned long long* pp = z.P + ((((size_t)(g0 + dt) * K + k) * NSL + sl) * NSP) * 16 + c;
+        // rotating deal: a region per column, so that every packet address keeps ONE writer (a workgroup of a head nobody selected may run a step late:
+        // its packet of step tau must not be able to land on top of another column's packet of step tau + 1)
+        unsigned long long* pp = z.P + ((((size_t)((rot ? col * G : 0) + g_at(dtau, dt)) * K + k) * NSL + sl) * NSP) * 16 + c;
 #pragma unroll
         for (int ocb = 0; ocb < OUT_CB; ++ocb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const int dim = 16 * ocb + 4 * q + r; if (dim < NS) res_st(pp + dim * 16, dseq, o[ocb][r]); }
+        RT_WALL(2, k == 0 && sl == 0 && g_at(dtau, dt) == 0, dtau)
+        RT_WMAX(1, g_at(dtau, dt) == 0, dtau)
         dt += 4;
-        if (dt >= NT) { dt = kap; ++dtau; }
+        duty_norm();
         return true;
     };
-    fetch(0);
+    fetch(g_at(0, 0));
     int t = 0, tau = 0; unsigned int seq = z.seq0 + 1u;
-    const int total = z.steps * NT;
-    for (int it = 0; it < total; ++it) {
+#ifdef RES_TIMING
+    const int wave = kap;
+#endif
+    RT_DECL
+    while (tau < z.steps) {
         float x[NIN_KS];
+        RT_MARK(3)
         {
             ResSpin sp;
             for (;;) {
@@ -393,10 +427,13 @@ __device__ __forceinline__ void resident_compute_wide(const ProblemDesc& pd, con
                 if (__all(ok)) break;
                 (void)try_finish();                                     // the input may be waiting for the very tile this wave still has to finish
                 if (sp.give_up(z)) return;
-                fetch(t);
+                fetch(g_at(tau, t));
             }
         }
-        fetch((t + 1 < NT) ? t + 1 : 0);
+        fetch((t + 1 < NT) ? g_at(tau, t + 1) : g_at(tau + 1, 0));        // (past the last step: a packet nobody waits for)
+        RT_MARK(0)
+        RT_WALL(1, k == 0 && sl == 0 && kap == 0 && g_at(tau, t) == 0, tau)
+        RT_WMAX(0, g_at(tau, t) == 0, tau)
         __builtin_amdgcn_sched_barrier(0);
         f32x4 a2[MT];
 #pragma unroll
@@ -419,6 +456,7 @@ __device__ __forceinline__ void resident_compute_wide(const ProblemDesc& pd, con
                     for (int mt = 0; mt < MT; ++mt) a2[mt] = MFMA16(w1f[mt][jb + jj][r], hr, a2[mt]);
                 }
         }
+        RT_MARK(1)
         {   // partial sums of env tile t out (LDS operations of one wave complete in issue order: the stamp lands after the data)
             const int s_ = t & (NSLOT - 1);
             const unsigned int uid = uid_of(tau, t);
@@ -441,11 +479,13 @@ __device__ __forceinline__ void resident_compute_wide(const ProblemDesc& pd, con
             ResSpin sp;
             while (dtau < z.steps && (dtau < tau || (dtau == tau && dt <= t))) { if (!try_finish() && sp.give_up(z)) return; }
         } else (void)try_finish();
-        if (++t == NT) { t = 0; ++seq; ++tau; }
+        RT_MARK(2)
+        if (++t == NT) { t = 0; ++seq; ++tau; if (rot) NT = cnt_at(tau); }
     }
+    RT_DUMP(0, 0)
     {   // what is left of this wave's duties (the other producers' last hand-overs may still be under way)
         ResSpin sp;
-        while (dt < NT && dtau < z.steps) { if (!try_finish() && sp.give_up(z)) return; }
+        for (;;) { duty_norm(); if (dtau >= z.steps) break; if (!try_finish() && sp.give_up(z)) return; }
     }
 }
 
@@ -641,8 +681,35 @@ __device__ __forceinline__ void resident_post(const ProblemDesc& pd, const Rollo
         if (tau + 1 < z.steps) draw(t_loc + 1);                        // next step's block and noise
         // ---- output layer of head `sel`: lane q adds slices q, q + 4, ... in slice order, then the four lanes' sums are added (fixed tree)
         const unsigned long long* pq = pbase + (size_t)sel * NSL * NSP * 16;
+        if (z.rot) pq += (size_t)((g + tau) % (z.U / (K * NSL))) * (size_t)(z.R * z.NT) * K * NSL * NSP * 16;      // the region of the column that serves this tile in this step
         float out[NS];
         RT_MARK(1)
+#ifdef RES_NO_SENT      // the RES_TIMING build of the Ant instantiation (scratch + 141 spilled scalars) faults with this loop compiled in: its phase runs use -DRES_NO_SENT
+        if (false) {
+#else
+        if (z.sentinel) {
+#endif
+            // Wait on ONE packet per slice first -- the dim a finisher stores in its last instruction -- and read the rest only when those are in: a
+            // polling round over all NSL x NS packets of an env takes 2 - 4 us (two dependent batches of 60 loads per lane through the fabric), and the
+            // round that finds everything started, on average, half a round before the last packet landed.  Every packet still carries its own stamp:
+            // the full read below checks them all and repeats if one is behind.
+            constexpr int SENT = 16 * (C::OUT_CB - 1) + ((NS - 16 * (C::OUT_CB - 1) - 1 < 3) ? NS - 16 * (C::OUT_CB - 1) - 1 : 3);
+            ResSpin sp;
+            for (;;) {
+                bool ok = true;
+                if (active) {
+                    for (int s0 = 0; s0 < NSL; s0 += 16) {
+                        unsigned long long pk[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) pk[j] = res_ld(pq + ((size_t)(s0 + 4 * j + q) * NSP + SENT) * 16);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) ok = ok && res_fresh(pk[j], seq);
+                    }
+                }
+                if (__all(ok)) break;
+                if (sp.give_up(z)) return;
+            }
+        }
         {
             ResSpin sp;
             for (;;) {
@@ -920,14 +987,14 @@ __global__ void __launch_bounds__(512) k_rollout_resident(ProblemDesc pd, Rollou
     else resident_post<ENV>(pd, r, z, dyn, theta, norm, lds);
 }
 
-template <int ENV, int DH, int WS>
+template <int ENV, int DH, int WS, bool ROT = false>
 __global__ void __launch_bounds__(256, 1) k_rollout_resident_wide(ProblemDesc pd, RolloutK r, ResidentK z, const float* __restrict__ dyn,
                                                                   const float* __restrict__ theta, const float* __restrict__ norm) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using C = Cfg<ENV, 64, 32>;
     if (r.stop != nullptr && *r.stop != 0) return;
     if ((int)blockIdx.x == z.skip_block) return;
-    if ((int)blockIdx.x < z.U) resident_compute_wide<C::NS, C::NIN, DH, WS>(pd, z, dyn, lds);
+    if ((int)blockIdx.x < z.U) resident_compute_wide<C::NS, C::NIN, DH, WS, ROT>(pd, z, dyn, lds);
     else resident_post<ENV>(pd, r, z, dyn, theta, norm, lds);
 }
 
@@ -947,9 +1014,9 @@ template <int ENV, int DH, int WS> static size_t resident_lds_bytes_wide() {
     return std::max(comp, post);
 }
 typedef void (*resident_kernel_t)(ProblemDesc, RolloutK, ResidentK, const float*, const float*, const float*);
-struct ResidentEntry { int env, ns, na, n_drop, dh, ws, threads; resident_kernel_t fn; size_t lds; };     // threads: 512 = 4 producer + 4 finisher waves, 256 = 4 waves doing both (2 x 1024)
-#define RES_ENTRY(ENV, DH, WS) {ENV, EnvDim<ENV>::NS, EnvDim<ENV>::NA, EnvDim<ENV>::NDROP, DH, WS, 512, k_rollout_resident<ENV, DH, WS>, resident_lds_bytes<ENV, DH, WS>()}
-#define RES_ENTRY_WIDE(ENV, DH, WS) {ENV, EnvDim<ENV>::NS, EnvDim<ENV>::NA, EnvDim<ENV>::NDROP, DH, WS, 256, k_rollout_resident_wide<ENV, DH, WS>, resident_lds_bytes_wide<ENV, DH, WS>()}
+struct ResidentEntry { int env, ns, na, n_drop, dh, ws, threads; resident_kernel_t fn; size_t lds; resident_kernel_t fn_rot; };     // threads: 512 = 4 producer + 4 finisher waves, 256 = 4 waves doing both (2 x 1024)
+#define RES_ENTRY(ENV, DH, WS) {ENV, EnvDim<ENV>::NS, EnvDim<ENV>::NA, EnvDim<ENV>::NDROP, DH, WS, 512, k_rollout_resident<ENV, DH, WS>, resident_lds_bytes<ENV, DH, WS>(), nullptr}
+#define RES_ENTRY_WIDE(ENV, DH, WS) {ENV, EnvDim<ENV>::NS, EnvDim<ENV>::NA, EnvDim<ENV>::NDROP, DH, WS, 256, k_rollout_resident_wide<ENV, DH, WS>, resident_lds_bytes_wide<ENV, DH, WS>(), k_rollout_resident_wide<ENV, DH, WS, true>}
 static const ResidentEntry* resident_table(int* n) {
     static const ResidentEntry tab[] = {                                // per (env, width): narrowest slice first
         RES_ENTRY(METRPO_ENV_SWIMMER, 512, 16), RES_ENTRY(METRPO_ENV_SWIMMER, 512, 32),
@@ -1011,7 +1078,10 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
     if (pick->lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)pick->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pick->lds));
     if (!grid_is_coresident(c, (const void*)pick->fn, pick->threads, pick->lds, 1, st)) return METRPO_EUNSUPPORTED;      // >= one workgroup per CU, exclusive device
     const int NSL = DH / pick->ws, OUT_CB = (pd.ns + 15) / 16, NIN_KS = (pd.nin + 1 + 3) / 4;
-    const size_t nX = (size_t)Rg * NT * 4 * NIN_KS * 16, nP = (size_t)Rg * NT * K * NSL * 16 * OUT_CB * 16;
+    // rotating deal (ResidentK::rot): launches of the 4-wave form whose few tiles do not divide by the columns; one partial-sum region per column
+    const bool may_rot = pick->threads == 256 && pick->fn_rot != nullptr && getenv("METRPO_RESIDENT_NO_ROTATE") == nullptr;
+    const int max_cols = std::max(1, n_cu / (K * (DH / pick->ws)));
+    const size_t nX = (size_t)Rg * NT * 4 * NIN_KS * 16, nP = (size_t)Rg * NT * K * NSL * 16 * OUT_CB * 16 * (may_rot ? max_cols : 1);
     const size_t need = (nX + nP + 32) * sizeof(unsigned long long);
     if (need > c->res_cap) {
         if (c->d_res) HIP_TRY(c, hipFree(c->d_res));
@@ -1031,28 +1101,36 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
         HIP_TRY(c, hipMemsetAsync(c->d_res, 0, c->res_cap, st));
         c->res_seq = 0;
     }
-    if (pick->lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)pick->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pick->lds));
+    if (pick->lds > 64 * 1024) {
+        HIP_TRY(c, hipFuncSetAttribute((const void*)pick->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pick->lds));
+        if (pick->fn_rot) HIP_TRY(c, hipFuncSetAttribute((const void*)pick->fn_rot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pick->lds));
+    }
     RolloutK rk = make_rollout_k(a);
     for (int round0 = 0; round0 < R; round0 += Rg) {
         const int rg = std::min(Rg, R - round0);
         ResidentK z;
-        z.R = rg; z.round0 = round0; z.rounds_total = R; z.NT = NT; z.NSL = NSL; z.U = rg * K * NSL; z.PW = PW; z.steps = steps; z.NTC = NT;
+        z.R = rg; z.round0 = round0; z.rounds_total = R; z.NT = NT; z.NSL = NSL; z.U = rg * K * NSL; z.PW = PW; z.steps = steps; z.NTC = NT; z.rot = 0;
         z.det = 0; z.NTM = 0; z.gamma = 1.0f; z.s0 = nullptr; z.det_part = nullptr; z.part_stride = 0; z.part_off = 0; z.Btot = 0;
         if (pick->threads == 256) {
             const int G = rg * NT, post_blocks = (G + PW - 1) / PW;
             const int ncol = std::max(1, std::min(G, (n_cu - post_blocks) / (K * NSL)));
             z.NTC = (G + ncol - 1) / ncol;
             z.U = ((G + z.NTC - 1) / z.NTC) * K * NSL;
+            const int cols = z.U / (K * NSL);
+            z.rot = (may_rot && cols > 1 && z.NTC <= 4 && G % cols != 0 && G >= cols) ? 1 : 0;
         }
         z.seq0 = c->res_seq; c->res_seq += (unsigned int)steps + 1u;
         z.skip_block = -1;
+        // few tiles per column (Ant's chunks, single rounds): the step is a latency chain and the post wave's polling rounds are on it; with many tiles per
+        // column the partial sums are there before the post wave looks, and the extra round trip of the sentinel read costs 2 - 4 % (half-cheetah, 5 rounds)
+        z.sentinel = (pick->threads == 256 && z.NTC <= 4 && getenv("METRPO_RESIDENT_NO_SENTINEL") == nullptr) ? 1 : 0;
         if (const char* sk = getenv("METRPO_RESIDENT_TEST_SKIP")) z.skip_block = atoi(sk);
         z.abort_cell = (unsigned int*)c->d_res;
         z.X = (unsigned long long*)c->d_res + 32; z.P = z.X + nX;
         z.err = comm_err_cell(c) + 1;                               // scal[S_ROLLERR]
         const int grid = z.U + (rg * NT + PW - 1) / PW;
         if (grid > n_cu) return set_err(c, METRPO_EHIP, "resident rollout: grid larger than the schedulable CUs (launch rule out of step with the census)");
-        hipLaunchKernelGGL(pick->fn, dim3(grid), dim3(pick->threads), pick->lds, st, pd, rk, z, c->d_dyn, c->d_theta, c->d_norm);
+        hipLaunchKernelGGL(z.rot ? pick->fn_rot : pick->fn, dim3(grid), dim3(pick->threads), pick->lds, st, pd, rk, z, c->d_dyn, c->d_theta, c->d_norm);
     }
     HIP_TRY(c, hipGetLastError());
     c->last_rollout_kernel = 4;
@@ -1135,11 +1213,11 @@ int launch_validation_resident(metrpo_ctx* c, const float* s0, int Bv, int T, do
     for (int ch = 0; ch < nb; ++ch) {
         const int b_lo = ch * Bc, bn = std::min(Bc, Bv - b_lo);
         ResidentK z;
-        z.R = 1; z.round0 = 0; z.rounds_total = 1; z.NT = NTM; z.NSL = NSL; z.U = cols * K * NSL; z.PW = PW; z.steps = T; z.NTC = NTC;
+        z.R = 1; z.round0 = 0; z.rounds_total = 1; z.NT = NTM; z.NSL = NSL; z.U = cols * K * NSL; z.PW = PW; z.steps = T; z.NTC = NTC; z.rot = 0;
         z.det = 1; z.NTM = NTM; z.gamma = (float)gamma; z.s0 = s0 + (size_t)b_lo * pd.ns; z.det_part = c->d_detpart;
         z.part_stride = nb * NTM; z.part_off = ch * NTM; z.Btot = Bv;
         z.seq0 = c->res_seq; c->res_seq += (unsigned int)T + 1u;
-        z.skip_block = -1;
+        z.skip_block = -1; z.sentinel = 0;
         z.abort_cell = (unsigned int*)c->d_res;
         z.X = (unsigned long long*)c->d_res + 32; z.P = z.X + nX;
         z.err = comm_err_cell(c) + 1;

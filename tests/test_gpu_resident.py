@@ -97,6 +97,29 @@ def test_stepwise_workspace_after_freed_resident_regions():
         gc.collect()
 
 
+@pytest.mark.parametrize('env,B,T,H,mode', [('ant', 100, 23, 9, 'step_rand'),            # 7 tiles on 3 columns: 3 / 2 / 2 -> every column 3, 2, 2, 3, ... (Ant's chunks)
+                                             ('half_cheetah', 100, 14, 14, 'eps_rand'),    # one round of a horizon-terminated env
+                                             ('hopper', 70, 11, 4, 'one_model'),           # 5 tiles on 3 columns, heads nobody selects
+                                             ('snake', 16 * 4, 9, 9, 'step_rand')])        # 4 tiles on 3 columns
+def test_rotating_tile_deal_and_sentinel_wait_are_bitwise_the_fixed_deal(env, B, T, H, mode, monkeypatch):
+    """Launches of few env tiles that do not divide by the workgroup columns (4-wave form): tile g is served by column (g + step) mod columns, and the
+    post waves wait on one packet per slice before they read a tile's partial sums (rollout_resident.hip: ResidentK::rot, ::sentinel).  Neither
+    changes who adds what in which order: every trajectory tensor bit for bit the fixed deal's, with and without the sentinel wait."""
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, 5, (1024, 1024), (32, 32), seed=67)
+    if env == 'ant':
+        pool[::3, 2] = 0.21; dm.diff_mean[2] = -0.02
+        eng.set_dynamics_layers(dm.Ws, dm.bs, dm.in_mean, dm.in_std, dm.diff_mean, dm.diff_std)
+    rot = _fields(eng.rollout(B, T, H, mode, pool, seed=11))
+    assert eng.last_rollout_kernel() == 'resident'
+    for var in ('METRPO_RESIDENT_NO_SENTINEL', 'METRPO_RESIDENT_NO_ROTATE'):      # first without the sentinel wait, then also on the fixed deal
+        monkeypatch.setenv(var, '1')
+        other = eng.rollout(B, T, H, mode, pool, seed=11)
+        assert eng.last_rollout_kernel() == 'resident'
+        for a, b in zip(rot, _fields(other)):
+            assert torch.equal(a, b), var
+    eng.comm_check()
+
+
 @pytest.mark.parametrize('K,B,H,R,ws', [(5, 100, 7, 3, 32),        # params-file layout: 240 compute workgroups, rounds side by side
                                         (5, 100, 3, 8, 32),        # more rounds than fit at once: round groups (3 + 3 + 2), one launch each
                                         (2, 40, 5, 2, 16),         # narrow slices with the rounds side by side
