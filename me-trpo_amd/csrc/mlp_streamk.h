@@ -25,6 +25,12 @@
 //     and nobody waits for a workgroup that was dispatched after it (no co-residency assumption: a producer never waits before it exports
 //     unless its whole range lies inside one tile, and then only for lower-numbered workgroups).
 //
+//   * FEWER tiles than CUs (a.late; small batches: the Humanoid params file has 80 tiles): cut that way a tile would be three or four pieces in a row, each
+//     waiting for the one before it.  Instead every piece starts from ZERO, so the pieces of a tile run at the same time on different CUs, and a piece
+//     that does not begin its tile imports the running sum of the pieces before it at its END and adds it to its own (then exports, or finishes the
+//     tile).  An output is then (((p0) + p1) + p2) ... of k-ordered chains: still a fixed order for a given grid, no longer independent of the grid.
+//     Waits are again only for lower-numbered workgroups, and only at the end of a range.
+//
 // Summation order of one output: chunks of 32 k in order; inside a chunk the steps (j, e) = (0,0) .. (1,3), step (j, e) adding
 // k = 16 j + e + {0, 4, 8, 12} in that order (the four lane groups of the matrix instruction) -- fixed, independent of grid and split.
 #pragma once
@@ -33,7 +39,7 @@
 
 enum { SK_A_GLOBAL = 0, SK_A_PRODUCER = 1 };      // main layer's input: activations [M][K1] in HBM | computed from x by layer 0 on the fly
 enum { SK_EPI_STORE = 0, SK_EPI_OUT = 1 };        // relu(acc + b1) stored row-major | contracted with the (<= 64 column) output layer, partial per column block
-enum { SKF_ZERO = 1, SKF_IMPORT = 2, SKF_EXPORT = 4, SKF_LAST = 8, SKF_EPI = 16, SKF_EPILAST = 32, SKF_NONE = 64, SKF_NEWTILE = 128 };
+enum { SKF_ZERO = 1, SKF_IMPORT = 2, SKF_EXPORT = 4, SKF_LAST = 8, SKF_EPI = 16, SKF_EPILAST = 32, SKF_NONE = 64, SKF_NEWTILE = 128, SKF_LATE = 256 };
 
 struct SkRec;
 struct SkArgs {
@@ -53,6 +59,7 @@ struct SkArgs {
 #endif
     const int* hdr; const SkRec* recs;         // schedule: entries per workgroup | [grid][sched_cap] records (k_sk_sched)
     int RB, CB, NCk, L, tiles, sched_cap;      // row blocks of 128, column blocks of 256, chunks per tile, units per tile (chunks + epilogue weight)
+    int late;                                  // FEWER tiles than workgroups: the pieces of a tile run side by side from zero and are ADDED at their ends (below)
     long long units;
 };
 
@@ -133,8 +140,8 @@ __global__ void __launch_bounds__(512) k_sk_sched(const SkArgs a, int* __restric
         int tile, c, fl = 0;                                                   // c: chunk, or EPI chunk index when fl & SKF_EPI
         if (t < n_h) {                                                         // the piece that begins a tile: first, exported at once
             tile = te; c = (ts == te ? cs : 0) + t;
-            if (t == 0) fl |= (c == 0) ? SKF_ZERO : SKF_IMPORT;
-            if (t == n_h - 1) fl |= SKF_EXPORT;
+            if (t == 0) fl |= (c == 0 || a.late) ? SKF_ZERO : SKF_IMPORT;
+            if (t == n_h - 1) fl |= SKF_EXPORT | ((a.late && ts == te && cs > 0) ? SKF_LATE : 0);      // a middle piece: adds what came before, hands the sum on
         } else if (t < n_h + nf * Le) {
             const int tt = t - n_h; tile = tf + tt / Le; c = tt % Le;
             if (c == 0) fl |= SKF_ZERO;
@@ -142,8 +149,8 @@ __global__ void __launch_bounds__(512) k_sk_sched(const SkArgs a, int* __restric
             if (c >= NCk) { c -= NCk; fl = SKF_EPI | (c == E - 1 ? SKF_EPILAST : 0); }
         } else {                                                               // the piece that ends a tile: last, continues the previous workgroup's sums
             const int tt = t - n_h - nf * Le; tile = ts; c = cs + tt;
-            if (tt == 0) fl |= SKF_IMPORT;
-            if (c == NCk - 1) fl |= SKF_LAST;
+            if (tt == 0) fl |= a.late ? SKF_ZERO : SKF_IMPORT;
+            if (c == NCk - 1) fl |= SKF_LAST | (a.late ? SKF_LATE : 0);
             if (c >= NCk) { c -= NCk; fl = SKF_EPI | (c == E - 1 ? SKF_EPILAST : 0); }
         }
         const int head = tile / tph, cb = (tile / a.RB) % a.CB, rb = tile % a.RB;
@@ -302,6 +309,14 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
 #endif
 
     bool export_issued = false;
+    auto wait_prev = [&]() {                                                   // the previous workgroup's export flag of this launch (bounded: report, do not hang)
+        const unsigned* fp = a.xflag + (size_t)(blockIdx.x - 1) * 8 + wave;
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > 200000000ull) { if (lane == 0) *a.err = 1.0; break; }      // 2 s at 100 MHz
+        }
+    };
     auto body = [&](auto par_, const int q) {
         constexpr int PAR = decltype(par_)::value;
         f32x4 (&h)[2] = hs[PAR];
@@ -335,12 +350,7 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
                     for (int v = 0; v < 4; ++v) acc[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             if (r0.fl & SKF_IMPORT) {                                          // the previous workgroup's partial sums of this tile (exported at its start)
-                const unsigned* fp = a.xflag + (size_t)(blockIdx.x - 1) * 8 + wave;
-                const unsigned long long t0 = wall_clock64();
-                while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (wall_clock64() - t0 > 200000000ull) { if (lane == 0) *a.err = 1.0; break; }      // 2 s at 100 MHz: report, do not hang
-                }
+                wait_prev();
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xacc + ((size_t)(blockIdx.x - 1) * 8 + wave) * 4096), 0, 16384, 0x00020000);
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
@@ -384,6 +394,21 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
             }
             SK_STAMP(2);
+            if (r0.fl & SKF_LATE) {                                            // a.late: the running sum of the tile's earlier pieces, added to this piece's own sums
+                wait_prev();
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xacc + ((size_t)(blockIdx.x - 1) * 8 + wave) * 4096), 0, 16384, 0x00020000);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {                                  // 16 registers at a time
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    u32x4 raw[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) raw[v] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((u * 4 + v) * 64 + lane) * 16, 0, 16);
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc[u][v] += __builtin_bit_cast(f32x4, raw[v]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             if (r0.fl & SKF_EXPORT) {
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xacc + ((size_t)blockIdx.x * 8 + wave) * 4096), 0, 16384, 0x00020000);
 #pragma unroll
@@ -494,7 +519,7 @@ static inline SkPlan sk_plan(SkArgs& a, int n_sm, int grid_override = 0) {
     a.tiles = a.heads * a.CB * a.RB;
     a.units = (long long)a.tiles * a.L;
     SkPlan p;
-    p.grid = grid_override > 0 ? grid_override : (a.tiles < n_sm ? a.tiles : n_sm);
+    p.grid = grid_override > 0 ? grid_override : ((a.tiles < n_sm && !a.late) ? a.tiles : n_sm);
     const long long cap = a.units / p.grid + 2LL * a.L + 8;
     a.sched_cap = (int)cap;
     p.lds_bytes = (size_t)4 * GE::STAGE * sizeof(float);

@@ -644,7 +644,8 @@ static size_t sk_epi_floats(int OT, int N, int heads) {
     const size_t per = (OT == 1) ? SkEpi<1>::FLOATS * SkEpi<1>::E : (OT == 2) ? SkEpi<2>::FLOATS * SkEpi<2>::E : SkEpi<4>::FLOATS * SkEpi<4>::E;
     return (size_t)heads * (N / 256) * per;
 }
-struct SkPath {            // mode 0: off; 1: x -> [layer 0 | layer 1 | output layer] in one launch; 2: layer L-3 stored, [layer L-2 | output layer]
+struct SkPath {            // mode 0: off; 1: x -> [layer 0 | layer 1 | output layer] in one launch; 2: layer L-3 stored, [layer L-2 | output layer];
+                           // 3: two hidden layers with a wide input: layer 0 stored by the tile GEMM, [layer 1 | output layer] in one launch
     int mode, S0, OT;
     SkVt v1, v2; SkArgs a1, a2; SkPlan p1, p2;
 };
@@ -661,22 +662,35 @@ static SkPath sk_select(const metrpo_ctx* c, int B) {
     const int K1 = pd.dyn.dims[L - 2], N = pd.dyn.dims[L - 1];            // the layer in front of the output layer: [K1 x N]
     if (K1 % 32 != 0 || N % 256 != 0) return sp;
     sp.OT = (pd.ns <= 16) ? 1 : (pd.ns <= 32) ? 2 : 4;
-    if (!force && (long long)K * ((B + 127) / 128) * (N / 256) < c->n_sm) return sp;   // fewer tiles than CUs: the tile GEMMs / the resident kernels serve those shapes
-    auto shape = [&](SkArgs& a, int K1_, int N_) { a = SkArgs{}; a.M = B; a.heads = K; a.K1 = K1_; a.N = N_; };
+    // Fewer tiles than CUs: the pieces of a tile side by side, added at their ends (mlp_streamk.h: SkArgs::late).  Built and measured at the Humanoid
+    // params file's shape (K = 5, M = 500, 2 x 1024: 80 tiles, 10.6 chunks per workgroup): 71.7 us against the tile GEMM's 69.9 us -- a tile is 3-4
+    // pieces, and the hand-overs at the END of the pieces (store + drain + flag + four load passes, ~9 us per link) form a chain of 2-3 links after
+    // the last matrix instruction.  So it is not selected by itself: METRPO_STREAMK_LATE=1 selects it from 8 chunks per workgroup up, forced launches
+    // (METRPO_STREAMK=1: the parity tests) use it from 2 up, METRPO_STREAMK_LATE=0 never (forced launches then run one unsplit tile per workgroup).
+    const char* le = getenv("METRPO_STREAMK_LATE");
+    const bool late_ok = (le != nullptr) ? le[0] == '1' : force;
+    auto late_for = [&](int K1_, int N_, int epi_units) -> int {
+        const long long tiles = (long long)K * ((B + 127) / 128) * (N_ / 256), units = tiles * (K1_ / 32 + epi_units);
+        return (late_ok && tiles < c->n_sm && units / c->n_sm >= (force ? 2 : 8)) ? 1 : 0;
+    };
+    const int epi_units = (sp.OT == 4) ? 2 : 1;
+    if (!force && (long long)K * ((B + 127) / 128) * (N / 256) < c->n_sm && !late_for(K1, N, epi_units)) return sp;
+    auto shape = [&](SkArgs& a, int K1_, int N_, int eu) { a = SkArgs{}; a.M = B; a.heads = K; a.K1 = K1_; a.N = N_; a.late = late_for(K1_, N_, eu); };
     if (L == 3) {
         sp.S0 = (pd.nin + 1 + 3) / 4;
-        if (!sk_fused_vt(sp.S0, sp.OT, &sp.v1)) return sp;
-        shape(sp.a1, K1, N);
-        sp.a1.lda = 4 * sp.S0; sp.a1.ldp = 16 * sp.OT; sp.a1.stridePart = (long long)B * sp.a1.ldp;
+        const bool fused = sk_fused_vt(sp.S0, sp.OT, &sp.v1);                   // layer 0 as producer: inputs of up to 36 values (Humanoid's 76 + 1: mode 3)
+        if (!fused && !sk_out_vt(sp.OT, &sp.v1)) return sp;
+        shape(sp.a1, K1, N, epi_units);
+        sp.a1.lda = fused ? 4 * sp.S0 : K1; sp.a1.ldp = 16 * sp.OT; sp.a1.stridePart = (long long)B * sp.a1.ldp;
         sp.p1 = sp.v1.plan(sp.a1, c->n_sm);
         if (sp.p1.lds_bytes > 160 * 1024) return sp;
-        sp.mode = 1;
+        sp.mode = fused ? 1 : 3;
     } else {
         const int K0 = pd.dyn.dims[1], N0 = pd.dyn.dims[2];                  // layer 1: [K0 x N0], N0 == K1
         if (K0 % 32 != 0 || N0 % 256 != 0 || N0 != K1) return sp;
         if (!sk_out_vt(sp.OT, &sp.v2)) return sp;
         sp.v1 = sk_vt<SK_A_GLOBAL, SK_EPI_STORE, 1, 1>();
-        shape(sp.a1, K0, N0); shape(sp.a2, K1, N);
+        shape(sp.a1, K0, N0, 1); shape(sp.a2, K1, N, epi_units);
         sp.a2.ldp = 16 * sp.OT; sp.a2.stridePart = (long long)B * sp.a2.ldp;
         sp.p1 = sp.v1.plan(sp.a1, c->n_sm); sp.p2 = sp.v2.plan(sp.a2, c->n_sm);
         if (sp.p1.lds_bytes > 160 * 1024 || sp.p2.lds_bytes > 160 * 1024) return sp;
@@ -761,6 +775,8 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
         if (sk.mode == 1) {
             o.A = bs.X; o.strideA = 0;
             o.W0 = c->d_dyn + pd.dyn.w_off[0]; o.strideW0 = pd.dyn.n_params;      // row nin of the resident layout = b0 (X[nin] = 1), the rows behind it meet X's zero pad
+        } else if (sk.mode == 3) {
+            o.A = bs.HA; o.strideA = (long long)B * o.K1; o.lda = o.K1;
         } else {
             SkArgs& h = sk.a1;                               // layer 1: relu(HA W1 + b1) -> HB
             h.A = bs.HA; h.strideA = (long long)B * h.K1; h.lda = h.K1;
@@ -808,13 +824,15 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
         if (sk.mode == 1) {                                  // the whole dynamics ensemble of this step in one launch
             sk.a1.epoch = ++sk_epoch;
             HIP_TRY(c, sk.v1.launch(sk.a1, sk.p1, st));
-        } else if (sk.mode == 2) {
+        } else if (sk.mode >= 2) {
             gemm_launch(METRPO_ACT_RELU, bs.X, 0, bs.ldx, c->d_dyn + pd.dyn.w_off[0], pd.dyn.n_params, pd.dyn.dims[1], c->d_dyn + pd.dyn.b_off[0], pd.dyn.n_params,
                         bs.HA, (long long)B * pd.dyn.dims[1], pd.dyn.dims[1], B, pd.dyn.dims[1], bs.ldx, K, st);
             sk.a1.epoch = ++sk_epoch;
             HIP_TRY(c, sk.v1.launch(sk.a1, sk.p1, st));
-            sk.a2.epoch = ++sk_epoch;
-            HIP_TRY(c, sk.v2.launch(sk.a2, sk.p2, st));
+            if (sk.mode == 2) {
+                sk.a2.epoch = ++sk_epoch;
+                HIP_TRY(c, sk.v2.launch(sk.a2, sk.p2, st));
+            }
         }
         for (int l = 0; l < L && !sk.mode; ++l) {
             // layer 0 contracts over the PADDED input row (X's pad columns are 0, the weight rows they meet are the first bias entries that follow

@@ -39,9 +39,11 @@ def _rollout_vs_oracle(eng, dm, theta, pdims, pool, env, K, B, T, H, sam_mode='s
 
 
 # (env, K, hidden, B): every (input steps, output tiles) instantiation of the fused kernel -- swimmer (3, 1), hopper (4, 1), snake (5, 1),
-# half-cheetah (6, 2), ant (9, 2) -- and the three-hidden-layer form (humanoid: stored layer + (.., 4)); batches that are not multiples of 16 / 128
+# half-cheetah (6, 2), ant (9, 2) -- and the three-hidden-layer form (humanoid: stored layer + (.., 4)); batches that are not multiples of 16 / 128.
+# Below one tile per CU the forced launches cut every tile into pieces that run side by side and are added at their ends (SkArgs::late).
 SHAPES = [('swimmer', 5, (512, 512), 100), ('hopper', 3, (256, 256), 77), ('snake', 4, (256, 512), 130), ('half_cheetah', 5, (1024, 1024), 48),
-          ('ant', 10, (512, 512), 64), ('ant', 3, (512, 256), 333), ('humanoid', 4, (1024, 1024, 1024), 24), ('humanoid', 2, (256, 512, 256), 150)]
+          ('ant', 10, (512, 512), 64), ('ant', 3, (512, 256), 333), ('humanoid', 4, (1024, 1024, 1024), 24), ('humanoid', 2, (256, 512, 256), 150),
+          ('humanoid', 3, (512, 1024), 200), ('humanoid', 5, (1024, 1024), 500)]    # two hidden layers behind 76 inputs: layer 0 stored, the rest in one launch; the params file's batch (80 tiles: pieces side by side)
 
 
 @pytest.mark.parametrize('env,K,dh,B', SHAPES)
