@@ -243,6 +243,12 @@ def main():
     if args.config == 'C0p' and eng.last_rollout_kernel() == 'resident' and os.path.exists(rpath):
         traffic = json.load(open(rpath)).get('hbm_bytes_per_launch')
         traffic_src = 'profiles/r03_resident_traffic.json (rocprofv3 --pmc, offline run of the same launch; mostly the uncached step hand-over packets)'
+    spath = os.path.join(REPO, 'profiles', 'r04_streamk_traffic.json')
+    if eng.last_rollout_kernel() == 'gemm-streamk' and os.path.exists(spath):      # (the per-GPU share does not depend on --gpus: weak scaling)
+        ent = json.load(open(spath)).get(args.config)
+        if ent:                                                 # per-step bytes of the stream-K launches (the per-GPU share the file was measured at) x the steps of this rollout
+            traffic = float(ent['hbm_bytes_per_step']) * T_mean
+            traffic_src = 'profiles/r04_streamk_traffic.json (rocprofv3 --pmc, offline run of the same launches at this per-GPU share: (2 x FETCH_SIZE + WRITE_SIZE) per step x %.0f steps; algorithmic %.3g B per step)' % (T_mean, ent['algorithmic_bytes_per_step'])
     out = {
         "metric": "imagined env-steps/sec (KxBxH) over the full TRPO iteration", "value": units_per_step / (dt / args.steps),
         "unit": "env-steps/s", "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup,

@@ -59,6 +59,7 @@ struct SkArgs {
 #endif
     const int* hdr; const SkRec* recs;         // schedule: entries per workgroup | [grid][sched_cap] records (k_sk_sched)
     int RB, CB, NCk, L, tiles, sched_cap;      // row blocks of 128, column blocks of 256, chunks per tile, units per tile (chunks + epilogue weight)
+    int xcd;                                   // > 1: workgroup b is taken to run on XCD b % xcd and gets range (b % xcd) * (grid / xcd) + b / xcd of the unit sequence (below)
     int late;                                  // FEWER tiles than workgroups: the pieces of a tile run side by side from zero and are ADDED at their ends (below)
     long long units;
 };
@@ -123,7 +124,18 @@ __global__ void __launch_bounds__(512) k_sk_sched(const SkArgs a, int* __restric
     const int tid = threadIdx.x;
     const long long U = a.units;
     const int G = gridDim.x, b = blockIdx.x, NCk = a.NCk;
-    const long long u0 = U * b / G, u1 = U * (b + 1) / G;
+    // XCD-aware ranges (a.xcd = 8 on MI355X; the dispatcher deals workgroups to the XCDs round-robin): the workgroups of ONE XCD get CONSECUTIVE ranges, so
+    // the tiles that share a weight slice (same head and column block: consecutive tiles) are worked on by CUs behind the same L2 and the slice is
+    // fetched from HBM once instead of once per XCD.  The unit sequence is cut into a.xcd parts at TILE boundaries (nothing is handed over between
+    // XCD groups), each part evenly over its grid / xcd workgroups; inside a part range i belongs to workgroup i * xcd + x, so a piece is still handed
+    // to a HIGHER-numbered workgroup (blockIdx + xcd): nobody waits for a workgroup dispatched after it.
+    long long u0, u1;
+    if (a.xcd > 1) {
+        const int GP = G / a.xcd, x = b % a.xcd, i = b / a.xcd;
+        auto part = [&](int xx) -> long long { return xx >= a.xcd ? U : ((U * xx / a.xcd + a.L / 2) / a.L) * a.L; };
+        const long long s0 = part(x), s1 = part(x + 1);
+        u0 = s0 + (s1 - s0) * i / GP; u1 = s0 + (s1 - s0) * (i + 1) / GP;
+    } else { u0 = U * b / G; u1 = U * (b + 1) / G; }
     auto cut = [&](long long u, int& t, int& o) { t = (int)(u / a.L); o = (int)(u % a.L); if (o >= NCk) { ++t; o = 0; } };
     int ts, cs, te, ce;
     cut(u0, ts, cs); cut(u1, te, ce);
@@ -309,8 +321,9 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
 #endif
 
     bool export_issued = false;
+    const int prev_d = a.xcd > 1 ? a.xcd : 1;                                  // the workgroup that holds the range in front of this one
     auto wait_prev = [&]() {                                                   // the previous workgroup's export flag of this launch (bounded: report, do not hang)
-        const unsigned* fp = a.xflag + (size_t)(blockIdx.x - 1) * 8 + wave;
+        const unsigned* fp = a.xflag + (size_t)(blockIdx.x - prev_d) * 8 + wave;
         const unsigned long long t0 = wall_clock64();
         while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
             __builtin_amdgcn_s_sleep(8);
@@ -351,7 +364,7 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
             }
             if (r0.fl & SKF_IMPORT) {                                          // the previous workgroup's partial sums of this tile (exported at its start)
                 wait_prev();
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xacc + ((size_t)(blockIdx.x - 1) * 8 + wave) * 4096), 0, 16384, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xacc + ((size_t)(blockIdx.x - prev_d) * 8 + wave) * 4096), 0, 16384, 0x00020000);
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -396,7 +409,7 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
             SK_STAMP(2);
             if (r0.fl & SKF_LATE) {                                            // a.late: the running sum of the tile's earlier pieces, added to this piece's own sums
                 wait_prev();
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xacc + ((size_t)(blockIdx.x - 1) * 8 + wave) * 4096), 0, 16384, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xacc + ((size_t)(blockIdx.x - prev_d) * 8 + wave) * 4096), 0, 16384, 0x00020000);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {                                  // 16 registers at a time
                     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -520,6 +533,7 @@ static inline SkPlan sk_plan(SkArgs& a, int n_sm, int grid_override = 0) {
     a.units = (long long)a.tiles * a.L;
     SkPlan p;
     p.grid = grid_override > 0 ? grid_override : ((a.tiles < n_sm && !a.late) ? a.tiles : n_sm);
+    if (a.xcd > 1 && (a.late || p.grid % a.xcd != 0 || a.tiles < p.grid)) a.xcd = 0;      // whole XCD groups, at least a tile per workgroup
     const long long cap = a.units / p.grid + 2LL * a.L + 8;
     a.sched_cap = (int)cap;
     p.lds_bytes = (size_t)4 * GE::STAGE * sizeof(float);

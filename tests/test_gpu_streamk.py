@@ -89,6 +89,20 @@ def test_streamk_split_tiles_equal_the_oracle_and_do_not_depend_on_the_split():
     assert torch.equal(again.obs, traj.obs) and torch.equal(again.rew, traj.rew) and torch.equal(again.mean, traj.mean)
 
 
+def test_streamk_xcd_aware_ranges_are_bitwise_the_plain_split(monkeypatch):
+    """The workgroups of one XCD take consecutive ranges of the (tile, chunk) sequence (mlp_streamk.h: SkArgs::xcd; parts cut at tile boundaries): who
+    computes what changes, the k-ordered chains do not -- every tensor bit for bit the plain blockIdx-ordered split."""
+    env, K, B, T, H = 'half_cheetah', 5, 2600, 3, 3                # 5 x 21 x 4 = 420 tiles of 32 + 1 units
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (1024, 1024), (32, 32), seed=85)
+    xcd = eng.rollout(B, T, H, 'step_rand', pool, seed=3)
+    assert eng.last_rollout_kernel() == 'gemm-streamk'
+    keep = [x.clone() for x in (xcd.obs, xcd.rew, xcd.mean, xcd.done)]
+    monkeypatch.setenv('METRPO_STREAMK_NO_XCD', '1')
+    plain = eng.rollout(B, T, H, 'step_rand', pool, seed=3)
+    for a, b in zip(keep, (plain.obs, plain.rew, plain.mean, plain.done)):
+        assert torch.equal(a, b)
+
+
 def test_streamk_three_hidden_layers_split_tiles():
     env, K, B, T, H = 'humanoid', 6, 1500, 2, 2                # 6 x 12 x 4 = 288 tiles per launch
     eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (1024, 1024, 1024), (100, 50, 25), seed=83)
