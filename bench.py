@@ -124,17 +124,25 @@ def main():
     if backend == 'nccl':
         os.environ['LOCAL_RANK'] = str(dev)
     comm = metrpo_amd.Comm.init_from_env(backend)
+    preflight_rep = None
     assert comm.world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (comm.world, args.gpus)
     if comm.world > 1 and os.environ.get('METRPO_BENCH_NO_PREFLIGHT') is None:
         # first contact with a multi-GPU box made cheap (tools/multi_gpu_preflight.py): peer access, the agreed transport, exact sums, bit-identical
         # theta after one sharded update -- on stderr, before anything is timed; a failure ends the run with its reason instead of a hang or a wrong number
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools'))
         from multi_gpu_preflight import preflight
-        ok, _rep = preflight(comm.world, comm.rank, dev, latency_table=False, out=lambda *a: print(*a, file=sys.stderr, flush=True))
+        try:
+            ok, preflight_rep = preflight(comm.world, comm.rank, dev, latency_table=False, out=lambda *a: print(*a, file=sys.stderr, flush=True))
+        except Exception as e:                                   # the check itself must not cost the run its number
+            ok, preflight_rep = False, {'reason': 'preflight raised %s: %s' % (type(e).__name__, e)}
         okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=('cuda' if backend == 'nccl' else 'cpu'))
         torch.distributed.all_reduce(okt, op=torch.distributed.ReduceOp.MIN)
-        if int(okt.item()) != 1:
-            sys.exit(3)
+        preflight_rep['ok'] = bool(int(okt.item()) == 1)
+        if not preflight_rep['ok']:
+            print('[bench rank %d] multi-GPU preflight FAILED on some rank (%s): the line below carries "preflight": {"ok": false}; '
+                  'METRPO_BENCH_STRICT_PREFLIGHT=1 makes this fatal' % (comm.rank, preflight_rep.get('reason', 'another rank')), file=sys.stderr, flush=True)
+            if os.environ.get('METRPO_BENCH_STRICT_PREFLIGHT') is not None:
+                sys.exit(3)
 
     cfg = synthetic.CONFIGS[args.config]
     env, K, H = cfg['env'], cfg['K'], cfg['H']
@@ -262,6 +270,7 @@ def main():
                                % (args.config, env, K, list(cfg['dyn_hidden']), list(cfg['pol_hidden']), B, cfg['B'], cfg['gpus'], H, T_mean, int(bool(algo.device_baseline_fit)), int(bool(algo.async_line_search))),
                    "parallelism": "B-sharded x%d, sum all-reduce of g/FVP/scalars" % comm.world},
         "trpo_iter_ms": ms_per_step,
+        "preflight": preflight_rep,
         "rollout": {"ms": roll_ms, "env_steps_per_s": units_per_step / (roll_ms * 1e-3),
                     "kernel": eng.last_rollout_kernel() or {3: "gemm-stepwise", 2: "mfma-cooperative", 1: "mfma-head-per-wave", 0: "generic"}[variant]},
         "roofline": {"bound": "mfma", "kernel": "rollout", "achieved": achieved, "peak": PEAK_F32, "unit": "TFLOP/s",

@@ -21,8 +21,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def _fail(rank, msg):
-    print('[preflight rank %d] FAIL: %s' % (rank, msg), flush=True)
+def _fail(rank, msg, rep=None):
+    print('[preflight rank %d] FAIL: %s' % (rank, msg), file=sys.stderr, flush=True)
+    if rep is not None:
+        rep['reason'] = msg
     return False
 
 
@@ -50,13 +52,13 @@ def preflight(world, rank, device_index, latency_table=True, out=print):
         eng.set_exclusive(False)                             # ranks share devices: no kernel whose workgroups wait on each other inside one launch
     comm = metrpo_amd.Comm()
     if comm.world != world:
-        return _fail(rank, 'torch.distributed world size %d != %d' % (comm.world, world)), rep
+        return _fail(rank, 'torch.distributed world size %d != %d' % (comm.world, world), rep), rep
     transport = comm.attach_engine(eng, transport=os.environ.get('METRPO_COMM', 'auto')) or 'torch.distributed callback'
     names = [None] * world
     dist.all_gather_object(names, transport)
     rep['transport'] = transport
     if len(set(names)) != 1:
-        return _fail(rank, 'ranks disagree on the transport: %s' % names), rep
+        return _fail(rank, 'ranks disagree on the transport: %s' % names, rep), rep
     say('[preflight] transport agreed on by all ranks: %s%s' % (transport, '' if transport == 'one-shot' else
                                                                  ' (one-shot unavailable: %s)' % getattr(comm, 'one_shot_error', 'not attempted')))
     # 3. exchange correctness: rank r contributes (r + 1) * [1 .. n]
@@ -66,7 +68,7 @@ def preflight(world, rank, device_index, latency_table=True, out=print):
         comm.allreduce_sum_(buf)
         torch.cuda.synchronize()
         if not torch.equal(buf, ramp * (world * (world + 1) // 2)):
-            return _fail(rank, 'all-reduce of %d float64 returned a wrong sum' % n), rep
+            return _fail(rank, 'all-reduce of %d float64 returned a wrong sum' % n, rep), rep
     if transport == 'one-shot':
         eng.comm_check()
     say('[preflight] all-reduce sums exact for 2 / %d / 12493 float64 on every rank' % (eng.P + 1))
@@ -104,7 +106,7 @@ def preflight(world, rank, device_index, latency_table=True, out=print):
     rep['theta_identical'] = same
     if not same:
         return _fail(rank, 'theta differs between ranks after one sharded update (max |diff| %.3e)'
-                     % max(float((all_theta[0] - t).abs().max()) for t in all_theta)), rep
+                     % max(float((all_theta[0] - t).abs().max()) for t in all_theta), rep), rep
     say('[preflight] sharded TRPO update: accepted=%s, kl=%.3e, theta bit-identical on all %d ranks' % (bool(res['accepted']), res['kl'], world))
     if transport == 'one-shot':
         eng.comm_ipc_detach()
