@@ -90,6 +90,13 @@ __global__ void k_big_pre(ProblemDesc pd, RolloutK r, int t, const float* __rest
 // chain below reads.  One launch per step instead of two between the ensemble kernels: k_big_post(t - 1) + this kernel's own launch and
 // its reload of the state cost ~17 us of a 150 us step at the C3 share.  Same arithmetic in the same order as k_big_post: trajectories are
 // bit for bit those of the two-launch sequence (tests/test_gpu_streamk.py).
+#ifdef PP_TIMING        // developer instrumentation (SRC=rollout_gemm.hip tools/build_variant.sh pptiming -DPP_TIMING): shader-clock phases of workgroup 0, wave 0 of the merged launch
+__device__ unsigned long long g_pp_phase[8];
+#define PP_MARK(i) { if (POST && blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); g_pp_phase[i] += n_ - pp_t; pp_t = n_; } }
+extern "C" int32_t metrpo_debug_pp_phases(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp_phase), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -1; }
+#else
+#define PP_MARK(i)
+#endif
 template <int ENV, bool POST>
 __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r, int t, const float* __restrict__ theta,
                                                       const float* __restrict__ norm, BigState st) {
@@ -103,9 +110,14 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
     const bool active = b < r.B;
     float* ST = lds + IMG + wave * 16 * NS;
     if (r.stop != nullptr && *r.stop != 0) return;               // the sampling loop already ended (metrpo_sampler_progress)
-    {   // weight image: all gathers of a thread are issued before the first LDS store (one L2 round trip, not one per element)
-        constexpr int NIT = (IMG + 255) / 256;
-        float wv[NIT];
+#ifdef PP_TIMING
+    unsigned long long pp_t = __builtin_readcyclecounter();
+#endif
+    // weight image: all gathers of a thread are issued before the first LDS store (one L2 round trip, not one per element) -- and the stores wait until
+    // step t - 1 has been closed below: the gathers' round trip passes behind the post part's own loads instead of in front of them
+    constexpr int NIT = (IMG + 255) / 256;
+    float wv[NIT];
+    {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = tid + 256 * it;
@@ -119,8 +131,6 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
             else if (i < IMG) { const int d = i - O_B2; if (d < NA) w = theta[C::pb2 + d]; }
             wv[it] = w;
         }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) { const int i = tid + 256 * it; if (i < IMG) lds[i] = wv[it]; }
     }
     const uint64_t genv = r.stream_offset + (uint64_t)RK_ENV(r, b);
     const int tt = t + RK_TOFF(r, b);                            // row of the trajectory tensors / draw counter of this env's step
@@ -134,8 +144,28 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
         st.ts[b] = 0;
         for (int i = 0; i < NS; ++i) st.S[(size_t)b * NS + i] = r.pool[(size_t)row * NS + i];
     }
-    __syncthreads();                                             // image complete; the reset rows of this tile are written by its own wave
+    if constexpr (!POST) { __builtin_amdgcn_s_waitcnt(0x0F70); wave_lds_sync(); }      // t == 0: the reset rows of this tile were written by lanes of its own wave and are read back below
     const int lim = min(16, max(0, r.B - b0)) * NS;
+    // Everything the END of this launch needs that depends on nothing computed here goes out NOW, with the loads of the post part: the normaliser
+    // rows and log_std of this lane's dims (L2 hits, but a round trip of their own when first touched behind the policy chain) and the action
+    // noise of step t (Philox + Box-Muller: ~150 vector instructions that run while the loads are under way).  Same values, same arithmetic.
+    const float* in_mean = norm; const float* in_std = norm + (NS + NA);
+    const float* __restrict__ log_std = theta + C::pLS;
+    constexpr int NSQ = (NS + 3) / 4;
+    float smn[NSQ], ssd[NSQ], amn[4], asd[4], lsd[4], zn[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NSQ; ++j) { const int i = min(q + 4 * j, NS - 1); smn[j] = in_mean[i]; ssd[j] = in_std[i]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int d = min(4 * q + j, NA - 1); amn[j] = in_mean[NS + d]; asd[j] = in_std[NS + d]; lsd[j] = log_std[d]; }
+    if (!r.determ && r.eps == nullptr) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int d0 = 4 * q + 2 * h;
+            if (d0 >= NA) continue;
+            const uint4 blk = rng_draw(r.seed, genv, r.t0 + tt, RNG_STEP, d0 >> 1);
+            normal2(blk.x, blk.y, zn[2 * h], zn[2 * h + 1]);
+        }
+    }
     if constexpr (POST) {
         // ---- close step t - 1 (k_big_post) for this wave's 16 envs ----
         const int bc = active ? b : max(r.B - 1, 0);
@@ -148,8 +178,10 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
         if (r.sam_mode == METRPO_SAM_STEP_RAND) sel = (r.model_idx != nullptr) ? r.model_idx[tbp] : rng_index(dstep.z, K);
         if (r.sam_mode == METRPO_SAM_ONE_MODEL) sel = 0;
         const bool simple = (r.sam_mode == METRPO_SAM_STEP_RAND || r.sam_mode == METRPO_SAM_EPS_RAND || r.sam_mode == METRPO_SAM_ONE_MODEL);
-        float su2 = 0.0f;                                        // sum of squared clipped actions in action order (every lane of the env, redundantly)
-        for (int d = 0; d < NA; ++d) { const float a_ = st.U[(size_t)bc * NA + d]; su2 = fmaf(a_, a_, su2); }
+        float ua_[NA];                                           // clipped actions of step t - 1 (summed below, behind the loads of the output partials: one round trip for both)
+#pragma unroll
+        for (int d = 0; d < NA; ++d) ua_[d] = st.U[(size_t)bc * NA + d];
+        PP_MARK(4)
         float vnew[2][4];
         bool finl = true;
 #pragma unroll
@@ -223,6 +255,10 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) if (i0 + rr < NS) { vnew[hh][rr] = v4[rr]; finl = finl && isfinite(v4[rr]); ST[c * NS + i0 + rr] = v4[rr]; }
         }
+        float su2 = 0.0f;                                        // sum of squared clipped actions in action order (every lane of the env, redundantly)
+#pragma unroll
+        for (int d = 0; d < NA; ++d) su2 = fmaf(ua_[d], ua_[d], su2);
+        PP_MARK(5)
         int fin = finl ? 1 : 0;                                  // all-finite over the env's dims: the env's four lanes are c, c + 16, c + 32, c + 48
         fin &= __shfl_xor(fin, 16, 64); fin &= __shfl_xor(fin, 32, 64);
         wave_lds_sync();
@@ -243,6 +279,7 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
         bool dn = (ENV == METRPO_ENV_ANT) ? !((zc >= 0.2f) && (zc <= 1.0f) && (fin != 0)) : false;
         dn = dn || (ts >= r.H);
         int cur = st.cur_model[bc];
+        PP_MARK(6)
         if (active && q == 0) { r.rew[tbp] = -cost; r.done[tbp] = dn ? 1 : 0; r.tpath[tbp] = ts - 1; }
         wave_lds_sync();                                         // every lane has read its env's scalars: the reset rows may overwrite the tile
         if (dn) {                                                // uniform over the env's four lanes
@@ -271,6 +308,7 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
         for (int i = lane; i < 16 * NS; i += 64) ST[i] = (i < lim) ? st.S[(size_t)b0 * NS + i] : 0.0f;
     }
     wave_lds_sync();
+    PP_MARK(0)
     if (lim > 0) {
         if (r.vB == 0) { const size_t base = ((size_t)t * r.B + b0) * NS; for (int i = lane; i < lim; i += 64) r.obs[base + i] = ST[i]; }
         else for (int i = lane; i < lim; i += 64) {              // merged rounds: a tile's envs may belong to two rounds
@@ -278,6 +316,10 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
             r.obs[((size_t)(t + RK_TOFF(r, bi)) * r.vB + RK_ENV(r, bi)) * NS + i % NS] = ST[i];
         }
     }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) { const int i = tid + 256 * it; if (i < IMG) lds[i] = wv[it]; }
+    __syncthreads();                                             // image complete
+    PP_MARK(1)
     f32x4 p0[2], p1[2];
     p0[0] = *(const f32x4*)&lds[O_B0 + 4 * q]; p0[1] = *(const f32x4*)&lds[O_B0 + 16 + 4 * q];
 #pragma unroll
@@ -309,35 +351,34 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
     }
     const f32x4 mu = m0 + m1;
     if (!active) return;
+    PP_MARK(2)
     const size_t tb = (size_t)tt * RK_STRIDE(r) + RK_ENV(r, b);
-    const float* in_mean = norm; const float* in_std = norm + (NS + NA);
-    const float* __restrict__ log_std = theta + C::pLS;
-    // state part of the normalised, dropped input: lane (c, q) writes its dims 4q .. (every 16th column block)
-    for (int i = q; i < NS; i += 4) if (i >= NDROP) st.X[(size_t)b * st.ldx + i - NDROP] = (ST[c * NS + i] - in_mean[i]) / in_std[i];     // training.py:228,146-151
+    // state part of the normalised, dropped input: lane (c, q) writes its dims q, q + 4, ...
+#pragma unroll
+    for (int j = 0; j < NSQ; ++j) { const int i = q + 4 * j; if (i < NS && i >= NDROP) st.X[(size_t)b * st.ldx + i - NDROP] = (ST[c * NS + i] - smn[j]) / ssd[j]; }     // training.py:228,146-151
     if (q == 0) for (int j = C::NIN; j < st.ldx; ++j) st.X[(size_t)b * st.ldx + j] = (st.xone && j == C::NIN) ? 1.0f : 0.0f;   // pad columns of the 16-byte aligned rows (layer 0 contracts over ldx)
     // action dims 4q .. 4q+3 of this lane = Philox chunks 2q, 2q+1 (chunk 0 = the step block), exactly as k_big_pre
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int d0 = 4 * q + 2 * h;
         if (d0 >= NA) continue;
-        float z[2] = {0.f, 0.f};
-        if (!r.determ && r.eps == nullptr) {
-            const uint4 blk = rng_draw(r.seed, genv, r.t0 + tt, RNG_STEP, d0 >> 1);
-            normal2(blk.x, blk.y, z[0], z[1]);
-        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int d = d0 + j;
             if (d >= NA) continue;
             const float m = mu[2 * h + j];
             float a = m;
-            if (!r.determ) a = fmaf((r.eps != nullptr) ? r.eps[tb * NA + d] : z[j], __expf(fmaxf(log_std[d], LOG_MIN_STD)), m);
+            if (!r.determ) a = fmaf((r.eps != nullptr) ? r.eps[tb * NA + d] : zn[2 * h + j], __expf(fmaxf(lsd[2 * h + j], LOG_MIN_STD)), m);
             r.act[tb * NA + d] = a; r.mean[tb * NA + d] = m;
             const float ac = fminf(fmaxf(a, -1.0f), 1.0f);          // env_helpers.py:599
             st.U[(size_t)b * NA + d] = ac;
-            st.X[(size_t)b * st.ldx + (NS - NDROP) + d] = (ac - in_mean[NS + d]) / in_std[NS + d];
+            st.X[(size_t)b * st.ldx + (NS - NDROP) + d] = (ac - amn[2 * h + j]) / asd[2 * h + j];
         }
     }
+#ifdef PP_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    PP_MARK(3)
 }
 
 // MFMA pre-kernel for tanh policies with THREE hidden layers (Humanoid's 100-50-25, params-humanoid.json): the same transposed chain as
