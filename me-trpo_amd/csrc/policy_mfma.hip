@@ -70,6 +70,11 @@ __device__ __forceinline__ float xsum_c(float v) {
 }
 
 enum { MODE_GRAD = 0, MODE_FVP = 1, MODE_LOSSKL = 2, MODE_FVPC = 3 };
+// POL_PRIO (experiment, round 4): issue priorities of the two waves of a SIMD.  1: the younger wave of every SIMD (waves 4 .. 7) runs at priority 1 for the whole
+// kernel; 2: a wave raises its priority for the vector-ALU stretch of a tile (S4 / S5: output layer, tanh' factors, deltas) and drops it for the matrix runs.
+#ifndef POL_PRIO
+#define POL_PRIO 0
+#endif
 // POL_H0R = 1 (experiment, round 4): MODE_FVPC reads only h1 from the cache and recomputes h0 (one layer: NS_KS x HB MFMAs + 4 HB tanh per lane): -128 of
 // 302 B per sample from HBM, +8 % MFMAs.  Measured SLOWER at C1 (tools/variant_update.py h0r, twice: update 0.846 vs 0.798 ms = +4.8 us per
 // product): the product is bound by its dependent issue chain, not by HBM; the extra layer + tanh at the head of every tile's chain costs more than the bytes.
@@ -111,6 +116,8 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index in an SGPR: tile indices and base pointers stay scalar
     const int c = lane & 15, q = lane >> 4;
+    if (POL_PRIO == 1 && wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(1);
+    if (POL_PRIO == 3 && wave < NWAVES / 2) __builtin_amdgcn_s_setprio(1);
     if (MODE_ == MODE_LOSSKL && k.skip != nullptr && k.skip[0] >= 0.0) return;      // speculative line-search trial after the search stopped
     float* IMG = lds;
     float* TL = lds + I::TOTAL + wave * WTL;
@@ -316,6 +323,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
     for (long long m = (SPL && wave >= 4) ? 1 : 0, tile = sp_base + m * sp_stride; tile < ntiles; m = sp_next(m), tile = sp_base + m * sp_stride) {
         const long long n0 = tile * 16, n = n0 + c;
         const bool inr = n < k.N;
+        if (POL_PRIO == 2) __builtin_amdgcn_s_setprio(0);
         TileIn in = nxt;
         fetch(sp_base + sp_next(m) * sp_stride, nxt);
         asm volatile("" ::: "memory");                      // the loads are issued HERE (left alone, the compiler sinks them to the end of the iteration)
@@ -396,6 +404,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
             for (int cb = 0; cb < HB; ++cb) { hw[cb * 64] = h0[cb]; hw[(HB + cb) * 64] = h1[cb]; }
         }
 
+        if (POL_PRIO == 2) __builtin_amdgcn_s_setprio(2);
         f32x4 um = Z4;                                      // d(objective)/d(mean) in D layout [d = 4q+r][sample c]
         float ual[NAV];                                     // FVP with the VALU output layer: the sample's mean-adjoint, already in all of its lanes
 #pragma unroll
@@ -545,6 +554,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const fl
 #pragma unroll
             for (int r = 0; r < 4; ++r) { d1[cb][r] *= fmaf(-h1[cb][r], h1[cb][r], 1.f); T_D1[cb * TILE + (4 * q + r) * TS + wpos] = d1[cb][r]; }
         }
+        if (POL_PRIO == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
