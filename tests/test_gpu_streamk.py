@@ -103,6 +103,33 @@ def test_streamk_xcd_aware_ranges_are_bitwise_the_plain_split(monkeypatch):
         assert torch.equal(a, b)
 
 
+def test_streamk_random_shapes_equal_the_tile_gemms(monkeypatch):
+    """Shapes nobody tuned for: head counts, batches and layer widths drawn at random (>= one tile per CU, so the path is chosen by itself; tile counts that
+    are not multiples of the 8 XCD parts, ragged last row blocks, 1-3 column blocks, contraction lengths from 128 to 1024) -- stream-K against the tile
+    GEMMs on the same draws, two steps free-running."""
+    rs = np.random.RandomState(4321)
+    envs = ['swimmer', 'half_cheetah', 'ant', 'hopper', 'snake']
+    for case in range(8):
+        env = envs[case % len(envs)]
+        n1 = int(rs.choice([256, 512, 768])); k1 = int(rs.choice([128, 160, 256, 352, 512, 1024]))
+        K = int(rs.randint(2, 8))
+        tiles_per_row_block = K * (n1 // 256)
+        B = 128 * int(np.ceil(300.0 / tiles_per_row_block)) + int(rs.randint(1, 128))          # > 256 tiles, ragged last row block
+        eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (k1, n1), (32, 32), seed=500 + case)
+        msg = str((case, env, K, (k1, n1), B))
+        sk = eng.rollout(B, 2, 2, 'step_rand', pool, seed=case)
+        assert eng.last_rollout_kernel() == 'gemm-streamk', msg
+        keep = [x.clone() for x in (sk.obs, sk.rew, sk.mean, sk.done)]
+        monkeypatch.setenv('METRPO_NO_STREAMK', '1')
+        tile = eng.rollout(B, 2, 2, 'step_rand', pool, seed=case)
+        monkeypatch.delenv('METRPO_NO_STREAMK')
+        assert eng.last_rollout_kernel() == 'gemm-stepwise', msg
+        assert torch.equal(keep[3], tile.done), msg
+        for a, b in zip(keep[:3], (tile.obs, tile.rew, tile.mean)):
+            np.testing.assert_allclose(cpu(a), cpu(b), **TOL.CROSS_KERNEL, err_msg=msg)
+        del eng
+
+
 def test_streamk_three_hidden_layers_split_tiles():
     env, K, B, T, H = 'humanoid', 6, 1500, 2, 2                # 6 x 12 x 4 = 288 tiles per launch
     eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (1024, 1024, 1024), (100, 50, 25), seed=83)
