@@ -257,6 +257,18 @@ def main():
         if ent:                                                 # per-step bytes of the stream-K launches (the per-GPU share the file was measured at) x the steps of this rollout
             traffic = float(ent['hbm_bytes_per_step']) * T_mean
             traffic_src = 'profiles/r04_streamk_traffic.json (rocprofv3 --pmc, offline run of the same launches at this per-GPU share: (2 x FETCH_SIZE + WRITE_SIZE) per step x %.0f steps; algorithmic %.3g B per step)' % (T_mean, ent['algorithmic_bytes_per_step'])
+    # what bounds the rollout when it is not the matrix pipe: a 16-env tile is a chain of T dependent steps, and with fewer tiles than CUs the chip is not filled
+    n_tiles = (B + 15) // 16
+    kern = eng.last_rollout_kernel() or ''
+    if 'cooperative' in kern or variant == 2:
+        note = ('one launch; a 16-env tile is a chain of %d dependent steps (3.6 us each at 2x64), %d tiles on 256 CUs' % (int(T_mean), n_tiles)
+                + (': chain-latency-bound by construction, the fraction of the matrix peak says nothing about the kernel here' if n_tiles < 200 else ''))
+    elif kern == 'resident':
+        note = 'one launch for the whole time loop, weights register-resident; bound by matrix-instruction issue of the compute workgroups + the step hand-over latency (B = %d: %d env tiles per round)' % (B, n_tiles)
+    elif kern == 'gemm-streamk':
+        note = 'per step: one stream-K launch for the K-head forward (two for three hidden layers) + one pre/post launch; f32 MFMA issue bound'
+    else:
+        note = 'step-wise tile GEMMs: %d rows per head and step (fewer tiles than CUs: launch-chain latency bound)' % B
     out = {
         "metric": "imagined env-steps/sec (KxBxH) over the full TRPO iteration", "value": units_per_step / (dt / args.steps),
         "unit": "env-steps/s", "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup,
@@ -274,7 +286,7 @@ def main():
         "rollout": {"ms": roll_ms, "env_steps_per_s": units_per_step / (roll_ms * 1e-3),
                     "kernel": eng.last_rollout_kernel() or {3: "gemm-stepwise", 2: "mfma-cooperative", 1: "mfma-head-per-wave", 0: "generic"}[variant]},
         "roofline": {"bound": "mfma", "kernel": "rollout", "achieved": achieved, "peak": PEAK_F32, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_F32, "traffic": traffic, "traffic_source": traffic_src,
+                     "frac": achieved / PEAK_F32, "note": note, "traffic": traffic, "traffic_source": traffic_src,
                      "hbm_frac_unfused_88B": (K * B * T_mean * (2 * ns + na) * 4) / (roll_ms * 1e-3) / PEAK_HBM,
                      "update": {"kernel": "policy update (1 gradient + %d Fisher-vector products + %d line-search evaluations, N=%d)"
                                           % (n_hvp, n_ls, int(N_local)),
