@@ -35,6 +35,7 @@
 // k = 16 j + e + {0, 4, 8, 12} in that order (the four lane groups of the matrix instruction) -- fixed, independent of grid and split.
 #pragma once
 #include <type_traits>
+#include <algorithm>
 #include "mfma_common.h"
 
 enum { SK_A_GLOBAL = 0, SK_A_PRODUCER = 1 };      // main layer's input: activations [M][K1] in HBM | computed from x by layer 0 on the fly
@@ -561,5 +562,80 @@ static inline hipError_t sk_launch(const SkArgs& a, const SkPlan& p, hipStream_t
         attr_set = p.lds_bytes;
     }
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(512), p.lds_bytes, st, a);
+    return hipGetLastError();
+}
+
+// ---- layer 0 of a net whose first hidden layer is STORED (three hidden layers; two behind an input too wide for the producer) -----------------------
+// relu(x W0 + b0) for all heads: a contraction of only n_in + 1 <= 4 S0 values per output, so the tile GEMM spends its time in prologues and epilogues
+// (C4 share: 259 us per step for 20 GFLOP).  Here a workgroup keeps its 256-column slice of W0 (bias as one more input row, x[n_in] = 1) in LDS as srcA
+// fragments for the whole launch and walks its share of the rows: a wave = 16 rows, x in S0 registers (the next 16 rows' loads under way), per group
+// of 64 columns all S0 operand reads (one ds_read_b128 feeds four matrix instructions), then 4 S0 matrix instructions, then four 16-byte stores.
+// Same transposed form and k order as the producer of k_mlp_sk.
+struct L0Args { int M, heads, N, ldx, rows_per_wg, nsplit; const float* x; const float* W0; long long strideW0; float* C; long long strideC; };
+template <int S0>
+__global__ void __launch_bounds__(512) k_l0_rows(const L0Args a) {
+    extern __shared__ __attribute__((aligned(16))) float img[];               // [s][jq][lane][u]: W0[4 s + g][col0 + 16 (4 jq + u) + i], lane = 16 g + i
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int CQ = a.N / 256;
+    // the CQ workgroups that write the column slices of the SAME rows are neighbours in the grid: dispatched together, they walk the rows in step
+    const int cq = blockIdx.x % CQ, sp = (blockIdx.x / CQ) % a.nsplit, head = blockIdx.x / (a.nsplit * CQ);
+    const float* __restrict__ W = a.W0 + (size_t)head * a.strideW0 + cq * 256;
+    for (int idx = tid; idx < S0 * 1024; idx += 512) {
+        const int u = idx & 3, ln = (idx >> 2) & 63, jq = (idx >> 8) & 3, s = idx >> 10;
+        img[idx] = W[(size_t)(4 * s + (ln >> 4)) * a.N + 16 * (4 * jq + u) + (ln & 15)];
+    }
+    __syncthreads();
+    const int r1 = min(a.M, (sp + 1) * a.rows_per_wg);
+    float* __restrict__ Ch = a.C + (size_t)head * a.strideC + cq * 256 + 4 * g;
+    float xr[S0], xn[S0];
+    auto load_x = [&](int m0_, float (&dst)[S0]) {
+        const float* __restrict__ xp = a.x + (size_t)min(m0_ + i, a.M - 1) * a.ldx + g;
+#pragma unroll
+        for (int s = 0; s < S0; ++s) dst[s] = xp[4 * s];
+    };
+    int m0 = sp * a.rows_per_wg + wave * 16;
+    if (m0 < r1) load_x(m0, xn);
+    for (; m0 < r1; m0 += 128) {
+#pragma unroll
+        for (int s = 0; s < S0; ++s) xr[s] = xn[s];
+        if (m0 + 128 < r1) load_x(m0 + 128, xn);                               // the next 16 rows are under way while these are multiplied
+        const int row = min(m0 + i, a.M - 1);
+#pragma unroll
+        for (int jq = 0; jq < 4; ++jq) {
+            // all S0 operand reads of this column group first (hipcc otherwise sinks each read to its use: read, wait the LDS latency, four
+            // instructions, read ...), then the run of 4 S0 matrix instructions, waiting only for the operand each step needs
+            f32x4 w[S0];
+#pragma unroll
+            for (int s = 0; s < S0; ++s) w[s] = *(const f32x4*)&img[((s * 4 + jq) * 64 + lane) * 4];
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) d[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < S0; ++s)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) d[u] = MFMA16(w[s][u], xr[s], d[u]);
+            if (m0 + i < a.M) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    f32x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = relu1(d[u][r]);
+                    *(f32x4*)(Ch + (size_t)row * a.N + 16 * (4 * jq + u)) = o;
+                }
+            }
+        }
+    }
+}
+template <int S0> static inline hipError_t l0_rows_launch(L0Args a, int n_cu, hipStream_t st) {
+    const int pairs = a.heads * (a.N / 256), rb = (a.M + 127) / 128;
+    a.nsplit = std::max(1, std::min(rb, n_cu / std::max(1, pairs)));           // whole (head, column slice) pairs per CU round; at least 128 rows per workgroup
+    a.rows_per_wg = ((rb + a.nsplit - 1) / a.nsplit) * 128;
+    const size_t lds = (size_t)S0 * 1024 * sizeof(float);
+    auto kern = k_l0_rows<S0>;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) { const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; attr_set = true; }
+    hipLaunchKernelGGL(kern, dim3(pairs * a.nsplit), dim3(512), lds, st, a);
     return hipGetLastError();
 }

@@ -673,6 +673,19 @@ static bool sk_out_vt(int OT, SkVt* v) {
     if (OT == 4) { *v = sk_vt<SK_A_GLOBAL, SK_EPI_OUT, 1, 4>(); return true; }
     return false;
 }
+// layer 0 of the stored-layer-0 forms (modes 2, 3) on k_l0_rows: the input widths of the six envs
+static bool l0_rows(int S0, const L0Args& a, int n_cu, hipStream_t st, hipError_t* e) {
+    switch (S0) {
+    case 3: *e = l0_rows_launch<3>(a, n_cu, st); return true;
+    case 4: *e = l0_rows_launch<4>(a, n_cu, st); return true;
+    case 5: *e = l0_rows_launch<5>(a, n_cu, st); return true;
+    case 6: *e = l0_rows_launch<6>(a, n_cu, st); return true;
+    case 10: *e = l0_rows_launch<10>(a, n_cu, st); return true;
+    case 20: *e = l0_rows_launch<20>(a, n_cu, st); return true;
+    default: return false;
+    }
+}
+static bool l0_rows_ok(int S0) { return S0 == 3 || S0 == 4 || S0 == 5 || S0 == 6 || S0 == 10 || S0 == 20; }
 static void sk_epi_image(int OT, const float* b1, long long sB1, const float* W2, long long sW2, int no, int N, int heads, float* img, hipStream_t st) {
     const long long per = (OT == 1) ? SkEpi<1>::FLOATS * SkEpi<1>::E : (OT == 2) ? SkEpi<2>::FLOATS * SkEpi<2>::E : SkEpi<4>::FLOATS * SkEpi<4>::E;
     const long long tot = (long long)heads * (N / 256) * per;
@@ -760,7 +773,11 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
     // workspace (floats): S, X, U, HA, HB, OUT + ints ts, cur_model
     auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };       // keep every sub-buffer 16-byte aligned
     SkPath sk = sk_select(c, B);
-    const int ldx = (sk.mode == 1) ? 4 * sk.S0 : ((pd.nin + 3) & ~3);
+    // stored layer 0 (modes 2, 3) by k_l0_rows: the bias rides as input row n_in, as for the producer of mode 1 (METRPO_NO_L0_ROWS: the tile GEMM)
+    const int S0all = (pd.nin + 1 + 3) / 4;
+    const bool l0r = sk.mode >= 2 && l0_rows_ok(S0all) && pd.dyn.dims[1] % 256 == 0 && pd.dyn.act[0] == METRPO_ACT_RELU &&
+                     pd.dyn.b_off[0] == pd.dyn.w_off[0] + pd.nin * pd.dyn.dims[1] && getenv("METRPO_NO_L0_ROWS") == nullptr;
+    const int ldx = (sk.mode == 1) ? 4 * sk.S0 : (l0r ? 4 * S0all : ((pd.nin + 3) & ~3));
     const size_t nS = up4((size_t)B * pd.ns), nX = up4((size_t)B * ldx), nU = up4((size_t)B * pd.na), nH = (sk.mode == 1) ? 0 : up4((size_t)K * B * maxh), nO = up4((size_t)K * B * pd.ns);
     size_t nP = 0;
     for (int l = 0; l < L; ++l) nP = std::max(nP, up4(skinny_part_floats(B, pd.dyn.dims[l + 1], pd.dyn.dims[l], K)));
@@ -804,7 +821,7 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
     float* sk_xacc = p; p += nSkX;
     unsigned* sk_flag = (unsigned*)p; p += nSkFlag;
     bs.ts = (int*)p; bs.cur_model = bs.ts + B;
-    bs.out_ld = pd.ns; bs.xone = (sk.mode == 1) ? 1 : 0;
+    bs.out_ld = pd.ns; bs.xone = (sk.mode == 1 || l0r) ? 1 : 0;
     if (sk.mode) c->last_rollout_kernel = 5;
     unsigned sk_epoch = 0;                                   // flags are zeroed below; every launch of this chain takes the next epoch
     if (sk.mode) {
@@ -867,6 +884,14 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
             sk.a1.epoch = ++sk_epoch;
             HIP_TRY(c, sk.v1.launch(sk.a1, sk.p1, st));
         } else if (sk.mode >= 2) {
+            if (l0r) {
+                L0Args la = {};
+                la.M = B; la.heads = K; la.N = pd.dyn.dims[1]; la.ldx = bs.ldx; la.x = bs.X; la.W0 = c->d_dyn + pd.dyn.w_off[0]; la.strideW0 = pd.dyn.n_params;
+                la.C = bs.HA; la.strideC = (long long)B * pd.dyn.dims[1];
+                hipError_t e = hipSuccess;
+                (void)l0_rows(S0all, la, c->n_sm, st, &e);
+                HIP_TRY(c, e);
+            } else
             gemm_launch(METRPO_ACT_RELU, bs.X, 0, bs.ldx, c->d_dyn + pd.dyn.w_off[0], pd.dyn.n_params, pd.dyn.dims[1], c->d_dyn + pd.dyn.b_off[0], pd.dyn.n_params,
                         bs.HA, (long long)B * pd.dyn.dims[1], pd.dyn.dims[1], B, pd.dyn.dims[1], bs.ldx, K, st);
             sk.a1.epoch = ++sk_epoch;
