@@ -568,9 +568,10 @@ static inline hipError_t sk_launch(const SkArgs& a, const SkPlan& p, hipStream_t
 // ---- layer 0 of a net whose first hidden layer is STORED (three hidden layers; two behind an input too wide for the producer) -----------------------
 // relu(x W0 + b0) for all heads: a contraction of only n_in + 1 <= 4 S0 values per output, so the tile GEMM spends its time in prologues and epilogues
 // (C4 share: 259 us per step for 20 GFLOP).  Here a workgroup keeps its 256-column slice of W0 (bias as one more input row, x[n_in] = 1) in LDS as srcA
-// fragments for the whole launch and walks its share of the rows: a wave = 16 rows, x in S0 registers (the next 16 rows' loads under way), per group
-// of 64 columns all S0 operand reads (one ds_read_b128 feeds four matrix instructions), then 4 S0 matrix instructions, then four 16-byte stores.
-// Same transposed form and k order as the producer of k_mlp_sk.
+// fragments for the whole launch and walks its share of the rows: a wave = 16 rows, x in S0 registers (the next 16 rows' loads under way), 64 S0 matrix
+// instructions per 16 rows x 256 columns fed by S0 registers of operands that are re-read a whole column group ahead (one ds_read_b128 feeds four
+// instructions), the tile's sixteen 16-byte stores issued together behind the wait for the next rows.  Same transposed form and k order as the producer
+// of k_mlp_sk.  C4 share (20 heads x 6250 rows, 76 + 1 inputs -> 1024): 205 us (tile GEMM: 258 us).
 struct L0Args { int M, heads, N, ldx, rows_per_wg, nsplit; const float* x; const float* W0; long long strideW0; float* C; long long strideC; };
 template <int S0>
 __global__ void __launch_bounds__(512) k_l0_rows(const L0Args a) {
@@ -578,8 +579,7 @@ __global__ void __launch_bounds__(512) k_l0_rows(const L0Args a) {
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int CQ = a.N / 256;
-    // the CQ workgroups that write the column slices of the SAME rows are neighbours in the grid: dispatched together, they walk the rows in step
-    const int cq = blockIdx.x % CQ, sp = (blockIdx.x / CQ) % a.nsplit, head = blockIdx.x / (a.nsplit * CQ);
+    const int sp = blockIdx.x % a.nsplit, cq = (blockIdx.x / a.nsplit) % CQ, head = blockIdx.x / (a.nsplit * CQ);      // (other orders of the grid measured the same)
     const float* __restrict__ W = a.W0 + (size_t)head * a.strideW0 + cq * 256;
     for (int idx = tid; idx < S0 * 1024; idx += 512) {
         const int u = idx & 3, ln = (idx >> 2) & 63, jq = (idx >> 8) & 3, s = idx >> 10;
@@ -595,36 +595,49 @@ __global__ void __launch_bounds__(512) k_l0_rows(const L0Args a) {
         for (int s = 0; s < S0; ++s) dst[s] = xp[4 * s];
     };
     int m0 = sp * a.rows_per_wg + wave * 16;
-    if (m0 < r1) load_x(m0, xn);
-    for (; m0 < r1; m0 += 128) {
+    if (m0 < r1) load_x(m0, xr);
+    f32x4 w[S0];                                                               // srcA operands of the column group at hand (see the loop)
 #pragma unroll
-        for (int s = 0; s < S0; ++s) xr[s] = xn[s];
-        if (m0 + 128 < r1) load_x(m0 + 128, xn);                               // the next 16 rows are under way while these are multiplied
+    for (int s = 0; s < S0; ++s) w[s] = *(const f32x4*)&img[((s * 4) * 64 + lane) * 4];
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                        // nothing pending at the loop head: otherwise every iteration's matrix run waits for "the loads of xr" -- in fact for the previous tile's stores
+    for (; m0 < r1; m0 += 128) {
+        const bool more = m0 + 128 < r1;
+        if (more) load_x(m0 + 128, xn);                                        // the next 16 rows are under way while these are multiplied
+        asm volatile("" ::: "memory");                                         // ... issued HERE (left alone, hipcc sinks the loads to their use in the next iteration)
         const int row = min(m0 + i, a.M - 1);
+        f32x4 o[16];
 #pragma unroll
         for (int jq = 0; jq < 4; ++jq) {
-            // all S0 operand reads of this column group first (hipcc otherwise sinks each read to its use: read, wait the LDS latency, four
-            // instructions, read ...), then the run of 4 S0 matrix instructions, waiting only for the operand each step needs
-            f32x4 w[S0];
-#pragma unroll
-            for (int s = 0; s < S0; ++s) w[s] = *(const f32x4*)&img[((s * 4 + jq) * 64 + lane) * 4];
-            __builtin_amdgcn_sched_barrier(0);
+            // w[s] feeds the four matrix instructions of step s and is re-read for the NEXT column group (the next tile's first one after the last:
+            // the image never changes) the moment they are issued: every operand read is a whole column group ahead of its use.  sched_barrier keeps
+            // the order (hipcc otherwise sinks each read to its use: read, wait the LDS latency, four instructions, read ...).
             f32x4 d[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) d[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < S0; ++s)
+            for (int s = 0; s < S0; ++s) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) d[u] = MFMA16(w[s][u], xr[s], d[u]);
-            if (m0 + i < a.M) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    f32x4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = relu1(d[u][r]);
-                    *(f32x4*)(Ch + (size_t)row * a.N + 16 * (4 * jq + u)) = o;
-                }
+                __builtin_amdgcn_sched_barrier(0);
+                w[s] = *(const f32x4*)&img[((s * 4 + ((jq + 1) & 3)) * 64 + lane) * 4];
+                __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[4 * jq + u][r] = relu1(d[u][r]);
+        }
+        // The tile's 16 stores go out only HERE, behind the wait for the next rows' loads: loads and stores share one counter that does not retire in
+        // order, so the compiler waits with vmcnt(0) -- placed at the loop head, with the stores of each column group issued as they were ready, that wait
+        // sat behind 16 fresh stores in every iteration (267 us per C4 step; 184 us with the stores left out).  Now it finds only loads issued a tile ago.
+        if (more) {
+#pragma unroll
+            for (int s = 0; s < S0; ++s) xr[s] = xn[s];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (m0 + i < a.M) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) *(f32x4*)(Ch + (size_t)row * a.N + 16 * k) = o[k];
         }
     }
 }

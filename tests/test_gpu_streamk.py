@@ -130,6 +130,22 @@ def test_streamk_random_shapes_equal_the_tile_gemms(monkeypatch):
         del eng
 
 
+@pytest.mark.parametrize('env,K,dh,B', [('humanoid', 6, (1024, 1024, 1024), 1500), ('ant', 5, (256, 512, 256), 1700), ('humanoid', 5, (512, 1024), 2600)])
+def test_stored_layer0_kernel_equals_the_tile_gemm(env, K, dh, B, monkeypatch):
+    """Layer 0 of the forms that store it (three hidden layers; two behind Humanoid's 77 inputs) on k_l0_rows -- the head's weight slice LDS-resident, bias as
+    one more input row -- against the tile GEMM it replaces (METRPO_NO_L0_ROWS), and both against the oracle through the rollout."""
+    ph = (100, 50, 25) if env == 'humanoid' else (32, 32)
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, dh, ph, seed=87)
+    traj, dr32 = _rollout_vs_oracle(eng, dm, theta, pdims, pool, env, K, B, 2, 2)
+    assert eng.last_rollout_kernel() == 'gemm-streamk'
+    monkeypatch.setenv('METRPO_NO_L0_ROWS', '1')
+    tile = eng.rollout(B, 2, 2, 'step_rand', pool, **dr32)
+    assert eng.last_rollout_kernel() == 'gemm-streamk'
+    assert torch.equal(tile.done, traj.done)
+    # (both are k-ordered fmaf chains over the same 77 products, the bias last: on the fixtures the two kernels agree bit for bit)
+    np.testing.assert_allclose(cpu(tile.obs), cpu(traj.obs), **TOL.CROSS_KERNEL)
+
+
 def test_streamk_three_hidden_layers_split_tiles():
     env, K, B, T, H = 'humanoid', 6, 1500, 2, 2                # 6 x 12 x 4 = 288 tiles per launch
     eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (1024, 1024, 1024), (100, 50, 25), seed=83)
