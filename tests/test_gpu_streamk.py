@@ -130,7 +130,7 @@ def test_streamk_random_shapes_equal_the_tile_gemms(monkeypatch):
         del eng
 
 
-@pytest.mark.parametrize('env,K,dh,B', [('humanoid', 6, (1024, 1024, 1024), 1500), ('ant', 5, (256, 512, 256), 1700), ('humanoid', 5, (512, 1024), 2600)])
+@pytest.mark.parametrize('env,K,dh,B', [('humanoid', 6, (1024, 1024, 1024), 1500), ('ant', 5, (256, 512, 512), 3400), ('humanoid', 5, (512, 1024), 2600)])
 def test_stored_layer0_kernel_equals_the_tile_gemm(env, K, dh, B, monkeypatch):
     """Layer 0 of the forms that store it (three hidden layers; two behind Humanoid's 77 inputs) on k_l0_rows -- the head's weight slice LDS-resident, bias as
     one more input row -- against the tile GEMM it replaces (METRPO_NO_L0_ROWS), and both against the oracle through the rollout."""
