@@ -90,6 +90,149 @@ __global__ void k_big_pre(ProblemDesc pd, RolloutK r, int t, const float* __rest
 // chain below reads.  One launch per step instead of two between the ensemble kernels: k_big_post(t - 1) + this kernel's own launch and
 // its reload of the state cost ~17 us of a 150 us step at the C3 share.  Same arithmetic in the same order as k_big_post: trajectories are
 // bit for bit those of the two-launch sequence (tests/test_gpu_streamk.py).
+// Step t - 1 closed for a wave's 16 envs in the lane layout of the MFMA pre-kernels (env c, quarter q: dims 16 hh + 4 q .. + 3 of every 16-dim block):
+// what k_big_post computes, same arithmetic in the same order; the new state lands in the wave's LDS tile ST [16][NS] (and in S), ready for the policy chain.
+template <int ENV, int NS, int NA>
+__device__ __forceinline__ void big_close_step(const ProblemDesc& pd, const RolloutK& r, int t, const float* __restrict__ norm, const BigState& st, float* ST,
+                                               int c, int q, bool active, int b, uint64_t genv) {
+    constexpr int NH = (NS + 15) / 16;
+    // ---- close step t - 1 (k_big_post) for this wave's 16 envs ----
+    const int bc = active ? b : max(r.B - 1, 0);
+    const int K = pd.K, tp = t - 1;
+    const int ttp = tp + RK_TOFF(r, bc);
+    const size_t tbp = (size_t)ttp * RK_STRIDE(r) + RK_ENV(r, bc);
+    const float* diff_mean = norm + 2 * (NS + NA); const float* diff_std = diff_mean + NS;
+    const uint4 dstep = rng_draw(r.seed, genv, r.t0 + ttp, RNG_STEP, 0);
+    int sel = st.cur_model[bc];
+    if (r.sam_mode == METRPO_SAM_STEP_RAND) sel = (r.model_idx != nullptr) ? r.model_idx[tbp] : rng_index(dstep.z, K);
+    if (r.sam_mode == METRPO_SAM_ONE_MODEL) sel = 0;
+    const bool simple = (r.sam_mode == METRPO_SAM_STEP_RAND || r.sam_mode == METRPO_SAM_EPS_RAND || r.sam_mode == METRPO_SAM_ONE_MODEL);
+    float ua_[NA];                                           // clipped actions of step t - 1 (summed below, behind the loads of the output partials: one round trip for both)
+#pragma unroll
+    for (int d = 0; d < NA; ++d) ua_[d] = st.U[(size_t)bc * NA + d];
+        float vnew[NH][4];
+    bool finl = true;
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) {
+        const int i0 = 16 * hh + 4 * q;                      // dims i0 .. i0 + 3 (the partial rows are 16 OT floats wide, zero beyond ns)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) vnew[hh][rr] = 0.0f;
+        if (i0 >= NS) continue;
+        auto outv4 = [&](int k, float (&o)[4]) {             // output layer of head k, dims i0 .. i0 + 3: bias, then the partials in split order (k_big_post: outv)
+            if (st.out_splits == 0) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) o[rr] = (i0 + rr < NS) ? st.OUT[((size_t)k * r.B + bc) * NS + i0 + rr] : 0.0f;
+                return;
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) o[rr] = (i0 + rr < NS) ? st.out_bias[(size_t)k * st.out_bias_stride + i0 + rr] : 0.0f;
+            for (int sp = 0; sp < st.out_splits; ++sp) {
+                const float* pr_ = st.PART + ((size_t)sp * K + k) * st.out_stride + (size_t)bc * st.out_ld + i0;
+                if ((st.out_ld & 3) == 0) { const f32x4 p4 = *(const f32x4*)pr_;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) o[rr] += p4[rr]; }
+                else {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) if (i0 + rr < NS) o[rr] += pr_[rr];
+                }
+            }
+        };
+        float so[4], dm_[4], ds_[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) { const int i = min(i0 + rr, NS - 1); so[rr] = st.S[(size_t)bc * NS + i]; dm_[rr] = diff_mean[i]; ds_[rr] = diff_std[i]; }
+        auto head4 = [&](int k, float (&hv)[4]) { float o[4]; outv4(k, o);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) hv[rr] = fmaf(ds_[rr], o[rr], dm_[rr]) + so[rr]; };
+        float v4[4];
+        if (simple) head4(sel, v4);
+        else {
+            float m4[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < K; ++k) { float h4[4]; head4(k, h4);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) m4[rr] += h4[rr]; }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) { m4[rr] /= (float)K; v4[rr] = m4[rr]; }
+            if (r.sam_mode == METRPO_SAM_MODEL_MEAN_STD) {
+                float var4[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int k = 0; k < K; ++k) { float h4[4]; head4(k, h4);
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) { const float d_ = h4[rr] - m4[rr]; var4[rr] = fmaf(d_, d_, var4[rr]); } }
+                float z4[4];
+                if (r.sel_noise == nullptr) normal4(rng_draw(r.seed, genv, r.t0 + ttp, RNG_SELNOISE, i0 >> 2), z4);     // dims i0 .. i0 + 3 = chunk i0 / 4
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const float nz = (r.sel_noise != nullptr) ? r.sel_noise[tbp * NS + min(i0 + rr, NS - 1)] : z4[rr];
+                    v4[rr] = fmaf(nz, sqrtf(var4[rr] / (float)K), m4[rr]);
+                }
+            } else if (r.sam_mode == METRPO_SAM_MODEL_MED) {
+                const int r_lo = (K - 1) / 2, r_hi = K / 2;
+                float lo4[4] = {0.f, 0.f, 0.f, 0.f}, hi4[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int k = 0; k < K; ++k) {
+                    float xk[4]; head4(k, xk);
+                    int rank[4] = {0, 0, 0, 0};
+                    for (int j = 0; j < K; ++j) { float xj[4]; head4(j, xj);
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) rank[rr] += (xj[rr] < xk[rr]) || (xj[rr] == xk[rr] && j < k); }
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) { if (rank[rr] == r_lo) lo4[rr] = xk[rr]; if (rank[rr] == r_hi) hi4[rr] = xk[rr]; }
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) v4[rr] = 0.5f * (lo4[rr] + hi4[rr]);
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) if (i0 + rr < NS) { vnew[hh][rr] = v4[rr]; finl = finl && isfinite(v4[rr]); ST[c * NS + i0 + rr] = v4[rr]; }
+    }
+    float su2 = 0.0f;                                        // sum of squared clipped actions in action order (every lane of the env, redundantly)
+#pragma unroll
+    for (int d = 0; d < NA; ++d) su2 = fmaf(ua_[d], ua_[d], su2);
+    int fin = finl ? 1 : 0;                                  // all-finite over the env's dims: the env's four lanes are c, c + 16, c + 32, c + 48
+    fin &= __shfl_xor(fin, 16, 64); fin &= __shfl_xor(fin, 32, 64);
+    wave_lds_sync();
+    const float* Sv = ST + c * NS;                           // the env's next state, every dim
+    constexpr int ki = (ENV == METRPO_ENV_SWIMMER || ENV == METRPO_ENV_HOPPER) ? 5 : (ENV == METRPO_ENV_HALF_CHEETAH) ? 9 : (ENV == METRPO_ENV_ANT) ? 15 : (ENV == METRPO_ENV_SNAKE) ? 7 : (ENV == METRPO_ENV_HUMANOID) ? NS - 1 : 0;
+    const float key = Sv[ki], h0v = Sv[0], h1v = Sv[1], zc = Sv[2];
+    float pen = 0.0f;
+    if (ENV == METRPO_ENV_HOPPER) for (int j = 2; j < NS; ++j) pen += fmaxf(fabsf(Sv[j]) - 100.0f, 0.0f);
+    float cost = 0.0f;
+    switch (ENV) {
+    case METRPO_ENV_SWIMMER: cost = -(key - 1e-2f * (su2 / (float)NA)); break;
+    case METRPO_ENV_HALF_CHEETAH: cost = -fminf(fmaxf(key - 1e-1f * 0.5f * su2, -10.0f), 10.0f); break;
+    case METRPO_ENV_ANT: cost = -(key - 1e-2f * 0.5f * su2 + 0.05f); break;
+    case METRPO_ENV_HOPPER: cost = -(key - 0.01f * 0.5f * su2 - 10.0f * fmaxf(0.45f - h0v, 0.0f) - 10.0f * fmaxf(fabsf(h1v) - 0.2f, 0.0f) - pen); break;
+    case METRPO_ENV_SNAKE: cost = -(key - 1e-2f * 0.5f * su2); break;
+    case METRPO_ENV_HUMANOID: cost = (key - 1.5f) * (key - 1.5f) + 1e-2f * 1e-3f * su2; break;      // key = the last state dim (k_big_post: last)
+    }
+    int ts = st.ts[bc] + 1;
+    bool dn = (ENV == METRPO_ENV_ANT) ? !((zc >= 0.2f) && (zc <= 1.0f) && (fin != 0)) : false;
+    dn = dn || (ts >= r.H);
+    int cur = st.cur_model[bc];
+    if (active && q == 0) { r.rew[tbp] = -cost; r.done[tbp] = dn ? 1 : 0; r.tpath[tbp] = ts - 1; }
+    wave_lds_sync();                                         // every lane has read its env's scalars: the reset rows may overwrite the tile
+    if (dn) {                                                // uniform over the env's four lanes
+        const size_t rb = (size_t)(tp + 1) * r.B + bc;
+        const int row = (r.reset_idx != nullptr) ? r.reset_idx[rb] : rng_index(dstep.w, r.n_pool);
+        cur = (r.reset_model != nullptr) ? r.reset_model[rb] : rng_index16(dstep.z, K);
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) { const int i = 16 * hh + 4 * q + rr; if (i < NS) { vnew[hh][rr] = r.pool[(size_t)row * NS + i]; ST[c * NS + i] = vnew[hh][rr]; } }
+        ts = 0;
+    }
+    if (active) {
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) { const int i = 16 * hh + 4 * q + rr; if (i < NS) st.S[(size_t)b * NS + i] = vnew[hh][rr]; }
+        if (q == 0) { st.ts[b] = ts; if (dn) st.cur_model[b] = cur; }
+    } else {
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) { const int i = 16 * hh + 4 * q + rr; if (i < NS) ST[c * NS + i] = 0.0f; }       // rows beyond the batch: zeros, as the reload below gives
+    }
+}
+
 #ifdef PP_TIMING        // developer instrumentation (SRC=rollout_gemm.hip tools/build_variant.sh pptiming -DPP_TIMING): shader-clock phases of workgroup 0, wave 0 of the merged launch
 __device__ unsigned long long g_pp_phase[8];
 #define PP_MARK(i) { if (POST && blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); g_pp_phase[i] += n_ - pp_t; pp_t = n_; } }
@@ -167,143 +310,7 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
         }
     }
     if constexpr (POST) {
-        // ---- close step t - 1 (k_big_post) for this wave's 16 envs ----
-        const int bc = active ? b : max(r.B - 1, 0);
-        const int K = pd.K, tp = t - 1;
-        const int ttp = tp + RK_TOFF(r, bc);
-        const size_t tbp = (size_t)ttp * RK_STRIDE(r) + RK_ENV(r, bc);
-        const float* diff_mean = norm + 2 * (NS + NA); const float* diff_std = diff_mean + NS;
-        const uint4 dstep = rng_draw(r.seed, genv, r.t0 + ttp, RNG_STEP, 0);
-        int sel = st.cur_model[bc];
-        if (r.sam_mode == METRPO_SAM_STEP_RAND) sel = (r.model_idx != nullptr) ? r.model_idx[tbp] : rng_index(dstep.z, K);
-        if (r.sam_mode == METRPO_SAM_ONE_MODEL) sel = 0;
-        const bool simple = (r.sam_mode == METRPO_SAM_STEP_RAND || r.sam_mode == METRPO_SAM_EPS_RAND || r.sam_mode == METRPO_SAM_ONE_MODEL);
-        float ua_[NA];                                           // clipped actions of step t - 1 (summed below, behind the loads of the output partials: one round trip for both)
-#pragma unroll
-        for (int d = 0; d < NA; ++d) ua_[d] = st.U[(size_t)bc * NA + d];
-        PP_MARK(4)
-        float vnew[2][4];
-        bool finl = true;
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int i0 = 16 * hh + 4 * q;                      // dims i0 .. i0 + 3 (the partial rows are 16 OT floats wide, zero beyond ns)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) vnew[hh][rr] = 0.0f;
-            if (i0 >= NS) continue;
-            auto outv4 = [&](int k, float (&o)[4]) {             // output layer of head k, dims i0 .. i0 + 3: bias, then the partials in split order (k_big_post: outv)
-                if (st.out_splits == 0) {
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) o[rr] = (i0 + rr < NS) ? st.OUT[((size_t)k * r.B + bc) * NS + i0 + rr] : 0.0f;
-                    return;
-                }
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) o[rr] = (i0 + rr < NS) ? st.out_bias[(size_t)k * st.out_bias_stride + i0 + rr] : 0.0f;
-                for (int sp = 0; sp < st.out_splits; ++sp) {
-                    const float* pr_ = st.PART + ((size_t)sp * K + k) * st.out_stride + (size_t)bc * st.out_ld + i0;
-                    if ((st.out_ld & 3) == 0) { const f32x4 p4 = *(const f32x4*)pr_;
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) o[rr] += p4[rr]; }
-                    else {
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) if (i0 + rr < NS) o[rr] += pr_[rr];
-                    }
-                }
-            };
-            float so[4], dm_[4], ds_[4];
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) { const int i = min(i0 + rr, NS - 1); so[rr] = st.S[(size_t)bc * NS + i]; dm_[rr] = diff_mean[i]; ds_[rr] = diff_std[i]; }
-            auto head4 = [&](int k, float (&hv)[4]) { float o[4]; outv4(k, o);
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) hv[rr] = fmaf(ds_[rr], o[rr], dm_[rr]) + so[rr]; };
-            float v4[4];
-            if (simple) head4(sel, v4);
-            else {
-                float m4[4] = {0.f, 0.f, 0.f, 0.f};
-                for (int k = 0; k < K; ++k) { float h4[4]; head4(k, h4);
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) m4[rr] += h4[rr]; }
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) { m4[rr] /= (float)K; v4[rr] = m4[rr]; }
-                if (r.sam_mode == METRPO_SAM_MODEL_MEAN_STD) {
-                    float var4[4] = {0.f, 0.f, 0.f, 0.f};
-                    for (int k = 0; k < K; ++k) { float h4[4]; head4(k, h4);
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) { const float d_ = h4[rr] - m4[rr]; var4[rr] = fmaf(d_, d_, var4[rr]); } }
-                    float z4[4];
-                    if (r.sel_noise == nullptr) normal4(rng_draw(r.seed, genv, r.t0 + ttp, RNG_SELNOISE, i0 >> 2), z4);     // dims i0 .. i0 + 3 = chunk i0 / 4
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const float nz = (r.sel_noise != nullptr) ? r.sel_noise[tbp * NS + min(i0 + rr, NS - 1)] : z4[rr];
-                        v4[rr] = fmaf(nz, sqrtf(var4[rr] / (float)K), m4[rr]);
-                    }
-                } else if (r.sam_mode == METRPO_SAM_MODEL_MED) {
-                    const int r_lo = (K - 1) / 2, r_hi = K / 2;
-                    float lo4[4] = {0.f, 0.f, 0.f, 0.f}, hi4[4] = {0.f, 0.f, 0.f, 0.f};
-                    for (int k = 0; k < K; ++k) {
-                        float xk[4]; head4(k, xk);
-                        int rank[4] = {0, 0, 0, 0};
-                        for (int j = 0; j < K; ++j) { float xj[4]; head4(j, xj);
-#pragma unroll
-                            for (int rr = 0; rr < 4; ++rr) rank[rr] += (xj[rr] < xk[rr]) || (xj[rr] == xk[rr] && j < k); }
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) { if (rank[rr] == r_lo) lo4[rr] = xk[rr]; if (rank[rr] == r_hi) hi4[rr] = xk[rr]; }
-                    }
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) v4[rr] = 0.5f * (lo4[rr] + hi4[rr]);
-                }
-            }
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) if (i0 + rr < NS) { vnew[hh][rr] = v4[rr]; finl = finl && isfinite(v4[rr]); ST[c * NS + i0 + rr] = v4[rr]; }
-        }
-        float su2 = 0.0f;                                        // sum of squared clipped actions in action order (every lane of the env, redundantly)
-#pragma unroll
-        for (int d = 0; d < NA; ++d) su2 = fmaf(ua_[d], ua_[d], su2);
-        PP_MARK(5)
-        int fin = finl ? 1 : 0;                                  // all-finite over the env's dims: the env's four lanes are c, c + 16, c + 32, c + 48
-        fin &= __shfl_xor(fin, 16, 64); fin &= __shfl_xor(fin, 32, 64);
-        wave_lds_sync();
-        const float* Sv = ST + c * NS;                           // the env's next state, every dim
-        constexpr int ki = (ENV == METRPO_ENV_SWIMMER || ENV == METRPO_ENV_HOPPER) ? 5 : (ENV == METRPO_ENV_HALF_CHEETAH) ? 9 : (ENV == METRPO_ENV_ANT) ? 15 : (ENV == METRPO_ENV_SNAKE) ? 7 : 0;
-        const float key = Sv[ki], h0v = Sv[0], h1v = Sv[1], zc = Sv[2];
-        float pen = 0.0f;
-        if (ENV == METRPO_ENV_HOPPER) for (int j = 2; j < NS; ++j) pen += fmaxf(fabsf(Sv[j]) - 100.0f, 0.0f);
-        float cost = 0.0f;
-        switch (ENV) {
-        case METRPO_ENV_SWIMMER: cost = -(key - 1e-2f * (su2 / (float)NA)); break;
-        case METRPO_ENV_HALF_CHEETAH: cost = -fminf(fmaxf(key - 1e-1f * 0.5f * su2, -10.0f), 10.0f); break;
-        case METRPO_ENV_ANT: cost = -(key - 1e-2f * 0.5f * su2 + 0.05f); break;
-        case METRPO_ENV_HOPPER: cost = -(key - 0.01f * 0.5f * su2 - 10.0f * fmaxf(0.45f - h0v, 0.0f) - 10.0f * fmaxf(fabsf(h1v) - 0.2f, 0.0f) - pen); break;
-        case METRPO_ENV_SNAKE: cost = -(key - 1e-2f * 0.5f * su2); break;
-        }
-        int ts = st.ts[bc] + 1;
-        bool dn = (ENV == METRPO_ENV_ANT) ? !((zc >= 0.2f) && (zc <= 1.0f) && (fin != 0)) : false;
-        dn = dn || (ts >= r.H);
-        int cur = st.cur_model[bc];
-        PP_MARK(6)
-        if (active && q == 0) { r.rew[tbp] = -cost; r.done[tbp] = dn ? 1 : 0; r.tpath[tbp] = ts - 1; }
-        wave_lds_sync();                                         // every lane has read its env's scalars: the reset rows may overwrite the tile
-        if (dn) {                                                // uniform over the env's four lanes
-            const size_t rb = (size_t)(tp + 1) * r.B + bc;
-            const int row = (r.reset_idx != nullptr) ? r.reset_idx[rb] : rng_index(dstep.w, r.n_pool);
-            cur = (r.reset_model != nullptr) ? r.reset_model[rb] : rng_index16(dstep.z, K);
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) { const int i = 16 * hh + 4 * q + rr; if (i < NS) { vnew[hh][rr] = r.pool[(size_t)row * NS + i]; ST[c * NS + i] = vnew[hh][rr]; } }
-            ts = 0;
-        }
-        if (active) {
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) { const int i = 16 * hh + 4 * q + rr; if (i < NS) st.S[(size_t)b * NS + i] = vnew[hh][rr]; }
-            if (q == 0) { st.ts[b] = ts; if (dn) st.cur_model[b] = cur; }
-        } else {
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) { const int i = 16 * hh + 4 * q + rr; if (i < NS) ST[c * NS + i] = 0.0f; }       // rows beyond the batch: zeros, as the reload below gives
-        }
+        big_close_step<ENV, NS, NA>(pd, r, t, norm, st, ST, c, q, active, b, genv);
     } else {
         for (int i = lane; i < 16 * NS; i += 64) ST[i] = (i < lim) ? st.S[(size_t)b0 * NS + i] : 0.0f;
     }
@@ -385,7 +392,7 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
 // k_big_pre_mfma, every width padded to whole 16-unit tiles (zero weights, tanh(0) = 0 meets zero rows of the next layer).  One wave per 16-env
 // tile: NS_KS C1 + 4 C1 C2 + 4 C2 C3 + 4 C3 CO matrix instructions (258 for Humanoid) instead of the gather -> four small GEMMs -> action
 // chain of six launches (41 us per step at 500 rows) or the thread-per-env k_big_pre (302 us).  Same draws, same outputs layout.
-template <int NS, int NA, int NDROP, int W1, int W2, int W3>
+template <int NS, int NA, int NDROP, int W1, int W2, int W3, bool POST = false>
 __global__ void __launch_bounds__(256) k_big_pre_mfma3(ProblemDesc pd, RolloutK r, int t, const float* __restrict__ theta,
                                                        const float* __restrict__ norm, BigState st) {
     using PC = P3<NS, NA, W1, W2, W3>;
@@ -412,7 +419,8 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma3(ProblemDesc pd, RolloutK 
     }
     __syncthreads();                                             // image complete; the reset rows of this tile are written by its own wave
     const int lim = min(16, max(0, r.B - b0)) * NS;
-    for (int i = lane; i < 16 * NS; i += 64) ST[i] = (i < lim) ? st.S[(size_t)b0 * NS + i] : 0.0f;
+    if constexpr (POST) big_close_step<METRPO_ENV_HUMANOID, NS, NA>(pd, r, t, norm, st, ST, c, q, active, b, genv);      // step t - 1 closed here (k_big_post), as in k_big_pre_mfma<ENV, true>
+    else for (int i = lane; i < 16 * NS; i += 64) ST[i] = (i < lim) ? st.S[(size_t)b0 * NS + i] : 0.0f;
     wave_lds_sync();
     for (int i = lane; i < lim; i += 64) {                       // obs[t] (merged rounds: a tile's envs may belong to two rounds)
         const int bi = b0 + i / NS;
@@ -513,11 +521,10 @@ __global__ void __launch_bounds__(256) k_big_pre_action(ProblemDesc pd, RolloutK
 typedef void (*big_pre_mfma_t)(ProblemDesc, RolloutK, int, const float*, const float*, BigState);
 static big_pre_mfma_t big_pre_mfma_select(const ProblemDesc& pd, size_t* dyn_lds, bool post = false) {
     *dyn_lds = 0;
-    if (post && (pd.pol.n_layers != 3 || pd.pol.dims[1] != 32 || pd.pol.dims[2] != 32)) return nullptr;     // the merged form exists for the 2 x 32 policies
     if (pd.env == METRPO_ENV_HUMANOID && pd.ns == 55 && pd.na == 21 && pd.n_drop == 0 && pd.pol.n_layers == 4 && pd.pol.dims[1] == 100 && pd.pol.dims[2] == 50 &&
         pd.pol.dims[3] == 25 && pd.pol.act[0] == METRPO_ACT_TANH && pd.pol.act[1] == METRPO_ACT_TANH && pd.pol.act[2] == METRPO_ACT_TANH && getenv("METRPO_NO_PRE_MFMA3") == nullptr) {
         *dyn_lds = big_pre_mfma3_lds<55, 21, 0, 100, 50, 25>();
-        return k_big_pre_mfma3<55, 21, 0, 100, 50, 25>;
+        return post ? k_big_pre_mfma3<55, 21, 0, 100, 50, 25, true> : k_big_pre_mfma3<55, 21, 0, 100, 50, 25, false>;
     }
     if (pd.pol.n_layers != 3 || pd.pol.dims[1] != 32 || pd.pol.dims[2] != 32 || pd.pol.act[0] != METRPO_ACT_TANH) return nullptr;
     switch (pd.env) {
@@ -799,9 +806,12 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
     if (fuse_out) nP = std::max(nP, up4(gemm_fused_out_part_floats(B, pd.dyn.dims[L - 1], K, pd.ns, fuse_tile)));
     size_t pre_lds = 0;
     const big_pre_mfma_t pre_mfma = big_pre_mfma_select(pd, &pre_lds);
-    // steps t >= 1: k_big_post(t - 1) rides in the pre-step's launch (2 x 32 policies; METRPO_NO_STEP_MERGE=1 keeps the two launches: A/B runs, tests)
+    // steps t >= 1: k_big_post(t - 1) rides in the pre-step's launch (the MFMA pre-kernels: 2 x 32 policies and Humanoid's 100-50-25; METRPO_NO_STEP_MERGE=1 keeps the two launches: A/B runs, tests)
     size_t pre_lds_post = 0;
-    const big_pre_mfma_t pre_post = (pre_mfma && getenv("METRPO_NO_STEP_MERGE") == nullptr) ? big_pre_mfma_select(pd, &pre_lds_post, true) : nullptr;
+    // (Humanoid's 55 dims are 16 per lane in that layout: behind the tile GEMMs' 16 output partials per head -- small batches -- the closing part is slower
+    //  than k_big_post's lane per dim, 12.9 vs 11.1 ms per params-file rollout; behind stream-K's 4 partials it is merged.  METRPO_STEP_MERGE=1 forces it: tests)
+    const bool merge_ok = getenv("METRPO_NO_STEP_MERGE") == nullptr && (pd.ns <= 32 || sk.mode != 0 || getenv("METRPO_STEP_MERGE") != nullptr);
+    const big_pre_mfma_t pre_post = (pre_mfma && merge_ok) ? big_pre_mfma_select(pd, &pre_lds_post, true) : nullptr;
     // policies without an MFMA pre-kernel: GEMM chain over the batch from B = 1024 up -- and at ANY batch when the policy is large
     // (k_big_pre walks the weights through scalar loads, one block's time whatever B: 302 us per step for Humanoid's 100-50-25 at B = 100,
     // the params-humanoid.json shape, against ~40 us for the six small launches of the chain: iteration 77 -> 28 ms)
@@ -861,6 +871,7 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
     if (psh > 160 * 1024) return set_err(c, METRPO_EUNSUPPORTED, "policy too wide for k_big_pre");
     if (psh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_big_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psh));
     if (pre_mfma && pre_lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)pre_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pre_lds));
+    if (pre_post && pre_lds_post > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)pre_post, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pre_lds_post));
     for (int t = 0; t < a->T; ++t) {
         if (pre_post && t > 0) hipLaunchKernelGGL(pre_post, dim3((B + 63) / 64), dim3(256), pre_lds_post, st, pd, r, t, c->d_theta, c->d_norm, bs);
         else if (pre_mfma) hipLaunchKernelGGL(pre_mfma, dim3((B + 63) / 64), dim3(256), pre_lds, st, pd, r, t, c->d_theta, c->d_norm, bs);

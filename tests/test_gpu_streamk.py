@@ -157,17 +157,19 @@ def test_streamk_three_hidden_layers_split_tiles():
 
 @pytest.mark.parametrize('env,K,dh,B,sam_mode,streamk', [
     ('ant', 4, (512, 512), 333, 'step_rand', True), ('ant', 4, (256, 256), 100, 'model_med', False), ('half_cheetah', 3, (256, 512), 77, 'model_mean_std', True),
-    ('hopper', 3, (256, 256), 130, 'eps_rand', False), ('snake', 5, (512, 512), 64, 'model_mean', True), ('swimmer', 5, (512, 512), 100, 'one_model', False)])
+    ('hopper', 3, (256, 256), 130, 'eps_rand', False), ('snake', 5, (512, 512), 64, 'model_mean', True), ('swimmer', 5, (512, 512), 100, 'one_model', False),
+    ('humanoid', 4, (1024, 1024), 150, 'step_rand', False), ('humanoid', 3, (256, 512, 256), 77, 'model_med', True), ('humanoid', 2, (128, 256), 500, 'model_mean_std', False)])
 def test_step_closed_in_the_next_launch_is_bitwise_the_two_launch_sequence(env, K, dh, B, sam_mode, streamk, monkeypatch):
     """k_big_post(t - 1) folded into the pre-step launch of step t (rollout_gemm.hip: k_big_pre_mfma<ENV, true>): same arithmetic in the same
     order -- every trajectory tensor bit for bit what the two-launch sequence writes, on the stream-K path and on the tile GEMMs, for every
     selection mode, with early termination (Ant) and horizon resets inside the rollout."""
     T, H = 7, 3
-    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, dh, (32, 32), seed=91)
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, dh, (100, 50, 25) if env == 'humanoid' else (32, 32), seed=91)      # (Humanoid: k_big_pre_mfma3<.., true>)
     if env == 'ant':
         pool[::3, 2] = 0.21; dm.diff_mean[2] = -0.02
         eng.set_dynamics_layers(dm.Ws, dm.bs, dm.in_mean, dm.in_std, dm.diff_mean, dm.diff_std)
     monkeypatch.setenv('METRPO_STREAMK' if streamk else 'METRPO_NO_STREAMK', '1')
+    monkeypatch.setenv('METRPO_STEP_MERGE', '1')                # Humanoid behind the tile GEMMs: merged only on request
     eng.set_rollout_variant(1)
     dr = Hh.draws(np.random.RandomState(8), K, B, T, dm.ns, dm.na, len(pool))
     dr32 = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in dr.items()}

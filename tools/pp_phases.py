@@ -27,6 +27,3 @@ print('%s K=%d 2x%d B=%d: %s' % (env, K, hid, B, eng.last_rollout_kernel()))
 for i, nm in enumerate(names):
     print('  %-72s %7.0f cycles = %.2f us' % (nm, (b[i] - a[i]) / n, (b[i] - a[i]) / n / 2400.0))
 print('  sum %.2f us' % (sum(b[i] - a[i] for i in range(8)) / n / 2400.0))
-for i, nm in ((4, 'inside the first line: entry .. draws, head choice, action norm (su2)'), (5, '.. output partials of the chosen head, residual, state tile'), (6, '.. reward, done (ts / model loads)')):
-    print('  %-72s %7.0f cycles = %.2f us' % (nm, (b[i] - a[i]) / n, (b[i] - a[i]) / n / 2400.0))
-print('  (line 1 above then only holds what follows those marks: reset rows, state / ts stores)')
