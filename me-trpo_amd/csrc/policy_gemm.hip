@@ -157,6 +157,30 @@ __global__ void __launch_bounds__(256) k_pg_head(int mode, PolK k, int na, int n
     }
 }
 
+// The same head for the Fisher-vector products (10 of the 12-13 launches of an update), one LANE per (sample, padded action dim): k_pg_head's thread per
+// sample walks a row of nap floats per lane -- every load and store instruction touches 64 lines (0.6 TB/s at N = 6.25 M: 2.66 ms of a 18 ms product);
+// elementwise, MU and U stream through at the copy rate.  Same expression per element; the valid weight is a sum of identical 1/N values (exact in float64
+// whatever the grouping).  part rows as k_pg_head's: only [2] is non-zero.
+__global__ void __launch_bounds__(256) k_pg_head_fvp(PolK k, int na, int nap, const float* __restrict__ MU, const float* __restrict__ log_std,
+                                                     float* __restrict__ U, double* __restrict__ parts) {
+    __shared__ double sh[16];
+    double w = 0.0;
+    const long long tot = (long long)k.N * nap;
+    const long long stride = (long long)gridDim.x * 256, e0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    long long n = e0 / nap; int d = (int)(e0 - n * nap);                       // (sample, dim) walk along with e: no 64-bit division per element
+    const long long step_n = stride / nap; const int step_d = (int)(stride - step_n * nap);
+    for (long long e = e0; e < tot; e += stride, n += step_n, d += step_d) {
+        if (d >= nap) { d -= nap; ++n; }
+        const bool ok = (k.valid == nullptr || k.valid[n]);
+        float u = 0.0f;
+        if (ok && d < na) { const float ls = fmaxf(log_std[d], LOG_MIN_STD); u = MU[e] / (expf(2.0f * ls) + 0.5f * KL_EPS) * k.inv_n; }
+        U[e] = u;
+        if (ok && d == 0) w += (double)k.inv_n;
+    }
+    const double t = block_sum(w, sh);
+    if (threadIdx.x == 0) for (int i = 0; i < 3 + na; ++i) parts[(size_t)blockIdx.x * 40 + i] = (i == 2) ? t : 0.0;
+}
+
 // ordered (deterministic) assembly of the result vector in float64:
 //   mode 0: out[0] = loss, out[1 + p] = g[p];   mode 1: out[p] = (H v)[p];   mode 2: out[0] = loss, out[1] = kl
 __global__ void __launch_bounds__(256) k_pg_assemble(int mode, PgLay g, int P, int n_params, int nblk_head, const float* __restrict__ part,
@@ -300,8 +324,10 @@ int policy_gemm_run(metrpo_ctx* c, int mode, const metrpo_batch* b, const PolK& 
         }
     }
     // per-sample head
-    const int nblk = (int)std::min<long long>(1024, (N + 255) / 256);
-    hipLaunchKernelGGL(k_pg_head, dim3(nblk), dim3(256), 0, st, mode, k, na, nap, MU, theta + pd.pol.n_params, U, B.hparts);
+    const bool head_elem = (mode == 1 && k.gm == nullptr && getenv("METRPO_PG_HEAD_ROWS") == nullptr);
+    const int nblk = head_elem ? (int)std::min<long long>(1024, (N * nap + 2047) / 2048) : (int)std::min<long long>(1024, (N + 255) / 256);
+    if (head_elem) hipLaunchKernelGGL(k_pg_head_fvp, dim3(nblk), dim3(256), 0, st, k, na, nap, MU, theta + pd.pol.n_params, U, B.hparts);
+    else hipLaunchKernelGGL(k_pg_head, dim3(nblk), dim3(256), 0, st, mode, k, na, nap, MU, theta + pd.pol.n_params, U, B.hparts);
     if (mode != 2) {
         // back-prop D_l = (D_{l+1} W_l^T) * (1 - H_l^2), l = L-1 .. 1
         for (long long r0 = 0; r0 < N; r0 += CH) {
