@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define METRPO_ABI_VERSION 3
+#define METRPO_ABI_VERSION 4
 #define METRPO_MAX_LAYERS 6      /* hidden layers per MLP */
 
 typedef struct metrpo_ctx metrpo_ctx;
@@ -93,6 +93,15 @@ int32_t metrpo_destroy(metrpo_ctx* ctx);
  * schedule this process's waves (a census: CU masks and partitions count) covers their grid.  No reference counterpart: the reference is
  * single-process and single-session (utils.py:229-232). */
 int32_t metrpo_set_exclusive(metrpo_ctx* ctx, int32_t exclusive);
+/* Variant / tuning switches of a context (ABI 4).  The reference steers its run with params-*.json and command-line flags (main.py:21-60); this library's
+ * kernel-selection switches were process-global METRPO_<KEY> environment variables read inside the launch paths up to ABI 3.  They are now one table per
+ * context: metrpo_create() fills the defaults ONCE from the environment (METRPO_<KEY>), afterwards only metrpo_set_option() changes them (value NULL
+ * unsets a key; takes effect at the next launch) and metrpo_get_option() reports them (returns the value's length, -1 when unset, METRPO_EINVAL for an unknown
+ * key).  Keys: the names metrpo_option_name(i), i = 0, 1, ... returns (NULL beyond the table), e.g. "STREAMK", "NO_STREAMK", "NO_RESIDENT", "SEQ_ROUNDS",
+ * "PRE_GEMM"; lower case and a "METRPO_" prefix are accepted.  None of them changes results beyond the summation-order notes in DESIGN.md section 4. */
+int32_t metrpo_set_option(metrpo_ctx* ctx, const char* key, const char* value);
+int32_t metrpo_get_option(metrpo_ctx* ctx, const char* key, char* buf, int32_t cap);
+const char* metrpo_option_name(int32_t index);
 const char* metrpo_last_error(const metrpo_ctx* ctx);
 /* floats per dynamics model: [W0 (n_in x h0, row-major), b0, W1, b1, ..., Wout, bout]          */
 int32_t metrpo_dyn_param_count(const metrpo_ctx* ctx);
@@ -170,6 +179,12 @@ typedef struct {
                                     written (see metrpo_sampler_progress)                                                   */
 } metrpo_rollout_args;
 int32_t metrpo_rollout(metrpo_ctx* ctx, const metrpo_rollout_args* args, void* stream);
+/* Which kernel family the last metrpo_rollout of this context ran on (-1 none yet; 0 thread-per-env, 1 head-per-wave fused, 2 cooperative fused, 3 step-wise
+ * GEMM, 4 resident, 5 step-wise stream-K, 6 persistent stream-K), and -- when the shape fell off the fast dispatch table (K != 5 at 2 x 64; hidden widths
+ * 65..127) -- why ("" otherwise; also printed once per context on stderr unless option QUIET is set).  The reference has one code path for every shape
+ * (env_helpers.py:609-635); these two calls are how a caller learns which of this library's it got. */
+int32_t metrpo_last_rollout_kernel(const metrpo_ctx* ctx);
+const char* metrpo_rollout_note(const metrpo_ctx* ctx);
 
 /* Loop condition of obtain_samples (samplers/vectorized_sampler.py:60,104): n_samples counts the samples of COMPLETED paths
  * only and is tested once per time step.  For the chunk [t0, t0+T) just rolled out (d_done, d_tpath [T][B]) this adds each

@@ -105,6 +105,11 @@ SYMBOLS = {
     'metrpo_rms_accumulate': (_I, [_P, _P, _L, _I, _P, _P, _P]),
     'metrpo_bptt_grad': (_I, [_P, _P, _I, _I, _D, _P, _P, _P]),
     'metrpo_set_exclusive': (_I, [_P, _I]),
+    'metrpo_set_option': (_I, [_P, C.c_char_p, C.c_char_p]),
+    'metrpo_get_option': (_I, [_P, C.c_char_p, C.c_char_p, _I]),
+    'metrpo_option_name': (C.c_char_p, [_I]),
+    'metrpo_last_rollout_kernel': (_I, [_P]),
+    'metrpo_rollout_note': (C.c_char_p, [_P]),
     'metrpo_policy_adam_reset': (_I, [_P, _P]),
     'metrpo_policy_adam_step': (_I, [_P, _P, _D, _D, _D, _D, _D, _P]),
 }
@@ -116,7 +121,6 @@ EXTRA_SYMBOLS = {
     'metrpo_update_path': (_I, [_P, _L]),
     'metrpo_set_rollout_variant': (_I, [_P, _I]),
     'metrpo_set_det_path': (_I, [_P, _I]),
-    'metrpo_last_rollout_kernel': (_I, [_P]),
     'metrpo_probe_peaks': (_I, [_P, _P, _P]),
     'metrpo_schedulable_cus': (_I, [_P, _P]),
 }
@@ -131,7 +135,7 @@ def load():
         for name, (res, args) in table.items():
             fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
             fn.restype, fn.argtypes = res, args
-    if lib.metrpo_abi_version() != 3:
+    if lib.metrpo_abi_version() != 4:
         raise ImportError("libmetrpo.so ABI version mismatch")
     return lib
 

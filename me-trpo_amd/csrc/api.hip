@@ -94,6 +94,50 @@ static void repack_dyn(const metrpo_ctx* c, const float* src, float* dst, int n_
 }
 
 
+// ---- option table (metrpo_internal.h: METRPO_OPT_LIST) ----
+static const char* const OPT_NAMES[OPT_COUNT] = {
+#define X(n) #n,
+    METRPO_OPT_LIST(X)
+#undef X
+};
+const char* metrpo_opt_name(int id) { return (id >= 0 && id < OPT_COUNT) ? OPT_NAMES[id] : nullptr; }
+int metrpo_opt_id(const char* key) {
+    if (!key) return -1;
+    std::string k(key);
+    for (auto& ch : k) ch = (char)toupper((unsigned char)ch);
+    if (k.rfind("METRPO_", 0) == 0) k = k.substr(7);
+    for (int i = 0; i < OPT_COUNT; ++i) if (k == OPT_NAMES[i]) return i;
+    return -1;
+}
+// fields of the context derived from an option (id < 0: all of them)
+static void opt_apply(metrpo_ctx* c, int id) {
+    if (id < 0 || id == OPT_UPD_TILES_PER_WAVE) c->upd_tiles_per_wave = ctx_opt(c, OPT_UPD_TILES_PER_WAVE) ? std::max(1, atoi(ctx_opt(c, OPT_UPD_TILES_PER_WAVE))) : 1;
+    if (id < 0 || id == OPT_NO_RESIDENT) c->exclusive = (ctx_opt(c, OPT_NO_RESIDENT) == nullptr) ? 1 : 0;
+    if (id < 0 || id == OPT_GEMM_PREFETCH) { const char* g = ctx_opt(c, OPT_GEMM_PREFETCH); g_gemm_prefetch_off.store((g && g[0] == '1') ? 1 : 0); }   // process-wide (gemm_mfma.h has no context)
+    if (id == OPT_XCHG_TIMEOUT_MS && ctx_opt(c, OPT_XCHG_TIMEOUT_MS)) { const long long v = atoll(ctx_opt(c, OPT_XCHG_TIMEOUT_MS)); if (v > 0) c->xg_timeout = (unsigned long long)v * 100000ull; }
+}
+// value == NULL unsets the key.  Read by the NEXT launch; options that size a workspace or select a kernel table entry at set_dynamics / set_policy time
+// (none today) would say so here.
+extern "C" int32_t metrpo_set_option(metrpo_ctx* c, const char* key, const char* value) {
+    if (!c || !key) return METRPO_ENULL;
+    const int id = metrpo_opt_id(key);
+    if (id < 0) return set_err(c, METRPO_EINVAL, std::string("set_option: unknown key '") + key + "'");
+    c->opt_set[id] = (value != nullptr); c->opt_val[id] = value ? value : "";
+    opt_apply(c, id);
+    return METRPO_OK;
+}
+// returns the value's length (copied into buf, NUL-terminated, truncated to cap - 1), -1 when the key is unset, METRPO_EINVAL for an unknown key
+extern "C" int32_t metrpo_get_option(metrpo_ctx* c, const char* key, char* buf, int32_t cap) {
+    if (!c || !key) return METRPO_ENULL;
+    const int id = metrpo_opt_id(key);
+    if (id < 0) return set_err(c, METRPO_EINVAL, std::string("get_option: unknown key '") + key + "'");
+    if (!c->opt_set[id]) return -1;
+    if (buf && cap > 0) { const size_t n = std::min<size_t>(c->opt_val[id].size(), (size_t)cap - 1); memcpy(buf, c->opt_val[id].data(), n); buf[n] = 0; }
+    return (int32_t)c->opt_val[id].size();
+}
+// key of option i (NULL beyond the table): lets a binding enumerate the switches
+extern "C" const char* metrpo_option_name(int32_t i) { return metrpo_opt_name(i); }
+
 extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_dims* d) {
     if (!out || !d) return METRPO_ENULL;
     *out = nullptr;
@@ -109,7 +153,13 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     c->d_dyn_img = c->d_pol_img = nullptr; c->pol_img_idx = -1; c->d_pol_imgval = nullptr; c->d_pol_vpos = nullptr; c->img_live = 0;
     c->d_bptt = nullptr; c->bptt_cap = 0; c->det_cfg = -1; c->d_detpart = nullptr; c->detpart_cap = 0; c->det_gemm = 0; c->d_dg = nullptr; c->dg_cap = 0; c->vjp_gm = nullptr; c->ls_skip = nullptr; c->d_pol_adam = nullptr; c->pol_adam_t = 0; c->mfma_cfg = -1; c->pol_mfma = -1; c->coop_cfg = -1; c->rollout_variant = 0;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_cg = nullptr; c->d_vf = nullptr; c->d_theta_try = nullptr;
-    c->d_valbuf = nullptr; c->h_pinned = nullptr; c->n_sm = 256; c->n_cu_sched = 0; c->upd_tiles_per_wave = getenv("METRPO_UPD_TILES_PER_WAVE") ? std::max(1, atoi(getenv("METRPO_UPD_TILES_PER_WAVE"))) : 1; c->exclusive = (getenv("METRPO_NO_RESIDENT") == nullptr) ? 1 : 0;
+    c->d_valbuf = nullptr; c->h_pinned = nullptr; c->n_sm = 256; c->n_cu_sched = 0; c->fallback_logged = 0;
+    for (int i = 0; i < OPT_COUNT; ++i) {                     // the ONLY place the library reads the environment for kernel selection: defaults of the option table
+        const std::string ev = std::string(i == OPT_GEMM_PREFETCH ? "" : "METRPO_") + metrpo_opt_name(i);
+        const char* e = getenv(ev.c_str());
+        c->opt_set[i] = (e != nullptr); c->opt_val[i] = e ? e : "";
+    }
+    opt_apply(c, -1);
     c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gae_part = nullptr; c->gae_part_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0; c->d_res = nullptr; c->res_cap = 0; c->res_seq = 0; c->res_failed = 0; c->last_rollout_kernel = -1; c->upd_pending = 0; c->upd_spec = 0; c->upd_changed_in_end = 0; c->h_upd = nullptr; c->upd_stamp = 0; c->side_ready = 0; c->d_ticket = nullptr; c->d_hcache = nullptr; c->hcache_cap = 0; c->hcache_on = 0; c->d_mig = nullptr; c->mig_cap = 0; c->mig_epoch = 0; c->nccl_comm = nullptr; c->comm_world = 0; c->comm_rank = 0; c->pol_path = 1; c->d_pg = nullptr; c->pg_cap = 0; c->pg_fwd_rows = -1; c->pg_fwd_obs = nullptr; c->d_adam = nullptr; c->adam_t = 0; c->d_train = nullptr; c->train_cap = 0; c->d_train_part = nullptr; c->train_part_cap = 0;
     ProblemDesc& pd = c->pd;
     pd.env = d->env; pd.ns = d->ns; pd.na = d->na; pd.K = d->n_models; pd.n_drop = d->n_drop;
@@ -124,7 +174,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     if (hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return METRPO_EHIP; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_sm = prop.multiProcessorCount;
-    const size_t ncg = (size_t)(1 + pd.P) + 5 * (size_t)pd.P + 8 + 2 + 4;
+    const size_t ncg = (size_t)(1 + pd.P) + 5 * (size_t)pd.P + 8 + 2 + 4 + 1;      // ... | scal[8] | lk[2] | ls[4] | validation time-out cell (val_err_cell)
     if (hipMalloc(&c->d_dyn, sizeof(float) * (size_t)pd.K * pd.dyn.n_params) != hipSuccess ||
         hipMalloc(&c->d_norm, sizeof(float) * (2 * (pd.ns + pd.na) + 2 * pd.ns)) != hipSuccess ||
         hipMalloc(&c->d_theta, sizeof(float) * pd.P) != hipSuccess ||
@@ -146,6 +196,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     c->det_cfg = det_mfma_select(c);
     c->det_gemm = det_gemm_applicable(c) ? 1 : 0;
     c->rollout_variant = 0;
+    (void)sched_cus(c, nullptr);                              // CU census here, not inside the first resident / cooperative launch (probe.hip)
     return METRPO_OK;
 }
 
@@ -238,6 +289,12 @@ extern "C" int32_t metrpo_step(metrpo_ctx* c, const float* s, const float* a, in
     return launch_step(c, s, a, B, sam_mode, model_idx, noise, s_next, reward, done, next_all, (hipStream_t)stream);
 }
 
+// a shape that the fast kernels' tables do not hold: remembered for metrpo_rollout_note and reported ONCE per context on stderr (option QUIET silences it)
+static void note_off_table(metrpo_ctx* c, const std::string& why) {
+    c->rollout_note = why;
+    if (!c->fallback_logged && ctx_opt(c, OPT_QUIET) == nullptr) fprintf(stderr, "metrpo: rollout off the fast path: %s\n", why.c_str());
+    c->fallback_logged = 1;
+}
 extern "C" int32_t metrpo_rollout(metrpo_ctx* c, const metrpo_rollout_args* a, void* stream) {
     TraceRange trace_("metrpo:rollout (obtain_samples: policy + env)");
     if (!c) return METRPO_ENULL;
@@ -251,9 +308,16 @@ extern "C" int32_t metrpo_rollout(metrpo_ctx* c, const metrpo_rollout_args* a, v
     if ((a->d_init_obs != nullptr) != (a->d_init_ts != nullptr) || (a->d_init_obs != nullptr) != (a->d_init_model != nullptr))
         return set_err(c, METRPO_EINVAL, "rollout: d_init_obs, d_init_ts and d_init_model must be given together");
     if (a->B == 0 || a->T == 0) return METRPO_OK;
+    c->rollout_note.clear();
     if (c->mfma_cfg >= 0) {
         const int rc = launch_rollout_mfma(c, a, (hipStream_t)stream);
-        if (rc != METRPO_EUNSUPPORTED) { c->last_rollout_kernel = (c->coop_cfg >= 0 && c->rollout_variant != 1) ? 2 : 1; return rc; }
+        if (rc != METRPO_EUNSUPPORTED) {
+            c->last_rollout_kernel = (c->coop_cfg >= 0 && c->rollout_variant != 1) ? 2 : 1;
+            if (c->coop_cfg < 0 && c->rollout_variant == 0)
+                note_off_table(c, "the cooperative fused kernel (rollout_coop.hip) is instantiated for K = 5 heads, 2 x 64 dynamics, 2 x 32 policy of the six envs; this shape (K = " +
+                                  std::to_string(c->pd.K) + ") runs on the head-per-wave fused kernel (rollout_mfma.hip), ~2.9x the cooperative kernel's time at B = 5000");
+            return rc;
+        }
     }
     if (gemm_path_applicable(c)) {                                                           // large dynamics nets
         const int rc = launch_rollout_resident(c, a, (hipStream_t)stream);                   // ... at small batch: the whole time loop in one launch
@@ -262,8 +326,16 @@ extern "C" int32_t metrpo_rollout(metrpo_ctx* c, const metrpo_rollout_args* a, v
         return launch_rollout_gemm(c, a, (hipStream_t)stream);
     }
     c->last_rollout_kernel = 0;
+    {
+        std::string w;
+        for (int l = 1; l < c->pd.dyn.n_layers; ++l) w += (l > 1 ? "x" : "") + std::to_string(c->pd.dyn.dims[l]);
+        note_off_table(c, "dynamics hidden widths " + w + " have no matrix-core rollout kernel (fused kernels: two hidden layers of 64; GEMM / stream-K / resident paths: every "
+                          "hidden layer >= 128, ns <= 64): thread-per-env kernel (rollout_generic.hip), ~80x the fused kernels' time per env step");
+    }
     return launch_rollout_generic(c, a, (hipStream_t)stream);
 }
+// why the last metrpo_rollout of this context ran outside the fast dispatch table ("" when it did not)
+extern "C" const char* metrpo_rollout_note(const metrpo_ctx* c) { return c ? c->rollout_note.c_str() : ""; }
 // which kernel family the last metrpo_rollout of this context ran on (-1: none yet): 0 generic, 1 head-per-wave MFMA, 2 cooperative MFMA,
 // 3 step-wise GEMM, 4 resident (rollout_resident.hip), 5 step-wise with the stream-K fused ensemble kernel (mlp_streamk.h)
 extern "C" int32_t metrpo_last_rollout_kernel(const metrpo_ctx* c) { return c ? c->last_rollout_kernel : METRPO_ENULL; }
@@ -506,7 +578,7 @@ int run_trpo_update(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_para
 static bool device_line_search_ok(const metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_params* pr) {
     const bool xg = (pr->allreduce == nullptr && c->xg_world > 1);
     const bool fused = (pr->allreduce == nullptr && ((c->nccl_comm == nullptr && !xg) || (xg && !policy_gemm_applicable(c, b->N) && c->pd.P + 1 <= c->xg_cap)));
-    return fused && !policy_gemm_applicable(c, b->N) && getenv("METRPO_NO_DEVICE_LINESEARCH") == nullptr;
+    return fused && !policy_gemm_applicable(c, b->N) && ctx_opt(c, OPT_NO_DEVICE_LINESEARCH) == nullptr;
 }
 static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_params* pr, metrpo_trpo_diag* diag,
                                 double* g_out, double* dir_out, hipStream_t st, int phase, int spec) {
@@ -538,7 +610,7 @@ static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metr
     tl.op = 3;
     c->hcache_on = 1;                    // the gradient kernel publishes tanh activations, the CG products of this solve reuse them
     // ... and, when every CG vector comes out of a fused tail, its weight-fragment image; the tails add the tangent entries (policy_mfma.hip)
-    c->img_live = (fused && c->pol_mfma >= 0 && !policy_gemm_applicable(c, b->N) && getenv("METRPO_NO_IMGVAL") == nullptr) ? 1 : 0;
+    c->img_live = (fused && c->pol_mfma >= 0 && !policy_gemm_applicable(c, b->N) && ctx_opt(c, OPT_NO_IMGVAL) == nullptr) ? 1 : 0;
     struct CacheOff { metrpo_ctx* c; ~CacheOff() { c->hcache_on = 0; c->img_live = 0; } } cache_off{c};
     if (c->img_live) {
         if ((rc = policy_mfma_image_buffers(c))) return rc;

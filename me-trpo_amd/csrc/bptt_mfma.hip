@@ -378,9 +378,10 @@ __global__ void __launch_bounds__(256, 2) k_det_mfma(int K, int B, int T, double
 }
 
 // fixed-order sum of the per-tile cost partials of one model
-// err (may be NULL): sticky time-out cell of the rollout kernels' hand-overs (scal[S_ROLLERR]).  A resident validation launch whose grid was not
-// co-resident leaves invalid partial sums; callers of metrpo_validation_cost never read that cell (only metrpo_trpo_update / metrpo_comm_check
-// do), so the costs themselves carry the failure: NaN instead of plausible garbage feeding model selection and early stopping.
+// err (may be NULL): time-out cell of the launch that wrote the partials (val_err_cell: the resident validation launches; cleared in front of them).  A
+// resident validation launch whose grid was not co-resident leaves invalid partial sums; callers of metrpo_validation_cost read no error cell, so the
+// costs themselves carry the failure: NaN instead of plausible garbage feeding model selection and early stopping.  Every other producer of partials
+// passes NULL: an unrelated rollout's sticky time-out must not turn valid costs into NaN.
 __global__ void k_det_cost_reduce(int n_part, const double* __restrict__ part, double* __restrict__ costs, const double* __restrict__ err) {
     if (threadIdx.x == 0) {
         double s = 0.0;
@@ -391,8 +392,8 @@ __global__ void k_det_cost_reduce(int n_part, const double* __restrict__ part, d
 }
 
 // costs[k] = the n_part partials of model k added in index order (also the generic forward kernels' block sums: rollout_generic.hip, bptt.hip)
-int launch_det_cost_reduce(metrpo_ctx* c, int n_part, const double* part, double* costs, hipStream_t st) {
-    hipLaunchKernelGGL(k_det_cost_reduce, dim3(c->pd.K), dim3(64), 0, st, n_part, part, costs, (const double*)(c->d_cg ? comm_err_cell(c) + 1 : nullptr));
+int launch_det_cost_reduce(metrpo_ctx* c, int n_part, const double* part, double* costs, hipStream_t st, const double* err) {
+    hipLaunchKernelGGL(k_det_cost_reduce, dim3(c->pd.K), dim3(64), 0, st, n_part, part, costs, err);
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;
 }

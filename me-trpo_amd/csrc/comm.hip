@@ -179,7 +179,7 @@ extern "C" int32_t metrpo_comm_ipc_attach(metrpo_ctx* c, const void* blobs, int3
     }
     c->xg_world = world; c->xg_rank = rank; c->xg_seq = 0; c->xg_fuse = 0;
     long long ms = 20000;
-    if (const char* t = getenv("METRPO_XCHG_TIMEOUT_MS")) { const long long v = atoll(t); if (v > 0) ms = v; }
+    if (const char* t = ctx_opt(c, OPT_XCHG_TIMEOUT_MS)) { const long long v = atoll(t); if (v > 0) ms = v; }
     c->xg_timeout = (unsigned long long)ms * 100000ull;       // wall_clock64: 100 MHz
     return METRPO_OK;
 }

@@ -174,11 +174,12 @@ __global__ void __launch_bounds__(256) k_dg_pre_mfma3(ProblemDesc pd, int B, con
 }
 
 typedef void (*dg_pre_mfma_t)(ProblemDesc, int, const float*, const float*, const float*, long long, DgState);
-static dg_pre_mfma_t dg_pre_mfma_select(const ProblemDesc& pd, size_t* dyn_lds = nullptr) {
+static dg_pre_mfma_t dg_pre_mfma_select(const metrpo_ctx* c, size_t* dyn_lds = nullptr) {
+    const ProblemDesc& pd = c->pd;
     if (dyn_lds) *dyn_lds = 0;
     if (dyn_lds && pd.env == METRPO_ENV_HUMANOID && pd.ns == 55 && pd.na == 21 && pd.n_drop == 0 && pd.pol.n_layers == 4 && pd.pol.dims[1] == 100 &&
         pd.pol.dims[2] == 50 && pd.pol.dims[3] == 25 && pd.pol.act[0] == METRPO_ACT_TANH && pd.pol.act[1] == METRPO_ACT_TANH && pd.pol.act[2] == METRPO_ACT_TANH &&
-        getenv("METRPO_NO_PRE_MFMA3") == nullptr) {
+        ctx_opt(c, OPT_NO_PRE_MFMA3) == nullptr) {
         *dyn_lds = sizeof(float) * (size_t)(P3<55, 21, 100, 50, 25>::IMG + 4 * 16 * 55);
         return k_dg_pre_mfma3<55, 21, 0, 100, 50, 25>;
     }
@@ -392,7 +393,7 @@ bool det_gemm_applicable(const metrpo_ctx* c) {
 static int dg_fuse_tile(const metrpo_ctx* c, int B) {
     const ProblemDesc& pd = c->pd;
     const int L = pd.dyn.n_layers;
-    if (L < 2 || pd.dyn.act[L - 2] != METRPO_ACT_RELU || pd.dyn.act[L - 1] != METRPO_ACT_IDENTITY || getenv("METRPO_NO_FUSED_OUT") != nullptr) return 0;
+    if (L < 2 || pd.dyn.act[L - 2] != METRPO_ACT_RELU || pd.dyn.act[L - 1] != METRPO_ACT_IDENTITY || ctx_opt(c, OPT_NO_FUSED_OUT) != nullptr) return 0;
     return gemm_fused_out_tile(B, pd.dyn.dims[L - 1], pd.K, pd.ns);
 }
 static int dg_workspace(metrpo_ctx* c, int B, DgState* s) {
@@ -467,7 +468,7 @@ int launch_dg_forward(metrpo_ctx* c, const float* s0, int B, int T, double gamma
     if (psh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_dg_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psh));
     double g = 1.0;
     size_t pre_lds = 0;
-    const dg_pre_mfma_t pre_mfma = dg_pre_mfma_select(pd, &pre_lds);
+    const dg_pre_mfma_t pre_mfma = dg_pre_mfma_select(c, &pre_lds);
     if (pre_lds) {
         hipLaunchKernelGGL((k_pre_mfma3_image<55, 21, 100, 50, 25>), dim3((unsigned)((P3<55, 21, 100, 50, 25>::IMG + 255) / 256)), dim3(256), 0, st, c->d_theta, s.PIMG);
         if (pre_lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)pre_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pre_lds));
@@ -501,7 +502,7 @@ int launch_dg_backward(metrpo_ctx* c, int B, int T, const float* XS, const float
     if (bsh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_dg_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bsh));
     const long long xs_model = (long long)(T + 1) * B * pd.ns;
     size_t pre_lds = 0;
-    const dg_pre_mfma_t pre_mfma = dg_pre_mfma_select(pd, &pre_lds);
+    const dg_pre_mfma_t pre_mfma = dg_pre_mfma_select(c, &pre_lds);
     if (pre_lds) {
         hipLaunchKernelGGL((k_pre_mfma3_image<55, 21, 100, 50, 25>), dim3((unsigned)((P3<55, 21, 100, 50, 25>::IMG + 255) / 256)), dim3(256), 0, st, c->d_theta, s.PIMG);
         if (pre_lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)pre_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pre_lds));

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <atomic>
 #include "metrpo.h"
 #include "xchg_device.h"
 
@@ -31,6 +32,17 @@ struct ProblemDesc {
 };
 
 #define METRPO_MAX_PAR_ROUNDS 8
+// ---- variant / tuning switches of a context (metrpo_set_option / metrpo_get_option, include/metrpo.h) ----------------------------------------------
+// One table per context, read by the launch paths through ctx_opt(); metrpo_create fills the defaults ONCE from the environment (METRPO_<KEY>), nothing
+// else in the library reads the environment for kernel selection.  A key is the upper-case name below (the ABI also takes lower case and a METRPO_ prefix).
+#define METRPO_OPT_LIST(X) X(COOP_MODE) X(EXTRA_LDS) X(GEMM_PREFETCH) X(NO_DEVICE_LINESEARCH) X(NO_FUSED_OUT) X(NO_IMGVAL) X(NO_L0_ROWS) X(NO_MERGED_ROUNDS) X(NO_PRE_MFMA3) X(NO_RESIDENT) X(NO_RESIDENT_VALIDATION) X(NO_STEP_MERGE) X(NO_STREAMK) X(PG_HEAD_ROWS) X(PRE_GEMM) X(RESIDENT_NO_ROTATE) X(RESIDENT_NO_SENTINEL) X(RESIDENT_TEST_SKIP) X(RESIDENT_WS) X(RES_UNCACHED) X(SEQ_ROUNDS) X(SOLVE_BLOCK) X(STEP_MERGE) X(STREAMK) X(STREAMK_LATE) X(STREAMK_NO_XCD) X(UPD_TILES_PER_WAVE) X(VAL_CHUNKS) X(VAL_TILES_PER_WAVE) X(XCHG_TIMEOUT_MS) X(NO_PERSIST) X(PERSIST) X(QUIET)
+enum MetrpoOpt {
+#define X(n) OPT_##n,
+    METRPO_OPT_LIST(X)
+#undef X
+    OPT_COUNT
+};
+
 struct metrpo_ctx {
     int device;
     metrpo_dims dims;
@@ -104,8 +116,17 @@ struct metrpo_ctx {
     int upd_tiles_per_wave;   // MFMA update kernels: at least this many 16-sample tiles per wave before another block is added (METRPO_UPD_TILES_PER_WAVE)
     int n_cu_sched;      // CUs that actually ran this process's waves (probe.hip: census; 0 = not measured yet)
     int exclusive;       // 0: the GPU is shared with other compute processes (metrpo_set_exclusive; METRPO_NO_RESIDENT=1 in the environment means the same)
+    std::string opt_val[OPT_COUNT]; bool opt_set[OPT_COUNT];   // METRPO_OPT_LIST: set by metrpo_create from the environment, then only by metrpo_set_option
+    std::string rollout_note;   // why the last metrpo_rollout left the fast dispatch table ("" when it did not): metrpo_rollout_note
+    int fallback_logged;  // a rollout shape that fell off the fast dispatch table has been reported once (METRPO_VERBOSE)
     std::string err;
 };
+
+// value of a switch, NULL when unset -- the same contract as the getenv() calls these replaced
+static inline const char* ctx_opt(const metrpo_ctx* c, int id) { return c->opt_set[id] ? c->opt_val[id].c_str() : nullptr; }
+inline std::atomic<int> g_gemm_prefetch_off{0};     // option GEMM_PREFETCH (process-wide: gemm_mfma.h's dispatch has no context)
+const char* metrpo_opt_name(int id);
+int metrpo_opt_id(const char* key);       // -1: unknown
 
 struct RolloutK {          // device-side copy of metrpo_rollout_args (plain pointers)
     int B, T, H, sam_mode, determ, eval_all, n_pool;
@@ -187,7 +208,7 @@ int launch_det_forward(metrpo_ctx*, int idx, const float* s0, int B, int T, doub
 int launch_det_backward(metrpo_ctx*, int idx, int B, int T, const float* XS, const float* WT, float* GM, hipStream_t);
 int ensure_detpart(metrpo_ctx*, int B);
 int ensure_detpart_n(metrpo_ctx*, size_t n_doubles);
-int launch_det_cost_reduce(metrpo_ctx*, int n_part, const double* part, double* costs, hipStream_t);
+int launch_det_cost_reduce(metrpo_ctx*, int n_part, const double* part, double* costs, hipStream_t, const double* err = nullptr);   // err: time-out cell of the launch that wrote the partials (NaN costs when set)
 int launch_validation_resident(metrpo_ctx*, const float* s0, int Bv, int T, double gamma, double* costs, hipStream_t);   // rollout_resident.hip; METRPO_EUNSUPPORTED: not this shape
 bool det_gemm_applicable(const metrpo_ctx*);
 int launch_dg_forward(metrpo_ctx*, const float* s0, int B, int T, double gamma, float* XS, float* WT, double* costs, hipStream_t);
@@ -217,6 +238,9 @@ XchgK xchg_next(metrpo_ctx*);
 static inline XchgK xchg_none() { XchgK x = {}; return x; }
 // scal[S_COMMERR] of the CG workspace (gout[1+P] | x r p z step [5P] | scal[8] | lk[2]): sticky error cell of the exchanges
 static inline double* comm_err_cell(metrpo_ctx* c) { return c->d_cg + (size_t)(1 + c->pd.P) + 5 * (size_t)c->pd.P + 6; }
+// time-out cell of the resident VALIDATION launches (behind scal | lk | ls): cleared in front of every such launch, so an earlier rollout's sticky S_ROLLERR
+// cannot poison validation costs and a validation time-out cannot be mistaken for a rollout's
+static inline double* val_err_cell(metrpo_ctx* c) { return comm_err_cell(c) + 8; }
 // A rollout kernel reported a timed-out hand-over (scal[S_ROLLERR]): the trajectories of that launch are invalid.  The cell is cleared so the
 // context can go on, and the resident kernel -- the one whose hand-overs need every workgroup of its grid on the chip at once -- is retired.
 static inline int rollout_error_seen(metrpo_ctx* c, hipStream_t st) {

@@ -555,11 +555,9 @@ static inline hipError_t sk_build_sched(SkArgs& a, const SkPlan& p, void* mem, h
 template <int AMODE, int EPI, int S0, int OT>
 static inline hipError_t sk_launch(const SkArgs& a, const SkPlan& p, hipStream_t st) {
     auto kern = k_mlp_sk<AMODE, EPI, S0, OT>;
-    static size_t attr_set = 0;
-    if (p.lds_bytes > attr_set) {
+    {   // every launch (the attribute belongs to the CURRENT device and the call is cheap: a process-wide cache broke a second context on another GPU)
         const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
         if (e != hipSuccess) return e;
-        attr_set = p.lds_bytes;
     }
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(512), p.lds_bytes, st, a);
     return hipGetLastError();
@@ -647,8 +645,7 @@ template <int S0> static inline hipError_t l0_rows_launch(L0Args a, int n_cu, hi
     a.rows_per_wg = ((rb + a.nsplit - 1) / a.nsplit) * 128;
     const size_t lds = (size_t)S0 * 1024 * sizeof(float);
     auto kern = k_l0_rows<S0>;
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) { const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; attr_set = true; }
+    if (lds > 64 * 1024) { const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(kern, dim3(pairs * a.nsplit), dim3(512), lds, st, a);
     return hipGetLastError();
 }

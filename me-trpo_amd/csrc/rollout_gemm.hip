@@ -519,10 +519,11 @@ __global__ void __launch_bounds__(256) k_big_pre_action(ProblemDesc pd, RolloutK
 }
 
 typedef void (*big_pre_mfma_t)(ProblemDesc, RolloutK, int, const float*, const float*, BigState);
-static big_pre_mfma_t big_pre_mfma_select(const ProblemDesc& pd, size_t* dyn_lds, bool post = false) {
+static big_pre_mfma_t big_pre_mfma_select(const metrpo_ctx* c, size_t* dyn_lds, bool post = false) {
+    const ProblemDesc& pd = c->pd;
     *dyn_lds = 0;
     if (pd.env == METRPO_ENV_HUMANOID && pd.ns == 55 && pd.na == 21 && pd.n_drop == 0 && pd.pol.n_layers == 4 && pd.pol.dims[1] == 100 && pd.pol.dims[2] == 50 &&
-        pd.pol.dims[3] == 25 && pd.pol.act[0] == METRPO_ACT_TANH && pd.pol.act[1] == METRPO_ACT_TANH && pd.pol.act[2] == METRPO_ACT_TANH && getenv("METRPO_NO_PRE_MFMA3") == nullptr) {
+        pd.pol.dims[3] == 25 && pd.pol.act[0] == METRPO_ACT_TANH && pd.pol.act[1] == METRPO_ACT_TANH && pd.pol.act[2] == METRPO_ACT_TANH && ctx_opt(c, OPT_NO_PRE_MFMA3) == nullptr) {
         *dyn_lds = big_pre_mfma3_lds<55, 21, 0, 100, 50, 25>();
         return post ? k_big_pre_mfma3<55, 21, 0, 100, 50, 25, true> : k_big_pre_mfma3<55, 21, 0, 100, 50, 25, false>;
     }
@@ -715,9 +716,9 @@ static SkPath sk_select(const metrpo_ctx* c, int B) {
     SkPath sp = {};
     const ProblemDesc& pd = c->pd;
     const int L = pd.dyn.n_layers, K = pd.K;
-    const char* fe = getenv("METRPO_STREAMK");                               // "1": also below one tile per CU (tests at oracle-sized batches)
+    const char* fe = ctx_opt(c, OPT_STREAMK);                               // "1": also below one tile per CU (tests at oracle-sized batches)
     const bool force = fe != nullptr && fe[0] == '1';
-    if (getenv("METRPO_NO_STREAMK") != nullptr || L < 3 || L > 4 || pd.ns > 64) return sp;
+    if (ctx_opt(c, OPT_NO_STREAMK) != nullptr || L < 3 || L > 4 || pd.ns > 64) return sp;
     for (int l = 0; l < L - 1; ++l) if (pd.dyn.act[l] != METRPO_ACT_RELU) return sp;
     if (pd.dyn.act[L - 1] != METRPO_ACT_IDENTITY) return sp;
     const int K1 = pd.dyn.dims[L - 2], N = pd.dyn.dims[L - 1];            // the layer in front of the output layer: [K1 x N]
@@ -728,7 +729,7 @@ static SkPath sk_select(const metrpo_ctx* c, int B) {
     // pieces, and the hand-overs at the END of the pieces (store + drain + flag + four load passes, ~9 us per link) form a chain of 2-3 links after
     // the last matrix instruction.  So it is not selected by itself: METRPO_STREAMK_LATE=1 selects it from 8 chunks per workgroup up, forced launches
     // (METRPO_STREAMK=1: the parity tests) use it from 2 up, METRPO_STREAMK_LATE=0 never (forced launches then run one unsplit tile per workgroup).
-    const char* le = getenv("METRPO_STREAMK_LATE");
+    const char* le = ctx_opt(c, OPT_STREAMK_LATE);
     const bool late_ok = (le != nullptr) ? le[0] == '1' : force;
     auto late_for = [&](int K1_, int N_, int epi_units) -> int {
         const long long tiles = (long long)K * ((B + 127) / 128) * (N_ / 256), units = tiles * (K1_ / 32 + epi_units);
@@ -737,7 +738,7 @@ static SkPath sk_select(const metrpo_ctx* c, int B) {
     const int epi_units = (sp.OT == 4) ? 2 : 1;
     if (!force && (long long)K * ((B + 127) / 128) * (N / 256) < c->n_sm && !late_for(K1, N, epi_units)) return sp;
     auto shape = [&](SkArgs& a, int K1_, int N_, int eu) { a = SkArgs{}; a.M = B; a.heads = K; a.K1 = K1_; a.N = N_; a.late = late_for(K1_, N_, eu);
-                                                             a.xcd = getenv("METRPO_STREAMK_NO_XCD") == nullptr ? 8 : 0; };      // MI355X: 8 XCDs, workgroups dealt round-robin
+                                                             a.xcd = ctx_opt(c, OPT_STREAMK_NO_XCD) == nullptr ? 8 : 0; };      // MI355X: 8 XCDs, workgroups dealt round-robin
     if (L == 3) {
         sp.S0 = (pd.nin + 1 + 3) / 4;
         const bool fused = sk_fused_vt(sp.S0, sp.OT, &sp.v1);                   // layer 0 as producer: inputs of up to 36 values (Humanoid's 76 + 1: mode 3)
@@ -760,6 +761,8 @@ static SkPath sk_select(const metrpo_ctx* c, int B) {
     }
     // element offsets of the schedule records are 32 bits
     if ((long long)K * pd.dyn.n_params >= (1LL << 31) || (long long)K * B * std::max(K1, N) >= (1LL << 31)) { sp.mode = 0; return sp; }
+    // ... and the kernel forms BYTE offsets of a row inside one head's activations / outputs in 32 bits (a_voff, the STORE and partial-output rows)
+    if ((long long)B * std::max(std::max(K1, N), 64) * 4 >= (1LL << 32)) { sp.mode = 0; return sp; }
     return sp;
 }
 
@@ -783,7 +786,7 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
     // stored layer 0 (modes 2, 3) by k_l0_rows: the bias rides as input row n_in, as for the producer of mode 1 (METRPO_NO_L0_ROWS: the tile GEMM)
     const int S0all = (pd.nin + 1 + 3) / 4;
     const bool l0r = sk.mode >= 2 && l0_rows_ok(S0all) && pd.dyn.dims[1] % 256 == 0 && pd.dyn.act[0] == METRPO_ACT_RELU &&
-                     pd.dyn.b_off[0] == pd.dyn.w_off[0] + pd.nin * pd.dyn.dims[1] && getenv("METRPO_NO_L0_ROWS") == nullptr;
+                     pd.dyn.b_off[0] == pd.dyn.w_off[0] + pd.nin * pd.dyn.dims[1] && ctx_opt(c, OPT_NO_L0_ROWS) == nullptr;
     const int ldx = (sk.mode == 1) ? 4 * sk.S0 : (l0r ? 4 * S0all : ((pd.nin + 3) & ~3));
     const size_t nS = up4((size_t)B * pd.ns), nX = up4((size_t)B * ldx), nU = up4((size_t)B * pd.na), nH = (sk.mode == 1) ? 0 : up4((size_t)K * B * maxh), nO = up4((size_t)K * B * pd.ns);
     size_t nP = 0;
@@ -800,23 +803,23 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
     }
     // last hidden layer + output layer as ONE launch when the hidden layer runs on 64x64 tiles anyway (C0-params-file, C2, C3 shapes): its
     // activations (K x B x width floats: 51 MB at C3) are then neither written nor read back; k_big_post adds the width/64 partials
-    const int fuse_tile = (!sk.mode && L >= 2 && pd.dyn.act[L - 2] == METRPO_ACT_RELU && pd.dyn.act[L - 1] == METRPO_ACT_IDENTITY && getenv("METRPO_NO_FUSED_OUT") == nullptr)
+    const int fuse_tile = (!sk.mode && L >= 2 && pd.dyn.act[L - 2] == METRPO_ACT_RELU && pd.dyn.act[L - 1] == METRPO_ACT_IDENTITY && ctx_opt(c, OPT_NO_FUSED_OUT) == nullptr)
                               ? gemm_fused_out_tile(B, pd.dyn.dims[L - 1], K, pd.ns) : 0;
     const bool fuse_out = fuse_tile > 0;
     if (fuse_out) nP = std::max(nP, up4(gemm_fused_out_part_floats(B, pd.dyn.dims[L - 1], K, pd.ns, fuse_tile)));
     size_t pre_lds = 0;
-    const big_pre_mfma_t pre_mfma = big_pre_mfma_select(pd, &pre_lds);
+    const big_pre_mfma_t pre_mfma = big_pre_mfma_select(c, &pre_lds);
     // steps t >= 1: k_big_post(t - 1) rides in the pre-step's launch (the MFMA pre-kernels: 2 x 32 policies and Humanoid's 100-50-25; METRPO_NO_STEP_MERGE=1 keeps the two launches: A/B runs, tests)
     size_t pre_lds_post = 0;
     // (Humanoid's 55 dims are 16 per lane in that layout: behind the tile GEMMs' 16 output partials per head -- small batches -- the closing part is slower
     //  than k_big_post's lane per dim, 12.9 vs 11.1 ms per params-file rollout; behind stream-K's 4 partials it is merged.  METRPO_STEP_MERGE=1 forces it: tests)
-    const bool merge_ok = getenv("METRPO_NO_STEP_MERGE") == nullptr && (pd.ns <= 32 || sk.mode != 0 || getenv("METRPO_STEP_MERGE") != nullptr);
-    const big_pre_mfma_t pre_post = (pre_mfma && merge_ok) ? big_pre_mfma_select(pd, &pre_lds_post, true) : nullptr;
+    const bool merge_ok = ctx_opt(c, OPT_NO_STEP_MERGE) == nullptr && (pd.ns <= 32 || sk.mode != 0 || ctx_opt(c, OPT_STEP_MERGE) != nullptr);
+    const big_pre_mfma_t pre_post = (pre_mfma && merge_ok) ? big_pre_mfma_select(c, &pre_lds_post, true) : nullptr;
     // policies without an MFMA pre-kernel: GEMM chain over the batch from B = 1024 up -- and at ANY batch when the policy is large
     // (k_big_pre walks the weights through scalar loads, one block's time whatever B: 302 us per step for Humanoid's 100-50-25 at B = 100,
     // the params-humanoid.json shape, against ~40 us for the six small launches of the chain: iteration 77 -> 28 ms)
     // (METRPO_PRE_GEMM=1 forces it, =0 forbids it: tests)
-    const char* pg_env = getenv("METRPO_PRE_GEMM");
+    const char* pg_env = ctx_opt(c, OPT_PRE_GEMM);
     const bool pre_gemm = !pre_mfma && ((pg_env && pg_env[0] == '1') || (!(pg_env && pg_env[0] == '0') && (B >= 1024 || pd.pol.n_params >= 4096)));
     const size_t nPol = pre_gemm ? up4((size_t)B * pd.pol.max_width) : 0;
     const size_t nPimg = pre_lds ? up4((size_t)pre_mfma3_image_floats<55, 21, 100, 50, 25>()) : 0;      // the only three-hidden-layer instantiation (big_pre_mfma_select)
@@ -987,11 +990,11 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
     const int R = (H > 0 && a->T % H == 0) ? a->T / H : 1;
     const bool par = R >= 2 && R <= METRPO_MAX_PAR_ROUNDS && pd.env != METRPO_ENV_ANT && (long long)pd.K * B <= 8192 &&
                      a->t0 == 0 && a->d_init_obs == nullptr && a->d_stop == nullptr && a->d_eps == nullptr && a->d_model_idx == nullptr &&
-                     a->d_sel_noise == nullptr && a->d_reset_idx == nullptr && a->d_reset_model == nullptr && getenv("METRPO_SEQ_ROUNDS") == nullptr;
+                     a->d_sel_noise == nullptr && a->d_reset_idx == nullptr && a->d_reset_model == nullptr && ctx_opt(c, OPT_SEQ_ROUNDS) == nullptr;
     // Small batches (R B <= 1024 rows): the rounds as ONE batch of R B envs stepping H times -- one launch chain instead of R concurrent ones, and
     // GEMMs over R B rows instead of R GEMMs over B (B = 100 fills 100 of 128 tile rows, 500 fill 500 of 512; params-humanoid.json: 27.7 -> see DESIGN).
     // Row b of the merged batch = env b % B of round b / B (RolloutK::vB / vR); same draws, same trajectory rows as the round-by-round loop.
-    const bool merged = par && (long long)R * B <= 1024 && getenv("METRPO_NO_MERGED_ROUNDS") == nullptr;
+    const bool merged = par && (long long)R * B <= 1024 && ctx_opt(c, OPT_NO_MERGED_ROUNDS) == nullptr;
     size_t need1 = 0;
     {
         metrpo_rollout_args probe = *a;

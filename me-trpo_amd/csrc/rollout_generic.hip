@@ -351,7 +351,7 @@ int launch_validation_cost(metrpo_ctx* c, const float* s0, int Bv, int T, double
         return launch_det_forward(c, c->det_cfg, s0, Bv, T, gamma, nullptr, nullptr, c->d_detpart, costs, st);
     }
     if (c->det_gemm) {                                       // large nets: the resident kernel's validation mode where its table has the shape, else the GEMM-path sweep (det_gemm.hip)
-        if (getenv("METRPO_NO_RESIDENT_VALIDATION") == nullptr) {
+        if (ctx_opt(c, OPT_NO_RESIDENT_VALIDATION) == nullptr) {
             const int rcr = launch_validation_resident(c, s0, Bv, T, gamma, costs, st);
             if (rcr != METRPO_EUNSUPPORTED) return rcr;
         }

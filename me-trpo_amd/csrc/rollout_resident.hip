@@ -1031,7 +1031,7 @@ static const ResidentEntry* resident_table(int* n) {
 // METRPO_EUNSUPPORTED: this shape / call stays on the step-wise path (rollout_gemm.hip)
 int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t st) {
     const ProblemDesc& pd = c->pd;
-    if (c->rollout_variant == 1 || c->res_failed || !c->exclusive || getenv("METRPO_NO_RESIDENT") != nullptr) return METRPO_EUNSUPPORTED;
+    if (c->rollout_variant == 1 || c->res_failed || !c->exclusive || ctx_opt(c, OPT_NO_RESIDENT) != nullptr) return METRPO_EUNSUPPORTED;
     if (pd.dyn.n_layers != 3 || pd.dyn.dims[1] != pd.dyn.dims[2] || pd.dyn.act[0] != METRPO_ACT_RELU || pd.dyn.act[1] != METRPO_ACT_RELU ||
         pd.dyn.act[2] != METRPO_ACT_IDENTITY) return METRPO_EUNSUPPORTED;
     if (pd.pol.n_layers != 3 || pd.pol.dims[1] != 32 || pd.pol.dims[2] != 32 || pd.pol.act[0] != METRPO_ACT_TANH || pd.pol.act[1] != METRPO_ACT_TANH)
@@ -1047,7 +1047,7 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
     // rounds of a horizon-terminated rollout are independent given the counter-based draws (see launch_rollout_gemm): they run side by side
     int R = 1;
     if (H > 0 && a->T % H == 0 && a->T / H >= 2 && pd.env != METRPO_ENV_ANT && a->t0 == 0 && a->d_init_obs == nullptr && a->d_stop == nullptr &&
-        getenv("METRPO_SEQ_ROUNDS") == nullptr) R = a->T / H;
+        ctx_opt(c, OPT_SEQ_ROUNDS) == nullptr) R = a->T / H;
     const int steps = a->T / R;
     int n = 0;
     const ResidentEntry* tab = resident_table(&n);
@@ -1065,7 +1065,7 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
     };
     // (the post wave adds the slices in batches of 16: DH / ws must be a multiple of 16)
     auto matches = [&](const ResidentEntry& e) { return e.env == pd.env && e.ns == pd.ns && e.na == pd.na && e.n_drop == pd.n_drop && e.dh == DH && (DH / e.ws) % 16 == 0; };
-    const char* ws_env = getenv("METRPO_RESIDENT_WS");                // test hook: pin the slice width (results are bit-identical only at equal widths)
+    const char* ws_env = ctx_opt(c, OPT_RESIDENT_WS);                // test hook: pin the slice width (results are bit-identical only at equal widths)
     const ResidentEntry* widest = nullptr;
     for (int i = 0; i < n && !pick; ++i) {
         if (!matches(tab[i]) || (ws_env != nullptr && atoi(ws_env) != tab[i].ws)) continue;
@@ -1079,7 +1079,7 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
     if (!grid_is_coresident(c, (const void*)pick->fn, pick->threads, pick->lds, 1, st)) return METRPO_EUNSUPPORTED;      // >= one workgroup per CU, exclusive device
     const int NSL = DH / pick->ws, OUT_CB = (pd.ns + 15) / 16, NIN_KS = (pd.nin + 1 + 3) / 4;
     // rotating deal (ResidentK::rot): launches of the 4-wave form whose few tiles do not divide by the columns; one partial-sum region per column
-    const bool may_rot = pick->threads == 256 && pick->fn_rot != nullptr && getenv("METRPO_RESIDENT_NO_ROTATE") == nullptr;
+    const bool may_rot = pick->threads == 256 && pick->fn_rot != nullptr && ctx_opt(c, OPT_RESIDENT_NO_ROTATE) == nullptr;
     const int max_cols = std::max(1, n_cu / (K * (DH / pick->ws)));
     const size_t nX = (size_t)Rg * NT * 4 * NIN_KS * 16, nP = (size_t)Rg * NT * K * NSL * 16 * OUT_CB * 16 * (may_rot ? max_cols : 1);
     const size_t need = (nX + nP + 32) * sizeof(unsigned long long);
@@ -1092,7 +1092,7 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
         // life still sitting in one XCD's L2: seen as a step-wise rollout (rollout_gemm.hip) of a LATER engine reading two stale cache lines of
         // its fresh workspace, gone after evicting the L2s (tests/test_gpu_resident.py::test_stepwise_workspace_after_freed_resident_regions).
         // METRPO_RES_UNCACHED=1 brings the uncached flavour back (reproducing the above).
-        if (getenv("METRPO_RES_UNCACHED") != nullptr) HIP_TRY(c, hipExtMallocWithFlags(&c->d_res, need, hipDeviceMallocUncached));
+        if (ctx_opt(c, OPT_RES_UNCACHED) != nullptr) HIP_TRY(c, hipExtMallocWithFlags(&c->d_res, need, hipDeviceMallocUncached));
         else HIP_TRY(c, hipMalloc(&c->d_res, need));
         HIP_TRY(c, hipMemsetAsync(c->d_res, 0, need, st));
         c->res_cap = need; c->res_seq = 0;
@@ -1123,8 +1123,8 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
         z.skip_block = -1;
         // few tiles per column (Ant's chunks, single rounds): the step is a latency chain and the post wave's polling rounds are on it; with many tiles per
         // column the partial sums are there before the post wave looks, and the extra round trip of the sentinel read costs 2 - 4 % (half-cheetah, 5 rounds)
-        z.sentinel = (pick->threads == 256 && z.NTC <= 4 && getenv("METRPO_RESIDENT_NO_SENTINEL") == nullptr) ? 1 : 0;
-        if (const char* sk = getenv("METRPO_RESIDENT_TEST_SKIP")) z.skip_block = atoi(sk);
+        z.sentinel = (pick->threads == 256 && z.NTC <= 4 && ctx_opt(c, OPT_RESIDENT_NO_SENTINEL) == nullptr) ? 1 : 0;
+        if (const char* sk = ctx_opt(c, OPT_RESIDENT_TEST_SKIP)) z.skip_block = atoi(sk);
         z.abort_cell = (unsigned int*)c->d_res;
         z.X = (unsigned long long*)c->d_res + 32; z.P = z.X + nX;
         z.err = comm_err_cell(c) + 1;                               // scal[S_ROLLERR]
@@ -1154,7 +1154,7 @@ int launch_validation_resident(metrpo_ctx* c, const float* s0, int Bv, int T, do
         RES_VAL_ENTRY(METRPO_ENV_ANT, 1024, 64),
     };
     const ProblemDesc& pd = c->pd;
-    if (c->res_failed || !c->exclusive || getenv("METRPO_NO_RESIDENT") != nullptr || T <= 0) return METRPO_EUNSUPPORTED;
+    if (c->res_failed || !c->exclusive || ctx_opt(c, OPT_NO_RESIDENT) != nullptr || T <= 0) return METRPO_EUNSUPPORTED;
     if (pd.dyn.n_layers != 3 || pd.dyn.dims[1] != pd.dyn.dims[2] || pd.dyn.act[0] != METRPO_ACT_RELU || pd.dyn.act[1] != METRPO_ACT_RELU ||
         pd.dyn.act[2] != METRPO_ACT_IDENTITY) return METRPO_EUNSUPPORTED;
     if (pd.pol.n_layers != 3 || pd.pol.dims[1] != 32 || pd.pol.dims[2] != 32 || pd.pol.act[0] != METRPO_ACT_TANH || pd.pol.act[1] != METRPO_ACT_TANH)
@@ -1175,8 +1175,8 @@ int launch_validation_resident(metrpo_ctx* c, const float* s0, int Bv, int T, do
     int nb = 0, NTM = 0, NTC = 0, cols = 0, ntw_i = 0;
     double best = 1e30;
     const double t_tile = (DH >= 1024) ? 6.1 : 2.0, t_trip = 8.0, t_post = 3.0, t_launch = 60.0;
-    const char* ntw_env = getenv("METRPO_VAL_TILES_PER_WAVE");              // test hook: 1 | 2 | 4
-    const char* chunks_env = getenv("METRPO_VAL_CHUNKS");                   // test hook: number of batch chunks (launches), 1 .. 8
+    const char* ntw_env = ctx_opt(c, OPT_VAL_TILES_PER_WAVE);              // test hook: 1 | 2 | 4
+    const char* chunks_env = ctx_opt(c, OPT_VAL_CHUNKS);                   // test hook: number of batch chunks (launches), 1 .. 8
     for (int wi = 0; wi < 3; ++wi) {
         const int ntw = 1 << wi;
         if (ntw_env != nullptr && atoi(ntw_env) != ntw) continue;
@@ -1210,6 +1210,7 @@ int launch_validation_resident(metrpo_ctx* c, const float* s0, int Bv, int T, do
     { const int rc = ensure_detpart_n(c, (size_t)K * nb * NTM); if (rc) return rc; }
     if (e->lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)e->fn[ntw_i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds));
     if (!grid_is_coresident(c, (const void*)e->fn[ntw_i], 256, e->lds, (long long)cols * K * NSL + post_blocks, st)) return METRPO_EUNSUPPORTED;
+    HIP_TRY(c, hipMemsetAsync(val_err_cell(c), 0, sizeof(double), st));       // this launch chain's own time-out cell (read by k_det_cost_reduce below)
     for (int ch = 0; ch < nb; ++ch) {
         const int b_lo = ch * Bc, bn = std::min(Bc, Bv - b_lo);
         ResidentK z;
@@ -1220,9 +1221,9 @@ int launch_validation_resident(metrpo_ctx* c, const float* s0, int Bv, int T, do
         z.skip_block = -1; z.sentinel = 0;
         z.abort_cell = (unsigned int*)c->d_res;
         z.X = (unsigned long long*)c->d_res + 32; z.P = z.X + nX;
-        z.err = comm_err_cell(c) + 1;
+        z.err = val_err_cell(c);
         hipLaunchKernelGGL(e->fn[ntw_i], dim3(z.U + post_blocks), dim3(256), e->lds, st, pd, std::max(bn, 0), z, c->d_dyn, c->d_theta, c->d_norm);
     }
     HIP_TRY(c, hipGetLastError());
-    return launch_det_cost_reduce(c, nb * NTM, c->d_detpart, costs, st);
+    return launch_det_cost_reduce(c, nb * NTM, c->d_detpart, costs, st, val_err_cell(c));
 }

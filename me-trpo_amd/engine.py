@@ -166,6 +166,30 @@ class Engine(object):
         launch (resident rollout / validation, migrating tiles) are never selected.  Default True."""
         self._chk(lib.metrpo_set_exclusive(self._ctx, int(bool(exclusive))))
 
+    def set_option(self, key, value=None):
+        """Variant / tuning switch of THIS engine (`metrpo_set_option`): `key` is one of `Engine.option_names()` (the former METRPO_<KEY> environment
+        variables; the environment only fills the defaults when the engine is created), `value` a string / number, None unsets.  Read at the next launch."""
+        self._chk(lib.metrpo_set_option(self._ctx, str(key).encode(), None if value is None else str(value).encode()))
+
+    def get_option(self, key):
+        """Current value of a switch as a string, None when unset."""
+        buf = C.create_string_buffer(256)
+        n = lib.metrpo_get_option(self._ctx, str(key).encode(), buf, 256)
+        if n == -1:
+            return None
+        if n < 0:
+            self._chk(n)
+        return buf.value.decode()
+
+    @staticmethod
+    def option_names():
+        out, i = [], 0
+        while True:
+            nm = lib.metrpo_option_name(i)
+            if nm is None:
+                return out
+            out.append(nm.decode()); i += 1
+
     def schedulable_cus(self):
         """CUs that actually run this process's waves (a census kernel; CU masks and partitions count), measured once per engine."""
         return int(lib.metrpo_schedulable_cus(self._ctx, self._stream()))
@@ -307,9 +331,13 @@ class Engine(object):
     def last_rollout_kernel(self):
         """Kernel family the last rollout() of this engine ran on: 'generic', 'mfma-head-per-wave', 'mfma-cooperative', 'gemm-stepwise',
         'resident' (whole time loop in one launch, rollout_resident.hip), 'gemm-streamk' (step-wise, the whole ensemble of a step in one
-        evenly split launch, mlp_streamk.h); None before the first rollout."""
+        evenly split launch, mlp_streamk.h), 'streamk-persistent' (all steps of a chunk in one launch, rollout_persist.hip); None before the first rollout."""
         k = int(lib.metrpo_last_rollout_kernel(self._ctx))
-        return {0: 'generic', 1: 'mfma-head-per-wave', 2: 'mfma-cooperative', 3: 'gemm-stepwise', 4: 'resident', 5: 'gemm-streamk'}.get(k)
+        return {0: 'generic', 1: 'mfma-head-per-wave', 2: 'mfma-cooperative', 3: 'gemm-stepwise', 4: 'resident', 5: 'gemm-streamk', 6: 'streamk-persistent'}.get(k)
+
+    def rollout_note(self):
+        """Why the last rollout() ran outside the fast dispatch table (K != 5 at 2x64, hidden widths 65..127, ...); '' when it did not."""
+        return lib.metrpo_rollout_note(self._ctx).decode()
 
     def alloc_trajectory(self, B, T, H):
         dev, f = self.device, torch.float32

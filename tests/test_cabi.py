@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(_lib.lib, n), "libmetrpo.so does not export %s" % n
         assert n in _lib.SYMBOLS, "%s is declared in metrpo.h but not bound in _lib.SYMBOLS" % n
     assert set(_lib.SYMBOLS) == set(names)
-    assert _lib.lib.metrpo_abi_version() == 3
+    assert _lib.lib.metrpo_abi_version() == 4
 
 
 def test_struct_layouts_match_header():
@@ -73,3 +73,24 @@ def test_product_never_imports_oracle():
             if f.endswith(('.py', '.hip', '.h', '.cpp')):
                 txt = open(os.path.join(root, f)).read()
                 assert not re.search(r'(import|from)\s+oracle|oracle\.|oracle/', txt), "%s references the oracle" % f
+
+
+def test_option_table_is_enumerable_and_the_library_reads_the_environment_in_one_place():
+    """ABI 4: kernel-selection switches are per-context options (metrpo_set_option / metrpo_get_option); the environment only fills the defaults
+    inside metrpo_create.  Without a GPU: the key table, the NULL-context status, and a source check that no launch path calls getenv."""
+    from metrpo_amd import _lib
+    lib = _lib.lib
+    names = []
+    while lib.metrpo_option_name(len(names)) is not None:
+        names.append(lib.metrpo_option_name(len(names)).decode())
+    assert {'STREAMK', 'NO_STREAMK', 'NO_RESIDENT', 'SEQ_ROUNDS', 'PRE_GEMM', 'UPD_TILES_PER_WAVE', 'QUIET'} <= set(names)
+    assert len(names) == len(set(names)) >= 30
+    assert lib.metrpo_set_option(None, b'STREAMK', b'1') == -2 and lib.metrpo_get_option(None, b'STREAMK', None, 0) == -2      # METRPO_ENULL
+    csrc = os.path.join(REPO, 'me-trpo_amd', 'csrc')
+    sites = []
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith(('.hip', '.h')):
+            for ln, line in enumerate(open(os.path.join(csrc, fn)), 1):
+                if re.search(r'\bgetenv\s*\(', line) and not line.lstrip().startswith('//'):
+                    sites.append((fn, ln))
+    assert [f for f, _ in sites] == ['api.hip', 'trace.hip'], sites       # metrpo_create's default fill; the roctx tracing switch (process-wide, not kernel selection)

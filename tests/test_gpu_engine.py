@@ -539,11 +539,11 @@ def test_gemm_rollout_wide_policy_gemm_prestep(draws, monkeypatch):
     if draws:
         dr = Hh.draws(np.random.RandomState(5), K, B, T, dm.ns, dm.na, len(pool))
         kw = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in dr.items()}
-    monkeypatch.setenv('METRPO_PRE_GEMM', '0')
+    eng.set_option('METRPO_PRE_GEMM', '0')
     blocks = eng.rollout(B, T, H, 'step_rand', pool, seed=3, **kw)
     ref = {k: cpu(getattr(blocks, k)).copy() for k in ('obs', 'act', 'mean', 'rew')}
     ref_done = blocks.done.clone()
-    monkeypatch.setenv('METRPO_PRE_GEMM', '1')
+    eng.set_option('METRPO_PRE_GEMM', '1')
     gemm = eng.rollout(B, T, H, 'step_rand', pool, seed=3, **kw)
     for k in ref:
         np.testing.assert_allclose(cpu(getattr(gemm, k)), ref[k], **TOL.CROSS_KERNEL, err_msg=k)
@@ -566,11 +566,11 @@ def test_gemm_rollout_fused_output_layer_equals_separate_layers(env, K, B, hidde
     T, H = 4, 3
     eng, dm, theta, pdims, pool = Hh.make_engine(env, K, hidden, (32, 32) if env != 'humanoid' else (100, 50, 25), seed=29)
     assert eng.set_rollout_variant(0) == 3
-    monkeypatch.setenv('METRPO_NO_FUSED_OUT', '1')
+    eng.set_option('METRPO_NO_FUSED_OUT', '1')
     sep = eng.rollout(B, T, H, 'model_mean', pool, seed=9)
     ref = {k: cpu(getattr(sep, k)).copy() for k in ('obs', 'act', 'rew')}
     ref_done = sep.done.clone()
-    monkeypatch.delenv('METRPO_NO_FUSED_OUT')
+    eng.set_option('METRPO_NO_FUSED_OUT', None)
     fused = eng.rollout(B, T, H, 'model_mean', pool, seed=9)
     for k in ref:
         got = cpu(getattr(fused, k))
@@ -645,12 +645,12 @@ def test_gemm_rollout_concurrent_rounds_equal_sequential_rounds(env, K, hidden, 
     eng, dm, theta, pdims, pool = Hh.make_engine(env, K, hidden, pol, seed=77)
     assert eng.set_rollout_variant(1) == 3                          # 1: stay on the step-wise path where the resident kernel would take over (test_gpu_resident.py)
     if not merged:
-        monkeypatch.setenv('METRPO_NO_MERGED_ROUNDS', '1')
+        eng.set_option('METRPO_NO_MERGED_ROUNDS', '1')
     T = R * H
     par = eng.rollout(B, T, H, mode, pool, seed=5)
     assert eng.last_rollout_kernel() == 'gemm-stepwise'
     par = [x.clone() for x in (par.obs, par.act, par.mean, par.rew, par.done, par.tpath, par.last_obs)]
-    monkeypatch.setenv('METRPO_SEQ_ROUNDS', '1')
+    eng.set_option('METRPO_SEQ_ROUNDS', '1')
     seq = eng.rollout(B, T, H, mode, pool, seed=5)
     for a, b in zip(par, (seq.obs, seq.act, seq.mean, seq.rew, seq.done, seq.tpath, seq.last_obs)):
         assert torch.equal(a, b)

@@ -112,7 +112,7 @@ def test_rotating_tile_deal_and_sentinel_wait_are_bitwise_the_fixed_deal(env, B,
     rot = _fields(eng.rollout(B, T, H, mode, pool, seed=11))
     assert eng.last_rollout_kernel() == 'resident'
     for var in ('METRPO_RESIDENT_NO_SENTINEL', 'METRPO_RESIDENT_NO_ROTATE'):      # first without the sentinel wait, then also on the fixed deal
-        monkeypatch.setenv(var, '1')
+        eng.set_option(var, '1')
         other = eng.rollout(B, T, H, mode, pool, seed=11)
         assert eng.last_rollout_kernel() == 'resident'
         for a, b in zip(rot, _fields(other)):
@@ -131,11 +131,11 @@ def test_resident_rounds_side_by_side_equal_sequential_rounds(K, B, H, R, ws, mo
     hid = 1024 if ws == 64 else 512
     eng, dm, theta, pdims, pool = Hh.make_engine('half_cheetah' if ws == 64 else 'swimmer', K, (hid, hid), (32, 32), seed=77)
     T = R * H
-    monkeypatch.setenv('METRPO_RESIDENT_WS', str(ws))
+    eng.set_option('METRPO_RESIDENT_WS', str(ws))
     par = eng.rollout(B, T, H, 'step_rand', pool, seed=5)
     assert eng.last_rollout_kernel() == 'resident'
     par = _fields(par)
-    monkeypatch.setenv('METRPO_SEQ_ROUNDS', '1')
+    eng.set_option('METRPO_SEQ_ROUNDS', '1')
     seq = eng.rollout(B, T, H, 'step_rand', pool, seed=5)
     assert eng.last_rollout_kernel() == 'resident'
     for a, b in zip(par, _fields(seq)):
@@ -276,14 +276,14 @@ def test_resident_missing_workgroup_times_out_and_context_recovers(env, hid, mon
     import metrpo_amd
     eng, dm, theta, pdims, pool = Hh.make_engine(env, 5, (hid, hid), (32, 32), seed=33)
     B, T, H = 64, 6, 6
-    monkeypatch.setenv('METRPO_RESIDENT_TEST_SKIP', '3')
+    eng.set_option('METRPO_RESIDENT_TEST_SKIP', '3')
     t0 = time.time()
     eng.rollout(B, T, H, 'step_rand', pool, seed=2)
     assert eng.last_rollout_kernel() == 'resident'
     with pytest.raises(metrpo_amd._lib.MetrpoError, match="resident kernel's hand-over timed out"):
         eng.comm_check()
     assert 1.5 < time.time() - t0 < 20.0
-    monkeypatch.delenv('METRPO_RESIDENT_TEST_SKIP')
+    eng.set_option('METRPO_RESIDENT_TEST_SKIP', None)
     again = eng.rollout(B, T, H, 'step_rand', pool, seed=2)
     assert eng.last_rollout_kernel() == 'gemm-stepwise'
     eng.comm_check()                                                     # the error cell was cleared: the context is usable
@@ -311,9 +311,9 @@ def test_resident_validation_costs_against_oracle_and_the_stepwise_sweep(env, hi
     s0 = pool[:Bv].astype(np.float32)
     got = cpu(eng.validation_cost(s0, T, gamma))
     eng.comm_check()                                                      # no hand-over timed out
-    monkeypatch.setenv('METRPO_NO_RESIDENT_VALIDATION', '1')
+    eng.set_option('METRPO_NO_RESIDENT_VALIDATION', '1')
     sweep = cpu(eng.validation_cost(s0, T, gamma))
-    monkeypatch.delenv('METRPO_NO_RESIDENT_VALIDATION')
+    eng.set_option('METRPO_NO_RESIDENT_VALIDATION', None)
     ref = O.validation_costs(dm, theta.astype(np.float32).astype(np.float64), pdims, env, s0.astype(np.float64), T, gamma)
     np.testing.assert_allclose(got, ref, **TOL.VALIDATION_COST)
     np.testing.assert_allclose(got, sweep, **TOL.VALIDATION_COST)
@@ -321,12 +321,12 @@ def test_resident_validation_costs_against_oracle_and_the_stepwise_sweep(env, hi
     again = cpu(eng.validation_cost(s0, T, gamma))
     np.testing.assert_array_equal(got, again)                             # bitwise repeatable
     for ntw in (1, 2, 4):                                                 # tiles per post wave (the launcher picks by a cost model): same sums whatever the deal
-        monkeypatch.setenv('METRPO_VAL_TILES_PER_WAVE', str(ntw))
+        eng.set_option('METRPO_VAL_TILES_PER_WAVE', str(ntw))
         np.testing.assert_allclose(cpu(eng.validation_cost(s0, T, gamma)), got, rtol=1e-6, atol=1e-6)
-    monkeypatch.delenv('METRPO_VAL_TILES_PER_WAVE')
+    eng.set_option('METRPO_VAL_TILES_PER_WAVE', None)
     for nb in (2, 3, 5):                                                  # the batch in chunks (one launch each; the last one ragged)
         if Bv >= nb:
-            monkeypatch.setenv('METRPO_VAL_CHUNKS', str(nb))
+            eng.set_option('METRPO_VAL_CHUNKS', str(nb))
             np.testing.assert_allclose(cpu(eng.validation_cost(s0, T, gamma)), got, rtol=1e-6, atol=1e-6)
     eng.comm_check()
 

@@ -54,14 +54,14 @@ def test_streamk_rollout_vs_oracle_and_tile_gemm(env, K, dh, B, monkeypatch):
     if env == 'ant':
         pool[::3, 2] = 0.21; dm.diff_mean[2] = -0.02
         eng.set_dynamics_layers(dm.Ws, dm.bs, dm.in_mean, dm.in_std, dm.diff_mean, dm.diff_std)
-    monkeypatch.setenv('METRPO_STREAMK', '1')                  # also below one tile per CU
+    eng.set_option('METRPO_STREAMK', '1')                  # also below one tile per CU
     eng.set_rollout_variant(1)                                 # large nets: the step-wise path even where the resident kernel applies
     traj, dr32 = _rollout_vs_oracle(eng, dm, theta, pdims, pool, env, K, B, T, H)
     assert eng.last_rollout_kernel() == 'gemm-streamk'
     again = eng.rollout(B, T, H, 'step_rand', pool, **dr32)    # bitwise repeatable
     assert torch.equal(again.obs, traj.obs) and torch.equal(again.rew, traj.rew)
-    monkeypatch.delenv('METRPO_STREAMK')
-    monkeypatch.setenv('METRPO_NO_STREAMK', '1')
+    eng.set_option('METRPO_STREAMK', None)
+    eng.set_option('METRPO_NO_STREAMK', '1')
     tile = eng.rollout(B, T, H, 'step_rand', pool, **dr32)     # free-running for 5 steps: same path structure, states within fp32 rounding of 5 steps
     assert eng.last_rollout_kernel() == 'gemm-stepwise'
     assert torch.equal(tile.tpath, traj.tpath) and torch.equal(tile.done, traj.done)
@@ -72,7 +72,7 @@ def test_streamk_rollout_vs_oracle_and_tile_gemm(env, K, dh, B, monkeypatch):
 def test_streamk_rollout_all_sam_modes(sam_mode, monkeypatch):
     env, K, B, T, H = 'half_cheetah', 4, 70, 6, 3
     eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (256, 256), (32, 32), seed=61)
-    monkeypatch.setenv('METRPO_STREAMK', '1')
+    eng.set_option('METRPO_STREAMK', '1')
     eng.set_rollout_variant(1)
     _rollout_vs_oracle(eng, dm, theta, pdims, pool, env, K, B, T, H, sam_mode=sam_mode)
     assert eng.last_rollout_kernel() == 'gemm-streamk'
@@ -97,7 +97,7 @@ def test_streamk_xcd_aware_ranges_are_bitwise_the_plain_split(monkeypatch):
     xcd = eng.rollout(B, T, H, 'step_rand', pool, seed=3)
     assert eng.last_rollout_kernel() == 'gemm-streamk'
     keep = [x.clone() for x in (xcd.obs, xcd.rew, xcd.mean, xcd.done)]
-    monkeypatch.setenv('METRPO_STREAMK_NO_XCD', '1')
+    eng.set_option('METRPO_STREAMK_NO_XCD', '1')
     plain = eng.rollout(B, T, H, 'step_rand', pool, seed=3)
     for a, b in zip(keep, (plain.obs, plain.rew, plain.mean, plain.done)):
         assert torch.equal(a, b)
@@ -120,9 +120,9 @@ def test_streamk_random_shapes_equal_the_tile_gemms(monkeypatch):
         sk = eng.rollout(B, 2, 2, 'step_rand', pool, seed=case)
         assert eng.last_rollout_kernel() == 'gemm-streamk', msg
         keep = [x.clone() for x in (sk.obs, sk.rew, sk.mean, sk.done)]
-        monkeypatch.setenv('METRPO_NO_STREAMK', '1')
+        eng.set_option('METRPO_NO_STREAMK', '1')
         tile = eng.rollout(B, 2, 2, 'step_rand', pool, seed=case)
-        monkeypatch.delenv('METRPO_NO_STREAMK')
+        eng.set_option('METRPO_NO_STREAMK', None)
         assert eng.last_rollout_kernel() == 'gemm-stepwise', msg
         assert torch.equal(keep[3], tile.done), msg
         for a, b in zip(keep[:3], (tile.obs, tile.rew, tile.mean)):
@@ -138,7 +138,7 @@ def test_stored_layer0_kernel_equals_the_tile_gemm(env, K, dh, B, monkeypatch):
     eng, dm, theta, pdims, pool = Hh.make_engine(env, K, dh, ph, seed=87)
     traj, dr32 = _rollout_vs_oracle(eng, dm, theta, pdims, pool, env, K, B, 2, 2)
     assert eng.last_rollout_kernel() == 'gemm-streamk'
-    monkeypatch.setenv('METRPO_NO_L0_ROWS', '1')
+    eng.set_option('METRPO_NO_L0_ROWS', '1')
     tile = eng.rollout(B, 2, 2, 'step_rand', pool, **dr32)
     assert eng.last_rollout_kernel() == 'gemm-streamk'
     assert torch.equal(tile.done, traj.done)
@@ -168,20 +168,20 @@ def test_step_closed_in_the_next_launch_is_bitwise_the_two_launch_sequence(env, 
     if env == 'ant':
         pool[::3, 2] = 0.21; dm.diff_mean[2] = -0.02
         eng.set_dynamics_layers(dm.Ws, dm.bs, dm.in_mean, dm.in_std, dm.diff_mean, dm.diff_std)
-    monkeypatch.setenv('METRPO_STREAMK' if streamk else 'METRPO_NO_STREAMK', '1')
-    monkeypatch.setenv('METRPO_STEP_MERGE', '1')                # Humanoid behind the tile GEMMs: merged only on request
+    eng.set_option('METRPO_STREAMK' if streamk else 'METRPO_NO_STREAMK', '1')
+    eng.set_option('METRPO_STEP_MERGE', '1')                # Humanoid behind the tile GEMMs: merged only on request
     eng.set_rollout_variant(1)
     dr = Hh.draws(np.random.RandomState(8), K, B, T, dm.ns, dm.na, len(pool))
     dr32 = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in dr.items()}
     merged = eng.rollout(B, T, H, sam_mode, pool, **dr32)
-    monkeypatch.setenv('METRPO_NO_STEP_MERGE', '1')
+    eng.set_option('METRPO_NO_STEP_MERGE', '1')
     two = eng.rollout(B, T, H, sam_mode, pool, **dr32)
     for name in ('obs', 'act', 'rew', 'mean', 'done', 'tpath', 'last_obs'):
         assert torch.equal(getattr(merged, name), getattr(two, name)), name
     # and with the library's own draws (Philox): same streams in both forms
-    monkeypatch.delenv('METRPO_NO_STEP_MERGE')
+    eng.set_option('METRPO_NO_STEP_MERGE', None)
     m2 = eng.rollout(B, T, H, sam_mode, pool, seed=5)
-    monkeypatch.setenv('METRPO_NO_STEP_MERGE', '1')
+    eng.set_option('METRPO_NO_STEP_MERGE', '1')
     t2 = eng.rollout(B, T, H, sam_mode, pool, seed=5)
     for name in ('obs', 'act', 'rew', 'mean', 'done', 'tpath', 'last_obs'):
         assert torch.equal(getattr(m2, name), getattr(t2, name)), name
