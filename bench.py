@@ -44,6 +44,18 @@ def flops_per_unit(ns, na, n_drop, dyn_hidden, pol_hidden):
     return (2 * sum(d[i] * d[i + 1] for i in range(len(d) - 1)), 2 * sum(p[i] * p[i + 1] for i in range(len(p) - 1)))
 
 
+def newest_profile(suffix):
+    """profiles/rNN_<...><suffix> of the highest round NN ('' when there is none): the offline PMC figures a bench line quotes are the newest committed ones."""
+    import re
+    best, best_r = '', -1
+    pdir = os.path.join(REPO, 'profiles')
+    for fn in (os.listdir(pdir) if os.path.isdir(pdir) else []):
+        m = re.match(r'r(\d+)' + re.escape(suffix) + '$', fn)
+        if m and int(m.group(1)) > best_r:
+            best, best_r = os.path.join(pdir, fn), int(m.group(1))
+    return best
+
+
 def cpu_baseline_block(env, K, dyn_hidden, pol_hidden, B, H):
     """The CPU restatement (oracle/cpu_baseline.py) on the host cores: 1 thread (what the reference configures,
     utils.py:229-232) and all hardware threads."""
@@ -106,6 +118,10 @@ def main():
     ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--warmup', type=int, default=10)          # the first ~8 iterations after start-up run 5-10 % slow (clocks, allocator): 3 warm-up steps left two of them in a 20-step mean
     ap.add_argument('--config', default='C1')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
+                    help='weak (default): every GPU runs the per-GPU share of the config (B / gpus the config is quoted on), total work grows with --gpus; '
+                         'strong: the config\'s WHOLE batch B is divided over the --gpus ranks (B / N envs each: the literal reading of BASELINE.json\'s "K=5, B=5000 ... at 1/2/4/8")')
+    ap.add_argument('--params', default=None, help='one of the reference\'s params/params-*.json files: run ITS shapes (overrides --config; metrpo_amd.shapes_from_params)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-H', type=int, default=100, help='horizon of the bounded CPU-baseline sample')
     args = ap.parse_args()
@@ -144,9 +160,17 @@ def main():
             if os.environ.get('METRPO_BENCH_STRICT_PREFLIGHT') is not None:
                 sys.exit(3)
 
-    cfg = synthetic.CONFIGS[args.config]
+    if args.params:
+        cfg = synthetic.config_from_params(args.params)
+        args.config = 'params:' + os.path.basename(args.params)
+    else:
+        cfg = synthetic.CONFIGS[args.config]
     env, K, H = cfg['env'], cfg['K'], cfg['H']
-    B = cfg['B'] // cfg['gpus']                               # per-GPU share of the config's B (weak scaling keeps it fixed)
+    if args.scaling == 'strong':                              # the config's whole batch over the ranks of THIS run ("B/G envs each")
+        B = cfg['B'] // args.gpus
+        assert B >= 16, "--scaling strong: %d envs over %d ranks leaves fewer than one 16-env tile per rank" % (cfg['B'], args.gpus)
+    else:
+        B = cfg['B'] // cfg['gpus']                           # per-GPU share of the config's B (weak scaling keeps it fixed)
     ns, na, n_drop = synthetic.ENV_SPECS[env]
     eng = metrpo_amd.Engine(env, K, cfg['dyn_hidden'], cfg['pol_hidden'], device=dev)
     if oversub:
@@ -211,6 +235,19 @@ def main():
     dt = comm.max_float(time.perf_counter() - t0, device='cuda' if backend == 'nccl' else 'cpu')
     if gc_was:
         gc.enable()
+    # the time-dominant kernel of the update, measured live: one more (untimed) iteration with HIP events around every Fisher-vector-product KERNEL of
+    # the CG solve (option TIME_FVP; the events sit on the update's own stream, between the kernel and its reduction)
+    fvp_us, fvp_n = float('nan'), 0
+    try:
+        eng.set_option('TIME_FVP', '1')
+        step(args.warmup + args.steps, False)
+        algo.optimizer.finish()
+        torch.cuda.synchronize()
+        fvp_us, fvp_n = eng.fvp_kernel_us()
+    except Exception as e:                                     # a diagnostics leg must not cost the run its line
+        sys.stderr.write('rank %d: FVP timing leg failed: %r\n' % (comm.rank, e))
+    finally:
+        eng.set_option('TIME_FVP', None)
     side = 'cuda' if backend == 'nccl' else 'cpu'             # where the bench's own bookkeeping reductions live
     iter_ms = [a.elapsed_time(b) for a, b in zip(ev_iter[:-1], ev_iter[1:])]        # per-iteration times on the stream (median of >= 20)
 
@@ -236,27 +273,27 @@ def main():
     upd_exec = (3 + fvp_mult * n_hvp + n_ls) * f_pol * N_local / (upd_ms * 1e-3) / 1e12
     variant = eng.rollout_path()
     upd_traffic, upd_traffic_src = None, None                   # HBM bytes per policy update (all of its launches), from the OFFLINE per-sample PMC figures
-    upath = next((q for q in (os.path.join(REPO, 'profiles', r + '_update_traffic.json') for r in ('r03', 'r02')) if os.path.exists(q)), '')
+    upath = newest_profile('_update_traffic.json')
     if args.config in ('C0', 'C0p', 'C1') and eng.update_path(int(N_local)) == 'mfma' and os.path.exists(upath):
         bps = json.load(open(upath)).get('hbm_bytes_per_sample', {})
         if all(k in bps for k in ('fvp', 'grad', 'losskl')):
             upd_traffic = float(N_local) * (n_hvp * bps['fvp'] + bps['grad'] + n_ls * bps['losskl'])
             upd_traffic_src = 'profiles/' + os.path.basename(upath) + ' (rocprofv3 --pmc bytes per sample of each kernel, offline, x this run\'s launch counts)'
     traffic, traffic_src = None, None                           # HBM bytes per rollout launch: rocprofv3 PMC, measured OFFLINE (profiles/)
-    tpath = next((q for q in (os.path.join(REPO, 'profiles', r + '_rollout_traffic.json') for r in ('r03', 'r02')) if os.path.exists(q)), '')
+    tpath = newest_profile('_rollout_traffic.json')
     if args.config == 'C1' and variant == 2 and os.path.exists(tpath):
         traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
         traffic_src = 'profiles/' + os.path.basename(tpath) + ' (rocprofv3 --pmc, offline run of the same launch)'
-    rpath = os.path.join(REPO, 'profiles', 'r03_resident_traffic.json')
+    rpath = newest_profile('_resident_traffic.json')
     if args.config == 'C0p' and eng.last_rollout_kernel() == 'resident' and os.path.exists(rpath):
         traffic = json.load(open(rpath)).get('hbm_bytes_per_launch')
-        traffic_src = 'profiles/r03_resident_traffic.json (rocprofv3 --pmc, offline run of the same launch; mostly the uncached step hand-over packets)'
-    spath = os.path.join(REPO, 'profiles', 'r04_streamk_traffic.json')
-    if eng.last_rollout_kernel() == 'gemm-streamk' and os.path.exists(spath):      # (the per-GPU share does not depend on --gpus: weak scaling)
+        traffic_src = 'profiles/' + os.path.basename(rpath) + ' (rocprofv3 --pmc, offline run of the same launch; mostly the uncached step hand-over packets)'
+    spath = newest_profile('_streamk_traffic.json')
+    if eng.last_rollout_kernel() in ('gemm-streamk', 'streamk-persistent') and os.path.exists(spath):      # (the per-GPU share does not depend on --gpus: weak scaling)
         ent = json.load(open(spath)).get(args.config)
         if ent:                                                 # per-step bytes of the stream-K launches (the per-GPU share the file was measured at) x the steps of this rollout
             traffic = float(ent['hbm_bytes_per_step']) * T_mean
-            traffic_src = 'profiles/r04_streamk_traffic.json (rocprofv3 --pmc, offline run of the same launches at this per-GPU share: (2 x FETCH_SIZE + WRITE_SIZE) per step x %.0f steps; algorithmic %.3g B per step)' % (T_mean, ent['algorithmic_bytes_per_step'])
+            traffic_src = 'profiles/' + os.path.basename(spath) + ' (rocprofv3 --pmc, offline run of the same launches at this per-GPU share: (2 x FETCH_SIZE + WRITE_SIZE) per step x %.0f steps; algorithmic %.3g B per step)' % (T_mean, ent['algorithmic_bytes_per_step'])
     # what bounds the rollout when it is not the matrix pipe: a 16-env tile is a chain of T dependent steps, and with fewer tiles than CUs the chip is not filled
     n_tiles = (B + 15) // 16
     kern = eng.last_rollout_kernel() or ''
@@ -272,14 +309,14 @@ def main():
     out = {
         "metric": "imagined env-steps/sec (KxBxH) over the full TRPO iteration", "value": units_per_step / (dt / args.steps),
         "unit": "env-steps/s", "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "ms_per_step_median": comm.max_float(float(np.median(iter_ms)), device=side), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "ms_per_step_median": comm.max_float(float(np.median(iter_ms)), device=side), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s rollout+GAE+TRPO: env=%s K=%d dyn=%s policy=%s B=%d/GPU (config B=%d on %d GPUs) H=%d sam_mode=step_rand "
+        "config": {"workload": "%s rollout+GAE+TRPO: env=%s K=%d dyn=%s policy=%s B=%d/GPU (%s scaling; config B=%d on %d GPUs) H=%d sam_mode=step_rand "
                                "all-K-heads-evaluated max_kl=0.01 cg_iters=10; env steps per rollout %.1f; reuse_trajectory_buffers=1 (one set of "
                                "[T,B,.] tensors overwritten every iteration) device_baseline_fit=%d (1: the fit's normal equations are solved by a kernel, float64, coefficients stay on the device; "
                                "0: host lstsq deferred behind the next rollout, defer_baseline_fit) async_line_search=%d (the accept test of the first two line-search trials runs on "
                                "the device and the host closes the update after it has enqueued the next rollout: same trials, same rule, same results)"
-                               % (args.config, env, K, list(cfg['dyn_hidden']), list(cfg['pol_hidden']), B, cfg['B'], cfg['gpus'], H, T_mean, int(bool(algo.device_baseline_fit)), int(bool(algo.async_line_search))),
+                               % (args.config, env, K, list(cfg['dyn_hidden']), list(cfg['pol_hidden']), B, args.scaling, cfg['B'], cfg['gpus'], H, T_mean, int(bool(algo.device_baseline_fit)), int(bool(algo.async_line_search))),
                    "parallelism": "B-sharded x%d, sum all-reduce of g/FVP/scalars" % comm.world},
         "trpo_iter_ms": ms_per_step,
         "preflight": preflight_rep,
@@ -294,13 +331,20 @@ def main():
                                 "ms": upd_ms, "achieved": upd_exec, "peak": PEAK_F32, "unit": "TFLOP/s", "frac": upd_exec / PEAK_F32,
                                 "flop_count": "executed: gradient 3 x, Fisher-vector product %d x, evaluation 1 x the forward FLOPs per sample" % fvp_mult,
                                 "achieved_survey_8d": upd_achieved, "frac_survey_8d": upd_achieved / PEAK_F32,
-                                "traffic": upd_traffic, "traffic_source": upd_traffic_src}},
+                                "traffic": upd_traffic, "traffic_source": upd_traffic_src,
+                                "fvp": (None if not fvp_n else {
+                                    "kernel": "Fisher-vector-product kernel of one CG iteration (the update's time-dominant kernel: %d launches per update), HIP events around the kernel itself" % n_hvp,
+                                    "launches_timed": fvp_n, "us": fvp_us,
+                                    "achieved": fvp_mult * f_pol * N_local / (fvp_us * 1e-6) / 1e12, "peak": PEAK_F32, "unit": "TFLOP/s",
+                                    "frac": fvp_mult * f_pol * N_local / (fvp_us * 1e-6) / 1e12 / PEAK_F32,
+                                    "frac_survey_8d": 4 * f_pol * N_local / (fvp_us * 1e-6) / 1e12 / PEAK_F32,
+                                    "share_of_update": n_hvp * fvp_us * 1e-3 / upd_ms})}},
     }
     if comm.rank == 0:
         try:                                                    # measured peaks of THIS device next to the nominal denominators
             mf, hb = eng.probe_peaks()
             out["roofline"]["measured_peaks"] = {"f32_mfma_tflops": mf, "hbm_copy_gbs": hb, "frac_of_measured": achieved / mf,
-                                                 "note": "register-resident v_mfma_f32_32x32x2_f32 issue loop / 1 GiB streaming copy (csrc/probe.hip); "
+                                                 "hbm_copy_gbs_guide": 6290.0, "note": "register-resident v_mfma_f32_32x32x2_f32 issue loop / 1 GiB streaming copy, best of 12 loop forms (csrc/probe.hip; MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy); "
                                                          "`frac` keeps the nominal peak (the stricter denominator)"}
         except Exception as e:
             out["roofline"]["measured_peaks"] = {"error": repr(e)}

@@ -19,7 +19,8 @@ from . import early_stop
 from . import dynamics_training
 from .bptt import BPTT
 from . import formats
+from .params import from_params, shapes_from_params
 
 __all__ = ['Engine', 'Trajectory', 'xavier_policy_theta', 'Comm', 'NeuralNetEnv', 'VecSimpleEnv', 'InitStatePool',
            'Box', 'EnvSpec', 'GaussianMLPPolicy', 'LinearFeatureBaseline', 'VectorizedSampler', 'BaseSampler',
-           'DevicePaths', 'ConjugateGradientOptimizer', 'BatchPolopt', 'NPO', 'TRPO', 'early_stop', 'dynamics_training']
+           'DevicePaths', 'ConjugateGradientOptimizer', 'BatchPolopt', 'NPO', 'TRPO', 'early_stop', 'dynamics_training', 'from_params', 'shapes_from_params']

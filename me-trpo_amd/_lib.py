@@ -123,6 +123,7 @@ EXTRA_SYMBOLS = {
     'metrpo_set_det_path': (_I, [_P, _I]),
     'metrpo_probe_peaks': (_I, [_P, _P, _P]),
     'metrpo_schedulable_cus': (_I, [_P, _P]),
+    'metrpo_debug_fvp_us': (_I, [_P, _P, _P]),
 }
 
 

@@ -94,6 +94,20 @@ static void repack_dyn(const metrpo_ctx* c, const float* src, float* dst, int n_
 }
 
 
+// Diagnostics hook (not part of include/metrpo.h; bench.py's roofline.update.fvp): with option TIME_FVP set, launch_fvp_tail brackets the Fisher-vector-product
+// KERNEL of every CG iteration (not its reduction) with HIP events on the update's stream.  Returns their mean in microseconds, the count in *n.
+extern "C" int32_t metrpo_debug_fvp_us(metrpo_ctx* c, double* mean_us, int32_t* n) {
+    if (!c || !mean_us || !n) return METRPO_ENULL;
+    *mean_us = 0.0; *n = 0;
+    const int pairs = c->fvp_ev_n / 2;
+    if (pairs == 0) return METRPO_OK;
+    HIP_TRY(c, hipEventSynchronize(c->fvp_ev[2 * pairs - 1]));
+    double sum = 0.0;
+    for (int i = 0; i < pairs; ++i) { float ms = 0.0f; HIP_TRY(c, hipEventElapsedTime(&ms, c->fvp_ev[2 * i], c->fvp_ev[2 * i + 1])); sum += ms; }
+    *mean_us = sum / pairs * 1e3; *n = pairs; c->fvp_ev_n = 0;
+    return METRPO_OK;
+}
+
 // ---- option table (metrpo_internal.h: METRPO_OPT_LIST) ----
 static const char* const OPT_NAMES[OPT_COUNT] = {
 #define X(n) #n,
@@ -153,7 +167,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     c->d_dyn_img = c->d_pol_img = nullptr; c->pol_img_idx = -1; c->d_pol_imgval = nullptr; c->d_pol_vpos = nullptr; c->img_live = 0;
     c->d_bptt = nullptr; c->bptt_cap = 0; c->det_cfg = -1; c->d_detpart = nullptr; c->detpart_cap = 0; c->det_gemm = 0; c->d_dg = nullptr; c->dg_cap = 0; c->vjp_gm = nullptr; c->ls_skip = nullptr; c->d_pol_adam = nullptr; c->pol_adam_t = 0; c->mfma_cfg = -1; c->pol_mfma = -1; c->coop_cfg = -1; c->rollout_variant = 0;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_cg = nullptr; c->d_vf = nullptr; c->d_theta_try = nullptr;
-    c->d_valbuf = nullptr; c->h_pinned = nullptr; c->n_sm = 256; c->n_cu_sched = 0; c->fallback_logged = 0;
+    c->d_valbuf = nullptr; c->h_pinned = nullptr; c->n_sm = 256; c->n_cu_sched = 0; c->fallback_logged = 0; c->fvp_ev_n = 0; c->fvp_ev_made = 0;
     for (int i = 0; i < OPT_COUNT; ++i) {                     // the ONLY place the library reads the environment for kernel selection: defaults of the option table
         const std::string ev = std::string(i == OPT_GEMM_PREFETCH ? "" : "METRPO_") + metrpo_opt_name(i);
         const char* e = getenv(ev.c_str());
@@ -212,6 +226,7 @@ extern "C" int32_t metrpo_destroy(metrpo_ctx* c) {
         for (int i = 0; i < METRPO_MAX_PAR_ROUNDS - 1; ++i) { (void)hipStreamDestroy(c->side_stream[i]); (void)hipEventDestroy(c->ev_join[i]); }
         (void)hipEventDestroy(c->ev_fork);
     }
+    for (int i = 0; i < c->fvp_ev_made; ++i) (void)hipEventDestroy(c->fvp_ev[i]);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->h_upd) (void)hipHostFree(c->h_upd);
     delete c;

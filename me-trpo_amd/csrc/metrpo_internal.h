@@ -35,7 +35,7 @@ struct ProblemDesc {
 // ---- variant / tuning switches of a context (metrpo_set_option / metrpo_get_option, include/metrpo.h) ----------------------------------------------
 // One table per context, read by the launch paths through ctx_opt(); metrpo_create fills the defaults ONCE from the environment (METRPO_<KEY>), nothing
 // else in the library reads the environment for kernel selection.  A key is the upper-case name below (the ABI also takes lower case and a METRPO_ prefix).
-#define METRPO_OPT_LIST(X) X(COOP_MODE) X(EXTRA_LDS) X(GEMM_PREFETCH) X(NO_DEVICE_LINESEARCH) X(NO_FUSED_OUT) X(NO_IMGVAL) X(NO_L0_ROWS) X(NO_MERGED_ROUNDS) X(NO_PRE_MFMA3) X(NO_RESIDENT) X(NO_RESIDENT_VALIDATION) X(NO_STEP_MERGE) X(NO_STREAMK) X(PG_HEAD_ROWS) X(PRE_GEMM) X(RESIDENT_NO_ROTATE) X(RESIDENT_NO_SENTINEL) X(RESIDENT_TEST_SKIP) X(RESIDENT_WS) X(RES_UNCACHED) X(SEQ_ROUNDS) X(SOLVE_BLOCK) X(STEP_MERGE) X(STREAMK) X(STREAMK_LATE) X(STREAMK_NO_XCD) X(UPD_TILES_PER_WAVE) X(VAL_CHUNKS) X(VAL_TILES_PER_WAVE) X(XCHG_TIMEOUT_MS) X(NO_PERSIST) X(PERSIST) X(QUIET)
+#define METRPO_OPT_LIST(X) X(COOP_MODE) X(EXTRA_LDS) X(GEMM_PREFETCH) X(NO_DEVICE_LINESEARCH) X(NO_FUSED_OUT) X(NO_IMGVAL) X(NO_L0_ROWS) X(NO_MERGED_ROUNDS) X(NO_PRE_MFMA3) X(NO_RESIDENT) X(NO_RESIDENT_VALIDATION) X(NO_STEP_MERGE) X(NO_STREAMK) X(PG_HEAD_ROWS) X(PRE_GEMM) X(RESIDENT_NO_ROTATE) X(RESIDENT_NO_SENTINEL) X(RESIDENT_TEST_SKIP) X(RESIDENT_WS) X(RES_UNCACHED) X(SEQ_ROUNDS) X(SOLVE_BLOCK) X(STEP_MERGE) X(STREAMK) X(STREAMK_LATE) X(STREAMK_NO_XCD) X(UPD_TILES_PER_WAVE) X(VAL_CHUNKS) X(VAL_TILES_PER_WAVE) X(XCHG_TIMEOUT_MS) X(NO_PERSIST) X(PERSIST) X(QUIET) X(TIME_FVP)
 enum MetrpoOpt {
 #define X(n) OPT_##n,
     METRPO_OPT_LIST(X)
@@ -117,6 +117,7 @@ struct metrpo_ctx {
     int n_cu_sched;      // CUs that actually ran this process's waves (probe.hip: census; 0 = not measured yet)
     int exclusive;       // 0: the GPU is shared with other compute processes (metrpo_set_exclusive; METRPO_NO_RESIDENT=1 in the environment means the same)
     std::string opt_val[OPT_COUNT]; bool opt_set[OPT_COUNT];   // METRPO_OPT_LIST: set by metrpo_create from the environment, then only by metrpo_set_option
+    hipEvent_t fvp_ev[32]; int fvp_ev_n, fvp_ev_made;   // option TIME_FVP: events around the Fisher-vector-product kernel of launch_fvp_tail (metrpo_debug_fvp_us)
     std::string rollout_note;   // why the last metrpo_rollout left the fast dispatch table ("" when it did not): metrpo_rollout_note
     int fallback_logged;  // a rollout shape that fell off the fast dispatch table has been reported once (METRPO_VERBOSE)
     std::string err;

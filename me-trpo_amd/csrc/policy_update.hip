@@ -506,7 +506,13 @@ int launch_fvp_tail(metrpo_ctx* c, const metrpo_batch* b, const float* vf, const
     PolK k; int rc = fill_polk(c, b, &k, false); if (rc) return rc;
     if (policy_gemm_applicable(c, b->N)) return policy_gemm_run(c, 1, b, k, c->d_theta, vf, v, hv, tail, st);
     int nrows, stride, lk;
+    const bool timed = ctx_opt(c, OPT_TIME_FVP) != nullptr && c->fvp_ev_n + 2 <= 32;      // diagnostics: metrpo_debug_fvp_us
+    if (timed) {
+        for (; c->fvp_ev_made < 32; ++c->fvp_ev_made) HIP_TRY(c, hipEventCreate(&c->fvp_ev[c->fvp_ev_made]));
+        HIP_TRY(c, hipEventRecord(c->fvp_ev[c->fvp_ev_n], st));
+    }
     if ((rc = run_mode(c, 1, b, k, c->d_theta, vf, &nrows, &stride, &lk, st))) return rc;
+    if (timed) { HIP_TRY(c, hipEventRecord(c->fvp_ev[c->fvp_ev_n + 1], st)); c->fvp_ev_n += 2; }
     finalize(c, 1, nrows, stride, lk, v, hv, st, tail);
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;

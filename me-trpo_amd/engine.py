@@ -200,6 +200,13 @@ class Engine(object):
         self._chk(lib.metrpo_probe_peaks(self._ctx, out, self._stream()))
         return float(out[0]), float(out[1])
 
+    def fvp_kernel_us(self):
+        """Diagnostics: mean duration (us) and count of the Fisher-vector-product KERNEL launches recorded since the last call while option
+        TIME_FVP was set (HIP events around the kernel itself inside the update's launch sequence)."""
+        us, n = C.c_double(0.0), C.c_int32(0)
+        self._chk(lib.metrpo_debug_fvp_us(self._ctx, C.byref(us), C.byref(n)))
+        return float(us.value), int(n.value)
+
     def update_path(self, N):
         """Kernel family the policy update of an N-sample batch runs on: 'mfma' (fused), 'gemm' or 'generic'."""
         return {1: 'mfma', 2: 'gemm', 0: 'generic'}[int(lib.metrpo_update_path(self._ctx, int(N)))]

@@ -26,6 +26,14 @@ CONFIGS = {
 }
 
 
+def config_from_params(path_or_dict):
+    """A CONFIGS row from one of the reference's params files (params.shapes_from_params): `bench.py --params FILE`.  The C0p / C0hc / C0ho / C0sn /
+    C0an / C0hu rows above are exactly these for the six shipped files (tests/test_params.py)."""
+    from .params import shapes_from_params
+    sh = shapes_from_params(path_or_dict)
+    return dict(env=sh['env'], K=sh['K'], dyn_hidden=sh['dyn_hidden'], pol_hidden=sh['pol_hidden'], B=sh['n_envs'], H=sh['T'], gpus=1, batch_size=sh['batch_size'])
+
+
 def make_dynamics(env, K, dyn_hidden, seed=0):
     ns, na, n_drop = ENV_SPECS[env]
     rng = np.random.RandomState(seed)

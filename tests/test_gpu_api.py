@@ -311,3 +311,39 @@ def test_end_to_end_outer_loop_example():
     assert len(hist) == 2 and hist[1]['n_data'] > hist[0]['n_data'] > 0
     assert all(np.isfinite([h['real_cost'], h['model_val'], h['est_cost']]).all() for h in hist)
     assert hist[1]['model_val'] < 10 * hist[0]['model_val'] + 1.0          # training did not blow up on the grown buffer
+
+
+def test_from_params_builds_the_loop_of_a_params_file():
+    """metrpo_amd.from_params on the reference's own params-swimmer.json key set (tests/golden/params_swimmer.json): the objects of
+    training.py:297-372 / model_based_rl.py:373-380 with the file's shapes, and two iterations of the reference's loop body on them."""
+    import os
+    import metrpo_amd
+    from metrpo_amd import synthetic
+    s = metrpo_amd.from_params(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'params_swimmer.json'))
+    eng, algo = s.engine, s.algo
+    assert (eng.K, eng.dyn_hidden, eng.pol_hidden, eng.n_drop) == (5, [512, 512], [32, 32], 2)
+    assert (algo.batch_size, algo.max_path_length, algo.discount, algo.step_size) == (50000, 200, 1.0, 0.01)
+    assert s.optimize_policy_kwargs['T'] == 200 and s.optimize_policy_kwargs['log_every'] == 5 and s.optimize_policy_kwargs['reset_log_std'] is True
+    Ws, bs, norm = synthetic.make_dynamics('swimmer', 5, (512, 512), seed=0)
+    eng.set_dynamics_layers(Ws, bs, norm['in_mean'], norm['in_std'], norm['diff_mean'], norm['diff_std'])
+    for j in range(2):
+        algo.start_worker()
+        paths = algo.obtain_samples(j)
+        assert (paths.traj.B, paths.traj.T) == (100, 600)                 # the sampler's 100-env clamp, 3 rounds of T = 200: 60 000 >= 50 000 samples
+        algo.optimize_policy(j, algo.process_samples(j, paths))
+    assert eng.last_rollout_kernel() == 'resident' and eng.rollout_note() == ''
+    assert np.isfinite(cpu(eng.get_policy())).all()
+
+
+def test_rollout_note_names_shapes_off_the_fast_table():
+    """metrpo_rollout reports the kernel family it chose, and says why when a shape falls off the fast dispatch table (once per context on stderr)."""
+    for K, hid, family, needle in ((5, (64, 64), 'mfma-cooperative', ''), (3, (64, 64), 'mfma-head-per-wave', 'K = 3'), (5, (96, 96), 'generic', '96x96')):
+        eng, dm, theta, pdims, pool = Hh.make_engine('swimmer', K, hid, (32, 32), seed=3)
+        eng.set_option('QUIET', '1')
+        assert eng.get_option('quiet') == '1' and eng.get_option('STREAMK') is None and 'STREAMK' in eng.option_names()
+        eng.rollout(64, 4, 4, 'step_rand', pool, seed=1)
+        assert eng.last_rollout_kernel() == family, (K, hid, eng.last_rollout_kernel())
+        note = eng.rollout_note()
+        assert (note == '') if not needle else (needle in note), note
+    with pytest.raises(Exception, match='unknown key'):
+        eng.set_option('NO_SUCH_SWITCH', '1')

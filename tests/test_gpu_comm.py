@@ -152,5 +152,40 @@ def test_bench_self_launches_for_n_gpus():
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 4 and rec['steps'] == 3 and rec['scaling'] == 'weak' and rec['value'] > 0
     assert 'one-shot' in rec['allreduce_us']['transport'], rec['allreduce_us']
+    assert rec['preflight'] is not None and rec['preflight']['ok'] is True and rec['preflight']['theta_identical'] is True, rec['preflight']
     assert 'oversubscribed' in rec and 'cpu_baseline' not in rec
     assert abs(rec['value'] - 4 * 5 * 5000 * 100 / (rec['ms_per_step'] * 1e-3)) / rec['value'] < 1e-9
+
+
+def test_preflight_tool_two_ranks_on_one_device_prints_the_latency_table():
+    """`python tools/multi_gpu_preflight.py --gpus 2` (the first command on a multi-GPU box) on this 1-GPU box: the two ranks share cuda:0
+    over gloo + the one-shot transport; exit code 0, every stage's line, and the us-per-all-reduce table for P = 2 / 1476 / 2288 / 12492."""
+    import re
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'multi_gpu_preflight.py'), '--gpus', '2'],
+                         capture_output=True, text=True, timeout=600, env=dict(env, MASTER_ADDR='127.0.0.1'), cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    assert '[preflight] OK' in res.stdout and 'theta bit-identical on all 2 ranks' in res.stdout
+    m = re.search(r'us per all-reduce .*: (.*)', res.stdout)
+    assert m, res.stdout[-2000:]
+    table = dict((int(a), float(b)) for a, b in re.findall(r'P = (\d+): ([0-9.]+)', m.group(1)))
+    assert sorted(table) == [2, 1476, 2288, 12492] and all(0.5 < v < 5000 for v in table.values()), table
+
+
+def test_preflight_collectives_run_on_an_nccl_group():
+    """the preflight's bookkeeping collectives must live on the process group's device type.  One rank, backend nccl (RCCL accepts a
+    single-rank communicator on a 1-GPU box): preflight() returns ok with the report filled in."""
+    script = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tools'))
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29571', world_size=1, rank=0)
+from multi_gpu_preflight import preflight
+ok, rep = preflight(1, 0, 0, latency_table=True)
+assert ok and rep['theta_identical'] and sorted(rep['allreduce_us']) == [2, 1476, 2288, 12492], rep
+print('NCCL-PREFLIGHT-OK', rep['transport'])
+dist.destroy_process_group()
+""" % (ROOT, ROOT)
+    res = subprocess.run([sys.executable, '-c', script], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0 and 'NCCL-PREFLIGHT-OK' in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]

@@ -29,15 +29,29 @@ def _fail(rank, msg, rep=None):
 
 
 def preflight(world, rank, device_index, latency_table=True, out=print):
-    """Collective over torch.distributed (already initialised).  Returns (ok, report dict); prints from rank 0 through `out`."""
+    """Collective over torch.distributed (already initialised).  Returns (ok, report dict); prints from rank 0 through `out`.
+    Every stage's verdict is agreed on by ALL ranks (a MIN all-reduce of the local ok flag) before anybody moves on or returns: a rank-local failure
+    ends the check on every rank together instead of leaving the others inside the next collective.  The bookkeeping collectives run on tensors of
+    the process group's own device type (NCCL: cuda; gloo: cpu)."""
     import torch
     import torch.distributed as dist
     import metrpo_amd
     rep = {'world': world}
     say = (lambda *a: out(*a)) if rank == 0 else (lambda *a: None)
     n_dev = torch.cuda.device_count()
+    side = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
     rep['devices'] = n_dev
     rep['oversubscribed'] = world > n_dev
+
+    def agree(ok_local, msg):
+        """True iff the stage passed on every rank; a failing rank prints its reason, the others name the stage."""
+        flag = torch.tensor([1 if ok_local else 0], dtype=torch.int32, device=side)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            return True
+        _fail(rank, msg if not ok_local else 'another rank failed at: ' + msg, rep)
+        return False
+
     # 1. peer access between every pair of devices the ranks use
     devs = sorted(set(r % n_dev for r in range(world)))
     bad = [(i, j) for i in devs for j in devs if i != j and not torch.cuda.can_device_access_peer(i, j)]
@@ -51,26 +65,32 @@ def preflight(world, rank, device_index, latency_table=True, out=print):
     if world > n_dev:
         eng.set_exclusive(False)                             # ranks share devices: no kernel whose workgroups wait on each other inside one launch
     comm = metrpo_amd.Comm()
-    if comm.world != world:
-        return _fail(rank, 'torch.distributed world size %d != %d' % (comm.world, world), rep), rep
+    if not agree(comm.world == world, 'torch.distributed world size %d != %d' % (comm.world, world)):
+        return False, rep
     transport = comm.attach_engine(eng, transport=os.environ.get('METRPO_COMM', 'auto')) or 'torch.distributed callback'
     names = [None] * world
     dist.all_gather_object(names, transport)
     rep['transport'] = transport
-    if len(set(names)) != 1:
-        return _fail(rank, 'ranks disagree on the transport: %s' % names, rep), rep
+    if not agree(len(set(names)) == 1, 'ranks disagree on the transport: %s' % names):
+        return False, rep
     say('[preflight] transport agreed on by all ranks: %s%s' % (transport, '' if transport == 'one-shot' else
                                                                  ' (one-shot unavailable: %s)' % getattr(comm, 'one_shot_error', 'not attempted')))
     # 3. exchange correctness: rank r contributes (r + 1) * [1 .. n]
+    sums_ok, bad_n = True, None
     for n in (2, eng.P + 1, 12493):
         ramp = torch.arange(1, n + 1, dtype=torch.float64, device=eng.device)
         buf = ramp * (rank + 1)
         comm.allreduce_sum_(buf)
         torch.cuda.synchronize()
-        if not torch.equal(buf, ramp * (world * (world + 1) // 2)):
-            return _fail(rank, 'all-reduce of %d float64 returned a wrong sum' % n, rep), rep
+        if not torch.equal(buf, ramp * (world * (world + 1) // 2)) and sums_ok:
+            sums_ok, bad_n = False, n                        # keep going: the other ranks are inside the same sequence of exchanges
     if transport == 'one-shot':
-        eng.comm_check()
+        try:
+            eng.comm_check()
+        except Exception as e:
+            sums_ok, bad_n = False, 'comm_check: %s' % e
+    if not agree(sums_ok, 'all-reduce of %s float64 returned a wrong sum' % bad_n):
+        return False, rep
     say('[preflight] all-reduce sums exact for 2 / %d / 12493 float64 on every rank' % (eng.P + 1))
     # 4. latency table
     if latency_table:
@@ -85,7 +105,7 @@ def preflight(world, rank, device_index, latency_table=True, out=print):
                 comm.allreduce_sum_(buf)
             torch.cuda.synchronize()
             us = (time.perf_counter() - t0) / 200 * 1e6
-            t = torch.tensor([us], dtype=torch.float64)
+            t = torch.tensor([us], dtype=torch.float64, device=side)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             rep['allreduce_us'][n] = float(t.item())
         say('[preflight] us per all-reduce (max over ranks, 200 back-to-back, G = %d): ' % world +
@@ -99,14 +119,14 @@ def preflight(world, rank, device_index, latency_table=True, out=print):
     batch = eng.make_batch(obs, act, adv, mean, eng.get_policy()[-2:], n_global=N * world)
     kw = {} if transport != 'torch.distributed callback' else {'allreduce': lambda t: dist.all_reduce(t)}
     res = eng.trpo_update(batch, **kw)
-    theta = eng.get_policy().double().cpu()
+    theta = eng.get_policy().double().to(side)
     all_theta = [torch.empty_like(theta) for _ in range(world)]
     dist.all_gather(all_theta, theta)
     same = all(torch.equal(all_theta[0], t) for t in all_theta)
     rep['theta_identical'] = same
-    if not same:
-        return _fail(rank, 'theta differs between ranks after one sharded update (max |diff| %.3e)'
-                     % max(float((all_theta[0] - t).abs().max()) for t in all_theta), rep), rep
+    if not agree(same, 'theta differs between ranks after one sharded update (max |diff| %.3e)'
+                 % max(float((all_theta[0] - t).abs().max()) for t in all_theta)):
+        return False, rep
     say('[preflight] sharded TRPO update: accepted=%s, kl=%.3e, theta bit-identical on all %d ranks' % (bool(res['accepted']), res['kl'], world))
     if transport == 'one-shot':
         eng.comm_ipc_detach()
