@@ -102,6 +102,7 @@ struct metrpo_ctx {
     void* d_big;         // workspace of the GEMM step-wise rollout (rollout_gemm.hip)
     size_t big_cap;
     void* d_res; size_t res_cap; unsigned int res_seq;   // rollout_resident.hip: uncached exchange region (abort cell | X packets | P packets) and the step stamps issued so far
+    void* d_skp_tab; size_t skp_tab_cap; long long skp_key[8]; int skp_Jx[8], skp_Jmax, skp_L; int persist_failed;   // mlp_persist.h: cached chunk-record table of the persistent stream-K rollout (key: the launch's shape) | a persistent launch timed out
     int res_failed;                                       // a resident launch gave up (its grid was not co-resident): this context stays on the step-wise path from then on
     int last_rollout_kernel;
     // metrpo_trpo_update_begin / _end: an update whose line search is still undecided on the host
@@ -248,6 +249,11 @@ static inline int rollout_error_seen(metrpo_ctx* c, hipStream_t st) {
     (void)hipMemsetAsync(comm_err_cell(c) + 1, 0, sizeof(double), st);
     const bool was_resident = (c->last_rollout_kernel == 4);
     if (was_resident) c->res_failed = 1;
+    if (c->last_rollout_kernel == 6) {
+        c->persist_failed = 1;
+        return set_err(c, METRPO_EHIP, "rollout: the persistent stream-K kernel's wait for a row block timed out (a workgroup of its grid never ran: is another process using "
+                                       "this GPU?); the trajectories of that launch are invalid, later rollouts of this context use the launch-per-step path");
+    }
     return set_err(c, METRPO_EHIP, was_resident ? "rollout: the resident kernel's hand-over timed out (a workgroup of its grid never ran: is another process using this GPU?); "
                                                   "the trajectories of that launch are invalid, later rollouts of this context use the step-wise path"
                                                 : "rollout: a migrating tile's hand-over timed out (producer workgroup never ran); trajectories are invalid");

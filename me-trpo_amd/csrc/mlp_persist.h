@@ -1,0 +1,359 @@
+// Persistent stream-K rollout: ALL steps of a rollout chunk of a two-hidden-layer ensemble (hidden >= 256: BASELINE's C2 / C3 shapes) in ONE launch.
+// The launch-per-step path (rollout_gemm.hip + mlp_streamk.h) pays, per 146 us step at the C3 share: a pre / post launch (12 us), two kernel
+// boundaries, the stream-K launch's prologue and drain, the accumulator hand-over of the even split (1.56 tiles per workgroup: 64 MB per step), and
+// the tile quantisation the even split exists to avoid.  None of that is needed once the time loop is inside the launch:
+//
+//   * the unit of work is a WHOLE tile (128 envs x 256 columns of one head: the k_mlp_sk tile, same transposed MFMA chain, same LDS-DMA ring, same operand
+//     reads -- mlp_streamk.h), the tiles of ALL steps form one sequence, and workgroup (x, i) -- XCD list x = blockIdx % 8, i = blockIdx / 8 -- takes
+//     positions i, i + G/8, ... of list x.  Over hundreds of steps every workgroup gets the same number of tiles to within one: no split tiles, no hand-over;
+//   * step t + 1 of a 128-env row block needs only step t of THAT row block (all heads and column blocks: NSL tiles).  Every finished tile adds one to
+//     the row block's arrival counter; the workgroup whose arrival completes the step closes it for those 128 envs -- de-normalise + residual, selection
+//     over the heads, reward, done, reset, then the policy and the normalised input row of step t + 1: the wave functions of big_prepost.h, the very code
+//     the launch-per-step path runs as k_big_pre_mfma<ENV, true> -- and raises the row block's ready flag.  A tile waits for its row block's flag
+//     before it loads its input rows; in the steady state the flag was raised about half a tile time earlier (the tiles of one step are ordered row block
+//     first, so a row block's tiles finish together and long before the next step's tiles of that row block come up): nobody waits, nothing is launched,
+//     and the closing work (20 x 5 us per step over 256 workgroups) disappears into the matrix stream;
+//   * each XCD list holds the tiles of 1/8 of the (head, column block) weight slices (2.5 slices of 20 at the C2 / C3 shapes), row block first: the 32
+//     workgroups behind one L2 stream the same 2-3 slices, which therefore stay in that L2 for the whole launch.
+//
+// Inter-workgroup visibility (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"):
+//   tile -> closing workgroup:  output partials by 16-byte sc1 (write-through) stores, every wave drains (vmcnt 0), workgroup barrier, ONE returning
+//                               agent-scope atomic add on the row block's counter.  The closer: one-lane agent acquire (L1 invalidate), barrier, plain loads;
+//   closing workgroup -> tiles: X rows by sc1 stores; S / U / ts / cur_model (read by the NEXT closer of the row block) by plain stores; every wave drains,
+//                               barrier, one-lane agent release + drain, relaxed agent store of the flag.  A tile's waves poll the flag (one agent-scope load,
+//                               issued a chunk ahead) and read their X rows with agent-scope loads.
+// Waits are bounded (2 s) and report through the sticky rollout error cell; the launch needs its whole grid on the chip (one workgroup per CU:
+// grid_is_coresident, probe.hip) -- otherwise, and for every shape outside (two hidden layers, producer-sized input, 2 x 32 policy), the launch-per-step
+// path runs.  Summation order of every output: the k-ordered chain of an unsplit k_mlp_sk tile -- bit for bit the launch-per-step path's results.
+#pragma once
+#include <vector>
+#include "mlp_streamk.h"
+#include "big_prepost.h"
+
+struct SkpPost {                                   // what the closing part needs; lives in device memory (written by k_skp_post_args in front of the launch)
+    ProblemDesc pd; RolloutK r; BigState st; const float* theta; const float* norm;
+};
+struct SkpArgs {
+    SkArgs a;                                      // shapes and pointers of the fused launch (x rows, W0, W1, epilogue images, output partials): mlp_streamk.h
+    const SkRec* tab;                              // [8][Jmax][L] chunk records of ONE step's tiles, per XCD list, row block first; [8 Jmax L] = the sentinel record
+    int Jx[8];                                     // tiles per step in list x
+    int Jmax, L, G8, T, NSL;                       // entries per tile (chunks + epilogue chunks); workgroups per list; steps of this launch; tiles per row-block step
+    int* xflag; unsigned* arrive;                  // [RB] each, zeroed in front of the launch: x of step t is ready when xflag[rb] >= t; arrivals so far
+    const int32_t* stop;                           // metrpo_sampler_progress's flag (constant during the launch)
+    const SkpPost* post;
+};
+
+__global__ void k_skp_post_args(SkpPost v, SkpPost* dst) { if (threadIdx.x == 0) *dst = v; }
+
+// Step t closed and step t + 1 prepared for the 128 envs of row block rb, by all 8 waves of the calling workgroup (whose arrival completed the step).
+// Not inlined: it runs once per 20 tiles, its ~160 registers and three large argument structs must not shape the register allocation of the chunk loop.
+template <int ENV>
+__device__ __noinline__ void skp_close_and_prepare(const SkpPost* __restrict__ pp, int t, int rb, const float* img, float* scratch, int* xflag) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // the other tiles' partials, the previous closer's S / U / ts / cur_model
+    __syncthreads();
+    const int b0 = rb * 128 + wave * 16;
+    if (b0 < pp->r.B) {
+        PreLane<ENV> pl;
+        float* ST = scratch + wave * 16 * Cfg<ENV, 64, 32>::NS;
+        big_pre_head<ENV, true>(pp->pd, pp->r, t + 1, pp->theta, pp->norm, pp->st, ST, b0, lane, pl);
+        big_pre_tail<ENV, true>(pp->r, t + 1, pp->st, img, ST, b0, lane, pl);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   // every writing wave drains
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               // (the compiler may drop the wait behind buffer_wbl2: restated where it cannot)
+        __hip_atomic_store(xflag + rb, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int ENV, int S0, int OT>
+__global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
+    using EP = SkEpi<OT>;
+    using GE = SkGeom<SK_A_PRODUCER, SK_EPI_OUT, S0, OT>;
+    using IM = PreImg<ENV>;
+    constexpr int E = EP::E, UPC = EP::UPC, NI0 = GE::NI0, STAGE = GE::STAGE;
+    static_assert(EP::FLOATS <= STAGE, "EPI image larger than a ring stage");
+    static_assert(NI0 <= 8, "layer-0 slice: at most 8 one-KB pieces (one per wave)");
+    static_assert(8 * 16 * Cfg<ENV, 64, 32>::NS <= STAGE, "the closing part's state tiles live in a free ring stage");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const ring = lds;
+    float* const img = lds + 4 * STAGE;                                        // policy image (PreImg<ENV>), built once
+    int* const lds_flag = (int*)(img + IM::IMG);
+    const SkArgs& a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (p.stop != nullptr && *p.stop != 0) return;                             // the sampling loop already ended
+    const int xl = blockIdx.x & 7, wi = blockIdx.x >> 3;                       // XCD list | position stride start
+    const int Jx = p.Jx[xl], L = p.L, G8 = p.G8, T = p.T;
+    const long long npos = (long long)T * Jx;
+    const int n_tiles = (wi < npos) ? (int)((npos - wi + G8 - 1) / G8) : 0;
+    const int nq = n_tiles * L;
+    if (nq == 0) return;
+    for (int k = tid; k < IM::IMG; k += 512) img[k] = IM::entry(p.post->theta, k);
+    const SkRec* const tabx = p.tab + (size_t)xl * p.Jmax * L;
+    const SkRec* const sentinel = p.tab + (size_t)8 * p.Jmax * L;
+
+    // position of an entry of this workgroup's sequence: tile jj of list xl at step t, chunk c.  Scalar bookkeeping only.
+    struct Cur { int jj, t, c; };
+    auto adv = [&](Cur& k) { if (++k.c == L) { k.c = 0; k.jj += G8; while (k.jj >= Jx) { k.jj -= Jx; ++k.t; } } };
+    auto rec_of = [&](const Cur& k) -> const SkRec* { return (k.t < T) ? tabx + ((size_t)k.jj * L + k.c) : sentinel; };
+
+    struct RecL { int kc, fl, m0, t; unsigned offA, offC; };                   // the chunk itself / the look-ahead (t: its tile's step)
+    struct RecI { int fl; unsigned offW1, offW0; };                            // its LDS-DMA copies
+    auto decL = [](const sk_i32x4& v, int t) { RecL r; r.kc = v[0] & 0xFFFF; r.fl = v[0] >> 16; r.m0 = v[1]; r.offA = (unsigned)v[2]; r.offC = (unsigned)v[3]; r.t = t; return r; };
+    auto decI = [](const sk_i32x4& v) { RecI r; r.fl = v[0] >> 16; r.offW1 = (unsigned)v[1]; r.offW0 = (unsigned)v[2]; return r; };
+    auto fetch2 = [&](const SkRec* pl_, const SkRec* pi_, int tl, RecL& rl, RecI& ri) {       // load + wait in ONE statement (mlp_streamk.h: why)
+        sk_i32x4 vl, vi;
+        asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx4 %1, %3, 0x10\n\ts_waitcnt lgkmcnt(0)" : "=&s"(vl), "=&s"(vi) : "s"(pl_), "s"(pi_));
+        rl = decL(vl, tl); ri = decI(vi);
+    };
+
+    const unsigned ring_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)ring;
+    const unsigned w1_voff = (unsigned)(wave * a.N + 4 * lane) * 4u;
+    unsigned w0_voff;
+    { const int pz = (wave % NI0) * 64 + lane, i4 = pz & 3, gg = (pz >> 2) & 3, jt = (pz >> 4) & 1, s = pz >> 5; w0_voff = (unsigned)((4 * s + gg) * a.K1 + 16 * jt + 4 * i4) * 4u; }
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto issue_piece = [&](const RecI& r, int q, auto tc) {
+        constexpr int t = decltype(tc)::value;
+        if (r.fl & SKF_NONE) return;
+        const unsigned st = ring_lds + (unsigned)((q & 3) * STAGE) * 4u;
+        if (!(r.fl & SKF_EPI)) {
+            if constexpr (t < 4) sk_glds16_s(w1_voff, (const char*)(a.W1 + r.offW1) + (size_t)t * ((size_t)a.N * 32), st + (unsigned)(wave + 8 * t) * 1024u);
+            else { if (wave < NI0) sk_glds16_s(w0_voff, a.W0 + r.offW0, st + (8192u + (unsigned)wave * 256u) * 4u); }
+        } else {
+            constexpr int NIE = EP::FLOATS / 256;
+            const int ii = wave + 8 * t;
+            if (ii < NIE) sk_glds16_s(lane16, (const char*)(a.epi + r.offW1) + (size_t)ii * 1024, st + (unsigned)ii * 1024u);
+        }
+    };
+    auto issue = [&](const RecI& r, int q) {
+        issue_piece(r, q, std::integral_constant<int, 0>{}); issue_piece(r, q, std::integral_constant<int, 1>{}); issue_piece(r, q, std::integral_constant<int, 2>{});
+        issue_piece(r, q, std::integral_constant<int, 3>{}); issue_piece(r, q, std::integral_constant<int, 4>{});
+    };
+    auto drain_vm = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_waitcnt(0x0F70); };
+
+    f32x4 acc[4][4];
+    f32x4 oacc[OT];
+    f32x4 hs[2][2];
+    float xr[S0];
+
+    // ready flag of a tile's row block: one agent-scope load (every lane the same word), issued a chunk ahead of the wait
+    auto probe_flag = [&](const RecL& r) -> int { return __hip_atomic_load(p.xflag + (r.m0 >> 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto wait_x = [&](const RecL& r, int seen) {                               // bounded: report, do not hang
+        if (seen >= r.t) return;
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(p.xflag + (r.m0 >> 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < r.t) {
+            __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t0 > 200000000ull) { if (lane == 0) *a.err = 1.0; break; }      // 2 s at 100 MHz
+        }
+    };
+    auto load_x = [&](const RecL& r) {                                         // agent-scope loads: the rows were written by another workgroup of this launch
+        const int m = min(r.m0 + wave * 16 + i, a.M - 1);
+        float* xp = const_cast<float*>(a.A) + r.offA + (size_t)m * a.lda + g;
+#pragma unroll
+        for (int s = 0; s < S0; ++s) xr[s] = __hip_atomic_load(xp + 4 * s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto produce = [&](int q, f32x4 (&dst)[2]) {
+        f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+        const float* w0 = ring + (q & 3) * STAGE + 8192 + lane;
+#pragma unroll
+        for (int s = 0; s < S0; ++s) {
+            d0 = MFMA16(w0[(2 * s) * 64], xr[s], d0);
+            d1 = MFMA16(w0[(2 * s + 1) * 64], xr[s], d1);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { dst[0][r] = relu1(d0[r]); dst[1][r] = relu1(d1[r]); }
+    };
+
+    f32x4 w[8];
+    const unsigned lane_off = (unsigned)((4 * g) * 256 + 4 * i) * 4u;
+    auto stage_addr = [&](int q) { return ring_lds + (unsigned)((q & 3) * STAGE) * 4u + lane_off; };
+    auto first4 = [&](unsigned addr) {
+        asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
+                     : "v"(addr), "i"(SK_WOFF(0)), "i"(SK_WOFF(1)), "i"(SK_WOFF(2)), "i"(SK_WOFF(3)));
+    };
+
+    // ---- prologue: entries 0 .. 2 under way, the first rows loaded ----
+    Cur cA, cB;                                                                // cA: the entry the next look-ahead fetch reads (q + 2); cB: the next copy record (q + 4)
+    RecL r0, r1; RecI r3;
+    {
+        Cur k; k.jj = wi % Jx; k.t = wi / Jx; k.c = 0;
+        const SkRec* e0 = rec_of(k); const int t0_ = k.t; adv(k);
+        const SkRec* e1 = rec_of(k); const int t1_ = k.t; adv(k);
+        cA = k;
+        const SkRec* e2 = rec_of(k); adv(k);
+        const SkRec* e3 = rec_of(k); adv(k);
+        cB = k;
+        sk_i32x4 l0, l1, i0, i1, i2, i3;
+        asm volatile("s_load_dwordx4 %0, %6, 0x0\n\ts_load_dwordx4 %1, %7, 0x0\n\ts_load_dwordx4 %2, %6, 0x10\n\ts_load_dwordx4 %3, %7, 0x10\n\t"
+                     "s_load_dwordx4 %4, %8, 0x10\n\ts_load_dwordx4 %5, %9, 0x10\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(l0), "=&s"(l1), "=&s"(i0), "=&s"(i1), "=&s"(i2), "=&s"(i3) : "s"(e0), "s"(e1), "s"(e2), "s"(e3));
+        r0 = decL(l0, t0_); r1 = decL(l1, t1_); r3 = decI(i3);
+        issue(decI(i0), 0); issue(decI(i1), 1); issue(decI(i2), 2);
+    }
+    wait_x(r0, -1);
+    load_x(r0);
+    drain_vm();
+    __syncthreads();                                                           // (also: the policy image is complete)
+    first4(stage_addr(0));
+
+    // an arrival whose outcome is still under way: issued behind the barrier that ended the tile's last chunk, looked at one chunk later
+    bool pend = false; int pend_t = 0, pend_rb = 0; unsigned arr_old = 0;
+    int seen = 0;                                                              // flag value probed for the next tile
+    __amdgpu_buffer_rsrc_t part_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.part, 0, 0xFFFFFFFFu, 0x00020000);
+    auto body = [&](auto par_, const int q) {
+        constexpr int PAR = decltype(par_)::value;
+        f32x4 (&h)[2] = hs[PAR];
+        const bool nmain = !(r1.fl & SKF_EPI);
+        const float* st = ring + (q & 3) * STAGE;
+        if (!(r0.fl & SKF_EPI)) produce(q, h);
+        if (nmain && (r1.fl & SKF_NEWTILE)) { wait_x(r1, seen); load_x(r1); }  // the next tile's rows (its flag was probed a chunk ago)
+        RecI r4; RecL rn;
+        const SkRec* const fa = rec_of(cA); const SkRec* const fb = rec_of(cB); const int fat = cA.t;
+        adv(cA); adv(cB);
+
+        if (!(r0.fl & SKF_EPI)) {
+            if (r0.fl & SKF_ZERO) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            {
+                const unsigned cur_a = stage_addr(q), nxt_a = stage_addr(q + 1);
+                auto group = [&](auto kc_) {
+                    constexpr int k = decltype(kc_)::value;
+                    constexpr int j = k >> 4, e = (k >> 2) & 3, u = k & 3;
+                    if constexpr (k < 28)
+                        asm volatile("s_waitcnt lgkmcnt(3)\n\tds_read_b128 %0, %2 offset:%3" : "=&v"(w[(k + 4) & 7]), "+v"(w[k & 7]) : "v"(cur_a), "i"(SK_WOFF(k + 4)));
+                    else if (nmain)
+                        asm volatile("s_waitcnt lgkmcnt(3)\n\tds_read_b128 %0, %2 offset:%3" : "=&v"(w[(k + 4) & 7]), "+v"(w[k & 7]) : "v"(nxt_a), "i"(SK_WOFF(k - 28)));
+                    else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(w[k & 7]) : "i"(31 - k));
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc[u][v] = MFMA16(w[k & 7][v], h[j][e], acc[u][v]);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+#define SKP_G4(b) group(std::integral_constant<int, (b)>{}); group(std::integral_constant<int, (b) + 1>{}); group(std::integral_constant<int, (b) + 2>{}); group(std::integral_constant<int, (b) + 3>{});
+#define SKP_P(t) issue_piece(r3, q + 3, std::integral_constant<int, (t)>{})
+                SKP_G4(0)  SKP_P(0);
+                SKP_G4(4)  SKP_P(1);
+                SKP_G4(8)  SKP_P(2);
+                SKP_G4(12) SKP_P(3);
+                SKP_G4(16) SKP_P(4);
+                SKP_G4(20) if (wave < 4) fetch2(fa, fb, fat, rn, r4);
+                SKP_G4(24) if (wave >= 4) fetch2(fa, fb, fat, rn, r4);
+                SKP_G4(28)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+            }
+        } else {
+            issue(r3, q + 3);
+            fetch2(fa, fb, fat, rn, r4);
+            if (!(r0.fl & SKF_NONE)) {
+                auto epi_chunk = [&](auto ee) {
+                    constexpr int EE = decltype(ee)::value;
+                    if (EE == 0) {
+#pragma unroll
+                        for (int ot = 0; ot < OT; ++ot) oacc[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int ul = 0; ul < UPC; ++ul) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const f32x4 bq = *(const f32x4*)(st + (ul * 4 + g) * 16 + 4 * r);
+                            f32x4 wf[OT];
+#pragma unroll
+                            for (int ot = 0; ot < OT; ++ot) wf[ot] = *(const f32x4*)(st + 256 + ((((ul * 4 + r) * 4 + g) * OT + ot) * 16 + i) * 4);
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                const float hb = relu1(acc[EE * UPC + ul][v][r] + bq[v]);
+#pragma unroll
+                                for (int ot = 0; ot < OT; ++ot) oacc[ot] = MFMA16(wf[ot][v], hb, oacc[ot]);
+                            }
+                        }
+                    }
+                };
+                if (E == 1 || r0.kc == 0) epi_chunk(std::integral_constant<int, 0>{});
+                else epi_chunk(std::integral_constant<int, E - 1>{});
+                if (r0.fl & SKF_EPILAST) {
+                    const int m = r0.m0 + wave * 16 + i;
+                    if (m < a.M) {                                            // write-through (sc1): read by the closing workgroup, possibly behind another L2
+                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                        const unsigned off = (r0.offC + (unsigned)m * (unsigned)a.ldp + 4u * g) * 4u;
+#pragma unroll
+                        for (int ot = 0; ot < OT; ++ot) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oacc[ot]), part_rs, off + 64u * ot, 0, 16);
+                    }
+                }
+                if (nmain) first4(stage_addr(q + 1));
+            }
+        }
+        if (rn.fl & SKF_NEWTILE) seen = probe_flag(rn);                        // (sentinels carry no NEWTILE)
+        drain_vm();                                                            // copies of entry q + 3, the rows, the output partials -- and a pending arrival's result
+        if (pend && tid == 0) *lds_flag = (arr_old == (unsigned)(pend_t + 1) * (unsigned)p.NSL - 1u) ? 1 : 0;
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (pend) {                                                            // uniform over the workgroup
+            pend = false;
+            if (*(volatile int*)lds_flag) skp_close_and_prepare<ENV>(p.post, pend_t, pend_rb, img, ring + (q & 3) * STAGE, p.xflag);     // stage q % 4: free until the next chunk's copies
+            __builtin_amdgcn_s_barrier();                                      // lds_flag may be rewritten only after everybody has read it
+            asm volatile("" ::: "memory");
+        }
+        if ((r0.fl & SKF_EPILAST) && r0.t + 1 < T) {                           // every wave's partials are complete behind the barrier: arrive (the last step is closed by the host's k_big_post)
+            pend = true; pend_t = r0.t; pend_rb = r0.m0 >> 7;
+            if (tid == 0) arr_old = __hip_atomic_fetch_add(p.arrive + pend_rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        r0 = r1; r1 = rn; r3 = r4;
+    };
+    for (int q = 0; q < nq; q += 2) {
+        body(std::integral_constant<int, 0>{}, q);
+        if (q + 1 < nq) body(std::integral_constant<int, 1>{}, q + 1);
+    }
+    if (pend) {                                                                // the arrival of this workgroup's last tile
+        if (tid == 0) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(arr_old) :: "memory"); *lds_flag = (arr_old == (unsigned)(pend_t + 1) * (unsigned)p.NSL - 1u) ? 1 : 0; }
+        __syncthreads();
+        if (*(volatile int*)lds_flag) skp_close_and_prepare<ENV>(p.post, pend_t, pend_rb, img, ring, p.xflag);
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------------------------------------
+// The chunk records of ONE step's tiles, per XCD list.  List x holds the (slice, row block) pairs u = slice * RB + rb of [x TPS / 8, (x + 1) TPS / 8) -- 1/8 of
+// the weight slices, so that the workgroups behind one L2 stream the same 2-3 slices -- ordered row block first (a row block's tiles finish together, early).
+template <int OT>
+static inline void skp_build_tab(const SkArgs& a, std::vector<SkRec>& tab, int (&Jx)[8], int& Jmax, int& L_out) {
+    using EP = SkEpi<OT>;
+    constexpr int E = EP::E;
+    const int RB = (a.M + 127) / 128, CB = a.N / 256, NCk = a.K1 / 32, NSL = a.heads * CB, TPS = NSL * RB, L = NCk + E;
+    std::vector<std::vector<std::pair<int, int>>> lists(8);
+    for (int x = 0; x < 8; ++x) {
+        const int u0 = (int)((long long)TPS * x / 8), u1 = (int)((long long)TPS * (x + 1) / 8);
+        for (int u = u0; u < u1; ++u) lists[x].push_back({u % RB, u / RB});       // (rb, slice)
+        std::sort(lists[x].begin(), lists[x].end());
+    }
+    Jmax = 0;
+    for (int x = 0; x < 8; ++x) { Jx[x] = (int)lists[x].size(); Jmax = std::max(Jmax, Jx[x]); }
+    L_out = L;
+    tab.assign((size_t)8 * Jmax * L + 1, SkRec{});
+    for (int x = 0; x < 8; ++x)
+        for (int jj = 0; jj < Jx[x]; ++jj) {
+            const int rb = lists[x][jj].first, sl = lists[x][jj].second, head = sl / CB, cb = sl % CB;
+            for (int c = 0; c < L; ++c) {
+                SkRec r = {};
+                int fl = 0, kc = c;
+                if (c < NCk) { if (c == 0) fl |= SKF_ZERO | SKF_NEWTILE; if (c == NCk - 1) fl |= SKF_LAST; }
+                else { kc = c - NCk; fl = SKF_EPI | (kc == E - 1 ? SKF_EPILAST : 0); }
+                r.w = r.w2 = kc | (fl << 16); r.m0 = rb * 128;
+                r.offA = (unsigned)(head * a.strideA);
+                r.offC = (unsigned)(((long long)cb * a.heads + head) * a.stridePart);
+                if (fl & SKF_EPI) { r.offW1 = (unsigned)(((head * CB + cb) * E + kc) * EP::FLOATS); r.offW0 = 0; }
+                else { r.offW1 = (unsigned)(head * a.strideW1 + (long long)(32 * c) * a.N + cb * 256); r.offW0 = (unsigned)(head * a.strideW0 + 32 * c); }
+                r.tile = (head * CB + cb) * RB + rb;
+                tab[((size_t)x * Jmax + jj) * L + c] = r;
+            }
+        }
+    SkRec s = {};
+    s.w = s.w2 = (SKF_NONE | SKF_EPI) << 16; s.tile = -1;
+    tab[(size_t)8 * Jmax * L] = s;
+}

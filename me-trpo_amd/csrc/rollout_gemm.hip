@@ -12,17 +12,9 @@
 #include "gemm_mfma.h"
 #include "mfma_common.h"
 #include "mlp_streamk.h"
+#include "big_prepost.h"
+#include "mlp_persist.h"
 #include "policy_chain3.h"
-
-// ------------------------------------------------------------------------------------------------
-struct BigState { float* S; int* ts; int* cur_model; float* X; float* U; float* HA; float* HB; float* OUT; float* PART;
-                  int ldx;
-                  // output layer left as split-K partials (gemm_skinny_bias with defer): k_big_post adds them and the bias
-                  int out_splits; long long out_stride; const float* out_bias; long long out_bias_stride;
-                  int out_ld;      // row stride of a partial (ns; 16 OT on the stream-K path, mlp_streamk.h)
-                  int xone;        // 1: X[nin] = 1 -- the stream-K path's layer-0 producer takes the bias as one more input row
-                  float* PA; float* PB;
-                  float* PIMG; };   // k_big_pre_mfma3: the policy's fragment image, built once per launch chain (k_pre_mfma3_image)      // policy activations of the GEMM pre-path [B][max policy width]   // ldx: row stride of X = n_in rounded up to 4 floats, so every row is 16-byte aligned for the layer-0 GEMM's loads
 
 // policy.get_actions + clip + normalise/drop for policies without an MFMA pre-kernel (Humanoid's 100-50-25): a block = 64 envs x G thread
 // groups; the outputs of every policy layer are split over the groups (activations in LDS columns), group 0 owns the env's bookkeeping
@@ -90,149 +82,6 @@ __global__ void k_big_pre(ProblemDesc pd, RolloutK r, int t, const float* __rest
 // chain below reads.  One launch per step instead of two between the ensemble kernels: k_big_post(t - 1) + this kernel's own launch and
 // its reload of the state cost ~17 us of a 150 us step at the C3 share.  Same arithmetic in the same order as k_big_post: trajectories are
 // bit for bit those of the two-launch sequence (tests/test_gpu_streamk.py).
-// Step t - 1 closed for a wave's 16 envs in the lane layout of the MFMA pre-kernels (env c, quarter q: dims 16 hh + 4 q .. + 3 of every 16-dim block):
-// what k_big_post computes, same arithmetic in the same order; the new state lands in the wave's LDS tile ST [16][NS] (and in S), ready for the policy chain.
-template <int ENV, int NS, int NA>
-__device__ __forceinline__ void big_close_step(const ProblemDesc& pd, const RolloutK& r, int t, const float* __restrict__ norm, const BigState& st, float* ST,
-                                               int c, int q, bool active, int b, uint64_t genv) {
-    constexpr int NH = (NS + 15) / 16;
-    // ---- close step t - 1 (k_big_post) for this wave's 16 envs ----
-    const int bc = active ? b : max(r.B - 1, 0);
-    const int K = pd.K, tp = t - 1;
-    const int ttp = tp + RK_TOFF(r, bc);
-    const size_t tbp = (size_t)ttp * RK_STRIDE(r) + RK_ENV(r, bc);
-    const float* diff_mean = norm + 2 * (NS + NA); const float* diff_std = diff_mean + NS;
-    const uint4 dstep = rng_draw(r.seed, genv, r.t0 + ttp, RNG_STEP, 0);
-    int sel = st.cur_model[bc];
-    if (r.sam_mode == METRPO_SAM_STEP_RAND) sel = (r.model_idx != nullptr) ? r.model_idx[tbp] : rng_index(dstep.z, K);
-    if (r.sam_mode == METRPO_SAM_ONE_MODEL) sel = 0;
-    const bool simple = (r.sam_mode == METRPO_SAM_STEP_RAND || r.sam_mode == METRPO_SAM_EPS_RAND || r.sam_mode == METRPO_SAM_ONE_MODEL);
-    float ua_[NA];                                           // clipped actions of step t - 1 (summed below, behind the loads of the output partials: one round trip for both)
-#pragma unroll
-    for (int d = 0; d < NA; ++d) ua_[d] = st.U[(size_t)bc * NA + d];
-        float vnew[NH][4];
-    bool finl = true;
-#pragma unroll
-    for (int hh = 0; hh < NH; ++hh) {
-        const int i0 = 16 * hh + 4 * q;                      // dims i0 .. i0 + 3 (the partial rows are 16 OT floats wide, zero beyond ns)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) vnew[hh][rr] = 0.0f;
-        if (i0 >= NS) continue;
-        auto outv4 = [&](int k, float (&o)[4]) {             // output layer of head k, dims i0 .. i0 + 3: bias, then the partials in split order (k_big_post: outv)
-            if (st.out_splits == 0) {
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) o[rr] = (i0 + rr < NS) ? st.OUT[((size_t)k * r.B + bc) * NS + i0 + rr] : 0.0f;
-                return;
-            }
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) o[rr] = (i0 + rr < NS) ? st.out_bias[(size_t)k * st.out_bias_stride + i0 + rr] : 0.0f;
-            for (int sp = 0; sp < st.out_splits; ++sp) {
-                const float* pr_ = st.PART + ((size_t)sp * K + k) * st.out_stride + (size_t)bc * st.out_ld + i0;
-                if ((st.out_ld & 3) == 0) { const f32x4 p4 = *(const f32x4*)pr_;
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) o[rr] += p4[rr]; }
-                else {
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) if (i0 + rr < NS) o[rr] += pr_[rr];
-                }
-            }
-        };
-        float so[4], dm_[4], ds_[4];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) { const int i = min(i0 + rr, NS - 1); so[rr] = st.S[(size_t)bc * NS + i]; dm_[rr] = diff_mean[i]; ds_[rr] = diff_std[i]; }
-        auto head4 = [&](int k, float (&hv)[4]) { float o[4]; outv4(k, o);
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) hv[rr] = fmaf(ds_[rr], o[rr], dm_[rr]) + so[rr]; };
-        float v4[4];
-        if (simple) head4(sel, v4);
-        else {
-            float m4[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int k = 0; k < K; ++k) { float h4[4]; head4(k, h4);
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) m4[rr] += h4[rr]; }
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) { m4[rr] /= (float)K; v4[rr] = m4[rr]; }
-            if (r.sam_mode == METRPO_SAM_MODEL_MEAN_STD) {
-                float var4[4] = {0.f, 0.f, 0.f, 0.f};
-                for (int k = 0; k < K; ++k) { float h4[4]; head4(k, h4);
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) { const float d_ = h4[rr] - m4[rr]; var4[rr] = fmaf(d_, d_, var4[rr]); } }
-                float z4[4];
-                if (r.sel_noise == nullptr) normal4(rng_draw(r.seed, genv, r.t0 + ttp, RNG_SELNOISE, i0 >> 2), z4);     // dims i0 .. i0 + 3 = chunk i0 / 4
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const float nz = (r.sel_noise != nullptr) ? r.sel_noise[tbp * NS + min(i0 + rr, NS - 1)] : z4[rr];
-                    v4[rr] = fmaf(nz, sqrtf(var4[rr] / (float)K), m4[rr]);
-                }
-            } else if (r.sam_mode == METRPO_SAM_MODEL_MED) {
-                const int r_lo = (K - 1) / 2, r_hi = K / 2;
-                float lo4[4] = {0.f, 0.f, 0.f, 0.f}, hi4[4] = {0.f, 0.f, 0.f, 0.f};
-                for (int k = 0; k < K; ++k) {
-                    float xk[4]; head4(k, xk);
-                    int rank[4] = {0, 0, 0, 0};
-                    for (int j = 0; j < K; ++j) { float xj[4]; head4(j, xj);
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) rank[rr] += (xj[rr] < xk[rr]) || (xj[rr] == xk[rr] && j < k); }
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) { if (rank[rr] == r_lo) lo4[rr] = xk[rr]; if (rank[rr] == r_hi) hi4[rr] = xk[rr]; }
-                }
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) v4[rr] = 0.5f * (lo4[rr] + hi4[rr]);
-            }
-        }
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) if (i0 + rr < NS) { vnew[hh][rr] = v4[rr]; finl = finl && isfinite(v4[rr]); ST[c * NS + i0 + rr] = v4[rr]; }
-    }
-    float su2 = 0.0f;                                        // sum of squared clipped actions in action order (every lane of the env, redundantly)
-#pragma unroll
-    for (int d = 0; d < NA; ++d) su2 = fmaf(ua_[d], ua_[d], su2);
-    int fin = finl ? 1 : 0;                                  // all-finite over the env's dims: the env's four lanes are c, c + 16, c + 32, c + 48
-    fin &= __shfl_xor(fin, 16, 64); fin &= __shfl_xor(fin, 32, 64);
-    wave_lds_sync();
-    const float* Sv = ST + c * NS;                           // the env's next state, every dim
-    constexpr int ki = (ENV == METRPO_ENV_SWIMMER || ENV == METRPO_ENV_HOPPER) ? 5 : (ENV == METRPO_ENV_HALF_CHEETAH) ? 9 : (ENV == METRPO_ENV_ANT) ? 15 : (ENV == METRPO_ENV_SNAKE) ? 7 : (ENV == METRPO_ENV_HUMANOID) ? NS - 1 : 0;
-    const float key = Sv[ki], h0v = Sv[0], h1v = Sv[1], zc = Sv[2];
-    float pen = 0.0f;
-    if (ENV == METRPO_ENV_HOPPER) for (int j = 2; j < NS; ++j) pen += fmaxf(fabsf(Sv[j]) - 100.0f, 0.0f);
-    float cost = 0.0f;
-    switch (ENV) {
-    case METRPO_ENV_SWIMMER: cost = -(key - 1e-2f * (su2 / (float)NA)); break;
-    case METRPO_ENV_HALF_CHEETAH: cost = -fminf(fmaxf(key - 1e-1f * 0.5f * su2, -10.0f), 10.0f); break;
-    case METRPO_ENV_ANT: cost = -(key - 1e-2f * 0.5f * su2 + 0.05f); break;
-    case METRPO_ENV_HOPPER: cost = -(key - 0.01f * 0.5f * su2 - 10.0f * fmaxf(0.45f - h0v, 0.0f) - 10.0f * fmaxf(fabsf(h1v) - 0.2f, 0.0f) - pen); break;
-    case METRPO_ENV_SNAKE: cost = -(key - 1e-2f * 0.5f * su2); break;
-    case METRPO_ENV_HUMANOID: cost = (key - 1.5f) * (key - 1.5f) + 1e-2f * 1e-3f * su2; break;      // key = the last state dim (k_big_post: last)
-    }
-    int ts = st.ts[bc] + 1;
-    bool dn = (ENV == METRPO_ENV_ANT) ? !((zc >= 0.2f) && (zc <= 1.0f) && (fin != 0)) : false;
-    dn = dn || (ts >= r.H);
-    int cur = st.cur_model[bc];
-    if (active && q == 0) { r.rew[tbp] = -cost; r.done[tbp] = dn ? 1 : 0; r.tpath[tbp] = ts - 1; }
-    wave_lds_sync();                                         // every lane has read its env's scalars: the reset rows may overwrite the tile
-    if (dn) {                                                // uniform over the env's four lanes
-        const size_t rb = (size_t)(tp + 1) * r.B + bc;
-        const int row = (r.reset_idx != nullptr) ? r.reset_idx[rb] : rng_index(dstep.w, r.n_pool);
-        cur = (r.reset_model != nullptr) ? r.reset_model[rb] : rng_index16(dstep.z, K);
-#pragma unroll
-        for (int hh = 0; hh < NH; ++hh)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) { const int i = 16 * hh + 4 * q + rr; if (i < NS) { vnew[hh][rr] = r.pool[(size_t)row * NS + i]; ST[c * NS + i] = vnew[hh][rr]; } }
-        ts = 0;
-    }
-    if (active) {
-#pragma unroll
-        for (int hh = 0; hh < NH; ++hh)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) { const int i = 16 * hh + 4 * q + rr; if (i < NS) st.S[(size_t)b * NS + i] = vnew[hh][rr]; }
-        if (q == 0) { st.ts[b] = ts; if (dn) st.cur_model[b] = cur; }
-    } else {
-#pragma unroll
-        for (int hh = 0; hh < NH; ++hh)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) { const int i = 16 * hh + 4 * q + rr; if (i < NS) ST[c * NS + i] = 0.0f; }       // rows beyond the batch: zeros, as the reload below gives
-    }
-}
-
 #ifdef PP_TIMING        // developer instrumentation (SRC=rollout_gemm.hip tools/build_variant.sh pptiming -DPP_TIMING): shader-clock phases of workgroup 0, wave 0 of the merged launch
 __device__ unsigned long long g_pp_phase[8];
 #define PP_MARK(i) { if (POST && blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); g_pp_phase[i] += n_ - pp_t; pp_t = n_; } }
@@ -244,8 +93,8 @@ template <int ENV, bool POST>
 __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r, int t, const float* __restrict__ theta,
                                                       const float* __restrict__ norm, BigState st) {
     using C = Cfg<ENV, 64, 32>;
-    constexpr int NS = C::NS, NA = C::NA, NDROP = C::NDROP, PH = 32, NS_KS = C::NS_KS;
-    constexpr int O_PF1 = NS_KS * 2 * 64, O_PF2 = O_PF1 + 16 * 64, O_B0 = O_PF2 + 8 * 64, O_B1 = O_B0 + 32, O_B2 = O_B1 + 32, IMG = O_B2 + 16;
+    using IM = PreImg<ENV>;
+    constexpr int NS = C::NS, IMG = IM::IMG;
     __shared__ __attribute__((aligned(16))) float lds[IMG + 4 * 16 * NS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
@@ -260,23 +109,9 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
     // step t - 1 has been closed below: the gathers' round trip passes behind the post part's own loads instead of in front of them
     constexpr int NIT = (IMG + 255) / 256;
     float wv[NIT];
-    {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = tid + 256 * it;
-            float w = 0.0f;
-            const int ln = i & 63, cc = ln & 15, qq = ln >> 4;
-            if (i < O_PF1) { const int f = i >> 6, s_ = f >> 1, cb = f & 1, in = 4 * s_ + qq; if (in < NS) w = theta[C::pW0 + in * PH + 16 * cb + cc]; }
-            else if (i < O_PF2) { const int f = (i - O_PF1) >> 6, kk = f >> 1, cb = f & 1; w = theta[C::pW1 + (16 * (kk >> 2) + 4 * qq + (kk & 3)) * PH + 16 * cb + cc]; }
-            else if (i < O_B0) { const int kk = (i - O_PF2) >> 6; if (cc < NA) w = theta[C::pW2 + (16 * (kk >> 2) + 4 * qq + (kk & 3)) * NA + cc]; }
-            else if (i < O_B1) w = theta[C::pb0 + (i - O_B0)];
-            else if (i < O_B2) w = theta[C::pb1 + (i - O_B1)];
-            else if (i < IMG) { const int d = i - O_B2; if (d < NA) w = theta[C::pb2 + d]; }
-            wv[it] = w;
-        }
-    }
+    for (int it = 0; it < NIT; ++it) wv[it] = IM::entry(theta, tid + 256 * it);
     const uint64_t genv = r.stream_offset + (uint64_t)RK_ENV(r, b);
-    const int tt = t + RK_TOFF(r, b);                            // row of the trajectory tensors / draw counter of this env's step
     if (t == 0 && active && q == 0 && r.init_obs != nullptr) {   // continuation of a chunked rollout
         st.cur_model[b] = r.init_model[b]; st.ts[b] = r.init_ts[b];
         for (int i = 0; i < NS; ++i) st.S[(size_t)b * NS + i] = r.init_obs[(size_t)b * NS + i];
@@ -288,100 +123,14 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma(ProblemDesc pd, RolloutK r
         for (int i = 0; i < NS; ++i) st.S[(size_t)b * NS + i] = r.pool[(size_t)row * NS + i];
     }
     if constexpr (!POST) { __builtin_amdgcn_s_waitcnt(0x0F70); wave_lds_sync(); }      // t == 0: the reset rows of this tile were written by lanes of its own wave and are read back below
-    const int lim = min(16, max(0, r.B - b0)) * NS;
-    // Everything the END of this launch needs that depends on nothing computed here goes out NOW, with the loads of the post part: the normaliser
-    // rows and log_std of this lane's dims (L2 hits, but a round trip of their own when first touched behind the policy chain) and the action
-    // noise of step t (Philox + Box-Muller: ~150 vector instructions that run while the loads are under way).  Same values, same arithmetic.
-    const float* in_mean = norm; const float* in_std = norm + (NS + NA);
-    const float* __restrict__ log_std = theta + C::pLS;
-    constexpr int NSQ = (NS + 3) / 4;
-    float smn[NSQ], ssd[NSQ], amn[4], asd[4], lsd[4], zn[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < NSQ; ++j) { const int i = min(q + 4 * j, NS - 1); smn[j] = in_mean[i]; ssd[j] = in_std[i]; }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const int d = min(4 * q + j, NA - 1); amn[j] = in_mean[NS + d]; asd[j] = in_std[NS + d]; lsd[j] = log_std[d]; }
-    if (!r.determ && r.eps == nullptr) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int d0 = 4 * q + 2 * h;
-            if (d0 >= NA) continue;
-            const uint4 blk = rng_draw(r.seed, genv, r.t0 + tt, RNG_STEP, d0 >> 1);
-            normal2(blk.x, blk.y, zn[2 * h], zn[2 * h + 1]);
-        }
-    }
-    if constexpr (POST) {
-        big_close_step<ENV, NS, NA>(pd, r, t, norm, st, ST, c, q, active, b, genv);
-    } else {
-        for (int i = lane; i < 16 * NS; i += 64) ST[i] = (i < lim) ? st.S[(size_t)b0 * NS + i] : 0.0f;
-    }
-    wave_lds_sync();
+    PreLane<ENV> pl;
+    big_pre_head<ENV, POST>(pd, r, t, theta, norm, st, ST, b0, lane, pl);      // (POST: closes step t - 1 first) state tile, obs[t]
     PP_MARK(0)
-    if (lim > 0) {
-        if (r.vB == 0) { const size_t base = ((size_t)t * r.B + b0) * NS; for (int i = lane; i < lim; i += 64) r.obs[base + i] = ST[i]; }
-        else for (int i = lane; i < lim; i += 64) {              // merged rounds: a tile's envs may belong to two rounds
-            const int bi = b0 + i / NS;
-            r.obs[((size_t)(t + RK_TOFF(r, bi)) * r.vB + RK_ENV(r, bi)) * NS + i % NS] = ST[i];
-        }
-    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) { const int i = tid + 256 * it; if (i < IMG) lds[i] = wv[it]; }
     __syncthreads();                                             // image complete
     PP_MARK(1)
-    f32x4 p0[2], p1[2];
-    p0[0] = *(const f32x4*)&lds[O_B0 + 4 * q]; p0[1] = *(const f32x4*)&lds[O_B0 + 16 + 4 * q];
-#pragma unroll
-    for (int s_ = 0; s_ < NS_KS; ++s_) {
-        const int f = 4 * s_ + q;
-        const float x = (f < NS) ? ST[c * NS + f] : 0.0f;
-        p0[0] = MFMA16(lds[(s_ * 2 + 0) * 64 + lane], x, p0[0]);
-        p0[1] = MFMA16(lds[(s_ * 2 + 1) * 64 + lane], x, p0[1]);
-    }
-    p1[0] = *(const f32x4*)&lds[O_B1 + 4 * q]; p1[1] = *(const f32x4*)&lds[O_B1 + 16 + 4 * q];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) p0[cb][rr] = tanh_fast(p0[cb][rr]);
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-        p1[0] = MFMA16(lds[O_PF1 + (kk * 2 + 0) * 64 + lane], p0[kk >> 2][kk & 3], p1[0]);
-        p1[1] = MFMA16(lds[O_PF1 + (kk * 2 + 1) * 64 + lane], p0[kk >> 2][kk & 3], p1[1]);
-    }
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) p1[cb][rr] = tanh_fast(p1[cb][rr]);
-    f32x4 m0 = *(const f32x4*)&lds[O_B2 + 4 * q], m1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kk = 0; kk < 8; kk += 2) {
-        m0 = MFMA16(lds[O_PF2 + kk * 64 + lane], p1[kk >> 2][kk & 3], m0);
-        m1 = MFMA16(lds[O_PF2 + (kk + 1) * 64 + lane], p1[(kk + 1) >> 2][(kk + 1) & 3], m1);
-    }
-    const f32x4 mu = m0 + m1;
-    if (!active) return;
-    PP_MARK(2)
-    const size_t tb = (size_t)tt * RK_STRIDE(r) + RK_ENV(r, b);
-    // state part of the normalised, dropped input: lane (c, q) writes its dims q, q + 4, ...
-#pragma unroll
-    for (int j = 0; j < NSQ; ++j) { const int i = q + 4 * j; if (i < NS && i >= NDROP) st.X[(size_t)b * st.ldx + i - NDROP] = (ST[c * NS + i] - smn[j]) / ssd[j]; }     // training.py:228,146-151
-    if (q == 0) for (int j = C::NIN; j < st.ldx; ++j) st.X[(size_t)b * st.ldx + j] = (st.xone && j == C::NIN) ? 1.0f : 0.0f;   // pad columns of the 16-byte aligned rows (layer 0 contracts over ldx)
-    // action dims 4q .. 4q+3 of this lane = Philox chunks 2q, 2q+1 (chunk 0 = the step block), exactly as k_big_pre
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int d0 = 4 * q + 2 * h;
-        if (d0 >= NA) continue;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int d = d0 + j;
-            if (d >= NA) continue;
-            const float m = mu[2 * h + j];
-            float a = m;
-            if (!r.determ) a = fmaf((r.eps != nullptr) ? r.eps[tb * NA + d] : zn[2 * h + j], __expf(fmaxf(lsd[2 * h + j], LOG_MIN_STD)), m);
-            r.act[tb * NA + d] = a; r.mean[tb * NA + d] = m;
-            const float ac = fminf(fmaxf(a, -1.0f), 1.0f);          // env_helpers.py:599
-            st.U[(size_t)b * NA + d] = ac;
-            st.X[(size_t)b * st.ldx + (NS - NDROP) + d] = (ac - amn[2 * h + j]) / asd[2 * h + j];
-        }
-    }
+    big_pre_tail<ENV, false>(r, t, st, lds, ST, b0, lane, pl);   // policy chain, action, act / mean / U / X
 #ifdef PP_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -766,6 +515,56 @@ static SkPath sk_select(const metrpo_ctx* c, int B) {
     return sp;
 }
 
+// ---- persistent stream-K rollout (mlp_persist.h): the (env, input steps, output tiles) instantiations = the five envs of the 2 x 32 MFMA pre-step ----
+struct SkpVt {
+    const void* kern; size_t lds;
+    void (*launch)(const SkpArgs&, int grid, size_t lds, hipStream_t);
+    void (*tab)(const SkArgs&, std::vector<SkRec>&, int (&)[8], int&, int&);
+};
+template <int ENV, int S0, int OT> static SkpVt skp_vt() {
+    SkpVt v;
+    v.kern = (const void*)k_sk_persist<ENV, S0, OT>;
+    v.lds = sizeof(float) * (size_t)(4 * SkGeom<SK_A_PRODUCER, SK_EPI_OUT, S0, OT>::STAGE + PreImg<ENV>::IMG + 4);
+    v.launch = [](const SkpArgs& p, int grid, size_t lds, hipStream_t st) { hipLaunchKernelGGL((k_sk_persist<ENV, S0, OT>), dim3(grid), dim3(512), lds, st, p); };
+    v.tab = [](const SkArgs& a, std::vector<SkRec>& t, int (&Jx)[8], int& Jmax, int& L) { skp_build_tab<OT>(a, t, Jx, Jmax, L); };
+    return v;
+}
+static bool skp_select(const ProblemDesc& pd, int S0, int OT, SkpVt* v) {
+    if (pd.pol.n_layers != 3 || pd.pol.dims[1] != 32 || pd.pol.dims[2] != 32 || pd.pol.act[0] != METRPO_ACT_TANH) return false;
+    switch (pd.env) {
+    case METRPO_ENV_SWIMMER:      if (pd.ns == 10 && pd.na == 2 && pd.n_drop == 2 && S0 == 3 && OT == 1) { *v = skp_vt<METRPO_ENV_SWIMMER, 3, 1>(); return true; } break;
+    case METRPO_ENV_HOPPER:       if (pd.ns == 11 && pd.na == 3 && pd.n_drop == 0 && S0 == 4 && OT == 1) { *v = skp_vt<METRPO_ENV_HOPPER, 4, 1>(); return true; } break;
+    case METRPO_ENV_SNAKE:        if (pd.ns == 14 && pd.na == 4 && pd.n_drop == 2 && S0 == 5 && OT == 1) { *v = skp_vt<METRPO_ENV_SNAKE, 5, 1>(); return true; } break;
+    case METRPO_ENV_HALF_CHEETAH: if (pd.ns == 18 && pd.na == 6 && pd.n_drop == 1 && S0 == 6 && OT == 2) { *v = skp_vt<METRPO_ENV_HALF_CHEETAH, 6, 2>(); return true; } break;
+    case METRPO_ENV_ANT:          if (pd.ns == 29 && pd.na == 8 && pd.n_drop == 2 && S0 == 9 && OT == 2) { *v = skp_vt<METRPO_ENV_ANT, 9, 2>(); return true; } break;
+    }
+    return false;
+}
+// chunk-record table of this launch shape in device memory (cached in the context: the shape repeats every iteration)
+static int skp_table(metrpo_ctx* c, const SkpVt& v, const SkArgs& a, SkpArgs* p, hipStream_t st) {
+    const long long key[8] = {a.M, a.heads, a.K1, a.N, (long long)a.strideW1, (long long)a.strideW0, (long long)a.stridePart, (long long)c->pd.env};
+    bool same = c->d_skp_tab != nullptr;
+    for (int i = 0; i < 8; ++i) same = same && c->skp_key[i] == key[i];
+    if (!same) {
+        std::vector<SkRec> tab;
+        v.tab(a, tab, c->skp_Jx, c->skp_Jmax, c->skp_L);
+        const size_t bytes = tab.size() * sizeof(SkRec);
+        if (bytes > c->skp_tab_cap) {
+            if (c->d_skp_tab) HIP_TRY(c, hipFree(c->d_skp_tab));
+            c->d_skp_tab = nullptr; c->skp_tab_cap = 0;
+            HIP_TRY(c, hipMalloc(&c->d_skp_tab, bytes));
+            c->skp_tab_cap = bytes;
+        }
+        HIP_TRY(c, hipStreamSynchronize(st));                 // an earlier launch may still read the old table (first use of a shape only)
+        HIP_TRY(c, hipMemcpy(c->d_skp_tab, tab.data(), bytes, hipMemcpyHostToDevice));
+        for (int i = 0; i < 8; ++i) c->skp_key[i] = key[i];
+    }
+    p->tab = (const SkRec*)c->d_skp_tab;
+    for (int x = 0; x < 8; ++x) p->Jx[x] = c->skp_Jx[x];
+    p->Jmax = c->skp_Jmax; p->L = c->skp_L;
+    return METRPO_OK;
+}
+
 bool gemm_path_applicable(const metrpo_ctx* c) {
     const ProblemDesc& pd = c->pd;
     if (pd.ns > 64) return false;
@@ -823,7 +622,19 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
     const bool pre_gemm = !pre_mfma && ((pg_env && pg_env[0] == '1') || (!(pg_env && pg_env[0] == '0') && (B >= 1024 || pd.pol.n_params >= 4096)));
     const size_t nPol = pre_gemm ? up4((size_t)B * pd.pol.max_width) : 0;
     const size_t nPimg = pre_lds ? up4((size_t)pre_mfma3_image_floats<55, 21, 100, 50, 25>()) : 0;      // the only three-hidden-layer instantiation (big_pre_mfma_select)
-    const size_t need = ((nS + nX + nU + 2 * nH + nO + nP + 2 * nPol + nPimg + nSkImg + nSkSched + nSkX + nSkFlag) * sizeof(float) + 2 * (size_t)B * sizeof(int) + 1023) & ~(size_t)255;
+    // persistent form of mode 1 (mlp_persist.h): every step of this chunk in ONE launch.  Needs the MFMA pre-step of the 2 x 32 policies (its wave functions close a
+    // step and prepare the next inside the launch), whole-batch rows (no merged rounds), at least two steps, and its grid on the chip at once.
+    SkpVt skp = {};
+    int skp_grid = 0;
+    bool persist = sk.mode == 1 && vB == 0 && a->T >= 2 && ctx_opt(c, OPT_NO_PERSIST) == nullptr && !c->persist_failed && pre_lds == 0 && pre_mfma != nullptr &&
+                   skp_select(pd, sk.S0, sk.OT, &skp);
+    if (persist) {
+        if (skp.lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute(skp.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)skp.lds));
+        skp_grid = (std::min(sched_cus(c, st), c->n_sm) / 8) * 8;
+        persist = skp_grid >= 8 && grid_is_coresident(c, skp.kern, 512, skp.lds, skp_grid, st);
+    }
+    const size_t nSkpFlag = persist ? up4(2 * (size_t)((B + 127) / 128)) : 0, nSkpPost = persist ? up4((sizeof(SkpPost) + 3) / 4) : 0;
+    const size_t need = ((nS + nX + nU + 2 * nH + nO + nP + 2 * nPol + nPimg + nSkImg + nSkSched + nSkX + nSkFlag + nSkpFlag + nSkpPost) * sizeof(float) + 2 * (size_t)B * sizeof(int) + 1023) & ~(size_t)255;
     if (need_out) *need_out = need;
     if (ws == nullptr) return METRPO_OK;
     BigState bs = {};
@@ -833,6 +644,8 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
     char* sk_sched = (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255); p += nSkSched;     // 256-byte aligned inside its (64 floats larger) slot
     float* sk_xacc = p; p += nSkX;
     unsigned* sk_flag = (unsigned*)p; p += nSkFlag;
+    int* skp_flags = (int*)p; p += nSkpFlag;
+    SkpPost* skp_post = (SkpPost*)p; p += nSkpPost;
     bs.ts = (int*)p; bs.cur_model = bs.ts + B;
     bs.out_ld = pd.ns; bs.xone = (sk.mode == 1 || l0r) ? 1 : 0;
     if (sk.mode) c->last_rollout_kernel = 5;
@@ -857,7 +670,7 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
             o.A = bs.HB; o.strideA = (long long)B * o.K1; o.lda = o.K1;
         }
         sk.a1.xacc = sk_xacc; sk.a1.xflag = sk_flag; sk.a1.err = comm_err_cell(c) + 1;      // scal[S_ROLLERR]
-        HIP_TRY(c, sk.v1.sched(sk.a1, sk.p1, sk_sched, st));
+        if (!persist) HIP_TRY(c, sk.v1.sched(sk.a1, sk.p1, sk_sched, st));
         if (sk.mode == 2) {
             sk.a2.xacc = sk_xacc; sk.a2.xflag = sk_flag; sk.a2.err = comm_err_cell(c) + 1;
             HIP_TRY(c, sk.v2.sched(sk.a2, sk.p2, sk_sched + ((sk.p1.sched_bytes + 255) & ~(size_t)255), st));
@@ -875,6 +688,26 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
     if (psh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_big_pre, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psh));
     if (pre_mfma && pre_lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)pre_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pre_lds));
     if (pre_post && pre_lds_post > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)pre_post, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pre_lds_post));
+    if (persist) {
+        // step 0's pre-step as its own launch (vec_env.reset() / the continuation state), then ONE launch for the tiles of all T steps: it closes steps 0 .. T - 2 and
+        // prepares steps 1 .. T - 1 itself; the last step is closed by k_big_post below, which also hands out the continuation state
+        SkpArgs pa = {};
+        pa.a = sk.a1; pa.a.epoch = 0;
+        { const int rc = skp_table(c, skp, sk.a1, &pa, st); if (rc) return rc; }
+        pa.G8 = skp_grid / 8; pa.T = a->T; pa.NSL = K * (sk.a1.N / 256);
+        pa.xflag = skp_flags; pa.arrive = (unsigned*)(skp_flags + (B + 127) / 128); pa.stop = r.stop; pa.post = skp_post;
+        HIP_TRY(c, hipMemsetAsync(skp_flags, 0, nSkpFlag * sizeof(float), st));
+        SkpPost po; po.pd = pd; po.r = r; po.st = bs; po.theta = c->d_theta; po.norm = c->d_norm;
+        hipLaunchKernelGGL(k_skp_post_args, dim3(1), dim3(64), 0, st, po, skp_post);
+        hipLaunchKernelGGL(pre_mfma, dim3((B + 63) / 64), dim3(256), pre_lds, st, pd, r, 0, c->d_theta, c->d_norm, bs);
+        skp.launch(pa, skp_grid, skp.lds, st);
+        const int tl = a->T - 1;
+        if (pd.ns <= 32) hipLaunchKernelGGL(k_big_post<32>, dim3((B + 7) / 8), dim3(256), 0, st, pd, r, tl, c->d_norm, bs);
+        else hipLaunchKernelGGL(k_big_post<64>, dim3((B + 3) / 4), dim3(256), 0, st, pd, r, tl, c->d_norm, bs);
+        HIP_TRY(c, hipGetLastError());
+        c->last_rollout_kernel = 6;
+        return METRPO_OK;
+    }
     for (int t = 0; t < a->T; ++t) {
         if (pre_post && t > 0) hipLaunchKernelGGL(pre_post, dim3((B + 63) / 64), dim3(256), pre_lds_post, st, pd, r, t, c->d_theta, c->d_norm, bs);
         else if (pre_mfma) hipLaunchKernelGGL(pre_mfma, dim3((B + 63) / 64), dim3(256), pre_lds, st, pd, r, t, c->d_theta, c->d_norm, bs);

@@ -21,6 +21,14 @@ def cpu(t):
     return t.detach().cpu().numpy().astype(np.float64)
 
 
+def make_engine(*a, **k):
+    """This file tests the LAUNCH-PER-STEP stream-K path; the persistent form that production takes for the two-hidden-layer shapes (mlp_persist.h) has
+    tests/test_gpu_persist.py."""
+    out = Hh.make_engine(*a, **k)
+    out[0].set_option('NO_PERSIST', '1')
+    return out
+
+
 def _rollout_vs_oracle(eng, dm, theta, pdims, pool, env, K, B, T, H, sam_mode='step_rand', seed=6):
     th = theta.astype(np.float32).astype(np.float64)
     pool32 = pool.astype(np.float32).astype(np.float64)
@@ -50,7 +58,7 @@ SHAPES = [('swimmer', 5, (512, 512), 100), ('hopper', 3, (256, 256), 77), ('snak
 def test_streamk_rollout_vs_oracle_and_tile_gemm(env, K, dh, B, monkeypatch):
     ph = (100, 50, 25) if env == 'humanoid' else (32, 32)
     T, H = 5, 3
-    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, dh, ph, seed=71)
+    eng, dm, theta, pdims, pool = make_engine(env, K, dh, ph, seed=71)
     if env == 'ant':
         pool[::3, 2] = 0.21; dm.diff_mean[2] = -0.02
         eng.set_dynamics_layers(dm.Ws, dm.bs, dm.in_mean, dm.in_std, dm.diff_mean, dm.diff_std)
@@ -71,7 +79,7 @@ def test_streamk_rollout_vs_oracle_and_tile_gemm(env, K, dh, B, monkeypatch):
 @pytest.mark.parametrize('sam_mode', list(O.SAM_MODES))
 def test_streamk_rollout_all_sam_modes(sam_mode, monkeypatch):
     env, K, B, T, H = 'half_cheetah', 4, 70, 6, 3
-    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (256, 256), (32, 32), seed=61)
+    eng, dm, theta, pdims, pool = make_engine(env, K, (256, 256), (32, 32), seed=61)
     eng.set_option('METRPO_STREAMK', '1')
     eng.set_rollout_variant(1)
     _rollout_vs_oracle(eng, dm, theta, pdims, pool, env, K, B, T, H, sam_mode=sam_mode)
@@ -82,7 +90,7 @@ def test_streamk_split_tiles_equal_the_oracle_and_do_not_depend_on_the_split():
     """More tiles than CUs and not a multiple of them: workgroup ranges start and end inside tiles, accumulators are handed over between
     workgroups.  K = 5 heads x 32 row blocks x 2 column blocks = 320 tiles on the chip's CUs; the rollout picks the path by itself."""
     env, K, B, T, H = 'ant', 5, 4000, 3, 3
-    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (512, 512), (32, 32), seed=81)
+    eng, dm, theta, pdims, pool = make_engine(env, K, (512, 512), (32, 32), seed=81)
     traj, dr32 = _rollout_vs_oracle(eng, dm, theta, pdims, pool, env, K, B, T, H)
     assert eng.last_rollout_kernel() == 'gemm-streamk'
     again = eng.rollout(B, T, H, 'step_rand', pool, **dr32)
@@ -93,7 +101,7 @@ def test_streamk_xcd_aware_ranges_are_bitwise_the_plain_split(monkeypatch):
     """The workgroups of one XCD take consecutive ranges of the (tile, chunk) sequence (mlp_streamk.h: SkArgs::xcd; parts cut at tile boundaries): who
     computes what changes, the k-ordered chains do not -- every tensor bit for bit the plain blockIdx-ordered split."""
     env, K, B, T, H = 'half_cheetah', 5, 2600, 3, 3                # 5 x 21 x 4 = 420 tiles of 32 + 1 units
-    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (1024, 1024), (32, 32), seed=85)
+    eng, dm, theta, pdims, pool = make_engine(env, K, (1024, 1024), (32, 32), seed=85)
     xcd = eng.rollout(B, T, H, 'step_rand', pool, seed=3)
     assert eng.last_rollout_kernel() == 'gemm-streamk'
     keep = [x.clone() for x in (xcd.obs, xcd.rew, xcd.mean, xcd.done)]
@@ -115,7 +123,7 @@ def test_streamk_random_shapes_equal_the_tile_gemms(monkeypatch):
         K = int(rs.randint(2, 8))
         tiles_per_row_block = K * (n1 // 256)
         B = 128 * int(np.ceil(300.0 / tiles_per_row_block)) + int(rs.randint(1, 128))          # > 256 tiles, ragged last row block
-        eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (k1, n1), (32, 32), seed=500 + case)
+        eng, dm, theta, pdims, pool = make_engine(env, K, (k1, n1), (32, 32), seed=500 + case)
         msg = str((case, env, K, (k1, n1), B))
         sk = eng.rollout(B, 2, 2, 'step_rand', pool, seed=case)
         assert eng.last_rollout_kernel() == 'gemm-streamk', msg
@@ -135,7 +143,7 @@ def test_stored_layer0_kernel_equals_the_tile_gemm(env, K, dh, B, monkeypatch):
     """Layer 0 of the forms that store it (three hidden layers; two behind Humanoid's 77 inputs) on k_l0_rows -- the head's weight slice LDS-resident, bias as
     one more input row -- against the tile GEMM it replaces (METRPO_NO_L0_ROWS), and both against the oracle through the rollout."""
     ph = (100, 50, 25) if env == 'humanoid' else (32, 32)
-    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, dh, ph, seed=87)
+    eng, dm, theta, pdims, pool = make_engine(env, K, dh, ph, seed=87)
     traj, dr32 = _rollout_vs_oracle(eng, dm, theta, pdims, pool, env, K, B, 2, 2)
     assert eng.last_rollout_kernel() == 'gemm-streamk'
     eng.set_option('METRPO_NO_L0_ROWS', '1')
@@ -148,7 +156,7 @@ def test_stored_layer0_kernel_equals_the_tile_gemm(env, K, dh, B, monkeypatch):
 
 def test_streamk_three_hidden_layers_split_tiles():
     env, K, B, T, H = 'humanoid', 6, 1500, 2, 2                # 6 x 12 x 4 = 288 tiles per launch
-    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (1024, 1024, 1024), (100, 50, 25), seed=83)
+    eng, dm, theta, pdims, pool = make_engine(env, K, (1024, 1024, 1024), (100, 50, 25), seed=83)
     traj, dr32 = _rollout_vs_oracle(eng, dm, theta, pdims, pool, env, K, B, T, H)
     assert eng.last_rollout_kernel() == 'gemm-streamk'
     again = eng.rollout(B, T, H, 'step_rand', pool, **dr32)
@@ -164,7 +172,7 @@ def test_step_closed_in_the_next_launch_is_bitwise_the_two_launch_sequence(env, 
     order -- every trajectory tensor bit for bit what the two-launch sequence writes, on the stream-K path and on the tile GEMMs, for every
     selection mode, with early termination (Ant) and horizon resets inside the rollout."""
     T, H = 7, 3
-    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, dh, (100, 50, 25) if env == 'humanoid' else (32, 32), seed=91)      # (Humanoid: k_big_pre_mfma3<.., true>)
+    eng, dm, theta, pdims, pool = make_engine(env, K, dh, (100, 50, 25) if env == 'humanoid' else (32, 32), seed=91)      # (Humanoid: k_big_pre_mfma3<.., true>)
     if env == 'ant':
         pool[::3, 2] = 0.21; dm.diff_mean[2] = -0.02
         eng.set_dynamics_layers(dm.Ws, dm.bs, dm.in_mean, dm.in_std, dm.diff_mean, dm.diff_std)
