@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const ring = lds;
     float* const img = lds + 4 * STAGE;                                        // policy image (PreImg<ENV>), built once
-    int* const lds_flag = (int*)(img + IM::IMG);
+    int* const lds_flag = (int*)(img + IM::IMG);                                // [0]: outcome of an arrival | [4 .. 11]: per-wave "has the next tile's rows" votes
     const SkArgs& a = p.a;
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -146,7 +146,8 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
         const unsigned long long t0 = wall_clock64();
         while (__hip_atomic_load(p.xflag + (r.m0 >> 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < r.t) {
             __builtin_amdgcn_s_sleep(4);
-            if (wall_clock64() - t0 > 200000000ull) { if (lane == 0) *a.err = 1.0; break; }      // 2 s at 100 MHz
+            if (wall_clock64() - t0 > 200000000ull) { if (lane == 0) __hip_atomic_store(a.err, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }      // 2 s at 100 MHz
+            if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) break;      // somebody gave up: the launch's results are invalid, leave quickly
         }
     };
     auto load_x = [&](const RecL& r) {                                         // agent-scope loads: the rows were written by another workgroup of this launch
@@ -210,7 +211,11 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
         const bool nmain = !(r1.fl & SKF_EPI);
         const float* st = ring + (q & 3) * STAGE;
         if (!(r0.fl & SKF_EPI)) produce(q, h);
-        if (nmain && (r1.fl & SKF_NEWTILE)) { wait_x(r1, seen); load_x(r1); }  // the next tile's rows (its flag was probed a chunk ago)
+        // The next tile's rows: loaded HERE only if its row block's flag (probed a chunk ago) was already raised.  A wave never BLOCKS on a flag while its
+        // workgroup still owes the closing of a step (an unfinished tile, an arrival whose outcome is unknown): the awaited step may depend on exactly that.
+        const bool boundary = nmain && (r1.fl & SKF_NEWTILE);
+        bool have_x = true;
+        if (boundary) { have_x = seen >= r1.t; if (have_x) load_x(r1); }
         RecI r4; RecL rn;
         const SkRec* const fa = rec_of(cA); const SkRec* const fb = rec_of(cB); const int fat = cA.t;
         adv(cA); adv(cB);
@@ -292,10 +297,11 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
         }
         if (rn.fl & SKF_NEWTILE) seen = probe_flag(rn);                        // (sentinels carry no NEWTILE)
         drain_vm();                                                            // copies of entry q + 3, the rows, the output partials -- and a pending arrival's result
-        if (pend && tid == 0) *lds_flag = (arr_old == (unsigned)(pend_t + 1) * (unsigned)p.NSL - 1u) ? 1 : 0;
+        if (pend && tid == 0) lds_flag[0] = (arr_old == (unsigned)(pend_t + 1) * (unsigned)p.NSL - 1u) ? 1 : 0;
+        if (boundary && lane == 0) lds_flag[4 + wave] = have_x ? 1 : 0;
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (pend) {                                                            // uniform over the workgroup
+        if (pend) {                                                            // uniform over the workgroup: the previous tile's arrival, looked at one chunk later
             pend = false;
             if (*(volatile int*)lds_flag) skp_close_and_prepare<ENV>(p.post, pend_t, pend_rb, img, ring + (q & 3) * STAGE, p.xflag);     // stage q % 4: free until the next chunk's copies
             __builtin_amdgcn_s_barrier();                                      // lds_flag may be rewritten only after everybody has read it
@@ -304,6 +310,20 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
         if ((r0.fl & SKF_EPILAST) && r0.t + 1 < T) {                           // every wave's partials are complete behind the barrier: arrive (the last step is closed by the host's k_big_post)
             pend = true; pend_t = r0.t; pend_rb = r0.m0 >> 7;
             if (tid == 0) arr_old = __hip_atomic_fetch_add(p.arrive + pend_rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (boundary) {
+            const sk_i32x4 v0 = *(volatile sk_i32x4*)(lds_flag + 4), v1 = *(volatile sk_i32x4*)(lds_flag + 8);
+            const bool all_x = (v0[0] & v0[1] & v0[2] & v0[3] & v1[0] & v1[1] & v1[2] & v1[3]) != 0;
+            if (!all_x) {                                                      // some wave still has to wait for the next tile's rows: first discharge this tile's arrival
+                if (pend) {
+                    if (tid == 0) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(arr_old) :: "memory"); lds_flag[0] = (arr_old == (unsigned)(pend_t + 1) * (unsigned)p.NSL - 1u) ? 1 : 0; }
+                    __syncthreads();
+                    pend = false;
+                    if (*(volatile int*)lds_flag) skp_close_and_prepare<ENV>(p.post, pend_t, pend_rb, img, ring + (q & 3) * STAGE, p.xflag);
+                }
+                if (!have_x) { wait_x(r1, -1); load_x(r1); }
+                __syncthreads();                                               // votes and flag are rewritten only after everybody has read them
+            }
         }
         r0 = r1; r1 = rn; r3 = r4;
     };

@@ -524,7 +524,7 @@ struct SkpVt {
 template <int ENV, int S0, int OT> static SkpVt skp_vt() {
     SkpVt v;
     v.kern = (const void*)k_sk_persist<ENV, S0, OT>;
-    v.lds = sizeof(float) * (size_t)(4 * SkGeom<SK_A_PRODUCER, SK_EPI_OUT, S0, OT>::STAGE + PreImg<ENV>::IMG + 4);
+    v.lds = sizeof(float) * (size_t)(4 * SkGeom<SK_A_PRODUCER, SK_EPI_OUT, S0, OT>::STAGE + PreImg<ENV>::IMG + 16);
     v.launch = [](const SkpArgs& p, int grid, size_t lds, hipStream_t st) { hipLaunchKernelGGL((k_sk_persist<ENV, S0, OT>), dim3(grid), dim3(512), lds, st, p); };
     v.tab = [](const SkArgs& a, std::vector<SkRec>& t, int (&Jx)[8], int& Jmax, int& L) { skp_build_tab<OT>(a, t, Jx, Jmax, L); };
     return v;

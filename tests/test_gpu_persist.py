@@ -26,6 +26,7 @@ def _both(eng, B, T, H, mode, pool, **kw):
     assert eng.last_rollout_kernel() == 'streamk-persistent', eng.last_rollout_kernel()
     a = {k: getattr(a, k).clone() for k in FIELDS}
     eng.set_option('NO_PERSIST', '1')
+    eng.set_option('STREAMK_LATE', '0')                          # forced launches below one tile per CU: whole tiles (the side-by-side pieces of SkArgs::late add in another order)
     b = eng.rollout(B, T, H, mode, pool, **kw)
     assert eng.last_rollout_kernel() == 'gemm-streamk', eng.last_rollout_kernel()
     b = {k: getattr(b, k).clone() for k in FIELDS}
