@@ -108,6 +108,17 @@ extern "C" int32_t metrpo_debug_fvp_us(metrpo_ctx* c, double* mean_us, int32_t* 
     return METRPO_OK;
 }
 
+// Diagnostics hook (tools/persist_stats.py): per-workgroup statistics of the last persistent stream-K launch made with option PERSIST_STATS set
+// (mlp_persist.h: SkpArgs::stats), 8 values per workgroup; returns the number of workgroups (0: none recorded).
+extern "C" int32_t metrpo_debug_persist_stats(metrpo_ctx* c, unsigned long long* out, int32_t cap_wgs, void* stream) {
+    if (!c || !out) return METRPO_ENULL;
+    if (!c->d_skp_stats || c->skp_stats_n == 0) return 0;
+    const int n = std::min(cap_wgs, c->skp_stats_n);
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_skp_stats, sizeof(unsigned long long) * 8 * n, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(c, hipStreamSynchronize((hipStream_t)stream));
+    return n;
+}
+
 // ---- option table (metrpo_internal.h: METRPO_OPT_LIST) ----
 static const char* const OPT_NAMES[OPT_COUNT] = {
 #define X(n) #n,
@@ -167,7 +178,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     c->d_dyn_img = c->d_pol_img = nullptr; c->pol_img_idx = -1; c->d_pol_imgval = nullptr; c->d_pol_vpos = nullptr; c->img_live = 0;
     c->d_bptt = nullptr; c->bptt_cap = 0; c->det_cfg = -1; c->d_detpart = nullptr; c->detpart_cap = 0; c->det_gemm = 0; c->d_dg = nullptr; c->dg_cap = 0; c->vjp_gm = nullptr; c->ls_skip = nullptr; c->d_pol_adam = nullptr; c->pol_adam_t = 0; c->mfma_cfg = -1; c->pol_mfma = -1; c->coop_cfg = -1; c->rollout_variant = 0;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_cg = nullptr; c->d_vf = nullptr; c->d_theta_try = nullptr;
-    c->d_valbuf = nullptr; c->h_pinned = nullptr; c->n_sm = 256; c->n_cu_sched = 0; c->fallback_logged = 0; c->fvp_ev_n = 0; c->fvp_ev_made = 0; c->d_skp_tab = nullptr; c->skp_tab_cap = 0; c->persist_failed = 0; for (int i = 0; i < 8; ++i) c->skp_key[i] = -1;
+    c->d_valbuf = nullptr; c->h_pinned = nullptr; c->n_sm = 256; c->n_cu_sched = 0; c->fallback_logged = 0; c->fvp_ev_n = 0; c->fvp_ev_made = 0; c->d_skp_tab = nullptr; c->d_skp_stats = nullptr; c->skp_stats_n = 0; c->skp_tab_cap = 0; c->persist_failed = 0; for (int i = 0; i < 8; ++i) c->skp_key[i] = -1;
     for (int i = 0; i < OPT_COUNT; ++i) {                     // the ONLY place the library reads the environment for kernel selection: defaults of the option table
         const std::string ev = std::string(i == OPT_GEMM_PREFETCH ? "" : "METRPO_") + metrpo_opt_name(i);
         const char* e = getenv(ev.c_str());
@@ -228,6 +239,7 @@ extern "C" int32_t metrpo_destroy(metrpo_ctx* c) {
     }
     for (int i = 0; i < c->fvp_ev_made; ++i) (void)hipEventDestroy(c->fvp_ev[i]);
     if (c->d_skp_tab) (void)hipFree(c->d_skp_tab);
+    if (c->d_skp_stats) (void)hipFree(c->d_skp_stats);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->h_upd) (void)hipHostFree(c->h_upd);
     delete c;

@@ -19,7 +19,9 @@ struct BigState { float* S; int* ts; int* cur_model; float* X; float* U; float* 
 
 // Step t - 1 closed for a wave's 16 envs in the lane layout of the MFMA pre-kernels (env c, quarter q: dims 16 hh + 4 q .. + 3 of every 16-dim block):
 // what k_big_post computes, same arithmetic in the same order; the new state lands in the wave's LDS tile ST [16][NS] (and in S), ready for the policy chain.
-template <int ENV, int NS, int NA>
+// SC1P (the persistent rollout's closing workgroups): the output partials were written by workgroups of the SAME launch behind other L2s -- read them with
+// agent-scope (sc1) loads, which a line this XCD's L2 still holds from the previous step's read cannot serve.
+template <int ENV, int NS, int NA, bool SC1P = false>
 __device__ __forceinline__ void big_close_step(const ProblemDesc& pd, const RolloutK& r, int t, const float* __restrict__ norm, const BigState& st, float* ST,
                                                int c, int q, bool active, int b, uint64_t genv) {
     constexpr int NH = (NS + 15) / 16;
@@ -55,7 +57,11 @@ __device__ __forceinline__ void big_close_step(const ProblemDesc& pd, const Roll
             for (int rr = 0; rr < 4; ++rr) o[rr] = (i0 + rr < NS) ? st.out_bias[(size_t)k * st.out_bias_stride + i0 + rr] : 0.0f;
             for (int sp = 0; sp < st.out_splits; ++sp) {
                 const float* pr_ = st.PART + ((size_t)sp * K + k) * st.out_stride + (size_t)bc * st.out_ld + i0;
-                if ((st.out_ld & 3) == 0) { const f32x4 p4 = *(const f32x4*)pr_;
+                if constexpr (SC1P) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) if ((st.out_ld & 3) == 0 || i0 + rr < NS) o[rr] += __hip_atomic_load(const_cast<float*>(pr_) + rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                else if ((st.out_ld & 3) == 0) { const f32x4 p4 = *(const f32x4*)pr_;
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) o[rr] += p4[rr]; }
                 else {
@@ -189,7 +195,7 @@ template <int ENV> struct PreLane {
 
 // First half of a wave's pre-step for its 16 envs b0 .. b0 + 15 at step t: normaliser rows, log_std and the action noise of step t; then (POST) step t - 1
 // closed (big_close_step: the new state lands in ST and S) or (!POST) the state tile loaded from S; obs[t] written.  ST: this wave's [16][NS] LDS tile.
-template <int ENV, bool POST>
+template <int ENV, bool POST, bool SC1P = false>
 __device__ __forceinline__ void big_pre_head(const ProblemDesc& pd, const RolloutK& r, int t, const float* __restrict__ theta, const float* __restrict__ norm,
                                              const BigState& st, float* ST, int b0, int lane, PreLane<ENV>& pl) {
     using C = Cfg<ENV, 64, 32>;
@@ -218,7 +224,7 @@ __device__ __forceinline__ void big_pre_head(const ProblemDesc& pd, const Rollou
         }
     }
     if constexpr (POST) {
-        big_close_step<ENV, NS, NA>(pd, r, t, norm, st, ST, c, q, active, b, genv);
+        big_close_step<ENV, NS, NA, SC1P>(pd, r, t, norm, st, ST, c, q, active, b, genv);
     } else {
         for (int i = lane; i < 16 * NS; i += 64) ST[i] = (i < lim) ? st.S[(size_t)b0 * NS + i] : 0.0f;
     }

@@ -7,21 +7,25 @@
 //     reads -- mlp_streamk.h), the tiles of ALL steps form one sequence, and workgroup (x, i) -- XCD list x = blockIdx % 8, i = blockIdx / 8 -- takes
 //     positions i, i + G/8, ... of list x.  Over hundreds of steps every workgroup gets the same number of tiles to within one: no split tiles, no hand-over;
 //   * step t + 1 of a 128-env row block needs only step t of THAT row block (all heads and column blocks: NSL tiles).  Every finished tile adds one to
-//     the row block's arrival counter; the workgroup whose arrival completes the step closes it for those 128 envs -- de-normalise + residual, selection
-//     over the heads, reward, done, reset, then the policy and the normalised input row of step t + 1: the wave functions of big_prepost.h, the very code
-//     the launch-per-step path runs as k_big_pre_mfma<ENV, true> -- and raises the row block's ready flag.  A tile waits for its row block's flag
-//     before it loads its input rows; in the steady state the flag was raised about half a tile time earlier (the tiles of one step are ordered row block
-//     first, so a row block's tiles finish together and long before the next step's tiles of that row block come up): nobody waits, nothing is launched,
-//     and the closing work (20 x 5 us per step over 256 workgroups) disappears into the matrix stream;
-//   * each XCD list holds the tiles of 1/8 of the (head, column block) weight slices (2.5 slices of 20 at the C2 / C3 shapes), row block first: the 32
+//     the row block's arrival counter (a fire-and-forget atomic behind the barrier that ends its last chunk).  A FEW workgroups of the launch (NCLOSE = 8, one
+//     per XCD; the other 248 compute) do nothing but close steps: closer c watches the counters of row blocks c, c + 8, ..., and as soon as a row block's step
+//     is complete it de-normalises + adds the residual, selects over the heads, forms reward / done / reset, evaluates the policy and writes the normalised
+//     input row of step t + 1 for those 128 envs -- the wave functions of big_prepost.h, the very code the launch-per-step path runs as
+//     k_big_pre_mfma<ENV, true> -- and raises the row block's ready flag.  A tile waits for its row block's flag before it loads its input rows (probed a
+//     chunk ahead, so the common case costs nothing).  The tiles of one step are ordered row block first: a row block's tiles finish together and, once the
+//     workgroups have staggered themselves, about half a tile time before the next step's tiles of that row block come up;
+//     (first version: the workgroup whose arrival completed a step closed it itself, through a call inside the chunk loop.  The returning atomic, the votes
+//     that keep a workgroup from blocking while it owes a closing, and above all the call -- every loop-carried register live across it -- cost 73 scalar and
+//     28 vector spills INSIDE the matrix phase: 6.5 us per chunk against k_mlp_sk's 4.7.  Compute workgroups now owe nothing, may block freely, and their
+//     loop is k_mlp_sk's plus a scalar cursor.)
+//   * each XCD list holds the tiles of 1/8 of the (head, column block) weight slices (2.5 slices of 20 at the C2 / C3 shapes), row block first: the
 //     workgroups behind one L2 stream the same 2-3 slices, which therefore stay in that L2 for the whole launch.
 //
 // Inter-workgroup visibility (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"):
-//   tile -> closing workgroup:  output partials by 16-byte sc1 (write-through) stores, every wave drains (vmcnt 0), workgroup barrier, ONE returning
-//                               agent-scope atomic add on the row block's counter.  The closer: one-lane agent acquire (L1 invalidate), barrier, plain loads;
-//   closing workgroup -> tiles: X rows by sc1 stores; S / U / ts / cur_model (read by the NEXT closer of the row block) by plain stores; every wave drains,
-//                               barrier, one-lane agent release + drain, relaxed agent store of the flag.  A tile's waves poll the flag (one agent-scope load,
-//                               issued a chunk ahead) and read their X rows with agent-scope loads.
+//   tile -> closer:   output partials by 16-byte sc1 (write-through) stores, every wave drains (vmcnt 0), workgroup barrier, ONE agent-scope atomic add on the row
+//                     block's counter.  The closer: relaxed agent-scope poll, one-lane agent acquire (L1 invalidate), barrier, plain loads;
+//   closer -> tiles:  X rows by sc1 stores; S / U / ts / cur_model (read by the same closer one step later) by plain stores; every wave drains, barrier, one-lane
+//                     agent release + drain, relaxed agent store of the flag.  A tile's waves poll the flag and read their X rows with agent-scope loads.
 // Waits are bounded (2 s) and report through the sticky rollout error cell; the launch needs its whole grid on the chip (one workgroup per CU:
 // grid_is_coresident, probe.hip) -- otherwise, and for every shape outside (two hidden layers, producer-sized input, 2 x 32 policy), the launch-per-step
 // path runs.  Summation order of every output: the k-ordered chain of an unsplit k_mlp_sk tile -- bit for bit the launch-per-step path's results.
@@ -41,22 +45,25 @@ struct SkpArgs {
     int* xflag; unsigned* arrive;                  // [RB] each, zeroed in front of the launch: x of step t is ready when xflag[rb] >= t; arrivals so far
     const int32_t* stop;                           // metrpo_sampler_progress's flag (constant during the launch)
     const SkpPost* post;
+    int nowait;                                    // developer timing (option PERSIST_STATS=2; results INVALID): no tile waits for its row block's flag
+    unsigned long long* stats;                     // developer statistics (option PERSIST_STATS; NULL otherwise): per workgroup {100 MHz ticks of the launch, ticks blocked (compute: on a flag,
+                                                   // longest wave; closer: on arrival counters), 0, steps closed, ticks spent closing, tiles, ticks in the prologue, 1 = closing role}
 };
 
 __global__ void k_skp_post_args(SkpPost v, SkpPost* dst) { if (threadIdx.x == 0) *dst = v; }
 
-// Step t closed and step t + 1 prepared for the 128 envs of row block rb, by all 8 waves of the calling workgroup (whose arrival completed the step).
-// Not inlined: it runs once per 20 tiles, its ~160 registers and three large argument structs must not shape the register allocation of the chunk loop.
+enum { SKP_NCLOSE = 8 };                           // closing workgroups of a launch: blockIdx 0 .. 7, one per XCD
+
+// Step t closed and step t + 1 prepared for the 128 envs of row block rb, by all 8 waves of a closing workgroup: the wave functions of the launch-per-step
+// pre-kernel (big_prepost.h).  scratch: [8][16][NS] floats of LDS state tiles; img: the policy image (PreImg<ENV>).
 template <int ENV>
-__device__ __noinline__ void skp_close_and_prepare(const SkpPost* __restrict__ pp, int t, int rb, const float* img, float* scratch, int* xflag) {
+__device__ __forceinline__ void skp_close_and_prepare(const SkpPost* __restrict__ pp, int t, int rb, const float* img, float* scratch, int* xflag) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // the other tiles' partials, the previous closer's S / U / ts / cur_model
-    __syncthreads();
     const int b0 = rb * 128 + wave * 16;
     if (b0 < pp->r.B) {
         PreLane<ENV> pl;
         float* ST = scratch + wave * 16 * Cfg<ENV, 64, 32>::NS;
-        big_pre_head<ENV, true>(pp->pd, pp->r, t + 1, pp->theta, pp->norm, pp->st, ST, b0, lane, pl);
+        big_pre_head<ENV, true, true>(pp->pd, pp->r, t + 1, pp->theta, pp->norm, pp->st, ST, b0, lane, pl);
         big_pre_tail<ENV, true>(pp->r, t + 1, pp->st, img, ST, b0, lane, pl);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   // every writing wave drains
@@ -68,30 +75,63 @@ __device__ __noinline__ void skp_close_and_prepare(const SkpPost* __restrict__ p
     }
 }
 
+// The closing role: workgroup c of SKP_NCLOSE watches row blocks c, c + NCLOSE, ...; for every step in order, every one of its row blocks in order.  It waits
+// for nothing but arrival counters (whose tiles need only flags this closer raised a step earlier): no cycle, whatever the dispatch order of the compute workgroups.
+template <int ENV>
+__device__ __forceinline__ void skp_closer_role(const SkpArgs& p, float* lds) {
+    using IM = PreImg<ENV>;
+    float* const img = lds;
+    float* const scratch = lds + IM::IMG;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < IM::IMG; k += 512) img[k] = IM::entry(p.post->theta, k);
+    __syncthreads();
+    const int RB = (p.a.M + 127) / 128;
+    unsigned long long st_wait = 0, st_work = 0, st_n = 0;
+    const unsigned long long st_t0 = wall_clock64();
+    for (int t = 0; t + 1 < p.T; ++t)
+        for (int rb = blockIdx.x; rb < RB; rb += SKP_NCLOSE) {
+            const unsigned long long w0 = wall_clock64();
+            if (tid == 0) {
+                const unsigned want = (unsigned)(t + 1) * (unsigned)p.NSL;
+                while (__hip_atomic_load(p.arrive + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (wall_clock64() - w0 > 200000000ull) { __hip_atomic_store(p.a.err, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }      // 2 s at 100 MHz
+                    if (__hip_atomic_load(p.a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) break;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");             // the tiles' partials; (S / U / ts / cur_model are this workgroup's own stores of a step ago)
+            }
+            __syncthreads();
+            const unsigned long long w1 = wall_clock64();
+            skp_close_and_prepare<ENV>(p.post, t, rb, img, scratch, p.xflag);
+            __syncthreads();                                                    // the state tiles are rewritten by the next row block
+            st_wait += w1 - w0; st_work += wall_clock64() - w1; ++st_n;
+        }
+    if (p.stats != nullptr && tid == 0) { unsigned long long* o = p.stats + 8 * (size_t)blockIdx.x; o[0] = wall_clock64() - st_t0; o[1] = st_wait; o[3] = st_n; o[4] = st_work; o[7] = 1; }
+}
+
 template <int ENV, int S0, int OT>
 __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
     using EP = SkEpi<OT>;
     using GE = SkGeom<SK_A_PRODUCER, SK_EPI_OUT, S0, OT>;
-    using IM = PreImg<ENV>;
     constexpr int E = EP::E, UPC = EP::UPC, NI0 = GE::NI0, STAGE = GE::STAGE;
     static_assert(EP::FLOATS <= STAGE, "EPI image larger than a ring stage");
     static_assert(NI0 <= 8, "layer-0 slice: at most 8 one-KB pieces (one per wave)");
-    static_assert(8 * 16 * Cfg<ENV, 64, 32>::NS <= STAGE, "the closing part's state tiles live in a free ring stage");
+    static_assert(PreImg<ENV>::IMG + 8 * 16 * Cfg<ENV, 64, 32>::NS <= 4 * STAGE, "the closing role's image and state tiles fit the ring's LDS");
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (p.stop != nullptr && *p.stop != 0) return;                             // the sampling loop already ended
+    if (blockIdx.x < SKP_NCLOSE) { skp_closer_role<ENV>(p, lds); return; }
     float* const ring = lds;
-    float* const img = lds + 4 * STAGE;                                        // policy image (PreImg<ENV>), built once
-    int* const lds_flag = (int*)(img + IM::IMG);                                // [0]: outcome of an arrival | [4 .. 11]: per-wave "has the next tile's rows" votes
     const SkArgs& a = p.a;
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (p.stop != nullptr && *p.stop != 0) return;                             // the sampling loop already ended
-    const int xl = blockIdx.x & 7, wi = blockIdx.x >> 3;                       // XCD list | position stride start
+    const int cbk = blockIdx.x - SKP_NCLOSE;
+    const int xl = cbk & 7, wi = cbk >> 3;                                     // XCD list (blockIdx % 8 as well: NCLOSE is a multiple of 8) | first position
     const int Jx = p.Jx[xl], L = p.L, G8 = p.G8, T = p.T;
     const long long npos = (long long)T * Jx;
     const int n_tiles = (wi < npos) ? (int)((npos - wi + G8 - 1) / G8) : 0;
     const int nq = n_tiles * L;
     if (nq == 0) return;
-    for (int k = tid; k < IM::IMG; k += 512) img[k] = IM::entry(p.post->theta, k);
+    const unsigned long long st_t0 = wall_clock64();
     const SkRec* const tabx = p.tab + (size_t)xl * p.Jmax * L;
     const SkRec* const sentinel = p.tab + (size_t)8 * p.Jmax * L;
 
@@ -100,9 +140,9 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
     auto adv = [&](Cur& k) { if (++k.c == L) { k.c = 0; k.jj += G8; while (k.jj >= Jx) { k.jj -= Jx; ++k.t; } } };
     auto rec_of = [&](const Cur& k) -> const SkRec* { return (k.t < T) ? tabx + ((size_t)k.jj * L + k.c) : sentinel; };
 
-    struct RecL { int kc, fl, m0, t; unsigned offA, offC; };                   // the chunk itself / the look-ahead (t: its tile's step)
+    struct RecL { int kc, fl, m0, t; unsigned offC; };                         // the chunk itself / the look-ahead (t: its tile's step)
     struct RecI { int fl; unsigned offW1, offW0; };                            // its LDS-DMA copies
-    auto decL = [](const sk_i32x4& v, int t) { RecL r; r.kc = v[0] & 0xFFFF; r.fl = v[0] >> 16; r.m0 = v[1]; r.offA = (unsigned)v[2]; r.offC = (unsigned)v[3]; r.t = t; return r; };
+    auto decL = [](const sk_i32x4& v, int t) { RecL r; r.kc = v[0] & 0xFFFF; r.fl = v[0] >> 16; r.m0 = v[1]; r.offC = (unsigned)v[3]; r.t = t; return r; };
     auto decI = [](const sk_i32x4& v) { RecI r; r.fl = v[0] >> 16; r.offW1 = (unsigned)v[1]; r.offW0 = (unsigned)v[2]; return r; };
     auto fetch2 = [&](const SkRec* pl_, const SkRec* pi_, int tl, RecL& rl, RecI& ri) {       // load + wait in ONE statement (mlp_streamk.h: why)
         sk_i32x4 vl, vi;
@@ -141,18 +181,20 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
 
     // ready flag of a tile's row block: one agent-scope load (every lane the same word), issued a chunk ahead of the wait
     auto probe_flag = [&](const RecL& r) -> int { return __hip_atomic_load(p.xflag + (r.m0 >> 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    unsigned long long st_blocked_w = 0;
     auto wait_x = [&](const RecL& r, int seen) {                               // bounded: report, do not hang
-        if (seen >= r.t) return;
+        if (seen >= r.t || p.nowait) return;
         const unsigned long long t0 = wall_clock64();
         while (__hip_atomic_load(p.xflag + (r.m0 >> 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < r.t) {
-            __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_s_sleep(2);
             if (wall_clock64() - t0 > 200000000ull) { if (lane == 0) __hip_atomic_store(a.err, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }      // 2 s at 100 MHz
             if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) break;      // somebody gave up: the launch's results are invalid, leave quickly
         }
+        st_blocked_w += wall_clock64() - t0;
     };
     auto load_x = [&](const RecL& r) {                                         // agent-scope loads: the rows were written by another workgroup of this launch
         const int m = min(r.m0 + wave * 16 + i, a.M - 1);
-        float* xp = const_cast<float*>(a.A) + r.offA + (size_t)m * a.lda + g;
+        float* xp = const_cast<float*>(a.A) + (size_t)m * a.lda + g;
 #pragma unroll
         for (int s = 0; s < S0; ++s) xr[s] = __hip_atomic_load(xp + 4 * s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
@@ -198,11 +240,10 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
     wait_x(r0, -1);
     load_x(r0);
     drain_vm();
-    __syncthreads();                                                           // (also: the policy image is complete)
+    __syncthreads();
     first4(stage_addr(0));
+    const unsigned long long st_pro = wall_clock64() - st_t0;
 
-    // an arrival whose outcome is still under way: issued behind the barrier that ended the tile's last chunk, looked at one chunk later
-    bool pend = false; int pend_t = 0, pend_rb = 0; unsigned arr_old = 0;
     int seen = 0;                                                              // flag value probed for the next tile
     __amdgpu_buffer_rsrc_t part_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.part, 0, 0xFFFFFFFFu, 0x00020000);
     auto body = [&](auto par_, const int q) {
@@ -211,11 +252,12 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
         const bool nmain = !(r1.fl & SKF_EPI);
         const float* st = ring + (q & 3) * STAGE;
         if (!(r0.fl & SKF_EPI)) produce(q, h);
-        // The next tile's rows: loaded HERE only if its row block's flag (probed a chunk ago) was already raised.  A wave never BLOCKS on a flag while its
-        // workgroup still owes the closing of a step (an unfinished tile, an arrival whose outcome is unknown): the awaited step may depend on exactly that.
+        // The next tile's rows: loaded HERE if its row block's flag (probed a chunk ago) was already raised -- normally long since.  If not, the wave must not block
+        // yet: its workgroup still owes the arrival of the tile in progress, and the awaited step may (in small problems: does) depend on exactly that tile.  It
+        // blocks behind the arrival, at the end of this chunk.
         const bool boundary = nmain && (r1.fl & SKF_NEWTILE);
-        bool have_x = true;
-        if (boundary) { have_x = seen >= r1.t; if (have_x) load_x(r1); }
+        const bool have_x = !boundary || seen >= r1.t || p.nowait;
+        if (boundary && have_x) load_x(r1);
         RecI r4; RecL rn;
         const SkRec* const fa = rec_of(cA); const SkRec* const fb = rec_of(cB); const int fat = cA.t;
         adv(cA); adv(cB);
@@ -249,14 +291,15 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
                 SKP_G4(8)  SKP_P(2);
                 SKP_G4(12) SKP_P(3);
                 SKP_G4(16) SKP_P(4);
-                SKP_G4(20) if (wave < 4) fetch2(fa, fb, fat, rn, r4);
-                SKP_G4(24) if (wave >= 4) fetch2(fa, fb, fat, rn, r4);
+                SKP_G4(20) if (wave < 4) { fetch2(fa, fb, fat, rn, r4); if (rn.fl & SKF_NEWTILE) seen = probe_flag(rn); }
+                SKP_G4(24) if (wave >= 4) { fetch2(fa, fb, fat, rn, r4); if (rn.fl & SKF_NEWTILE) seen = probe_flag(rn); }
                 SKP_G4(28)
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
             }
         } else {
             issue(r3, q + 3);
             fetch2(fa, fb, fat, rn, r4);
+            if (rn.fl & SKF_NEWTILE) seen = probe_flag(rn);                    // (two epilogue chunks: the next tile comes into view here; sentinels carry no NEWTILE)
             if (!(r0.fl & SKF_NONE)) {
                 auto epi_chunk = [&](auto ee) {
                     constexpr int EE = decltype(ee)::value;
@@ -285,7 +328,7 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
                 else epi_chunk(std::integral_constant<int, E - 1>{});
                 if (r0.fl & SKF_EPILAST) {
                     const int m = r0.m0 + wave * 16 + i;
-                    if (m < a.M) {                                            // write-through (sc1): read by the closing workgroup, possibly behind another L2
+                    if (m < a.M) {                                            // write-through (sc1): read by a closing workgroup, possibly behind another L2
                         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                         const unsigned off = (r0.offC + (unsigned)m * (unsigned)a.ldp + 4u * g) * 4u;
 #pragma unroll
@@ -295,46 +338,22 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
                 if (nmain) first4(stage_addr(q + 1));
             }
         }
-        if (rn.fl & SKF_NEWTILE) seen = probe_flag(rn);                        // (sentinels carry no NEWTILE)
-        drain_vm();                                                            // copies of entry q + 3, the rows, the output partials -- and a pending arrival's result
-        if (pend && tid == 0) lds_flag[0] = (arr_old == (unsigned)(pend_t + 1) * (unsigned)p.NSL - 1u) ? 1 : 0;
-        if (boundary && lane == 0) lds_flag[4 + wave] = have_x ? 1 : 0;
+        drain_vm();                                                            // copies of entry q + 3, the rows, the output partials (and the probe)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (pend) {                                                            // uniform over the workgroup: the previous tile's arrival, looked at one chunk later
-            pend = false;
-            if (*(volatile int*)lds_flag) skp_close_and_prepare<ENV>(p.post, pend_t, pend_rb, img, ring + (q & 3) * STAGE, p.xflag);     // stage q % 4: free until the next chunk's copies
-            __builtin_amdgcn_s_barrier();                                      // lds_flag may be rewritten only after everybody has read it
-            asm volatile("" ::: "memory");
-        }
-        if ((r0.fl & SKF_EPILAST) && r0.t + 1 < T) {                           // every wave's partials are complete behind the barrier: arrive (the last step is closed by the host's k_big_post)
-            pend = true; pend_t = r0.t; pend_rb = r0.m0 >> 7;
-            if (tid == 0) arr_old = __hip_atomic_fetch_add(p.arrive + pend_rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (boundary) {
-            const sk_i32x4 v0 = *(volatile sk_i32x4*)(lds_flag + 4), v1 = *(volatile sk_i32x4*)(lds_flag + 8);
-            const bool all_x = (v0[0] & v0[1] & v0[2] & v0[3] & v1[0] & v1[1] & v1[2] & v1[3]) != 0;
-            if (!all_x) {                                                      // some wave still has to wait for the next tile's rows: first discharge this tile's arrival
-                if (pend) {
-                    if (tid == 0) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(arr_old) :: "memory"); lds_flag[0] = (arr_old == (unsigned)(pend_t + 1) * (unsigned)p.NSL - 1u) ? 1 : 0; }
-                    __syncthreads();
-                    pend = false;
-                    if (*(volatile int*)lds_flag) skp_close_and_prepare<ENV>(p.post, pend_t, pend_rb, img, ring + (q & 3) * STAGE, p.xflag);
-                }
-                if (!have_x) { wait_x(r1, -1); load_x(r1); }
-                __syncthreads();                                               // votes and flag are rewritten only after everybody has read them
-            }
-        }
+        // every wave's partials are complete behind the barrier: the tile arrives (fire and forget; the last step is closed by the host's k_big_post)
+        if ((r0.fl & SKF_EPILAST) && r0.t + 1 < T && tid == 0) (void)__hip_atomic_fetch_add(p.arrive + (r0.m0 >> 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!have_x) { wait_x(r1, -1); load_x(r1); }                            // (a compute workgroup that has arrived for all it finished owes nobody anything: it may block)
         r0 = r1; r1 = rn; r3 = r4;
     };
     for (int q = 0; q < nq; q += 2) {
         body(std::integral_constant<int, 0>{}, q);
         if (q + 1 < nq) body(std::integral_constant<int, 1>{}, q + 1);
     }
-    if (pend) {                                                                // the arrival of this workgroup's last tile
-        if (tid == 0) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(arr_old) :: "memory"); *lds_flag = (arr_old == (unsigned)(pend_t + 1) * (unsigned)p.NSL - 1u) ? 1 : 0; }
-        __syncthreads();
-        if (*(volatile int*)lds_flag) skp_close_and_prepare<ENV>(p.post, pend_t, pend_rb, img, ring, p.xflag);
+    if (p.stats != nullptr && lane == 0) {
+        unsigned long long* o = p.stats + 8 * (size_t)blockIdx.x;
+        atomicMax(&o[1], st_blocked_w);                                        // the wave that waited longest
+        if (tid == 0) { o[0] = wall_clock64() - st_t0; o[5] = (unsigned long long)n_tiles; o[6] = st_pro; }
     }
 }
 

@@ -524,7 +524,7 @@ struct SkpVt {
 template <int ENV, int S0, int OT> static SkpVt skp_vt() {
     SkpVt v;
     v.kern = (const void*)k_sk_persist<ENV, S0, OT>;
-    v.lds = sizeof(float) * (size_t)(4 * SkGeom<SK_A_PRODUCER, SK_EPI_OUT, S0, OT>::STAGE + PreImg<ENV>::IMG + 16);
+    v.lds = sizeof(float) * (size_t)(4 * SkGeom<SK_A_PRODUCER, SK_EPI_OUT, S0, OT>::STAGE);
     v.launch = [](const SkpArgs& p, int grid, size_t lds, hipStream_t st) { hipLaunchKernelGGL((k_sk_persist<ENV, S0, OT>), dim3(grid), dim3(512), lds, st, p); };
     v.tab = [](const SkArgs& a, std::vector<SkRec>& t, int (&Jx)[8], int& Jmax, int& L) { skp_build_tab<OT>(a, t, Jx, Jmax, L); };
     return v;
@@ -631,7 +631,7 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
     if (persist) {
         if (skp.lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute(skp.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)skp.lds));
         skp_grid = (std::min(sched_cus(c, st), c->n_sm) / 8) * 8;
-        persist = skp_grid >= 8 && grid_is_coresident(c, skp.kern, 512, skp.lds, skp_grid, st);
+        persist = skp_grid >= SKP_NCLOSE + 8 && grid_is_coresident(c, skp.kern, 512, skp.lds, skp_grid, st);
     }
     const size_t nSkpFlag = persist ? up4(2 * (size_t)((B + 127) / 128)) : 0, nSkpPost = persist ? up4((sizeof(SkpPost) + 3) / 4) : 0;
     const size_t need = ((nS + nX + nU + 2 * nH + nO + nP + 2 * nPol + nPimg + nSkImg + nSkSched + nSkX + nSkFlag + nSkpFlag + nSkpPost) * sizeof(float) + 2 * (size_t)B * sizeof(int) + 1023) & ~(size_t)255;
@@ -694,9 +694,16 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
         SkpArgs pa = {};
         pa.a = sk.a1; pa.a.epoch = 0;
         { const int rc = skp_table(c, skp, sk.a1, &pa, st); if (rc) return rc; }
-        pa.G8 = skp_grid / 8; pa.T = a->T; pa.NSL = K * (sk.a1.N / 256);
+        pa.G8 = (skp_grid - SKP_NCLOSE) / 8; pa.T = a->T; pa.NSL = K * (sk.a1.N / 256);
         pa.xflag = skp_flags; pa.arrive = (unsigned*)(skp_flags + (B + 127) / 128); pa.stop = r.stop; pa.post = skp_post;
         HIP_TRY(c, hipMemsetAsync(skp_flags, 0, nSkpFlag * sizeof(float), st));
+        if (ctx_opt(c, OPT_PERSIST_STATS) != nullptr) {           // developer statistics of this launch (metrpo_debug_persist_stats)
+            if (c->skp_stats_n < skp_grid) { if (c->d_skp_stats) HIP_TRY(c, hipFree(c->d_skp_stats)); c->d_skp_stats = nullptr; HIP_TRY(c, hipMalloc((void**)&c->d_skp_stats, sizeof(unsigned long long) * 8 * skp_grid)); }
+            c->skp_stats_n = skp_grid;
+            HIP_TRY(c, hipMemsetAsync(c->d_skp_stats, 0, sizeof(unsigned long long) * 8 * skp_grid, st));
+            pa.stats = c->d_skp_stats;
+            pa.nowait = ctx_opt(c, OPT_PERSIST_STATS)[0] == '2' ? 1 : 0;
+        }
         SkpPost po; po.pd = pd; po.r = r; po.st = bs; po.theta = c->d_theta; po.norm = c->d_norm;
         hipLaunchKernelGGL(k_skp_post_args, dim3(1), dim3(64), 0, st, po, skp_post);
         hipLaunchKernelGGL(pre_mfma, dim3((B + 63) / 64), dim3(256), pre_lds, st, pd, r, 0, c->d_theta, c->d_norm, bs);
