@@ -35,7 +35,7 @@ struct ProblemDesc {
 // ---- variant / tuning switches of a context (metrpo_set_option / metrpo_get_option, include/metrpo.h) ----------------------------------------------
 // One table per context, read by the launch paths through ctx_opt(); metrpo_create fills the defaults ONCE from the environment (METRPO_<KEY>), nothing
 // else in the library reads the environment for kernel selection.  A key is the upper-case name below (the ABI also takes lower case and a METRPO_ prefix).
-#define METRPO_OPT_LIST(X) X(COOP_MODE) X(EXTRA_LDS) X(GEMM_PREFETCH) X(NO_DEVICE_LINESEARCH) X(NO_FUSED_OUT) X(NO_IMGVAL) X(NO_L0_ROWS) X(NO_MERGED_ROUNDS) X(NO_PRE_MFMA3) X(NO_RESIDENT) X(NO_RESIDENT_VALIDATION) X(NO_STEP_MERGE) X(NO_STREAMK) X(PG_HEAD_ROWS) X(PRE_GEMM) X(RESIDENT_NO_ROTATE) X(RESIDENT_NO_SENTINEL) X(RESIDENT_TEST_SKIP) X(RESIDENT_WS) X(RES_UNCACHED) X(SEQ_ROUNDS) X(SOLVE_BLOCK) X(STEP_MERGE) X(STREAMK) X(STREAMK_LATE) X(STREAMK_NO_XCD) X(UPD_TILES_PER_WAVE) X(VAL_CHUNKS) X(VAL_TILES_PER_WAVE) X(XCHG_TIMEOUT_MS) X(NO_PERSIST) X(PERSIST) X(QUIET) X(TIME_FVP) X(PERSIST_STATS)
+#define METRPO_OPT_LIST(X) X(COOP_MODE) X(EXTRA_LDS) X(GEMM_PREFETCH) X(NO_DEVICE_LINESEARCH) X(NO_FUSED_OUT) X(NO_IMGVAL) X(NO_L0_ROWS) X(NO_MERGED_ROUNDS) X(NO_PRE_MFMA3) X(NO_RESIDENT) X(NO_RESIDENT_VALIDATION) X(NO_STEP_MERGE) X(NO_STREAMK) X(PG_HEAD_ROWS) X(PRE_GEMM) X(RESIDENT_NO_ROTATE) X(RESIDENT_NO_SENTINEL) X(RESIDENT_TEST_SKIP) X(RESIDENT_WS) X(RES_UNCACHED) X(SEQ_ROUNDS) X(SOLVE_BLOCK) X(STEP_MERGE) X(STREAMK) X(STREAMK_LATE) X(STREAMK_NO_XCD) X(UPD_TILES_PER_WAVE) X(VAL_CHUNKS) X(VAL_TILES_PER_WAVE) X(XCHG_TIMEOUT_MS) X(NO_PERSIST) X(PERSIST) X(QUIET) X(TIME_FVP) X(PERSIST_STATS) X(PERSIST_NARROW) X(PERSIST_WIDE) X(PERSIST_NCLOSE)
 enum MetrpoOpt {
 #define X(n) OPT_##n,
     METRPO_OPT_LIST(X)
@@ -103,7 +103,7 @@ struct metrpo_ctx {
     size_t big_cap;
     void* d_res; size_t res_cap; unsigned int res_seq;   // rollout_resident.hip: uncached exchange region (abort cell | X packets | P packets) and the step stamps issued so far
     unsigned long long* d_skp_stats; int skp_stats_n;   // option PERSIST_STATS: per-workgroup statistics of the last persistent launch (metrpo_debug_persist_stats)
-    void* d_skp_tab; size_t skp_tab_cap; long long skp_key[8]; int skp_Jx[8], skp_Jmax, skp_L; int persist_failed;   // mlp_persist.h: cached chunk-record table of the persistent stream-K rollout (key: the launch's shape) | a persistent launch timed out
+    void* d_skp_tab; size_t skp_tab_cap; long long skp_key[8]; int skp_Jx[8], skp_Jmax, skp_L, skp_NSL; int persist_failed;   // mlp_persist.h: cached chunk-record table of the persistent stream-K rollout (key: the launch's shape) | a persistent launch timed out
     int res_failed;                                       // a resident launch gave up (its grid was not co-resident): this context stays on the step-wise path from then on
     int last_rollout_kernel;
     // metrpo_trpo_update_begin / _end: an update whose line search is still undecided on the host

@@ -41,6 +41,7 @@ struct SkpArgs {
     SkArgs a;                                      // shapes and pointers of the fused launch (x rows, W0, W1, epilogue images, output partials): mlp_streamk.h
     const SkRec* tab;                              // [8][Jmax][L] chunk records of ONE step's tiles, per XCD list, row block first; [8 Jmax L] = the sentinel record
     int Jx[8];                                     // tiles per step in list x
+    int nclose;                                    // closing workgroups (1 .. 8): blockIdx < nclose; the compute workgroups of list x are the other blockIdx = x (mod 8)
     int Jmax, L, G8, T, NSL;                       // entries per tile (chunks + epilogue chunks); workgroups per list; steps of this launch; tiles per row-block step
     int* xflag; unsigned* arrive;                  // [RB] each, zeroed in front of the launch: x of step t is ready when xflag[rb] >= t; arrivals so far
     const int32_t* stop;                           // metrpo_sampler_progress's flag (constant during the launch)
@@ -52,7 +53,7 @@ struct SkpArgs {
 
 __global__ void k_skp_post_args(SkpPost v, SkpPost* dst) { if (threadIdx.x == 0) *dst = v; }
 
-enum { SKP_NCLOSE = 8 };                           // closing workgroups of a launch: blockIdx 0 .. 7, one per XCD
+enum { SKP_NCLOSE = 8 };                           // most closing workgroups of a launch (SkpArgs::nclose of them: blockIdx 0 .. nclose - 1, on different XCDs)
 
 // Step t closed and step t + 1 prepared for the 128 envs of row block rb, by all 8 waves of a closing workgroup: the wave functions of the launch-per-step
 // pre-kernel (big_prepost.h).  scratch: [8][16][NS] floats of LDS state tiles; img: the policy image (PreImg<ENV>).
@@ -89,7 +90,7 @@ __device__ __forceinline__ void skp_closer_role(const SkpArgs& p, float* lds) {
     unsigned long long st_wait = 0, st_work = 0, st_n = 0;
     const unsigned long long st_t0 = wall_clock64();
     for (int t = 0; t + 1 < p.T; ++t)
-        for (int rb = blockIdx.x; rb < RB; rb += SKP_NCLOSE) {
+        for (int rb = blockIdx.x; rb < RB; rb += p.nclose) {
             const unsigned long long w0 = wall_clock64();
             if (tid == 0) {
                 const unsigned want = (unsigned)(t + 1) * (unsigned)p.NSL;
@@ -109,28 +110,31 @@ __device__ __forceinline__ void skp_closer_role(const SkpArgs& p, float* lds) {
     if (p.stats != nullptr && tid == 0) { unsigned long long* o = p.stats + 8 * (size_t)blockIdx.x; o[0] = wall_clock64() - st_t0; o[1] = st_wait; o[3] = st_n; o[4] = st_work; o[7] = 1; }
 }
 
-template <int ENV, int S0, int OT>
+// WIDE: a workgroup's tile is TWO adjacent column blocks of one (head, row block) -- 128 x 512 -- whose chunks alternate in the entry sequence and share the
+// layer-0 producer (each 32-unit slice of layer 0 is computed once per 512 columns instead of once per 256: -6 % matrix instructions at 2 x 512, -4 % at
+// 2 x 1024).  Every column block keeps its own accumulators, its own epilogue and its own output partial: the sums are those of two separate tiles.
+template <int ENV, int S0, int OT, bool WIDE>
 __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
     using EP = SkEpi<OT>;
     using GE = SkGeom<SK_A_PRODUCER, SK_EPI_OUT, S0, OT>;
-    constexpr int E = EP::E, UPC = EP::UPC, NI0 = GE::NI0, STAGE = GE::STAGE;
+    constexpr int E = EP::E, UPC = EP::UPC, NI0 = GE::NI0, STAGE = GE::STAGE, NH = WIDE ? 2 : 1;
     static_assert(EP::FLOATS <= STAGE, "EPI image larger than a ring stage");
     static_assert(NI0 <= 8, "layer-0 slice: at most 8 one-KB pieces (one per wave)");
     static_assert(PreImg<ENV>::IMG + 8 * 16 * Cfg<ENV, 64, 32>::NS <= 4 * STAGE, "the closing role's image and state tiles fit the ring's LDS");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (p.stop != nullptr && *p.stop != 0) return;                             // the sampling loop already ended
-    if (blockIdx.x < SKP_NCLOSE) { skp_closer_role<ENV>(p, lds); return; }
+    if ((int)blockIdx.x < p.nclose) { skp_closer_role<ENV>(p, lds); return; }
     float* const ring = lds;
     const SkArgs& a = p.a;
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cbk = blockIdx.x - SKP_NCLOSE;
-    const int xl = cbk & 7, wi = cbk >> 3;                                     // XCD list (blockIdx % 8 as well: NCLOSE is a multiple of 8) | first position
-    const int Jx = p.Jx[xl], L = p.L, G8 = p.G8, T = p.T;
+    const int xl = blockIdx.x & 7;                                             // XCD list = the XCD the dispatcher puts this workgroup on (blockIdx % 8)
+    const int wi = (int)(blockIdx.x >> 3) - (xl < p.nclose ? 1 : 0);           // first position: the list's workgroups in blockIdx order, its closer (if any) left out
+    const int Jx = p.Jx[xl], L = p.L, G8 = p.G8 - (xl < p.nclose ? 1 : 0), T = p.T;      // p.G8 = gridDim / 8
     const long long npos = (long long)T * Jx;
     const int n_tiles = (wi < npos) ? (int)((npos - wi + G8 - 1) / G8) : 0;
     const int nq = n_tiles * L;
-    if (nq == 0) return;
+    if (nq == 0 || G8 <= 0) return;
     const unsigned long long st_t0 = wall_clock64();
     const SkRec* const tabx = p.tab + (size_t)xl * p.Jmax * L;
     const SkRec* const sentinel = p.tab + (size_t)8 * p.Jmax * L;
@@ -160,8 +164,14 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
         if (r.fl & SKF_NONE) return;
         const unsigned st = ring_lds + (unsigned)((q & 3) * STAGE) * 4u;
         if (!(r.fl & SKF_EPI)) {
-            if constexpr (t < 4) sk_glds16_s(w1_voff, (const char*)(a.W1 + r.offW1) + (size_t)t * ((size_t)a.N * 32), st + (unsigned)(wave + 8 * t) * 1024u);
-            else { if (wave < NI0) sk_glds16_s(w0_voff, a.W0 + r.offW0, st + (8192u + (unsigned)wave * 256u) * 4u); }
+            if constexpr (t < 4) {
+                // (row stride made opaque per use: left visible, the four row-block bases W1 + t * 32 N of every entry are hoisted into eight more live scalar
+                //  registers -- this kernel's scalar file is full, and a spilled scalar comes back through v_readlane, a VECTOR instruction inside the matrix phase)
+                unsigned rs = (unsigned)a.N * 128u;
+                asm volatile("" : "+s"(rs));
+                sk_glds16_s(w1_voff, (const char*)(a.W1 + r.offW1) + (size_t)t * rs, st + (unsigned)(wave + 8 * t) * 1024u);
+            }
+            else { if (wave < NI0 && !(r.fl & SKF_NOPROD)) sk_glds16_s(w0_voff, a.W0 + r.offW0, st + (8192u + (unsigned)wave * 256u) * 4u); }
         } else {
             constexpr int NIE = EP::FLOATS / 256;
             const int ii = wave + 8 * t;
@@ -174,9 +184,9 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
     };
     auto drain_vm = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_waitcnt(0x0F70); };
 
-    f32x4 acc[4][4];
-    f32x4 oacc[OT];
-    f32x4 hs[2][2];
+    f32x4 acc[NH][4][4];
+    f32x4 oacc[NH][OT];
+    f32x4 hs[2];                                                               // layer-0 activations of the chunk's 32 units, srcB layout (WIDE: shared by the two column blocks' entries)
     float xr[S0];
 
     // ready flag of a tile's row block: one agent-scope load (every lane the same word), issued a chunk ahead of the wait
@@ -247,11 +257,11 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
     int seen = 0;                                                              // flag value probed for the next tile
     __amdgpu_buffer_rsrc_t part_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.part, 0, 0xFFFFFFFFu, 0x00020000);
     auto body = [&](auto par_, const int q) {
-        constexpr int PAR = decltype(par_)::value;
-        f32x4 (&h)[2] = hs[PAR];
+        constexpr int H = decltype(par_)::value % NH;                          // which of the tile's column blocks this entry belongs to (entries alternate)
+        f32x4 (&h)[2] = hs;
         const bool nmain = !(r1.fl & SKF_EPI);
         const float* st = ring + (q & 3) * STAGE;
-        if (!(r0.fl & SKF_EPI)) produce(q, h);
+        if (!(r0.fl & SKF_EPI) && H == 0) produce(q, h);
         // The next tile's rows: loaded HERE if its row block's flag (probed a chunk ago) was already raised -- normally long since.  If not, the wave must not block
         // yet: its workgroup still owes the arrival of the tile in progress, and the awaited step may (in small problems: does) depend on exactly that tile.  It
         // blocks behind the arrival, at the end of this chunk.
@@ -267,7 +277,7 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) acc[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int v = 0; v < 4; ++v) acc[H][u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             {
                 const unsigned cur_a = stage_addr(q), nxt_a = stage_addr(q + 1);
@@ -281,7 +291,7 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
                     else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(w[k & 7]) : "i"(31 - k));
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) acc[u][v] = MFMA16(w[k & 7][v], h[j][e], acc[u][v]);
+                    for (int v = 0; v < 4; ++v) acc[H][u][v] = MFMA16(w[k & 7][v], h[j][e], acc[H][u][v]);
                     __builtin_amdgcn_sched_barrier(0);
                 };
 #define SKP_G4(b) group(std::integral_constant<int, (b)>{}); group(std::integral_constant<int, (b) + 1>{}); group(std::integral_constant<int, (b) + 2>{}); group(std::integral_constant<int, (b) + 3>{});
@@ -305,7 +315,7 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
                     constexpr int EE = decltype(ee)::value;
                     if (EE == 0) {
 #pragma unroll
-                        for (int ot = 0; ot < OT; ++ot) oacc[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        for (int ot = 0; ot < OT; ++ot) oacc[H][ot] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
 #pragma unroll
                     for (int ul = 0; ul < UPC; ++ul) {
@@ -317,9 +327,9 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
                             for (int ot = 0; ot < OT; ++ot) wf[ot] = *(const f32x4*)(st + 256 + ((((ul * 4 + r) * 4 + g) * OT + ot) * 16 + i) * 4);
 #pragma unroll
                             for (int v = 0; v < 4; ++v) {
-                                const float hb = relu1(acc[EE * UPC + ul][v][r] + bq[v]);
+                                const float hb = relu1(acc[H][EE * UPC + ul][v][r] + bq[v]);
 #pragma unroll
-                                for (int ot = 0; ot < OT; ++ot) oacc[ot] = MFMA16(wf[ot][v], hb, oacc[ot]);
+                                for (int ot = 0; ot < OT; ++ot) oacc[H][ot] = MFMA16(wf[ot][v], hb, oacc[H][ot]);
                             }
                         }
                     }
@@ -332,7 +342,7 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
                         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                         const unsigned off = (r0.offC + (unsigned)m * (unsigned)a.ldp + 4u * g) * 4u;
 #pragma unroll
-                        for (int ot = 0; ot < OT; ++ot) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oacc[ot]), part_rs, off + 64u * ot, 0, 16);
+                        for (int ot = 0; ot < OT; ++ot) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oacc[H][ot]), part_rs, off + 64u * ot, 0, 16);
                     }
                 }
                 if (nmain) first4(stage_addr(q + 1));
@@ -342,7 +352,7 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         // every wave's partials are complete behind the barrier: the tile arrives (fire and forget; the last step is closed by the host's k_big_post)
-        if ((r0.fl & SKF_EPILAST) && r0.t + 1 < T && tid == 0) (void)__hip_atomic_fetch_add(p.arrive + (r0.m0 >> 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((r0.fl & SKF_ARRIVE) && r0.t + 1 < T && tid == 0) (void)__hip_atomic_fetch_add(p.arrive + (r0.m0 >> 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!have_x) { wait_x(r1, -1); load_x(r1); }                            // (a compute workgroup that has arrived for all it finished owes nobody anything: it may block)
         r0 = r1; r1 = rn; r3 = r4;
     };
@@ -358,13 +368,17 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------------------------------
-// The chunk records of ONE step's tiles, per XCD list.  List x holds the (slice, row block) pairs u = slice * RB + rb of [x TPS / 8, (x + 1) TPS / 8) -- 1/8 of
-// the weight slices, so that the workgroups behind one L2 stream the same 2-3 slices -- ordered row block first (a row block's tiles finish together, early).
+// The chunk records of ONE step's tiles, per XCD list.  A tile = NH adjacent column blocks of one (head, row block); a "slice" = one (head, tile column) pair.
+// List x holds the (slice, row block) pairs u = slice * RB + rb of [x TPS / 8, (x + 1) TPS / 8) -- 1/8 of the weight slices, so that the workgroups behind one
+// L2 stream the same 2-3 slices -- ordered row block first (a row block's tiles finish together, early).  Entries of a tile: the chunks of its column blocks
+// alternating (c = 0: block 0, block 1; c = 1: ...), then their epilogue chunks alternating; SKF_NOPROD on the entries that reuse the other block's layer-0
+// activations, SKF_ARRIVE on the tile's last entry.
 template <int OT>
-static inline void skp_build_tab(const SkArgs& a, std::vector<SkRec>& tab, int (&Jx)[8], int& Jmax, int& L_out) {
+static inline void skp_build_tab(const SkArgs& a, bool wide, std::vector<SkRec>& tab, int (&Jx)[8], int& Jmax, int& L_out, int& NSL_out) {
     using EP = SkEpi<OT>;
     constexpr int E = EP::E;
-    const int RB = (a.M + 127) / 128, CB = a.N / 256, NCk = a.K1 / 32, NSL = a.heads * CB, TPS = NSL * RB, L = NCk + E;
+    const int NH = wide ? 2 : 1;
+    const int RB = (a.M + 127) / 128, CB = a.N / 256, CBW = CB / NH, NCk = a.K1 / 32, NSL = a.heads * CBW, TPS = NSL * RB, L = NH * (NCk + E);
     std::vector<std::vector<std::pair<int, int>>> lists(8);
     for (int x = 0; x < 8; ++x) {
         const int u0 = (int)((long long)TPS * x / 8), u1 = (int)((long long)TPS * (x + 1) / 8);
@@ -373,26 +387,28 @@ static inline void skp_build_tab(const SkArgs& a, std::vector<SkRec>& tab, int (
     }
     Jmax = 0;
     for (int x = 0; x < 8; ++x) { Jx[x] = (int)lists[x].size(); Jmax = std::max(Jmax, Jx[x]); }
-    L_out = L;
+    L_out = L; NSL_out = NSL;
     tab.assign((size_t)8 * Jmax * L + 1, SkRec{});
     for (int x = 0; x < 8; ++x)
         for (int jj = 0; jj < Jx[x]; ++jj) {
-            const int rb = lists[x][jj].first, sl = lists[x][jj].second, head = sl / CB, cb = sl % CB;
-            for (int c = 0; c < L; ++c) {
+            const int rb = lists[x][jj].first, sl = lists[x][jj].second, head = sl / CBW, cbw = sl % CBW;
+            for (int e = 0; e < L; ++e) {
+                const int hf = e % NH, c = e / NH, cb = cbw * NH + hf;          // column block of this entry | chunk (or NCk + epilogue chunk)
                 SkRec r = {};
                 int fl = 0, kc = c;
-                if (c < NCk) { if (c == 0) fl |= SKF_ZERO | SKF_NEWTILE; if (c == NCk - 1) fl |= SKF_LAST; }
+                if (c < NCk) { if (c == 0) fl |= SKF_ZERO; if (e == 0) fl |= SKF_NEWTILE; if (c == NCk - 1) fl |= SKF_LAST; if (hf != 0) fl |= SKF_NOPROD; }
                 else { kc = c - NCk; fl = SKF_EPI | (kc == E - 1 ? SKF_EPILAST : 0); }
+                if (e == L - 1) fl |= SKF_ARRIVE;
                 r.w = r.w2 = kc | (fl << 16); r.m0 = rb * 128;
                 r.offA = (unsigned)(head * a.strideA);
                 r.offC = (unsigned)(((long long)cb * a.heads + head) * a.stridePart);
                 if (fl & SKF_EPI) { r.offW1 = (unsigned)(((head * CB + cb) * E + kc) * EP::FLOATS); r.offW0 = 0; }
                 else { r.offW1 = (unsigned)(head * a.strideW1 + (long long)(32 * c) * a.N + cb * 256); r.offW0 = (unsigned)(head * a.strideW0 + 32 * c); }
                 r.tile = (head * CB + cb) * RB + rb;
-                tab[((size_t)x * Jmax + jj) * L + c] = r;
+                tab[((size_t)x * Jmax + jj) * L + e] = r;
             }
         }
-    SkRec s = {};
-    s.w = s.w2 = (SKF_NONE | SKF_EPI) << 16; s.tile = -1;
-    tab[(size_t)8 * Jmax * L] = s;
+    SkRec sn = {};
+    sn.w = sn.w2 = (SKF_NONE | SKF_EPI) << 16; sn.tile = -1;
+    tab[(size_t)8 * Jmax * L] = sn;
 }

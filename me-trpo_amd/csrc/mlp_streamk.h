@@ -40,7 +40,8 @@
 
 enum { SK_A_GLOBAL = 0, SK_A_PRODUCER = 1 };      // main layer's input: activations [M][K1] in HBM | computed from x by layer 0 on the fly
 enum { SK_EPI_STORE = 0, SK_EPI_OUT = 1 };        // relu(acc + b1) stored row-major | contracted with the (<= 64 column) output layer, partial per column block
-enum { SKF_ZERO = 1, SKF_IMPORT = 2, SKF_EXPORT = 4, SKF_LAST = 8, SKF_EPI = 16, SKF_EPILAST = 32, SKF_NONE = 64, SKF_NEWTILE = 128, SKF_LATE = 256 };
+enum { SKF_ZERO = 1, SKF_IMPORT = 2, SKF_EXPORT = 4, SKF_LAST = 8, SKF_EPI = 16, SKF_EPILAST = 32, SKF_NONE = 64, SKF_NEWTILE = 128, SKF_LATE = 256,
+       SKF_NOPROD = 512, SKF_ARRIVE = 1024 };   // mlp_persist.h: the entry reuses the layer-0 activations of the entry before it | last entry of a tile
 
 struct SkRec;
 struct SkArgs {

@@ -517,37 +517,46 @@ static SkPath sk_select(const metrpo_ctx* c, int B) {
 
 // ---- persistent stream-K rollout (mlp_persist.h): the (env, input steps, output tiles) instantiations = the five envs of the 2 x 32 MFMA pre-step ----
 struct SkpVt {
-    const void* kern; size_t lds;
+    const void* kern; size_t lds; bool wide;
     void (*launch)(const SkpArgs&, int grid, size_t lds, hipStream_t);
-    void (*tab)(const SkArgs&, std::vector<SkRec>&, int (&)[8], int&, int&);
+    void (*tab)(const SkArgs&, bool wide, std::vector<SkRec>&, int (&)[8], int&, int&, int&);
 };
-template <int ENV, int S0, int OT> static SkpVt skp_vt() {
+template <int ENV, int S0, int OT, bool WIDE> static SkpVt skp_vt() {
     SkpVt v;
-    v.kern = (const void*)k_sk_persist<ENV, S0, OT>;
+    v.kern = (const void*)k_sk_persist<ENV, S0, OT, WIDE>; v.wide = WIDE;
     v.lds = sizeof(float) * (size_t)(4 * SkGeom<SK_A_PRODUCER, SK_EPI_OUT, S0, OT>::STAGE);
-    v.launch = [](const SkpArgs& p, int grid, size_t lds, hipStream_t st) { hipLaunchKernelGGL((k_sk_persist<ENV, S0, OT>), dim3(grid), dim3(512), lds, st, p); };
-    v.tab = [](const SkArgs& a, std::vector<SkRec>& t, int (&Jx)[8], int& Jmax, int& L) { skp_build_tab<OT>(a, t, Jx, Jmax, L); };
+    v.launch = [](const SkpArgs& p, int grid, size_t lds, hipStream_t st) { hipLaunchKernelGGL((k_sk_persist<ENV, S0, OT, WIDE>), dim3(grid), dim3(512), lds, st, p); };
+    v.tab = [](const SkArgs& a, bool wide, std::vector<SkRec>& t, int (&Jx)[8], int& Jmax, int& L, int& NSL) { skp_build_tab<OT>(a, wide, t, Jx, Jmax, L, NSL); };
     return v;
 }
-static bool skp_select(const ProblemDesc& pd, int S0, int OT, SkpVt* v) {
+// wide: an even number of 256-column blocks -> tiles of two adjacent blocks sharing the layer-0 producer (option PERSIST_NARROW keeps one block per tile: A/B runs, tests)
+static bool skp_select(const metrpo_ctx* c, int S0, int OT, int CB, int B, SkpVt* v) {
+    const ProblemDesc& pd = c->pd;
     if (pd.pol.n_layers != 3 || pd.pol.dims[1] != 32 || pd.pol.dims[2] != 32 || pd.pol.act[0] != METRPO_ACT_TANH) return false;
+    // A row block's steps form a chain: (one tile + its closing) per step.  Two-block tiles double the tile time, so they only pay where the chip has more than
+    // ~1.2 of them per compute workgroup and step -- below that the chain, not the matrix pipe, sets the step time (C3 share: 170 vs 128 us per step).
+    const long long wide_tiles = (long long)pd.K * (CB / 2) * ((B + 127) / 128);
+    const char* wo = ctx_opt(c, OPT_PERSIST_WIDE);
+    const bool wide = (CB % 2 == 0) && ctx_opt(c, OPT_PERSIST_NARROW) == nullptr && ((wo && wo[0] == '1') || 10 * wide_tiles >= 12 * (long long)(c->n_sm - 8));
+#define SKP_PICK(ENV_, S0_, OT_) { *v = wide ? skp_vt<ENV_, S0_, OT_, true>() : skp_vt<ENV_, S0_, OT_, false>(); return true; }
     switch (pd.env) {
-    case METRPO_ENV_SWIMMER:      if (pd.ns == 10 && pd.na == 2 && pd.n_drop == 2 && S0 == 3 && OT == 1) { *v = skp_vt<METRPO_ENV_SWIMMER, 3, 1>(); return true; } break;
-    case METRPO_ENV_HOPPER:       if (pd.ns == 11 && pd.na == 3 && pd.n_drop == 0 && S0 == 4 && OT == 1) { *v = skp_vt<METRPO_ENV_HOPPER, 4, 1>(); return true; } break;
-    case METRPO_ENV_SNAKE:        if (pd.ns == 14 && pd.na == 4 && pd.n_drop == 2 && S0 == 5 && OT == 1) { *v = skp_vt<METRPO_ENV_SNAKE, 5, 1>(); return true; } break;
-    case METRPO_ENV_HALF_CHEETAH: if (pd.ns == 18 && pd.na == 6 && pd.n_drop == 1 && S0 == 6 && OT == 2) { *v = skp_vt<METRPO_ENV_HALF_CHEETAH, 6, 2>(); return true; } break;
-    case METRPO_ENV_ANT:          if (pd.ns == 29 && pd.na == 8 && pd.n_drop == 2 && S0 == 9 && OT == 2) { *v = skp_vt<METRPO_ENV_ANT, 9, 2>(); return true; } break;
+    case METRPO_ENV_SWIMMER:      if (pd.ns == 10 && pd.na == 2 && pd.n_drop == 2 && S0 == 3 && OT == 1) SKP_PICK(METRPO_ENV_SWIMMER, 3, 1) break;
+    case METRPO_ENV_HOPPER:       if (pd.ns == 11 && pd.na == 3 && pd.n_drop == 0 && S0 == 4 && OT == 1) SKP_PICK(METRPO_ENV_HOPPER, 4, 1) break;
+    case METRPO_ENV_SNAKE:        if (pd.ns == 14 && pd.na == 4 && pd.n_drop == 2 && S0 == 5 && OT == 1) SKP_PICK(METRPO_ENV_SNAKE, 5, 1) break;
+    case METRPO_ENV_HALF_CHEETAH: if (pd.ns == 18 && pd.na == 6 && pd.n_drop == 1 && S0 == 6 && OT == 2) SKP_PICK(METRPO_ENV_HALF_CHEETAH, 6, 2) break;
+    case METRPO_ENV_ANT:          if (pd.ns == 29 && pd.na == 8 && pd.n_drop == 2 && S0 == 9 && OT == 2) SKP_PICK(METRPO_ENV_ANT, 9, 2) break;
     }
+#undef SKP_PICK
     return false;
 }
 // chunk-record table of this launch shape in device memory (cached in the context: the shape repeats every iteration)
 static int skp_table(metrpo_ctx* c, const SkpVt& v, const SkArgs& a, SkpArgs* p, hipStream_t st) {
-    const long long key[8] = {a.M, a.heads, a.K1, a.N, (long long)a.strideW1, (long long)a.strideW0, (long long)a.stridePart, (long long)c->pd.env};
+    const long long key[8] = {a.M, a.heads, a.K1, a.N, (long long)a.strideW1, (long long)a.strideW0, (long long)a.stridePart, (long long)c->pd.env * 2 + (v.wide ? 1 : 0)};
     bool same = c->d_skp_tab != nullptr;
     for (int i = 0; i < 8; ++i) same = same && c->skp_key[i] == key[i];
     if (!same) {
         std::vector<SkRec> tab;
-        v.tab(a, tab, c->skp_Jx, c->skp_Jmax, c->skp_L);
+        v.tab(a, v.wide, tab, c->skp_Jx, c->skp_Jmax, c->skp_L, c->skp_NSL);
         const size_t bytes = tab.size() * sizeof(SkRec);
         if (bytes > c->skp_tab_cap) {
             if (c->d_skp_tab) HIP_TRY(c, hipFree(c->d_skp_tab));
@@ -561,7 +570,7 @@ static int skp_table(metrpo_ctx* c, const SkpVt& v, const SkArgs& a, SkpArgs* p,
     }
     p->tab = (const SkRec*)c->d_skp_tab;
     for (int x = 0; x < 8; ++x) p->Jx[x] = c->skp_Jx[x];
-    p->Jmax = c->skp_Jmax; p->L = c->skp_L;
+    p->Jmax = c->skp_Jmax; p->L = c->skp_L; p->NSL = c->skp_NSL;
     return METRPO_OK;
 }
 
@@ -627,11 +636,18 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
     SkpVt skp = {};
     int skp_grid = 0;
     bool persist = sk.mode == 1 && vB == 0 && a->T >= 2 && ctx_opt(c, OPT_NO_PERSIST) == nullptr && !c->persist_failed && pre_lds == 0 && pre_mfma != nullptr &&
-                   skp_select(pd, sk.S0, sk.OT, &skp);
+                   skp_select(c, sk.S0, sk.OT, sk.a1.N / 256, B, &skp);
     if (persist) {
         if (skp.lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute(skp.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)skp.lds));
         skp_grid = (std::min(sched_cus(c, st), c->n_sm) / 8) * 8;
-        persist = skp_grid >= SKP_NCLOSE + 8 && grid_is_coresident(c, skp.kern, 512, skp.lds, skp_grid, st);
+        persist = skp_grid >= 16 && grid_is_coresident(c, skp.kern, 512, skp.lds, skp_grid, st);
+    }
+    int skp_nclose = SKP_NCLOSE;
+    if (persist) {
+        // per step: RB closings of ~17 us on nclose workgroups against (tiles x chunks x ~4.6 us) / compute workgroups of matrix work
+        const int RBp = (B + 127) / 128, CBp = sk.a1.N / 256;
+        const double step_us = (double)K * CBp * RBp * (sk.a1.K1 / 32 + 1) * 4.6 / std::max(1, skp_grid - 8);
+        skp_nclose = std::max(2, std::min((int)SKP_NCLOSE, (int)std::ceil(RBp * 17.0 / (0.6 * step_us))));
     }
     const size_t nSkpFlag = persist ? up4(2 * (size_t)((B + 127) / 128)) : 0, nSkpPost = persist ? up4((sizeof(SkpPost) + 3) / 4) : 0;
     const size_t need = ((nS + nX + nU + 2 * nH + nO + nP + 2 * nPol + nPimg + nSkImg + nSkSched + nSkX + nSkFlag + nSkpFlag + nSkpPost) * sizeof(float) + 2 * (size_t)B * sizeof(int) + 1023) & ~(size_t)255;
@@ -694,7 +710,9 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
         SkpArgs pa = {};
         pa.a = sk.a1; pa.a.epoch = 0;
         { const int rc = skp_table(c, skp, sk.a1, &pa, st); if (rc) return rc; }
-        pa.G8 = (skp_grid - SKP_NCLOSE) / 8; pa.T = a->T; pa.NSL = K * (sk.a1.N / 256);
+        pa.G8 = skp_grid / 8; pa.T = a->T;
+        // closing workgroups: each closes ~17 us per (row block, step); enough of them to stay under ~60 % busy at this launch's step time, at most one per XCD
+        { const char* nc = ctx_opt(c, OPT_PERSIST_NCLOSE); pa.nclose = nc ? std::max(1, std::min((int)SKP_NCLOSE, atoi(nc))) : skp_nclose; }
         pa.xflag = skp_flags; pa.arrive = (unsigned*)(skp_flags + (B + 127) / 128); pa.stop = r.stop; pa.post = skp_post;
         HIP_TRY(c, hipMemsetAsync(skp_flags, 0, nSkpFlag * sizeof(float), st));
         if (ctx_opt(c, OPT_PERSIST_STATS) != nullptr) {           // developer statistics of this launch (metrpo_debug_persist_stats)

@@ -25,6 +25,15 @@ def _both(eng, B, T, H, mode, pool, **kw):
     a = eng.rollout(B, T, H, mode, pool, **kw)
     assert eng.last_rollout_kernel() == 'streamk-persistent', eng.last_rollout_kernel()
     a = {k: getattr(a, k).clone() for k in FIELDS}
+    # two adjacent column blocks per tile sharing the layer-0 producer (selected by itself from ~1.2 such tiles per workgroup and step; forced here), and a
+    # different number of closing workgroups: who computes and who closes changes, the sums do not
+    for opt, val in (('PERSIST_WIDE', '1'), ('PERSIST_NCLOSE', '3')):
+        eng.set_option(opt, val)
+        n = eng.rollout(B, T, H, mode, pool, **kw)
+        assert eng.last_rollout_kernel() == 'streamk-persistent'
+        for k in FIELDS:
+            assert torch.equal(a[k], getattr(n, k)), (opt, k)
+        eng.set_option(opt, None)
     eng.set_option('NO_PERSIST', '1')
     eng.set_option('STREAMK_LATE', '0')                          # forced launches below one tile per CU: whole tiles (the side-by-side pieces of SkArgs::late add in another order)
     b = eng.rollout(B, T, H, mode, pool, **kw)
