@@ -302,6 +302,9 @@ def main():
                 + (': chain-latency-bound by construction, the fraction of the matrix peak says nothing about the kernel here' if n_tiles < 200 else ''))
     elif kern == 'resident':
         note = 'one launch for the whole time loop, weights register-resident; bound by matrix-instruction issue of the compute workgroups + the step hand-over latency (B = %d: %d env tiles per round)' % (B, n_tiles)
+    elif kern == 'streamk-persistent':
+        note = ('one launch per rollout chunk (mlp_persist.h): whole 128 x 256 tiles of all steps in one sequence, 248 compute workgroups + closing workgroups that close a row '
+                'block\'s step (reward / done / reset / policy / next input rows) as soon as its tiles have arrived; f32 MFMA issue bound')
     elif kern == 'gemm-streamk':
         note = 'per step: one stream-K launch for the K-head forward (two for three hidden layers) + one pre/post launch; f32 MFMA issue bound'
     else:

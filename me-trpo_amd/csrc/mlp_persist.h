@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
             if constexpr (t < 4) {
                 // (row stride made opaque per use: left visible, the four row-block bases W1 + t * 32 N of every entry are hoisted into eight more live scalar
                 //  registers -- this kernel's scalar file is full, and a spilled scalar comes back through v_readlane, a VECTOR instruction inside the matrix phase)
-                unsigned rs = (unsigned)a.N * 128u;
+                unsigned rs = (unsigned)a.N * 32u;                         // bytes between row blocks t and t + 1: 8 rows x N floats
                 asm volatile("" : "+s"(rs));
                 sk_glds16_s(w1_voff, (const char*)(a.W1 + r.offW1) + (size_t)t * rs, st + (unsigned)(wave + 8 * t) * 1024u);
             }

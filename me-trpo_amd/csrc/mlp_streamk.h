@@ -62,6 +62,7 @@ struct SkArgs {
     const int* hdr; const SkRec* recs;         // schedule: entries per workgroup | [grid][sched_cap] records (k_sk_sched)
     int RB, CB, NCk, L, tiles, sched_cap;      // row blocks of 128, column blocks of 256, chunks per tile, units per tile (chunks + epilogue weight)
     int xcd;                                   // > 1: workgroup b is taken to run on XCD b % xcd and gets range (b % xcd) * (grid / xcd) + b / xcd of the unit sequence (below)
+    int team;                                  // XCD teams (below): the workgroups of one XCD walk the tiles in lock step, sharing weight slices AND activation rows in their L2
     int late;                                  // FEWER tiles than workgroups: the pieces of a tile run side by side from zero and are ADDED at their ends (below)
     long long units;
 };
@@ -131,8 +132,24 @@ __global__ void __launch_bounds__(512) k_sk_sched(const SkArgs a, int* __restric
     // fetched from HBM once instead of once per XCD.  The unit sequence is cut into a.xcd parts at TILE boundaries (nothing is handed over between
     // XCD groups), each part evenly over its grid / xcd workgroups; inside a part range i belongs to workgroup i * xcd + x, so a piece is still handed
     // to a HIGHER-numbered workgroup (blockIdx + xcd): nobody waits for a workgroup dispatched after it.
+    // XCD TEAMS (a.team; activations read from memory: SK_A_GLOBAL): with ranges of consecutive tiles per workgroup, the 32 workgroups behind one L2 sit at 32
+    // different places of their tiles -- a weight slice or a 128-row block of activations fetched by one of them has left the 4 MB L2 (48 MB stream through it per
+    // tile time) before the next one wants it, and the C4 share moved 3.1 GB per launch for 0.6 GB of operands.  Here the unit of the split is a SUPER-TILE = the
+    // GP = grid / 8 tiles {PP = GP / CB consecutive (head, row block) pairs} x {CB column blocks}; slot i = blockIdx / 8 of every XCD owns tile (pair i / CB,
+    // column block i % CB) of each super-tile, the XCDs split the super-tile sequence evenly (ranges start and end inside super-tiles), and all slots of an XCD
+    // have the SAME range: they step through the same chunks at the same time, so a weight chunk is fetched once for the PP workgroups that share the column
+    // block and an activation chunk once for the CB that share the row block.  Pieces are handed to the SAME slot of the NEXT XCD (blockIdx + 1: still a
+    // higher-numbered workgroup; through memory, as before); every output remains one k-ordered chain.
+    const int tph = a.CB * a.RB;
+    bool team_idle_tail = false; int team_pairs = 0, team_PP = 1, team_slot = 0;
     long long u0, u1;
-    if (a.xcd > 1) {
+    if (a.team) {
+        const int GP = G / 8, x = b % 8;
+        team_slot = b / 8; team_PP = GP / a.CB; team_pairs = a.heads * a.RB;
+        const long long n_st = (team_pairs + team_PP - 1) / team_PP, SU = n_st * a.L;
+        u0 = SU * x / 8; u1 = SU * (x + 1) / 8;
+        team_idle_tail = true;
+    } else if (a.xcd > 1) {
         const int GP = G / a.xcd, x = b % a.xcd, i = b / a.xcd;
         auto part = [&](int xx) -> long long { return xx >= a.xcd ? U : ((U * xx / a.xcd + a.L / 2) / a.L) * a.L; };
         const long long s0 = part(x), s1 = part(x + 1);
@@ -147,7 +164,6 @@ __global__ void __launch_bounds__(512) k_sk_sched(const SkArgs a, int* __restric
     else { n_h = ce; tf = ts + (cs > 0 ? 1 : 0); nf = te - tf; n_t = cs > 0 ? (NCk - cs) + (OUT ? E : 0) : 0; }
     const int nq = n_h + nf * Le + n_t;
     if (tid == 0) hdr[b] = nq;
-    const int tph = a.CB * a.RB;
     for (int t = tid; t < nq + 4; t += 512) {
         SkRec r = {};
         if (t >= nq) { r.w = r.w2 = (SKF_NONE | SKF_EPI) << 16; r.tile = -1; recs[(size_t)b * a.sched_cap + t] = r; continue; }     // four sentinels behind the last entry
@@ -167,7 +183,13 @@ __global__ void __launch_bounds__(512) k_sk_sched(const SkArgs a, int* __restric
             if (c == NCk - 1) fl |= SKF_LAST | (a.late ? SKF_LATE : 0);
             if (c >= NCk) { c -= NCk; fl = SKF_EPI | (c == E - 1 ? SKF_EPILAST : 0); }
         }
-        const int head = tile / tph, cb = (tile / a.RB) % a.CB, rb = tile % a.RB;
+        int head = tile / tph, cb = (tile / a.RB) % a.CB, rb = tile % a.RB;
+        if (a.team) {                                                          // `tile` is a super-tile: this slot's tile of it (none beyond the last pair: an idle entry)
+            const int pair = tile * team_PP + team_slot / a.CB;
+            cb = team_slot % a.CB; head = pair / a.RB; rb = pair % a.RB;
+            if (pair >= team_pairs) { r.w = r.w2 = (SKF_NONE | SKF_EPI) << 16; r.tile = -1; recs[(size_t)b * a.sched_cap + t] = r; continue; }
+            tile = (head * a.CB + cb) * a.RB + rb;
+        }
         if (t == 0 || t == n_h || (t >= n_h && t < n_h + nf * Le && (t - n_h) % Le == 0) || t == n_h + nf * Le) fl |= SKF_NEWTILE;   // first entry of a piece
         r.w = r.w2 = c | (fl << 16); r.m0 = rb * 128;
         r.offA = (unsigned)(head * a.strideA) + ((!PROD && !(fl & SKF_EPI)) ? 32u * c : 0u);
@@ -323,7 +345,7 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
 #endif
 
     bool export_issued = false;
-    const int prev_d = a.xcd > 1 ? a.xcd : 1;                                  // the workgroup that holds the range in front of this one
+    const int prev_d = a.team ? 1 : (a.xcd > 1 ? a.xcd : 1);                   // the workgroup that holds the range in front of this one (teams: the same slot of the previous XCD)
     auto wait_prev = [&]() {                                                   // the previous workgroup's export flag of this launch (bounded: report, do not hang)
         const unsigned* fp = a.xflag + (size_t)(blockIdx.x - prev_d) * 8 + wave;
         const unsigned long long t0 = wall_clock64();
@@ -536,7 +558,10 @@ static inline SkPlan sk_plan(SkArgs& a, int n_sm, int grid_override = 0) {
     SkPlan p;
     p.grid = grid_override > 0 ? grid_override : ((a.tiles < n_sm && !a.late) ? a.tiles : n_sm);
     if (a.xcd > 1 && (a.late || p.grid % a.xcd != 0 || a.tiles < p.grid)) a.xcd = 0;      // whole XCD groups, at least a tile per workgroup
-    const long long cap = a.units / p.grid + 2LL * a.L + 8;
+    // teams: 8 XCDs x GP slots, GP a multiple of the column blocks, at least ~2 super-tiles per XCD
+    if (a.team && (AMODE != SK_A_GLOBAL || a.late || a.xcd != 8 || p.grid % 8 != 0 || (p.grid / 8) % a.CB != 0 || a.tiles < 2LL * p.grid)) a.team = 0;
+    long long cap = a.units / p.grid + 2LL * a.L + 8;
+    if (a.team) { const long long PP = (p.grid / 8) / a.CB, n_st = ((long long)a.heads * a.RB + PP - 1) / PP; cap = n_st * a.L / 8 + 2LL * a.L + 8; }
     a.sched_cap = (int)cap;
     p.lds_bytes = (size_t)4 * GE::STAGE * sizeof(float);
     p.xacc_floats = (size_t)p.grid * 8 * 4096;

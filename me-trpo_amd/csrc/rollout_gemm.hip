@@ -487,7 +487,8 @@ static SkPath sk_select(const metrpo_ctx* c, int B) {
     const int epi_units = (sp.OT == 4) ? 2 : 1;
     if (!force && (long long)K * ((B + 127) / 128) * (N / 256) < c->n_sm && !late_for(K1, N, epi_units)) return sp;
     auto shape = [&](SkArgs& a, int K1_, int N_, int eu) { a = SkArgs{}; a.M = B; a.heads = K; a.K1 = K1_; a.N = N_; a.late = late_for(K1_, N_, eu);
-                                                             a.xcd = ctx_opt(c, OPT_STREAMK_NO_XCD) == nullptr ? 8 : 0; };      // MI355X: 8 XCDs, workgroups dealt round-robin
+                                                             a.xcd = ctx_opt(c, OPT_STREAMK_NO_XCD) == nullptr ? 8 : 0;
+                                                             a.team = ctx_opt(c, OPT_STREAMK_NO_TEAM) == nullptr ? 1 : 0; };      // (sk_plan keeps it for SK_A_GLOBAL launches with enough tiles only)      // MI355X: 8 XCDs, workgroups dealt round-robin
     if (L == 3) {
         sp.S0 = (pd.nin + 1 + 3) / 4;
         const bool fused = sk_fused_vt(sp.S0, sp.OT, &sp.v1);                   // layer 0 as producer: inputs of up to 36 values (Humanoid's 76 + 1: mode 3)

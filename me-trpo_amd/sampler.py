@@ -212,8 +212,11 @@ class VectorizedSampler(BaseSampler):
                         resume=None if t == 0 else (buf.last_obs, last_ts, last_model), **common, **chunk_draws(t, t_hi))
             eng.sampler_progress(out.done, out.tpath, t, batch, self._ant_counts, state, stop)
             t = t_hi
-            if poll and t < T_max and int(stop.item()):
-                break
+            if poll and t < T_max:
+                if eng.last_rollout_kernel() == 'streamk-persistent':
+                    poll = False                                   # a chunk behind the stop flag is four empty launches there: enqueue ahead, never wait for the GPU
+                elif int(stop.item()):
+                    break
         t_stop = int(state[1].item())
         if t_stop < 0:
             raise RuntimeError("obtain_samples: %d completed samples < batch_size %d after %d steps (draws too short?)"

@@ -193,3 +193,19 @@ def test_step_closed_in_the_next_launch_is_bitwise_the_two_launch_sequence(env, 
     t2 = eng.rollout(B, T, H, sam_mode, pool, seed=5)
     for name in ('obs', 'act', 'rew', 'mean', 'done', 'tpath', 'last_obs'):
         assert torch.equal(getattr(m2, name), getattr(t2, name)), name
+
+
+def test_streamk_xcd_teams_are_bitwise_the_consecutive_ranges():
+    """Three hidden layers (activations read from memory) with enough tiles for the XCD-team split (mlp_streamk.h: SkArgs::team -- the workgroups of an XCD walk
+    super-tiles in lock step, pieces handed to the same slot of the next XCD): who computes what changes, every output stays one k-ordered chain -- bit for bit the
+    consecutive-range split, which tests above hold against the oracle."""
+    env, K, B, T, H = 'humanoid', 8, 2200, 3, 3                   # 8 heads x 4 column blocks x 18 row blocks = 576 tiles per layer launch (>= 2 per workgroup)
+    eng, dm, theta, pdims, pool = make_engine(env, K, (1024, 1024, 1024), (100, 50, 25), seed=89)
+    team = eng.rollout(B, T, H, 'step_rand', pool, seed=3)
+    assert eng.last_rollout_kernel() == 'gemm-streamk'
+    keep = [x.clone() for x in (team.obs, team.rew, team.mean, team.done)]
+    eng.set_option('STREAMK_NO_TEAM', '1')
+    plain = eng.rollout(B, T, H, 'step_rand', pool, seed=3)
+    for a, b in zip(keep, (plain.obs, plain.rew, plain.mean, plain.done)):
+        assert torch.equal(a, b)
+    assert np.isfinite(cpu(team.obs)).all() and float(np.abs(cpu(team.obs[1]) - cpu(team.obs[0])).max()) > 1e-3
