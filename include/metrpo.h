@@ -177,6 +177,16 @@ typedef struct {
     int32_t* d_last_model;
     const int32_t* d_stop;       /* optional device flag: if *d_stop != 0 when the call executes, nothing is computed or
                                     written (see metrpo_sampler_progress)                                                   */
+    /* ---- in-launch stop rule (ABI 4; 0 / NULL = off) ----
+     * stop_batch > 0: the loop condition of obtain_samples (`while n_samples < batch_size`, vectorized_sampler.py:60,104) may be
+     * applied INSIDE the call: a kernel family that runs all T steps in one launch (the persistent stream-K rollout) counts the
+     * samples of completed paths per step itself, starting from *d_stop_cum (the total of the steps in front of this call:
+     * metrpo_sampler_progress's d_state[0]), and stops stepping behind the first step at which the total reaches stop_batch.
+     * Rows beyond that step, d_last_* included, are then UNDEFINED; metrpo_sampler_progress over this call's d_done / d_tpath
+     * still finds the stop step (it scans in step order and stops there).  Kernel families that launch per step ignore both fields
+     * and run all T steps.                                                                                                       */
+    int64_t stop_batch;
+    const double* d_stop_cum;
 } metrpo_rollout_args;
 int32_t metrpo_rollout(metrpo_ctx* ctx, const metrpo_rollout_args* args, void* stream);
 /* Which kernel family the last metrpo_rollout of this context ran on (-1 none yet; 0 thread-per-env, 1 head-per-wave fused, 2 cooperative fused, 3 step-wise

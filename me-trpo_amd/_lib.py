@@ -29,7 +29,9 @@ class RolloutArgs(C.Structure):
                 ('d_done', C.c_void_p), ('d_tpath', C.c_void_p), ('d_last_obs', C.c_void_p),
                 # continuation (ABI 2)
                 ('t0', C.c_int32), ('d_init_obs', C.c_void_p), ('d_init_ts', C.c_void_p), ('d_init_model', C.c_void_p),
-                ('d_last_ts', C.c_void_p), ('d_last_model', C.c_void_p), ('d_stop', C.c_void_p)]
+                ('d_last_ts', C.c_void_p), ('d_last_model', C.c_void_p), ('d_stop', C.c_void_p),
+                # in-launch stop rule (ABI 4)
+                ('stop_batch', C.c_int64), ('d_stop_cum', C.c_void_p)]
 
 
 class Batch(C.Structure):

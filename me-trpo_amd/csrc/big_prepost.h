@@ -23,7 +23,7 @@ struct BigState { float* S; int* ts; int* cur_model; float* X; float* U; float* 
 // agent-scope (sc1) loads, which a line this XCD's L2 still holds from the previous step's read cannot serve.
 template <int ENV, int NS, int NA, bool SC1P = false>
 __device__ __forceinline__ void big_close_step(const ProblemDesc& pd, const RolloutK& r, int t, const float* __restrict__ norm, const BigState& st, float* ST,
-                                               int c, int q, bool active, int b, uint64_t genv) {
+                                               int c, int q, bool active, int b, uint64_t genv, int* len_acc = nullptr) {
     constexpr int NH = (NS + 15) / 16;
     // ---- close step t - 1 (k_big_post) for this wave's 16 envs ----
     const int bc = active ? b : max(r.B - 1, 0);
@@ -141,6 +141,7 @@ __device__ __forceinline__ void big_close_step(const ProblemDesc& pd, const Roll
     dn = dn || (ts >= r.H);
     int cur = st.cur_model[bc];
     if (active && q == 0) { r.rew[tbp] = -cost; r.done[tbp] = dn ? 1 : 0; r.tpath[tbp] = ts - 1; }
+    if (len_acc != nullptr && active && q == 0 && dn) *len_acc += ts;      // samples of the path that just completed (the sampler's n_samples: vectorized_sampler.py:104)
     wave_lds_sync();                                         // every lane has read its env's scalars: the reset rows may overwrite the tile
     if (dn) {                                                // uniform over the env's four lanes
         const size_t rb = (size_t)(tp + 1) * r.B + bc;
@@ -197,7 +198,7 @@ template <int ENV> struct PreLane {
 // closed (big_close_step: the new state lands in ST and S) or (!POST) the state tile loaded from S; obs[t] written.  ST: this wave's [16][NS] LDS tile.
 template <int ENV, bool POST, bool SC1P = false>
 __device__ __forceinline__ void big_pre_head(const ProblemDesc& pd, const RolloutK& r, int t, const float* __restrict__ theta, const float* __restrict__ norm,
-                                             const BigState& st, float* ST, int b0, int lane, PreLane<ENV>& pl) {
+                                             const BigState& st, float* ST, int b0, int lane, PreLane<ENV>& pl, int* len_acc = nullptr) {
     using C = Cfg<ENV, 64, 32>;
     constexpr int NS = C::NS, NA = C::NA, NSQ = PreLane<ENV>::NSQ;
     const int c = lane & 15, q = lane >> 4, b = b0 + c;
@@ -224,7 +225,7 @@ __device__ __forceinline__ void big_pre_head(const ProblemDesc& pd, const Rollou
         }
     }
     if constexpr (POST) {
-        big_close_step<ENV, NS, NA, SC1P>(pd, r, t, norm, st, ST, c, q, active, b, genv);
+        big_close_step<ENV, NS, NA, SC1P>(pd, r, t, norm, st, ST, c, q, active, b, genv, len_acc);
     } else {
         for (int i = lane; i < 16 * NS; i += 64) ST[i] = (i < lim) ? st.S[(size_t)b0 * NS + i] : 0.0f;
     }

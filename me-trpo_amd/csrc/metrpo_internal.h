@@ -144,6 +144,7 @@ struct RolloutK {          // device-side copy of metrpo_rollout_args (plain poi
     // continuation (metrpo_rollout_args ABI 2)
     int t0; const float* init_obs; const int32_t* init_ts; const int32_t* init_model;
     int32_t* last_ts; int32_t* last_model; const int32_t* stop;
+    long long stop_batch; const double* stop_cum;     // in-launch stop rule (metrpo_rollout_args ABI 4): honoured by the persistent stream-K rollout only
     // tile migration of the cooperative kernel (rollout_coop.hip; ctx-owned hand-over slots, NULL elsewhere)
     int32_t* mig_flag; float* mig_obs; int32_t* mig_ts; int32_t* mig_model; int mig_epoch; double* mig_err;
     // merged rounds of the step-wise path (rollout_gemm.hip): vB > 0 -> the B rows of this launch are vR rounds of vB envs, row b = env b % vB of round
@@ -165,6 +166,7 @@ static inline RolloutK make_rollout_k(const metrpo_rollout_args* a) {
     r.done = a->d_done; r.tpath = a->d_tpath; r.last_obs = a->d_last_obs;
     r.t0 = a->t0; r.init_obs = a->d_init_obs; r.init_ts = a->d_init_ts; r.init_model = a->d_init_model;
     r.last_ts = a->d_last_ts; r.last_model = a->d_last_model; r.stop = a->d_stop;
+    r.stop_batch = a->stop_batch; r.stop_cum = a->d_stop_cum;
     r.mig_flag = nullptr; r.mig_obs = nullptr; r.mig_ts = nullptr; r.mig_model = nullptr; r.mig_epoch = 0; r.mig_err = nullptr;
     r.vB = 0; r.vR = 0;
     return r;

@@ -46,6 +46,9 @@ struct SkpArgs {
     int* xflag; unsigned* arrive;                  // [RB] each, zeroed in front of the launch: x of step t is ready when xflag[rb] >= t; arrivals so far
     const int32_t* stop;                           // metrpo_sampler_progress's flag (constant during the launch)
     const SkpPost* post;
+    // in-launch stop rule (metrpo_rollout_args::stop_batch; 0 = off): cnt[T] samples of the paths completed at each step | closed[T] row blocks closed per step |
+    // misc: [0] lock, [1] next step to fold, [2] stop step (SKP_NOHALT until known) | cum: samples folded so far (without *stop_cum0)
+    long long stop_batch; const double* stop_cum0; unsigned long long* cnt; unsigned* closed; unsigned* misc; unsigned long long* cum;
     int nowait;                                    // developer timing (option PERSIST_STATS=2; results INVALID): no tile waits for its row block's flag
     unsigned long long* stats;                     // developer statistics (option PERSIST_STATS; NULL otherwise): per workgroup {100 MHz ticks of the launch, ticks blocked (compute: on a flag,
                                                    // longest wave; closer: on arrival counters), 0, steps closed, ticks spent closing, tiles, ticks in the prologue, 1 = closing role}
@@ -53,19 +56,27 @@ struct SkpArgs {
 
 __global__ void k_skp_post_args(SkpPost v, SkpPost* dst) { if (threadIdx.x == 0) *dst = v; }
 
+enum { SKP_HALT = 0x40000000, SKP_NOHALT = 0x7fffffff };      // ready-flag value "nothing behind the stop step is computed any more" | misc[2] before the stop step is known
 enum { SKP_NCLOSE = 8 };                           // most closing workgroups of a launch (SkpArgs::nclose of them: blockIdx 0 .. nclose - 1, on different XCDs)
 
 // Step t closed and step t + 1 prepared for the 128 envs of row block rb, by all 8 waves of a closing workgroup: the wave functions of the launch-per-step
 // pre-kernel (big_prepost.h).  scratch: [8][16][NS] floats of LDS state tiles; img: the policy image (PreImg<ENV>).
 template <int ENV>
-__device__ __forceinline__ void skp_close_and_prepare(const SkpPost* __restrict__ pp, int t, int rb, const float* img, float* scratch, int* xflag) {
+__device__ __forceinline__ void skp_close_and_prepare(const SkpPost* __restrict__ pp, int t, int rb, const float* img, float* scratch, int* xflag,
+                                                      unsigned long long* cnt_t = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b0 = rb * 128 + wave * 16;
+    int len = 0;
     if (b0 < pp->r.B) {
         PreLane<ENV> pl;
         float* ST = scratch + wave * 16 * Cfg<ENV, 64, 32>::NS;
-        big_pre_head<ENV, true, true>(pp->pd, pp->r, t + 1, pp->theta, pp->norm, pp->st, ST, b0, lane, pl);
+        big_pre_head<ENV, true, true>(pp->pd, pp->r, t + 1, pp->theta, pp->norm, pp->st, ST, b0, lane, pl, cnt_t != nullptr ? &len : nullptr);
         big_pre_tail<ENV, true>(pp->r, t + 1, pp->st, img, ST, b0, lane, pl);
+    }
+    if (cnt_t != nullptr) {                                                            // this wave's completed-path samples of step t (integers: any order of the adds)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) len += __shfl_xor(len, o, 64);
+        if (lane == 0 && len != 0) (void)__hip_atomic_fetch_add(cnt_t, (unsigned long long)len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   // every writing wave drains
     __syncthreads();
@@ -83,30 +94,61 @@ __device__ __forceinline__ void skp_closer_role(const SkpArgs& p, float* lds) {
     using IM = PreImg<ENV>;
     float* const img = lds;
     float* const scratch = lds + IM::IMG;
+    int* const sh = (int*)(scratch + 8 * 16 * Cfg<ENV, 64, 32>::NS);
     const int tid = threadIdx.x;
     for (int k = tid; k < IM::IMG; k += 512) img[k] = IM::entry(p.post->theta, k);
     __syncthreads();
     const int RB = (p.a.M + 127) / 128;
+    const bool stopping = p.stop_batch > 0;
     unsigned long long st_wait = 0, st_work = 0, st_n = 0;
     const unsigned long long st_t0 = wall_clock64();
-    for (int t = 0; t + 1 < p.T; ++t)
+    bool halted = false;
+    for (int t = 0; t + 1 < p.T && !halted; ++t)
         for (int rb = blockIdx.x; rb < RB; rb += p.nclose) {
             const unsigned long long w0 = wall_clock64();
             if (tid == 0) {
                 const unsigned want = (unsigned)(t + 1) * (unsigned)p.NSL;
-                while (__hip_atomic_load(p.arrive + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                int go = 1;
+                if (stopping && t > (int)__hip_atomic_load(p.misc + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) go = 0;
+                while (go && __hip_atomic_load(p.arrive + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                     __builtin_amdgcn_s_sleep(2);
+                    if (stopping && t > (int)__hip_atomic_load(p.misc + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) go = 0;      // the tiles behind the stop step may never arrive
                     if (wall_clock64() - w0 > 200000000ull) { __hip_atomic_store(p.a.err, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }      // 2 s at 100 MHz
                     if (__hip_atomic_load(p.a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) break;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");             // the tiles' partials; (S / U / ts / cur_model are this workgroup's own stores of a step ago)
+                sh[0] = go;
             }
             __syncthreads();
+            if (!sh[0]) { halted = true; break; }
             const unsigned long long w1 = wall_clock64();
-            skp_close_and_prepare<ENV>(p.post, t, rb, img, scratch, p.xflag);
+            skp_close_and_prepare<ENV>(p.post, t, rb, img, scratch, p.xflag, stopping ? p.cnt + t : nullptr);
+            if (stopping && tid == 0) {
+                // Step t is complete once all RB row blocks are closed; complete steps are folded into the running total IN STEP ORDER by whoever completes
+                // one (a short critical section), and the first step at which the total reaches stop_batch becomes the stop step: every step up to it is
+                // closed by then (the sampler's loop condition, tested once per step: vectorized_sampler.py:60,104).
+                if (__hip_atomic_fetch_add(p.closed + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (unsigned)RB) {
+                    while (atomicCAS(p.misc, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
+                    unsigned nx = __hip_atomic_load(p.misc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned long long cum = __hip_atomic_load(p.cum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const double cum0 = *p.stop_cum0, need = (double)p.stop_batch;
+                    while ((int)nx + 1 < p.T && __hip_atomic_load(p.closed + nx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)RB) {
+                        cum += __hip_atomic_load(p.cnt + nx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (cum0 + (double)cum >= need && __hip_atomic_load(p.misc + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)SKP_NOHALT)
+                            __hip_atomic_store(p.misc + 2, nx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ++nx;
+                    }
+                    __hip_atomic_store(p.cum, cum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(p.misc + 1, nx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    __hip_atomic_store(p.misc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
             __syncthreads();                                                    // the state tiles are rewritten by the next row block
             st_wait += w1 - w0; st_work += wall_clock64() - w1; ++st_n;
         }
+    if (halted && tid == 0)                                                     // nothing behind the stop step is closed: release every tile that waits on this closer's row blocks
+        for (int rb = blockIdx.x; rb < RB; rb += p.nclose) __hip_atomic_store(p.xflag + rb, (int)SKP_HALT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (p.stats != nullptr && tid == 0) { unsigned long long* o = p.stats + 8 * (size_t)blockIdx.x; o[0] = wall_clock64() - st_t0; o[1] = st_wait; o[3] = st_n; o[4] = st_work; o[7] = 1; }
 }
 
@@ -120,7 +162,7 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
     constexpr int E = EP::E, UPC = EP::UPC, NI0 = GE::NI0, STAGE = GE::STAGE, NH = WIDE ? 2 : 1;
     static_assert(EP::FLOATS <= STAGE, "EPI image larger than a ring stage");
     static_assert(NI0 <= 8, "layer-0 slice: at most 8 one-KB pieces (one per wave)");
-    static_assert(PreImg<ENV>::IMG + 8 * 16 * Cfg<ENV, 64, 32>::NS <= 4 * STAGE, "the closing role's image and state tiles fit the ring's LDS");
+    static_assert(PreImg<ENV>::IMG + 8 * 16 * Cfg<ENV, 64, 32>::NS + 4 <= 4 * STAGE, "the closing role's image and state tiles fit the ring's LDS");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (p.stop != nullptr && *p.stop != 0) return;                             // the sampling loop already ended
     if ((int)blockIdx.x < p.nclose) { skp_closer_role<ENV>(p, lds); return; }
@@ -192,14 +234,18 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
     // ready flag of a tile's row block: one agent-scope load (every lane the same word), issued a chunk ahead of the wait
     auto probe_flag = [&](const RecL& r) -> int { return __hip_atomic_load(p.xflag + (r.m0 >> 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     unsigned long long st_blocked_w = 0;
+    bool my_halt = false;                                                      // this wave saw the halt value on a ready flag (the stop step is behind us)
+    int* const lds_halt = (int*)(lds + 4 * STAGE);
     auto wait_x = [&](const RecL& r, int seen) {                               // bounded: report, do not hang
-        if (seen >= r.t || p.nowait) return;
+        if (seen >= r.t || p.nowait) { my_halt = my_halt || seen >= (int)SKP_HALT; return; }
         const unsigned long long t0 = wall_clock64();
-        while (__hip_atomic_load(p.xflag + (r.m0 >> 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < r.t) {
+        int fv;
+        while ((fv = __hip_atomic_load(p.xflag + (r.m0 >> 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < r.t) {
             __builtin_amdgcn_s_sleep(2);
             if (wall_clock64() - t0 > 200000000ull) { if (lane == 0) __hip_atomic_store(a.err, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }      // 2 s at 100 MHz
             if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) break;      // somebody gave up: the launch's results are invalid, leave quickly
         }
+        my_halt = my_halt || fv >= (int)SKP_HALT;
         st_blocked_w += wall_clock64() - t0;
     };
     auto load_x = [&](const RecL& r) {                                         // agent-scope loads: the rows were written by another workgroup of this launch
@@ -247,6 +293,7 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
         r0 = decL(l0, t0_); r1 = decL(l1, t1_); r3 = decI(i3);
         issue(decI(i0), 0); issue(decI(i1), 1); issue(decI(i2), 2);
     }
+    if (tid == 0) *lds_halt = 0;
     wait_x(r0, -1);
     load_x(r0);
     drain_vm();
@@ -255,6 +302,7 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
     const unsigned long long st_pro = wall_clock64() - st_t0;
 
     int seen = 0;                                                              // flag value probed for the next tile
+    bool halted = false;                                                       // the stop step is behind this workgroup's next tile: leave
     __amdgpu_buffer_rsrc_t part_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.part, 0, 0xFFFFFFFFu, 0x00020000);
     auto body = [&](auto par_, const int q) {
         constexpr int H = decltype(par_)::value % NH;                          // which of the tile's column blocks this entry belongs to (entries alternate)
@@ -267,6 +315,7 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
         // blocks behind the arrival, at the end of this chunk.
         const bool boundary = nmain && (r1.fl & SKF_NEWTILE);
         const bool have_x = !boundary || seen >= r1.t || p.nowait;
+        if (boundary && seen >= (int)SKP_HALT) my_halt = true;
         if (boundary && have_x) load_x(r1);
         RecI r4; RecL rn;
         const SkRec* const fa = rec_of(cA); const SkRec* const fb = rec_of(cB); const int fat = cA.t;
@@ -349,16 +398,18 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
             }
         }
         drain_vm();                                                            // copies of entry q + 3, the rows, the output partials (and the probe)
+        if (my_halt && tid == 0) *lds_halt = 1;                                // (wave 0's view decides for the workgroup: the loop must end for all waves at the same entry)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (p.stop_batch > 0 && (r0.fl & SKF_NEWTILE) && __builtin_amdgcn_readfirstlane(*(volatile int*)lds_halt)) { halted = true; return; }      // uniform: r0 and the LDS word are the same for every wave
         // every wave's partials are complete behind the barrier: the tile arrives (fire and forget; the last step is closed by the host's k_big_post)
         if ((r0.fl & SKF_ARRIVE) && r0.t + 1 < T && tid == 0) (void)__hip_atomic_fetch_add(p.arrive + (r0.m0 >> 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!have_x) { wait_x(r1, -1); load_x(r1); }                            // (a compute workgroup that has arrived for all it finished owes nobody anything: it may block)
         r0 = r1; r1 = rn; r3 = r4;
     };
-    for (int q = 0; q < nq; q += 2) {
+    for (int q = 0; q < nq && !halted; q += 2) {
         body(std::integral_constant<int, 0>{}, q);
-        if (q + 1 < nq) body(std::integral_constant<int, 1>{}, q + 1);
+        if (q + 1 < nq && !halted) body(std::integral_constant<int, 1>{}, q + 1);
     }
     if (p.stats != nullptr && lane == 0) {
         unsigned long long* o = p.stats + 8 * (size_t)blockIdx.x;

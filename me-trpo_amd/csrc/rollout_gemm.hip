@@ -525,7 +525,7 @@ struct SkpVt {
 template <int ENV, int S0, int OT, bool WIDE> static SkpVt skp_vt() {
     SkpVt v;
     v.kern = (const void*)k_sk_persist<ENV, S0, OT, WIDE>; v.wide = WIDE;
-    v.lds = sizeof(float) * (size_t)(4 * SkGeom<SK_A_PRODUCER, SK_EPI_OUT, S0, OT>::STAGE);
+    v.lds = sizeof(float) * (size_t)(4 * SkGeom<SK_A_PRODUCER, SK_EPI_OUT, S0, OT>::STAGE + 4);      // the ring + the workgroup's halt word
     v.launch = [](const SkpArgs& p, int grid, size_t lds, hipStream_t st) { hipLaunchKernelGGL((k_sk_persist<ENV, S0, OT, WIDE>), dim3(grid), dim3(512), lds, st, p); };
     v.tab = [](const SkArgs& a, bool wide, std::vector<SkRec>& t, int (&Jx)[8], int& Jmax, int& L, int& NSL) { skp_build_tab<OT>(a, wide, t, Jx, Jmax, L, NSL); };
     return v;
@@ -651,7 +651,9 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
         skp_nclose = std::max(2, std::min((int)SKP_NCLOSE, (int)std::ceil(RBp * 17.0 / (0.6 * step_us))));
     }
     const size_t nSkpFlag = persist ? up4(2 * (size_t)((B + 127) / 128)) : 0, nSkpPost = persist ? up4((sizeof(SkpPost) + 3) / 4) : 0;
-    const size_t need = ((nS + nX + nU + 2 * nH + nO + nP + 2 * nPol + nPimg + nSkImg + nSkSched + nSkX + nSkFlag + nSkpFlag + nSkpPost) * sizeof(float) + 2 * (size_t)B * sizeof(int) + 1023) & ~(size_t)255;
+    const bool skp_stop = persist && a->stop_batch > 0 && a->d_stop_cum != nullptr;
+    const size_t nSkpStop = skp_stop ? up4(3 * (size_t)a->T + 8) : 0;       // floats: cnt[T] u64 | closed[T] u32 | misc[4] u32 | cum u64
+    const size_t need = ((nS + nX + nU + 2 * nH + nO + nP + 2 * nPol + nPimg + nSkImg + nSkSched + nSkX + nSkFlag + nSkpFlag + nSkpPost + nSkpStop) * sizeof(float) + 2 * (size_t)B * sizeof(int) + 1023) & ~(size_t)255;
     if (need_out) *need_out = need;
     if (ws == nullptr) return METRPO_OK;
     BigState bs = {};
@@ -663,6 +665,7 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
     unsigned* sk_flag = (unsigned*)p; p += nSkFlag;
     int* skp_flags = (int*)p; p += nSkpFlag;
     SkpPost* skp_post = (SkpPost*)p; p += nSkpPost;
+    float* skp_stopmem = p; p += nSkpStop;
     bs.ts = (int*)p; bs.cur_model = bs.ts + B;
     bs.out_ld = pd.ns; bs.xone = (sk.mode == 1 || l0r) ? 1 : 0;
     if (sk.mode) c->last_rollout_kernel = 5;
@@ -722,6 +725,13 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
             HIP_TRY(c, hipMemsetAsync(c->d_skp_stats, 0, sizeof(unsigned long long) * 8 * skp_grid, st));
             pa.stats = c->d_skp_stats;
             pa.nowait = ctx_opt(c, OPT_PERSIST_STATS)[0] == '2' ? 1 : 0;
+        }
+        if (skp_stop) {                                          // the sampler's stop rule inside the launch (mlp_persist.h)
+            HIP_TRY(c, hipMemsetAsync(skp_stopmem, 0, nSkpStop * sizeof(float), st));
+            pa.cnt = (unsigned long long*)skp_stopmem; pa.closed = (unsigned*)(pa.cnt + a->T); pa.misc = pa.closed + a->T + (a->T & 1);      // (misc 8-byte aligned: cum follows it)
+            pa.cum = (unsigned long long*)(pa.misc + 4);
+            HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)(pa.misc + 2), (int)SKP_NOHALT, 1, st));
+            pa.stop_batch = a->stop_batch; pa.stop_cum0 = a->d_stop_cum;
         }
         SkpPost po; po.pd = pd; po.r = r; po.st = bs; po.theta = c->d_theta; po.norm = c->d_norm;
         hipLaunchKernelGGL(k_skp_post_args, dim3(1), dim3(64), 0, st, po, skp_post);

@@ -274,14 +274,16 @@ class Engine(object):
     # ------------------------------------------------------------------ fused rollout
     def rollout(self, B, T, H, sam_mode, pool, determ=False, eval_all_heads=True, seed=0, stream_offset=0,
                 eps=None, model_idx=None, sel_noise=None, reset_idx=None, reset_model=None, out=None,
-                force_generic=False, t0=0, resume=None, last_state=None, stop=None):
+                force_generic=False, t0=0, resume=None, last_state=None, stop=None, stop_batch=0, stop_cum=None):
         """`resume` = (obs [B,ns] f32, ts [B] i32, model [B] i32) continues a chunked rollout at global step `t0` (the supplied
         draw tensors are then indexed from this chunk's first step); `last_state` = (ts, model) int32 output tensors;
-        `stop` = int32 device flag that turns the call into a no-op when set (metrpo_sampler_progress)."""
+        `stop` = int32 device flag that turns the call into a no-op when set (metrpo_sampler_progress); `stop_batch` > 0 with `stop_cum` (float64 device
+        scalar: samples completed in front of this call) lets a one-launch kernel family apply the sampler's stop rule inside the call (rows behind the stop
+        step are then undefined)."""
         dev = self.device
         # launch fast path (the bench / training loop): same buffers, same modes, production draws -> only the seed changes in the cached struct
         no_draws = eps is None and model_idx is None and sel_noise is None and reset_idx is None and reset_model is None
-        chunked = resume is not None or last_state is not None or stop is not None or t0 != 0
+        chunked = resume is not None or last_state is not None or stop is not None or t0 != 0 or stop_batch
         if no_draws and not chunked and out is not None and not force_generic and isinstance(pool, torch.Tensor):
             key = (id(out), pool.data_ptr(), B, T, H, sam_mode, bool(determ), bool(eval_all_heads), int(stream_offset))
             cached = getattr(self, '_ra_cache', None)
@@ -317,9 +319,12 @@ class Engine(object):
         if stop is not None:
             assert stop.dtype == torch.int32
             a.d_stop = stop.data_ptr()
+        if stop_batch:
+            assert stop_cum is not None and stop_cum.dtype == torch.float64 and stop_cum.is_cuda
+            a.stop_batch, a.d_stop_cum = int(stop_batch), stop_cum.data_ptr()
         fn = lib.metrpo_rollout_generic if force_generic else lib.metrpo_rollout
         self._chk(fn(self._ctx, C.byref(a), self._stream()))
-        self._keep = (pool, eps, model_idx, sel_noise, reset_idx, reset_model, resume, last_state, stop)   # alive until the stream has consumed them
+        self._keep = (pool, eps, model_idx, sel_noise, reset_idx, reset_model, resume, last_state, stop, stop_cum)   # alive until the stream has consumed them
         if no_draws and not chunked and not force_generic:
             self._ra_cache = ((id(out), pool.data_ptr(), B, T, H, sam_mode, bool(determ), bool(eval_all_heads), int(stream_offset)), a, out, pool)
         return out

@@ -186,7 +186,7 @@ class VectorizedSampler(BaseSampler):
         if getattr(self, '_ant_key', None) != key or not getattr(algo, 'reuse_trajectory_buffers', False):
             self._ant_buf, self._ant_key = eng.alloc_trajectory(B, T_max, H), key
             self._ant_state = (torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev))
-            self._ant_counts = torch.empty(max(T_first, chunk), dtype=torch.float64, device=dev)
+            self._ant_counts = torch.empty(max(T_first, chunk, T_max - T_first), dtype=torch.float64, device=dev)
         buf, (last_ts, last_model) = self._ant_buf, self._ant_state
         state = torch.tensor([0.0, -1.0], dtype=torch.float64, device=dev)
         stop = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -205,16 +205,20 @@ class VectorizedSampler(BaseSampler):
             return d
 
         t = 0
+        one_launch = False                                         # the kernel family of the first chunk runs all steps of a call in one launch
         while t < T_max:
-            t_hi = min(T_max, t + (T_first if t == 0 else chunk))
+            t_hi = min(T_max, t + (T_first if t == 0 else (T_max - t if one_launch else chunk)))
             out = view(t, t_hi)
+            # one-launch families apply the stop rule INSIDE the call (metrpo_rollout_args::stop_batch): everything behind the first T_first steps is one
+            # call that stops stepping at the stop step -- no chunk granularity, no dead steps
+            extra = dict(stop_batch=batch, stop_cum=state[0:1]) if one_launch else {}
             eng.rollout(B, t_hi - t, H, sam_mode, pool, out=out, t0=t, last_state=(last_ts, last_model), stop=stop,
-                        resume=None if t == 0 else (buf.last_obs, last_ts, last_model), **common, **chunk_draws(t, t_hi))
+                        resume=None if t == 0 else (buf.last_obs, last_ts, last_model), **extra, **common, **chunk_draws(t, t_hi))
             eng.sampler_progress(out.done, out.tpath, t, batch, self._ant_counts, state, stop)
             t = t_hi
             if poll and t < T_max:
                 if eng.last_rollout_kernel() == 'streamk-persistent':
-                    poll = False                                   # a chunk behind the stop flag is four empty launches there: enqueue ahead, never wait for the GPU
+                    poll, one_launch = False, True                 # (nothing to wait for: the rest is one call)
                 elif int(stop.item()):
                     break
         t_stop = int(state[1].item())

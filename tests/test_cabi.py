@@ -32,7 +32,7 @@ def test_struct_layouts_match_header():
     from metrpo_amd import _lib
     # sizes implied by the C declarations (LP64): see include/metrpo.h
     assert C.sizeof(_lib.Dims) == 4 * (4 + 1 + 6 + 6 + 1 + 1 + 6)
-    assert C.sizeof(_lib.RolloutArgs) == 6 * 4 + 8 + 4 + 4 + 8 + 8 + 5 * 8 + 7 * 8 + (4 + 4 + 6 * 8)
+    assert C.sizeof(_lib.RolloutArgs) == 6 * 4 + 8 + 4 + 4 + 8 + 8 + 5 * 8 + 7 * 8 + (4 + 4 + 6 * 8) + (8 + 8)
     assert C.sizeof(_lib.Batch) == 5 * 8 + 4 + 4 + 8 + 8 + 8
     assert C.sizeof(_lib.TrpoParams) == 8 + 4 + 4 + 8 + 8 + 4 + 4 + 8 + 8 + 8 + 4 + 4
     assert C.sizeof(_lib.TrpoDiag) == 4 * 8 + 3 * 4 + 4

@@ -138,3 +138,30 @@ def test_persistent_is_not_selected_on_a_shared_gpu_or_for_one_step():
     eng.set_exclusive(False)                                     # other tenants: no kernel that waits on workgroups of its own launch
     eng.rollout(B, 3, H, 'step_rand', pool, seed=1)
     assert eng.last_rollout_kernel() == 'gemm-streamk'
+
+
+def test_stop_rule_inside_the_launch_gives_the_chunked_samplers_paths():
+    """Early-terminating env through VectorizedSampler.obtain_samples: on the persistent path everything behind the first ceil(batch / B) steps is ONE call
+    that applies `while n_samples < batch_size` (vectorized_sampler.py:60,104) inside the launch (metrpo_rollout_args::stop_batch) and stops stepping at the
+    stop step; the launch-per-step path runs chunks and a flag.  Same stop step, same trajectory prefix bit for bit, same list of paths."""
+    from test_gpu_api import build_algo
+    B, H, batch = 300, 12, 2100
+    outs = []
+    for persist in (True, False):
+        algo, eng, dm, theta, pdims, pool = build_algo('ant', K=4, B=B, H=H, batch=batch, dyn_hidden=(256, 256))
+        pool[::3, 2] = 0.21
+        algo.env.env.states[::3, 2] = 0.21; algo.env.env._dev = None
+        eng.set_option('STREAMK', '1'); eng.set_option('STREAMK_LATE', '0'); eng.set_rollout_variant(1)
+        if not persist:
+            eng.set_option('NO_PERSIST', '1')
+        algo.start_worker()
+        paths = algo.obtain_samples(3)
+        assert eng.last_rollout_kernel() == ('streamk-persistent' if persist else 'gemm-streamk')
+        tr = paths.traj
+        outs.append({k: getattr(tr, k).clone() for k in ('obs', 'act', 'mean', 'rew', 'done', 'tpath')})
+        done, tp = cpu(tr.done), cpu(tr.tpath)
+        per_step = (done * (tp + 1)).sum(axis=1).cumsum()
+        assert per_step[-1] >= batch and per_step[-2] < batch        # the LAST step is the first at which completed samples >= batch
+        assert tr.T > -(-batch // B)                                 # the stop step lies behind the first call
+    for k in outs[0]:
+        assert outs[0][k].shape == outs[1][k].shape and torch.equal(outs[0][k], outs[1][k]), k
