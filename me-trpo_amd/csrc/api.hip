@@ -333,6 +333,7 @@ extern "C" int32_t metrpo_rollout(metrpo_ctx* c, const metrpo_rollout_args* a, v
     if (!a->d_pool || !a->d_obs || !a->d_act || !a->d_rew || !a->d_mean || !a->d_done || !a->d_tpath)
         return set_err(c, METRPO_ENULL, "rollout: required pointer is NULL");
     if (a->t0 < 0) return set_err(c, METRPO_EINVAL, "rollout: t0 < 0");
+    if (a->stop_batch < 0 || (a->stop_batch > 0 && a->d_stop_cum == nullptr)) return set_err(c, METRPO_EINVAL, "rollout: stop_batch needs d_stop_cum (and must not be negative)");
     if ((a->d_init_obs != nullptr) != (a->d_init_ts != nullptr) || (a->d_init_obs != nullptr) != (a->d_init_model != nullptr))
         return set_err(c, METRPO_EINVAL, "rollout: d_init_obs, d_init_ts and d_init_model must be given together");
     if (a->B == 0 || a->T == 0) return METRPO_OK;

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <string>
 #include <atomic>
+#include <vector>
 #include "metrpo.h"
 #include "xchg_device.h"
 
@@ -103,6 +104,7 @@ struct metrpo_ctx {
     size_t big_cap;
     void* d_res; size_t res_cap; unsigned int res_seq;   // rollout_resident.hip: uncached exchange region (abort cell | X packets | P packets) and the step stamps issued so far
     unsigned long long* d_skp_stats; int skp_stats_n;   // option PERSIST_STATS: per-workgroup statistics of the last persistent launch (metrpo_debug_persist_stats)
+    std::vector<int> skp_tab_host;                    // host copy of the table below, as raw 32-bit words (source of its asynchronous upload; SkRec: mlp_streamk.h)
     void* d_skp_tab; size_t skp_tab_cap; long long skp_key[8]; int skp_Jx[8], skp_Jmax, skp_L, skp_NSL; int persist_failed;   // mlp_persist.h: cached chunk-record table of the persistent stream-K rollout (key: the launch's shape) | a persistent launch timed out
     int res_failed;                                       // a resident launch gave up (its grid was not co-resident): this context stays on the step-wise path from then on
     int last_rollout_kernel;

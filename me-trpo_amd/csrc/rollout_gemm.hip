@@ -556,17 +556,19 @@ static int skp_table(metrpo_ctx* c, const SkpVt& v, const SkArgs& a, SkpArgs* p,
     bool same = c->d_skp_tab != nullptr;
     for (int i = 0; i < 8; ++i) same = same && c->skp_key[i] == key[i];
     if (!same) {
+        // first use of a shape only.  The records live in the context (the copy below is ordered on the caller's stream behind the launches that still read the old
+        // table; a pageable source is staged before the call returns, and the vector outlives it anyway); no synchronisation of the stream
         std::vector<SkRec> tab;
         v.tab(a, v.wide, tab, c->skp_Jx, c->skp_Jmax, c->skp_L, c->skp_NSL);
         const size_t bytes = tab.size() * sizeof(SkRec);
+        c->skp_tab_host.assign((const int*)tab.data(), (const int*)tab.data() + bytes / sizeof(int));
         if (bytes > c->skp_tab_cap) {
-            if (c->d_skp_tab) HIP_TRY(c, hipFree(c->d_skp_tab));
+            if (c->d_skp_tab) HIP_TRY(c, hipFree(c->d_skp_tab));          // (hipFree waits for the device: nothing reads the old table any more)
             c->d_skp_tab = nullptr; c->skp_tab_cap = 0;
             HIP_TRY(c, hipMalloc(&c->d_skp_tab, bytes));
             c->skp_tab_cap = bytes;
         }
-        HIP_TRY(c, hipStreamSynchronize(st));                 // an earlier launch may still read the old table (first use of a shape only)
-        HIP_TRY(c, hipMemcpy(c->d_skp_tab, tab.data(), bytes, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpyAsync(c->d_skp_tab, c->skp_tab_host.data(), bytes, hipMemcpyHostToDevice, st));
         for (int i = 0; i < 8; ++i) c->skp_key[i] = key[i];
     }
     p->tab = (const SkRec*)c->d_skp_tab;
