@@ -399,7 +399,7 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
         }
         drain_vm();                                                            // copies of entry q + 3, the rows, the output partials (and the probe)
         if (my_halt && tid == 0) *lds_halt = 1;                                // (wave 0's view decides for the workgroup: the loop must end for all waves at the same entry)
-        __builtin_amdgcn_s_barrier();
+        if (!(p.nowait & 2)) __builtin_amdgcn_s_barrier();                     // (nowait & 2: developer timing without the chunk barrier -- results invalid)
         asm volatile("" ::: "memory");
         if (p.stop_batch > 0 && (r0.fl & SKF_NEWTILE) && __builtin_amdgcn_readfirstlane(*(volatile int*)lds_halt)) { halted = true; return; }      // uniform: r0 and the LDS word are the same for every wave
         // every wave's partials are complete behind the barrier: the tile arrives (fire and forget; the last step is closed by the host's k_big_post)

@@ -726,7 +726,7 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
             c->skp_stats_n = skp_grid;
             HIP_TRY(c, hipMemsetAsync(c->d_skp_stats, 0, sizeof(unsigned long long) * 8 * skp_grid, st));
             pa.stats = c->d_skp_stats;
-            pa.nowait = ctx_opt(c, OPT_PERSIST_STATS)[0] == '2' ? 1 : 0;
+            pa.nowait = ctx_opt(c, OPT_PERSIST_STATS)[0] == '2' ? 1 : ctx_opt(c, OPT_PERSIST_STATS)[0] == '3' ? 3 : 0;      // 2: no flag waits; 3: no flag waits and no chunk barrier (timing only)
         }
         if (skp_stop) {                                          // the sampler's stop rule inside the launch (mlp_persist.h)
             HIP_TRY(c, hipMemsetAsync(skp_stopmem, 0, nSkpStop * sizeof(float), st));
