@@ -185,7 +185,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
         c->opt_set[i] = (e != nullptr); c->opt_val[i] = e ? e : "";
     }
     opt_apply(c, -1);
-    c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gae_part = nullptr; c->gae_part_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0; c->d_res = nullptr; c->res_cap = 0; c->res_seq = 0; c->res_failed = 0; c->last_rollout_kernel = -1; c->upd_pending = 0; c->upd_spec = 0; c->upd_changed_in_end = 0; c->h_upd = nullptr; c->upd_stamp = 0; c->side_ready = 0; c->d_ticket = nullptr; c->d_hcache = nullptr; c->hcache_cap = 0; c->hcache_on = 0; c->d_mig = nullptr; c->mig_cap = 0; c->mig_epoch = 0; c->nccl_comm = nullptr; c->comm_world = 0; c->comm_rank = 0; c->pol_path = 1; c->d_pg = nullptr; c->pg_cap = 0; c->pg_fwd_rows = -1; c->pg_fwd_obs = nullptr; c->d_adam = nullptr; c->adam_t = 0; c->d_train = nullptr; c->train_cap = 0; c->d_train_part = nullptr; c->train_part_cap = 0;
+    c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gae_part = nullptr; c->gae_part_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0; c->d_res = nullptr; c->res_cap = 0; c->res_seq = 0; c->res_failed = 0; c->last_rollout_kernel = -1; c->upd_pending = 0; c->upd_spec = 0; c->upd_changed_in_end = 0; c->h_upd = nullptr; c->upd_stamp = 0; c->side_ready = 0; c->d_ticket = nullptr; c->d_hcache = nullptr; c->hcache_cap = 0; c->hcache_on = 0; c->d_mig = nullptr; c->mig_cap = 0; c->mig_epoch = 0; c->nccl_comm = nullptr; c->comm_world = 0; c->comm_rank = 0; c->pol_path = 1; c->d_pg = nullptr; c->pg_cap = 0; c->pg_fwd_rows = -1; c->pg_fwd_obs = nullptr; c->pol_f3 = 0; c->d_f3 = nullptr; c->f3_cap = 0; c->f3_rows = -1; c->f3_obs = nullptr; c->f3_theta = nullptr; c->d_adam = nullptr; c->adam_t = 0; c->d_train = nullptr; c->train_cap = 0; c->d_train_part = nullptr; c->train_part_cap = 0;
     ProblemDesc& pd = c->pd;
     pd.env = d->env; pd.ns = d->ns; pd.na = d->na; pd.K = d->n_models; pd.n_drop = d->n_drop;
     pd.nin = d->ns + d->na - d->n_drop;
@@ -217,6 +217,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     if (hipMemset(c->d_ticket, 0, sizeof(unsigned int)) != hipSuccess) { c->err = "hipMemset failed"; return METRPO_EHIP; }   // the reductions' arrival counter resets itself
     c->mfma_cfg = mfma_select_config(c);
     c->pol_mfma = policy_mfma_select(pd);
+    c->pol_f3 = policy_f3_select(pd);
     c->coop_cfg = coop_select_config(c);
     c->det_cfg = det_mfma_select(c);
     c->det_gemm = det_gemm_applicable(c) ? 1 : 0;
@@ -231,7 +232,7 @@ extern "C" int32_t metrpo_destroy(metrpo_ctx* c) {
     (void)metrpo_comm_ipc_detach(c);
     if (c->xg_region) (void)hipFree(c->xg_region);
     void* bufs[] = {c->d_dyn, c->d_norm, c->d_theta, c->d_vf, c->d_theta_try, c->d_cg, c->d_valbuf, c->d_partials,
-                    c->d_dyn_img, c->d_pol_img, c->d_pol_imgval, c->d_pol_vpos, c->d_vbuf, c->d_gae_part, c->d_train_part, c->d_gram_part, c->d_big, c->d_res, c->d_ticket, c->d_hcache, c->d_mig, c->d_pg, c->d_adam, c->d_train, c->d_bptt, c->d_pol_adam, c->d_detpart, c->d_dg};
+                    c->d_dyn_img, c->d_pol_img, c->d_pol_imgval, c->d_pol_vpos, c->d_vbuf, c->d_gae_part, c->d_train_part, c->d_gram_part, c->d_big, c->d_res, c->d_ticket, c->d_hcache, c->d_mig, c->d_pg, c->d_f3, c->d_adam, c->d_train, c->d_bptt, c->d_pol_adam, c->d_detpart, c->d_dg};
     for (void* p : bufs) if (p) (void)hipFree(p);
     if (c->side_ready) {
         for (int i = 0; i < METRPO_MAX_PAR_ROUNDS - 1; ++i) { (void)hipStreamDestroy(c->side_stream[i]); (void)hipEventDestroy(c->ev_join[i]); }
@@ -400,7 +401,7 @@ extern "C" int32_t metrpo_set_rollout_variant(metrpo_ctx* c, int32_t v) {
 // which policy-update kernels a batch of N samples would run on: 1 fused MFMA (policy_mfma.hip), 2 GEMM path (policy_gemm.hip), 0 generic
 extern "C" int32_t metrpo_update_path(const metrpo_ctx* c, int64_t N) {
     if (!c) return METRPO_ENULL;
-    return policy_gemm_applicable(c, N) ? 2 : (c->pol_mfma >= 0 ? 1 : 0);
+    return policy_gemm_applicable(c, N) ? 2 : ((c->pol_mfma >= 0 || f3_active(c)) ? 1 : 0);
 }
 // test hook: 0 forces the generic (VALU) update kernels, 1 restores the MFMA ones when available
 extern "C" int32_t metrpo_set_update_path(metrpo_ctx* c, int32_t use_mfma) {
@@ -408,8 +409,9 @@ extern "C" int32_t metrpo_set_update_path(metrpo_ctx* c, int32_t use_mfma) {
     // 0: generic (VALU) kernels, 1: fastest path of the shape (fused MFMA kernels, else the GEMM path for large N), 2: GEMM path forced
     c->pol_path = (use_mfma == 2) ? 2 : (use_mfma ? 1 : 0);
     c->pol_mfma = (use_mfma == 1) ? policy_mfma_select(c->pd) : -1;
-    c->pg_fwd_rows = -1;
-    return c->pol_mfma >= 0 ? 1 : (c->pol_path == 2 ? 2 : 0);
+    c->pol_f3 = (use_mfma == 1) ? policy_f3_select(c->pd) : 0;
+    c->pg_fwd_rows = -1; c->f3_rows = -1;
+    return (c->pol_mfma >= 0 || f3_active(c)) ? 1 : (c->pol_path == 2 ? 2 : 0);
 }
 
 extern "C" int32_t metrpo_validation_cost(metrpo_ctx* c, const float* s0, int32_t Bv, int32_t T, double gamma,

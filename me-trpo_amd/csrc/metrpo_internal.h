@@ -36,7 +36,7 @@ struct ProblemDesc {
 // ---- variant / tuning switches of a context (metrpo_set_option / metrpo_get_option, include/metrpo.h) ----------------------------------------------
 // One table per context, read by the launch paths through ctx_opt(); metrpo_create fills the defaults ONCE from the environment (METRPO_<KEY>), nothing
 // else in the library reads the environment for kernel selection.  A key is the upper-case name below (the ABI also takes lower case and a METRPO_ prefix).
-#define METRPO_OPT_LIST(X) X(COOP_MODE) X(EXTRA_LDS) X(GEMM_PREFETCH) X(NO_DEVICE_LINESEARCH) X(NO_FUSED_OUT) X(NO_IMGVAL) X(NO_L0_ROWS) X(NO_MERGED_ROUNDS) X(NO_PRE_MFMA3) X(NO_RESIDENT) X(NO_RESIDENT_VALIDATION) X(NO_STEP_MERGE) X(NO_STREAMK) X(PG_HEAD_ROWS) X(PRE_GEMM) X(RESIDENT_NO_ROTATE) X(RESIDENT_NO_SENTINEL) X(RESIDENT_TEST_SKIP) X(RESIDENT_WS) X(RES_UNCACHED) X(SEQ_ROUNDS) X(SOLVE_BLOCK) X(STEP_MERGE) X(STREAMK) X(STREAMK_LATE) X(STREAMK_NO_XCD) X(UPD_TILES_PER_WAVE) X(VAL_CHUNKS) X(VAL_TILES_PER_WAVE) X(XCHG_TIMEOUT_MS) X(NO_PERSIST) X(PERSIST) X(QUIET) X(TIME_FVP) X(PERSIST_STATS) X(PERSIST_NARROW) X(PERSIST_WIDE) X(PERSIST_NCLOSE) X(STREAMK_NO_TEAM)
+#define METRPO_OPT_LIST(X) X(COOP_MODE) X(EXTRA_LDS) X(GEMM_PREFETCH) X(NO_DEVICE_LINESEARCH) X(NO_FUSED_OUT) X(NO_IMGVAL) X(NO_L0_ROWS) X(NO_MERGED_ROUNDS) X(NO_PRE_MFMA3) X(NO_RESIDENT) X(NO_RESIDENT_VALIDATION) X(NO_STEP_MERGE) X(NO_STREAMK) X(PG_HEAD_ROWS) X(PRE_GEMM) X(RESIDENT_NO_ROTATE) X(RESIDENT_NO_SENTINEL) X(RESIDENT_TEST_SKIP) X(RESIDENT_WS) X(RES_UNCACHED) X(SEQ_ROUNDS) X(SOLVE_BLOCK) X(STEP_MERGE) X(STREAMK) X(STREAMK_LATE) X(STREAMK_NO_XCD) X(UPD_TILES_PER_WAVE) X(VAL_CHUNKS) X(VAL_TILES_PER_WAVE) X(XCHG_TIMEOUT_MS) X(NO_PERSIST) X(PERSIST) X(QUIET) X(TIME_FVP) X(PERSIST_STATS) X(PERSIST_NARROW) X(PERSIST_WIDE) X(PERSIST_NCLOSE) X(STREAMK_NO_TEAM) X(NO_POL_FUSED3)
 enum MetrpoOpt {
 #define X(n) OPT_##n,
     METRPO_OPT_LIST(X)
@@ -95,6 +95,8 @@ struct metrpo_ctx {
     void* xg_region; void* xg_peer[XCHG_MAX_WORLD]; int xg_world, xg_rank, xg_cap, xg_fuse; unsigned int xg_seq; unsigned long long xg_timeout;
     int pol_path;        // 1 auto (fused MFMA kernels where the shape has them, GEMM path for large N otherwise), 0 generic forced, 2 GEMM path forced
     void* d_pg; size_t pg_cap; long long pg_fwd_rows; const float* pg_fwd_obs;   // policy_gemm.hip workspace + validity of its cached forward pass
+    int pol_f3;          // 1: fused MFMA update kernels for three-hidden-layer policies (policy_fused3.hip) serve this shape
+    void* d_f3; size_t f3_cap; long long f3_rows; const float* f3_obs; const float* f3_theta;   // policy_fused3.hip: activation cache + mean-adjoint of one (theta, batch) and its validity
     void* d_adam;        // Adam moments [2][K][Pd] + loss accumulators (dyn_train.hip)
     long long adam_t;    // Adam step count
     void* d_train;       // training activation workspace
@@ -130,6 +132,8 @@ struct metrpo_ctx {
 // value of a switch, NULL when unset -- the same contract as the getenv() calls these replaced
 static inline const char* ctx_opt(const metrpo_ctx* c, int id) { return c->opt_set[id] ? c->opt_val[id].c_str() : nullptr; }
 inline std::atomic<int> g_gemm_prefetch_off{0};     // option GEMM_PREFETCH (process-wide: gemm_mfma.h's dispatch has no context)
+// the three-hidden-layer fused update kernels (policy_fused3.hip) serve this context's next update launch (not the VJP mode of the gradient kernels: GEMM path)
+static inline bool f3_active(const metrpo_ctx* c) { return c->pol_f3 != 0 && c->pol_path == 1 && c->vjp_gm == nullptr && ctx_opt(c, OPT_NO_POL_FUSED3) == nullptr; }
 const char* metrpo_opt_name(int id);
 int metrpo_opt_id(const char* key);       // -1: unknown
 
@@ -264,6 +268,8 @@ static inline int rollout_error_seen(metrpo_ctx* c, hipStream_t st) {
                                                 : "rollout: a migrating tile's hand-over timed out (producer workgroup never ran); trajectories are invalid");
 }
 bool policy_gemm_applicable(const metrpo_ctx*, long long N);
+int policy_f3_select(const ProblemDesc& pd);      // policy_fused3.hip: 1 when the three-hidden-layer kernels cover this policy shape
+int policy_f3_launch(metrpo_ctx*, int mode, const metrpo_batch*, const float* theta, const float* vf, float* partials, int nblocks, hipStream_t);
 int policy_gemm_run(metrpo_ctx*, int mode, const metrpo_batch*, const PolK&, const float* theta, const float* vf, const double* v64, double* out,
                     const CgTail* tail, hipStream_t);
 int launch_fvp(metrpo_ctx*, const metrpo_batch*, const double*, double*, hipStream_t);

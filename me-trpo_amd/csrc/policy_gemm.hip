@@ -244,6 +244,7 @@ __global__ void k_pg_tail(CgTail t) {
 bool policy_gemm_applicable(const metrpo_ctx* c, long long N) {
     if (c->pol_path == 2) return true;                       // forced (test hook)
     if (c->pol_path == 0) return false;                      // generic forced
+    if (f3_active(c)) return false;                          // fused three-hidden-layer kernels (policy_fused3.hip)
     // no fused kernel for this shape, and either enough rows to fill GEMM tiles or a policy large enough that the generic kernels' per-launch cost
     // (thread-per-parameter phases: 1.2 ms per launch for Humanoid's 12 275 weights, whatever N) exceeds the whole GEMM-path update (1.4 ms at N = 64)
     return c->pol_mfma < 0 && (N >= 8192 || c->pd.pol.n_params >= 4096);

@@ -450,6 +450,19 @@ static int run_mode(metrpo_ctx* c, int mode, const metrpo_batch* b, const PolK& 
         c->ls_skip = nullptr;
         return rc;
     }
+    if (f3_active(c)) {
+        // policy_fused3.hip: one block per CU; the back-prop kernel runs 4 waves per block (one per SIMD, 272 accumulator registers each), the
+        // forward / tangent kernels 8; all write the same `g` partial rows
+        const long long tiles = (b->N + 15) / 16;
+        const long long per_block = 4ll * std::max(1, c->upd_tiles_per_wave);
+        const int g = (int)std::max<long long>(1, std::min<long long>((tiles + per_block - 1) / per_block, (long long)c->n_sm));
+        int rc = ensure_partials(c, g); if (rc) return rc;
+        *nrows = g; *stride = P + PART_EXTRA; *lk_col = P;
+        c->ls_skip = k.skip;
+        rc = policy_f3_launch(c, mode, b, theta, vf, c->d_partials, g, st);
+        c->ls_skip = nullptr;
+        return rc;
+    }
     *stride = (mode == 2) ? 2 : P + PART_EXTRA; *lk_col = 0;
     int rc = launch_generic<128>(c, mode, k, theta, vf, nrows, st);
     if (rc == METRPO_EUNSUPPORTED) rc = launch_generic<64>(c, mode, k, theta, vf, nrows, st);
