@@ -99,6 +99,7 @@ __device__ __forceinline__ void cg_init_body(int P, const double* gout, double* 
 // What a CG iteration reads that the Fisher-vector product it follows does NOT write (p, r, x and the two scalars): k_finalize loads these
 // before it waits on the arrival ticket, so the last block's CG step has one global round trip (z) left instead of two dependent ones.
 constexpr int CG_R = 2;              // register-resident fast path: P <= 2 * blockDim (1024 threads)
+constexpr int CG_RBIG = 13;          // ... and P <= 13 * blockDim without the prefetch
 struct CgPre { double pv[CG_R], rv[CG_R], xv[CG_R], done, rdotr; bool have; };
 __device__ __forceinline__ void cg_prefetch(const CgTail& t, CgPre& pre) {
     pre.have = (t.op == 1 && t.P <= CG_R * (int)blockDim.x);
@@ -112,25 +113,21 @@ __device__ __forceinline__ void cg_prefetch(const CgTail& t, CgPre& pre) {
     }
 }
 
-// one krylov.cg iteration after z = f_Ax(p) has been formed (z lacks the reg term: added here)
-__device__ __forceinline__ void cg_step_body(int P, double reg, double tol, int last, double* x, double* r, double* p, double* z,
-                                             PfOut pf, double* scal, double* sh, const CgPre* pre = nullptr) {
-    const bool pf_ = (pre != nullptr && pre->have);
-    if ((pf_ ? pre->done : scal[S_DONE]) != 0.0) {
-        if (last) for (int i = threadIdx.x; i < P; i += blockDim.x) pf.put(i, (float)x[i]);   // next FVP input is x (step scale)
-        return;
-    }
-    const double rdotr = pf_ ? pre->rdotr : scal[S_RDOTR];
-    // every vector element is read ONCE (one global round trip) and kept in registers across the two reductions: element i = tid + j*blockDim
-    if (P <= CG_R * (int)blockDim.x) {
-        double pv[CG_R], zv[CG_R], rv[CG_R], xv[CG_R];
+// every vector element is read ONCE (one global round trip) and kept in registers across the two reductions: element i = tid + j*blockDim, R per thread.
+// Per thread the same elements in the same order as the loop form below (t, t + blockDim, ..): the same sums bit for bit.  R = CG_R takes the vectors the
+// caller prefetched (CgPre); R = CG_RBIG serves the 100-50-25 policy's 12 492 parameters (the loop form's dependent global passes were 40 us of every CG step).
+template <int R> __device__ __forceinline__ void cg_step_regs(int P, double reg, double tol, int last, double* x, double* r, double* p, double* z,
+                                                              PfOut pf, double* scal, double* sh, double rdotr, const CgPre* pre) {
+    const bool pf_ = (R == CG_R && pre != nullptr && pre->have);
+
+        double pv[R], zv[R], rv[R], xv[R];
         double acc = 0.0;
 #pragma unroll
-        for (int j = 0; j < CG_R; ++j) {
+        for (int j = 0; j < R; ++j) {
             const int i = threadIdx.x + j * blockDim.x;
             pv[j] = zv[j] = rv[j] = xv[j] = 0.0;
             if (i < P) {
-                if (pf_) { pv[j] = pre->pv[j]; rv[j] = pre->rv[j]; xv[j] = pre->xv[j]; } else { pv[j] = p[i]; rv[j] = r[i]; xv[j] = x[i]; }
+                if (pf_) { pv[j] = pre->pv[j < CG_R ? j : 0]; rv[j] = pre->rv[j < CG_R ? j : 0]; xv[j] = pre->xv[j < CG_R ? j : 0]; } else { pv[j] = p[i]; rv[j] = r[i]; xv[j] = x[i]; }
                 zv[j] = z[i] + reg * pv[j]; acc += pv[j] * zv[j];
             }
         }
@@ -140,12 +137,12 @@ __device__ __forceinline__ void cg_step_body(int P, double reg, double tol, int 
         const double v = rdotr / pz;
         acc = 0.0;
 #pragma unroll
-        for (int j = 0; j < CG_R; ++j) { xv[j] += v * pv[j]; rv[j] -= v * zv[j]; acc += rv[j] * rv[j]; }
+        for (int j = 0; j < R; ++j) { xv[j] += v * pv[j]; rv[j] -= v * zv[j]; acc += rv[j] * rv[j]; }
         const double newrdotr = blk_sum(acc, sh);
         CG_MARK(7)
         const double mu = newrdotr / rdotr;
 #pragma unroll
-        for (int j = 0; j < CG_R; ++j) {
+        for (int j = 0; j < R; ++j) {
             const int i = threadIdx.x + j * blockDim.x;
             if (i < P) {
                 const double pn = rv[j] + mu * pv[j];
@@ -159,8 +156,19 @@ __device__ __forceinline__ void cg_step_body(int P, double reg, double tol, int 
             scal[S_ITERS] += 1.0;
             if (newrdotr < tol) scal[S_DONE] = 1.0;
         }
+        }
+
+// one krylov.cg iteration after z = f_Ax(p) has been formed (z lacks the reg term: added here)
+__device__ __forceinline__ void cg_step_body(int P, double reg, double tol, int last, double* x, double* r, double* p, double* z,
+                                             PfOut pf, double* scal, double* sh, const CgPre* pre = nullptr) {
+    const bool pf_ = (pre != nullptr && pre->have);
+    if ((pf_ ? pre->done : scal[S_DONE]) != 0.0) {
+        if (last) for (int i = threadIdx.x; i < P; i += blockDim.x) pf.put(i, (float)x[i]);   // next FVP input is x (step scale)
         return;
     }
+    const double rdotr = pf_ ? pre->rdotr : scal[S_RDOTR];
+    if (P <= CG_R * (int)blockDim.x) { cg_step_regs<CG_R>(P, reg, tol, last, x, r, p, z, pf, scal, sh, rdotr, pre); return; }
+    if (P <= CG_RBIG * (int)blockDim.x) { cg_step_regs<CG_RBIG>(P, reg, tol, last, x, r, p, z, pf, scal, sh, rdotr, nullptr); return; }
     double acc = 0.0;
     for (int i = threadIdx.x; i < P; i += blockDim.x) { const double zi = z[i] + reg * p[i]; z[i] = zi; acc += p[i] * zi; }
     const double pz = blk_sum(acc, sh);
@@ -197,6 +205,93 @@ __device__ __forceinline__ void cg_finish_body(int P, double reg, double max_kl,
     if (isnan(beta)) beta = 1.0;
     for (int i = threadIdx.x; i < P; i += blockDim.x) step[i] = beta * x[i];
     if (threadIdx.x == 0) { scal[S_BETA] = beta; scal[S_XHX] = xhx; }
+}
+
+// ---- the same CG step on a block of 1024 / VT threads (persistent CG solve of policy_mfma.hip: its blocks are 512 threads) ----------------------
+// Thread t stands in for the threads t, t + blockDim, .. of the 1024-thread block the fused tails run on: the same elements per (virtual) thread, the same
+// per-thread partial sums, the same wave sums (virtual wave = wave + k * blockDim / 64) and the same order over the 16 wave sums -- bit for bit the
+// results of cg_step_body / cg_finish_implicit in k_finalize's tail.
+template <int VT> __device__ __forceinline__ double blk_sum_v(const double (&v)[VT], double* sh) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nwr = blockDim.x >> 6;
+    double s[VT];
+#pragma unroll
+    for (int k = 0; k < VT; ++k) s[k] = wave_sum_f64(v[k]);
+    __syncthreads();
+    if (l == 0) {
+#pragma unroll
+        for (int k = 0; k < VT; ++k) sh[w + k * nwr] = s[k];
+    }
+    __syncthreads();
+    double r = 0.0;
+    for (int i = 0; i < VT * nwr; ++i) r += sh[i];
+    return r;
+}
+template <int VT> __device__ __forceinline__ void cgv_finish_implicit(int P, double max_kl, const double* x, const double* r, const double* g,
+                                                                      double* step, double* scal, double* sh) {
+    const int NV = VT * (int)blockDim.x;
+    double acc[VT];
+#pragma unroll
+    for (int k = 0; k < VT; ++k) {
+        acc[k] = 0.0;
+        for (int i = threadIdx.x + k * blockDim.x; i < P; i += NV) acc[k] += x[i] * (g[i] - r[i]);
+    }
+    const double xhx = blk_sum_v<VT>(acc, sh);
+    double beta = sqrt(2.0 * max_kl * (1.0 / (xhx + 1e-8)));
+    if (isnan(beta)) beta = 1.0;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) step[i] = beta * x[i];
+    if (threadIdx.x == 0) { scal[S_BETA] = beta; scal[S_XHX] = xhx; }
+}
+// every element in registers, R per (virtual) thread: P <= R * 1024.  R = R is cg_step_body's register path, a larger R its loop path (thread t walks
+// t, t + 1024, .. in order: the same sums)
+template <int VT, int R> __device__ __forceinline__ void cgv_step_body(int P, double reg, double tol, int last, double* x, double* r, double* p, double* z,
+                                                                PfOut pf, double* scal, double* sh) {
+    const int NV = VT * (int)blockDim.x;
+    if (scal[S_DONE] != 0.0) {
+        if (last) for (int i = threadIdx.x; i < P; i += blockDim.x) pf.put(i, (float)x[i]);
+        return;
+    }
+    const double rdotr = scal[S_RDOTR];
+    double pv[VT][R], zv[VT][R], rv[VT][R], xv[VT][R], acc[VT];
+#pragma unroll
+    for (int k = 0; k < VT; ++k) {
+        acc[k] = 0.0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int i = threadIdx.x + k * blockDim.x + j * NV;
+            pv[k][j] = zv[k][j] = rv[k][j] = xv[k][j] = 0.0;
+            if (i < P) {
+                pv[k][j] = p[i]; rv[k][j] = r[i]; xv[k][j] = x[i];
+                zv[k][j] = z[i] + reg * pv[k][j]; acc[k] += pv[k][j] * zv[k][j];
+            }
+        }
+    }
+    const double pz = blk_sum_v<VT>(acc, sh);
+    const double v = rdotr / pz;
+#pragma unroll
+    for (int k = 0; k < VT; ++k) {
+        acc[k] = 0.0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) { xv[k][j] += v * pv[k][j]; rv[k][j] -= v * zv[k][j]; acc[k] += rv[k][j] * rv[k][j]; }
+    }
+    const double newrdotr = blk_sum_v<VT>(acc, sh);
+    const double mu = newrdotr / rdotr;
+#pragma unroll
+    for (int k = 0; k < VT; ++k)
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int i = threadIdx.x + k * blockDim.x + j * NV;
+            if (i < P) {
+                const double pn = rv[k][j] + mu * pv[k][j];
+                z[i] = zv[k][j]; x[i] = xv[k][j]; r[i] = rv[k][j]; p[i] = pn;
+                pf.put(i, last ? (float)xv[k][j] : (float)pn);
+            }
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        scal[S_RDOTR] = newrdotr;
+        scal[S_ITERS] += 1.0;
+        if (newrdotr < tol) scal[S_DONE] = 1.0;
+    }
 }
 
 // One pass of ConjugateGradientOptimizer.optimize's backtracking loop, decided where the numbers are: the loop's break test

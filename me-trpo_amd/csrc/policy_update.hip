@@ -335,7 +335,10 @@ __global__ void __launch_bounds__(1024) k_finalize(ProblemDesc pd, int mode, int
             const double c = 4.0 * s2 * (2.0 * s2 - 1e-8) / ((2.0 * s2 + 1e-8) * (2.0 * s2 + 1e-8));
             t = (raw > (double)LOG_MIN_STD) ? c * v[p] * t : 0.0;
         }
-        out[p] = t;
+        // a fused tail reads `out` in ANOTHER workgroup (the last to arrive): write-through (sc1) stores, drained before the arrival ticket, instead of a
+        // cache-wide release per workgroup (buffer_wbl2 x 45 workgroups at C1, x 391 for the 100-50-25 policy: 25-49 us of that reduction)
+        if (tail.op != 0 || xc.world > 1) __hip_atomic_store(out + p, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else out[p] = t;
         if (xc.world > 1) xchg_push(xc, p, t);                // sharded run: this rank's share goes straight into every rank's receive slot
     }
     if (tail.op == 0 && xc.world <= 1) return;
@@ -348,8 +351,6 @@ __global__ void __launch_bounds__(1024) k_finalize(ProblemDesc pd, int mode, int
     __syncthreads();
     FT_MARK(3)
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned int tk = __hip_atomic_fetch_add(tail.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (tk == gridDim.x - 1) ? 1u : 0u;
         if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -469,6 +470,16 @@ static int run_mode(metrpo_ctx* c, int mode, const metrpo_batch* b, const PolK& 
     if (rc == METRPO_EUNSUPPORTED) rc = launch_generic<32>(c, mode, k, theta, vf, nrows, st);
     if (rc == METRPO_EUNSUPPORTED) return set_err(c, rc, "policy too wide for the update kernels' LDS tile");
     return rc;
+}
+
+// all `n_it` Fisher-vector products of a CG solve + the vector steps in one launch (policy_mfma.hip MODE_CGP); METRPO_EUNSUPPORTED: per-launch path
+int launch_cg_persist(metrpo_ctx* c, const metrpo_batch* b, const CgTail& tl, int n_it, hipStream_t st) {
+    if (c->pol_mfma < 0 || policy_gemm_applicable(c, b->N) || c->vjp_gm != nullptr) return METRPO_EUNSUPPORTED;
+    const long long tiles = (b->N + 15) / 16;
+    const long long per_block = 8ll * std::max(1, c->upd_tiles_per_wave);
+    const int g = (int)std::max<long long>(1, std::min<long long>((tiles + per_block - 1) / per_block, (long long)c->n_sm));      // run_mode's grid of the products
+    int rc = ensure_partials(c, g); if (rc) return rc;
+    return policy_mfma_cg_persist(c, c->pol_mfma, b, c->d_theta, tl, n_it, c->d_partials, g, st);
 }
 
 int launch_loss_grad(metrpo_ctx* c, const metrpo_batch* b, double* out, hipStream_t st, const CgTail* tail) {
