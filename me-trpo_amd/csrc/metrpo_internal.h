@@ -36,7 +36,7 @@ struct ProblemDesc {
 // ---- variant / tuning switches of a context (metrpo_set_option / metrpo_get_option, include/metrpo.h) ----------------------------------------------
 // One table per context, read by the launch paths through ctx_opt(); metrpo_create fills the defaults ONCE from the environment (METRPO_<KEY>), nothing
 // else in the library reads the environment for kernel selection.  A key is the upper-case name below (the ABI also takes lower case and a METRPO_ prefix).
-#define METRPO_OPT_LIST(X) X(COOP_MODE) X(EXTRA_LDS) X(GEMM_PREFETCH) X(NO_DEVICE_LINESEARCH) X(NO_FUSED_OUT) X(NO_IMGVAL) X(NO_L0_ROWS) X(NO_MERGED_ROUNDS) X(NO_PRE_MFMA3) X(NO_RESIDENT) X(NO_RESIDENT_VALIDATION) X(NO_STEP_MERGE) X(NO_STREAMK) X(PG_HEAD_ROWS) X(PRE_GEMM) X(RESIDENT_NO_ROTATE) X(RESIDENT_NO_SENTINEL) X(RESIDENT_TEST_SKIP) X(RESIDENT_WS) X(RES_UNCACHED) X(SEQ_ROUNDS) X(SOLVE_BLOCK) X(STEP_MERGE) X(STREAMK) X(STREAMK_LATE) X(STREAMK_NO_XCD) X(UPD_TILES_PER_WAVE) X(VAL_CHUNKS) X(VAL_TILES_PER_WAVE) X(XCHG_TIMEOUT_MS) X(NO_PERSIST) X(PERSIST) X(QUIET) X(TIME_FVP) X(PERSIST_STATS) X(PERSIST_NARROW) X(PERSIST_WIDE) X(PERSIST_NCLOSE) X(STREAMK_NO_TEAM) X(NO_POL_FUSED3) X(CG_PERSIST)
+#define METRPO_OPT_LIST(X) X(COOP_MODE) X(EXTRA_LDS) X(GEMM_PREFETCH) X(NO_DEVICE_LINESEARCH) X(NO_FUSED_OUT) X(NO_IMGVAL) X(NO_L0_ROWS) X(NO_MERGED_ROUNDS) X(NO_PRE_MFMA3) X(NO_RESIDENT) X(NO_RESIDENT_VALIDATION) X(NO_STEP_MERGE) X(NO_STREAMK) X(PG_HEAD_ROWS) X(PRE_GEMM) X(RESIDENT_NO_ROTATE) X(RESIDENT_NO_SENTINEL) X(RESIDENT_TEST_SKIP) X(RESIDENT_WS) X(RES_UNCACHED) X(SEQ_ROUNDS) X(SOLVE_BLOCK) X(STEP_MERGE) X(STREAMK) X(STREAMK_LATE) X(STREAMK_NO_XCD) X(UPD_TILES_PER_WAVE) X(VAL_CHUNKS) X(VAL_TILES_PER_WAVE) X(XCHG_TIMEOUT_MS) X(NO_PERSIST) X(PERSIST) X(QUIET) X(TIME_FVP) X(PERSIST_STATS) X(PERSIST_NARROW) X(PERSIST_WIDE) X(PERSIST_NCLOSE) X(STREAMK_NO_TEAM) X(NO_POL_FUSED3) X(CG_PERSIST) X(NO_PRE_SPLIT)
 enum MetrpoOpt {
 #define X(n) OPT_##n,
     METRPO_OPT_LIST(X)

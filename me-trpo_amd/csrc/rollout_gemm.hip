@@ -209,6 +209,182 @@ __global__ void __launch_bounds__(256) k_big_pre_mfma3(ProblemDesc pd, RolloutK 
             }
         }
 }
+// The same pre-step for SMALL batches (the params-file shape: 500 rows = 32 tiles on 256 CUs), where k_big_pre_mfma3's one wave per tile is a chain of 258
+// dependent-ish matrix instructions behind a 67 KB image copy into every workgroup's LDS (23 us per step, a fifth of params-humanoid's rollout).  Here a
+// tile is a whole workgroup: wave w owns column blocks w, w + 4 (layer 0: 2 w, 2 w + 1) of every layer -- 28 + 28 + 16 + 8 matrix instructions on its path
+// instead of 258 --, loads ITS fragments of the image straight into registers (one round trip, no LDS image), and the layers' D fragments change hands
+// through 13 KB of LDS.  Same image, same k order per output unit, same draws: bit for bit k_big_pre_mfma3<.., false>.
+template <int NS, int NA, int NDROP, int W1, int W2, int W3>
+__global__ void __launch_bounds__(256) k_big_pre_mfma3_split(ProblemDesc pd, RolloutK r, int t, const float* __restrict__ theta,
+                                                             const float* __restrict__ norm, BigState st) {
+    using PC = P3<NS, NA, W1, W2, W3>;
+    constexpr int NS_KS = PC::NS_KS, C1 = PC::C1, C2 = PC::C2, C3 = PC::C3, CO = PC::CO, pLS = PC::pLS, NIN = NS - NDROP + NA;
+    constexpr int NB0 = cdiv(C1, 4), NB1 = cdiv(C2, 4), NB2 = cdiv(C3, 4), NB3 = cdiv(CO, 4);
+    static_assert(NB3 == 1, "one output block per wave (na <= 64)");
+    __shared__ __attribute__((aligned(16))) float ST[16 * NS];
+    __shared__ f32x4 H1[C1 * 64], H2[C2 * 64], H3[C3 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int b0 = blockIdx.x * 16, b = b0 + c;
+    const bool active = b < r.B;
+    if (r.stop != nullptr && *r.stop != 0) return;
+    const float* __restrict__ img = st.PIMG;
+    // this wave's fragments and biases: issued first, they fly under the reset / state-tile work
+    float f0[NS_KS][NB0], f1[4 * C1][NB1], f2[4 * C2][NB2], f3[4 * C3];
+    f32x4 bi0[NB0], bi1[NB1], bi2[NB2], bi3;
+#pragma unroll
+    for (int j = 0; j < NB0; ++j) {
+        const int cb = wave * NB0 + j, cbc = (cb < C1) ? cb : C1 - 1;
+#pragma unroll
+        for (int s_ = 0; s_ < NS_KS; ++s_) f0[s_][j] = img[PC::O_F0 + (s_ * C1 + cbc) * 64 + lane];
+        bi0[j] = *(const f32x4*)&img[PC::O_B0 + 16 * cbc + 4 * q];
+    }
+#pragma unroll
+    for (int j = 0; j < NB1; ++j) {
+        const int cb = wave * NB1 + j, cbc = (cb < C2) ? cb : C2 - 1;
+#pragma unroll
+        for (int kk = 0; kk < 4 * C1; ++kk) f1[kk][j] = img[PC::O_F1 + (kk * C2 + cbc) * 64 + lane];
+        bi1[j] = *(const f32x4*)&img[PC::O_B1 + 16 * cbc + 4 * q];
+    }
+#pragma unroll
+    for (int j = 0; j < NB2; ++j) {
+        const int cb = wave * NB2 + j, cbc = (cb < C3) ? cb : C3 - 1;
+#pragma unroll
+        for (int kk = 0; kk < 4 * C2; ++kk) f2[kk][j] = img[PC::O_F2 + (kk * C3 + cbc) * 64 + lane];
+        bi2[j] = *(const f32x4*)&img[PC::O_B2 + 16 * cbc + 4 * q];
+    }
+    {
+        const int cbc = (wave < CO) ? wave : CO - 1;
+#pragma unroll
+        for (int kk = 0; kk < 4 * C3; ++kk) f3[kk] = img[PC::O_F3 + (kk * CO + cbc) * 64 + lane];
+        bi3 = *(const f32x4*)&img[PC::O_B3 + 16 * cbc + 4 * q];
+    }
+    const uint64_t genv = r.stream_offset + (uint64_t)RK_ENV(r, b);
+    const int tt = t + RK_TOFF(r, b);
+    const int lim = min(16, max(0, r.B - b0)) * NS;
+    if (t == 0) {                                                // wave 0 resets its tile's envs and reads the rows back itself (as k_big_pre_mfma3's wave does)
+        if (wave == 0) {
+            if (active && q == 0 && r.init_obs != nullptr) {     // continuation of a chunked rollout / merged rounds
+                st.cur_model[b] = r.init_model[b]; st.ts[b] = r.init_ts[b];
+                for (int i = 0; i < NS; ++i) st.S[(size_t)b * NS + i] = r.init_obs[(size_t)b * NS + i];
+            } else if (active && q == 0) {                       // vec_env.reset() (env_helpers.py:585-595)
+                const uint4 d0 = rng_draw(r.seed, genv, 0, RNG_RESET, 0);
+                const int row = (r.reset_idx != nullptr) ? r.reset_idx[b] : rng_index(d0.x, r.n_pool);
+                st.cur_model[b] = (r.reset_model != nullptr) ? r.reset_model[b] : rng_index(d0.y, pd.K);
+                st.ts[b] = 0;
+                for (int i = 0; i < NS; ++i) st.S[(size_t)b * NS + i] = r.pool[(size_t)row * NS + i];
+            }
+            wave_lds_sync();
+            for (int i = lane; i < 16 * NS; i += 64) ST[i] = (i < lim) ? st.S[(size_t)b0 * NS + i] : 0.0f;
+        }
+    } else {
+        for (int i = tid; i < 16 * NS; i += 256) ST[i] = (i < lim) ? st.S[(size_t)b0 * NS + i] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = tid; i < lim; i += 256) {                       // obs[t] (merged rounds: a tile's envs may belong to two rounds)
+        const int bi = b0 + i / NS;
+        r.obs[((size_t)(t + RK_TOFF(r, bi)) * RK_STRIDE(r) + RK_ENV(r, bi)) * NS + i % NS] = ST[i];
+    }
+    // ---- layer 0
+    {
+        f32x4 p0[NB0];
+#pragma unroll
+        for (int j = 0; j < NB0; ++j) p0[j] = bi0[j];
+#pragma unroll
+        for (int s_ = 0; s_ < NS_KS; ++s_) {
+            const int f = 4 * s_ + q;
+            const float x = (f < NS) ? ST[c * NS + f] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < NB0; ++j) p0[j] = MFMA16(f0[s_][j], x, p0[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NB0; ++j) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) p0[j][rr] = tanh_fast(p0[j][rr]);
+            if (wave * NB0 + j < C1) H1[(wave * NB0 + j) * 64 + lane] = p0[j];
+        }
+    }
+    __syncthreads();
+    // ---- layer 1
+    {
+        f32x4 h1[C1], p1[NB1];
+#pragma unroll
+        for (int cb = 0; cb < C1; ++cb) h1[cb] = H1[cb * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < NB1; ++j) p1[j] = bi1[j];
+#pragma unroll
+        for (int kk = 0; kk < 4 * C1; ++kk)
+#pragma unroll
+            for (int j = 0; j < NB1; ++j) p1[j] = MFMA16(f1[kk][j], h1[kk >> 2][kk & 3], p1[j]);
+#pragma unroll
+        for (int j = 0; j < NB1; ++j) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) p1[j][rr] = tanh_fast(p1[j][rr]);
+            if (wave * NB1 + j < C2) H2[(wave * NB1 + j) * 64 + lane] = p1[j];
+        }
+    }
+    __syncthreads();
+    // ---- layer 2
+    {
+        f32x4 h2[C2], p2[NB2];
+#pragma unroll
+        for (int cb = 0; cb < C2; ++cb) h2[cb] = H2[cb * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < NB2; ++j) p2[j] = bi2[j];
+#pragma unroll
+        for (int kk = 0; kk < 4 * C2; ++kk)
+#pragma unroll
+            for (int j = 0; j < NB2; ++j) p2[j] = MFMA16(f2[kk][j], h2[kk >> 2][kk & 3], p2[j]);
+#pragma unroll
+        for (int j = 0; j < NB2; ++j) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) p2[j][rr] = tanh_fast(p2[j][rr]);
+            if (wave * NB2 + j < C3) H3[(wave * NB2 + j) * 64 + lane] = p2[j];
+        }
+    }
+    __syncthreads();
+    const float* in_mean = norm; const float* in_std = norm + (NS + NA);
+    if (wave == 3 && active) {                                   // state columns of the dynamics input rows (the last wave has no output block)
+        for (int i = q; i < NS; i += 4) if (i >= NDROP) st.X[(size_t)b * st.ldx + i - NDROP] = (ST[c * NS + i] - in_mean[i]) / in_std[i];     // training.py:228,146-151
+        if (q == 0) for (int j = NIN; j < st.ldx; ++j) st.X[(size_t)b * st.ldx + j] = (st.xone && j == NIN) ? 1.0f : 0.0f;
+    }
+    if (wave >= CO) return;
+    // ---- output layer: wave w holds action dims 16 w + 4 q .. + 3 of env c
+    f32x4 mu = bi3;
+    {
+        f32x4 h3[C3];
+#pragma unroll
+        for (int cb = 0; cb < C3; ++cb) h3[cb] = H3[cb * 64 + lane];
+#pragma unroll
+        for (int kk = 0; kk < 4 * C3; ++kk) mu = MFMA16(f3[kk], h3[kk >> 2][kk & 3], mu);
+    }
+    if (!active) return;
+    const size_t tb = (size_t)tt * RK_STRIDE(r) + RK_ENV(r, b);
+    const float* __restrict__ log_std = theta + pLS;
+    const int cb = wave;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                                // Philox chunks (dim >> 1) of the step (chunk 0 = the step block), exactly as k_big_pre
+        const int d0 = 16 * cb + 4 * q + 2 * h;
+        if (d0 >= NA) continue;
+        float z[2] = {0.f, 0.f};
+        if (!r.determ && r.eps == nullptr) {
+            const uint4 blk = rng_draw(r.seed, genv, r.t0 + tt, RNG_STEP, d0 >> 1);
+            normal2(blk.x, blk.y, z[0], z[1]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int d = d0 + j;
+            if (d >= NA) continue;
+            const float m = mu[2 * h + j];
+            float a = m;
+            if (!r.determ) a = fmaf((r.eps != nullptr) ? r.eps[tb * NA + d] : z[j], __expf(fmaxf(log_std[d], LOG_MIN_STD)), m);
+            r.act[tb * NA + d] = a; r.mean[tb * NA + d] = m;
+            const float ac = fminf(fmaxf(a, -1.0f), 1.0f);          // env_helpers.py:599
+            st.U[(size_t)b * NA + d] = ac;
+            st.X[(size_t)b * st.ldx + (NS - NDROP) + d] = (ac - in_mean[NS + d]) / in_std[NS + d];
+        }
+    }
+}
 template <int NS, int NA, int NDROP, int W1, int W2, int W3> constexpr size_t big_pre_mfma3_lds() {
     return sizeof(float) * (size_t)(P3<NS, NA, W1, W2, W3>::IMG + 4 * 16 * NS);
 }
@@ -746,8 +922,11 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
         c->last_rollout_kernel = 6;
         return METRPO_OK;
     }
+    // Humanoid's 100-50-25 pre-step at small batches: a tile per workgroup, column blocks over its waves (k_big_pre_mfma3_split)
+    const bool pre_split = pre_mfma != nullptr && pre_lds != 0 && B <= 16 * c->n_sm && ctx_opt(c, OPT_NO_PRE_SPLIT) == nullptr;
     for (int t = 0; t < a->T; ++t) {
-        if (pre_post && t > 0) hipLaunchKernelGGL(pre_post, dim3((B + 63) / 64), dim3(256), pre_lds_post, st, pd, r, t, c->d_theta, c->d_norm, bs);
+        if (pre_split && !(pre_post && t > 0)) hipLaunchKernelGGL((k_big_pre_mfma3_split<55, 21, 0, 100, 50, 25>), dim3((B + 15) / 16), dim3(256), 0, st, pd, r, t, c->d_theta, c->d_norm, bs);
+        else if (pre_post && t > 0) hipLaunchKernelGGL(pre_post, dim3((B + 63) / 64), dim3(256), pre_lds_post, st, pd, r, t, c->d_theta, c->d_norm, bs);
         else if (pre_mfma) hipLaunchKernelGGL(pre_mfma, dim3((B + 63) / 64), dim3(256), pre_lds, st, pd, r, t, c->d_theta, c->d_norm, bs);
         else if (pre_gemm) {
             hipLaunchKernelGGL(k_big_pre_gather, dim3((unsigned)(((long long)B * pd.ns + 255) / 256)), dim3(256), 0, st, pd, r, t, c->d_norm, bs);

@@ -76,3 +76,25 @@ def test_fused3_trpo_update_vs_oracle(seed):
     assert abs(out['kl'] - ref['kl']) <= TOL.POST_UPDATE_RTOL * ref['kl'] and out['kl'] <= 0.01 and out['loss'] < out['loss_before']
     step_ref = ref['theta_new'] - th
     assert rel_l2(cpu(eng.get_policy()) - th.astype(np.float32).astype(np.float64), step_ref) <= TOL.THETA_STEP_REL_L2
+
+
+@pytest.mark.parametrize('B,T,H,draws', [(100, 7, 4, False), (37, 6, 3, True), (500, 5, 5, False), (16, 4, 2, False)])
+def test_humanoid_split_prestep_is_bitwise_the_wave_per_tile_prestep(B, T, H, draws):
+    """rollout_gemm.hip k_big_pre_mfma3_split (a 16-env tile per workgroup, the layers' column blocks over its four waves: the params-file batches) against
+    k_big_pre_mfma3 (a wave per tile; option NO_PRE_SPLIT): same fragment image, same k order per unit, same draws -- every trajectory tensor bit for bit.
+    Merged rounds (T > H: tiles spanning two rounds), ragged last tile, supplied and production draws."""
+    import helpers as Hh
+    K = 3
+    eng, dm, theta, pdims, pool = Hh.make_engine('humanoid', K, (128, 128), POL, seed=23)
+    assert eng.set_rollout_variant(1) == 3
+    kw = {}
+    if draws:
+        dr = Hh.draws(np.random.RandomState(5), K, B, T, dm.ns, dm.na, len(pool))
+        kw = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in dr.items()}
+    a = eng.rollout(B, T, H, 'step_rand', pool, seed=3, **kw)
+    assert eng.last_rollout_kernel() == 'gemm-stepwise'
+    a = [x.clone() for x in (a.obs, a.act, a.mean, a.rew, a.done, a.last_obs)]
+    eng.set_option('NO_PRE_SPLIT', 1)
+    b = eng.rollout(B, T, H, 'step_rand', pool, seed=3, **kw)
+    for x, y in zip(a, (b.obs, b.act, b.mean, b.rew, b.done, b.last_obs)):
+        assert torch.equal(x, y)
