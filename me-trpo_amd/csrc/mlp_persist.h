@@ -284,14 +284,15 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
         const SkRec* e1 = rec_of(k); const int t1_ = k.t; adv(k);
         cA = k;
         const SkRec* e2 = rec_of(k); adv(k);
+        if (SK_BAR2) cB = k;                                                       // (SK_BAR2, mlp_streamk.h: copies two entries ahead -- the next copy record is q + 3)
         const SkRec* e3 = rec_of(k); adv(k);
-        cB = k;
+        if (!SK_BAR2) cB = k;
         sk_i32x4 l0, l1, i0, i1, i2, i3;
         asm volatile("s_load_dwordx4 %0, %6, 0x0\n\ts_load_dwordx4 %1, %7, 0x0\n\ts_load_dwordx4 %2, %6, 0x10\n\ts_load_dwordx4 %3, %7, 0x10\n\t"
                      "s_load_dwordx4 %4, %8, 0x10\n\ts_load_dwordx4 %5, %9, 0x10\n\ts_waitcnt lgkmcnt(0)"
                      : "=&s"(l0), "=&s"(l1), "=&s"(i0), "=&s"(i1), "=&s"(i2), "=&s"(i3) : "s"(e0), "s"(e1), "s"(e2), "s"(e3));
-        r0 = decL(l0, t0_); r1 = decL(l1, t1_); r3 = decI(i3);
-        issue(decI(i0), 0); issue(decI(i1), 1); issue(decI(i2), 2);
+        r0 = decL(l0, t0_); r1 = decL(l1, t1_); r3 = SK_BAR2 ? decI(i2) : decI(i3);
+        issue(decI(i0), 0); issue(decI(i1), 1); if (!SK_BAR2) issue(decI(i2), 2);
     }
     if (tid == 0) *lds_halt = 0;
     wait_x(r0, -1);
@@ -305,7 +306,8 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
     bool halted = false;                                                       // the stop step is behind this workgroup's next tile: leave
     __amdgpu_buffer_rsrc_t part_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.part, 0, 0xFFFFFFFFu, 0x00020000);
     auto body = [&](auto par_, const int q) {
-        constexpr int H = decltype(par_)::value % NH;                          // which of the tile's column blocks this entry belongs to (entries alternate)
+        constexpr int PAR = decltype(par_)::value;
+        constexpr int H = PAR % NH;                          // which of the tile's column blocks this entry belongs to (entries alternate)
         f32x4 (&h)[2] = hs;
         const bool nmain = !(r1.fl & SKF_EPI);
         const float* st = ring + (q & 3) * STAGE;
@@ -335,7 +337,7 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
                     constexpr int j = k >> 4, e = (k >> 2) & 3, u = k & 3;
                     if constexpr (k < 28)
                         asm volatile("s_waitcnt lgkmcnt(3)\n\tds_read_b128 %0, %2 offset:%3" : "=&v"(w[(k + 4) & 7]), "+v"(w[k & 7]) : "v"(cur_a), "i"(SK_WOFF(k + 4)));
-                    else if (nmain)
+                    else if (nmain && !(SK_BAR2 && PAR == 1))
                         asm volatile("s_waitcnt lgkmcnt(3)\n\tds_read_b128 %0, %2 offset:%3" : "=&v"(w[(k + 4) & 7]), "+v"(w[k & 7]) : "v"(nxt_a), "i"(SK_WOFF(k - 28)));
                     else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(w[k & 7]) : "i"(31 - k));
                     __builtin_amdgcn_sched_barrier(0);
@@ -344,7 +346,7 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
                     __builtin_amdgcn_sched_barrier(0);
                 };
 #define SKP_G4(b) group(std::integral_constant<int, (b)>{}); group(std::integral_constant<int, (b) + 1>{}); group(std::integral_constant<int, (b) + 2>{}); group(std::integral_constant<int, (b) + 3>{});
-#define SKP_P(t) issue_piece(r3, q + 3, std::integral_constant<int, (t)>{})
+#define SKP_P(t) issue_piece(r3, q + (SK_BAR2 ? 2 : 3), std::integral_constant<int, (t)>{})
                 SKP_G4(0)  SKP_P(0);
                 SKP_G4(4)  SKP_P(1);
                 SKP_G4(8)  SKP_P(2);
@@ -356,7 +358,7 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
             }
         } else {
-            issue(r3, q + 3);
+            issue(r3, q + (SK_BAR2 ? 2 : 3));
             fetch2(fa, fb, fat, rn, r4);
             if (rn.fl & SKF_NEWTILE) seen = probe_flag(rn);                    // (two epilogue chunks: the next tile comes into view here; sentinels carry no NEWTILE)
             if (!(r0.fl & SKF_NONE)) {
@@ -394,13 +396,17 @@ __global__ void __launch_bounds__(512) k_sk_persist(const SkpArgs p) {
                         for (int ot = 0; ot < OT; ++ot) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oacc[H][ot]), part_rs, off + 64u * ot, 0, 16);
                     }
                 }
-                if (nmain) first4(stage_addr(q + 1));
+                if (nmain && !(SK_BAR2 && PAR == 1)) first4(stage_addr(q + 1));
             }
         }
         drain_vm();                                                            // copies of entry q + 3, the rows, the output partials (and the probe)
         if (my_halt && tid == 0) *lds_halt = 1;                                // (wave 0's view decides for the workgroup: the loop must end for all waves at the same entry)
-        if (!(p.nowait & 2)) __builtin_amdgcn_s_barrier();                     // (nowait & 2: developer timing without the chunk barrier -- results invalid)
+        // SK_BAR2 (mlp_streamk.h): the barrier stands behind the ODD chunks -- and behind every entry that needs the whole workgroup at its end: a tile's arrival
+        // (all waves' partials drained), the halt vote at a tile boundary
+        const bool bar_here = !SK_BAR2 || PAR == 1 || (r0.fl & SKF_ARRIVE) || (p.stop_batch > 0 && (r0.fl & SKF_NEWTILE));
+        if (!(p.nowait & 2) && bar_here) __builtin_amdgcn_s_barrier();         // (nowait & 2: developer timing without the chunk barrier -- results invalid)
         asm volatile("" ::: "memory");
+        if (SK_BAR2 && PAR == 1 && nmain) first4(stage_addr(q + 1));
         if (p.stop_batch > 0 && (r0.fl & SKF_NEWTILE) && __builtin_amdgcn_readfirstlane(*(volatile int*)lds_halt)) { halted = true; return; }      // uniform: r0 and the LDS word are the same for every wave
         // every wave's partials are complete behind the barrier: the tile arrives (fire and forget; the last step is closed by the host's k_big_post)
         if ((r0.fl & SKF_ARRIVE) && r0.t + 1 < T && tid == 0) (void)__hip_atomic_fetch_add(p.arrive + (r0.m0 >> 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -34,6 +34,12 @@
 // Summation order of one output: chunks of 32 k in order; inside a chunk the steps (j, e) = (0,0) .. (1,3), step (j, e) adding
 // k = 16 j + e + {0, 4, 8, 12} in that order (the four lane groups of the matrix instruction) -- fixed, independent of grid and split.
 #pragma once
+#ifndef SK_BAR2
+// 1: ONE workgroup barrier per TWO chunks.  A chunk's copies then go two entries ahead (three with a barrier per chunk) -- the stage they overwrite was last
+// read two chunks ago and a barrier lies in between whichever parity --, the barrier stands behind the ODD chunks, and an odd chunk does not read the next
+// chunk's first operands ahead of it (that entry was copied during the even chunk before it: complete for everybody only behind the barrier).
+#define SK_BAR2 1
+#endif
 #include <type_traits>
 #include <algorithm>
 #include "mfma_common.h"
@@ -331,8 +337,8 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
         asm volatile("s_load_dwordx4 %0, %6, 0x0\n\ts_load_dwordx4 %1, %6, 0x20\n\ts_load_dwordx4 %2, %6, 0x10\n\ts_load_dwordx4 %3, %6, 0x30\n\t"
                      "s_load_dwordx4 %4, %6, 0x50\n\ts_load_dwordx4 %5, %6, 0x70\n\ts_waitcnt lgkmcnt(0)"
                      : "=&s"(l0), "=&s"(l1), "=&s"(i0), "=&s"(i1), "=&s"(i2), "=&s"(i3) : "s"(my_recs));
-        r0 = decL(l0); r1 = decL(l1); r3 = decI(i3);
-        issue(decI(i0), 0); issue(decI(i1), 1); issue(decI(i2), 2);
+        r0 = decL(l0); r1 = decL(l1); r3 = SK_BAR2 ? decI(i2) : decI(i3);
+        issue(decI(i0), 0); issue(decI(i1), 1); if (!SK_BAR2) issue(decI(i2), 2);
     }
     if constexpr (PROD) load_x(r0);
     else { set_a_voff(r0); load_a(r0, hs[0]); drain_a(hs[0]); }
@@ -406,7 +412,7 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
                     constexpr int j = k >> 4, e = (k >> 2) & 3, u = k & 3;
                     if constexpr (k < 28)
                         asm volatile("s_waitcnt lgkmcnt(3)\n\tds_read_b128 %0, %2 offset:%3" : "=&v"(w[(k + 4) & 7]), "+v"(w[k & 7]) : "v"(cur_a), "i"(SK_WOFF(k + 4)));
-                    else if (nmain)
+                    else if (nmain && !(SK_BAR2 && PAR == 1))
                         asm volatile("s_waitcnt lgkmcnt(3)\n\tds_read_b128 %0, %2 offset:%3" : "=&v"(w[(k + 4) & 7]), "+v"(w[k & 7]) : "v"(nxt_a), "i"(SK_WOFF(k - 28)));
                     else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(w[k & 7]) : "i"(31 - k));
                     __builtin_amdgcn_sched_barrier(0);                         // the MFMAs below stay BEHIND the statement (hipcc hoists register-only instructions past asm)
@@ -417,14 +423,14 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
 #define SK_G4(b) group(std::integral_constant<int, (b)>{}); group(std::integral_constant<int, (b) + 1>{}); group(std::integral_constant<int, (b) + 2>{}); group(std::integral_constant<int, (b) + 3>{});
                 // the copies of entry q + 3 go out EARLY in the phase (they are drained at its end: issued in its last groups they were waited for, 300-1000
                 // cycles per chunk); the schedule fetch (it blocks its wave ~200 cycles) late, at different points for the two waves of a SIMD
-#define SK_P(t) issue_piece(r3, q + 3, std::integral_constant<int, (t)>{})
+#define SK_P(t) issue_piece(r3, q + (SK_BAR2 ? 2 : 3), std::integral_constant<int, (t)>{})
                 SK_G4(0)  SK_P(0);
                 SK_G4(4)  SK_P(1);
                 SK_G4(8)  SK_P(2);
                 SK_G4(12) SK_P(3);
                 SK_G4(16) SK_P(4);
-                SK_G4(20) if (wave < 4) fetch2(q + 2, q + 4, rn, r4);
-                SK_G4(24) if (wave >= 4) fetch2(q + 2, q + 4, rn, r4);
+                SK_G4(20) if (wave < 4) fetch2(q + 2, q + (SK_BAR2 ? 3 : 4), rn, r4);
+                SK_G4(24) if (wave >= 4) fetch2(q + 2, q + (SK_BAR2 ? 3 : 4), rn, r4);
                 SK_G4(28)
                 // the next chunk's first operands must be COMPLETE before the loop's back edge: hipcc takes an asm read's destination as written when the
                 // statement ends and may copy those registers where control flow merges (seen: half-landed copies behind an EPI chunk, 1 % errors)
@@ -475,8 +481,8 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
                 }
             }
         } else if constexpr (OUT) {
-            issue(r3, q + 3);
-            fetch2(q + 2, q + 4, rn, r4);
+            issue(r3, q + (SK_BAR2 ? 2 : 3));
+            fetch2(q + 2, q + (SK_BAR2 ? 3 : 4), rn, r4);
             if (!(r0.fl & SKF_NONE)) {
                 auto epi_chunk = [&](auto ee) {
                     constexpr int EE = decltype(ee)::value;
@@ -511,7 +517,7 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
                         for (int ot = 0; ot < OT; ++ot) *(f32x4*)(pp + 16 * ot) = oacc[ot];
                     }
                 }
-                if (nmain) first4(stage_addr(q + 1));
+                if (nmain && !(SK_BAR2 && PAR == 1)) first4(stage_addr(q + 1));
             }
         }
         SK_STAMP(3);
@@ -527,8 +533,9 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
 #ifdef SK_DEBUG
         if (!(a.skip & 4))
 #endif
-        __builtin_amdgcn_s_barrier();                                          // entry q + 3 complete in LDS for everybody; everybody is done reading stage q % 4
+        if (!SK_BAR2 || PAR == 1) __builtin_amdgcn_s_barrier();                // entry q + 3 (SK_BAR2: q + 1, q + 2) complete in LDS for everybody; everybody is done reading stage q % 4
         asm volatile("" ::: "memory");
+        if (SK_BAR2 && PAR == 1 && nmain) first4(stage_addr(q + 1));
         SK_STAMP(5);
         r0 = r1; r1 = rn; r3 = r4;
     };
