@@ -188,7 +188,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
         c->opt_set[i] = (e != nullptr); c->opt_val[i] = e ? e : "";
     }
     opt_apply(c, -1);
-    c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gae_part = nullptr; c->gae_part_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0; c->d_res = nullptr; c->res_cap = 0; c->res_seq = 0; c->res_failed = 0; c->last_rollout_kernel = -1; c->upd_pending = 0; c->upd_spec = 0; c->upd_changed_in_end = 0; c->h_upd = nullptr; c->upd_stamp = 0; c->side_ready = 0; c->d_ticket = nullptr; c->d_hcache = nullptr; c->hcache_cap = 0; c->hcache_on = 0; c->d_mig = nullptr; c->mig_cap = 0; c->mig_epoch = 0; c->nccl_comm = nullptr; c->comm_world = 0; c->comm_rank = 0; c->pol_path = 1; c->d_pg = nullptr; c->pg_cap = 0; c->pg_fwd_rows = -1; c->pg_fwd_obs = nullptr; c->d_cgp_bar = nullptr; c->cgp_failed = 0; c->cgp_launches = 0; c->pol_f3 = 0; c->d_f3 = nullptr; c->f3_cap = 0; c->f3_rows = -1; c->f3_obs = nullptr; c->f3_theta = nullptr; c->d_adam = nullptr; c->adam_t = 0; c->d_train = nullptr; c->train_cap = 0; c->d_train_part = nullptr; c->train_part_cap = 0;
+    c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gae_part = nullptr; c->gae_part_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0; c->d_res = nullptr; c->res_cap = 0; c->res_seq = 0; c->res_failed = 0; c->last_rollout_kernel = -1; c->upd_pending = 0; c->upd_spec = 0; c->upd_changed_in_end = 0; c->h_upd = nullptr; c->upd_stamp = 0; c->side_ready = 0; c->d_ticket = nullptr; c->d_hcache = nullptr; c->hcache_cap = 0; c->hcache_on = 0; c->d_mig = nullptr; c->mig_cap = 0; c->mig_epoch = 0; c->nccl_comm = nullptr; c->comm_world = 0; c->comm_rank = 0; c->pol_path = 1; c->d_pg = nullptr; c->pg_cap = 0; c->pg_fwd_rows = -1; c->pg_fwd_obs = nullptr; c->d_cgp_bar = nullptr; c->cgp_failed = 0; c->cgp_launches = 0; c->pol_f3 = 0; c->d_f3 = nullptr; c->f3_cap = 0; c->f3_rows = -1; c->f3_obs = nullptr; c->f3_theta = nullptr; c->f3_img_ok = 0; c->d_adam = nullptr; c->adam_t = 0; c->d_train = nullptr; c->train_cap = 0; c->d_train_part = nullptr; c->train_part_cap = 0;
     ProblemDesc& pd = c->pd;
     pd.env = d->env; pd.ns = d->ns; pd.na = d->na; pd.K = d->n_models; pd.n_drop = d->n_drop;
     pd.nin = d->ns + d->na - d->n_drop;

@@ -97,7 +97,7 @@ struct metrpo_ctx {
     void* d_pg; size_t pg_cap; long long pg_fwd_rows; const float* pg_fwd_obs;   // policy_gemm.hip workspace + validity of its cached forward pass
     unsigned int* d_cgp_bar; int cgp_failed, cgp_launches;   // policy_mfma.hip MODE_CGP: barrier counters of the persistent CG solve | a solve timed out: per-launch path from then on
     int pol_f3;          // 1: fused MFMA update kernels for three-hidden-layer policies (policy_fused3.hip) serve this shape
-    void* d_f3; size_t f3_cap; long long f3_rows; const float* f3_obs; const float* f3_theta;   // policy_fused3.hip: activation cache + mean-adjoint of one (theta, batch) and its validity
+    void* d_f3; size_t f3_cap; long long f3_rows; const float* f3_obs; const float* f3_theta; int f3_img_ok;   // policy_fused3.hip: activation cache + mean-adjoint of one (theta, batch) and its validity
     void* d_adam;        // Adam moments [2][K][Pd] + loss accumulators (dyn_train.hip)
     long long adam_t;    // Adam step count
     void* d_train;       // training activation workspace

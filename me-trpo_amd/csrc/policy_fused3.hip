@@ -29,6 +29,7 @@ struct F3K {                    // kernel arguments
     const float* obs; const float* act; const float* adv; const float* old_mean; const float* old_ls; int ls_stride;
     const uint8_t* valid; long long N; float inv_n; const double* skip;
     const float* theta; const float* v;
+    const float* img;           // fragment tables (k_f3_image)
     f32x4* hc; f32x4* u;        // activation cache / mean-adjoint: [tile][block][64 lanes] 16-byte words in the MFMA D layout
     float* partials; int row_stride, P, ls_off;
     int w_off[4], b_off[4];
@@ -63,6 +64,7 @@ struct F3Shape {
     static constexpr int F0 = KS0 * cbp_of(CB1) * 64, F1 = KS1 * cbp_of(CB2) * 64, F2 = KS2 * cbp_of(CB3) * 64, F3 = KS3 * cbp_of(CB4) * 64;
     static constexpr int B3 = KS4 * cbp_of(CB3) * 64, B2 = KS3 * cbp_of(CB2) * 64, B1 = KS2 * cbp_of(CB1) * 64;
     static constexpr int LDS_FWD = F0 + F1 + F2 + F3, LDS_JVP = 2 * (F0 + F1 + F2 + F3) - F0;
+    static constexpr int IMG_F = 0, IMG_V = LDS_FWD, IMG_B = 2 * LDS_FWD, IMG_FLOATS = 2 * LDS_FWD + B3 + B2 + B1;      // global table image (k_f3_image)
     // per-wave transpose tiles of the back-prop kernel: U, H3, H2, H1, D3, D2
     static constexpr int TS = 20, TILE = 16 * TS, NTB = CB4 + CB3 + CB2 + CB1 + CB3 + CB2;
     static constexpr int BWD_WAVES = 4;
@@ -82,34 +84,33 @@ struct F3Shape {
 //   lane (c, q) holds feature 4 kk + q of sample c), in = 16 (kk >> 2) + 4 q + (kk & 3) behind a hidden layer (B operand = register kk & 3 of that
 //   layer's D fragment kk >> 2).  Row DIN of Wx is the bias (the constant unit).
 // back-prop type: W[i = 16 cb + c][j = 16 (kk >> 2) + 4 q + (kk & 3)], i < DIN (rows of the constant / padding units are zero), j < DOUT.
-// A block builds its tables in two passes: every thread first issues the gathers of ALL its elements of ALL tables (independent, clamped addresses:
-// one L2 round trip), then stores them to LDS.  (As one dependent load per loop iteration the build was 40 us of every launch -- 54 round trips.)
-template <int KS, int CB, bool L0, bool BWDT, int NTH>
-struct Tab {
-    static constexpr int CBP = cbp_of(CB), TOT = KS * CBP * 64, NPT = (TOT + NTH - 1) / NTH;
-    float v[NPT];
-    __device__ __forceinline__ void load(const float* __restrict__ W, const float* __restrict__ bias, int DIN, int DOUT, int tid) {
-#pragma unroll
-        for (int t = 0; t < NPT; ++t) {
-            const int i = tid + t * NTH;
-            const int e4 = i & 3, ln = (i >> 2) & 63, j = i >> 8;
-            const int e = 4 * j + e4, kk = e / CBP, cb = e % CBP, c = ln & 15, q = ln >> 4;
-            const int kidx = L0 ? 4 * kk + q : 16 * (kk >> 2) + 4 * q + (kk & 3), u = 16 * cb + c;
-            const float* src = W; bool use = false;
-            if (i < TOT && cb < CB) {
-                if (!BWDT) {
-                    if (u < DOUT) { if (kidx < DIN) { src = W + kidx * DOUT + u; use = true; } else if (kidx == DIN && bias != nullptr) { src = bias + u; use = true; } }
-                } else if (u < DIN && kidx < DOUT) { src = W + u * DOUT + kidx; use = true; }
-            }
-            const float val = *src;                         // always a valid address
-            v[t] = use ? val : 0.f;
-        }
+// The tables are built ONCE per launch group by k_f3_image into a global image [F0 F1 F2 F3 | V0 V1 V2 V3 | B3 B2 B1] (gathers spread over the chip) and
+// copied into every workgroup's LDS by 16-byte loads.  (Built in every workgroup -- 256 workgroups gathering 27 000 four-byte words each from the same
+// 50 KB -- the prologue was 15-25 us of every launch, most of a Fisher-vector product at the params files' N = 50 000.)
+template <int KS, int CB, bool L0, bool BWDT>
+__device__ __forceinline__ float tab_value(int i, const float* __restrict__ W, const float* __restrict__ bias, int DIN, int DOUT) {
+    constexpr int CBP = cbp_of(CB);
+    const int e4 = i & 3, ln = (i >> 2) & 63, j = i >> 8;
+    const int e = 4 * j + e4, kk = e / CBP, cb = e % CBP, c = ln & 15, q = ln >> 4;
+    const int kidx = L0 ? 4 * kk + q : 16 * (kk >> 2) + 4 * q + (kk & 3), u = 16 * cb + c;
+    if (cb >= CB) return 0.f;
+    if (!BWDT) {
+        if (u >= DOUT) return 0.f;
+        if (kidx < DIN) return W[kidx * DOUT + u];
+        return (kidx == DIN && bias != nullptr) ? bias[u] : 0.f;
     }
-    __device__ __forceinline__ void store(float* __restrict__ tab, int tid) const {
+    return (u < DIN && kidx < DOUT) ? W[u * DOUT + kidx] : 0.f;
+}
+// LDS <- global, n floats (a multiple of 4), all NTH threads: every load issued before the first store
+template <int N, int NTH> __device__ __forceinline__ void copy_tab(float* __restrict__ dst, const float* __restrict__ src, int tid) {
+    static_assert(N % 4 == 0, "16-byte words");
+    constexpr int NQ = N / 4, NIT = (NQ + NTH - 1) / NTH;
+    float4 w4[NIT];
 #pragma unroll
-        for (int t = 0; t < NPT; ++t) { const int i = tid + t * NTH; if (i < TOT) tab[i] = v[t]; }
-    }
-};
+    for (int it = 0; it < NIT; ++it) { const int i = it * NTH + tid; w4[it] = (i < NQ) ? ((const float4*)src)[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) { const int i = it * NTH + tid; if (i < NQ) ((float4*)dst)[i] = w4[it]; }
+}
 
 // acc[cb] += sum over the KS k-steps of  table fragment (A)  x  bop(kk) (B)   -- or, SWAP: bop(kk) as A and the table fragment as B, which
 // delivers the product in the other orientation, D[sample 4q+r][unit c]
@@ -165,6 +166,38 @@ template <class S> __device__ __forceinline__ void fix_xb(float (&xb)[S::KS0], i
 }
 
 enum { F3_GRAD = 0, F3_LOSSKL = 2, F3_CACHE = 3 };
+enum { IMG_WHAT_F = 1, IMG_WHAT_V = 2, IMG_WHAT_B = 4 };
+// fragment tables of theta (F: forward, B: back-prop) and of the tangent vector v (V) -> the global image
+template <class S>
+__global__ void __launch_bounds__(256) k_f3_image(F3K k, float* __restrict__ img, int what) {
+    const float* __restrict__ th = k.theta; const float* __restrict__ v = k.v;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < S::IMG_FLOATS; i += gridDim.x * 256) {
+        float val;
+        if (i < S::IMG_V) {
+            if (!(what & IMG_WHAT_F)) continue;
+            const int j = i - S::IMG_F;
+            if (j < S::F0) val = tab_value<S::KS0, S::CB1, true, false>(j, th + k.w_off[0], th + k.b_off[0], S::D0, S::D1);
+            else if (j < S::F0 + S::F1) val = tab_value<S::KS1, S::CB2, false, false>(j - S::F0, th + k.w_off[1], th + k.b_off[1], S::D1, S::D2);
+            else if (j < S::F0 + S::F1 + S::F2) val = tab_value<S::KS2, S::CB3, false, false>(j - S::F0 - S::F1, th + k.w_off[2], th + k.b_off[2], S::D2, S::D3);
+            else val = tab_value<S::KS3, S::CB4, false, false>(j - S::F0 - S::F1 - S::F2, th + k.w_off[3], th + k.b_off[3], S::D3, S::D4);
+        } else if (i < S::IMG_B) {
+            if (!(what & IMG_WHAT_V)) continue;
+            const int j = i - S::IMG_V;
+            if (j < S::F0) val = tab_value<S::KS0, S::CB1, true, false>(j, v + k.w_off[0], v + k.b_off[0], S::D0, S::D1);
+            else if (j < S::F0 + S::F1) val = tab_value<S::KS1, S::CB2, false, false>(j - S::F0, v + k.w_off[1], v + k.b_off[1], S::D1, S::D2);
+            else if (j < S::F0 + S::F1 + S::F2) val = tab_value<S::KS2, S::CB3, false, false>(j - S::F0 - S::F1, v + k.w_off[2], v + k.b_off[2], S::D2, S::D3);
+            else val = tab_value<S::KS3, S::CB4, false, false>(j - S::F0 - S::F1 - S::F2, v + k.w_off[3], v + k.b_off[3], S::D3, S::D4);
+        } else {
+            if (!(what & IMG_WHAT_B)) continue;
+            const int j = i - S::IMG_B;
+            if (j < S::B3) val = tab_value<S::KS4, S::CB3, false, true>(j, th + k.w_off[3], nullptr, S::D3, S::D4);
+            else if (j < S::B3 + S::B2) val = tab_value<S::KS3, S::CB2, false, true>(j - S::B3, th + k.w_off[2], nullptr, S::D2, S::D3);
+            else val = tab_value<S::KS2, S::CB1, false, true>(j - S::B3 - S::B2, th + k.w_off[1], nullptr, S::D1, S::D2);
+        }
+        img[i] = val;
+    }
+}
+
 
 // =========================================================================================================================================
 // forward + head
@@ -175,15 +208,7 @@ __global__ void __launch_bounds__(NW * 64) k_f3_fwd(F3K k) {
     if (MODE == F3_LOSSKL && k.skip != nullptr && k.skip[0] >= 0.0) return;        // speculative line-search trial after the search stopped
     float* T0 = lds; float* T1 = T0 + S::F0; float* T2 = T1 + S::F1; float* T3 = T2 + S::F2;
     const float* __restrict__ th = k.theta;
-    {
-        Tab<S::KS0, S::CB1, true, false, NW * 64> t0; Tab<S::KS1, S::CB2, false, false, NW * 64> t1; Tab<S::KS2, S::CB3, false, false, NW * 64> t2;
-        Tab<S::KS3, S::CB4, false, false, NW * 64> t3;
-        t0.load(th + k.w_off[0], th + k.b_off[0], S::D0, S::D1, tid); t1.load(th + k.w_off[1], th + k.b_off[1], S::D1, S::D2, tid);
-        t2.load(th + k.w_off[2], th + k.b_off[2], S::D2, S::D3, tid);
-        if (MODE != F3_CACHE) t3.load(th + k.w_off[3], th + k.b_off[3], S::D3, S::D4, tid);
-        t0.store(T0, tid); t1.store(T1, tid); t2.store(T2, tid);
-        if (MODE != F3_CACHE) t3.store(T3, tid);
-    }
+    copy_tab<S::LDS_FWD, NW * 64>(lds, k.img + S::IMG_F, tid);
     // per-lane constants of the head: this lane's action dims d = 16 cb + 4 q + r
     float ls[S::CB4][4], inv_std[S::CB4][4];
 #pragma unroll
@@ -323,15 +348,9 @@ __global__ void __launch_bounds__(NW * 64) k_f3_jvp(F3K k) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 15, q = lane >> 4;
     float* V0 = lds; float* V1 = V0 + S::F0; float* V2 = V1 + S::F1; float* V3 = V2 + S::F2;
     float* W1 = V3 + S::F3; float* W2 = W1 + S::F1; float* W3 = W2 + S::F2;
-    const float* __restrict__ th = k.theta; const float* __restrict__ v = k.v;
-    {
-        Tab<S::KS0, S::CB1, true, false, NW * 64> v0; Tab<S::KS1, S::CB2, false, false, NW * 64> v1, w1; Tab<S::KS2, S::CB3, false, false, NW * 64> v2, w2;
-        Tab<S::KS3, S::CB4, false, false, NW * 64> v3, w3;
-        v0.load(v + k.w_off[0], v + k.b_off[0], S::D0, S::D1, tid); v1.load(v + k.w_off[1], v + k.b_off[1], S::D1, S::D2, tid);
-        v2.load(v + k.w_off[2], v + k.b_off[2], S::D2, S::D3, tid); v3.load(v + k.w_off[3], v + k.b_off[3], S::D3, S::D4, tid);
-        w1.load(th + k.w_off[1], nullptr, S::D1, S::D2, tid); w2.load(th + k.w_off[2], nullptr, S::D2, S::D3, tid); w3.load(th + k.w_off[3], nullptr, S::D3, S::D4, tid);
-        v0.store(V0, tid); v1.store(V1, tid); v2.store(V2, tid); v3.store(V3, tid); w1.store(W1, tid); w2.store(W2, tid); w3.store(W3, tid);
-    }
+    const float* __restrict__ th = k.theta;
+    copy_tab<S::LDS_FWD, NW * 64>(V0, k.img + S::IMG_V, tid);
+    copy_tab<S::F1 + S::F2 + S::F3, NW * 64>(W1, k.img + S::IMG_F + S::F0, tid);      // the forward tables of layers 1 .. 3 (their bias rows meet the constant unit's zero tangent)
     float fisher_w[S::CB4][4];                              // d2 KL / d mean^2 = 1 / (s^2 + eps/2)
 #pragma unroll
     for (int cb = 0; cb < S::CB4; ++cb)
@@ -418,12 +437,7 @@ __global__ void __launch_bounds__(S::BWD_WAVES * 64) k_f3_bwd(F3K k) {
     float* TL = B1 + S::B1 + wave * (S::NTB * TILE);
     float* T_U = TL; float* T_H3 = T_U + S::CB4 * TILE; float* T_H2 = T_H3 + S::CB3 * TILE; float* T_H1 = T_H2 + S::CB2 * TILE;
     float* T_D3 = T_H1 + S::CB1 * TILE; float* T_D2 = T_D3 + S::CB3 * TILE;
-    const float* __restrict__ th = k.theta;
-    {
-        Tab<S::KS4, S::CB3, false, true, NW * 64> b3; Tab<S::KS3, S::CB2, false, true, NW * 64> b2; Tab<S::KS2, S::CB1, false, true, NW * 64> b1;
-        b3.load(th + k.w_off[3], nullptr, S::D3, S::D4, tid); b2.load(th + k.w_off[2], nullptr, S::D2, S::D3, tid); b1.load(th + k.w_off[1], nullptr, S::D1, S::D2, tid);
-        b3.store(B3, tid); b2.store(B2, tid); b1.store(B1, tid);
-    }
+    copy_tab<S::B3 + S::B2 + S::B1, NW * 64>(B3, k.img + S::IMG_B, tid);
     const long long ntiles = (k.N + 15) / 16;
     // Registers: 272 gradient accumulators leave ~240 for everything else, so nothing is held twice.  The cached activations and U of tile t+1 are
     // fetched once tile t's copies are dead (behind its delta chain: they fly under the 272 gradient MFMAs, ~3.6 us), the transposed observations of
@@ -572,6 +586,7 @@ __global__ void __launch_bounds__(S::BWD_WAVES * 64) k_f3_bwd(F3K k) {
     float* R = lds + (wave & 1) * (S::GBN * 256);
     auto frag_rw = [&](bool add) {
         f32x4* r4 = (f32x4*)R;
+        // (LDS float atomics without return instead of the read / add / write of waves 2, 3 were measured: ds_add_f32 x 272 took 40 us)
         auto one = [&](int blk, const f32x4& g) { f32x4 t = g; if (add) t += r4[blk * 64 + lane]; r4[blk * 64 + lane] = t; };
 #pragma unroll
         for (int ci = 0; ci < S::XI; ++ci)
@@ -598,6 +613,7 @@ __global__ void __launch_bounds__(S::BWD_WAVES * 64) k_f3_bwd(F3K k) {
     float* row = k.partials + (size_t)blockIdx.x * k.row_stride;
     const float* RA = lds; const float* RB = lds + S::GBN * 256;
     auto frag = [&](int base, int CJ, int i, int j) { return ((base + (i >> 4) * CJ + (j >> 4)) * 64 + 16 * ((i & 15) >> 2) + (j & 15)) * 4 + (i & 3); };
+#pragma unroll 4
     for (int p = tid; p < S::NPAR; p += NW * 64) {
         int f;
         if (p < k.w_off[1]) { const int o = p - k.w_off[0]; f = (p < k.b_off[0]) ? frag(S::GB0, S::CB1, o / S::D1, o % S::D1) : frag(S::GB0, S::CB1, S::D0, p - k.b_off[0]); }
@@ -628,7 +644,7 @@ int policy_f3_select(const ProblemDesc& pd) {
 static int f3_ensure(metrpo_ctx* c, long long N) {
     typedef ShHumanoid S;
     const size_t tiles = (size_t)((N + 15) / 16);
-    const size_t need = tiles * (S::NHB + S::CB4) * 64 * sizeof(float) * 4;
+    const size_t need = tiles * (S::NHB + S::CB4) * 64 * sizeof(float) * 4 + (size_t)S::IMG_FLOATS * sizeof(float);
     if (need > c->f3_cap) {
         if (c->d_f3) { HIP_TRY(c, hipFree(c->d_f3)); c->d_f3 = nullptr; c->f3_cap = 0; }
         HIP_TRY(c, hipMalloc(&c->d_f3, need));
@@ -654,24 +670,31 @@ int policy_f3_launch(metrpo_ctx* c, int mode, const metrpo_batch* b, const float
     k.obs = b->d_obs; k.act = b->d_act; k.adv = b->d_adv; k.old_mean = b->d_old_mean; k.old_ls = b->d_old_log_std; k.ls_stride = b->old_log_std_stride;
     k.valid = b->d_valid; k.N = N; k.inv_n = (float)b->inv_n_global; k.skip = c->ls_skip; k.theta = theta; k.v = vf;
     k.hc = (f32x4*)c->d_f3; k.u = k.hc + tiles * S::NHB * 64;
+    float* img = (float*)(k.u + tiles * S::CB4 * 64);
+    k.img = img;
+    auto build_image = [&](int what) { hipLaunchKernelGGL((k_f3_image<S>), dim3(64), dim3(256), 0, st, k, img, what); };
     k.partials = partials; k.row_stride = c->pd.P + 3; k.P = c->pd.P; k.ls_off = c->pd.pol.n_params;
     for (int l = 0; l < 4; ++l) { k.w_off[l] = c->pd.pol.w_off[l]; k.b_off[l] = c->pd.pol.b_off[l]; }
     const size_t sh_fwd = sizeof(float) * S::LDS_FWD, sh_jvp = sizeof(float) * S::LDS_JVP, sh_bwd = sizeof(float) * S::LDS_BWD;
     const dim3 g(nblocks);
     if (mode == 2) {
+        build_image(IMG_WHAT_F); c->f3_img_ok = 0;          // (the trial theta's tables: the image no longer belongs to the cached activations)
         if ((rc = f3_attr(c, k_f3_fwd<S, F3_LOSSKL, FWD_NW>, sh_fwd))) return rc;
         hipLaunchKernelGGL((k_f3_fwd<S, F3_LOSSKL, FWD_NW>), g, dim3(FWD_NW * 64), sh_fwd, st, k);
         HIP_TRY(c, hipGetLastError());
         return METRPO_OK;
     }
     if (mode == 0) {
+        build_image(IMG_WHAT_F | IMG_WHAT_B); c->f3_img_ok = 1;
         if ((rc = f3_attr(c, k_f3_fwd<S, F3_GRAD, FWD_NW>, sh_fwd))) return rc;
         hipLaunchKernelGGL((k_f3_fwd<S, F3_GRAD, FWD_NW>), g, dim3(FWD_NW * 64), sh_fwd, st, k);
         // the activations stay valid for the Fisher-vector products of this CG solve (run_trpo_update raises hcache_on around it)
         c->f3_rows = c->hcache_on ? N : -1; c->f3_obs = b->d_obs; c->f3_theta = theta;
     } else {
-        const bool have = c->hcache_on && c->f3_rows == N && c->f3_obs == b->d_obs && c->f3_theta == theta;
+        const bool have = c->hcache_on && c->f3_img_ok && c->f3_rows == N && c->f3_obs == b->d_obs && c->f3_theta == theta;
+        build_image(IMG_WHAT_V | (have ? 0 : (IMG_WHAT_F | IMG_WHAT_B)));
         if (!have) {
+            c->f3_img_ok = 0;
             if ((rc = f3_attr(c, k_f3_fwd<S, F3_CACHE, FWD_NW>, sh_fwd))) return rc;
             hipLaunchKernelGGL((k_f3_fwd<S, F3_CACHE, FWD_NW>), g, dim3(FWD_NW * 64), sh_fwd, st, k);
             c->f3_rows = -1;
