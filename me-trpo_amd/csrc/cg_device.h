@@ -168,6 +168,7 @@ __device__ __forceinline__ void cg_step_body(int P, double reg, double tol, int 
     }
     const double rdotr = pf_ ? pre->rdotr : scal[S_RDOTR];
     if (P <= CG_R * (int)blockDim.x) { cg_step_regs<CG_R>(P, reg, tol, last, x, r, p, z, pf, scal, sh, rdotr, pre); return; }
+    if (P <= 4 * (int)blockDim.x) { cg_step_regs<4>(P, reg, tol, last, x, r, p, z, pf, scal, sh, rdotr, nullptr); return; }      // (Ant's 2 x 32 policy: 2 288)
     if (P <= CG_RBIG * (int)blockDim.x) { cg_step_regs<CG_RBIG>(P, reg, tol, last, x, r, p, z, pf, scal, sh, rdotr, nullptr); return; }
     double acc = 0.0;
     for (int i = threadIdx.x; i < P; i += blockDim.x) { const double zi = z[i] + reg * p[i]; z[i] = zi; acc += p[i] * zi; }

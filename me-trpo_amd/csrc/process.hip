@@ -87,13 +87,32 @@ __device__ __forceinline__ void gae_chunk_pass(const double* __restrict__ V, con
 // V buffer for the two scan passes (L2-resident: written and read by the same workgroup).  As a separate thread-per-sample kernel this
 // read rows of ns floats at a stride of ns floats per lane: 0.26 TB/s on Ant (560 us at the C3 share, 10x the scan itself).
 // NS = compile-time ns of the six envs (register-resident prefetch), NS = 0: any ns (no prefetch).
+// baseline.predict for ALL (step, 64-env block) pairs at once: a wave per pair.  k_gae's own first phase deals a block's steps over the 8 waves of ONE workgroup
+// per 64 env columns -- at the params-file batches (100-500 envs: 2-8 workgroups on 256 CUs) 12-60 dependent steps per wave, each a serial 2 ns + 4 term
+// float64 dot product per lane: 150 us (Ant) / 270 us (Humanoid) of a 50 000-sample batch.  Same staging, same baseline_value: the same V bit for bit.
+__global__ void __launch_bounds__(256) k_baseline_predict(const float* __restrict__ obs, const int32_t* __restrict__ tpath, const double* __restrict__ coeffs,
+                                                          int ns, double* __restrict__ V, int T, int B) {
+    extern __shared__ __attribute__((aligned(16))) float stage[];      // [4][64 * ns]
+    const int lane0 = threadIdx.x & 63, w0 = threadIdx.x >> 6;
+    const int t = blockIdx.y * 4 + w0;
+    if (t >= T) return;
+    const int b0 = blockIdx.x * 64, nv = min(64, B - b0);
+    float* S = stage + (size_t)w0 * 64 * ns;
+    const float* __restrict__ src = obs + ((size_t)t * B + b0) * ns;
+    for (int e = lane0; e < nv * ns; e += 64) S[e] = src[e];
+    const int tp = (lane0 < nv) ? tpath[(size_t)t * B + b0 + lane0] : 0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+    if (lane0 < nv) V[(size_t)t * B + b0 + lane0] = baseline_value(S + lane0 * ns, ns, tp, coeffs);
+}
+
 template <int NS, int NW>
 __global__ void __launch_bounds__(64 * NW) k_gae(const float* __restrict__ obs, const int32_t* __restrict__ tpath, const double* __restrict__ coeffs,
-                                                      int ns_rt, double* __restrict__ V, const float* __restrict__ rew, const uint8_t* __restrict__ done,
+                                                      int ns_rt, int pre_v, double* __restrict__ V, const float* __restrict__ rew, const uint8_t* __restrict__ done,
                                                       int T, int B, double gamma, double lam, float* __restrict__ adv, float* __restrict__ ret,
                                                       uint8_t* __restrict__ valid, double* __restrict__ stats, double* gpart) {
     extern __shared__ __attribute__((aligned(16))) float stage[];      // [NW][64 * ns]
-    if (coeffs != nullptr) {
+    if (coeffs != nullptr && pre_v) { /* V written by k_baseline_predict (few env columns: the predictions of all steps at once, chip-wide) */ }
+    else if (coeffs != nullptr) {
         const int ns = NS ? NS : ns_rt;
         const int lane0 = threadIdx.x & 63, w0 = threadIdx.x >> 6;
         const int b0 = blockIdx.x * 64, nv = min(64, B - b0);
@@ -564,10 +583,17 @@ int launch_gae(metrpo_ctx* c, const float* obs, const float* rew, const uint8_t*
     // dependent chain of one wave's steps -- 16 time chunks instead of 8 shorten it (84 -> 67 us at C0-params-file); at C1 (79 workgroups) 8 is faster
     const bool wide = (B <= 256 && T >= 128 && ns <= 18);
     const int nw = wide ? 16 : GAE_NW;
-    const size_t sh = (coeffs != nullptr) ? sizeof(float) * nw * 64 * (size_t)ns : 0;
+    // few env columns: the predictions of all steps by a launch of their own (k_baseline_predict), the scan kernel then starts from V
+    const int pre_v = (coeffs != nullptr && nblk <= 32 && T >= 16) ? 1 : 0;
+    if (pre_v) {
+        const size_t shp = sizeof(float) * 4 * 64 * (size_t)ns;
+        if (shp > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_baseline_predict, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp));
+        hipLaunchKernelGGL(k_baseline_predict, dim3(nblk, (T + 3) / 4), dim3(256), shp, st, obs, tpath, coeffs, ns, V, T, B);
+    }
+    const size_t sh = (coeffs != nullptr && !pre_v) ? sizeof(float) * nw * 64 * (size_t)ns : 0;
 #define GAE_LAUNCH_NW(NSV, NWV) do { \
         if (sh > 48 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_gae<NSV, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)); \
-        hipLaunchKernelGGL((k_gae<NSV, NWV>), dim3((B + 63) / 64), dim3(64 * NWV), sh, st, obs, tpath, coeffs, ns, V, rew, done, T, B, gamma, lam, adv, ret, valid, stats, c->d_gae_part); } while (0)
+        hipLaunchKernelGGL((k_gae<NSV, NWV>), dim3((B + 63) / 64), dim3(64 * NWV), sh, st, obs, tpath, coeffs, ns, pre_v, V, rew, done, T, B, gamma, lam, adv, ret, valid, stats, c->d_gae_part); } while (0)
 #define GAE_LAUNCH(NSV) do { if (wide) GAE_LAUNCH_NW(NSV, 16); else GAE_LAUNCH_NW(NSV, GAE_NW); } while (0)
 #define GAE_LAUNCH8(NSV) GAE_LAUNCH_NW(NSV, GAE_NW)
     if (sh + 48 * 1024 > 160 * 1024) return set_err(c, METRPO_EUNSUPPORTED, "gae: observation too wide for the staging buffer");
@@ -620,10 +646,11 @@ __global__ void __launch_bounds__(256) k_baseline_solve(int F, const double* __r
             if (p != k) for (int c = k + tid; c < W; c += 256) { const double t = Ms[k * W + c]; Ms[k * W + c] = Ms[p * W + c]; Ms[p * W + c] = t; }
             __syncthreads();
             const double inv = 1.0 / Ms[k * W + k];
-            const int nr = F - k - 1, nc = W - k - 1;        // rows below k x columns right of k (rhs included)
-            for (int i = tid; i < nr * nc; i += 256) {
-                const int r = k + 1 + i / nc, c = k + 1 + i % nc;
-                Ms[r * W + c] -= (Ms[r * W + k] * inv) * Ms[k * W + c];
+            // rows below k x columns right of k (rhs included): a thread owns ONE column (W <= 128) and every second row -- no integer division per element
+            // (as `i / nc, i % nc` over a flat index the update was 386 us at F = 114, most of it address arithmetic); the same expression per element
+            for (int c = k + 1 + (tid & 127); c < W; c += 128) {
+                const double mkc = Ms[k * W + c];
+                for (int r = k + 1 + (tid >> 7); r < F; r += 2) Ms[r * W + c] -= (Ms[r * W + k] * inv) * mkc;
             }
             __syncthreads();
         }

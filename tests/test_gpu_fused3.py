@@ -98,3 +98,19 @@ def test_humanoid_split_prestep_is_bitwise_the_wave_per_tile_prestep(B, T, H, dr
     b = eng.rollout(B, T, H, 'step_rand', pool, seed=3, **kw)
     for x, y in zip(a, (b.obs, b.act, b.mean, b.rew, b.done, b.last_obs)):
         assert torch.equal(x, y)
+
+
+def test_fused3_host_driven_solve_agrees_with_the_device_fused_one():
+    """An all-reduce callback between every reduction and its consumer (the multi-rank route without a peer-mapped transport: stand-alone k_cg_step kernels, host-side
+    line search) on the fused kernels: same CG trajectory as the single-launch-sequence update up to the float64 rounding of the two reduction routes."""
+    eng, th, pdims, obs, act, adv, om, ols = _problem(9000, seed=25)
+    batch = eng.make_batch(obs, act, adv, om, ols)
+    theta0 = eng.get_policy().clone()
+    dev = eng.trpo_update(batch, max_kl=0.01, want_vectors=True)
+    td = eng.get_policy().clone()
+    eng.set_policy(theta0)
+    host = eng.trpo_update(batch, max_kl=0.01, want_vectors=True, allreduce=lambda t: t)      # single rank: the sum is the identity
+    assert torch.equal(dev['g'], host['g'])
+    assert rel_l2(cpu(dev['d']), cpu(host['d'])) <= 1e-9 and abs(dev['beta'] - host['beta']) <= 1e-9 * host['beta']
+    assert dev['n_backtrack'] == host['n_backtrack'] and dev['accepted'] == host['accepted'] and dev['cg_iters_run'] == host['cg_iters_run'] == 10
+    np.testing.assert_allclose(cpu(td), cpu(eng.get_policy()), rtol=0, atol=1e-7)
