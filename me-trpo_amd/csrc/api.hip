@@ -363,7 +363,7 @@ extern "C" int32_t metrpo_rollout(metrpo_ctx* c, const metrpo_rollout_args* a, v
         std::string w;
         for (int l = 1; l < c->pd.dyn.n_layers; ++l) w += (l > 1 ? "x" : "") + std::to_string(c->pd.dyn.dims[l]);
         note_off_table(c, "dynamics hidden widths " + w + " have no matrix-core rollout kernel (fused kernels: two hidden layers of 64; GEMM / stream-K / resident paths: every "
-                          "hidden layer >= 128, ns <= 64): thread-per-env kernel (rollout_generic.hip), ~80x the fused kernels' time per env step");
+                          "hidden layer >= 16, ns <= 64): thread-per-env kernel (rollout_generic.hip), ~80x the fused kernels' time per env step");
     }
     return launch_rollout_generic(c, a, (hipStream_t)stream);
 }

@@ -758,7 +758,9 @@ bool gemm_path_applicable(const metrpo_ctx* c) {
     if (pd.ns > 64) return false;
     int minw = 1 << 30;
     for (int l = 1; l < pd.dyn.n_layers; ++l) minw = std::min(minw, pd.dyn.dims[l]);
-    return pd.dyn.n_layers >= 2 && minw >= 128;
+    // (>= 128 until round 5: the widths 65 .. 127 -- and any width the fused 2 x 64 kernels do not hold -- then fell to the thread-per-env kernel, ~80x the time
+    // per env step; the tile GEMMs take any width, every tile predicated)
+    return pd.dyn.n_layers >= 2 && minw >= 16;
 }
 
 // One chunk of the step loop on stream `st`.  ws == nullptr: only report the workspace size (bytes, 256-aligned) through *need_out.

@@ -611,11 +611,13 @@ def test_gemm_rollout_random_shapes_vs_generic_kernel():
     output layer), 2 and 3 hidden layers, MFMA / block / GEMM pre-step -- against the thread-per-env generic kernel with the same supplied draws."""
     rs = np.random.RandomState(1234)
     envs = ['swimmer', 'half_cheetah', 'ant', 'hopper', 'snake', 'humanoid']
-    for case in range(8):
+    for case in range(14):
         env = envs[case % len(envs)]
         K = int(rs.randint(1, 6))
         nl = 2 if case % 3 else 3
         hidden = tuple(int(rs.choice([128, 160, 192, 256, 320])) for _ in range(nl))
+        if case >= 8:                                                   # widths below 128 (round 5: no longer the thread-per-env kernel's), not multiples of 4 included
+            hidden = tuple(int(rs.choice([16, 48, 65, 72, 96, 100, 127])) for _ in range(nl))
         B = int(rs.randint(20, 400)); H = int(rs.randint(2, 6)); T = int(rs.randint(2, 2 * H + 1))
         mode = ['step_rand', 'eps_rand', 'model_mean', 'model_med', 'one_model'][int(rs.randint(5))]
         pol = (100, 50, 25) if env == 'humanoid' else (32, 32)
@@ -625,6 +627,7 @@ def test_gemm_rollout_random_shapes_vs_generic_kernel():
         dr32 = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in dr.items()}
         dr32.pop('sel_noise', None)
         got = eng.rollout(B, T, H, mode, pool, **dr32)
+        assert eng.last_rollout_kernel() in ('gemm-stepwise', 'gemm-streamk', 'resident'), (case, hidden, eng.last_rollout_kernel())
         ref = eng.rollout(B, T, H, mode, pool, force_generic=True, **dr32)
         msg = str((case, env, K, hidden, B, T, H, mode))
         assert torch.equal(got.tpath, ref.tpath) and torch.equal(got.done, ref.done), msg
