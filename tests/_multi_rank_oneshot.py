@@ -29,8 +29,10 @@ def main(out_path, path, n_updates):
     dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
-    eng, th, pdims, obs, act, adv, om, ols = _update_problem(N=6000, seed=29)
-    eng.set_update_path({'mfma': True, 'generic': False, 'gemm': 'gemm'}[path])
+    eng, th, pdims, obs, act, adv, om, ols = (_update_problem('humanoid', 6000, seed=29, pol_hidden=(100, 50, 25)) if path == 'f3'      # the fused three-hidden-layer kernels
+                                              else _update_problem(N=6000, seed=29))
+    eng.set_update_path({'mfma': True, 'generic': False, 'gemm': 'gemm', 'f3': True}[path])
+    assert path != 'f3' or eng.update_path(6000) == 'mfma'
     comm = metrpo_amd.Comm()
     assert comm.attach_engine(eng, transport='one-shot') == 'one-shot' and eng.comm_transport() == 'one-shot'
 

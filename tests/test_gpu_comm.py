@@ -25,15 +25,15 @@ def _launch(world, out_file, path, port, extra_env=None, n_updates=1):
     return subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
 
 
-@pytest.mark.parametrize('path,world', [('mfma', 4), ('gemm', 4), ('generic', 2), ('mfma', 8)])
+@pytest.mark.parametrize('path,world', [('mfma', 4), ('gemm', 4), ('generic', 2), ('mfma', 8), ('f3', 4)])
 def test_ranks_on_one_gpu_equal_one_rank(path, world, tmp_path):
     from test_gpu_engine import _update_problem
     out_file = str(tmp_path / 'ranks.npz')
     res = _launch(world, out_file, path, 29531 + world)
     assert res.returncode == 0, (res.stdout[-1500:] + res.stderr[-3000:])
     many = np.load(out_file)
-    eng, th, pdims, obs, act, adv, om, ols = _update_problem(N=6000, seed=29)
-    eng.set_update_path({'mfma': True, 'generic': False, 'gemm': 'gemm'}[path])
+    eng, th, pdims, obs, act, adv, om, ols = (_update_problem('humanoid', 6000, seed=29, pol_hidden=(100, 50, 25)) if path == 'f3' else _update_problem(N=6000, seed=29))
+    eng.set_update_path({'mfma': True, 'generic': False, 'gemm': 'gemm', 'f3': True}[path])
     one = eng.trpo_update(eng.make_batch(obs, act, adv, om, ols), want_vectors=True)
     # float32 partial sums over different sample groupings: 1e-7-relative differences in g, amplified by 10 CG iterations in d
     # (g rel-L2 1e-5, d rel-L2 1e-3)
