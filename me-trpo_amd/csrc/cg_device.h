@@ -126,9 +126,13 @@ template <int R> __device__ __forceinline__ void cg_step_regs(int P, double reg,
         for (int j = 0; j < R; ++j) {
             const int i = threadIdx.x + j * blockDim.x;
             pv[j] = zv[j] = rv[j] = xv[j] = 0.0;
+            // (every load on a clamped address, unconditionally: inside the `i < P` branch the R x 4 loads of a thread were R dependent round trips --
+            //  6 us of the 100-50-25 policy's CG step, tools/fin_phases.py)
+            const int ic = (i < P) ? i : P - 1;
+            const double pl = pf_ ? 0.0 : p[ic], rl = pf_ ? 0.0 : r[ic], xl = pf_ ? 0.0 : x[ic], zl = z[ic];
             if (i < P) {
-                if (pf_) { pv[j] = pre->pv[j < CG_R ? j : 0]; rv[j] = pre->rv[j < CG_R ? j : 0]; xv[j] = pre->xv[j < CG_R ? j : 0]; } else { pv[j] = p[i]; rv[j] = r[i]; xv[j] = x[i]; }
-                zv[j] = z[i] + reg * pv[j]; acc += pv[j] * zv[j];
+                if (pf_) { pv[j] = pre->pv[j < CG_R ? j : 0]; rv[j] = pre->rv[j < CG_R ? j : 0]; xv[j] = pre->xv[j < CG_R ? j : 0]; } else { pv[j] = pl; rv[j] = rl; xv[j] = xl; }
+                zv[j] = zl + reg * pv[j]; acc += pv[j] * zv[j];
             }
         }
         CG_MARK(5)

@@ -12,8 +12,8 @@
 // row of a global partial buffer; k_finalize sums rows in block order -> bitwise reproducible.
 #include "device_common.h"
 #ifdef FIN_TIMING
-__device__ unsigned long long g_fin_phase[64][8];
-#define CG_MARK(i) { if (threadIdx.x == 0) g_fin_phase[blockIdx.x][i] = __builtin_readcyclecounter(); }
+__device__ unsigned long long g_fin_phase[512][8];
+#define CG_MARK(i) { if (threadIdx.x == 0 && blockIdx.x < 512) g_fin_phase[blockIdx.x][i] = __builtin_readcyclecounter(); }
 #endif
 #include "cg_device.h"
 
@@ -282,8 +282,8 @@ __global__ void __launch_bounds__(PT) k_loss_kl(ProblemDesc pd, PolK k, const fl
 // mode 2: loss/kl -> out[0], out[1] from columns (lk_col, lk_col+1)
 #define FIN_C 32
 #ifdef FIN_TIMING      // developer instrumentation (SRC=policy_update.hip tools/build_variant.sh ftiming -DFIN_TIMING; tools/fin_phases.py)
-#define FT_MARK(i) { if (threadIdx.x == 0 && tail.op == 1) g_fin_phase[blockIdx.x][i] = __builtin_readcyclecounter(); }
-extern "C" int32_t metrpo_debug_fin_phases(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fin_phase), sizeof(unsigned long long) * 512) == hipSuccess ? 0 : -1; }
+#define FT_MARK(i) { if (threadIdx.x == 0 && tail.op == 1 && blockIdx.x < 512) g_fin_phase[blockIdx.x][i] = __builtin_readcyclecounter(); }
+extern "C" int32_t metrpo_debug_fin_phases(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fin_phase), sizeof(unsigned long long) * 4096) == hipSuccess ? 0 : -1; }
 #else
 #define FT_MARK(i)
 #endif
