@@ -614,7 +614,10 @@ static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metr
 int run_trpo_update(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_params* pr, metrpo_trpo_diag* diag,
                     double* g_out, double* dir_out, hipStream_t st, int phase, int spec) {
     const int rc = run_trpo_update_impl(c, b, pr, diag, g_out, dir_out, st, phase, spec);
-    if (rc != METRPO_OK) { (void)hipGetLastError(); (void)hipMemsetAsync(c->d_ticket, 0, sizeof(unsigned int), st); c->upd_pending = 0; }
+    if (rc != METRPO_OK) {
+        (void)hipGetLastError(); (void)hipMemsetAsync(c->d_ticket, 0, sizeof(unsigned int), st); c->upd_pending = 0;
+        if (c->d_cgp_bar) (void)hipMemsetAsync(c->d_cgp_bar, 0, 64, st);      // the one-launch CG solve's barrier counters (policy_mfma.hip MODE_CGP), should it have been cut short
+    }
     return rc;
 }
 // Can this update's line search be decided on the device?  Needs the single-launch-sequence update (no host callback / stand-alone
