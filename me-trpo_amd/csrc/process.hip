@@ -650,7 +650,13 @@ __global__ void __launch_bounds__(256) k_baseline_solve(int F, const double* __r
             // (as `i / nc, i % nc` over a flat index the update was 386 us at F = 114, most of it address arithmetic); the same expression per element
             for (int c = k + 1 + (tid & 127); c < W; c += 128) {
                 const double mkc = Ms[k * W + c];
-                for (int r = k + 1 + (tid >> 7); r < F; r += 2) Ms[r * W + c] -= (Ms[r * W + k] * inv) * mkc;
+                int r = k + 1 + (tid >> 7);
+                for (; r + 6 < F; r += 8) {                  // four rows in flight (independent read / multiply / write chains)
+                    const double f0 = Ms[r * W + k] * inv, f1 = Ms[(r + 2) * W + k] * inv, f2 = Ms[(r + 4) * W + k] * inv, f3 = Ms[(r + 6) * W + k] * inv;
+                    const double m0 = Ms[r * W + c], m1 = Ms[(r + 2) * W + c], m2 = Ms[(r + 4) * W + c], m3 = Ms[(r + 6) * W + c];
+                    Ms[r * W + c] = m0 - f0 * mkc; Ms[(r + 2) * W + c] = m1 - f1 * mkc; Ms[(r + 4) * W + c] = m2 - f2 * mkc; Ms[(r + 6) * W + c] = m3 - f3 * mkc;
+                }
+                for (; r < F; r += 2) Ms[r * W + c] -= (Ms[r * W + k] * inv) * mkc;
             }
             __syncthreads();
         }
