@@ -36,6 +36,9 @@ template <> struct EnvDim<METRPO_ENV_ANT>          { static constexpr int NS = 2
 template <> struct EnvDim<METRPO_ENV_HOPPER>       { static constexpr int NS = 11, NA = 3, NDROP = 0; };
 template <> struct EnvDim<METRPO_ENV_SNAKE>        { static constexpr int NS = 14, NA = 4, NDROP = 2; };
 
+#ifndef XOR_SUM_PERMLANE
+#define XOR_SUM_PERMLANE 0      // measured in the resident rollout (29 independent sums per post wave and step): +0.3 .. 0.9 % per rollout -- the LDS crossbar pipelines them better; the update kernels (one or two sums on a tile's dependent chain) take the vector-ALU form
+#endif
 constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 // A value DEFINED in an accumulation register stays there: the matrix instructions read their A operand from either register file, while a value
 // the allocator merely parks in the accumulation half (more than 256 live registers in a one-wave-per-SIMD kernel) is copied back before every
@@ -73,6 +76,14 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 __device__ __forceinline__ float xor_sum(float v) {      // sum over the 4 lanes (e, q=0..3) of one env
+#if XOR_SUM_PERMLANE
+    // v_permlane16_swap / v_permlane32_swap (gfx950): the same butterfly on the vector ALU, bit for bit (policy_mfma.hip: xsum_q)
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+    const u32x2_ a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const u32x2_ b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+#endif
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
     return v;

@@ -67,7 +67,17 @@ __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-__device__ __forceinline__ float xsum_q(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
+// sum over the four q-lanes of a sample (lanes c, c + 16, c + 32, c + 48) on the vector ALU: v_permlane16_swap (odd rows of one copy <-> even rows of the other:
+// the two copies then hold v[row] and v[row ^ 1] between them) and v_permlane32_swap (upper half <-> lower half), gfx950 -- the xor-16 / xor-32 butterfly
+// (v + v[lane ^ 16]) + (..)[lane ^ 32] bit for bit (the additions commute), without the two ds_bpermute round trips per sum that sat on every tile's
+// dependent chain (4 per tile in the Fisher-vector product)
+__device__ __forceinline__ float xsum_q(float v) {
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+    const u32x2_ a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const u32x2_ b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 // sum over the 16 lanes c of a row, on the VALU's DPP path (quad swaps, then half-row and row mirrors: after each step the lanes that are
 // exchanged hold equal partial sums, so this is the xor-1, 2, 4, 8 butterfly bit for bit).  The epilogue runs ~45 of these per wave: as
 // ds_bpermute chains (__shfl_xor) they were 6 us of every launch, measured with tools/pol_phases.py.
