@@ -14,6 +14,7 @@
 //     across all tiles of the wave;
 //   * waves -> block partial (LDS, fixed order) -> global partial row -> k_finalize (fixed order,
 //     float64): bitwise reproducible.
+#include <type_traits>
 #include "device_common.h"
 #include "cg_device.h"
 
@@ -37,6 +38,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // 115 k cycles at 7 : 6): 4 : 3 measured best of {5, 7, 9, 11, 13} (FVP 63.5 -> 62.2 us, evaluation 34.4 -> 32.8 us under the kernel tracer; the
 // gradient kernel keeps 7 : 6, 71.5 vs 72.0).
 #define POL_SPLIT_R_FVP 7
+#endif
+#ifndef POL_DEFER_S7
+// 1: the sample-contracted weight-gradient products of a tile (S7: 24 matrix instructions at 2 x 32, na <= 2) are issued ONE TILE LATER, in four groups placed
+// inside the next tile's vector-ALU stretch (output layer, tanh' factors, deltas: ~95 instructions with no matrix instruction of their own) -- their operands
+// wait in 28 registers.  Same products in the same order: the same sums bit for bit.
+#define POL_DEFER_S7 0      // measured (round 5): Fisher-vector product 59.8 -> 60.5 us at C1 -- the stretch is already covered by the SIMD's other wave; off
 #endif
 #ifndef NWAVES
 #define NWAVES 8                // waves per block: one block per CU (2 waves per SIMD), the weight image is shared by all 8
@@ -364,6 +371,28 @@ __device__ __forceinline__ void pol_body(const PolK& k, const float* __restrict_
     float dls[4] = {0.f, 0.f, 0.f, 0.f};
     float acc0 = 0.f, acc1 = 0.f, accw = 0.f;               // loss, kl, valid weight (per-lane partials)
 
+    constexpr bool DEFER = POL_DEFER_S7 && (NA <= 2) && MODE != MODE_LOSSKL;
+    f32x4 qa0[HB], qb1[HB], qd0[HB]; float qxT[4][NSI];     // DEFER: S7 operands of the previous tile (zeros in front of the first: its run adds nothing)
+#pragma unroll
+    for (int cb = 0; cb < HB; ++cb) { qa0[cb] = Z4; qb1[cb] = Z4; qd0[cb] = Z4; }
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+        for (int ci = 0; ci < NSI; ++ci) qxT[s_][ci] = 0.f;
+    auto s7_step = [&](auto sc) {                           // k-step s of the pending tile's products (samples 4q + s)
+        constexpr int s_ = decltype(sc)::value;
+        if constexpr (DEFER) {
+#pragma unroll
+            for (int ci = 0; ci < HB; ++ci)
+#pragma unroll
+                for (int cj = 0; cj < HB; ++cj) gW1[ci][cj] = MFMA16(qa0[ci][s_], qb1[cj][s_], gW1[ci][cj]);
+#pragma unroll
+            for (int ci = 0; ci < NSI; ++ci)
+#pragma unroll
+                for (int cj = 0; cj < HB; ++cj) gW0[ci][cj] = MFMA16(qxT[s_][ci], qd0[cj][s_], gW0[ci][cj]);
+        }
+    };
+#define S7_STEP(n) s7_step(std::integral_constant<int, (n)>{})
     // vmcnt(0) HERE: otherwise the wait for these first loads is placed inside the loop, at the top of every iteration, right
     // behind the prefetch of the next tile -- which it then waits for as well
     __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -457,6 +486,7 @@ __device__ __forceinline__ void pol_body(const PolK& k, const float* __restrict_
             for (int cb = 0; cb < HB; ++cb) { hw[cb * 64] = h0[cb]; hw[(HB + cb) * 64] = h1[cb]; }
         }
 
+        S7_STEP(0);
         if (POL_PRIO == 2) __builtin_amdgcn_s_setprio(2);
         f32x4 um = Z4;                                      // d(objective)/d(mean) in D layout [d = 4q+r][sample c]
         float ual[NAV];                                     // FVP with the VALU output layer: the sample's mean-adjoint, already in all of its lanes
@@ -568,6 +598,7 @@ __device__ __forceinline__ void pol_body(const PolK& k, const float* __restrict_
                 um[r] = (ok && 4 * q + r < NA) ? (m0[r] + m1[r]) * fisher_w[r] * k.inv_n : 0.f;
             if (ok && q == 0) accw += k.inv_n;
         }
+        S7_STEP(1);
         // ---- S5/S6: back-prop (transposed chain); deltas go straight into their transpose tiles ---------------------
         f32x4 d1[HB], d0n[HB];                              // d0n: layer-0 deltas in the OTHER orientation, [sample 4q+r][unit c] (see S6)
 #pragma unroll
@@ -601,12 +632,14 @@ __device__ __forceinline__ void pol_body(const PolK& k, const float* __restrict_
                 for (int cb = 0; cb < HB; ++cb) d1[cb] = MFMA16(FRAG2(I::O_W2B, r, cb), um[r], d1[cb]);
             }
         }
+        S7_STEP(2);
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb) {
             d0n[cb] = Z4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { d1[cb][r] *= fmaf(-h1[cb][r], h1[cb][r], 1.f); T_D1[cb * TILE + (4 * q + r) * TS + wpos] = d1[cb][r]; }
         }
+        S7_STEP(3);
         if (POL_PRIO == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
@@ -634,8 +667,16 @@ __device__ __forceinline__ void pol_body(const PolK& k, const float* __restrict_
             gb0[cb] += d0n[cb];
         }
         if (!L2V) buv = *(const f32x4*)&T_UM[c * TS + 4 * q];
+        if constexpr (DEFER) {                              // this tile's products run inside the next tile (or behind the loop)
 #pragma unroll
-        for (int s = 0; s < ((POL_SKIP & 2) ? 0 : 4); ++s) {
+            for (int cb = 0; cb < HB; ++cb) { qa0[cb] = a0v[cb]; qb1[cb] = b1v[cb]; qd0[cb] = d0n[cb]; }
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                for (int ci = 0; ci < NSI; ++ci) qxT[s_][ci] = xTs[s_][ci];
+        }
+#pragma unroll
+        for (int s = 0; s < ((DEFER || (POL_SKIP & 2)) ? 0 : 4); ++s) {
             const float bu = buv[s];
             float a1_[HB], a0_[HB], b1_[HB], b0_[HB], xT[NSI];
 #pragma unroll
@@ -658,6 +699,8 @@ __device__ __forceinline__ void pol_body(const PolK& k, const float* __restrict_
         }
         wave_sync_lds();
     }
+    S7_STEP(0); S7_STEP(1); S7_STEP(2); S7_STEP(3);       // the last tile's products
+#undef S7_STEP
 #undef FRAG2
 #undef FRAG1
 
