@@ -23,9 +23,9 @@
 //
 // Inter-workgroup visibility (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"):
 //   tile -> closer:   output partials by 16-byte sc1 (write-through) stores, every wave drains (vmcnt 0), workgroup barrier, ONE agent-scope atomic add on the row
-//                     block's counter.  The closer: relaxed agent-scope poll, one-lane agent acquire (L1 invalidate), barrier, plain loads;
+//                     block's counter.  The closer: relaxed agent-scope poll, barrier, sc1 loads of the partials (SKP_NO_FENCES = 0: a one-lane agent acquire first);
 //   closer -> tiles:  X rows by sc1 stores; S / U / ts / cur_model (read by the same closer one step later) by plain stores; every wave drains, barrier, one-lane
-//                     agent release + drain, relaxed agent store of the flag.  A tile's waves poll the flag and read their X rows with agent-scope loads.
+//                     relaxed agent store of the flag (SKP_NO_FENCES = 0: an agent release + drain in front of it).  A tile's waves poll the flag and read their X rows with agent-scope loads.
 // Waits are bounded (2 s) and report through the sticky rollout error cell; the launch needs its whole grid on the chip (one workgroup per CU:
 // grid_is_coresident, probe.hip) -- otherwise, and for every shape outside (two hidden layers, producer-sized input, 2 x 32 policy), the launch-per-step
 // path runs.  Summation order of every output: the k-ordered chain of an unsplit k_mlp_sk tile -- bit for bit the launch-per-step path's results.
@@ -57,6 +57,12 @@ struct SkpArgs {
 __global__ void k_skp_post_args(SkpPost v, SkpPost* dst) { if (threadIdx.x == 0) *dst = v; }
 
 enum { SKP_HALT = 0x40000000, SKP_NOHALT = 0x7fffffff };      // ready-flag value "nothing behind the stop step is computed any more" | misc[2] before the stop step is known
+// 1 (round 5): the closing workgroups issue no cache-wide release / acquire.  What crosses workgroups inside the launch already travels by sc1 stores and loads (the
+// tiles' partials, the X rows); S / U / ts / cur_model are read back by the closer that wrote them; the trajectory tensors are read behind the launch.  Closing 17.5 -> 17.2 us
+// at C3, rollouts 110.5 -> 110.2 / 47.2 -> 47.1 ms (C3 / C2); bitwise tests and the 400-rollout soak unchanged.
+#ifndef SKP_NO_FENCES
+#define SKP_NO_FENCES 1
+#endif
 enum { SKP_NCLOSE = 8 };                           // most closing workgroups of a launch (SkpArgs::nclose of them: blockIdx 0 .. nclose - 1, on different XCDs)
 
 // Step t closed and step t + 1 prepared for the 128 envs of row block rb, by all 8 waves of a closing workgroup: the wave functions of the launch-per-step
@@ -81,8 +87,10 @@ __device__ __forceinline__ void skp_close_and_prepare(const SkpPost* __restrict_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   // every writing wave drains
     __syncthreads();
     if (threadIdx.x == 0) {
+#if !SKP_NO_FENCES
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               // (the compiler may drop the wait behind buffer_wbl2: restated where it cannot)
+#endif
         __hip_atomic_store(xflag + rb, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -116,7 +124,9 @@ __device__ __forceinline__ void skp_closer_role(const SkpArgs& p, float* lds) {
                     if (wall_clock64() - w0 > 200000000ull) { __hip_atomic_store(p.a.err, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }      // 2 s at 100 MHz
                     if (__hip_atomic_load(p.a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) break;
                 }
+#if !SKP_NO_FENCES
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");             // the tiles' partials; (S / U / ts / cur_model are this workgroup's own stores of a step ago)
+#endif
                 sh[0] = go;
             }
             __syncthreads();
