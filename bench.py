@@ -199,19 +199,23 @@ def main():
     from metrpo_amd.tracing import timing_event          # HIP events with a device-scope release: a torch.cuda.Event record costs the next kernel 6-15 us
     ev_roll, ev_upd, ev_iter, steps_run, n_valid = [], [], [], [], []
 
-    def step(j, timed):
-        algo.rollout_events = ev_roll if timed else None      # HIP events recorded around the rollout launch(es) themselves
-        if timed:
+    def step(j, timed, events=False):
+        # `events`: HIP events around the rollout launch(es), the update and the iteration.  They are NOT recorded in the timed region: every record is a
+        # marker packet between two dependent kernels (3-6 us each, five per iteration = 1-1.5 % of a C1 iteration); the per-phase figures of the line come
+        # from a second, instrumented pass over the same iterations behind the timed one
+        algo.rollout_events = ev_roll if events else None     # HIP events recorded around the rollout launch(es) themselves
+        if events:
             ei = timing_event(); ei.record(); ev_iter.append(ei)
         algo.start_worker()
         paths = algo.obtain_samples(j)
         samples = algo.process_samples(j, paths)
-        if timed:
+        if events:
             e0, e1 = timing_event(), timing_event()
             e0.record()
         algo.optimize_policy(j, samples)
-        if timed:
+        if events:
             e1.record(); ev_upd.append((e0, e1))
+        if timed:
             steps_run.append(paths.traj.T); n_valid.append(samples['n_valid_global'])
 
     # The host meets the device once per iteration (the line search reads its trial back), so a stop-the-world pass of Python's cyclic
@@ -230,9 +234,16 @@ def main():
     for j in range(args.steps):
         step(args.warmup + j, True)
     algo.optimizer.finish()                                   # the last update's line search is closed inside the timed region
-    ei = timing_event(); ei.record(); ev_iter.append(ei)
     comm.barrier(); torch.cuda.synchronize()
     dt = comm.max_float(time.perf_counter() - t0, device='cuda' if backend == 'nccl' else 'cpu')
+    # instrumented pass (untimed): the same iterations with HIP events around rollout / update / iteration.  Iterations of tens of ms and more
+    # (C2 / C3 / C4) do not feel the events: a few of them are enough
+    n_inst = args.steps if dt / args.steps < 0.05 else max(1, min(args.steps, 3))
+    for j in range(n_inst):
+        step(args.warmup + args.steps + j, False, events=True)
+    algo.optimizer.finish()
+    ei = timing_event(); ei.record(); ev_iter.append(ei)
+    comm.barrier(); torch.cuda.synchronize()
     if gc_was:
         gc.enable()
     # the time-dominant kernel of the update, measured live: one more (untimed) iteration with HIP events around every Fisher-vector-product KERNEL of
@@ -240,7 +251,7 @@ def main():
     fvp_us, fvp_n = float('nan'), 0
     try:
         eng.set_option('TIME_FVP', '1')
-        step(args.warmup + args.steps, False)
+        step(args.warmup + args.steps + n_inst, False)
         algo.optimizer.finish()
         torch.cuda.synchronize()
         fvp_us, fvp_n = eng.fvp_kernel_us()
@@ -322,6 +333,9 @@ def main():
                                % (args.config, env, K, list(cfg['dyn_hidden']), list(cfg['pol_hidden']), B, args.scaling, cfg['B'], cfg['gpus'], H, T_mean, int(bool(algo.device_baseline_fit)), int(bool(algo.async_line_search))),
                    "parallelism": "B-sharded x%d, sum all-reduce of g/FVP/scalars" % comm.world},
         "trpo_iter_ms": ms_per_step,
+        "instrumented_pass": {"iterations": n_inst, "ms_per_step": comm.max_float(float(np.mean(iter_ms)), device=side),
+                              "note": "rollout.ms, roofline.update.ms and ms_per_step_median come from this second pass over the same iterations with HIP events "
+                                      "around the rollout launch, the update and the iteration; the timed region (ms_per_step, value) records no events"},
         "preflight": preflight_rep,
         "rollout": {"ms": roll_ms, "env_steps_per_s": units_per_step / (roll_ms * 1e-3),
                     "kernel": eng.last_rollout_kernel() or {3: "gemm-stepwise", 2: "mfma-cooperative", 1: "mfma-head-per-wave", 0: "generic"}[variant]},

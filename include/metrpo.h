@@ -222,6 +222,11 @@ int32_t metrpo_validation_cost(metrpo_ctx* ctx, const float* d_s0, int32_t Bv, i
 int32_t metrpo_gae(metrpo_ctx* ctx, const float* d_obs, const float* d_rew, const uint8_t* d_done,
                    const int32_t* d_tpath, int32_t T, int32_t B, const double* d_coeffs, double gamma,
                    double lam, float* d_adv, float* d_ret, uint8_t* d_valid, double* d_stats, void* stream);
+/* Opening launch of process_samples (samplers/base.py:48-104): d_old_log_std [na] <- max(log_std of the ctx policy, log 1e-6) -- the
+ * agent_infos['log_std'] every sample of the batch carries ([rllab] GaussianMLPPolicy.dist_info, min_std = 1e-6; vectorized_sampler.py:72-77) -- and
+ * d_acc [n_acc] float64 <- 0 (the accumulators metrpo_gae / metrpo_baseline_gram add into).  Either pointer may be NULL.  One launch, stream-ordered:
+ * call it after the rollout was enqueued and before the policy is updated. */
+int32_t metrpo_process_begin(metrpo_ctx* ctx, float* d_old_log_std, double* d_acc, int64_t n_acc, void* stream);
 /* [rllab] util.center_advantages (base.py:82-83): adv <- (adv-mean)/(std+1e-8) over valid samples,
  * mean/std from d_stats (after the caller all-reduced it across ranks). */
 int32_t metrpo_center_advantages(metrpo_ctx* ctx, float* d_adv, const uint8_t* d_valid, int64_t N,

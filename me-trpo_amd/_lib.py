@@ -89,6 +89,7 @@ SYMBOLS = {
     'metrpo_sampler_progress': (_I, [_P, _P, _P, _I, _I, _I, _L, _P, _P, _P, _P]),
     'metrpo_validation_cost': (_I, [_P, _P, _I, _I, _D, _P, _P]),
     'metrpo_gae': (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _D, _D, _P, _P, _P, _P, _P]),
+    'metrpo_process_begin': (_I, [_P, _P, _P, _L, _P]),
     'metrpo_center_advantages': (_I, [_P, _P, _P, _L, _P, _P]),
     'metrpo_baseline_gram': (_I, [_P, _P, _P, _P, _P, _L, _P, _P, _P]),
     'metrpo_baseline_solve': (_I, [_P, _P, _P, _D, _P, _P]),

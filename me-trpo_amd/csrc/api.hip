@@ -438,6 +438,14 @@ extern "C" int32_t metrpo_gae(metrpo_ctx* c, const float* obs, const float* rew,
     return launch_gae(c, obs, rew, done, tpath, T, B, coeffs, gamma, lam, adv, ret, valid, stats, (hipStream_t)stream);
 }
 
+extern "C" int32_t metrpo_process_begin(metrpo_ctx* c, float* old_log_std, double* acc, int64_t n_acc, void* stream) {
+    TraceRange trace_("metrpo:process_samples:begin");
+    if (!c) return METRPO_ENULL;
+    if (n_acc < 0 || (n_acc > 0 && !acc)) return set_err(c, METRPO_EINVAL, "process_begin: bad accumulator range");
+    if (!old_log_std && n_acc == 0) return METRPO_OK;
+    return launch_process_begin(c, old_log_std, n_acc > 0 ? acc : nullptr, n_acc, (hipStream_t)stream);
+}
+
 extern "C" int32_t metrpo_center_advantages(metrpo_ctx* c, float* adv, const uint8_t* valid, int64_t N,
                                             const double* stats, void* stream) {
     TraceRange trace_("metrpo:process_samples:center");
@@ -653,6 +661,11 @@ static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metr
     CgTail tl; tl.pub_dst = nullptr; tl.pub_stamp = 0; tl.P = P; tl.last = 0; tl.implicit_hd = implicit_hd; tl.reg = pr->reg_coeff; tl.tol = pr->residual_tol; tl.max_kl = pr->max_kl;
     tl.x = v.x; tl.r = v.r; tl.p = v.p; tl.z = v.z; tl.step = v.step; tl.scal = v.scal; tl.gout = v.gout; tl.pf = c->d_vf; tl.ticket = c->d_ticket;
     tl.vpos = nullptr; tl.imgval = nullptr; tl.ls = nullptr; tl.lk = nullptr; tl.th = nullptr; tl.th_try = nullptr; tl.trial = 0; tl.accept_violation = 0;
+    const int nspec = std::min(spec, (int)pr->max_backtracks);
+    // Device-decided line search (phase 1): theta of trial 0 is built by the tail that finishes the step size, theta of trial n + 1 by trial n's accept test
+    // when the search goes on (cg_device.h: CgTail::nx_*) -- no k_try_theta launches in front of the evaluations.  Where the step does not come out of a
+    // cg_tail_run (one-launch solve, cg_iters = 0, explicit H.d without a fused tail) the launches stay.
+    bool try0_built = false;
     if (phase != 2) {
     tl.op = 3;
     c->hcache_on = 1;                    // the gradient kernel publishes tanh activations, the CG products of this solve reuse them
@@ -681,8 +694,11 @@ static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metr
         if (rc == METRPO_OK) { cg_done = true; c->cgp_launches += 1; }
         else if (rc != METRPO_EUNSUPPORTED) return rc;
     }
+    const bool fold_try = (phase == 1 && nspec >= 1);
+    auto arm_try0 = [&]() { tl.nx_try = c->d_theta_try; tl.nx_prev = c->d_theta; tl.nx_ratio = 1.0; tl.nx_ls = v.ls; try0_built = true; };      // backtrack_ratio ^ 0
     for (int i = 0; i < pr->cg_iters && !cg_done; ++i) {
         tl.op = 1; tl.last = (i == pr->cg_iters - 1) ? 1 : 0;
+        if (fold_try && tl.last && implicit_hd) arm_try0();
         if (fused) { if ((rc = launch_fvp_tail(c, b, c->d_vf, v.p, v.z, &tl, st))) return rc; continue; }
         if ((rc = launch_fvp_f32(c, b, c->d_vf, v.p, v.z, st))) return rc;
         AR(v.z, P);
@@ -690,6 +706,7 @@ static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metr
     }
     if (!implicit_hd && pr->cg_iters > 0) {                      // rllab's literal route: one more f_Hx on the descent direction
         tl.op = 2; tl.last = 0;
+        if (fused && fold_try) arm_try0();
         if (fused) { if ((rc = launch_fvp_tail(c, b, c->d_vf, v.x, v.z, &tl, st))) return rc; }
         else {
             if ((rc = launch_fvp_f32(c, b, c->d_vf, v.x, v.z, st))) return rc;
@@ -697,11 +714,10 @@ static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metr
             hipLaunchKernelGGL(k_cg_finish, dim3(1), dim3(1024), 0, st, P, pr->reg_coeff, pr->max_kl, v.x, v.z, v.step, v.scal);
         }
     }
-    tl.vpos = nullptr; tl.imgval = nullptr;
+    tl.vpos = nullptr; tl.imgval = nullptr; tl.nx_try = nullptr; tl.nx_prev = nullptr; tl.nx_ls = nullptr;
     if (g_out) HIP_TRY(c, hipMemcpyAsync(g_out, v.gout + 1, sizeof(double) * P, hipMemcpyDeviceToDevice, st));
     if (dir_out) HIP_TRY(c, hipMemcpyAsync(dir_out, v.x, sizeof(double) * P, hipMemcpyDeviceToDevice, st));
     }
-    const int nspec = std::min(spec, (int)pr->max_backtracks);
     if (phase == 1) {
         // ---- the first `nspec` trials of the backtracking line search, each one's accept test in the tail of its own reduction (ls_decide): an
         //      accepted trial's theta is in place when the caller's next launch reads it; trials after the one that stopped the search leave at once
@@ -711,9 +727,10 @@ static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metr
         for (int n = 0; n < nspec; ++n) {
             const double ratio = std::pow(pr->backtrack_ratio, (double)n);
             // trial 0 opens the search (ls reset rides in its k_try_theta), the last trial's reduction publishes the outcome: no launches of their own
-            hipLaunchKernelGGL(k_try_theta, dim3((P + 255) / 256), dim3(256), 0, st, P, ratio, c->d_theta, v.step, c->d_theta_try,
-                               (n == 0) ? (const double*)nullptr : (const double*)v.ls, (n == 0) ? v.ls : (double*)nullptr);
+            if (n == 0 && !try0_built)
+                hipLaunchKernelGGL(k_try_theta, dim3((P + 255) / 256), dim3(256), 0, st, P, ratio, c->d_theta, v.step, c->d_theta_try, (const double*)nullptr, v.ls);
             CgTail dt = tl;
+            if (n + 1 < nspec) { dt.nx_try = c->d_theta_try; dt.nx_prev = c->d_theta; dt.nx_ratio = std::pow(pr->backtrack_ratio, (double)(n + 1)); dt.nx_ls = nullptr; }
             dt.op = 4; dt.ls = v.ls; dt.lk = v.lk; dt.th = c->d_theta; dt.th_try = c->d_theta_try; dt.trial = n; dt.accept_violation = pr->accept_violation;
             if (n == nspec - 1) { dt.pub_dst = c->h_upd; dt.pub_stamp = c->upd_stamp; }
             if ((rc = launch_loss_kl(c, b, c->d_theta_try, v.lk, st, &dt))) return rc;

@@ -29,6 +29,9 @@ struct CgTail {
     int trial, accept_violation;
     double* pub_dst;        // non-NULL on the LAST speculated trial: its reduction also publishes scal[8] | lk[2] | ls[4] to pinned host memory,
     unsigned long long pub_stamp;   // followed by this stamp at pub_dst[16] (ls_publish) -- what k_ls_publish does as a launch of its own
+    // The NEXT line-search trial's theta, built where its inputs appear instead of by a k_try_theta launch of its own (api.hip): behind the step-size
+    // finish (ops 1 / 2: trial 0, which also opens the search: nx_ls <- "not stopped yet") and behind a trial's accept test when the search goes on (op 4).
+    float* nx_try = nullptr; const float* nx_prev = nullptr; double nx_ratio = 1.0; double* nx_ls = nullptr;
 };
 
 // float copy of the next FVP input, element i; mirrored into the weight-fragment image the cached-activation FVP copies (see CgTail::vpos)
@@ -312,6 +315,18 @@ __device__ __forceinline__ void ls_decide(const CgTail& t) {
     } else if (threadIdx.x == 0) { t.ls[1] = loss; t.ls[2] = kl; }
 }
 
+// cur_param = prev_param - ratio * flat_descent_step (ConjugateGradientOptimizer.optimize's trial point; k_try_theta's arithmetic).  One block, all threads,
+// behind a barrier that follows the writes of t.step.
+__device__ __forceinline__ void ls_next_theta(const CgTail& t) {
+    for (int i = threadIdx.x; i < t.P; i += blockDim.x) t.nx_try[i] = (float)((double)t.nx_prev[i] - t.nx_ratio * t.step[i]);
+}
+__device__ __forceinline__ void ls_open_and_first_theta(const CgTail& t) {
+    if (t.nx_try == nullptr) return;
+    __syncthreads();
+    if (t.nx_ls != nullptr && threadIdx.x == 0) { t.nx_ls[0] = -1.0; t.nx_ls[1] = NAN; t.nx_ls[2] = NAN; t.nx_ls[3] = 0.0; }
+    ls_next_theta(t);
+}
+
 // The update's outcome (scal[8] | lk[2] | ls[4], contiguous at t.scal) into pinned host memory, then the stamp the host is polling for.  One wave:
 // program order + vmcnt.  System-scope stores bypass L2; once the wave's own stores are acknowledged the stamp may follow -- a system-scope
 // FENCE here would write back the whole L2 (15 us that the next kernel on the stream waits for).  Call behind a __syncthreads().
@@ -329,11 +344,13 @@ __device__ __forceinline__ void cg_tail_run(const CgTail& t, double* sh, const C
         if (t.last && t.implicit_hd) {
             __syncthreads();
             cg_finish_implicit(t.P, t.max_kl, t.x, t.r, t.gout + 1, t.step, t.scal, sh);
+            ls_open_and_first_theta(t);
         }
-    } else if (t.op == 2) cg_finish_body(t.P, t.reg, t.max_kl, t.x, t.z, t.step, t.scal, sh);
+    } else if (t.op == 2) { cg_finish_body(t.P, t.reg, t.max_kl, t.x, t.z, t.step, t.scal, sh); ls_open_and_first_theta(t); }
     else if (t.op == 3) cg_init_body(t.P, t.gout, t.x, t.r, t.p, PfOut{t.pf, t.vpos, t.imgval}, t.scal, sh);
     else if (t.op == 4) {
         ls_decide(t);
+        if (t.nx_try != nullptr && !(t.lk[0] < t.scal[S_LOSS0] && t.lk[1] <= t.max_kl)) ls_next_theta(t);      // the search goes on (ls_decide's test, uniform over the block)
         if (t.pub_dst != nullptr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); ls_publish(t.scal, t.pub_dst, t.pub_stamp); }
     }
 }

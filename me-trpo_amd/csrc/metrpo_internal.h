@@ -240,6 +240,7 @@ int launch_validation_cost(metrpo_ctx*, const float*, int, int, double, double*,
 int launch_gae(metrpo_ctx*, const float*, const float*, const uint8_t*, const int32_t*, int, int, const double*,
                double, double, float*, float*, uint8_t*, double*, hipStream_t);
 int launch_center(metrpo_ctx*, float*, const uint8_t*, int64_t, const double*, hipStream_t);
+int launch_process_begin(metrpo_ctx*, float*, double*, int64_t, hipStream_t);
 int launch_sampler_progress(metrpo_ctx*, const uint8_t*, const int32_t*, int, int, int, long long, double*, double*, int32_t*, hipStream_t);
 int launch_baseline_solve(metrpo_ctx*, const double* AtA, const double* Aty, double reg, double* coeffs, hipStream_t);
 int launch_gram(metrpo_ctx*, const float*, const float*, const int32_t*, const uint8_t*, int64_t, double*, double*,

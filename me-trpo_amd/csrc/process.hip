@@ -609,6 +609,21 @@ int launch_gae(metrpo_ctx* c, const float* obs, const float* rew, const uint8_t*
     return METRPO_OK;
 }
 
+// Opening launch of process_samples (metrpo_process_begin): the clamped log_std of the policy that generated the batch (agent_infos['log_std'],
+// [rllab] GaussianMLPPolicy: max(log_std, log min_std)) and the zero fill of the iteration's float64 accumulators (advantage statistics | AtA | Aty)
+// in ONE launch -- as separate operations (a copy of theta, a clamp, a fill) they were three dependent launches between the rollout and k_gae.
+__global__ void k_process_begin(const float* __restrict__ theta, int P, int na, float* __restrict__ ls_out, double* __restrict__ acc, int64_t n_acc) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (acc != nullptr && i < n_acc) acc[i] = 0.0;
+    if (ls_out != nullptr && i < na) { const float v = theta[P - na + i]; ls_out[i] = (v < LOG_MIN_STD) ? LOG_MIN_STD : v; }     // NaN stays NaN, as torch.clamp leaves it
+}
+int launch_process_begin(metrpo_ctx* c, float* ls_out, double* acc, int64_t n_acc, hipStream_t st) {
+    const int64_t n = std::max<int64_t>(n_acc, (int64_t)c->pd.na);
+    hipLaunchKernelGGL(k_process_begin, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)c->d_theta, c->pd.P, c->pd.na, ls_out, acc, n_acc);
+    HIP_TRY(c, hipGetLastError());
+    return METRPO_OK;
+}
+
 int launch_center(metrpo_ctx* c, float* adv, const uint8_t* valid, int64_t N, const double* stats, hipStream_t st) {
     const int bs = 256;
     const int grid = (int)std::min<int64_t>((N + bs - 1) / bs, (int64_t)c->n_sm * 8);

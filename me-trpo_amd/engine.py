@@ -399,6 +399,15 @@ class Engine(object):
                                  self._stream()))
         return adv, ret, valid, stats
 
+    def process_begin(self, n_acc):
+        """-> (old_log_std [na] float32, acc [n_acc] float64 zeros): metrpo_process_begin, one launch for what policy.log_std() + torch.zeros are as three.
+        Closes an update that is only enqueued first (as get_policy does): the snapshot must see the policy the rollout ran with."""
+        self._close_open_update()
+        ls = torch.empty(self.na, dtype=torch.float32, device=self.device)
+        acc = torch.empty(int(n_acc), dtype=torch.float64, device=self.device)
+        self._chk(lib.metrpo_process_begin(self._ctx, _ptr(ls), _ptr(acc), int(n_acc), self._stream()))
+        return ls, acc
+
     def center_advantages(self, adv, valid, stats):
         self._chk(lib.metrpo_center_advantages(self._ctx, _ptr(adv), _ptr(valid), adv.numel(), _ptr(stats), self._stream()))
         return adv

@@ -21,6 +21,7 @@ class DevicePaths(object):
 
     def __init__(self, traj, log_std, n_complete_samples):
         self.traj, self.log_std, self.n_complete_samples = traj, log_std, n_complete_samples
+        self.acc = None                      # zeroed float64 accumulators for process_samples (Engine.process_begin), consumed once
 
     def __len__(self):
         return int(self.traj.done.sum().item())
@@ -56,7 +57,10 @@ class BaseSampler(object):
         self.finish_baseline_fit()             # deferred solve of the previous iteration (overlaps the rollout just launched)
         coeffs = getattr(algo.baseline, 'coeffs_for_kernel', None) if hasattr(algo.baseline, 'coeffs_for_kernel') else algo.baseline.coeffs
         F = 2 * eng.ns + 4
-        acc = torch.zeros(3 + F * F + F, dtype=torch.float64, device=eng.device)     # one fill: [advantage statistics | AtA | Aty]
+        acc = getattr(paths, 'acc', None)                       # zeroed by obtain_samples' process_begin launch; used once
+        if acc is None or acc.numel() != 3 + F * F + F:
+            acc = torch.zeros(3 + F * F + F, dtype=torch.float64, device=eng.device)     # one fill: [advantage statistics | AtA | Aty]
+        paths.acc = None
         adv, ret, valid, stats = eng.gae(tr, coeffs, algo.discount, algo.gae_lambda, stats=acc[:3])
         comm.allreduce_sum_(stats)
         # fixed-horizon envs: every sample is valid and the global count is known without a host sync
@@ -163,8 +167,15 @@ class VectorizedSampler(BaseSampler):
         if ev is not None:
             e1.record()
             ev.append((e0, e1))
-        log_std = algo.policy.log_std()
-        return DevicePaths(traj, log_std, None)
+        if hasattr(eng, 'process_begin'):
+            # one launch: the batch's agent_infos['log_std'] (what policy.log_std() returns) + the zeroed accumulators process_samples adds into
+            F = 2 * eng.ns + 4
+            log_std, acc = eng.process_begin(3 + F * F + F)
+        else:
+            log_std, acc = algo.policy.log_std(), None
+        paths = DevicePaths(traj, log_std, None)
+        paths.acc = acc
+        return paths
 
     def _obtain_until_enough(self, B, H, sam_mode, pool, draws, common):
         """Early-terminating envs.  The reference steps all envs once, adds the lengths of the paths that just completed to

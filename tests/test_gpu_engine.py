@@ -751,6 +751,49 @@ def test_trpo_update_in_two_halves_equals_one_call(use_mfma):
         eng._upd_open = (batch, None, None, None, 1); eng.trpo_update_end()
 
 
+@pytest.mark.parametrize('explicit', [False, True])
+def test_trial_thetas_built_in_the_tails_equal_the_launches(explicit):
+    """Device-decided line search: theta of trial 0 comes out of the tail that finishes the step size (CG recurrence or, explicit_final_hvp, the extra
+    product), theta of trial n + 1 out of trial n's accept test (cg_device.h CgTail::nx_*) -- against the synchronous update, whose trial points are
+    k_try_theta launches: same policy, same trial index, bit for bit, for searches that stop at trial 0, in the middle and behind the speculated trials."""
+    eng, th, pdims, obs, act, adv, om, ols = _update_problem(N=6000, seed=29)
+    seen = set()
+    for scale in (1.0, 40.0, 400.0):
+        batch = eng.make_batch(obs, act, adv * scale, om, ols)
+        eng.set_policy(th)
+        ref = eng.trpo_update(batch, explicit_final_hvp=explicit)
+        th_ref = eng.get_policy().clone()
+        seen.add(ref['n_backtrack'])
+        for S in (1, 3, 6):
+            eng.set_policy(th)
+            assert eng.trpo_update(batch, explicit_final_hvp=explicit, spec_trials=S) is None
+            out = eng.trpo_update_end()
+            assert torch.equal(eng.get_policy(), th_ref), (scale, S)
+            for key in ('loss_before', 'loss', 'kl', 'beta', 'n_backtrack', 'accepted', 'cg_iters_run'):
+                assert out[key] == ref[key], (key, scale, S)
+    assert max(seen) >= 1, seen                                  # at least one search goes past trial 0 (theta of trial n + 1 built by trial n's accept test)
+
+
+def test_process_begin_is_log_std_clamp_plus_zero_fill():
+    """metrpo_process_begin: [rllab] GaussianMLPPolicy's clamped log_std of the ctx policy (what policy.log_std() = clamp(get_policy()[-na:]) returns) and
+    the zeroed accumulators, one launch; a log_std below log 1e-6 and a NaN behave as torch.clamp does."""
+    import math
+    eng, dm, theta, pdims, pool = Hh.make_engine('half_cheetah', 2, (64, 64), (32, 32), seed=3)
+    na = dm.na
+    th = np.asarray(theta, dtype=np.float32).copy()
+    th[-na] = -15.0; th[-na + 1] = -0.3; th[-na + 2] = float('nan')
+    eng.set_policy(th)
+    want = torch.clamp(eng.get_policy()[-na:], min=float(np.log(1e-6)))
+    ls, acc = eng.process_begin(3 + 40 * 40 + 40)
+    assert ls.dtype == torch.float32 and acc.dtype == torch.float64 and acc.numel() == 1643
+    assert torch.equal(torch.nan_to_num(ls, nan=7.0), torch.nan_to_num(want, nan=7.0)) and math.isnan(float(ls[2]))
+    assert float(ls[0]) == float(np.float32(np.log(1e-6)))
+    assert torch.count_nonzero(acc).item() == 0
+    acc.fill_(3.0)
+    ls2, acc2 = eng.process_begin(5)
+    assert acc2.numel() == 5 and torch.count_nonzero(acc2).item() == 0
+
+
 def test_deferred_optimizer_closes_after_the_next_rollout():
     """algos.async_line_search: optimize_policy only enqueues the update; the next obtain_samples enqueues its rollout and THEN closes it.
     Three iterations give the policy and the trajectories of the synchronous order (same seeds), whatever the trial the search stops at."""
