@@ -26,9 +26,11 @@
 //     unless its whole range lies inside one tile, and then only for lower-numbered workgroups).
 //
 //   * FEWER tiles than CUs (a.late; small batches: the Humanoid params file has 80 tiles): cut that way a tile would be three or four pieces in a row, each
-//     waiting for the one before it.  Instead every piece starts from ZERO, so the pieces of a tile run at the same time on different CUs, and a piece
-//     that does not begin its tile imports the running sum of the pieces before it at its END and adds it to its own (then exports, or finishes the
-//     tile).  An output is then (((p0) + p1) + p2) ... of k-ordered chains: still a fixed order for a given grid, no longer independent of the grid.
+//     waiting for the one before it.  Instead every piece starts from ZERO, so the pieces of a tile run at the same time on different CUs; every piece but
+//     the tile's last exports ITS OWN sums at the end of its range, and the last piece imports them all at its end and adds them to its own, first piece
+//     first (round 5: until then each piece added the running sum of its predecessor and handed it on -- a chain of 2-3 hand-overs of ~9 us behind the
+//     last matrix instruction, 71.7 us against the tile GEMM's 69.9 us at the Humanoid params file's shape; now ONE hand-over).  An output is then
+//     ((p_last + p0) + p1) + ... of k-ordered chains: still a fixed order for a given grid, no longer independent of the grid.
 //     Waits are again only for lower-numbered workgroups, and only at the end of a range.
 //
 // Summation order of one output: chunks of 32 k in order; inside a chunk the steps (j, e) = (0,0) .. (1,3), step (j, e) adding
@@ -177,7 +179,7 @@ __global__ void __launch_bounds__(512) k_sk_sched(const SkArgs a, int* __restric
         if (t < n_h) {                                                         // the piece that begins a tile: first, exported at once
             tile = te; c = (ts == te ? cs : 0) + t;
             if (t == 0) fl |= (c == 0 || a.late) ? SKF_ZERO : SKF_IMPORT;
-            if (t == n_h - 1) fl |= SKF_EXPORT | ((a.late && ts == te && cs > 0) ? SKF_LATE : 0);      // a middle piece: adds what came before, hands the sum on
+            if (t == n_h - 1) fl |= SKF_EXPORT;                                                        // (a.late: a middle piece exports ITS OWN sums, the tile's last piece adds them all)
         } else if (t < n_h + nf * Le) {
             const int tt = t - n_h; tile = tf + tt / Le; c = tt % Le;
             if (c == 0) fl |= SKF_ZERO;
@@ -352,8 +354,8 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
 
     bool export_issued = false;
     const int prev_d = a.team ? 1 : (a.xcd > 1 ? a.xcd : 1);                   // the workgroup that holds the range in front of this one (teams: the same slot of the previous XCD)
-    auto wait_prev = [&]() {                                                   // the previous workgroup's export flag of this launch (bounded: report, do not hang)
-        const unsigned* fp = a.xflag + (size_t)(blockIdx.x - prev_d) * 8 + wave;
+    auto wait_prev = [&](int dist = 0) {                                       // the export flag of this launch of the previous workgroup (or the one `dist` in front; bounded: report, do not hang)
+        const unsigned* fp = a.xflag + (size_t)(blockIdx.x - (dist > 0 ? dist : prev_d)) * 8 + wave;
         const unsigned long long t0 = wall_clock64();
         while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
             __builtin_amdgcn_s_sleep(8);
@@ -437,19 +439,36 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
             }
             SK_STAMP(2);
-            if (r0.fl & SKF_LATE) {                                            // a.late: the running sum of the tile's earlier pieces, added to this piece's own sums
-                wait_prev();
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xacc + ((size_t)(blockIdx.x - prev_d) * 8 + wave) * 4096), 0, 16384, 0x00020000);
+            if (r0.fl & SKF_LATE) {                                            // a.late, the piece that ENDS a tile: the sums of ALL earlier pieces of the tile, added to its own
+                // The earlier pieces sit in the workgroups b - n_prev .. b - 1 (consecutive ranges: no XCD remap with a.late), each exported at the end of
+                // its range -- all at about the same time, so the tile closes ONE hand-over behind its last matrix instruction instead of a chain of
+                // n_prev (each link: store + drain + flag + four load passes, ~9 us).  Order of the adds: own, then the pieces from the tile's first on.
+                int n_prev = 1;
+                {
+                    const int G = (int)gridDim.x, b = (int)blockIdx.x;
+                    const long long U = a.units, u_me = U * b / G;
+                    int ts_ = (int)(u_me / a.L); if ((int)(u_me % a.L) >= a.NCk) ++ts_;
+                    for (; n_prev < b; ++n_prev) {                             // b - n_prev holds the piece that BEGINS the tile: its range starts in an earlier tile or on chunk 0
+                        const long long u = U * (b - n_prev) / G;
+                        int t_ = (int)(u / a.L), o_ = (int)(u % a.L);
+                        if (o_ >= a.NCk) { ++t_; o_ = 0; }
+                        if (t_ < ts_ || o_ == 0) break;
+                    }
+                }
+                for (int d = n_prev; d >= 1; --d) {
+                    wait_prev(d);
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xacc + ((size_t)(blockIdx.x - d) * 8 + wave) * 4096), 0, 16384, 0x00020000);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {                                  // 16 registers at a time
-                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                    u32x4 raw[4];
+                    for (int u = 0; u < 4; ++u) {                              // 16 registers at a time
+                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                        u32x4 raw[4];
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) raw[v] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((u * 4 + v) * 64 + lane) * 16, 0, 16);
-                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                        for (int v = 0; v < 4; ++v) raw[v] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((u * 4 + v) * 64 + lane) * 16, 0, 16);
+                        __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) acc[u][v] += __builtin_bit_cast(f32x4, raw[v]);
-                    __builtin_amdgcn_sched_barrier(0);
+                        for (int v = 0; v < 4; ++v) acc[u][v] += __builtin_bit_cast(f32x4, raw[v]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
             if (r0.fl & SKF_EXPORT) {

@@ -5,7 +5,7 @@ cd ${GRAFT_REPO_ROOT:-/root/repo}; R=$PWD; tag=${1:-rXX}; out=$R/gpurun_out/roun
 for v in "20 5 drv" "40 10 def"; do set -- $v
   (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace -d /tmp/prof_C1$3 -o t -- python $R/bench.py --steps $1 --warmup $2 --no-cpu-baseline > $out/${tag}_C1_$3_traced.json 2>/dev/null)
   python tools/rocpd_stats.py /tmp/prof_C1$3/t_results.db > $out/${tag}_C1_$3.kernel_stats.txt; rm -rf /tmp/prof_C1$3
-  python - $out/${tag}_C1_$3_traced.json $out/${tag}_C1_$3.kernel_stats.txt $(( $1 + $2 + 1 )) <<'PY'
+  python - $out/${tag}_C1_$3_traced.json $out/${tag}_C1_$3.kernel_stats.txt $(( 2 * $1 + $2 + 1 )) <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1])); n_it = int(sys.argv[3])
 tot = other = 0.0
@@ -19,7 +19,7 @@ for l in open(sys.argv[2]).read().splitlines()[1:]:
         other += us
     else:
         tot += us
-print('%s: ms_per_step %.4f (median %.4f); kernel time of the iterations %.1f us over %d iterations (timed + warm-up + the FVP-timing one) = %.4f ms per iteration; probes / set-up %.1f us'
+print('%s: ms_per_step %.4f (median %.4f); kernel time of the iterations %.1f us over %d iterations (timed + warm-up + the instrumented pass + the FVP-timing one) = %.4f ms per iteration; probes / set-up %.1f us'
       % (sys.argv[1].split('/')[-1], d['ms_per_step'], d['ms_per_step_median'], tot, n_it, tot / n_it / 1e3, other))
 PY
 done
