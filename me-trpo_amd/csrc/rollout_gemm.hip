@@ -650,9 +650,10 @@ static SkPath sk_select(const metrpo_ctx* c, int B) {
     if (K1 % 32 != 0 || N % 256 != 0) return sp;
     sp.OT = (pd.ns <= 16) ? 1 : (pd.ns <= 32) ? 2 : 4;
     // Fewer tiles than CUs: the pieces of a tile side by side, added at their ends (mlp_streamk.h: SkArgs::late).  Built and measured at the Humanoid
-    // params file's shape (K = 5, M = 500, 2 x 1024: 80 tiles, 10.6 chunks per workgroup): 71.7 us against the tile GEMM's 69.9 us -- a tile is 3-4
-    // pieces, and the hand-overs at the END of the pieces (store + drain + flag + four load passes, ~9 us per link) form a chain of 2-3 links after
-    // the last matrix instruction.  So it is not selected by itself: METRPO_STREAMK_LATE=1 selects it from 8 chunks per workgroup up, forced launches
+    // params file's shape (K = 5, M = 500, 2 x 1024: 80 tiles, 10.6 chunks per workgroup): 71.7 us against the tile GEMM's 69.9 us while the hand-overs at the END
+    // of a tile's 3-4 pieces formed a chain of 2-3 links (store + drain + flag + four load passes, ~9 us each); 66.0 us since every piece but the last exports
+    // its own sums and the last adds them all (one link).  The launch is then faster than the tile GEMM (69.3), the STEP is not: this path's layer-0 rows
+    // (k_l0_rows 21 us) and unsplit pre-step (29 us) cost 20 us more than the GEMM path's (11 + 9.6 + 8.9): 116.6 vs 98.8 us per step.  So it is not selected by itself: METRPO_STREAMK_LATE=1 selects it from 8 chunks per workgroup up, forced launches
     // (METRPO_STREAMK=1: the parity tests) use it from 2 up, METRPO_STREAMK_LATE=0 never (forced launches then run one unsplit tile per workgroup).
     const char* le = ctx_opt(c, OPT_STREAMK_LATE);
     const bool late_ok = (le != nullptr) ? le[0] == '1' : force;

@@ -4,7 +4,8 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}; R=$PWD; tag=${1:-rXX}; out=$R/gpurun_out/round; mkdir -p $out
 for v in "20 5 drv" "40 10 def"; do set -- $v
   (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace -d /tmp/prof_C1$3 -o t -- python $R/bench.py --steps $1 --warmup $2 --no-cpu-baseline > $out/${tag}_C1_$3_traced.json 2>/dev/null)
-  python tools/rocpd_stats.py /tmp/prof_C1$3/t_results.db > $out/${tag}_C1_$3.kernel_stats.txt; rm -rf /tmp/prof_C1$3
+  python tools/rocpd_stats.py /tmp/prof_C1$3/t_results.db > $out/${tag}_C1_$3.kernel_stats.txt
+  python tools/rocpd_iter_check.py /tmp/prof_C1$3/t_results.db $2 $1; rm -rf /tmp/prof_C1$3
   python - $out/${tag}_C1_$3_traced.json $out/${tag}_C1_$3.kernel_stats.txt $(( 2 * $1 + $2 + 1 )) <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1])); n_it = int(sys.argv[3])
