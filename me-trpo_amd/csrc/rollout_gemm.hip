@@ -653,13 +653,20 @@ static SkPath sk_select(const metrpo_ctx* c, int B) {
     // params file's shape (K = 5, M = 500, 2 x 1024: 80 tiles, 10.6 chunks per workgroup): 71.7 us against the tile GEMM's 69.9 us while the hand-overs at the END
     // of a tile's 3-4 pieces formed a chain of 2-3 links (store + drain + flag + four load passes, ~9 us each); 66.0 us since every piece but the last exports
     // its own sums and the last adds them all (one link).  The launch is then faster than the tile GEMM (69.3), the STEP is not: this path's layer-0 rows
-    // (k_l0_rows 21 us) and unsplit pre-step (29 us) cost 20 us more than the GEMM path's (11 + 9.6 + 8.9): 116.6 vs 98.8 us per step.  So it is not selected by itself: METRPO_STREAMK_LATE=1 selects it from 8 chunks per workgroup up, forced launches
+    // (k_l0_rows 21 us) and unsplit pre-step (29 us) cost 20 us more than the GEMM path's (11 + 9.6 + 8.9): 116.6 vs 98.8 us per step.  So it was not selected by itself (METRPO_STREAMK_LATE=1 selected it from 8 chunks per workgroup up); forced launches
     // (METRPO_STREAMK=1: the parity tests) use it from 2 up, METRPO_STREAMK_LATE=0 never (forced launches then run one unsplit tile per workgroup).
+    // Third pass of round 5: with ONE hand-over per tile the launch beats the 64 x 64-tile GEMM at that shape (65.3 vs 69.3 us), and together with the tile GEMM
+    // for layer 0 and the split pre-step + separate post launch of small batches (rollout_gemm_chunk) the step is 93 us against 98.8: selected by itself for the
+    // wide-input two-hidden-layer form (mode 3: Humanoid's 76 inputs) -- and for the narrow-input forms (mode 1: one launch per
+    // step), which below one tile per CU are the resident kernel's shapes and get here when that kernel is off (a shared GPU: NO_RESIDENT / not exclusive):
+    // params-half-cheetah 9.17 -> 7.56 ms per rollout against the tile GEMMs (resident: 7.29).  STREAMK_LATE=0 keeps the tile GEMMs.
     const char* le = ctx_opt(c, OPT_STREAMK_LATE);
-    const bool late_ok = (le != nullptr) ? le[0] == '1' : force;
+    const bool late_ok = (le != nullptr) ? le[0] == '1' : true;
     auto late_for = [&](int K1_, int N_, int epi_units) -> int {
         const long long tiles = (long long)K * ((B + 127) / 128) * (N_ / 256), units = tiles * (K1_ / 32 + epi_units);
-        return (late_ok && tiles < c->n_sm && units / c->n_sm >= (force ? 2 : 8)) ? 1 : 0;
+        // from 5 units per workgroup up (tools/late_sweep.py, profiles/r05_e_late_sweep.txt: -3 ... -22 % per rollout against the tile GEMMs at 5.2 - 10.6 units; at 2.6 - 3.3 units
+        // it loses -- +14 ... +83 % -- except for the narrow-input 2 x 1024 form)
+        return (late_ok && tiles < c->n_sm && units / c->n_sm >= (force ? 2 : 5)) ? 1 : 0;
     };
     const int epi_units = (sp.OT == 4) ? 2 : 1;
     if (!force && (long long)K * ((B + 127) / 128) * (N / 256) < c->n_sm && !late_for(K1, N, epi_units)) return sp;
@@ -775,7 +782,9 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
     SkPath sk = sk_select(c, B);
     // stored layer 0 (modes 2, 3) by k_l0_rows: the bias rides as input row n_in, as for the producer of mode 1 (METRPO_NO_L0_ROWS: the tile GEMM)
     const int S0all = (pd.nin + 1 + 3) / 4;
-    const bool l0r = sk.mode >= 2 && l0_rows_ok(S0all) && pd.dyn.dims[1] % 256 == 0 && pd.dyn.act[0] == METRPO_ACT_RELU &&
+    // (below one tile per CU -- the late split -- the 64 x 64-tile GEMM is the faster layer 0: 11.9 vs 21.2 us at 500 rows per head)
+    const bool sk_small = sk.mode != 0 && ((sk.mode == 2) ? sk.a2.late : sk.a1.late) != 0;
+    const bool l0r = sk.mode >= 2 && !sk_small && l0_rows_ok(S0all) && pd.dyn.dims[1] % 256 == 0 && pd.dyn.act[0] == METRPO_ACT_RELU &&
                      pd.dyn.b_off[0] == pd.dyn.w_off[0] + pd.nin * pd.dyn.dims[1] && ctx_opt(c, OPT_NO_L0_ROWS) == nullptr;
     const int ldx = (sk.mode == 1) ? 4 * sk.S0 : (l0r ? 4 * S0all : ((pd.nin + 3) & ~3));
     const size_t nS = up4((size_t)B * pd.ns), nX = up4((size_t)B * ldx), nU = up4((size_t)B * pd.na), nH = (sk.mode == 1) ? 0 : up4((size_t)K * B * maxh), nO = up4((size_t)K * B * pd.ns);
@@ -803,7 +812,9 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
     size_t pre_lds_post = 0;
     // (Humanoid's 55 dims are 16 per lane in that layout: behind the tile GEMMs' 16 output partials per head -- small batches -- the closing part is slower
     //  than k_big_post's lane per dim, 12.9 vs 11.1 ms per params-file rollout; behind stream-K's 4 partials it is merged.  METRPO_STEP_MERGE=1 forces it: tests)
-    const bool merge_ok = ctx_opt(c, OPT_NO_STEP_MERGE) == nullptr && (pd.ns <= 32 || sk.mode != 0 || ctx_opt(c, OPT_STEP_MERGE) != nullptr);
+    //  Small batches of the 100-50-25 pre-step (a tile per workgroup: k_big_pre_mfma3_split, below) keep two launches also behind stream-K: 9.6 + 6.3 us against the merged 29.4.)
+    const bool split_pre_small = pd.ns > 32 && B <= 16 * c->n_sm && ctx_opt(c, OPT_NO_PRE_SPLIT) == nullptr && ctx_opt(c, OPT_STEP_MERGE) == nullptr;
+    const bool merge_ok = ctx_opt(c, OPT_NO_STEP_MERGE) == nullptr && !split_pre_small && (pd.ns <= 32 || sk.mode != 0 || ctx_opt(c, OPT_STEP_MERGE) != nullptr);
     const big_pre_mfma_t pre_post = (pre_mfma && merge_ok) ? big_pre_mfma_select(c, &pre_lds_post, true) : nullptr;
     // policies without an MFMA pre-kernel: GEMM chain over the batch from B = 1024 up -- and at ANY batch when the policy is large
     // (k_big_pre walks the weights through scalar loads, one block's time whatever B: 302 us per step for Humanoid's 100-50-25 at B = 100,

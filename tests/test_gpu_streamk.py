@@ -86,6 +86,33 @@ def test_streamk_rollout_all_sam_modes(sam_mode, monkeypatch):
     assert eng.last_rollout_kernel() == 'gemm-streamk'
 
 
+def test_streamk_is_selected_by_itself_at_the_humanoid_params_file_shape():
+    """params-humanoid.json: K = 5, 2 x 1024, 100 envs, rounds of 100 steps side by side = 500 rows per head: 80 tiles of 34 units on the chip's CUs.  With one
+    hand-over per tile (SkArgs::late) the stream-K launch beats the tile GEMM there and is the default (rollout_gemm.hip sk_select: the wide-input form from 8
+    units per workgroup up), with the tile GEMM for layer 0 and the split pre-step + separate post launch of small batches.  Merged rounds (tiles spanning two
+    rounds, resets inside the batch), production draws: bitwise repeatable, and within cross-kernel rounding of the tile-GEMM path (option STREAMK_LATE = 0)."""
+    env, K, B, H, R = 'humanoid', 5, 100, 3, 5
+    eng, dm, theta, pdims, pool = make_engine(env, K, (1024, 1024), (100, 50, 25), seed=91)
+    a = eng.rollout(B, R * H, H, 'step_rand', pool, seed=7)
+    if eng.last_rollout_kernel() != 'gemm-streamk':
+        pytest.skip('fewer than 8 units per workgroup on this device (CU count): the tile GEMMs stay')
+    keep = [x.clone() for x in (a.obs, a.act, a.mean, a.rew, a.done, a.tpath, a.last_obs)]
+    again = eng.rollout(B, R * H, H, 'step_rand', pool, seed=7)
+    for x, y in zip(keep, (again.obs, again.act, again.mean, again.rew, again.done, again.tpath, again.last_obs)):
+        assert torch.equal(x, y)
+    eng.set_option('STREAMK_LATE', '0')
+    tile = eng.rollout(B, R * H, H, 'step_rand', pool, seed=7)
+    assert eng.last_rollout_kernel() == 'gemm-stepwise'
+    assert torch.equal(tile.done, keep[4]) and torch.equal(tile.tpath, keep[5])
+    for x, y in zip(keep[:4], (tile.obs, tile.act, tile.mean, tile.rew)):
+        np.testing.assert_allclose(cpu(x), cpu(y), **TOL.CROSS_KERNEL)
+    eng.set_option('STREAMK_LATE', None)
+    eng.set_option('METRPO_SEQ_ROUNDS', '1')                     # the rounds one after the other: 20 tiles per launch, the tile GEMMs
+    seq = eng.rollout(B, R * H, H, 'step_rand', pool, seed=7)
+    for x, y in zip(keep[:4], (seq.obs, seq.act, seq.mean, seq.rew)):
+        np.testing.assert_allclose(cpu(x), cpu(y), **TOL.CROSS_KERNEL)
+
+
 def test_streamk_split_tiles_equal_the_oracle_and_do_not_depend_on_the_split():
     """More tiles than CUs and not a multiple of them: workgroup ranges start and end inside tiles, accumulators are handed over between
     workgroups.  K = 5 heads x 32 row blocks x 2 column blocks = 320 tiles on the chip's CUs; the rollout picks the path by itself."""
