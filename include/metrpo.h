@@ -240,7 +240,7 @@ int32_t metrpo_baseline_gram(metrpo_ctx* ctx, const float* d_obs, const float* d
 /* The solve of that fit, on the device ([rllab] linear_feature_baseline.py fit: lstsq(F^T F + reg I, F^T ret), reg x 10 while the
  * solution contains a NaN, at most 5 attempts): d_coeffs [F] float64 from d_AtA / d_Aty (summed over the ranks by the caller).
  * Stream-ordered, no host round trip: the coefficients go straight into the next metrpo_gae.  The system is square and nonsingular
- * for reg > 0, so elimination with partial pivoting returns lstsq's solution (to float64 conditioning). */
+ * (symmetric positive definite) for reg > 0, so elimination in the natural order returns lstsq's solution (to float64 conditioning). */
 int32_t metrpo_baseline_solve(metrpo_ctx* ctx, const double* d_AtA, const double* d_Aty, double reg_coeff, double* d_coeffs, void* stream);
 
 /* ---- NPO/TRPO update (algos/npo.py:68-111, algos/trpo.py:18-20; [rllab] ConjugateGradientOptimizer) */

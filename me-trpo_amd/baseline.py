@@ -3,7 +3,7 @@ samplers/base.py:55 (predict) and :164-167 (fit).  Features [o, o^2, t/100, (t/1
 with o = clip(obs, -10, 10).  predict is fused into the GAE kernel (coefficients are handed to it);
 fit reduces the normal equations on the GPU (metrpo_baseline_gram), all-reduces them across ranks
 and solves the (2 ns + 4)^2 system in float64 as rllab does (x10 reg on NaN) -- on the host with lstsq (solve), or on the device
-(solve_device: elimination with partial pivoting, metrpo_baseline_solve) so that the coefficients go from the fit into the next GAE kernel
+(solve_device: float64 elimination of the symmetric positive definite system, metrpo_baseline_solve) so that the coefficients go from the fit into the next GAE kernel
 without a host round trip; `coeffs` then copies them to the host only when somebody asks."""
 import numpy as np
 

@@ -634,44 +634,36 @@ int launch_center(metrpo_ctx* c, float* adv, const uint8_t* valid, int64_t N, co
 
 // [rllab] LinearFeatureBaseline.fit's solve (linear_feature_baseline.py: lstsq(F^T F + reg I, F^T returns), reg x 10 while the solution has
 // a NaN, at most 5 attempts) on the device, so that the coefficients the next process_samples needs never leave it: one workgroup, the
-// augmented system [A + reg I | b] in LDS (float64), Gaussian elimination with partial pivoting (the system is square and, with reg > 0,
-// nonsingular: the least-squares solution IS its solution), back substitution by the first wave.  F <= 114 (Humanoid): 0.1 MB of LDS.
-__global__ void __launch_bounds__(256) k_baseline_solve(int F, const double* __restrict__ AtA, const double* __restrict__ Aty, double reg0, double* __restrict__ coeffs) {
+// augmented system [A + reg I | b] in LDS (float64), Gaussian elimination in the natural order (the system is square and, with reg > 0,
+// symmetric positive definite: the least-squares solution IS its solution), back substitution by the first wave.  F <= 114 (Humanoid): 0.1 MB of LDS.
+__global__ void __launch_bounds__(1024) k_baseline_solve(int F, const double* __restrict__ AtA, const double* __restrict__ Aty, double reg0, double* __restrict__ coeffs) {
     extern __shared__ __attribute__((aligned(16))) double Ms[];      // [F][F + 1] | x [F]
-    __shared__ int s_piv, s_bad;
+    __shared__ int s_bad;
     const int tid = threadIdx.x, lane = tid & 63, W = F + 1;
     double* x = Ms + (size_t)F * W;
     double reg = reg0;
     for (int attempt = 0; attempt < 5; ++attempt) {
-        for (int i = tid; i < F * W; i += 256) { const int r = i / W, c = i % W; Ms[i] = (c < F) ? AtA[r * F + c] + (r == c ? reg : 0.0) : Aty[r]; }
+        for (int i = tid; i < F * W; i += (int)blockDim.x) { const int r = i / W, c = i % W; Ms[i] = (c < F) ? AtA[r * F + c] + (r == c ? reg : 0.0) : Aty[r]; }
         if (tid == 0) s_bad = 0;
         __syncthreads();
         for (int k = 0; k < F; ++k) {
-            if (tid < 64) {                                  // pivot row: largest |M[r][k]|, r >= k (lowest r among equals)
-                double best = -1.0; int bi = k;
-                for (int r = k + lane; r < F; r += 64) { const double v = fabs(Ms[r * W + k]); if (v > best || !(best >= 0.0)) { best = v; bi = r; } }
-                for (int o = 32; o > 0; o >>= 1) {
-                    const double ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
-                    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-                }
-                if (lane == 0) s_piv = bi;
-            }
-            __syncthreads();
-            const int p = s_piv;
-            if (p != k) for (int c = k + tid; c < W; c += 256) { const double t = Ms[k * W + c]; Ms[k * W + c] = Ms[p * W + c]; Ms[p * W + c] = t; }
-            __syncthreads();
+            // No row exchanges (third pass of round 5; until then: a pivot search by the first wave + the exchange = two more barriers per pivot, 302 us at F = 114):
+            // A + reg I is symmetric positive definite, for which elimination in the natural order is as stable as with partial pivoting -- what the one-wave
+            // solver of the small envs below has always done; a non-finite result escalates reg like a NaN.
             const double inv = 1.0 / Ms[k * W + k];
-            // rows below k x columns right of k (rhs included): a thread owns ONE column (W <= 128) and every second row -- no integer division per element
-            // (as `i / nc, i % nc` over a flat index the update was 386 us at F = 114, most of it address arithmetic); the same expression per element
+            // rows below k x columns right of k (rhs included): a thread owns ONE column (W <= 128) and every RS-th row (RS = blockDim / 128 = 8: 16 waves, a
+            // pivot's update is ~7 rows per thread) -- no integer division per element (as `i / nc, i % nc` over a flat index the update was 386 us at F = 114, most
+            // of it address arithmetic); the same expression per element whatever the block size
+            const int RS = (int)blockDim.x >> 7;
             for (int c = k + 1 + (tid & 127); c < W; c += 128) {
                 const double mkc = Ms[k * W + c];
                 int r = k + 1 + (tid >> 7);
-                for (; r + 6 < F; r += 8) {                  // four rows in flight (independent read / multiply / write chains)
-                    const double f0 = Ms[r * W + k] * inv, f1 = Ms[(r + 2) * W + k] * inv, f2 = Ms[(r + 4) * W + k] * inv, f3 = Ms[(r + 6) * W + k] * inv;
-                    const double m0 = Ms[r * W + c], m1 = Ms[(r + 2) * W + c], m2 = Ms[(r + 4) * W + c], m3 = Ms[(r + 6) * W + c];
-                    Ms[r * W + c] = m0 - f0 * mkc; Ms[(r + 2) * W + c] = m1 - f1 * mkc; Ms[(r + 4) * W + c] = m2 - f2 * mkc; Ms[(r + 6) * W + c] = m3 - f3 * mkc;
+                for (; r + 3 * RS < F; r += 4 * RS) {        // four rows in flight (independent read / multiply / write chains)
+                    const double f0 = Ms[r * W + k] * inv, f1 = Ms[(r + RS) * W + k] * inv, f2 = Ms[(r + 2 * RS) * W + k] * inv, f3 = Ms[(r + 3 * RS) * W + k] * inv;
+                    const double m0 = Ms[r * W + c], m1 = Ms[(r + RS) * W + c], m2 = Ms[(r + 2 * RS) * W + c], m3 = Ms[(r + 3 * RS) * W + c];
+                    Ms[r * W + c] = m0 - f0 * mkc; Ms[(r + RS) * W + c] = m1 - f1 * mkc; Ms[(r + 2 * RS) * W + c] = m2 - f2 * mkc; Ms[(r + 3 * RS) * W + c] = m3 - f3 * mkc;
                 }
-                for (; r < F; r += 2) Ms[r * W + c] -= (Ms[r * W + k] * inv) * mkc;
+                for (; r < F; r += RS) Ms[r * W + c] -= (Ms[r * W + k] * inv) * mkc;
             }
             __syncthreads();
         }
@@ -680,7 +672,7 @@ __global__ void __launch_bounds__(256) k_baseline_solve(int F, const double* __r
                 double a = 0.0;
                 for (int c = k + 1 + lane; c < F; c += 64) a += Ms[k * W + c] * x[c];
                 for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-                if (lane == 0) { const double v = (Ms[k * W + F] - a) / Ms[k * W + k]; x[k] = v; if (isnan(v)) s_bad = 1; }
+                if (lane == 0) { const double v = (Ms[k * W + F] - a) / Ms[k * W + k]; x[k] = v; if (!(fabs(v) <= 1.7e308)) s_bad = 1; }      // NaN or Inf
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
             }
         }
@@ -689,7 +681,7 @@ __global__ void __launch_bounds__(256) k_baseline_solve(int F, const double* __r
         reg *= 10.0;
         __syncthreads();
     }
-    for (int i = tid; i < F; i += 256) coeffs[i] = x[i];
+    for (int i = tid; i < F; i += (int)blockDim.x) coeffs[i] = x[i];
 }
 
 // The same solve for the feature counts of the five small envs (F = 24 ... 62), in ONE wave's registers: lane r holds row r of [A + reg I | b],
@@ -751,7 +743,7 @@ int launch_baseline_solve(metrpo_ctx* c, const double* AtA, const double* Aty, d
     const size_t sh = sizeof(double) * ((size_t)F * (F + 1) + F);
     if (sh > 160 * 1024) return set_err(c, METRPO_EUNSUPPORTED, "baseline_solve: feature count too large for one workgroup's LDS");
     if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_baseline_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    hipLaunchKernelGGL(k_baseline_solve, dim3(1), dim3(256), sh, st, F, AtA, Aty, reg, coeffs);
+    hipLaunchKernelGGL(k_baseline_solve, dim3(1), dim3(1024), sh, st, F, AtA, Aty, reg, coeffs);
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;
 }
