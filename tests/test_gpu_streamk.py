@@ -165,6 +165,41 @@ def test_streamk_random_shapes_equal_the_tile_gemms(monkeypatch):
         del eng
 
 
+def test_streamk_side_by_side_pieces_on_random_small_shapes():
+    """Below one tile per CU (SkArgs::late): a tile is cut into pieces that run at the same time, every piece but the last exports its own sums and the last adds
+    them all -- it finds the earlier pieces from the split's arithmetic (mlp_streamk.h: the workgroups in front of it whose ranges start inside the same tile).
+    Head counts, batches and widths drawn at random so that a tile is 2 ... 13 pieces, ranges end inside the epilogue units, last row blocks are ragged; forced
+    launches (from 2 units per workgroup) against the tile GEMMs on the same draws, two steps free-running, and bitwise repeatable."""
+    rs = np.random.RandomState(97531)
+    envs = ['swimmer', 'half_cheetah', 'ant', 'hopper', 'snake', 'humanoid']
+    ran = 0
+    for case in range(10):
+        env = envs[case % len(envs)]
+        k1 = int(rs.choice([256, 512, 768, 1024])); n1 = int(rs.choice([256, 512, 1024]))
+        K = int(rs.randint(1, 7))
+        B = int(rs.randint(17, 900))
+        ph = (100, 50, 25) if env == 'humanoid' else (32, 32)
+        eng, dm, theta, pdims, pool = make_engine(env, K, (k1, n1), ph, seed=900 + case)
+        msg = str((case, env, K, (k1, n1), B))
+        eng.set_option('STREAMK', '1'); eng.set_rollout_variant(1)
+        sk = eng.rollout(B, 2, 2, 'step_rand', pool, seed=case)
+        if eng.last_rollout_kernel() != 'gemm-streamk':
+            del eng; continue
+        ran += 1
+        keep = [x.clone() for x in (sk.obs, sk.rew, sk.mean, sk.done)]
+        again = eng.rollout(B, 2, 2, 'step_rand', pool, seed=case)
+        for a, b in zip(keep, (again.obs, again.rew, again.mean, again.done)):
+            assert torch.equal(a, b), msg
+        eng.set_option('STREAMK', None); eng.set_option('NO_STREAMK', '1')
+        tile = eng.rollout(B, 2, 2, 'step_rand', pool, seed=case)
+        assert eng.last_rollout_kernel() == 'gemm-stepwise', msg
+        assert torch.equal(keep[3], tile.done), msg
+        for a, b in zip(keep[:3], (tile.obs, tile.rew, tile.mean)):
+            np.testing.assert_allclose(cpu(a), cpu(b), **TOL.CROSS_KERNEL, err_msg=msg)
+        del eng
+    assert ran >= 6, ran
+
+
 @pytest.mark.parametrize('env,K,dh,B', [('humanoid', 6, (1024, 1024, 1024), 1500), ('ant', 5, (256, 512, 512), 3400), ('humanoid', 5, (512, 1024), 2600)])
 def test_stored_layer0_kernel_equals_the_tile_gemm(env, K, dh, B, monkeypatch):
     """Layer 0 of the forms that store it (three hidden layers; two behind Humanoid's 77 inputs) on k_l0_rows -- the head's weight slice LDS-resident, bias as
