@@ -347,7 +347,7 @@ extern "C" int32_t metrpo_rollout(metrpo_ctx* c, const metrpo_rollout_args* a, v
         if (rc != METRPO_EUNSUPPORTED) {
             c->last_rollout_kernel = (c->coop_cfg >= 0 && c->rollout_variant != 1) ? 2 : 1;
             if (c->coop_cfg < 0 && c->rollout_variant == 0)
-                note_off_table(c, "the cooperative fused kernel (rollout_coop.hip) is instantiated for K = 5 heads, 2 x 64 dynamics, 2 x 32 policy of the six envs; this shape (K = " +
+                note_off_table(c, "the cooperative fused kernel (rollout_coop.hip) is instantiated for K = 1 ... 5 heads, 2 x 64 dynamics, 2 x 32 policy of the six envs; this shape (K = " +
                                   std::to_string(c->pd.K) + ") runs on the head-per-wave fused kernel (rollout_mfma.hip), ~2.9x the cooperative kernel's time at B = 5000");
             return rc;
         }

@@ -643,9 +643,13 @@ struct CoopEntry { int env, K; coop_kernel_t kern[2][2]; int lds_floats; bool al
 #define CENTRY(ENVID, KK) {ENVID, KK, {{k_rollout_coop<ENVID, KK, false, false>, k_rollout_coop<ENVID, KK, false, true>}, \
                                        {k_rollout_coop<ENVID, KK, true, false>, k_rollout_coop<ENVID, KK, true, true>}}, Coop<ENVID, KK>::TOTAL, coop_two_per_cu_spills<ENVID>(), \
                                        (ENVID == METRPO_ENV_SWIMMER) ? 1.50 : (ENVID == METRPO_ENV_SNAKE) ? 1.58 : 1.65, (ENVID == METRPO_ENV_SWIMMER) ? 0.0 : 1.0}
+// K = 5 is every params file's n_models; 1 ... 4 heads run the same kernel (everything in it is a function of K: LDS map, fragment counts, head loops) instead of
+// falling to the head-per-wave kernel (2.9x at B = 5000).  More than 5 heads do not fit: a wave holds K x 23 weight fragments in registers.  The launch rule's
+// measured co-residency constants are those of K = 5.
+#define CENTRY_ENV(ENVID) CENTRY(ENVID, 5), CENTRY(ENVID, 4), CENTRY(ENVID, 3), CENTRY(ENVID, 2), CENTRY(ENVID, 1)
 static const CoopEntry kCoop[] = {
-    CENTRY(METRPO_ENV_SWIMMER, 5), CENTRY(METRPO_ENV_HALF_CHEETAH, 5), CENTRY(METRPO_ENV_HOPPER, 5),
-    CENTRY(METRPO_ENV_SNAKE, 5), CENTRY(METRPO_ENV_ANT, 5),
+    CENTRY_ENV(METRPO_ENV_SWIMMER), CENTRY_ENV(METRPO_ENV_HALF_CHEETAH), CENTRY_ENV(METRPO_ENV_HOPPER),
+    CENTRY_ENV(METRPO_ENV_SNAKE), CENTRY_ENV(METRPO_ENV_ANT),
 };
 
 // index into kCoop or -1; requires the head-per-wave selection to have accepted the shape (same env dims)

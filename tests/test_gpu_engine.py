@@ -106,12 +106,27 @@ def test_policy_actions_parity():
 def test_rollout_parity_teacher_forced(env, sam_mode, determ, variant):
     """Fused rollout vs oracle with supplied draws.  Free-running for the discrete structure (dones,
     tpath, resets), teacher-forced (oracle fed the device's own observations) for the per-step values."""
-    K, B, T, H = 5, 200, 12, 5
+    _rollout_parity_teacher_forced(env, sam_mode, determ, variant, 5)
+
+
+@pytest.mark.parametrize('variant', ['coop', 'coop_two_per_cu'])
+@pytest.mark.parametrize('env,sam_mode,K', [('swimmer', 'step_rand', 1), ('swimmer', 'model_med', 3), ('half_cheetah', 'step_rand', 2), ('hopper', 'model_mean_std', 4),
+                                            ('ant', 'step_rand', 3), ('snake', 'eps_rand', 2), ('ant', 'model_mean', 4)])
+def test_cooperative_rollout_with_one_to_four_heads(env, sam_mode, K, variant):
+    """rollout_coop.hip is instantiated for K = 1 ... 5 heads (every params file has 5; fewer heads used to fall to the head-per-wave kernel): the same
+    teacher-forced comparison against the oracle, both launch forms, selection modes that read all heads included."""
+    _rollout_parity_teacher_forced(env, sam_mode, False, variant, K)
+
+
+def _rollout_parity_teacher_forced(env, sam_mode, determ, variant, K):
+    B, T, H = 200, 12, 5
     eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (64, 64), (32, 32), seed=7)
     force_generic = variant == 'generic'
     running = eng.set_rollout_variant({'head_per_wave': 1, 'coop_two_per_cu': 2}.get(variant, 0))
     if not force_generic:
         assert running == (1 if variant == 'head_per_wave' else 2)
+        eng.rollout(16, 2, 2, sam_mode, pool, seed=1)
+        assert eng.last_rollout_kernel() == ('mfma-head-per-wave' if variant == 'head_per_wave' else 'mfma-cooperative')
     if env == 'ant':
         pool[::3, 2] = 0.21; dm.diff_mean[2] = -0.02
         eng.set_dynamics_layers(dm.Ws, dm.bs, dm.in_mean, dm.in_std, dm.diff_mean, dm.diff_std)
