@@ -441,7 +441,7 @@ extern "C" int32_t metrpo_gae(metrpo_ctx* c, const float* obs, const float* rew,
 extern "C" int32_t metrpo_process_begin(metrpo_ctx* c, float* old_log_std, double* acc, int64_t n_acc, void* stream) {
     TraceRange trace_("metrpo:process_samples:begin");
     if (!c) return METRPO_ENULL;
-    if (n_acc < 0 || (n_acc > 0 && !acc)) return set_err(c, METRPO_EINVAL, "process_begin: bad accumulator range");
+    if (n_acc < 0 || n_acc > (1LL << 30) || (n_acc > 0 && !acc)) return set_err(c, METRPO_EINVAL, "process_begin: bad accumulator range");
     if (!old_log_std && n_acc == 0) return METRPO_OK;
     return launch_process_begin(c, old_log_std, n_acc > 0 ? acc : nullptr, n_acc, (hipStream_t)stream);
 }
