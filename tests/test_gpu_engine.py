@@ -288,6 +288,38 @@ def test_gae_center_gram_parity(gamma, lam, use_coeffs):
     assert np.abs(pred_got - pred_ref).max() <= TOL.BASELINE_FIT * max(1.0, np.abs(pred_ref).max())
 
 
+@pytest.mark.parametrize('env', ['swimmer', 'hopper', 'snake', 'half_cheetah', 'ant'])
+def test_gram_kernel_on_ragged_sample_counts(env):
+    """k_gram_mfma (process.hip): a wave stages 64 consecutive samples per trip through LDS (coalesced loads) and runs their four 16-sample MFMA tiles.  Sample
+    counts around the 16 / 64 boundaries, a random valid mask, observations beyond the +-10 clip: against the float64 normal equations of the reference's feature
+    map ([rllab] LinearFeatureBaseline._features: [o, o^2, t/100, (t/100)^2, (t/100)^3, 1], o = clip(obs, -10, 10)) at f32-product accuracy; accumulating calls add."""
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, 2, (64, 64), (32, 32), seed=5)
+    ns, dev = dm.ns, eng.device
+    F = 2 * ns + 4
+    rng = np.random.RandomState(77)
+    for N in (1, 15, 16, 63, 64, 65, 1000, 4099, 70001):
+        obs = (rng.randn(N, ns) * 4.0).astype(np.float32)
+        obs[rng.rand(N, ns) < 0.02] *= 5.0                          # some entries beyond the clip
+        ret = rng.randn(N).astype(np.float32) * 3.0
+        tpath = rng.randint(0, 200, size=N).astype(np.int32)
+        valid = (rng.rand(N) < 0.8).astype(np.uint8)
+        o = np.clip(obs.astype(np.float64), -10.0, 10.0)
+        al = (tpath.astype(np.float32) / np.float32(100.0)).astype(np.float64)[:, None]
+        Fm = np.concatenate([o, o * o, al, al ** 2, al ** 3, np.ones((N, 1))], axis=1) * valid[:, None]
+        G, b = Fm.T @ Fm, Fm.T @ (ret.astype(np.float64) * valid)
+        out = torch.zeros(F * F + F, dtype=torch.float64, device=dev)
+        args = [torch.as_tensor(x, device=dev) for x in (obs, ret, tpath, valid)]
+        eng.baseline_gram(*args, out=out)
+        AtA, Aty = cpu(out[:F * F]).reshape(F, F), cpu(out[F * F:])
+        scale = np.sqrt(np.outer(np.diag(G), np.diag(G)))
+        assert (np.abs(AtA - G) <= TOL.NORMAL_EQ * scale + 1e-9).all(), (env, N)
+        assert (np.abs(Aty - b) <= TOL.NORMAL_EQ * np.sqrt(np.diag(G) * float((ret.astype(np.float64) * valid) @ (ret.astype(np.float64) * valid))) + 1e-6).all(), (env, N)
+        eng.baseline_gram(*args, out=out)                           # ACCUMULATES (metrpo.h)
+        np.testing.assert_allclose(cpu(out[:F * F]).reshape(F, F), 2.0 * AtA, rtol=1e-12, atol=1e-12)
+        again = torch.zeros_like(out); eng.baseline_gram(*args, out=again)
+        assert torch.equal(again[:F * F], torch.as_tensor(AtA.reshape(-1), device=dev))      # bitwise repeatable
+
+
 def _update_problem(env='swimmer', N=5000, seed=21, pol_hidden=(32, 32)):
     eng, dm, theta, pdims, pool = Hh.make_engine(env, 2, (64, 64), pol_hidden, seed=seed)
     rng = np.random.RandomState(seed)
