@@ -44,7 +44,8 @@ typedef enum {
     METRPO_ENULL = -2,           /* required pointer is NULL */
     METRPO_EHIP = -3,            /* HIP runtime error, see metrpo_last_error */
     METRPO_EUNSUPPORTED = -4,    /* configuration exceeds this build's limits (e.g. LDS) */
-    METRPO_ESTATE = -5           /* set_dynamics / set_policy not called yet */
+    METRPO_ESTATE = -5,          /* set_dynamics / set_policy not called yet */
+    METRPO_UNSET = -100          /* metrpo_get_option: the key is known and has no value (not an error; distinct from METRPO_EINVAL = unknown key) */
 } metrpo_status;
 
 /* analytic reward / termination of the env families the reference ships (envs/com_*_env.py) */
@@ -96,7 +97,7 @@ int32_t metrpo_set_exclusive(metrpo_ctx* ctx, int32_t exclusive);
 /* Variant / tuning switches of a context (ABI 4).  The reference steers its run with params-*.json and command-line flags (main.py:21-60); this library's
  * kernel-selection switches were process-global METRPO_<KEY> environment variables read inside the launch paths up to ABI 3.  They are now one table per
  * context: metrpo_create() fills the defaults ONCE from the environment (METRPO_<KEY>), afterwards only metrpo_set_option() changes them (value NULL
- * unsets a key; takes effect at the next launch) and metrpo_get_option() reports them (returns the value's length, -1 when unset, METRPO_EINVAL for an unknown
+ * unsets a key; takes effect at the next launch) and metrpo_get_option() reports them (returns the value's length, METRPO_UNSET when unset, METRPO_EINVAL for an unknown
  * key).  Keys: the names metrpo_option_name(i), i = 0, 1, ... returns (NULL beyond the table), e.g. "STREAMK", "NO_STREAMK", "NO_RESIDENT", "SEQ_ROUNDS",
  * "PRE_GEMM"; lower case and a "METRPO_" prefix are accepted.  None of them changes results beyond the summation-order notes in DESIGN.md section 4. */
 int32_t metrpo_set_option(metrpo_ctx* ctx, const char* key, const char* value);

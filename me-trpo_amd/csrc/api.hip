@@ -140,8 +140,10 @@ int metrpo_opt_id(const char* key) {
 // fields of the context derived from an option (id < 0: all of them)
 static void opt_apply(metrpo_ctx* c, int id) {
     if (id < 0 || id == OPT_UPD_TILES_PER_WAVE) c->upd_tiles_per_wave = ctx_opt(c, OPT_UPD_TILES_PER_WAVE) ? std::max(1, atoi(ctx_opt(c, OPT_UPD_TILES_PER_WAVE))) : 1;
-    if (id < 0 || id == OPT_NO_RESIDENT) c->exclusive = (ctx_opt(c, OPT_NO_RESIDENT) == nullptr) ? 1 : 0;
-    if (id < 0 || id == OPT_GEMM_PREFETCH) { const char* g = ctx_opt(c, OPT_GEMM_PREFETCH); g_gemm_prefetch_off.store((g && g[0] == '1') ? 1 : 0); }   // process-wide (gemm_mfma.h has no context)
+    // (NO_RESIDENT does not touch c->exclusive -- the caller's metrpo_set_exclusive value: ctx_exclusive() combines the two at every use.)
+    // GEMM_PREFETCH is process-wide (gemm_mfma.h has no context): written by metrpo_set_option, and by metrpo_create only when the environment names it --
+    // creating a second context must not cancel what another context set.
+    if (id == OPT_GEMM_PREFETCH || (id < 0 && c->opt_set[OPT_GEMM_PREFETCH])) { const char* g = ctx_opt(c, OPT_GEMM_PREFETCH); g_gemm_prefetch_off.store((g && g[0] == '1') ? 1 : 0); }
     if (id == OPT_XCHG_TIMEOUT_MS && ctx_opt(c, OPT_XCHG_TIMEOUT_MS)) { const long long v = atoll(ctx_opt(c, OPT_XCHG_TIMEOUT_MS)); if (v > 0) c->xg_timeout = (unsigned long long)v * 100000ull; }
 }
 // value == NULL unsets the key.  Read by the NEXT launch; options that size a workspace or select a kernel table entry at set_dynamics / set_policy time
@@ -154,12 +156,12 @@ extern "C" int32_t metrpo_set_option(metrpo_ctx* c, const char* key, const char*
     opt_apply(c, id);
     return METRPO_OK;
 }
-// returns the value's length (copied into buf, NUL-terminated, truncated to cap - 1), -1 when the key is unset, METRPO_EINVAL for an unknown key
+// returns the value's length (copied into buf, NUL-terminated, truncated to cap - 1), METRPO_UNSET when the key is unset, METRPO_EINVAL for an unknown key
 extern "C" int32_t metrpo_get_option(metrpo_ctx* c, const char* key, char* buf, int32_t cap) {
     if (!c || !key) return METRPO_ENULL;
     const int id = metrpo_opt_id(key);
     if (id < 0) return set_err(c, METRPO_EINVAL, std::string("get_option: unknown key '") + key + "'");
-    if (!c->opt_set[id]) return -1;
+    if (!c->opt_set[id]) return METRPO_UNSET;
     if (buf && cap > 0) { const size_t n = std::min<size_t>(c->opt_val[id].size(), (size_t)cap - 1); memcpy(buf, c->opt_val[id].data(), n); buf[n] = 0; }
     return (int32_t)c->opt_val[id].size();
 }
@@ -187,6 +189,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
         const char* e = getenv(ev.c_str());
         c->opt_set[i] = (e != nullptr); c->opt_val[i] = e ? e : "";
     }
+    c->exclusive = 1;                                         // until metrpo_set_exclusive(ctx, 0) says otherwise (option NO_RESIDENT is combined with it in ctx_exclusive())
     opt_apply(c, -1);
     c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gae_part = nullptr; c->gae_part_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0; c->d_res = nullptr; c->res_cap = 0; c->res_seq = 0; c->res_failed = 0; c->last_rollout_kernel = -1; c->upd_pending = 0; c->upd_spec = 0; c->upd_changed_in_end = 0; c->h_upd = nullptr; c->upd_stamp = 0; c->side_ready = 0; c->d_ticket = nullptr; c->d_hcache = nullptr; c->hcache_cap = 0; c->hcache_on = 0; c->d_mig = nullptr; c->mig_cap = 0; c->mig_epoch = 0; c->nccl_comm = nullptr; c->comm_world = 0; c->comm_rank = 0; c->pol_path = 1; c->d_pg = nullptr; c->pg_cap = 0; c->pg_fwd_rows = -1; c->pg_fwd_obs = nullptr; c->d_cgp_bar = nullptr; c->cgp_failed = 0; c->cgp_launches = 0; c->pol_f3 = 0; c->d_f3 = nullptr; c->f3_cap = 0; c->f3_rows = -1; c->f3_obs = nullptr; c->f3_theta = nullptr; c->f3_img_ok = 0; c->d_adam = nullptr; c->adam_t = 0; c->d_train = nullptr; c->train_cap = 0; c->d_train_part = nullptr; c->train_part_cap = 0;
     ProblemDesc& pd = c->pd;

@@ -122,7 +122,7 @@ struct metrpo_ctx {
     int n_sm;            // CU count (device property)
     int upd_tiles_per_wave;   // MFMA update kernels: at least this many 16-sample tiles per wave before another block is added (METRPO_UPD_TILES_PER_WAVE)
     int n_cu_sched;      // CUs that actually ran this process's waves (probe.hip: census; 0 = not measured yet)
-    int exclusive;       // 0: the GPU is shared with other compute processes (metrpo_set_exclusive; METRPO_NO_RESIDENT=1 in the environment means the same)
+    int exclusive;       // the caller's metrpo_set_exclusive value (1 at metrpo_create); 0: the GPU is shared with other compute processes.  Read through ctx_exclusive(), which also honours option NO_RESIDENT
     std::string opt_val[OPT_COUNT]; bool opt_set[OPT_COUNT];   // METRPO_OPT_LIST: set by metrpo_create from the environment, then only by metrpo_set_option
     hipEvent_t fvp_ev[32]; int fvp_ev_n, fvp_ev_made;   // option TIME_FVP: events around the Fisher-vector-product kernel of launch_fvp_tail (metrpo_debug_fvp_us)
     std::string rollout_note;   // why the last metrpo_rollout left the fast dispatch table ("" when it did not): metrpo_rollout_note
@@ -132,6 +132,8 @@ struct metrpo_ctx {
 
 // value of a switch, NULL when unset -- the same contract as the getenv() calls these replaced
 static inline const char* ctx_opt(const metrpo_ctx* c, int id) { return c->opt_set[id] ? c->opt_val[id].c_str() : nullptr; }
+// kernels that wait on other workgroups of their own launch may be selected: the caller said the device is its own (metrpo_set_exclusive) AND option NO_RESIDENT is unset
+static inline bool ctx_exclusive(const metrpo_ctx* c) { return c->exclusive != 0 && ctx_opt(c, OPT_NO_RESIDENT) == nullptr; }
 inline std::atomic<int> g_gemm_prefetch_off{0};     // option GEMM_PREFETCH (process-wide: gemm_mfma.h's dispatch has no context)
 // the three-hidden-layer fused update kernels (policy_fused3.hip) serve this context's next update launch (not the VJP mode of the gradient kernels: GEMM path)
 static inline bool f3_active(const metrpo_ctx* c) { return c->pol_f3 != 0 && c->pol_path == 1 && c->vjp_gm == nullptr && ctx_opt(c, OPT_NO_POL_FUSED3) == nullptr; }

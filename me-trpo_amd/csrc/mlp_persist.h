@@ -63,6 +63,9 @@ enum { SKP_HALT = 0x40000000, SKP_NOHALT = 0x7fffffff };      // ready-flag valu
 #ifndef SKP_NO_FENCES
 #define SKP_NO_FENCES 1
 #endif
+#if SKP_NO_FENCES && !defined(__gfx942__) && !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
+#error "SKP_NO_FENCES relies on gfx942 / gfx950 sc1 write-through stores: build other targets with -DSKP_NO_FENCES=0"
+#endif
 enum { SKP_NCLOSE = 8 };                           // most closing workgroups of a launch (SkpArgs::nclose of them: blockIdx 0 .. nclose - 1, on different XCDs)
 
 // Step t closed and step t + 1 prepared for the 128 envs of row block rb, by all 8 waves of a closing workgroup: the wave functions of the launch-per-step

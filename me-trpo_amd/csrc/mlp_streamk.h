@@ -42,7 +42,17 @@
 // chunk's first operands ahead of it (that entry was copied during the even chunk before it: complete for everybody only behind the barrier).
 #define SK_BAR2 1
 #endif
+#ifndef SK_COPY_TOP
+#define SK_COPY_TOP 0
+#endif
+#ifndef SK_PRIO
+#define SK_PRIO 0
+#endif
+#ifndef SK_FETCH_ONLY
+#define SK_FETCH_ONLY 0
+#endif
 #include <type_traits>
+#include <utility>
 #include <algorithm>
 #include "mfma_common.h"
 
@@ -54,6 +64,7 @@ enum { SKF_ZERO = 1, SKF_IMPORT = 2, SKF_EXPORT = 4, SKF_LAST = 8, SKF_EPI = 16,
 struct SkRec;
 struct SkArgs {
     int M, heads, K1, N;                       // rows per head; main layer W1[K1][N], K1 % 32 == 0, N % 256 == 0
+    int tm;                                    // rows per tile (SkForm<NW>::TM; set by sk_plan)
     const float* A; long long strideA; int lda;   // SK_A_GLOBAL: A[head][M][lda]; SK_A_PRODUCER: x[M][lda], x[n_in] = 1 (bias slot), zeros up to 4 S0
     const float* W0; long long strideW0;       // SK_A_PRODUCER: layer-0 weights [>= 4 S0 rows][K1] row-major, row n_in = its bias (the resident layout)
     const float* W1; long long strideW1;
@@ -68,7 +79,7 @@ struct SkArgs {
     unsigned long long* dbg2;                  // non-NULL: phase stamps (shader clock) of chunks 8 .. 11 of workgroup 0, waves 0 and 4: [wave / 4][chunk - 8][6]
 #endif
     const int* hdr; const SkRec* recs;         // schedule: entries per workgroup | [grid][sched_cap] records (k_sk_sched)
-    int RB, CB, NCk, L, tiles, sched_cap;      // row blocks of 128, column blocks of 256, chunks per tile, units per tile (chunks + epilogue weight)
+    int RB, CB, NCk, L, tiles, sched_cap;      // row blocks of tm rows, column blocks of 256, chunks per tile, units per tile (chunks + epilogue weight)
     int xcd;                                   // > 1: workgroup b is taken to run on XCD b % xcd and gets range (b % xcd) * (grid / xcd) + b / xcd of the unit sequence (below)
     int team;                                  // XCD teams (below): the workgroups of one XCD walk the tiles in lock step, sharing weight slices AND activation rows in their L2
     int late;                                  // FEWER tiles than workgroups: the pieces of a tile run side by side from zero and are ADDED at their ends (below)
@@ -79,6 +90,19 @@ template <int OT> struct SkEpi {
     static constexpr int E = (OT == 4) ? 2 : 1, UPC = 4 / E;                 // EPI chunks per tile; 64-column groups u per EPI chunk
     static constexpr int FLOATS = 256 + UPC * 1024 * OT;                      // [b1 part, 256 floats][W2 part]
 };
+// Form of the workgroup.  NW = 8: ONE workgroup of 8 waves per CU, a tile of 128 rows, a ring of four chunk stages (copies two or three chunks ahead).
+// NW = 4 (round 6): TWO workgroups of 4 waves per CU, a tile of 64 rows each, a ring of TWO stages each (copies one chunk ahead: 2 x <= 37 KB per workgroup,
+// two workgroups in the CU's 160 KB).  The two waves of a SIMD then belong to DIFFERENT workgroup barriers: whatever one of them waits for -- the barrier,
+// its copies' drain, the first operand reads behind the barrier, a schedule fetch -- the other one's matrix instructions fill.  Same per-wave code, same
+// k order of every sum; a weight chunk feeds 64 rows instead of 128 (twice the L2 -> LDS copy traffic per FLOP; operand reads unchanged).
+template <int NW> struct SkForm {
+    static_assert(NW == 8 || NW == 4, "8 waves x 1 workgroup per CU, or 4 waves x 2");
+    static constexpr int TM = 16 * NW, NST = (NW == 8) ? 4 : 2, WPC = 8 / NW, NPW = 32 / NW;      // rows per tile | ring stages | workgroups per CU | W1 rows (1 KB pieces) a wave copies per chunk
+    static constexpr bool BAR2 = (NW == 8) && (SK_BAR2 != 0);
+    static constexpr int AHEAD = (NW == 8) ? (BAR2 ? 2 : 3) : 1;
+};
+template <int N, class F, int... I> __device__ __forceinline__ void sk_static_for_(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void sk_static_for(F&& f) { sk_static_for_<N>(f, std::make_integer_sequence<int, N>{}); }
 template <int AMODE, int EPI, int S0, int OT> struct SkGeom {
     static constexpr int NI0 = (S0 + 1) / 2;                                  // 1 KB pieces of the layer-0 slice of a chunk
     static constexpr int W0F = (AMODE == SK_A_PRODUCER) ? NI0 * 256 : 0;
@@ -199,7 +223,7 @@ __global__ void __launch_bounds__(512) k_sk_sched(const SkArgs a, int* __restric
             tile = (head * a.CB + cb) * a.RB + rb;
         }
         if (t == 0 || t == n_h || (t >= n_h && t < n_h + nf * Le && (t - n_h) % Le == 0) || t == n_h + nf * Le) fl |= SKF_NEWTILE;   // first entry of a piece
-        r.w = r.w2 = c | (fl << 16); r.m0 = rb * 128;
+        r.w = r.w2 = c | (fl << 16); r.m0 = rb * a.tm;
         r.offA = (unsigned)(head * a.strideA) + ((!PROD && !(fl & SKF_EPI)) ? 32u * c : 0u);
         r.offC = OUT ? (unsigned)(((long long)cb * a.heads + head) * a.stridePart) : (unsigned)(head * a.strideC + cb * 256);
         if (fl & SKF_EPI) { r.offW1 = (unsigned)(((head * a.CB + cb) * E + c) * EP::FLOATS); r.offW0 = 0; }
@@ -215,20 +239,28 @@ __global__ void __launch_bounds__(512) k_sk_sched(const SkArgs a, int* __restric
 // one 1 KB LDS-DMA piece: lane's 16 bytes at sbase + voff -> LDS lds_addr + 16 lane.  Scalar base + 32-bit lane offset: no vector address
 // arithmetic per piece (hipcc folds a per-lane offset into a 64-bit VGPR base with one v_lshl_add_u64 per piece).  Invisible to hipcc's vmcnt
 // counting: drained by the explicit waits of the chunk loop.  M0 is saved and restored inside the statement.
+#ifdef SK_DEBUG
+__device__ int sk_dbg_noldswrite = 0;                                         // experiment: the copies fetch their 16 bytes into a dead register instead of LDS (results invalid)
+#endif
 __device__ __forceinline__ void sk_glds16_s(unsigned voff, const void* sbase, unsigned lds_addr) {
+#if defined(SK_DEBUG) && SK_FETCH_ONLY
+    { f32x4 dead; asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dead) : "v"(voff), "s"(sbase) : "memory"); return; }
+#endif
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
 }
 
-template <int AMODE, int EPI, int S0, int OT>
-__global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
+template <int AMODE, int EPI, int S0, int OT, int NW = 8>
+__global__ void __launch_bounds__(64 * NW, 8 / NW) k_mlp_sk(const SkArgs a) {      // (two waves per SIMD either way: without the second bound the 4-wave form is given 512 registers and keeps its accumulators in the accumulation half, a move in and out around every matrix instruction)
     using EP = SkEpi<OT>;
     using GE = SkGeom<AMODE, EPI, S0, OT>;
-    constexpr int E = EP::E, UPC = EP::UPC, NI0 = GE::NI0, B1O = GE::B1O, STAGE = GE::STAGE;
+    using FM = SkForm<NW>;
+    constexpr int E = EP::E, UPC = EP::UPC, NI0 = GE::NI0, B1O = GE::B1O, STAGE = GE::STAGE, NST = FM::NST, NPW = FM::NPW, AHEAD = FM::AHEAD;
+    constexpr bool BAR2 = FM::BAR2;
     constexpr bool PROD = (AMODE == SK_A_PRODUCER), OUT = (EPI == SK_EPI_OUT);
     static_assert(EP::FLOATS <= STAGE || !OUT, "EPI image larger than a ring stage");
-    static_assert(NI0 <= 8, "layer-0 slice: at most 8 one-KB pieces (one per wave)");
+    static_assert(NI0 <= 8, "layer-0 slice: at most 8 one-KB pieces (one or two per wave)");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const ring = lds;
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, g = lane >> 4;
@@ -255,35 +287,42 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
 
     // per-thread constants of the LDS-DMA copies (byte offsets from a scalar base)
     const unsigned ring_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)ring;
-    const unsigned w1_voff = (unsigned)(wave * a.N + 4 * lane) * 4u;           // row (wave + 8 t) of the chunk, this lane's 16 bytes
-    unsigned w0_voff = 0;                                                      // PROD: piece ii = wave of the layer-0 slice image [s][jt][g][i']
-    if constexpr (PROD) { const int p = (wave % NI0) * 64 + lane, i4 = p & 3, gg = (p >> 2) & 3, jt = (p >> 4) & 1, s = p >> 5; w0_voff = (unsigned)((4 * s + gg) * a.K1 + 16 * jt + 4 * i4) * 4u; }
+    const unsigned w1_voff = (unsigned)(wave * a.N + 4 * lane) * 4u;           // row (wave + NW t) of the chunk, this lane's 16 bytes
+    unsigned w0_voff = 0;                                                      // PROD: piece ii = wave (+ NW: 32 more rows of W0) of the layer-0 slice image [s][jt][g][i']
+    if constexpr (PROD) { const int p = (wave % (NI0 < NW ? NI0 : NW)) * 64 + lane, i4 = p & 3, gg = (p >> 2) & 3, jt = (p >> 4) & 1, s = p >> 5; w0_voff = (unsigned)((4 * s + gg) * a.K1 + 16 * jt + 4 * i4) * 4u; }
     const unsigned lane16 = (unsigned)lane * 16u;
-    // LDS-DMA copies of entry q into ring stage q % 4, as five PIECES per wave (spread over the matrix phase of the chunk that issues them)
+    // LDS-DMA copies of entry q into ring stage q % NST, as NPW + 1 PIECES per wave (spread over the matrix phase of the chunk that issues them)
     auto issue_piece = [&](const RecI& r, int q, auto tc) {
         constexpr int t = decltype(tc)::value;
+        if constexpr (t > NPW) return;
         if (r.fl & SKF_NONE) return;
 #ifdef SK_DEBUG
         if (a.skip & 1) return;
+        if ((a.skip & 32) && (t & 1)) return;                                  // half the copy traffic (the stage keeps older, equally random rows)
 #endif
-        const unsigned st = ring_lds + (unsigned)((q & 3) * STAGE) * 4u;
+        const unsigned st = ring_lds + (unsigned)((q & (NST - 1)) * STAGE) * 4u;
         if (!(r.fl & SKF_EPI)) {
-            if constexpr (t < 4) sk_glds16_s(w1_voff, (const char*)(a.W1 + r.offW1) + (size_t)t * ((size_t)a.N * 32), st + (unsigned)(wave + 8 * t) * 1024u);   // row wave + 8 t
+            if constexpr (t < NPW) sk_glds16_s(w1_voff, (const char*)(a.W1 + r.offW1) + (size_t)t * ((size_t)a.N * (4 * NW)), st + (unsigned)(wave + NW * t) * 1024u);   // row wave + NW t
             else {
-                if constexpr (!OUT) { if ((r.fl & SKF_LAST) && wave == 7) sk_glds16_s(lane16, a.b1 + r.offW0, st + B1O * 4u); }
-                if constexpr (PROD) { if (wave < NI0) sk_glds16_s(w0_voff, a.W0 + r.offW0, st + (8192u + (unsigned)wave * 256u) * 4u); }
+                if constexpr (!OUT) { if ((r.fl & SKF_LAST) && wave == NW - 1) sk_glds16_s(lane16, a.b1 + r.offW0, st + B1O * 4u); }
+                if constexpr (PROD) {
+                    if (wave < NI0) sk_glds16_s(w0_voff, a.W0 + r.offW0, st + (8192u + (unsigned)wave * 256u) * 4u);
+                    if constexpr (NI0 > NW) { if (wave + NW < NI0) sk_glds16_s(w0_voff, a.W0 + r.offW0 + (size_t)(8 * NW) * a.K1, st + (8192u + (unsigned)(wave + NW) * 256u) * 4u); }   // piece ii + NW: W0 rows 8 NW further on
+                }
             }
         } else if constexpr (OUT) {
             constexpr int NIE = EP::FLOATS / 256;
-            const int ii = wave + 8 * t;
+            static_assert(NIE <= NW * (NPW + 1), "EPI image: at most NPW + 1 pieces per wave");
+            const int ii = wave + NW * t;
             if (ii < NIE) sk_glds16_s(lane16, (const char*)(a.epi + r.offW1) + (size_t)ii * 1024, st + (unsigned)ii * 1024u);
         }
     };
-    auto issue = [&](const RecI& r, int q) {
-        issue_piece(r, q, std::integral_constant<int, 0>{}); issue_piece(r, q, std::integral_constant<int, 1>{}); issue_piece(r, q, std::integral_constant<int, 2>{});
-        issue_piece(r, q, std::integral_constant<int, 3>{}); issue_piece(r, q, std::integral_constant<int, 4>{});
-    };
+    auto issue = [&](const RecI& r, int q) { sk_static_for<NPW + 1>([&](auto tc) { issue_piece(r, q, tc); }); };
+#ifdef SK_DEBUG
+    auto drain_vm = [&]() { if (a.skip & 64) return; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_waitcnt(0x0F70); };   // (64: leave-one-out, no wait for the copies)
+#else
     auto drain_vm = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_waitcnt(0x0F70); };   // the asm copies | the loads hipcc counts
+#endif
 
     f32x4 acc[4][4];                                                           // [u][v]: columns 64 u + 16 g + 4 r + v of the block, row i
     f32x4 oacc[OT];
@@ -307,7 +346,7 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
     auto drain_a = [&](f32x4 (&dst)[2]) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(dst[0]), "+v"(dst[1]) :: "memory"); };
     auto produce = [&](int q, f32x4 (&dst)[2]) {                               // layer 0 for the 32 units of chunk q, relu, in srcB layout
         f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-        const float* w0 = ring + (q & 3) * STAGE + 8192 + lane;
+        const float* w0 = ring + (q & (NST - 1)) * STAGE + 8192 + lane;
 #pragma unroll
         for (int s = 0; s < S0; ++s) {
             d0 = MFMA16(w0[(2 * s) * 64], xr[s], d0);
@@ -324,7 +363,7 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
     // loads in flight can only make that wait stricter).  w[k & 7] feeds group k.
     f32x4 w[8];
     const unsigned lane_off = (unsigned)((4 * g) * 256 + 4 * i) * 4u;
-    auto stage_addr = [&](int q) { return ring_lds + (unsigned)((q & 3) * STAGE) * 4u + lane_off; };
+    auto stage_addr = [&](int q) { return ring_lds + (unsigned)((q & (NST - 1)) * STAGE) * 4u + lane_off; };
 #define SK_WOFF(k) (((16 * ((k) >> 4) + (((k) >> 2) & 3)) * 256 + 64 * ((k) & 3)) * 4)
     auto first4 = [&](unsigned addr) {                                         // groups 0 .. 3 of a chunk, complete on return
         asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8\n\ts_waitcnt lgkmcnt(0)"
@@ -339,8 +378,8 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
         asm volatile("s_load_dwordx4 %0, %6, 0x0\n\ts_load_dwordx4 %1, %6, 0x20\n\ts_load_dwordx4 %2, %6, 0x10\n\ts_load_dwordx4 %3, %6, 0x30\n\t"
                      "s_load_dwordx4 %4, %6, 0x50\n\ts_load_dwordx4 %5, %6, 0x70\n\ts_waitcnt lgkmcnt(0)"
                      : "=&s"(l0), "=&s"(l1), "=&s"(i0), "=&s"(i1), "=&s"(i2), "=&s"(i3) : "s"(my_recs));
-        r0 = decL(l0); r1 = decL(l1); r3 = SK_BAR2 ? decI(i2) : decI(i3);
-        issue(decI(i0), 0); issue(decI(i1), 1); if (!SK_BAR2) issue(decI(i2), 2);
+        r0 = decL(l0); r1 = decL(l1); r3 = AHEAD == 1 ? decI(i1) : (AHEAD == 2 ? decI(i2) : decI(i3));      // the first AHEAD entries' copies under way; r3 = the record of the next one
+        issue(decI(i0), 0); if (AHEAD >= 2) issue(decI(i1), 1); if (AHEAD >= 3) issue(decI(i2), 2);
     }
     if constexpr (PROD) load_x(r0);
     else { set_a_voff(r0); load_a(r0, hs[0]); drain_a(hs[0]); }
@@ -353,9 +392,10 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
 #endif
 
     bool export_issued = false;
-    const int prev_d = a.team ? 1 : (a.xcd > 1 ? a.xcd : 1);                   // the workgroup that holds the range in front of this one (teams: the same slot of the previous XCD)
+    const int prev_d = a.team ? 1 : (a.xcd > 1 ? a.xcd : 1);
+    constexpr int XW = NW;                                                     // hand-over slots and flags per workgroup                   // the workgroup that holds the range in front of this one (teams: the same slot of the previous XCD)
     auto wait_prev = [&](int dist = 0) {                                       // the export flag of this launch of the previous workgroup (or the one `dist` in front; bounded: report, do not hang)
-        const unsigned* fp = a.xflag + (size_t)(blockIdx.x - (dist > 0 ? dist : prev_d)) * 8 + wave;
+        const unsigned* fp = a.xflag + (size_t)(blockIdx.x - (dist > 0 ? dist : prev_d)) * XW + wave;
         const unsigned long long t0 = wall_clock64();
         while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
             __builtin_amdgcn_s_sleep(8);
@@ -364,10 +404,13 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
     };
     auto body = [&](auto par_, const int q) {
         constexpr int PAR = decltype(par_)::value;
+        // PRE: the next chunk's first operands are read AHEAD of the barrier that ends this chunk (its stage is complete since an earlier barrier).  Not behind
+        // the odd chunks of the barrier-per-two-chunks form, and never with the two-stage ring (the next chunk's stage is being filled during this chunk).
+        constexpr bool PRE = (NW == 8) && !(BAR2 && PAR == 1);
         f32x4 (&h)[2] = hs[PAR];
         f32x4 (&hn)[2] = hs[PAR ^ 1];
         const bool nmain = !(r1.fl & SKF_EPI);
-        const float* st = ring + (q & 3) * STAGE;
+        const float* st = ring + (q & (NST - 1)) * STAGE;
 #ifdef SK_DEBUG
         const bool stamp = a.dbg2 != nullptr && blockIdx.x == 0 && (wave & 3) == 0 && q >= 8 && q < 12;
         unsigned long long* sp_ = a.dbg2 + ((wave >> 2) * 4 + (q - 8)) * 6;
@@ -376,6 +419,15 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
 #define SK_STAMP(k) do { } while (0)
 #endif
         SK_STAMP(0);
+#if SK_PRIO                                                                    // experiment: the two workgroups of a CU take turns at raised priority, chunk by chunk
+        if (SK_PRIO == 1 || blockIdx.x < gridDim.x / 2) __builtin_amdgcn_s_setprio(PAR ? 1 : 0); else __builtin_amdgcn_s_setprio(PAR ? 0 : 1);
+#endif
+#if SK_COPY_TOP                                                                // experiment: 1 = the SIMD's younger waves (4 .. 7) issue the whole chunk's copies HERE, 2 = all waves
+        const bool top_copy = (SK_COPY_TOP == 2 || wave >= 4) && !(r0.fl & SKF_EPI);
+        if (top_copy) issue(r3, q + AHEAD);
+#else
+        constexpr bool top_copy = false;
+#endif
         // bookkeeping: the vector part here; the schedule entries q + 3 (to copy) and q + 2 (the next look-ahead) are fetched and the copies issued INSIDE the
         // matrix phase below (scalar + memory instructions: two or three per group of four MFMAs cost nothing)
         if constexpr (PROD) {
@@ -396,7 +448,7 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
             }
             if (r0.fl & SKF_IMPORT) {                                          // the previous workgroup's partial sums of this tile (exported at its start)
                 wait_prev();
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xacc + ((size_t)(blockIdx.x - prev_d) * 8 + wave) * 4096), 0, 16384, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xacc + ((size_t)(blockIdx.x - prev_d) * XW + wave) * 4096), 0, 16384, 0x00020000);
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -414,7 +466,7 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
                     constexpr int j = k >> 4, e = (k >> 2) & 3, u = k & 3;
                     if constexpr (k < 28)
                         asm volatile("s_waitcnt lgkmcnt(3)\n\tds_read_b128 %0, %2 offset:%3" : "=&v"(w[(k + 4) & 7]), "+v"(w[k & 7]) : "v"(cur_a), "i"(SK_WOFF(k + 4)));
-                    else if (nmain && !(SK_BAR2 && PAR == 1))
+                    else if (nmain && PRE)
                         asm volatile("s_waitcnt lgkmcnt(3)\n\tds_read_b128 %0, %2 offset:%3" : "=&v"(w[(k + 4) & 7]), "+v"(w[k & 7]) : "v"(nxt_a), "i"(SK_WOFF(k - 28)));
                     else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(w[k & 7]) : "i"(31 - k));
                     __builtin_amdgcn_sched_barrier(0);                         // the MFMAs below stay BEHIND the statement (hipcc hoists register-only instructions past asm)
@@ -425,14 +477,15 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
 #define SK_G4(b) group(std::integral_constant<int, (b)>{}); group(std::integral_constant<int, (b) + 1>{}); group(std::integral_constant<int, (b) + 2>{}); group(std::integral_constant<int, (b) + 3>{});
                 // the copies of entry q + 3 go out EARLY in the phase (they are drained at its end: issued in its last groups they were waited for, 300-1000
                 // cycles per chunk); the schedule fetch (it blocks its wave ~200 cycles) late, at different points for the two waves of a SIMD
-#define SK_P(t) issue_piece(r3, q + (SK_BAR2 ? 2 : 3), std::integral_constant<int, (t)>{})
+                // (NW = 4: nine pieces per wave, two per slot)
+#define SK_P(sl) if (!top_copy) { issue_piece(r3, q + AHEAD, std::integral_constant<int, (8 / NW) * (sl)>{}); if constexpr (NW == 4) issue_piece(r3, q + AHEAD, std::integral_constant<int, (8 / NW) * (sl) + 1>{}); }
                 SK_G4(0)  SK_P(0);
                 SK_G4(4)  SK_P(1);
                 SK_G4(8)  SK_P(2);
                 SK_G4(12) SK_P(3);
                 SK_G4(16) SK_P(4);
-                SK_G4(20) if (wave < 4) fetch2(q + 2, q + (SK_BAR2 ? 3 : 4), rn, r4);
-                SK_G4(24) if (wave >= 4) fetch2(q + 2, q + (SK_BAR2 ? 3 : 4), rn, r4);
+                SK_G4(20) if (wave < NW / 2) fetch2(q + 2, q + AHEAD + 1, rn, r4);
+                SK_G4(24) if (wave >= NW / 2) fetch2(q + 2, q + AHEAD + 1, rn, r4);
                 SK_G4(28)
                 // the next chunk's first operands must be COMPLETE before the loop's back edge: hipcc takes an asm read's destination as written when the
                 // statement ends and may copy those registers where control flow merges (seen: half-landed copies behind an EPI chunk, 1 % errors)
@@ -457,7 +510,7 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
                 }
                 for (int d = n_prev; d >= 1; --d) {
                     wait_prev(d);
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xacc + ((size_t)(blockIdx.x - d) * 8 + wave) * 4096), 0, 16384, 0x00020000);
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xacc + ((size_t)(blockIdx.x - d) * XW + wave) * 4096), 0, 16384, 0x00020000);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {                              // 16 registers at a time
                         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -472,7 +525,7 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
                 }
             }
             if (r0.fl & SKF_EXPORT) {
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xacc + ((size_t)blockIdx.x * 8 + wave) * 4096), 0, 16384, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xacc + ((size_t)blockIdx.x * XW + wave) * 4096), 0, 16384, 0x00020000);
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -500,8 +553,8 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
                 }
             }
         } else if constexpr (OUT) {
-            issue(r3, q + (SK_BAR2 ? 2 : 3));
-            fetch2(q + 2, q + (SK_BAR2 ? 3 : 4), rn, r4);
+            issue(r3, q + AHEAD);
+            fetch2(q + 2, q + AHEAD + 1, rn, r4);
             if (!(r0.fl & SKF_NONE)) {
                 auto epi_chunk = [&](auto ee) {
                     constexpr int EE = decltype(ee)::value;
@@ -536,7 +589,7 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
                         for (int ot = 0; ot < OT; ++ot) *(f32x4*)(pp + 16 * ot) = oacc[ot];
                     }
                 }
-                if (nmain && !(SK_BAR2 && PAR == 1)) first4(stage_addr(q + 1));
+                if (nmain && PRE) first4(stage_addr(q + 1));
             }
         }
         SK_STAMP(3);
@@ -545,16 +598,16 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
         if (export_issued) {                                                   // ... and its accumulator stores: every storing wave has drained before its flag.  (A counted
             // wait that left the 16 stores in flight -- vmcnt(16) -- let the barrier pass with LDS-DMA copies still under way: stores and loads do not
             // retire in one order; seen as a rollout that was not bitwise repeatable at the C4 share.)
-            if (lane == 0) __hip_atomic_store(a.xflag + (size_t)blockIdx.x * 8 + wave, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(a.xflag + (size_t)blockIdx.x * XW + wave, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             export_issued = false;
         }
         SK_STAMP(4);
 #ifdef SK_DEBUG
         if (!(a.skip & 4))
 #endif
-        if (!SK_BAR2 || PAR == 1) __builtin_amdgcn_s_barrier();                // entry q + 3 (SK_BAR2: q + 1, q + 2) complete in LDS for everybody; everybody is done reading stage q % 4
+        if (!BAR2 || PAR == 1) __builtin_amdgcn_s_barrier();                   // entry q + AHEAD (BAR2: q + 1, q + 2) complete in LDS for everybody; everybody is done reading stage q % NST
         asm volatile("" ::: "memory");
-        if (SK_BAR2 && PAR == 1 && nmain) first4(stage_addr(q + 1));
+        if (!PRE && nmain) first4(stage_addr(q + 1));
         SK_STAMP(5);
         r0 = r1; r1 = rn; r3 = r4;
     };
@@ -574,10 +627,13 @@ __global__ void __launch_bounds__(512) k_mlp_sk(const SkArgs a) {
 
 // ---- host side ----
 struct SkPlan { int grid; size_t lds_bytes; size_t xacc_floats; int nflags; size_t sched_bytes; };
-template <int AMODE, int EPI, int S0, int OT>
+template <int AMODE, int EPI, int S0, int OT, int NW = 8>
 static inline SkPlan sk_plan(SkArgs& a, int n_sm, int grid_override = 0) {
     using GE = SkGeom<AMODE, EPI, S0, OT>;
-    a.RB = (a.M + 127) / 128; a.CB = a.N / 256; a.NCk = a.K1 / 32;
+    using FM = SkForm<NW>;
+    n_sm *= FM::WPC;                                                           // workgroups the chip holds at a time
+    a.tm = FM::TM;
+    a.RB = (a.M + FM::TM - 1) / FM::TM; a.CB = a.N / 256; a.NCk = a.K1 / 32;
     a.L = a.NCk + ((EPI == SK_EPI_OUT) ? SkEpi<OT>::E : 1);
     a.tiles = a.heads * a.CB * a.RB;
     a.units = (long long)a.tiles * a.L;
@@ -589,9 +645,9 @@ static inline SkPlan sk_plan(SkArgs& a, int n_sm, int grid_override = 0) {
     long long cap = a.units / p.grid + 2LL * a.L + 8;
     if (a.team) { const long long PP = (p.grid / 8) / a.CB, n_st = ((long long)a.heads * a.RB + PP - 1) / PP; cap = n_st * a.L / 8 + 2LL * a.L + 8; }
     a.sched_cap = (int)cap;
-    p.lds_bytes = (size_t)4 * GE::STAGE * sizeof(float);
-    p.xacc_floats = (size_t)p.grid * 8 * 4096;
-    p.nflags = p.grid * 8;
+    p.lds_bytes = (size_t)FM::NST * GE::STAGE * sizeof(float);
+    p.xacc_floats = (size_t)p.grid * NW * 4096;
+    p.nflags = p.grid * NW;
     p.sched_bytes = (size_t)p.grid * cap * sizeof(SkRec) + (((size_t)p.grid * sizeof(int) + 255) & ~(size_t)255);
     return p;
 }
@@ -604,14 +660,14 @@ static inline hipError_t sk_build_sched(SkArgs& a, const SkPlan& p, void* mem, h
     a.hdr = hdr; a.recs = recs;
     return hipGetLastError();
 }
-template <int AMODE, int EPI, int S0, int OT>
+template <int AMODE, int EPI, int S0, int OT, int NW = 8>
 static inline hipError_t sk_launch(const SkArgs& a, const SkPlan& p, hipStream_t st) {
-    auto kern = k_mlp_sk<AMODE, EPI, S0, OT>;
+    auto kern = k_mlp_sk<AMODE, EPI, S0, OT, NW>;
     {   // every launch (the attribute belongs to the CURRENT device and the call is cheap: a process-wide cache broke a second context on another GPU)
         const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(p.grid), dim3(512), p.lds_bytes, st, a);
+    hipLaunchKernelGGL(kern, dim3(p.grid), dim3(64 * NW), p.lds_bytes, st, a);
     return hipGetLastError();
 }
 

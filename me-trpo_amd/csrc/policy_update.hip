@@ -336,7 +336,14 @@ __global__ void __launch_bounds__(1024) k_finalize(ProblemDesc pd, int mode, int
             t = (raw > (double)LOG_MIN_STD) ? c * v[p] * t : 0.0;
         }
         // a fused tail reads `out` in ANOTHER workgroup (the last to arrive): write-through (sc1) stores, drained before the arrival ticket, instead of a
-        // cache-wide release per workgroup (buffer_wbl2 x 45 workgroups at C1, x 391 for the 100-50-25 policy: 25-49 us of that reduction)
+        // cache-wide release per workgroup (buffer_wbl2 x 45 workgroups at C1, x 391 for the 100-50-25 policy: 25-49 us of that reduction).
+        // This relies on gfx942 / gfx950 lowering a relaxed agent-scope atomic store to an sc1 write-through store (visible beyond this XCD's L2 once vmcnt
+        // drains).  EVERYTHING the closing workgroup reads that another workgroup of this launch wrote must travel this way -- today exactly: `out` (here) and the
+        // exchange packets (xchg_push: agent-scope stores).  theta, v, partials and the CG state are written by EARLIER launches.  A plain store added to that list
+        // would be a silent stale read across XCDs: on any other target the build stops here instead of guessing.
+#if !defined(__gfx942__) && !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
+#error "k_finalize's fence-free hand-over is written for gfx942 / gfx950 (sc1 write-through stores); other targets need fence(release, agent) before the ticket"
+#endif
         if (tail.op != 0 || xc.world > 1) __hip_atomic_store(out + p, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else out[p] = t;
         if (xc.world > 1) xchg_push(xc, p, t);                // sharded run: this rank's share goes straight into every rank's receive slot

@@ -128,7 +128,7 @@ int sched_cus(metrpo_ctx* c, hipStream_t st) {
 }
 // grid <= (workgroups of this kernel the runtime says fit a CU) x (CUs that really schedule our waves); exclusive use of the device as told by the host
 bool grid_is_coresident(metrpo_ctx* c, const void* kernel, int threads, size_t lds, long long grid, hipStream_t st) {
-    if (!c->exclusive) return false;
+    if (!ctx_exclusive(c)) return false;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess) { (void)hipGetLastError(); return false; }
     if (per_cu > 1) per_cu -= 1;                                                // the API answers one too many at some SGPR counts (MI355X_MICROARCH.md, residency)

@@ -588,7 +588,9 @@ int launch_gae(metrpo_ctx* c, const float* obs, const float* rew, const uint8_t*
     if (pre_v) {
         const size_t shp = sizeof(float) * 4 * 64 * (size_t)ns;
         if (shp > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_baseline_predict, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp));
+        // (V = c->d_vbuf holds T * B doubles: ensured by the caller, metrpo_gae / launch_process_fused, before launch_gae is entered)
         hipLaunchKernelGGL(k_baseline_predict, dim3(nblk, (T + 3) / 4), dim3(256), shp, st, obs, tpath, coeffs, ns, V, T, B);
+        HIP_TRY(c, hipGetLastError());                       // a failed launch is reported HERE, not as k_gae's
     }
     const size_t sh = (coeffs != nullptr && !pre_v) ? sizeof(float) * nw * 64 * (size_t)ns : 0;
 #define GAE_LAUNCH_NW(NSV, NWV) do { \
@@ -650,6 +652,10 @@ __global__ void __launch_bounds__(1024) k_baseline_solve(int F, const double* __
             // No row exchanges (third pass of round 5; until then: a pivot search by the first wave + the exchange = two more barriers per pivot, 302 us at F = 114):
             // A + reg I is symmetric positive definite, for which elimination in the natural order is as stable as with partial pivoting -- what the one-wave
             // solver of the small envs below has always done; a non-finite result escalates reg like a NaN.
+            // A pivot that is not positive is numerical breakdown of a system that is positive definite on paper (columns collinear to within rounding): the attempt
+            // counts as failed and reg escalates, like a non-finite solution -- the reference's SVD-based lstsq returns a bounded solution there, large finite
+            // coefficients out of a sign-flipped pivot would not be one.
+            if (tid == 0 && !(Ms[k * W + k] > 0.0)) s_bad = 1;
             const double inv = 1.0 / Ms[k * W + k];
             // rows below k x columns right of k (rhs included): a thread owns ONE column (W <= 128) and every RS-th row (RS = blockDim / 128 = 8: 16 waves, a
             // pivot's update is ~7 rows per thread) -- no integer division per element (as `i / nc, i % nc` over a flat index the update was 386 us at F = 114, most
@@ -701,6 +707,7 @@ __global__ void __launch_bounds__(64) k_baseline_solve_wave(const double* __rest
     double x[FT];
     for (int attempt = 0; attempt < 5; ++attempt) {
         double row[FT + 1];
+        bool bad = false;
 #pragma unroll
         for (int c = 0; c < FT; ++c) row[c] = live ? AtA[lane * FT + c] + (lane == c ? reg : 0.0) : 0.0;
         row[FT] = live ? Aty[lane] : 0.0;
@@ -709,13 +716,13 @@ __global__ void __launch_bounds__(64) k_baseline_solve_wave(const double* __rest
             double pv[FT + 1];
 #pragma unroll
             for (int c = k; c <= FT; ++c) pv[c] = readlane_f64(row[c], k);
+            bad = bad || !(pv[k] > 0.0);                     // (uniform) a pivot that is not positive: numerical breakdown, the attempt fails and reg escalates (k_baseline_solve: why)
             const double f = row[k] * (1.0 / pv[k]);
             if (lane > k) {
 #pragma unroll
                 for (int c = k + 1; c <= FT; ++c) row[c] = fma(-f, pv[c], row[c]);
             }
         }
-        bool bad = false;
 #pragma unroll
         for (int k = FT - 1; k >= 0; --k) {
             double a = row[FT];

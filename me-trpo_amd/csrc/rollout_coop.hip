@@ -690,7 +690,7 @@ int launch_rollout_coop(metrpo_ctx* c, int idx, const RolloutK& r_in, hipStream_
     if (c->rollout_variant == 2) one = false;
     // a GPU shared with other compute processes (METRPO_NO_RESIDENT=1, the switch that also keeps rollout_resident.hip out): the migrating schedule's
     // consumers wait for producer workgroups of their own grid, which other processes' workgroups can keep off the chip until the bounded wait gives up
-    if (one && tiles > n_cu && (!c->exclusive || ctx_opt(c, OPT_NO_RESIDENT) != nullptr)) one = false;
+    if (one && tiles > n_cu && !ctx_exclusive(c)) one = false;
     const int grid = one ? (tiles < n_cu ? tiles : n_cu) : tiles;
     if (one && tiles > grid) {                                           // hand-over slots: flag[tiles] | ts[16 tiles] | model[16 tiles] | obs[16 tiles][ns]
         const int ns = c->pd.ns;

@@ -1031,7 +1031,7 @@ static const ResidentEntry* resident_table(int* n) {
 // METRPO_EUNSUPPORTED: this shape / call stays on the step-wise path (rollout_gemm.hip)
 int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t st) {
     const ProblemDesc& pd = c->pd;
-    if (c->rollout_variant == 1 || c->res_failed || !c->exclusive || ctx_opt(c, OPT_NO_RESIDENT) != nullptr) return METRPO_EUNSUPPORTED;
+    if (c->rollout_variant == 1 || c->res_failed || !ctx_exclusive(c)) return METRPO_EUNSUPPORTED;
     if (pd.dyn.n_layers != 3 || pd.dyn.dims[1] != pd.dyn.dims[2] || pd.dyn.act[0] != METRPO_ACT_RELU || pd.dyn.act[1] != METRPO_ACT_RELU ||
         pd.dyn.act[2] != METRPO_ACT_IDENTITY) return METRPO_EUNSUPPORTED;
     if (pd.pol.n_layers != 3 || pd.pol.dims[1] != 32 || pd.pol.dims[2] != 32 || pd.pol.act[0] != METRPO_ACT_TANH || pd.pol.act[1] != METRPO_ACT_TANH)
@@ -1154,7 +1154,7 @@ int launch_validation_resident(metrpo_ctx* c, const float* s0, int Bv, int T, do
         RES_VAL_ENTRY(METRPO_ENV_ANT, 1024, 64),
     };
     const ProblemDesc& pd = c->pd;
-    if (c->res_failed || !c->exclusive || ctx_opt(c, OPT_NO_RESIDENT) != nullptr || T <= 0) return METRPO_EUNSUPPORTED;
+    if (c->res_failed || !ctx_exclusive(c) || T <= 0) return METRPO_EUNSUPPORTED;
     if (pd.dyn.n_layers != 3 || pd.dyn.dims[1] != pd.dyn.dims[2] || pd.dyn.act[0] != METRPO_ACT_RELU || pd.dyn.act[1] != METRPO_ACT_RELU ||
         pd.dyn.act[2] != METRPO_ACT_IDENTITY) return METRPO_EUNSUPPORTED;
     if (pd.pol.n_layers != 3 || pd.pol.dims[1] != 32 || pd.pol.dims[2] != 32 || pd.pol.act[0] != METRPO_ACT_TANH || pd.pol.act[1] != METRPO_ACT_TANH)

@@ -10,6 +10,8 @@ import torch
 from . import _lib
 from ._lib import lib, check
 
+METRPO_UNSET = -100            # include/metrpo.h: metrpo_get_option of a known key without a value
+
 Trajectory = namedtuple('Trajectory', 'obs act rew mean done tpath last_obs B T H')
 """Time-major device tensors of one rollout: obs [T,B,ns], act [T,B,na] (unclipped), rew [T,B],
 mean [T,B,na], done [T,B] uint8, tpath [T,B] int32, last_obs [B,ns]."""
@@ -175,7 +177,7 @@ class Engine(object):
         """Current value of a switch as a string, None when unset."""
         buf = C.create_string_buffer(256)
         n = lib.metrpo_get_option(self._ctx, str(key).encode(), buf, 256)
-        if n == -1:
+        if n == METRPO_UNSET:                     # a known key without a value; an unknown key is METRPO_EINVAL and raises
             return None
         if n < 0:
             self._chk(n)

@@ -348,3 +348,5 @@ def test_rollout_note_names_shapes_off_the_fast_table():
         assert (note == '') if not needle else (needle in note), note
     with pytest.raises(Exception, match='unknown key'):
         eng.set_option('NO_SUCH_SWITCH', '1')
+    with pytest.raises(Exception, match='unknown key'):          # (an unknown key is an error, an unset one is None)
+        eng.get_option('NO_SUCH_SWITCH')

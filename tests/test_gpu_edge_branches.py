@@ -209,3 +209,28 @@ def test_baseline_solve_regulariser_retry(env):
     A3 = A2.copy(); A3[1, 1] = np.nan
     gram3 = torch.tensor(np.concatenate([A3.reshape(-1), b]), dtype=torch.float64, device=eng.device)
     assert not np.isfinite(cpu(eng.baseline_solve(gram3, reg_coeff=reg))).all()
+
+
+@pytest.mark.parametrize('env', ['swimmer', 'humanoid'])
+def test_baseline_solve_rank_deficient_features_match_lstsq(env):
+    """A constant observation column (a clipped, saturated state dim) makes the feature matrix rank deficient: obs_j = c * ones and obs_j^2 = c^2 * ones are
+    collinear with the constant feature.  F^T F + reg I is then positive definite only through reg (condition ~ 1e12).  The reference solves it with the
+    SVD-based np.linalg.lstsq (linear_feature_baseline.py [rllab]); the device's elimination in the natural order must return the same FIT -- the
+    predictions F x, which is all the next GAE reads -- and bounded coefficients, not large finite numbers out of a broken pivot."""
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, 2, (64, 64), (32, 32) if env != 'humanoid' else (100, 50, 25), seed=3)
+    ns = dm.ns
+    rng = np.random.RandomState(11)
+    n = 4000
+    obs = np.clip(rng.randn(n, ns), -10, 10)
+    obs[:, 1] = 0.75                                                                # the saturated dim
+    obs[:, ns - 1] = obs[:, 0]                                                      # and an exactly duplicated one
+    al = (np.arange(n) % 100).reshape(-1, 1) / 100.0
+    Fm = np.concatenate([obs, obs ** 2, al, al ** 2, al ** 3, np.ones((n, 1))], axis=1)      # LinearFeatureBaseline._features
+    y = rng.randn(n) + Fm[:, 0]
+    A, b, reg = Fm.T @ Fm, Fm.T @ y, 1e-5
+    gram = torch.tensor(np.concatenate([A.reshape(-1), b]), dtype=torch.float64, device=eng.device)
+    got = cpu(eng.baseline_solve(gram, reg_coeff=reg))
+    want = np.linalg.lstsq(A + reg * np.eye(Fm.shape[1]), b, rcond=None)[0]
+    assert np.isfinite(got).all()
+    assert np.abs(got).max() <= 10.0 * max(1.0, np.abs(want).max())                 # bounded like the minimum-norm solution
+    np.testing.assert_allclose(Fm @ got, Fm @ want, rtol=0, atol=1e-6 * np.abs(y).max())      # the same fit

@@ -53,7 +53,7 @@ static double timeit(const std::function<void()>& f, int reps = 10) {      // >=
 }
 
 // ---- fused 2-hidden-layer MLP: x -> relu(x W0 + b0) -> relu(. W1 + b1) -> . W2 (partials per 256-column block; b2 left to the consumer) ----
-template <int S0, int OT>
+template <int S0, int OT, int NW = 8>
 static void run_fused(const char* name, int M, int heads, int nin, int Hd, int no, bool check, int grid_override, int n_sm) {
     Net net = make_net(heads, nin, Hd, Hd, no, 7);
     const int lda = 4 * S0;
@@ -64,7 +64,7 @@ static void run_fused(const char* name, int M, int heads, int nin, int Hd, int n
     a.M = M; a.heads = heads; a.K1 = Hd; a.N = Hd;
     a.A = dX; a.strideA = 0; a.lda = lda;
     a.W0 = dW + net.oW0; a.strideW0 = net.np; a.W1 = dW + net.oW1; a.strideW1 = net.np;
-    SkPlan p = sk_plan<SK_A_PRODUCER, SK_EPI_OUT, S0, OT>(a, n_sm, grid_override);
+    SkPlan p = sk_plan<SK_A_PRODUCER, SK_EPI_OUT, S0, OT, NW>(a, n_sm, grid_override);
     const int CB = a.CB, E = SkEpi<OT>::E;
     float* dImg; CK(hipMalloc(&dImg, (size_t)heads * CB * E * SkEpi<OT>::FLOATS * 4));
     const long long tot = (long long)heads * CB * E * SkEpi<OT>::FLOATS;
@@ -76,7 +76,7 @@ static void run_fused(const char* name, int M, int heads, int nin, int Hd, int n
     CK(hipMalloc(&a.err, 8)); CK(hipMemset(a.err, 0, 8));
     void* smem; CK(hipMalloc(&smem, p.sched_bytes)); CK((sk_build_sched<SK_A_PRODUCER, SK_EPI_OUT, S0, OT>(a, p, smem, 0)));
     unsigned epoch = 0;
-    auto go = [&]() { a.epoch = ++epoch; CK((sk_launch<SK_A_PRODUCER, SK_EPI_OUT, S0, OT>(a, p, 0))); };
+    auto go = [&]() { a.epoch = ++epoch; CK((sk_launch<SK_A_PRODUCER, SK_EPI_OUT, S0, OT, NW>(a, p, 0))); };
     go(); CK(hipDeviceSynchronize());
     double err; CK(hipMemcpy(&err, a.err, 8, hipMemcpyDeviceToHost));
     if (err) printf("  !! hand-over time-out reported\n");
@@ -115,6 +115,7 @@ static void run_fused(const char* name, int M, int heads, int nin, int Hd, int n
 }
 
 // ---- one wide layer from activations in HBM: C = relu(A W1 + b1) ----
+template <int NW = 8>
 static void run_layer(const char* name, int M, int heads, int Kd, int N, bool check, int grid_override, int n_sm, bool old_too) {
     auto A = rnd((size_t)heads * M * Kd, 3), W = rnd((size_t)heads * Kd * N, 5, 1.0f / sqrtf((float)Kd)), b = rnd((size_t)heads * N, 9);
     float *dA = up(A), *dW = up(W), *db = up(b), *dC, *dC2;
@@ -123,12 +124,12 @@ static void run_layer(const char* name, int M, int heads, int Kd, int N, bool ch
     a.M = M; a.heads = heads; a.K1 = Kd; a.N = N; a.A = dA; a.strideA = (long long)M * Kd; a.lda = Kd; a.W1 = dW; a.strideW1 = (long long)Kd * N;
     a.b1 = db; a.strideB1 = N; a.C = dC; a.strideC = (long long)M * N; a.ldc = N;
     a.skip = (!check && getenv("SK_SKIP")) ? atoi(getenv("SK_SKIP")) : 0;
-    SkPlan p = sk_plan<SK_A_GLOBAL, SK_EPI_STORE, 1, 1>(a, n_sm, grid_override);
+    SkPlan p = sk_plan<SK_A_GLOBAL, SK_EPI_STORE, 1, 1, NW>(a, n_sm, grid_override);
     CK(hipMalloc(&a.xacc, p.xacc_floats * 4)); CK(hipMalloc(&a.xflag, p.nflags * 4)); CK(hipMemset(a.xflag, 0, p.nflags * 4));
     CK(hipMalloc(&a.err, 8)); CK(hipMemset(a.err, 0, 8));
     void* smem; CK(hipMalloc(&smem, p.sched_bytes)); CK((sk_build_sched<SK_A_GLOBAL, SK_EPI_STORE, 1, 1>(a, p, smem, 0)));
     unsigned epoch = 0;
-    auto go = [&]() { a.epoch = ++epoch; CK((sk_launch<SK_A_GLOBAL, SK_EPI_STORE, 1, 1>(a, p, 0))); };
+    auto go = [&]() { a.epoch = ++epoch; CK((sk_launch<SK_A_GLOBAL, SK_EPI_STORE, 1, 1, NW>(a, p, 0))); };
     GemmEpi ep = {}; ep.bias = db; ep.strideBias = N;
     auto go_old = [&]() { gemm_auto<EPI_BIAS_RELU, false, false>(dA, (long long)M * Kd, Kd, dW, (long long)Kd * N, N, dC2, (long long)M * N, N, M, N, Kd, heads, ep, 0); };
     go(); CK(hipDeviceSynchronize());
@@ -149,17 +150,17 @@ static void run_layer(const char* name, int M, int heads, int Kd, int N, bool ch
         printf("  check %-28s M=%5d heads=%2d K=%4d N=%4d grid=%3d : max|err| %.3e %s\n", name, M, heads, Kd, N, p.grid, maxerr, maxerr <= 2e-5 ? "OK" : "FAIL");
         // bitwise: another grid must give the same sums
         std::vector<float> C1 = C;
-        SkPlan p2 = sk_plan<SK_A_GLOBAL, SK_EPI_STORE, 1, 1>(a, n_sm, p.grid > 3 ? p.grid - 3 : p.grid + 1);
+        SkPlan p2 = sk_plan<SK_A_GLOBAL, SK_EPI_STORE, 1, 1, NW>(a, n_sm, p.grid > 3 ? p.grid - 3 : p.grid + 1);
         float* xa2; unsigned* xf2; CK(hipMalloc(&xa2, p2.xacc_floats * 4)); CK(hipMalloc(&xf2, p2.nflags * 4)); CK(hipMemset(xf2, 0, p2.nflags * 4));
         float* xa1 = a.xacc; unsigned* xf1 = a.xflag; a.xacc = xa2; a.xflag = xf2; a.epoch = 1;
         void* smem2; CK(hipMalloc(&smem2, p2.sched_bytes)); CK((sk_build_sched<SK_A_GLOBAL, SK_EPI_STORE, 1, 1>(a, p2, smem2, 0)));
         CK(hipMemset(dC, 0, C.size() * 4));
-        CK((sk_launch<SK_A_GLOBAL, SK_EPI_STORE, 1, 1>(a, p2, 0))); CK(hipDeviceSynchronize());
+        CK((sk_launch<SK_A_GLOBAL, SK_EPI_STORE, 1, 1, NW>(a, p2, 0))); CK(hipDeviceSynchronize());
         CK(hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost));
         size_t diff = 0; for (size_t q = 0; q < C.size(); ++q) diff += (memcmp(&C[q], &C1[q], 4) != 0);
         printf("        grid %d vs grid %d: %zu of %zu outputs differ bitwise %s\n", p.grid, p2.grid, diff, C.size(), diff == 0 ? "OK" : "FAIL");
         a.xacc = xa1; a.xflag = xf1; CK(hipFree(xa2)); CK(hipFree(xf2));
-        sk_plan<SK_A_GLOBAL, SK_EPI_STORE, 1, 1>(a, n_sm, grid_override);
+        sk_plan<SK_A_GLOBAL, SK_EPI_STORE, 1, 1, NW>(a, n_sm, grid_override);
         CK(hipFree(smem2));
     } else {
         if (getenv("SK_STAMPS")) { unsigned long long* d2; CK(hipMalloc(&d2, 48 * 8)); CK(hipMemset(d2, 0, 48 * 8)); a.dbg2 = d2; go(); go(); CK(hipDeviceSynchronize());
@@ -176,6 +177,8 @@ static void run_layer(const char* name, int M, int heads, int Kd, int N, bool ch
               t_in0 = std::min(t_in0, d[3]); t_in1 = std::max(t_in1, d[3]); t_l0 = std::min(t_l0, d[4]); t_l1 = std::max(t_l1, d[4]); t_e0 = std::min(t_e0, d[5]); t_e1 = std::max(t_e1, d[5]); }
           printf("    main loop (wave 0 of each workgroup): %.0f cycles (max %.0f) / %.1f us = %.2f GHz; %.0f entries -> %.0f cycles per entry (MFMA issue floor 8192)\n", cyc / p.grid, cmax, tk / p.grid / 100.0,
                  cyc / tk / 10.0, nqs / p.grid, cyc / nqs);
+          { double c0 = 0, c1 = 0; for (int b = 0; b < p.grid; ++b) (b < p.grid / 2 ? c0 : c1) += (double)hd[8 * b]; 
+            printf("    workgroups [0, grid/2): %.0f cycles, [grid/2, grid): %.0f cycles (mean loop time; dispatch order: first / second workgroup of a CU when grid = 2 x CUs)\n", c0 / (p.grid / 2), c1 / (p.grid - p.grid / 2)); }
           printf("    timeline (us from the first workgroup's entry): entries ..%.1f | loop starts %.1f..%.1f | last-wave exits %.1f..%.1f\n", (t_in1 - t_in0) / 100.0, (t_l0 - t_in0) / 100.0,
                  (t_l1 - t_in0) / 100.0, (t_e0 - t_in0) / 100.0, (t_e1 - t_in0) / 100.0); }
         a.dbg = nullptr; CK(hipFree(dbg));
@@ -194,6 +197,16 @@ int main(int argc, char** argv) {
     const bool perf_only = argc > 1 && argv[1][0] == 'p';
     if (argc > 1 && argv[1][0] == 'd') { run_fused<9, 2>("fused ant split", 300, 2, 35, 512, 29, true, 5, n_sm); return 0; }
     if (!perf_only) {
+        run_layer<4>("4w layer small", 300, 3, 64, 256, true, 0, n_sm, false);
+        run_layer<4>("4w layer split 7 tiles / 4 wg", 300, 1, 128, 512, true, 4, n_sm, false);
+        run_layer<4>("4w layer inside-one-tile", 100, 1, 256, 256, true, 3, n_sm, false);
+        run_layer<4>("4w layer C3-like", 2500, 10, 512, 512, true, 0, n_sm, false);
+        run_fused<9, 2, 4>("4w fused ant small", 300, 2, 35, 256, 29, true, 0, n_sm);
+        run_fused<9, 2, 4>("4w fused ant split", 300, 2, 35, 512, 29, true, 5, n_sm);
+        run_fused<10, 2, 4>("4w fused ant 37 in", 300, 2, 37, 512, 29, true, 5, n_sm);
+        run_fused<6, 2, 4>("4w fused half-cheetah", 200, 3, 23, 512, 18, true, 7, n_sm);
+        run_fused<3, 1, 4>("4w fused swimmer", 100, 5, 10, 512, 10, true, 0, n_sm);
+        run_fused<9, 2, 4>("4w fused ant C3 share", 2500, 10, 35, 512, 29, true, 0, n_sm);
         run_layer("layer small", 300, 3, 64, 256, true, 0, n_sm, false);
         run_layer("layer split 7 tiles / 4 wg", 300, 1, 128, 512, true, 4, n_sm, false);       // 3 row blocks x 2 col blocks = 6 tiles on 4 workgroups
         run_layer("layer inside-one-tile", 100, 1, 256, 256, true, 3, n_sm, false);             // 1 tile on 3 workgroups: import AND export in one piece
@@ -205,6 +218,12 @@ int main(int argc, char** argv) {
         run_fused<9, 2>("fused ant C3 share", 2500, 10, 35, 512, 29, true, 0, n_sm);
     }
     printf("-- timing (random operands) --\n");
+    run_layer<4>("4w C4 hidden layer", 6250, 20, 1024, 1024, false, 0, n_sm, false);
+    run_layer<4>("4w C2 hidden layer", 2500, 5, 1024, 1024, false, 0, n_sm, false);
+    run_layer<4>("4w C3 hidden layer", 2500, 10, 512, 512, false, 0, n_sm, false);
+    run_layer<4>("4w 8192 x 4096 x 4096", 8192, 1, 4096, 4096, false, 0, n_sm, false);
+    run_fused<9, 2, 4>("4w C3 fused MLP (ant 2x512)", 2500, 10, 35, 512, 29, false, 0, n_sm);
+    run_fused<6, 2, 4>("4w C2 fused MLP (half-cheetah 2x1024)", 2500, 5, 23, 1024, 18, false, 0, n_sm);
     run_layer("C4 hidden layer", 6250, 20, 1024, 1024, false, 0, n_sm, true);
     run_layer("C2 hidden layer", 2500, 5, 1024, 1024, false, 0, n_sm, true);
     run_layer("C3 hidden layer", 2500, 10, 512, 512, false, 0, n_sm, true);
