@@ -122,6 +122,8 @@ def main():
                     help='weak (default): every GPU runs the per-GPU share of the config (B / gpus the config is quoted on), total work grows with --gpus; '
                          'strong: the config\'s WHOLE batch B is divided over the --gpus ranks (B / N envs each: the literal reading of BASELINE.json\'s "K=5, B=5000 ... at 1/2/4/8")')
     ap.add_argument('--params', default=None, help='one of the reference\'s params/params-*.json files: run ITS shapes (overrides --config; metrpo_amd.shapes_from_params)')
+    ap.add_argument('--B', type=int, default=None, help='per-GPU env count instead of the config\'s share (tools/scaling_model.py times the strong-scaling shares on ONE GPU with it; the line says so)')
+    ap.add_argument('--no-strong', action='store_true', help='skip the second (strong-scaling) timed region of a --gpus N > 1 run')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-H', type=int, default=100, help='horizon of the bounded CPU-baseline sample')
     args = ap.parse_args()
@@ -171,30 +173,37 @@ def main():
         assert B >= 16, "--scaling strong: %d envs over %d ranks leaves fewer than one 16-env tile per rank" % (cfg['B'], args.gpus)
     else:
         B = cfg['B'] // cfg['gpus']                           # per-GPU share of the config's B (weak scaling keeps it fixed)
+    if args.B is not None:
+        B = args.B                                            # a share chosen by the caller (scaling model: what ONE rank of an N-rank strong run computes)
     ns, na, n_drop = synthetic.ENV_SPECS[env]
-    eng = metrpo_amd.Engine(env, K, cfg['dyn_hidden'], cfg['pol_hidden'], device=dev)
-    if oversub:
-        eng.set_exclusive(False)                              # several ranks per device: no kernel whose workgroups wait on each other inside one launch
-    Ws, bs, norm = synthetic.make_dynamics(env, K, cfg['dyn_hidden'], seed=0)
-    eng.set_dynamics_layers(Ws, bs, norm['in_mean'], norm['in_std'], norm['diff_mean'], norm['diff_std'])
-    policy = metrpo_amd.GaussianMLPPolicy(eng, init_std=1.0, seed=0)
-    baseline = metrpo_amd.LinearFeatureBaseline()
-    init = metrpo_amd.InitStatePool(synthetic.make_pool(env), na)
-    nne = metrpo_amd.NeuralNetEnv(env=init, inner_env=None, cost_np=env, dynamics_in=None, dynamics_outs=eng,
-                                  sam_mode='step_rand')
-    algo = metrpo_amd.TRPO(env=nne, policy=policy, baseline=baseline, batch_size=cfg.get('batch_size', B * H), max_path_length=H,
-                           discount=1.0, step_size=0.01, sampler_args=dict(n_envs=B), comm=comm, seed=0)
-    transport = False                         # N > 1: all-reduces issued from C (one-shot exchange over peer-mapped regions, else RCCL)
-    if comm.world > 1 and os.environ.get('METRPO_BENCH_NO_CTX_COMM', '0') != '1':
-        try:
-            transport = comm.attach_engine(eng)
-        except Exception as e:                # never lose the multi-GPU line: fall back to torch.distributed through the host callback
-            sys.stderr.write('rank %d: ctx-owned transport unavailable (%r); using the torch.distributed callback\n' % (comm.rank, e))
-            comm.engine = None
-    algo.defer_baseline_fit = True            # host solve of the 24x24 baseline system overlaps the next rollout
-    algo.reuse_trajectory_buffers = True      # one set of [T,B,.] tensors, overwritten every iteration
-    algo.device_baseline_fit = os.environ.get('METRPO_BENCH_HOST_BASELINE_FIT') != '1'   # the 24x24 solve of the baseline fit as a kernel: coefficients stay on the device
-    algo.async_line_search = os.environ.get('METRPO_BENCH_SYNC_LINESEARCH') != '1'     # update enqueued without a host round trip per trial; closed after the next rollout is enqueued
+    def build_leg(B):
+        """Engine + the reference's objects (policy, baseline, NeuralNetEnv, TRPO) for B envs on this rank, attached to the exchange transport."""
+        eng = metrpo_amd.Engine(env, K, cfg['dyn_hidden'], cfg['pol_hidden'], device=dev)
+        if oversub:
+            eng.set_exclusive(False)                          # several ranks per device: no kernel whose workgroups wait on each other inside one launch
+        Ws, bs, norm = synthetic.make_dynamics(env, K, cfg['dyn_hidden'], seed=0)
+        eng.set_dynamics_layers(Ws, bs, norm['in_mean'], norm['in_std'], norm['diff_mean'], norm['diff_std'])
+        policy = metrpo_amd.GaussianMLPPolicy(eng, init_std=1.0, seed=0)
+        baseline = metrpo_amd.LinearFeatureBaseline()
+        init = metrpo_amd.InitStatePool(synthetic.make_pool(env), na)
+        nne = metrpo_amd.NeuralNetEnv(env=init, inner_env=None, cost_np=env, dynamics_in=None, dynamics_outs=eng,
+                                      sam_mode='step_rand')
+        algo = metrpo_amd.TRPO(env=nne, policy=policy, baseline=baseline, batch_size=cfg.get('batch_size', B * H), max_path_length=H,
+                               discount=1.0, step_size=0.01, sampler_args=dict(n_envs=B), comm=comm, seed=0)
+        transport = False                     # N > 1: all-reduces issued from C (one-shot exchange over peer-mapped regions, else RCCL)
+        if comm.world > 1 and os.environ.get('METRPO_BENCH_NO_CTX_COMM', '0') != '1':
+            try:
+                transport = comm.attach_engine(eng)
+            except Exception as e:            # never lose the multi-GPU line: fall back to torch.distributed through the host callback
+                sys.stderr.write('rank %d: ctx-owned transport unavailable (%r); using the torch.distributed callback\n' % (comm.rank, e))
+                comm.engine = None
+        algo.defer_baseline_fit = True        # host solve of the 24x24 baseline system overlaps the next rollout
+        algo.reuse_trajectory_buffers = True  # one set of [T,B,.] tensors, overwritten every iteration
+        algo.device_baseline_fit = os.environ.get('METRPO_BENCH_HOST_BASELINE_FIT') != '1'   # the 24x24 solve of the baseline fit as a kernel: coefficients stay on the device
+        algo.async_line_search = os.environ.get('METRPO_BENCH_SYNC_LINESEARCH') != '1'     # update enqueued without a host round trip per trial; closed after the next rollout is enqueued
+        return eng, algo, transport
+
+    eng, algo, transport = build_leg(B)
 
     from metrpo_amd.tracing import timing_event          # HIP events with a device-scope release: a torch.cuda.Event record costs the next kernel 6-15 us
     ev_roll, ev_upd, ev_iter, steps_run, n_valid = [], [], [], [], []
@@ -331,7 +340,8 @@ def main():
                                "0: host lstsq deferred behind the next rollout, defer_baseline_fit) async_line_search=%d (the accept test of the first two line-search trials runs on "
                                "the device and the host closes the update after it has enqueued the next rollout: same trials, same rule, same results)"
                                % (args.config, env, K, list(cfg['dyn_hidden']), list(cfg['pol_hidden']), B, args.scaling, cfg['B'], cfg['gpus'], H, T_mean, int(bool(algo.device_baseline_fit)), int(bool(algo.async_line_search))),
-                   "parallelism": "B-sharded x%d, sum all-reduce of g/FVP/scalars" % comm.world},
+                   "parallelism": "B-sharded x%d, sum all-reduce of g/FVP/scalars" % comm.world,
+                   "B_override": args.B},                      # not None: --B chose the per-GPU share (tools/scaling_model.py), not the config
         "trpo_iter_ms": ms_per_step,
         "instrumented_pass": {"iterations": n_inst, "ms_per_step": comm.max_float(float(np.mean(iter_ms)), device=side),
                               "note": "rollout.ms, roofline.update.ms and ms_per_step_median come from this second pass over the same iterations with HIP events "
@@ -385,6 +395,57 @@ def main():
                                                    'rccl': "rccl-in-ctx (ncclAllReduce issued by libmetrpo.so)"}.get(
                                                        transport, "torch.distributed %s via host callback" % backend),
                                    one_shot_error=getattr(comm, 'one_shot_error', None))
+    # Second timed region of the same command: STRONG scaling (BASELINE.json reads "K=5, B=5000 ... at 1/2/4/8": the config's whole batch divided over the
+    # ranks of this run, cfg['B'] / N envs each), behind the weak-scaling one above (per-GPU share fixed).  Same K steps / W warm-up, same barrier +
+    # synchronize bracket, max over ranks; no events, no instrumented pass.  The driver runs one command per N and finds both scalings on its line.
+    if args.scaling == 'weak' and args.B is None and not args.no_strong:
+        B_s = cfg['B'] // comm.world
+        if B_s == B:                                            # N = the GPU count the config is quoted on (C1 at N = 1, C4 at N = 8 ...): the same run
+            out["strong"] = {"ms_per_step": ms_per_step, "value": out["value"], "unit": "env-steps/s", "B_per_gpu": B, "B_total": B * comm.world,
+                             "note": "config B = %d over %d rank(s) is the weak-scaling share: the timed region above IS the strong-scaling point" % (cfg['B'], comm.world)}
+        elif B_s < 16:
+            out["strong"] = {"ms_per_step": None, "value": None, "unit": "env-steps/s", "B_per_gpu": B_s, "note": "fewer than one 16-env tile per rank: not run"}
+        else:
+            try:
+                if transport == 'one-shot':
+                    eng.comm_ipc_detach()
+                elif transport == 'rccl':
+                    eng.comm_destroy()
+                comm.engine = None
+                algo.optimizer.finish()
+                torch.cuda.synchronize()
+                eng_s, algo_s, transport_s = build_leg(B_s)
+                T_s = []
+
+                def step_s(j, timed):
+                    algo_s.rollout_events = None
+                    algo_s.start_worker()
+                    paths = algo_s.obtain_samples(j)
+                    samples = algo_s.process_samples(j, paths)
+                    algo_s.optimize_policy(j, samples)
+                    if timed:
+                        T_s.append(paths.traj.T)
+                gc.collect()
+                if os.environ.get('METRPO_BENCH_GC') != '1':
+                    gc.disable()
+                for j in range(args.warmup):
+                    step_s(j, False)
+                comm.barrier(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for j in range(args.steps):
+                    step_s(args.warmup + j, True)
+                algo_s.optimizer.finish()
+                comm.barrier(); torch.cuda.synchronize()
+                dt_s = comm.max_float(time.perf_counter() - t0, device=side)
+                if gc_was:
+                    gc.enable()
+                out["strong"] = {"ms_per_step": dt_s / args.steps * 1e3, "value": K * B_s * float(np.mean(T_s)) * comm.world / (dt_s / args.steps),
+                                 "unit": "env-steps/s", "B_per_gpu": B_s, "B_total": B_s * comm.world, "steps": args.steps, "warmup": args.warmup,
+                                 "rollout_kernel": eng_s.last_rollout_kernel(), "transport": transport_s or ("torch.distributed %s via host callback" % backend),
+                                 "note": "second timed region of this command: config B = %d divided over %d ranks (strong scaling; `value` / `ms_per_step` of the line are the "
+                                         "weak-scaling region, %d envs per rank)" % (cfg['B'], comm.world, B)}
+            except Exception as e:                              # the second region must not cost the run its line
+                out["strong"] = {"ms_per_step": None, "value": None, "unit": "env-steps/s", "B_per_gpu": B_s, "note": "strong-scaling region failed: %r" % (e,)}
     if comm.rank == 0 and comm.world == 1 and not args.no_cpu_baseline:
         try:
             # bounded sample: ~10-30 s of 1-thread CPU work (about 0.4 TFLOP of dynamics forwards), same per-step structure

@@ -297,6 +297,21 @@ def test_bench_two_ranks_on_one_gpu():
     assert rec['n_gpus'] == 2 and rec['steps'] == 3 and rec['scaling'] == 'weak' and rec['value'] > 0
     assert 'cpu_baseline' not in rec                       # rank 0 at N=1 only
     assert abs(rec['value'] - 2 * 5 * 5000 * 100 / (rec['ms_per_step'] * 1e-3)) / rec['value'] < 1e-9
+    # the same command carries the strong-scaling region (verdict r5 item 2b): C1's B = 5000 divided over the 2 ranks, same K / W
+    st = rec['strong']
+    assert st['B_per_gpu'] == 2500 and st['B_total'] == 5000 and st['steps'] == 3 and st['ms_per_step'] > 0, st
+    assert abs(st['value'] - 5 * 5000 * 100 / (st['ms_per_step'] * 1e-3)) / st['value'] < 1e-9
+
+
+def test_bench_strong_block_at_one_gpu_is_the_timed_region():
+    """N = 1: C1 is quoted on one GPU, so the strong-scaling point IS the line's timed region (no second region is run)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '2', '--warmup', '1', '--no-cpu-baseline'], capture_output=True, text=True,
+                         timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
+    assert rec['strong']['value'] == rec['value'] and rec['strong']['B_per_gpu'] == 5000 and rec['config']['B_override'] is None
 
 
 def test_end_to_end_outer_loop_example():
