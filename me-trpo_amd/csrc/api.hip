@@ -245,6 +245,7 @@ extern "C" int32_t metrpo_destroy(metrpo_ctx* c) {
         (void)hipEventDestroy(c->ev_fork);
     }
     for (int i = 0; i < c->fvp_ev_made; ++i) (void)hipEventDestroy(c->fvp_ev[i]);
+    ws_sweep(c);
     if (c->d_skp_tab) (void)hipFree(c->d_skp_tab);
     if (c->d_skp_stats) (void)hipFree(c->d_skp_stats);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);

@@ -253,9 +253,9 @@ int launch_bptt_grad(metrpo_ctx* c, const float* init, int B, int T, double gamm
     const size_t need = (nXS + nWT + nGM) * sizeof(float) + sizeof(double) * (size_t)(pd.P + 1 + K);
     if (c->det_cfg >= 0) { const int rc0 = ensure_detpart(c, B); if (rc0) return rc0; }
     if (need > c->bptt_cap) {
-        if (c->d_bptt) HIP_TRY(c, hipFree(c->d_bptt));
+        ws_retire(c, c->d_bptt);
         c->d_bptt = nullptr; c->bptt_cap = 0;
-        HIP_TRY(c, hipMalloc(&c->d_bptt, need));
+        HIP_TRY(c, ws_alloc(c, (void**)&c->d_bptt, need));
         c->bptt_cap = need;
     }
     float* XS = (float*)c->d_bptt; float* WT = XS + nXS; float* GM = WT + nWT;
@@ -309,7 +309,7 @@ int launch_policy_adam(metrpo_ctx* c, const double* grad, double lr, double b1, 
     const ProblemDesc& pd = c->pd;
     const int P = pd.P, L = pd.pol.n_layers, nseg = 2 * L + 1;
     if (!c->d_pol_adam) {
-        HIP_TRY(c, hipMalloc(&c->d_pol_adam, sizeof(float) * 2 * (size_t)P + sizeof(int) * (nseg + 1)));
+        HIP_TRY(c, ws_alloc(c, (void**)&c->d_pol_adam, sizeof(float) * 2 * (size_t)P + sizeof(int) * (nseg + 1)));
         HIP_TRY(c, hipMemset(c->d_pol_adam, 0, sizeof(float) * 2 * (size_t)P));
         int seg[2 * MAXL + 2];
         for (int l = 0; l < L; ++l) { seg[2 * l] = pd.pol.w_off[l]; seg[2 * l + 1] = pd.pol.b_off[l]; }
@@ -335,9 +335,9 @@ int ensure_detpart(metrpo_ctx* c, int B) { return ensure_detpart_n(c, (size_t)c-
 int ensure_detpart_n(metrpo_ctx* c, size_t n_doubles) {
     const size_t need = sizeof(double) * n_doubles;
     if (need > c->detpart_cap) {
-        if (c->d_detpart) HIP_TRY(c, hipFree(c->d_detpart));
+        ws_retire(c, c->d_detpart);
         c->d_detpart = nullptr; c->detpart_cap = 0;
-        HIP_TRY(c, hipMalloc(&c->d_detpart, need));
+        HIP_TRY(c, ws_alloc(c, (void**)&c->d_detpart, need));
         c->detpart_cap = need;
     }
     return METRPO_OK;

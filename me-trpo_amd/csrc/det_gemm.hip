@@ -411,9 +411,9 @@ static int dg_workspace(metrpo_ctx* c, int B, DgState* s) {
     const size_t nPimg = up4((size_t)pre_mfma3_image_floats<55, 21, 100, 50, 25>());     // the one three-hidden-layer policy with an MFMA pre-step (dg_pre_mfma_select): 67 KB
     const size_t need = (4 * nS + nX + 2 * nU + nH + 2 * nZ + nD + nP + nPimg) * sizeof(float) + R * sizeof(double) + 64;
     if (need > c->dg_cap) {
-        if (c->d_dg) HIP_TRY(c, hipFree(c->d_dg));
+        ws_retire(c, c->d_dg);
         c->d_dg = nullptr; c->dg_cap = 0;
-        HIP_TRY(c, hipMalloc(&c->d_dg, need));
+        HIP_TRY(c, ws_alloc(c, (void**)&c->d_dg, need));
         c->dg_cap = need;
     }
     float* p = (float*)c->d_dg;

@@ -144,7 +144,7 @@ static int ensure_train_ws(metrpo_ctx* c, int rows, TrainWs* ws) {
     const size_t nP = up4((size_t)K * pd.dyn.n_params);
     // Adam moments live in their own allocation (they persist across steps and batch sizes)
     if (!c->d_adam) {
-        HIP_TRY(c, hipMalloc(&c->d_adam, 2 * nP * sizeof(float) + 64 * sizeof(double)));
+        HIP_TRY(c, ws_alloc(c, (void**)&c->d_adam, 2 * nP * sizeof(float) + 64 * sizeof(double)));
         HIP_TRY(c, hipMemset(c->d_adam, 0, 2 * nP * sizeof(float) + 64 * sizeof(double)));
         c->adam_t = 0;
     }
@@ -156,17 +156,17 @@ static int ensure_train_ws(metrpo_ctx* c, int rows, TrainWs* ws) {
     nPart = std::max(nPart, skinny_part_floats(rows, pd.ns, pd.dyn.dims[L - 1], K));      // forward output layer (train_forward)
     const size_t need = (nXn + hsum + nOut + 2 * nZ + nPart) * sizeof(float);
     if (need > c->train_cap) {
-        if (c->d_train) HIP_TRY(c, hipFree(c->d_train));
+        ws_retire(c, c->d_train);
         c->d_train = nullptr; c->train_cap = 0;
-        HIP_TRY(c, hipMalloc(&c->d_train, need));
+        HIP_TRY(c, ws_alloc(c, (void**)&c->d_train, need));
         c->train_cap = need;
     }
     const size_t nLp = (size_t)K * (1 + (size_t)(rows + 127) / 128);
     if (nLp > c->train_part_cap) {
-        if (c->d_train_part) HIP_TRY(c, hipFree(c->d_train_part));
+        ws_retire(c, c->d_train_part);
         c->d_train_part = nullptr; c->train_part_cap = 0;
         const size_t cap = std::max<size_t>(nLp, 2048);
-        HIP_TRY(c, hipMalloc(&c->d_train_part, cap * sizeof(double)));
+        HIP_TRY(c, ws_alloc(c, (void**)&c->d_train_part, cap * sizeof(double)));
         HIP_TRY(c, hipMemset(c->d_train_part, 0, cap * sizeof(double)));          // tickets start at zero; every launch leaves them there
         c->train_part_cap = cap;
     }

@@ -127,8 +127,32 @@ struct metrpo_ctx {
     hipEvent_t fvp_ev[32]; int fvp_ev_n, fvp_ev_made;   // option TIME_FVP: events around the Fisher-vector-product kernel of launch_fvp_tail (metrpo_debug_fvp_us)
     std::string rollout_note;   // why the last metrpo_rollout left the fast dispatch table ("" when it did not): metrpo_rollout_note
     int fallback_logged;  // a rollout shape that fell off the fast dispatch table has been reported once (METRPO_VERBOSE)
+    std::vector<void*> ws_retired; size_t ws_retired_bytes = 0;   // outgrown workspaces (ws_retire below): freed by metrpo_destroy, or by one sweep once they pass WS_RETIRED_MAX
     std::string err;
 };
+
+// Workspace growth inside a launch entry point (a larger B / N than any call before).  hipFree waits for the whole device -- every stream of the process -- while the
+// ABI promises stream-ordered calls (include/metrpo.h, Threading): an outgrown buffer is RETIRED instead of freed.  Kernels already enqueued on any stream may still
+// read it, which is exactly what retiring allows.  Retired buffers go at metrpo_destroy; a caller that sweeps ever larger shapes through ONE context pays one
+// synchronising sweep whenever the retired bytes pass WS_RETIRED_MAX (or an allocation fails), a loop at fixed shapes never does.  hipMalloc does not wait for
+// running work (tests/test_gpu_api.py::test_rollout_at_a_larger_batch_does_not_wait_for_other_streams).
+constexpr size_t WS_RETIRED_MAX = (size_t)4 << 30;
+static inline void ws_sweep(metrpo_ctx* c) {
+    for (void* p : c->ws_retired) (void)hipFree(p);           // (the first hipFree waits for the device)
+    c->ws_retired.clear(); c->ws_retired_bytes = 0;
+}
+static inline void ws_retire(metrpo_ctx* c, void* p) {
+    if (!p) return;
+    size_t sz = 0;
+    if (hipMemPtrGetInfo(p, &sz) != hipSuccess) { (void)hipGetLastError(); sz = 0; }
+    c->ws_retired.push_back(p); c->ws_retired_bytes += sz;
+    if (c->ws_retired_bytes > WS_RETIRED_MAX) ws_sweep(c);
+}
+static inline hipError_t ws_alloc(metrpo_ctx* c, void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory && !c->ws_retired.empty()) { (void)hipGetLastError(); ws_sweep(c); e = hipMalloc(p, bytes); }
+    return e;
+}
 
 // value of a switch, NULL when unset -- the same contract as the getenv() calls these replaced
 static inline const char* ctx_opt(const metrpo_ctx* c, int id) { return c->opt_set[id] ? c->opt_val[id].c_str() : nullptr; }

@@ -646,8 +646,8 @@ static int f3_ensure(metrpo_ctx* c, long long N) {
     const size_t tiles = (size_t)((N + 15) / 16);
     const size_t need = tiles * (S::NHB + S::CB4) * 64 * sizeof(float) * 4 + (size_t)S::IMG_FLOATS * sizeof(float);
     if (need > c->f3_cap) {
-        if (c->d_f3) { HIP_TRY(c, hipFree(c->d_f3)); c->d_f3 = nullptr; c->f3_cap = 0; }
-        HIP_TRY(c, hipMalloc(&c->d_f3, need));
+        if (c->d_f3) { ws_retire(c, c->d_f3); c->d_f3 = nullptr; c->f3_cap = 0; }
+        HIP_TRY(c, ws_alloc(c, (void**)&c->d_f3, need));
         c->f3_cap = need;
         c->f3_rows = -1;
     }

@@ -253,8 +253,8 @@ bool policy_gemm_applicable(const metrpo_ctx* c, long long N) {
 static int pg_ensure(metrpo_ctx* c, const PgLay& g, long long N, PgBufs* B) {
     const size_t need = (g.wfloats + g.row_floats_total * (size_t)N + g.part_floats) * sizeof(float) + g.head_parts * sizeof(double) + 256;
     if (need > c->pg_cap) {
-        if (c->d_pg) { HIP_TRY(c, hipFree(c->d_pg)); c->d_pg = nullptr; c->pg_cap = 0; }
-        HIP_TRY(c, hipMalloc(&c->d_pg, need));
+        if (c->d_pg) { ws_retire(c, c->d_pg); c->d_pg = nullptr; c->pg_cap = 0; }
+        HIP_TRY(c, ws_alloc(c, (void**)&c->d_pg, need));
         c->pg_cap = need;
         c->pg_fwd_rows = -1;
     }

@@ -972,13 +972,13 @@ int policy_mfma_image_buffers(metrpo_ctx* c) {
             if (j >= c->pd.P || vpos[j] != -1) return set_err(c, METRPO_EINVAL, "policy image map: tangent entry out of range or stored twice");
             vpos[j] = (int)i;
         }
-    for (void** q : {(void**)&c->d_pol_img, (void**)&c->d_pol_vpos, (void**)&c->d_pol_imgval}) if (*q) { HIP_TRY(c, hipFree(*q)); *q = nullptr; }
+    for (void** q : {(void**)&c->d_pol_img, (void**)&c->d_pol_vpos, (void**)&c->d_pol_imgval}) if (*q) { ws_retire(c, *q); *q = nullptr; }
     c->pol_img_idx = -1;
-    HIP_TRY(c, hipMalloc(&c->d_pol_img, sizeof(int) * map.size()));
+    HIP_TRY(c, ws_alloc(c, (void**)&c->d_pol_img, sizeof(int) * map.size()));
     HIP_TRY(c, hipMemcpy(c->d_pol_img, map.data(), sizeof(int) * map.size(), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMalloc(&c->d_pol_vpos, sizeof(int) * vpos.size()));
+    HIP_TRY(c, ws_alloc(c, (void**)&c->d_pol_vpos, sizeof(int) * vpos.size()));
     HIP_TRY(c, hipMemcpy(c->d_pol_vpos, vpos.data(), sizeof(int) * vpos.size(), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMalloc(&c->d_pol_imgval, sizeof(float) * map.size()));
+    HIP_TRY(c, ws_alloc(c, (void**)&c->d_pol_imgval, sizeof(float) * map.size()));
     HIP_TRY(c, hipMemset(c->d_pol_imgval, 0, sizeof(float) * map.size()));
     c->pol_img_idx = idx;
     return METRPO_OK;
@@ -1000,8 +1000,8 @@ int policy_mfma_launch(metrpo_ctx* c, int idx, int mode, const metrpo_batch* b, 
     if (c->hcache_on && (mode == MODE_GRAD || mode == MODE_FVP) && k.gm == nullptr) {      // set by run_trpo_update around one CG solve
         const size_t need = (size_t)((b->N + 15) / 16) * 2 * (size_t)cdiv_(en.ph, 16) * 64 * 4;
         if (need > c->hcache_cap) {
-            if (c->d_hcache) { HIP_TRY(c, hipFree(c->d_hcache)); c->d_hcache = nullptr; c->hcache_cap = 0; }
-            HIP_TRY(c, hipMalloc(&c->d_hcache, need * sizeof(float)));
+            if (c->d_hcache) { ws_retire(c, c->d_hcache); c->d_hcache = nullptr; c->hcache_cap = 0; }
+            HIP_TRY(c, ws_alloc(c, (void**)&c->d_hcache, need * sizeof(float)));
             c->hcache_cap = need;
         }
         k.hcache = c->d_hcache;
@@ -1028,7 +1028,7 @@ int policy_mfma_cg_persist(metrpo_ctx* c, int idx, const metrpo_batch* b, const 
     if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)en.cgp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     if (!grid_is_coresident(c, (const void*)en.cgp, NWAVES * 64, sh, nblocks, st)) return METRPO_EUNSUPPORTED;
     if (!c->d_cgp_bar) {
-        HIP_TRY(c, hipMalloc((void**)&c->d_cgp_bar, 64));
+        HIP_TRY(c, ws_alloc(c, (void**)&c->d_cgp_bar, 64));
         HIP_TRY(c, hipMemsetAsync(c->d_cgp_bar, 0, 64, st));      // the closing block of a solve leaves the counters at zero again
     }
     PolK k;

@@ -382,9 +382,9 @@ __global__ void k_d2f(const double* __restrict__ in, float* __restrict__ out, in
 static int ensure_partials(metrpo_ctx* c, int nrows) {
     const size_t need = (size_t)nrows * (c->pd.P + PART_EXTRA);
     if (need > c->partials_cap) {
-        if (c->d_partials) HIP_TRY(c, hipFree(c->d_partials));
+        ws_retire(c, c->d_partials);
         c->d_partials = nullptr; c->partials_cap = 0;
-        HIP_TRY(c, hipMalloc(&c->d_partials, need * sizeof(float)));
+        HIP_TRY(c, ws_alloc(c, (void**)&c->d_partials, need * sizeof(float)));
         c->partials_cap = need;
     }
     return METRPO_OK;

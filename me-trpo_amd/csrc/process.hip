@@ -518,9 +518,9 @@ static int launch_gram_mfma_wide(metrpo_ctx* c, const float* obs, const float* r
     const int g = (int)std::max<long long>(1, std::min<long long>(tiles, (long long)c->n_sm * 2));
     const size_t need = (size_t)g * (F * F + F);
     if (need > c->gram_cap) {
-        if (c->d_gram_part) HIP_TRY(c, hipFree(c->d_gram_part));
+        ws_retire(c, c->d_gram_part);
         c->d_gram_part = nullptr; c->gram_cap = 0;
-        HIP_TRY(c, hipMalloc(&c->d_gram_part, need * sizeof(double)));
+        HIP_TRY(c, ws_alloc(c, (void**)&c->d_gram_part, need * sizeof(double)));
         c->gram_cap = need;
     }
     const size_t sh = sizeof(double) * M * M;                         // >= the 2 x 16 x M floats of the main loop
@@ -541,9 +541,9 @@ static int launch_gram_mfma(metrpo_ctx* c, const float* obs, const float* ret, c
     const int g = (int)std::max<long long>(1, std::min<long long>((tiles + 3) / 4, (long long)c->n_sm * 2));   // inputs are prefetched one tile ahead: few blocks, few partial matrices
     const size_t need = (size_t)g * (F * F + F);
     if (need > c->gram_cap) {
-        if (c->d_gram_part) HIP_TRY(c, hipFree(c->d_gram_part));
+        ws_retire(c, c->d_gram_part);
         c->d_gram_part = nullptr; c->gram_cap = 0;
-        HIP_TRY(c, hipMalloc(&c->d_gram_part, need * sizeof(double)));
+        HIP_TRY(c, ws_alloc(c, (void**)&c->d_gram_part, need * sizeof(double)));
         c->gram_cap = need;
     }
     const size_t sh = sizeof(double) * 4 * M * M;
@@ -562,19 +562,19 @@ int launch_gae(metrpo_ctx* c, const float* obs, const float* rew, const uint8_t*
     double* V = nullptr;
     if (coeffs != nullptr) {
         if ((size_t)N > c->vbuf_cap) {
-            if (c->d_vbuf) HIP_TRY(c, hipFree(c->d_vbuf));
+            ws_retire(c, c->d_vbuf);
             c->d_vbuf = nullptr; c->vbuf_cap = 0;
-            HIP_TRY(c, hipMalloc(&c->d_vbuf, sizeof(double) * (size_t)N));
+            HIP_TRY(c, ws_alloc(c, (void**)&c->d_vbuf, sizeof(double) * (size_t)N));
             c->vbuf_cap = (size_t)N;
         }
         V = c->d_vbuf;
     }
     const int nblk = (B + 63) / 64;
     if ((size_t)nblk * 3 + 2 > c->gae_part_cap) {
-        if (c->d_gae_part) HIP_TRY(c, hipFree(c->d_gae_part));
+        ws_retire(c, c->d_gae_part);
         c->d_gae_part = nullptr; c->gae_part_cap = 0;
         const size_t cap = std::max<size_t>((size_t)nblk * 3 + 2, 1024);
-        HIP_TRY(c, hipMalloc(&c->d_gae_part, sizeof(double) * cap));
+        HIP_TRY(c, ws_alloc(c, (void**)&c->d_gae_part, sizeof(double) * cap));
         HIP_TRY(c, hipMemsetAsync(c->d_gae_part, 0, sizeof(double) * cap, st));       // the ticket (first word) starts at zero; every launch leaves it there
         c->gae_part_cap = cap;
     }
@@ -772,9 +772,9 @@ int launch_gram(metrpo_ctx* c, const float* obs, const float* ret, const int32_t
     const int nout = F * F + F;
     const size_t need = (size_t)grid * nout;
     if (need > c->gram_cap) {
-        if (c->d_gram_part) HIP_TRY(c, hipFree(c->d_gram_part));
+        ws_retire(c, c->d_gram_part);
         c->d_gram_part = nullptr; c->gram_cap = 0;
-        HIP_TRY(c, hipMalloc(&c->d_gram_part, sizeof(double) * need));
+        HIP_TRY(c, ws_alloc(c, (void**)&c->d_gram_part, sizeof(double) * need));
         c->gram_cap = need;
     }
     if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)k_gram, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));

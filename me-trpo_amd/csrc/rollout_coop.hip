@@ -695,9 +695,9 @@ int launch_rollout_coop(metrpo_ctx* c, int idx, const RolloutK& r_in, hipStream_
     if (one && tiles > grid) {                                           // hand-over slots: flag[tiles] | ts[16 tiles] | model[16 tiles] | obs[16 tiles][ns]
         const int ns = c->pd.ns;
         if (c->mig_cap < tiles) {
-            if (c->d_mig) { HIP_TRY(c, hipFree(c->d_mig)); c->d_mig = nullptr; c->mig_cap = 0; }
+            if (c->d_mig) { ws_retire(c, c->d_mig); c->d_mig = nullptr; c->mig_cap = 0; }
             const size_t bytes = sizeof(int32_t) * (size_t)tiles * (1 + 32 + 16 * ns);
-            HIP_TRY(c, hipMalloc(&c->d_mig, bytes));
+            HIP_TRY(c, ws_alloc(c, (void**)&c->d_mig, bytes));
             HIP_TRY(c, hipMemsetAsync(c->d_mig, 0, bytes, st));
             c->mig_cap = tiles; c->mig_epoch = 0;
         }

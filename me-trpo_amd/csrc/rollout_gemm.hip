@@ -747,9 +747,9 @@ static int skp_table(metrpo_ctx* c, const SkpVt& v, const SkArgs& a, SkpArgs* p,
         const size_t bytes = tab.size() * sizeof(SkRec);
         c->skp_tab_host.assign((const int*)tab.data(), (const int*)tab.data() + bytes / sizeof(int));
         if (bytes > c->skp_tab_cap) {
-            if (c->d_skp_tab) HIP_TRY(c, hipFree(c->d_skp_tab));          // (hipFree waits for the device: nothing reads the old table any more)
+            ws_retire(c, c->d_skp_tab);          // (launches already enqueued may still read the old table: retired, not freed)
             c->d_skp_tab = nullptr; c->skp_tab_cap = 0;
-            HIP_TRY(c, hipMalloc(&c->d_skp_tab, bytes));
+            HIP_TRY(c, ws_alloc(c, (void**)&c->d_skp_tab, bytes));
             c->skp_tab_cap = bytes;
         }
         HIP_TRY(c, hipMemcpyAsync(c->d_skp_tab, c->skp_tab_host.data(), bytes, hipMemcpyHostToDevice, st));
@@ -912,7 +912,7 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
         pa.xflag = skp_flags; pa.arrive = (unsigned*)(skp_flags + (B + 127) / 128); pa.stop = r.stop; pa.post = skp_post;
         HIP_TRY(c, hipMemsetAsync(skp_flags, 0, nSkpFlag * sizeof(float), st));
         if (ctx_opt(c, OPT_PERSIST_STATS) != nullptr) {           // developer statistics of this launch (metrpo_debug_persist_stats)
-            if (c->skp_stats_n < skp_grid) { if (c->d_skp_stats) HIP_TRY(c, hipFree(c->d_skp_stats)); c->d_skp_stats = nullptr; HIP_TRY(c, hipMalloc((void**)&c->d_skp_stats, sizeof(unsigned long long) * 8 * skp_grid)); }
+            if (c->skp_stats_n < skp_grid) { ws_retire(c, c->d_skp_stats); c->d_skp_stats = nullptr; HIP_TRY(c, ws_alloc(c, (void**)&c->d_skp_stats, sizeof(unsigned long long) * 8 * skp_grid)); }
             c->skp_stats_n = skp_grid;
             HIP_TRY(c, hipMemsetAsync(c->d_skp_stats, 0, sizeof(unsigned long long) * 8 * skp_grid, st));
             pa.stats = c->d_skp_stats;
@@ -1071,9 +1071,9 @@ int launch_rollout_gemm(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
     const size_t init_bytes = (init_rows * (pd.ns * sizeof(float) + 2 * sizeof(int32_t)) + 255) & ~(size_t)255;
     const size_t need = ((par && !merged) ? (size_t)R * need1 : need1) + init_bytes;
     if (need > c->big_cap) {
-        if (c->d_big) HIP_TRY(c, hipFree(c->d_big));
+        ws_retire(c, c->d_big);
         c->d_big = nullptr; c->big_cap = 0;
-        HIP_TRY(c, hipMalloc(&c->d_big, need));
+        HIP_TRY(c, ws_alloc(c, (void**)&c->d_big, need));
         c->big_cap = need;
     }
     if (merged) {

@@ -1084,7 +1084,7 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
     const size_t nX = (size_t)Rg * NT * 4 * NIN_KS * 16, nP = (size_t)Rg * NT * K * NSL * 16 * OUT_CB * 16 * (may_rot ? max_cols : 1);
     const size_t need = (nX + nP + 32) * sizeof(unsigned long long);
     if (need > c->res_cap) {
-        if (c->d_res) HIP_TRY(c, hipFree(c->d_res));
+        ws_retire(c, c->d_res);
         c->d_res = nullptr; c->res_cap = 0;
         // ORDINARY device memory.  The packets only ever move through agent-scope atomics (L2-served, never L1), so the memory type buys nothing:
         // uncached, fine-grained and ordinary memory all measure 2.73 ms at the params-file shape.  It is ordinary memory because a region that was
@@ -1093,7 +1093,7 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
         // its fresh workspace, gone after evicting the L2s (tests/test_gpu_resident.py::test_stepwise_workspace_after_freed_resident_regions).
         // METRPO_RES_UNCACHED=1 brings the uncached flavour back (reproducing the above).
         if (ctx_opt(c, OPT_RES_UNCACHED) != nullptr) HIP_TRY(c, hipExtMallocWithFlags(&c->d_res, need, hipDeviceMallocUncached));
-        else HIP_TRY(c, hipMalloc(&c->d_res, need));
+        else HIP_TRY(c, ws_alloc(c, (void**)&c->d_res, need));
         HIP_TRY(c, hipMemsetAsync(c->d_res, 0, need, st));
         c->res_cap = need; c->res_seq = 0;
     }
@@ -1197,9 +1197,9 @@ int launch_validation_resident(metrpo_ctx* c, const float* s0, int Bv, int T, do
     const size_t nX = (size_t)G * 4 * NIN_KS * 16, nP = (size_t)G * K * NSL * 16 * OUT_CB * 16;
     const size_t need = (nX + nP + 32) * sizeof(unsigned long long);
     if (need > c->res_cap) {
-        if (c->d_res) HIP_TRY(c, hipFree(c->d_res));
+        ws_retire(c, c->d_res);
         c->d_res = nullptr; c->res_cap = 0;
-        HIP_TRY(c, hipMalloc(&c->d_res, need));                      // ordinary device memory: see launch_rollout_resident
+        HIP_TRY(c, ws_alloc(c, (void**)&c->d_res, need));                      // ordinary device memory: see launch_rollout_resident
         HIP_TRY(c, hipMemsetAsync(c->d_res, 0, need, st));
         c->res_cap = need; c->res_seq = 0;
     }

@@ -314,6 +314,47 @@ def test_bench_strong_block_at_one_gpu_is_the_timed_region():
     assert rec['strong']['value'] == rec['value'] and rec['strong']['B_per_gpu'] == 5000 and rec['config']['B_override'] is None
 
 
+def test_rollout_at_a_larger_batch_does_not_wait_for_other_streams():
+    """SURVEY 8b Threading / verdict r5 item 5: a launch entry point neither allocates with a device-wide wait nor synchronises.  A one-thread spin kernel keeps a
+    SECOND stream busy for ~0.4 s; meanwhile metrpo_rollout + metrpo_gae are called at a batch size the context has never seen (the cooperative kernel's migration slots,
+    B > 16 x CUs, and the GAE partials grow: until round 6 a hipFree + hipMalloc pair, and hipFree waits for every stream of the device).  The calls must return while
+    the other stream is still busy; the trajectory equals a fresh context's at the same seed, bit for bit."""
+    import time
+    eng, dm, theta, pdims, pool = Hh.make_engine('swimmer', 5, (64, 64), (32, 32), seed=3)
+    dev = eng.device
+    pool_t = torch.tensor(pool, dtype=torch.float32, device=dev)
+    H = T = 12
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    B1, B2 = 16 * (n_cu + 4), 16 * (2 * n_cu + 24)                 # both past one tile per CU (migration slots in use), the second larger
+    out1, out2 = eng.alloc_trajectory(B1, T, H), eng.alloc_trajectory(B2, T, H)
+    eng.rollout(B1, T, H, 'step_rand', pool_t, seed=5, out=out1)
+    eng.gae(out1, None, 0.99, 0.95)
+    torch.cuda.synchronize()
+    # calibrate the spin kernel: cycles for ~0.4 s
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); torch.cuda._sleep(20000000); e1.record(); torch.cuda.synchronize()
+    cycles = int(20000000 * 400.0 / max(e0.elapsed_time(e1), 1e-3))
+    side = torch.cuda.Stream(device=dev)
+    done = torch.cuda.Event()
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(cycles)
+        done.record(side)
+    t0 = time.perf_counter()
+    eng.rollout(B2, T, H, 'step_rand', pool_t, seed=6, out=out2)
+    adv, ret, valid, stats = eng.gae(out2, None, 0.99, 0.95)
+    dt = time.perf_counter() - t0
+    still_busy = not done.query()
+    torch.cuda.synchronize()
+    assert still_busy and dt < 0.2, "the launch entry points waited for the other stream: returned after %.3f s, other stream busy at return: %s" % (dt, still_busy)
+    assert 'cooperative' in (eng.last_rollout_kernel() or ''), eng.last_rollout_kernel()
+    eng_b = Hh.make_engine('swimmer', 5, (64, 64), (32, 32), seed=3)[0]
+    ref = eng_b.rollout(B2, T, H, 'step_rand', pool_t, seed=6)
+    adv_b = eng_b.gae(ref, None, 0.99, 0.95)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(out2.obs, ref.obs) and torch.equal(out2.rew, ref.rew) and torch.equal(out2.act, ref.act)
+    assert torch.equal(adv, adv_b)
+
+
 def test_end_to_end_outer_loop_example():
     """examples/me_trpo_loop.py: collect (surrogate real env) -> split / normalise -> train the ensemble -> TRPO with validation-cost
     early stopping, two outer iterations at tiny sizes: the rows interoperate on one context without host copies of the weights."""

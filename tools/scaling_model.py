@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Predicted 1 / 2 / 4 / 8-GPU curve (weak AND strong) of every BASELINE config from ONE GPU (verdict r5 item 2a).
+
+The path shards the imagined-env axis B over ranks; a rank's iteration is its own rollout + process_samples + update on B_rank envs plus ~15
+latency-bound sum exchanges (advantage stats, baseline normal equations, loss + gradient, 10 Fisher-vector products, 1-2 line-search pairs).
+So what rank r of an N-rank run computes can be timed on one GPU by running bench.py at that rank's share (`bench.py --B B_rank`), and
+
+    t_iter(N) = rollout(B_rank) + process(B_rank) + update(B_rank * T) + n_exchanges * e(N)
+
+  weak:   B_rank = the config's per-GPU share at every N          value(N) = N * K * B_rank * T / t_iter(N)
+  strong: B_rank = config B / N                                   value(N) =     K * B      * T / t_iter(N)
+
+e(N): one exchange.  MEASURED for N = 2 only (profiles/r03_comm_overhead.txt: 6.3-6.7 us stand-alone, two processes on one device, independent of the
+vector length up to 13 110 float64); N = 4 / 8 cannot be measured on one device (processes time-slice its queues), so the model takes e(2) + 1 us per
+doubling (every rank writes N - 1 peer slots of <= 105 KB over N - 1 links and polls N - 1 arrival flags) -- an ASSUMPTION, flagged in the output.
+Not in the model: rank skew (the max over ranks of run-to-run jitter, ~1 % on one GPU) and xGMI contention (the exchanges are 12-105 KB).
+
+usage (GPU box):   python tools/scaling_model.py --out gpurun_out/scaling            -> measurements.json, r06_scaling_model.json / .txt
+       (anywhere): python tools/scaling_model.py --from gpurun_out/scaling/measurements.json --out profiles
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+NS = (1, 2, 4, 8)
+E2_US = 6.5            # one exchange, 2 ranks (profiles/r03_comm_overhead.txt, stand-alone: launch + packet write + poll; inside the update it rides in k_finalize's tail)
+E_STEP_US = 1.0        # assumed growth per doubling of N (not measurable on one device)
+# (steps, warmup) per config: iterations of tens of ms and more need few
+RUNS = {'C1': (40, 10), 'C2': (4, 1), 'C3': (4, 1), 'C4': (2, 1)}
+# largest share timed per config (beyond it: linear extrapolation from the two largest timed shares, flagged).  C4: [T, B, ns] float32 trajectories of
+# B = 50 000 are 2.75e9 elements -- past the int32 element indices of the trajectory kernels; a rank never sees more than B / N
+MAX_B = {'C4': 25000}
+
+
+def shares(cfg):
+    per = cfg['B'] // cfg['gpus']
+    s = set(cfg['B'] // n for n in NS) | {per} | {per // 2, per // 4, per // 8}
+    return sorted(b for b in s if b >= 16)
+
+
+def run_bench(name, B, steps, warmup):
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--config', name, '--B', str(B), '--steps', str(steps), '--warmup', str(warmup), '--no-cpu-baseline']
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    if res.returncode != 0 or not lines:
+        return {'error': (res.stderr or res.stdout)[-600:]}
+    d = json.loads(lines[-1])
+    it = d['instrumented_pass']['ms_per_step']
+    roll, upd = d['rollout']['ms'], d['roofline']['update']['ms']
+    T = d['value'] * d['ms_per_step'] * 1e-3 / (d['n_gpus'] * B * cfg_of(name)['K'])          # env steps per rollout (H, less for early-terminating Ant)
+    return {'B': B, 'ms_iter': d['ms_per_step'], 'ms_iter_median': d['ms_per_step_median'], 'ms_rollout': roll, 'ms_update': upd,
+            'ms_process_and_gaps': max(0.0, it - roll - upd), 'T': T, 'rollout_kernel': d['rollout']['kernel'], 'update_path': d['roofline']['update']['path'],
+            'rollout_frac_f32_peak': d['roofline']['frac'], 'steps': steps, 'warmup': warmup}
+
+
+def cfg_of(name):
+    import metrpo_amd                                          # (the alias module: puts the package `me-trpo_amd` on the import path under a Python-legal name)
+    from metrpo_amd import synthetic
+    return synthetic.CONFIGS[name]
+
+
+def n_exchanges(m):
+    return 3 + 10 + 2          # stats, normal equations, loss + gradient; 10 FVPs; line-search pairs (1-2 trials)
+
+
+def lookup(meas, B):
+    """timed share, else linear inter-/extrapolation over B of every phase (flagged)"""
+    by = {m['B']: m for m in meas if 'error' not in m}
+    if B in by:
+        return dict(by[B], extrapolated=False)
+    bs = sorted(by)
+    lo, hi = (bs[-2], bs[-1]) if B > bs[-1] else (bs[0], bs[1]) if B < bs[0] else max((a, b) for a, b in zip(bs, bs[1:]) if a <= B <= b)
+    w = (B - lo) / float(hi - lo)
+    out = {'B': B, 'extrapolated': True, 'T': by[hi]['T'], 'rollout_kernel': by[hi]['rollout_kernel']}
+    for k in ('ms_iter', 'ms_rollout', 'ms_update', 'ms_process_and_gaps'):
+        out[k] = by[lo][k] + w * (by[hi][k] - by[lo][k])
+    return out
+
+
+def model(name, meas):
+    cfg = cfg_of(name)
+    per = cfg['B'] // cfg['gpus']
+    out = {'config': name, 'env': cfg['env'], 'K': cfg['K'], 'B_config': cfg['B'], 'gpus_quoted_on': cfg['gpus'], 'per_gpu_share': per, 'weak': {}, 'strong': {}, 'shares_timed': meas}
+    for kind in ('weak', 'strong'):
+        base = None
+        for n in NS:
+            B = per if kind == 'weak' else cfg['B'] // n
+            if B < 16:
+                continue
+            m = lookup(meas, B)
+            e_us = 0.0 if n == 1 else E2_US + E_STEP_US * {2: 0, 4: 1, 8: 2}[n]
+            x_ms = n_exchanges(m) * e_us * 1e-3
+            t = m['ms_rollout'] + m['ms_process_and_gaps'] + m['ms_update'] + x_ms
+            # the bench's own timed region at that share (no events) is a few % below the sum of the instrumented phases: scale the phases to it
+            scale = m['ms_iter'] / (m['ms_rollout'] + m['ms_process_and_gaps'] + m['ms_update'])
+            t_pred = m['ms_iter'] + x_ms
+            val = n * cfg['K'] * B * m['T'] / (t_pred * 1e-3)
+            if base is None:
+                base = (n, val)
+            out[kind][str(n)] = {'B_per_gpu': B, 'ms_per_step': t_pred, 'value_env_steps_per_s': val,
+                                 'efficiency_vs_first_point': val / base[1] / (n / base[0]),
+                                 'phases_ms': {'rollout': m['ms_rollout'] * scale, 'process_samples_and_gaps': m['ms_process_and_gaps'] * scale, 'update': m['ms_update'] * scale,
+                                               'exchanges': x_ms},
+                                 'exchange_us_each': e_us, 'exchange_measured': n <= 2, 'share_extrapolated': m['extrapolated'], 'rollout_kernel': m['rollout_kernel']}
+    # Amdahl term of the strong curve: what does not shrink with B -- the time of the smallest timed share is (almost) all of it
+    small = min((m for m in meas if 'error' not in m), key=lambda m: m['B'])
+    out['amdahl'] = {'smallest_share_timed': small['B'], 'ms_iter_at_it': small['ms_iter'], 'ms_rollout_at_it': small['ms_rollout'], 'ms_update_at_it': small['ms_update'],
+                     'note': 'the rollout is a chain of T dependent steps per tile; with fewer tiles than CUs its time is T x the step latency whatever B is, and the update '
+                             'keeps its per-launch fixed cost (10 products + 10 reductions + line search): this floor is what strong scaling converges to'}
+    return out
+
+
+def table(models):
+    rows = ['config  scaling  N  B/GPU     ms/iter   G env-steps/s   efficiency   rollout   process   update   exchanges(ms)   flags']
+    for mo in models:
+        for kind in ('weak', 'strong'):
+            for n, r in sorted(mo[kind].items(), key=lambda kv: int(kv[0])):
+                p = r['phases_ms']
+                flags = ('share-extrapolated ' if r['share_extrapolated'] else '') + ('' if r['exchange_measured'] else 'exchange-assumed')
+                rows.append('%-7s %-7s %2s %6d %11.3f %13.3f %11.3f %10.3f %9.3f %8.3f %10.4f       %s' % (
+                    mo['config'], kind, n, r['B_per_gpu'], r['ms_per_step'], r['value_env_steps_per_s'] / 1e9, r['efficiency_vs_first_point'],
+                    p['rollout'], p['process_samples_and_gaps'], p['update'], p['exchanges'], flags))
+        a = mo['amdahl']
+        rows.append('%-7s floor: B = %d per GPU still takes %.3f ms per iteration (rollout %.3f, update %.3f)' % (mo['config'], a['smallest_share_timed'], a['ms_iter_at_it'], a['ms_rollout_at_it'], a['ms_update_at_it']))
+        rows.append('')
+    return '\n'.join(rows)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--out', default='gpurun_out/scaling')
+    ap.add_argument('--from', dest='src', default=None, help='measurements.json of an earlier run: rebuild the model without a GPU')
+    ap.add_argument('--configs', default='C1,C2,C3,C4')
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    if args.src:
+        meas = json.load(open(args.src))
+    else:
+        meas = {}
+        for name in args.configs.split(','):
+            steps, warmup = RUNS[name]
+            meas[name] = []
+            for B in shares(cfg_of(name)):
+                if B > MAX_B.get(name, 1 << 30):
+                    continue
+                m = run_bench(name, B, steps, warmup)
+                m.setdefault('B', B)
+                meas[name].append(m)
+                print(name, B, {k: (round(v, 4) if isinstance(v, float) else v) for k, v in m.items() if k != 'error'} if 'error' not in m else m, flush=True)
+                json.dump(meas, open(os.path.join(args.out, 'measurements.json'), 'w'), indent=1)
+    models = [model(name, meas[name]) for name in meas if sum('error' not in m for m in meas[name]) >= 2]
+    doc = {'what': 'predicted weak + strong scaling of the BASELINE configs at 1/2/4/8 MI355X from single-GPU timings of each rank\'s share (tools/scaling_model.py)',
+           'exchange_model': {'e2_us_measured': E2_US, 'per_doubling_us_assumed': E_STEP_US, 'exchanges_per_iteration': 15, 'source': 'profiles/r03_comm_overhead.txt'},
+           'not_modelled': ['rank skew (max over ranks of per-iteration jitter)', 'xGMI contention between the N - 1 simultaneous 12-105 KB packet writes'],
+           'models': models}
+    json.dump(doc, open(os.path.join(args.out, 'r06_scaling_model.json'), 'w'), indent=1)
+    txt = table(models)
+    open(os.path.join(args.out, 'r06_scaling_model.txt'), 'w').write(txt + '\n')
+    print(txt)
+
+
+if __name__ == '__main__':
+    main()
