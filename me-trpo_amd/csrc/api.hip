@@ -108,8 +108,6 @@ extern "C" int32_t metrpo_debug_fvp_us(metrpo_ctx* c, double* mean_us, int32_t* 
     return METRPO_OK;
 }
 
-// Diagnostics hook: CG solves of this context that ran as ONE launch (policy_mfma.hip MODE_CGP) so far
-extern "C" int32_t metrpo_debug_cg_persist_launches(metrpo_ctx* c) { return c ? c->cgp_launches : METRPO_ENULL; }
 
 // Diagnostics hook (tools/persist_stats.py): per-workgroup statistics of the last persistent stream-K launch made with option PERSIST_STATS set
 // (mlp_persist.h: SkpArgs::stats), 8 values per workgroup; returns the number of workgroups (0: none recorded).
@@ -139,11 +137,8 @@ int metrpo_opt_id(const char* key) {
 }
 // fields of the context derived from an option (id < 0: all of them)
 static void opt_apply(metrpo_ctx* c, int id) {
-    if (id < 0 || id == OPT_UPD_TILES_PER_WAVE) c->upd_tiles_per_wave = ctx_opt(c, OPT_UPD_TILES_PER_WAVE) ? std::max(1, atoi(ctx_opt(c, OPT_UPD_TILES_PER_WAVE))) : 1;
+    if (id < 0) c->upd_tiles_per_wave = 1;
     // (NO_RESIDENT does not touch c->exclusive -- the caller's metrpo_set_exclusive value: ctx_exclusive() combines the two at every use.)
-    // GEMM_PREFETCH is process-wide (gemm_mfma.h has no context): written by metrpo_set_option, and by metrpo_create only when the environment names it --
-    // creating a second context must not cancel what another context set.
-    if (id == OPT_GEMM_PREFETCH || (id < 0 && c->opt_set[OPT_GEMM_PREFETCH])) { const char* g = ctx_opt(c, OPT_GEMM_PREFETCH); g_gemm_prefetch_off.store((g && g[0] == '1') ? 1 : 0); }
     if (id == OPT_XCHG_TIMEOUT_MS && ctx_opt(c, OPT_XCHG_TIMEOUT_MS)) { const long long v = atoll(ctx_opt(c, OPT_XCHG_TIMEOUT_MS)); if (v > 0) c->xg_timeout = (unsigned long long)v * 100000ull; }
 }
 // value == NULL unsets the key.  Read by the NEXT launch; options that size a workspace or select a kernel table entry at set_dynamics / set_policy time
@@ -185,13 +180,13 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     c->d_partials = nullptr; c->partials_cap = 0; c->d_cg = nullptr; c->d_vf = nullptr; c->d_theta_try = nullptr;
     c->d_valbuf = nullptr; c->h_pinned = nullptr; c->n_sm = 256; c->n_cu_sched = 0; c->fallback_logged = 0; c->fvp_ev_n = 0; c->fvp_ev_made = 0; c->d_skp_tab = nullptr; c->d_skp_stats = nullptr; c->skp_stats_n = 0; c->skp_tab_cap = 0; c->persist_failed = 0; for (int i = 0; i < 8; ++i) c->skp_key[i] = -1;
     for (int i = 0; i < OPT_COUNT; ++i) {                     // the ONLY place the library reads the environment for kernel selection: defaults of the option table
-        const std::string ev = std::string(i == OPT_GEMM_PREFETCH ? "" : "METRPO_") + metrpo_opt_name(i);
+        const std::string ev = std::string("METRPO_") + metrpo_opt_name(i);
         const char* e = getenv(ev.c_str());
         c->opt_set[i] = (e != nullptr); c->opt_val[i] = e ? e : "";
     }
     c->exclusive = 1;                                         // until metrpo_set_exclusive(ctx, 0) says otherwise (option NO_RESIDENT is combined with it in ctx_exclusive())
     opt_apply(c, -1);
-    c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gae_part = nullptr; c->gae_part_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0; c->d_res = nullptr; c->res_cap = 0; c->res_seq = 0; c->res_failed = 0; c->last_rollout_kernel = -1; c->upd_pending = 0; c->upd_spec = 0; c->upd_changed_in_end = 0; c->h_upd = nullptr; c->upd_stamp = 0; c->side_ready = 0; c->d_ticket = nullptr; c->d_hcache = nullptr; c->hcache_cap = 0; c->hcache_on = 0; c->d_mig = nullptr; c->mig_cap = 0; c->mig_epoch = 0; c->nccl_comm = nullptr; c->comm_world = 0; c->comm_rank = 0; c->pol_path = 1; c->d_pg = nullptr; c->pg_cap = 0; c->pg_fwd_rows = -1; c->pg_fwd_obs = nullptr; c->d_cgp_bar = nullptr; c->cgp_failed = 0; c->cgp_launches = 0; c->pol_f3 = 0; c->d_f3 = nullptr; c->f3_cap = 0; c->f3_rows = -1; c->f3_obs = nullptr; c->f3_theta = nullptr; c->f3_img_ok = 0; c->d_adam = nullptr; c->adam_t = 0; c->d_train = nullptr; c->train_cap = 0; c->d_train_part = nullptr; c->train_part_cap = 0;
+    c->d_vbuf = nullptr; c->vbuf_cap = 0; c->d_gae_part = nullptr; c->gae_part_cap = 0; c->d_gram_part = nullptr; c->gram_cap = 0; c->d_big = nullptr; c->big_cap = 0; c->d_res = nullptr; c->res_cap = 0; c->res_seq = 0; c->res_failed = 0; c->last_rollout_kernel = -1; c->upd_pending = 0; c->upd_spec = 0; c->upd_changed_in_end = 0; c->h_upd = nullptr; c->upd_stamp = 0; c->side_ready = 0; c->d_ticket = nullptr; c->d_hcache = nullptr; c->hcache_cap = 0; c->hcache_on = 0; c->d_mig = nullptr; c->mig_cap = 0; c->mig_epoch = 0; c->nccl_comm = nullptr; c->comm_world = 0; c->comm_rank = 0; c->pol_path = 1; c->d_pg = nullptr; c->pg_cap = 0; c->pg_fwd_rows = -1; c->pg_fwd_obs = nullptr; c->pol_f3 = 0; c->d_f3 = nullptr; c->f3_cap = 0; c->f3_rows = -1; c->f3_obs = nullptr; c->f3_theta = nullptr; c->f3_img_ok = 0; c->d_adam = nullptr; c->adam_t = 0; c->d_train = nullptr; c->train_cap = 0; c->d_train_part = nullptr; c->train_part_cap = 0;
     ProblemDesc& pd = c->pd;
     pd.env = d->env; pd.ns = d->ns; pd.na = d->na; pd.K = d->n_models; pd.n_drop = d->n_drop;
     pd.nin = d->ns + d->na - d->n_drop;
@@ -238,7 +233,7 @@ extern "C" int32_t metrpo_destroy(metrpo_ctx* c) {
     (void)metrpo_comm_ipc_detach(c);
     if (c->xg_region) (void)hipFree(c->xg_region);
     void* bufs[] = {c->d_dyn, c->d_norm, c->d_theta, c->d_vf, c->d_theta_try, c->d_cg, c->d_valbuf, c->d_partials,
-                    c->d_dyn_img, c->d_pol_img, c->d_pol_imgval, c->d_pol_vpos, c->d_vbuf, c->d_gae_part, c->d_train_part, c->d_gram_part, c->d_big, c->d_res, c->d_ticket, c->d_hcache, c->d_mig, c->d_pg, c->d_f3, c->d_cgp_bar, c->d_adam, c->d_train, c->d_bptt, c->d_pol_adam, c->d_detpart, c->d_dg};
+                    c->d_dyn_img, c->d_pol_img, c->d_pol_imgval, c->d_pol_vpos, c->d_vbuf, c->d_gae_part, c->d_train_part, c->d_gram_part, c->d_big, c->d_res, c->d_ticket, c->d_hcache, c->d_mig, c->d_pg, c->d_f3, c->d_adam, c->d_train, c->d_bptt, c->d_pol_adam, c->d_detpart, c->d_dg};
     for (void* p : bufs) if (p) (void)hipFree(p);
     if (c->side_ready) {
         for (int i = 0; i < METRPO_MAX_PAR_ROUNDS - 1; ++i) { (void)hipStreamDestroy(c->side_stream[i]); (void)hipEventDestroy(c->ev_join[i]); }
@@ -608,16 +603,6 @@ __global__ void k_try_theta(int P, double ratio, const float* __restrict__ prev,
 // phase: 0 = the whole update with the line search decided on the host (one synchronisation per trial, as the reference does);
 //        1 = metrpo_trpo_update_begin: solve + the first `spec` line-search trials enqueued with the accept test on the DEVICE (ls_decide), no
 //            synchronisation; 2 = metrpo_trpo_update_end: fetch the outcome, continue on the host from trial `spec` if the search has not stopped
-// a block of the persistent CG solve gave up at a grid barrier (its grid was not co-resident after all): this context stays on the launch-per-product
-// solve from then on; the sticky cell and the barrier counters are cleared
-static int cg_persist_timed_out(metrpo_ctx* c, hipStream_t st) {
-    c->cgp_failed = 1;
-    CgView v = cg_view(c);
-    (void)hipMemsetAsync(v.scal + S_COMMERR, 0, sizeof(double), st);
-    if (c->d_cgp_bar) (void)hipMemsetAsync(c->d_cgp_bar, 0, 64, st);
-    (void)hipStreamSynchronize(st);
-    return set_err(c, METRPO_EHIP, "trpo_update: the persistent CG solve timed out at a grid barrier (grid not co-resident); this context now uses the launch-per-product solve");
-}
 static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_params* pr, metrpo_trpo_diag* diag,
                                 double* g_out, double* dir_out, hipStream_t st, int phase, int spec);
 // The arrival counter of the fused tails (d_ticket) resets itself in the last block of every reduction, so a completed update leaves it
@@ -628,7 +613,6 @@ int run_trpo_update(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_para
     const int rc = run_trpo_update_impl(c, b, pr, diag, g_out, dir_out, st, phase, spec);
     if (rc != METRPO_OK) {
         (void)hipGetLastError(); (void)hipMemsetAsync(c->d_ticket, 0, sizeof(unsigned int), st); c->upd_pending = 0;
-        if (c->d_cgp_bar) (void)hipMemsetAsync(c->d_cgp_bar, 0, 64, st);      // the one-launch CG solve's barrier counters (policy_mfma.hip MODE_CGP), should it have been cut short
     }
     return rc;
 }
@@ -637,7 +621,7 @@ int run_trpo_update(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_para
 static bool device_line_search_ok(const metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_params* pr) {
     const bool xg = (pr->allreduce == nullptr && c->xg_world > 1);
     const bool fused = (pr->allreduce == nullptr && ((c->nccl_comm == nullptr && !xg) || (xg && !policy_gemm_applicable(c, b->N) && c->pd.P + 1 <= c->xg_cap)));
-    return fused && !policy_gemm_applicable(c, b->N) && ctx_opt(c, OPT_NO_DEVICE_LINESEARCH) == nullptr;
+    return fused && !policy_gemm_applicable(c, b->N);
 }
 static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metrpo_trpo_params* pr, metrpo_trpo_diag* diag,
                                 double* g_out, double* dir_out, hipStream_t st, int phase, int spec) {
@@ -674,7 +658,7 @@ static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metr
     tl.op = 3;
     c->hcache_on = 1;                    // the gradient kernel publishes tanh activations, the CG products of this solve reuse them
     // ... and, when every CG vector comes out of a fused tail, its weight-fragment image; the tails add the tangent entries (policy_mfma.hip)
-    c->img_live = (fused && c->pol_mfma >= 0 && !policy_gemm_applicable(c, b->N) && ctx_opt(c, OPT_NO_IMGVAL) == nullptr) ? 1 : 0;
+    c->img_live = (fused && c->pol_mfma >= 0 && !policy_gemm_applicable(c, b->N)) ? 1 : 0;
     struct CacheOff { metrpo_ctx* c; ~CacheOff() { c->hcache_on = 0; c->img_live = 0; } } cache_off{c};
     if (c->img_live) {
         if ((rc = policy_mfma_image_buffers(c))) return rc;
@@ -689,18 +673,9 @@ static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metr
         hipLaunchKernelGGL(k_zero_f, dim3((P + 255) / 256), dim3(256), 0, st, c->d_vf, P);
         hipLaunchKernelGGL(k_cg_finish_implicit, dim3(1), dim3(1024), 0, st, P, pr->max_kl, v.x, v.r, v.gout, v.step, v.scal);
     }
-    // the whole solve in one launch (policy_mfma.hip MODE_CGP; option CG_PERSIST: opt-in -- measured SLOWER than the launch-per-product sequence, 93 vs 68 us per
-    // iteration at C1, profiles/r05_update_levers.txt) where the fused single-rank sequence runs on the two-layer kernels and the grid is co-resident
-    bool cg_done = false;
-    if (fused && c->img_live && !xg && c->nccl_comm == nullptr && pr->cg_iters > 0 && ctx_opt(c, OPT_CG_PERSIST) != nullptr && ctx_opt(c, OPT_TIME_FVP) == nullptr) {
-        tl.op = 1; tl.last = 0;
-        rc = launch_cg_persist(c, b, tl, pr->cg_iters, st);
-        if (rc == METRPO_OK) { cg_done = true; c->cgp_launches += 1; }
-        else if (rc != METRPO_EUNSUPPORTED) return rc;
-    }
     const bool fold_try = (phase == 1 && nspec >= 1);
     auto arm_try0 = [&]() { tl.nx_try = c->d_theta_try; tl.nx_prev = c->d_theta; tl.nx_ratio = 1.0; tl.nx_ls = v.ls; try0_built = true; };      // backtrack_ratio ^ 0
-    for (int i = 0; i < pr->cg_iters && !cg_done; ++i) {
+    for (int i = 0; i < pr->cg_iters; ++i) {
         tl.op = 1; tl.last = (i == pr->cg_iters - 1) ? 1 : 0;
         if (fold_try && tl.last && implicit_hd) arm_try0();
         if (fused) { if ((rc = launch_fvp_tail(c, b, c->d_vf, v.p, v.z, &tl, st))) return rc; continue; }
@@ -763,7 +738,6 @@ static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metr
             std::atomic_thread_fence(std::memory_order_acquire);
             for (int i = 0; i < 14; ++i) c->h_pinned[i] = c->h_upd[i];
         }
-        if (c->h_pinned[S_COMMERR] == 2.0) return cg_persist_timed_out(c, st);
         if (c->xg_world > 1 && c->h_pinned[S_COMMERR] != 0.0) return set_err(c, METRPO_EHIP, "trpo_update: one-shot all-reduce timed out (a rank did not arrive)");
         if (c->h_pinned[S_ROLLERR] != 0.0) return rollout_error_seen(c, st);
         loss_before = c->h_pinned[S_LOSS0]; first = false;
@@ -779,7 +753,6 @@ static int run_trpo_update_impl(metrpo_ctx* c, const metrpo_batch* b, const metr
         AR(v.lk, 2);
         HIP_TRY(c, hipMemcpyAsync(c->h_pinned, v.scal, sizeof(double) * 10, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
-        if (c->h_pinned[S_COMMERR] == 2.0) return cg_persist_timed_out(c, st);
         if (c->xg_world > 1 && c->h_pinned[S_COMMERR] != 0.0) return set_err(c, METRPO_EHIP, "trpo_update: one-shot all-reduce timed out (a rank did not arrive)");
         if (c->h_pinned[S_ROLLERR] != 0.0) return rollout_error_seen(c, st);
         if (first) { loss_before = c->h_pinned[S_LOSS0]; first = false; }

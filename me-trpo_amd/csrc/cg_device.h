@@ -215,93 +215,6 @@ __device__ __forceinline__ void cg_finish_body(int P, double reg, double max_kl,
     if (threadIdx.x == 0) { scal[S_BETA] = beta; scal[S_XHX] = xhx; }
 }
 
-// ---- the same CG step on a block of 1024 / VT threads (persistent CG solve of policy_mfma.hip: its blocks are 512 threads) ----------------------
-// Thread t stands in for the threads t, t + blockDim, .. of the 1024-thread block the fused tails run on: the same elements per (virtual) thread, the same
-// per-thread partial sums, the same wave sums (virtual wave = wave + k * blockDim / 64) and the same order over the 16 wave sums -- bit for bit the
-// results of cg_step_body / cg_finish_implicit in k_finalize's tail.
-template <int VT> __device__ __forceinline__ double blk_sum_v(const double (&v)[VT], double* sh) {
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nwr = blockDim.x >> 6;
-    double s[VT];
-#pragma unroll
-    for (int k = 0; k < VT; ++k) s[k] = wave_sum_f64(v[k]);
-    __syncthreads();
-    if (l == 0) {
-#pragma unroll
-        for (int k = 0; k < VT; ++k) sh[w + k * nwr] = s[k];
-    }
-    __syncthreads();
-    double r = 0.0;
-    for (int i = 0; i < VT * nwr; ++i) r += sh[i];
-    return r;
-}
-template <int VT> __device__ __forceinline__ void cgv_finish_implicit(int P, double max_kl, const double* x, const double* r, const double* g,
-                                                                      double* step, double* scal, double* sh) {
-    const int NV = VT * (int)blockDim.x;
-    double acc[VT];
-#pragma unroll
-    for (int k = 0; k < VT; ++k) {
-        acc[k] = 0.0;
-        for (int i = threadIdx.x + k * blockDim.x; i < P; i += NV) acc[k] += x[i] * (g[i] - r[i]);
-    }
-    const double xhx = blk_sum_v<VT>(acc, sh);
-    double beta = sqrt(2.0 * max_kl * (1.0 / (xhx + 1e-8)));
-    if (isnan(beta)) beta = 1.0;
-    for (int i = threadIdx.x; i < P; i += blockDim.x) step[i] = beta * x[i];
-    if (threadIdx.x == 0) { scal[S_BETA] = beta; scal[S_XHX] = xhx; }
-}
-// every element in registers, R per (virtual) thread: P <= R * 1024.  R = R is cg_step_body's register path, a larger R its loop path (thread t walks
-// t, t + 1024, .. in order: the same sums)
-template <int VT, int R> __device__ __forceinline__ void cgv_step_body(int P, double reg, double tol, int last, double* x, double* r, double* p, double* z,
-                                                                PfOut pf, double* scal, double* sh) {
-    const int NV = VT * (int)blockDim.x;
-    if (scal[S_DONE] != 0.0) {
-        if (last) for (int i = threadIdx.x; i < P; i += blockDim.x) pf.put(i, (float)x[i]);
-        return;
-    }
-    const double rdotr = scal[S_RDOTR];
-    double pv[VT][R], zv[VT][R], rv[VT][R], xv[VT][R], acc[VT];
-#pragma unroll
-    for (int k = 0; k < VT; ++k) {
-        acc[k] = 0.0;
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const int i = threadIdx.x + k * blockDim.x + j * NV;
-            pv[k][j] = zv[k][j] = rv[k][j] = xv[k][j] = 0.0;
-            if (i < P) {
-                pv[k][j] = p[i]; rv[k][j] = r[i]; xv[k][j] = x[i];
-                zv[k][j] = z[i] + reg * pv[k][j]; acc[k] += pv[k][j] * zv[k][j];
-            }
-        }
-    }
-    const double pz = blk_sum_v<VT>(acc, sh);
-    const double v = rdotr / pz;
-#pragma unroll
-    for (int k = 0; k < VT; ++k) {
-        acc[k] = 0.0;
-#pragma unroll
-        for (int j = 0; j < R; ++j) { xv[k][j] += v * pv[k][j]; rv[k][j] -= v * zv[k][j]; acc[k] += rv[k][j] * rv[k][j]; }
-    }
-    const double newrdotr = blk_sum_v<VT>(acc, sh);
-    const double mu = newrdotr / rdotr;
-#pragma unroll
-    for (int k = 0; k < VT; ++k)
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const int i = threadIdx.x + k * blockDim.x + j * NV;
-            if (i < P) {
-                const double pn = rv[k][j] + mu * pv[k][j];
-                z[i] = zv[k][j]; x[i] = xv[k][j]; r[i] = rv[k][j]; p[i] = pn;
-                pf.put(i, last ? (float)xv[k][j] : (float)pn);
-            }
-        }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        scal[S_RDOTR] = newrdotr;
-        scal[S_ITERS] += 1.0;
-        if (newrdotr < tol) scal[S_DONE] = 1.0;
-    }
-}
-
 // One pass of ConjugateGradientOptimizer.optimize's backtracking loop, decided where the numbers are: the loop's break test
 // (loss < loss_before and kl <= max_kl) and, when it breaks, the acceptance rule that follows the loop (rejects a NaN, loss >= loss_before or
 // kl >= max_kl unless accept_violation) -- an accepted trial's theta replaces the policy at once.  Later speculative trials see ls[0] >= 0

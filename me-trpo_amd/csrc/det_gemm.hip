@@ -178,8 +178,7 @@ static dg_pre_mfma_t dg_pre_mfma_select(const metrpo_ctx* c, size_t* dyn_lds = n
     const ProblemDesc& pd = c->pd;
     if (dyn_lds) *dyn_lds = 0;
     if (dyn_lds && pd.env == METRPO_ENV_HUMANOID && pd.ns == 55 && pd.na == 21 && pd.n_drop == 0 && pd.pol.n_layers == 4 && pd.pol.dims[1] == 100 &&
-        pd.pol.dims[2] == 50 && pd.pol.dims[3] == 25 && pd.pol.act[0] == METRPO_ACT_TANH && pd.pol.act[1] == METRPO_ACT_TANH && pd.pol.act[2] == METRPO_ACT_TANH &&
-        ctx_opt(c, OPT_NO_PRE_MFMA3) == nullptr) {
+        pd.pol.dims[2] == 50 && pd.pol.dims[3] == 25 && pd.pol.act[0] == METRPO_ACT_TANH && pd.pol.act[1] == METRPO_ACT_TANH && pd.pol.act[2] == METRPO_ACT_TANH) {
         *dyn_lds = sizeof(float) * (size_t)(P3<55, 21, 100, 50, 25>::IMG + 4 * 16 * 55);
         return k_dg_pre_mfma3<55, 21, 0, 100, 50, 25>;
     }

@@ -346,11 +346,10 @@ static inline void gemm_mfma_launch(const float* A, long long sA, int lda, const
     // contiguous axes: A rows run along Kd (or along M when TA), W rows along N (or along Kd when TB)
     const bool al = m4((long long)(uintptr_t)A >> 2) && (((uintptr_t)A & 15) == 0) && (((uintptr_t)W & 15) == 0) && m4(sA) && m4(sW) && m4(lda) && m4(ldw) &&
                     m4(TA ? M : Kd) && m4(TB ? Kd : N) && (EPI != EPI_PARTIAL || m4(ep.kchunk));
-    // few workgroups per CU and a long contraction: deeper prefetch (see k_gemm_mfma's PD); option GEMM_PREFETCH=1 (metrpo_set_option; process-wide) keeps distance 1 (A/B runs)
-    const bool pd_off = g_gemm_prefetch_off.load(std::memory_order_relaxed) != 0;
+    // few workgroups per CU and a long contraction: deeper prefetch (see k_gemm_mfma's PD)
     const long long nblocks = (long long)grid.x * grid.y * grid.z;
     if constexpr (TM * TN == 1) {
-        if (!pd_off && nblocks <= 1280 && Kd >= 256) {
+        if (nblocks <= 1280 && Kd >= 256) {
             if (al) hipLaunchKernelGGL((k_gemm_mfma<TM, TN, EPI, TA, TB, true, 4>), grid, dim3(256), 0, st, A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, ep);
             else hipLaunchKernelGGL((k_gemm_mfma<TM, TN, EPI, TA, TB, false, 4>), grid, dim3(256), 0, st, A, sA, lda, W, sW, ldw, C, sC, ldc, M, N, Kd, ep);
             return;

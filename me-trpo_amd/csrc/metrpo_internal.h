@@ -36,7 +36,7 @@ struct ProblemDesc {
 // ---- variant / tuning switches of a context (metrpo_set_option / metrpo_get_option, include/metrpo.h) ----------------------------------------------
 // One table per context, read by the launch paths through ctx_opt(); metrpo_create fills the defaults ONCE from the environment (METRPO_<KEY>), nothing
 // else in the library reads the environment for kernel selection.  A key is the upper-case name below (the ABI also takes lower case and a METRPO_ prefix).
-#define METRPO_OPT_LIST(X) X(COOP_MODE) X(EXTRA_LDS) X(GEMM_PREFETCH) X(NO_DEVICE_LINESEARCH) X(NO_FUSED_OUT) X(NO_IMGVAL) X(NO_L0_ROWS) X(NO_MERGED_ROUNDS) X(NO_PRE_MFMA3) X(NO_RESIDENT) X(NO_RESIDENT_VALIDATION) X(NO_STEP_MERGE) X(NO_STREAMK) X(PG_HEAD_ROWS) X(PRE_GEMM) X(RESIDENT_NO_ROTATE) X(RESIDENT_NO_SENTINEL) X(RESIDENT_TEST_SKIP) X(RESIDENT_WS) X(RES_UNCACHED) X(SEQ_ROUNDS) X(SOLVE_BLOCK) X(STEP_MERGE) X(STREAMK) X(STREAMK_LATE) X(STREAMK_NO_XCD) X(UPD_TILES_PER_WAVE) X(VAL_CHUNKS) X(VAL_TILES_PER_WAVE) X(XCHG_TIMEOUT_MS) X(NO_PERSIST) X(PERSIST) X(QUIET) X(TIME_FVP) X(PERSIST_STATS) X(PERSIST_NARROW) X(PERSIST_WIDE) X(PERSIST_NCLOSE) X(STREAMK_NO_TEAM) X(NO_POL_FUSED3) X(CG_PERSIST) X(NO_PRE_SPLIT)
+#define METRPO_OPT_LIST(X) X(NO_FUSED_OUT) X(NO_L0_ROWS) X(NO_MERGED_ROUNDS) X(NO_RESIDENT) X(NO_RESIDENT_VALIDATION) X(NO_STREAMK) X(PRE_GEMM) X(RESIDENT_PLAN) X(RESIDENT_TEST_SKIP) X(RESIDENT_WS) X(SEQ_ROUNDS) X(STEP_MERGE) X(STREAMK) X(STREAMK_LATE) X(STREAMK_PLACE) X(VAL_PLAN) X(XCHG_TIMEOUT_MS) X(NO_PERSIST) X(QUIET) X(TIME_FVP) X(PERSIST_STATS) X(PERSIST_WIDE) X(PERSIST_NCLOSE) X(NO_POL_FUSED3) X(NO_PRE_SPLIT)
 enum MetrpoOpt {
 #define X(n) OPT_##n,
     METRPO_OPT_LIST(X)
@@ -95,7 +95,6 @@ struct metrpo_ctx {
     void* xg_region; void* xg_peer[XCHG_MAX_WORLD]; int xg_world, xg_rank, xg_cap, xg_fuse; unsigned int xg_seq; unsigned long long xg_timeout;
     int pol_path;        // 1 auto (fused MFMA kernels where the shape has them, GEMM path for large N otherwise), 0 generic forced, 2 GEMM path forced
     void* d_pg; size_t pg_cap; long long pg_fwd_rows; const float* pg_fwd_obs;   // policy_gemm.hip workspace + validity of its cached forward pass
-    unsigned int* d_cgp_bar; int cgp_failed, cgp_launches;   // policy_mfma.hip MODE_CGP: barrier counters of the persistent CG solve | a solve timed out: per-launch path from then on
     int pol_f3;          // 1: fused MFMA update kernels for three-hidden-layer policies (policy_fused3.hip) serve this shape
     void* d_f3; size_t f3_cap; long long f3_rows; const float* f3_obs; const float* f3_theta; int f3_img_ok;   // policy_fused3.hip: activation cache + mean-adjoint of one (theta, batch) and its validity
     void* d_adam;        // Adam moments [2][K][Pd] + loss accumulators (dyn_train.hip)
@@ -158,7 +157,6 @@ static inline hipError_t ws_alloc(metrpo_ctx* c, void** p, size_t bytes) {
 static inline const char* ctx_opt(const metrpo_ctx* c, int id) { return c->opt_set[id] ? c->opt_val[id].c_str() : nullptr; }
 // kernels that wait on other workgroups of their own launch may be selected: the caller said the device is its own (metrpo_set_exclusive) AND option NO_RESIDENT is unset
 static inline bool ctx_exclusive(const metrpo_ctx* c) { return c->exclusive != 0 && ctx_opt(c, OPT_NO_RESIDENT) == nullptr; }
-inline std::atomic<int> g_gemm_prefetch_off{0};     // option GEMM_PREFETCH (process-wide: gemm_mfma.h's dispatch has no context)
 // the three-hidden-layer fused update kernels (policy_fused3.hip) serve this context's next update launch (not the VJP mode of the gradient kernels: GEMM path)
 static inline bool f3_active(const metrpo_ctx* c) { return c->pol_f3 != 0 && c->pol_path == 1 && c->vjp_gm == nullptr && ctx_opt(c, OPT_NO_POL_FUSED3) == nullptr; }
 const char* metrpo_opt_name(int id);
@@ -218,7 +216,6 @@ struct PolK {
 int policy_mfma_select(const ProblemDesc& pd);
 int policy_mfma_image_buffers(metrpo_ctx*);   // gather map, its inverse for the tangent entries and the image-value buffer of ctx->pol_mfma (idempotent)
 struct CgTail;
-int policy_mfma_cg_persist(metrpo_ctx*, int idx, const metrpo_batch*, const float* theta, const CgTail& tail, int n_it, float* partials, int nblocks, hipStream_t);
 int policy_mfma_launch(metrpo_ctx*, int idx, int mode, const metrpo_batch*, const float* theta, const float* v,
                        float* partials, int nblocks, hipStream_t);
 
@@ -305,7 +302,6 @@ int launch_fvp(metrpo_ctx*, const metrpo_batch*, const double*, double*, hipStre
 // vf = float copy of v already on the device (skips the conversion launch); v is still needed for the log_std rows
 int launch_fvp_f32(metrpo_ctx*, const metrpo_batch*, const float* vf, const double* v, double* hv, hipStream_t);
 // FVP + reduction + (in the reduction kernel's last block) the CG vector step described by `tail`
-int launch_cg_persist(metrpo_ctx*, const metrpo_batch*, const CgTail& tail, int n_it, hipStream_t);
 int launch_fvp_tail(metrpo_ctx*, const metrpo_batch*, const float* vf, const double* v, double* hv, const CgTail* tail, hipStream_t);
 int launch_loss_kl(metrpo_ctx*, const metrpo_batch*, const float*, double*, hipStream_t, const CgTail* decide = nullptr);   // decide: op 4 tail (device-side accept test)
 int run_trpo_update(metrpo_ctx*, const metrpo_batch*, const metrpo_trpo_params*, metrpo_trpo_diag*, double*,

@@ -325,7 +325,7 @@ int policy_gemm_run(metrpo_ctx* c, int mode, const metrpo_batch* b, const PolK& 
         }
     }
     // per-sample head
-    const bool head_elem = (mode == 1 && k.gm == nullptr && ctx_opt(c, OPT_PG_HEAD_ROWS) == nullptr);
+    const bool head_elem = (mode == 1 && k.gm == nullptr);
     const int nblk = head_elem ? (int)std::min<long long>(1024, (N * nap + 2047) / 2048) : (int)std::min<long long>(1024, (N + 255) / 256);
     if (head_elem) hipLaunchKernelGGL(k_pg_head_fvp, dim3(nblk), dim3(256), 0, st, k, na, nap, MU, theta + pd.pol.n_params, U, B.hparts);
     else hipLaunchKernelGGL(k_pg_head, dim3(nblk), dim3(256), 0, st, mode, k, na, nap, MU, theta + pd.pol.n_params, U, B.hparts);

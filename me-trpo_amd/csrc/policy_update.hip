@@ -479,16 +479,6 @@ static int run_mode(metrpo_ctx* c, int mode, const metrpo_batch* b, const PolK& 
     return rc;
 }
 
-// all `n_it` Fisher-vector products of a CG solve + the vector steps in one launch (policy_mfma.hip MODE_CGP); METRPO_EUNSUPPORTED: per-launch path
-int launch_cg_persist(metrpo_ctx* c, const metrpo_batch* b, const CgTail& tl, int n_it, hipStream_t st) {
-    if (c->pol_mfma < 0 || policy_gemm_applicable(c, b->N) || c->vjp_gm != nullptr) return METRPO_EUNSUPPORTED;
-    const long long tiles = (b->N + 15) / 16;
-    const long long per_block = 8ll * std::max(1, c->upd_tiles_per_wave);
-    const int g = (int)std::max<long long>(1, std::min<long long>((tiles + per_block - 1) / per_block, (long long)c->n_sm));      // run_mode's grid of the products
-    int rc = ensure_partials(c, g); if (rc) return rc;
-    return policy_mfma_cg_persist(c, c->pol_mfma, b, c->d_theta, tl, n_it, c->d_partials, g, st);
-}
-
 int launch_loss_grad(metrpo_ctx* c, const metrpo_batch* b, double* out, hipStream_t st, const CgTail* tail) {
     PolK k; int rc = fill_polk(c, b, &k, true); if (rc) return rc;
     if (policy_gemm_applicable(c, b->N)) return policy_gemm_run(c, 0, b, k, c->d_theta, nullptr, nullptr, out, tail, st);

@@ -743,9 +743,7 @@ __global__ void __launch_bounds__(64) k_baseline_solve_wave(const double* __rest
 int launch_baseline_solve(metrpo_ctx* c, const double* AtA, const double* Aty, double reg, double* coeffs, hipStream_t st) {
     const int F = 2 * c->pd.ns + 4;
 #define SOLVE_WAVE(FT_) case FT_: hipLaunchKernelGGL(k_baseline_solve_wave<FT_>, dim3(1), dim3(64), 0, st, AtA, Aty, reg, coeffs); HIP_TRY(c, hipGetLastError()); return METRPO_OK;
-    if (ctx_opt(c, OPT_SOLVE_BLOCK) == nullptr) {
-        switch (F) { SOLVE_WAVE(24) SOLVE_WAVE(26) SOLVE_WAVE(32) SOLVE_WAVE(40) SOLVE_WAVE(62) default: break; }
-    }
+    switch (F) { SOLVE_WAVE(24) SOLVE_WAVE(26) SOLVE_WAVE(32) SOLVE_WAVE(40) SOLVE_WAVE(62) default: break; }
 #undef SOLVE_WAVE
     const size_t sh = sizeof(double) * ((size_t)F * (F + 1) + F);
     if (sh > 160 * 1024) return set_err(c, METRPO_EUNSUPPORTED, "baseline_solve: feature count too large for one workgroup's LDS");

@@ -686,7 +686,6 @@ int launch_rollout_coop(metrpo_ctx* c, int idx, const RolloutK& r_in, hipStream_
         const double t_two = en.pair * rounds + (rest == 0 ? 0.0 : rest <= n_cu ? 1.0 + en.rem_slope * (en.pair - 1.0) * rest / n_cu : en.pair);
         one = t_one < t_two;
     }
-    if (const char* ex = ctx_opt(c, OPT_COOP_MODE)) one = (ex[0] == '1') || (one && ex[0] != '2');     // launch-rule experiments only: 1 / 2 workgroups per CU
     if (c->rollout_variant == 2) one = false;
     // a GPU shared with other compute processes (METRPO_NO_RESIDENT=1, the switch that also keeps rollout_resident.hip out): the migrating schedule's
     // consumers wait for producer workgroups of their own grid, which other processes' workgroups can keep off the chip until the bounded wait gives up

@@ -448,7 +448,7 @@ static big_pre_mfma_t big_pre_mfma_select(const metrpo_ctx* c, size_t* dyn_lds, 
     const ProblemDesc& pd = c->pd;
     *dyn_lds = 0;
     if (pd.env == METRPO_ENV_HUMANOID && pd.ns == 55 && pd.na == 21 && pd.n_drop == 0 && pd.pol.n_layers == 4 && pd.pol.dims[1] == 100 && pd.pol.dims[2] == 50 &&
-        pd.pol.dims[3] == 25 && pd.pol.act[0] == METRPO_ACT_TANH && pd.pol.act[1] == METRPO_ACT_TANH && pd.pol.act[2] == METRPO_ACT_TANH && ctx_opt(c, OPT_NO_PRE_MFMA3) == nullptr) {
+        pd.pol.dims[3] == 25 && pd.pol.act[0] == METRPO_ACT_TANH && pd.pol.act[1] == METRPO_ACT_TANH && pd.pol.act[2] == METRPO_ACT_TANH) {
         *dyn_lds = big_pre_mfma3_lds<55, 21, 0, 100, 50, 25>();
         return post ? k_big_pre_mfma3<55, 21, 0, 100, 50, 25, true> : k_big_pre_mfma3<55, 21, 0, 100, 50, 25, false>;
     }
@@ -634,6 +634,7 @@ static size_t sk_epi_floats(int OT, int N, int heads) {
 struct SkPath {            // mode 0: off; 1: x -> [layer 0 | layer 1 | output layer] in one launch; 2: layer L-3 stored, [layer L-2 | output layer];
                            // 3: two hidden layers with a wide input: layer 0 stored by the tile GEMM, [layer 1 | output layer] in one launch
     int mode, S0, OT;
+    int forced;                                                             // option STREAMK=1: the caller wants this family whatever the tile count (parity tests at oracle sizes)
     SkVt v1, v2; SkArgs a1, a2; SkPlan p1, p2;
 };
 // which path (and its plans) for this context and batch; a1 / a2 carry shapes only (pointers are filled in by rollout_gemm_chunk)
@@ -643,6 +644,7 @@ static SkPath sk_select(const metrpo_ctx* c, int B) {
     const int L = pd.dyn.n_layers, K = pd.K;
     const char* fe = ctx_opt(c, OPT_STREAMK);                               // "1": also below one tile per CU (tests at oracle-sized batches)
     const bool force = fe != nullptr && fe[0] == '1';
+    sp.forced = force ? 1 : 0;
     if (ctx_opt(c, OPT_NO_STREAMK) != nullptr || L < 3 || L > 4 || pd.ns > 64) return sp;
     for (int l = 0; l < L - 1; ++l) if (pd.dyn.act[l] != METRPO_ACT_RELU) return sp;
     if (pd.dyn.act[L - 1] != METRPO_ACT_IDENTITY) return sp;
@@ -669,10 +671,13 @@ static SkPath sk_select(const metrpo_ctx* c, int B) {
         return (late_ok && tiles < c->n_sm && units / c->n_sm >= (force ? 2 : 5)) ? 1 : 0;
     };
     const int epi_units = (sp.OT == 4) ? 2 : 1;
+    // test hook STREAMK_PLACE: "flat" = consecutive ranges over the workgroups (no XCD-aware deal), "xcd" = XCD-aware ranges without the team walk; default: teams
+    const char* place = ctx_opt(c, OPT_STREAMK_PLACE);
+    const bool place_flat = place != nullptr && place[0] == 'f', place_xcd = place != nullptr && place[0] == 'x';
     if (!force && (long long)K * ((B + 127) / 128) * (N / 256) < c->n_sm && !late_for(K1, N, epi_units)) return sp;
     auto shape = [&](SkArgs& a, int K1_, int N_, int eu) { a = SkArgs{}; a.M = B; a.heads = K; a.K1 = K1_; a.N = N_; a.late = late_for(K1_, N_, eu);
-                                                             a.xcd = ctx_opt(c, OPT_STREAMK_NO_XCD) == nullptr ? 8 : 0;
-                                                             a.team = ctx_opt(c, OPT_STREAMK_NO_TEAM) == nullptr ? 1 : 0; };      // (sk_plan keeps it for SK_A_GLOBAL launches with enough tiles only)      // MI355X: 8 XCDs, workgroups dealt round-robin
+                                                             a.xcd = place_flat ? 0 : 8;
+                                                             a.team = place_xcd ? 0 : 1; };      // (sk_plan keeps it for SK_A_GLOBAL launches with enough tiles only)      // MI355X: 8 XCDs, workgroups dealt round-robin
     if (L == 3) {
         sp.S0 = (pd.nin + 1 + 3) / 4;
         const bool fused = sk_fused_vt(sp.S0, sp.OT, &sp.v1);                   // layer 0 as producer: inputs of up to 36 values (Humanoid's 76 + 1: mode 3)
@@ -714,7 +719,7 @@ template <int ENV, int S0, int OT, bool WIDE> static SkpVt skp_vt() {
     v.tab = [](const SkArgs& a, bool wide, std::vector<SkRec>& t, int (&Jx)[8], int& Jmax, int& L, int& NSL) { skp_build_tab<OT>(a, wide, t, Jx, Jmax, L, NSL); };
     return v;
 }
-// wide: an even number of 256-column blocks -> tiles of two adjacent blocks sharing the layer-0 producer (option PERSIST_NARROW keeps one block per tile: A/B runs, tests)
+// wide: an even number of 256-column blocks -> tiles of two adjacent blocks sharing the layer-0 producer (option PERSIST_WIDE=0 keeps one block per tile, =1 forces two: tests)
 static bool skp_select(const metrpo_ctx* c, int S0, int OT, int CB, int B, SkpVt* v) {
     const ProblemDesc& pd = c->pd;
     if (pd.pol.n_layers != 3 || pd.pol.dims[1] != 32 || pd.pol.dims[2] != 32 || pd.pol.act[0] != METRPO_ACT_TANH) return false;
@@ -722,7 +727,7 @@ static bool skp_select(const metrpo_ctx* c, int S0, int OT, int CB, int B, SkpVt
     // ~1.2 of them per compute workgroup and step -- below that the chain, not the matrix pipe, sets the step time (C3 share: 170 vs 128 us per step).
     const long long wide_tiles = (long long)pd.K * (CB / 2) * ((B + 127) / 128);
     const char* wo = ctx_opt(c, OPT_PERSIST_WIDE);
-    const bool wide = (CB % 2 == 0) && ctx_opt(c, OPT_PERSIST_NARROW) == nullptr && ((wo && wo[0] == '1') || 10 * wide_tiles >= 12 * (long long)(c->n_sm - 8));
+    const bool wide = (CB % 2 == 0) && !(wo && wo[0] == '0') && ((wo && wo[0] == '1') || 10 * wide_tiles >= 12 * (long long)(c->n_sm - 8));
 #define SKP_PICK(ENV_, S0_, OT_) { *v = wide ? skp_vt<ENV_, S0_, OT_, true>() : skp_vt<ENV_, S0_, OT_, false>(); return true; }
     switch (pd.env) {
     case METRPO_ENV_SWIMMER:      if (pd.ns == 10 && pd.na == 2 && pd.n_drop == 2 && S0 == 3 && OT == 1) SKP_PICK(METRPO_ENV_SWIMMER, 3, 1) break;
@@ -808,13 +813,15 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
     if (fuse_out) nP = std::max(nP, up4(gemm_fused_out_part_floats(B, pd.dyn.dims[L - 1], K, pd.ns, fuse_tile)));
     size_t pre_lds = 0;
     const big_pre_mfma_t pre_mfma = big_pre_mfma_select(c, &pre_lds);
-    // steps t >= 1: k_big_post(t - 1) rides in the pre-step's launch (the MFMA pre-kernels: 2 x 32 policies and Humanoid's 100-50-25; METRPO_NO_STEP_MERGE=1 keeps the two launches: A/B runs, tests)
+    // steps t >= 1: k_big_post(t - 1) rides in the pre-step's launch (the MFMA pre-kernels: 2 x 32 policies and Humanoid's 100-50-25; STEP_MERGE=0 keeps the two launches: A/B runs, tests)
     size_t pre_lds_post = 0;
     // (Humanoid's 55 dims are 16 per lane in that layout: behind the tile GEMMs' 16 output partials per head -- small batches -- the closing part is slower
     //  than k_big_post's lane per dim, 12.9 vs 11.1 ms per params-file rollout; behind stream-K's 4 partials it is merged.  METRPO_STEP_MERGE=1 forces it: tests)
     //  Small batches of the 100-50-25 pre-step (a tile per workgroup: k_big_pre_mfma3_split, below) keep two launches also behind stream-K: 9.6 + 6.3 us against the merged 29.4.)
-    const bool split_pre_small = pd.ns > 32 && B <= 16 * c->n_sm && ctx_opt(c, OPT_NO_PRE_SPLIT) == nullptr && ctx_opt(c, OPT_STEP_MERGE) == nullptr;
-    const bool merge_ok = ctx_opt(c, OPT_NO_STEP_MERGE) == nullptr && !split_pre_small && (pd.ns <= 32 || sk.mode != 0 || ctx_opt(c, OPT_STEP_MERGE) != nullptr);
+    const char* sm_opt = ctx_opt(c, OPT_STEP_MERGE);          // "1" forces the merged launch, "0" keeps two launches (A/B runs, tests)
+    const bool step_merge_forced = sm_opt != nullptr && sm_opt[0] != '0', step_merge_off = sm_opt != nullptr && sm_opt[0] == '0';
+    const bool split_pre_small = pd.ns > 32 && B <= 16 * c->n_sm && ctx_opt(c, OPT_NO_PRE_SPLIT) == nullptr && !step_merge_forced;
+    const bool merge_ok = !step_merge_off && !split_pre_small && (pd.ns <= 32 || sk.mode != 0 || step_merge_forced);
     const big_pre_mfma_t pre_post = (pre_mfma && merge_ok) ? big_pre_mfma_select(c, &pre_lds_post, true) : nullptr;
     // policies without an MFMA pre-kernel: GEMM chain over the batch from B = 1024 up -- and at ANY batch when the policy is large
     // (k_big_pre walks the weights through scalar loads, one block's time whatever B: 302 us per step for Humanoid's 100-50-25 at B = 100,
@@ -834,6 +841,12 @@ static int rollout_gemm_chunk(metrpo_ctx* c, const metrpo_rollout_args* a, hipSt
         if (skp.lds > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute(skp.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)skp.lds));
         skp_grid = (std::min(sched_cus(c, st), c->n_sm) / 8) * 8;
         persist = skp_grid >= 16 && grid_is_coresident(c, skp.kern, 512, skp.lds, skp_grid, st);
+        // The persistent launch works in WHOLE 128 x 256 tiles: a step cannot be shorter than one tile's k loop on one CU (~150 us at hidden 1024, ~80 at 512), whatever
+        // B is.  With fewer tiles per step than workgroups the per-step stream-K launches win -- they split a tile's k range over the idle CUs -- by 2.5 x at the strong-
+        // scaling shares of C2 / C3 (B = 312: 33.5 -> 13.2 ms per rollout; B = 625 Ant: 52 -> 30 ms); the crossover sits at one tile per workgroup (240 tiles: per-step
+        // launches 7-11 % ahead, 280 tiles: persistent 0-6 % ahead, 400: 5-14 %; profiles/r06_share_sweep.txt).  STREAMK=1 (parity tests at oracle sizes) keeps it.
+        const long long tiles_step = (long long)K * ((B + 127) / 128) * (sk.a1.N / 256);
+        if (persist && !sk.forced && tiles_step < skp_grid + skp_grid / 16) persist = false;
     }
     int skp_nclose = SKP_NCLOSE;
     if (persist) {

@@ -407,7 +407,6 @@ int launch_rollout_mfma(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
     RolloutK r = make_rollout_k(a);
     if (c->coop_cfg >= 0 && c->rollout_variant != 1) return launch_rollout_coop(c, c->coop_cfg, r, st);
     size_t sh = sizeof(float) * ((size_t)K * en.w_total + 2 * (size_t)K * 16 * en.nsp);
-    if (const char* ex = ctx_opt(c, OPT_EXTRA_LDS)) sh += (size_t)atoi(ex);          // occupancy experiments only
     const int grid = (a->B + 15) / 16;
     hipLaunchKernelGGL(en.kern, dim3(grid), dim3(K * 64), sh, st, r, K, c->d_dyn, c->d_theta, c->d_norm);
     HIP_TRY(c, hipGetLastError());

@@ -24,6 +24,9 @@
 // every wait is bounded (2 s), a launch that gives up is reported by the next metrpo_trpo_update / metrpo_comm_check and retires the kernel
 // for its context (metrpo_internal.h: rollout_error_seen).
 #include "mfma_common.h"
+#include <string.h>
+// test hook RESIDENT_PLAN: comma-separated words -- "norotate" (fixed deal of tiles to columns), "nosentinel" (post wave polls without the sentinel read)
+static inline bool resident_plan_has(const metrpo_ctx* c, const char* word) { const char* v = ctx_opt(c, OPT_RESIDENT_PLAN); return v != nullptr && strstr(v, word) != nullptr; }
 
 // Developer instrumentation (SRC=rollout_resident.hip tools/build_variant.sh restiming -DRES_TIMING): shader-clock sums per phase of the
 // waves of compute workgroup 0 and of the first post workgroup, read back with metrpo_debug_resident_phases (tools/resident_phases.py).
@@ -1079,7 +1082,7 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
     if (!grid_is_coresident(c, (const void*)pick->fn, pick->threads, pick->lds, 1, st)) return METRPO_EUNSUPPORTED;      // >= one workgroup per CU, exclusive device
     const int NSL = DH / pick->ws, OUT_CB = (pd.ns + 15) / 16, NIN_KS = (pd.nin + 1 + 3) / 4;
     // rotating deal (ResidentK::rot): launches of the 4-wave form whose few tiles do not divide by the columns; one partial-sum region per column
-    const bool may_rot = pick->threads == 256 && pick->fn_rot != nullptr && ctx_opt(c, OPT_RESIDENT_NO_ROTATE) == nullptr;
+    const bool may_rot = pick->threads == 256 && pick->fn_rot != nullptr && !resident_plan_has(c, "norotate");
     const int max_cols = std::max(1, n_cu / (K * (DH / pick->ws)));
     const size_t nX = (size_t)Rg * NT * 4 * NIN_KS * 16, nP = (size_t)Rg * NT * K * NSL * 16 * OUT_CB * 16 * (may_rot ? max_cols : 1);
     const size_t need = (nX + nP + 32) * sizeof(unsigned long long);
@@ -1091,9 +1094,7 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
         // allocated hipDeviceMallocUncached and later hipFree'd can come back from hipMalloc as somebody's ordinary buffer with lines of its old
         // life still sitting in one XCD's L2: seen as a step-wise rollout (rollout_gemm.hip) of a LATER engine reading two stale cache lines of
         // its fresh workspace, gone after evicting the L2s (tests/test_gpu_resident.py::test_stepwise_workspace_after_freed_resident_regions).
-        // METRPO_RES_UNCACHED=1 brings the uncached flavour back (reproducing the above).
-        if (ctx_opt(c, OPT_RES_UNCACHED) != nullptr) HIP_TRY(c, hipExtMallocWithFlags(&c->d_res, need, hipDeviceMallocUncached));
-        else HIP_TRY(c, ws_alloc(c, (void**)&c->d_res, need));
+        HIP_TRY(c, ws_alloc(c, (void**)&c->d_res, need));
         HIP_TRY(c, hipMemsetAsync(c->d_res, 0, need, st));
         c->res_cap = need; c->res_seq = 0;
     }
@@ -1123,7 +1124,7 @@ int launch_rollout_resident(metrpo_ctx* c, const metrpo_rollout_args* a, hipStre
         z.skip_block = -1;
         // few tiles per column (Ant's chunks, single rounds): the step is a latency chain and the post wave's polling rounds are on it; with many tiles per
         // column the partial sums are there before the post wave looks, and the extra round trip of the sentinel read costs 2 - 4 % (half-cheetah, 5 rounds)
-        z.sentinel = (pick->threads == 256 && z.NTC <= 4 && ctx_opt(c, OPT_RESIDENT_NO_SENTINEL) == nullptr) ? 1 : 0;
+        z.sentinel = (pick->threads == 256 && z.NTC <= 4 && !resident_plan_has(c, "nosentinel")) ? 1 : 0;
         if (const char* sk = ctx_opt(c, OPT_RESIDENT_TEST_SKIP)) z.skip_block = atoi(sk);
         z.abort_cell = (unsigned int*)c->d_res;
         z.X = (unsigned long long*)c->d_res + 32; z.P = z.X + nX;
@@ -1175,13 +1176,14 @@ int launch_validation_resident(metrpo_ctx* c, const float* s0, int Bv, int T, do
     int nb = 0, NTM = 0, NTC = 0, cols = 0, ntw_i = 0;
     double best = 1e30;
     const double t_tile = (DH >= 1024) ? 6.1 : 2.0, t_trip = 8.0, t_post = 3.0, t_launch = 60.0;
-    const char* ntw_env = ctx_opt(c, OPT_VAL_TILES_PER_WAVE);              // test hook: 1 | 2 | 4
-    const char* chunks_env = ctx_opt(c, OPT_VAL_CHUNKS);                   // test hook: number of batch chunks (launches), 1 .. 8
+    // test hook VAL_PLAN = "<tiles per post wave: 1 | 2 | 4 | 0 = the model's pick>[,<batch chunks (launches): 1 .. 8>]"
+    int ntw_pin = 0, chunks_pin = 0;
+    if (const char* vp = ctx_opt(c, OPT_VAL_PLAN)) { ntw_pin = atoi(vp); if (const char* cm = strchr(vp, ',')) chunks_pin = atoi(cm + 1); }
     for (int wi = 0; wi < 3; ++wi) {
         const int ntw = 1 << wi;
-        if (ntw_env != nullptr && atoi(ntw_env) != ntw) continue;
+        if (ntw_pin != 0 && ntw_pin != ntw) continue;
         for (int n = 1; n <= 8; ++n) {
-            if (chunks_env != nullptr && atoi(chunks_env) != n) continue;
+            if (chunks_pin != 0 && chunks_pin != n) continue;
             const int bc = (Bv + n - 1) / n, ntm = (bc + 15) / 16, post = ((K * ntm + ntw - 1) / ntw + PW - 1) / PW;
             const int ncol = std::min(ntm, (n_cu - post) / (K * NSL));
             if (ncol < 1) continue;

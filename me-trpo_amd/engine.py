@@ -209,10 +209,6 @@ class Engine(object):
         self._chk(lib.metrpo_debug_fvp_us(self._ctx, C.byref(us), C.byref(n)))
         return float(us.value), int(n.value)
 
-    def cg_persist_launches(self):
-        """Diagnostics: CG solves of this engine that ran as ONE launch so far (policy_mfma.hip MODE_CGP; opt-in: option CG_PERSIST)."""
-        return int(lib.metrpo_debug_cg_persist_launches(self._ctx))
-
     def update_path(self, N):
         """Kernel family the policy update of an N-sample batch runs on: 'mfma' (fused), 'gemm' or 'generic'."""
         return {1: 'mfma', 2: 'gemm', 0: 'generic'}[int(lib.metrpo_update_path(self._ctx, int(N)))]

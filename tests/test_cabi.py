@@ -83,8 +83,8 @@ def test_option_table_is_enumerable_and_the_library_reads_the_environment_in_one
     names = []
     while lib.metrpo_option_name(len(names)) is not None:
         names.append(lib.metrpo_option_name(len(names)).decode())
-    assert {'STREAMK', 'NO_STREAMK', 'NO_RESIDENT', 'SEQ_ROUNDS', 'PRE_GEMM', 'UPD_TILES_PER_WAVE', 'QUIET'} <= set(names)
-    assert len(names) == len(set(names)) >= 30
+    assert {'STREAMK', 'NO_STREAMK', 'NO_RESIDENT', 'SEQ_ROUNDS', 'PRE_GEMM', 'STEP_MERGE', 'QUIET'} <= set(names)
+    assert 15 <= len(names) == len(set(names)) <= 25          # verdict r5 item 4: the switches a caller or a test needs, nothing parked
     assert lib.metrpo_set_option(None, b'STREAMK', b'1') == -2 and lib.metrpo_get_option(None, b'STREAMK', None, 0) == -2      # METRPO_ENULL
     csrc = os.path.join(REPO, 'me-trpo_amd', 'csrc')
     sites = []

@@ -111,8 +111,8 @@ def test_rotating_tile_deal_and_sentinel_wait_are_bitwise_the_fixed_deal(env, B,
         eng.set_dynamics_layers(dm.Ws, dm.bs, dm.in_mean, dm.in_std, dm.diff_mean, dm.diff_std)
     rot = _fields(eng.rollout(B, T, H, mode, pool, seed=11))
     assert eng.last_rollout_kernel() == 'resident'
-    for var in ('METRPO_RESIDENT_NO_SENTINEL', 'METRPO_RESIDENT_NO_ROTATE'):      # first without the sentinel wait, then also on the fixed deal
-        eng.set_option(var, '1')
+    for plan in ('nosentinel', 'nosentinel,norotate'):      # first without the sentinel wait, then also on the fixed deal
+        eng.set_option('RESIDENT_PLAN', plan)
         other = eng.rollout(B, T, H, mode, pool, seed=11)
         assert eng.last_rollout_kernel() == 'resident'
         for a, b in zip(rot, _fields(other)):
@@ -321,12 +321,11 @@ def test_resident_validation_costs_against_oracle_and_the_stepwise_sweep(env, hi
     again = cpu(eng.validation_cost(s0, T, gamma))
     np.testing.assert_array_equal(got, again)                             # bitwise repeatable
     for ntw in (1, 2, 4):                                                 # tiles per post wave (the launcher picks by a cost model): same sums whatever the deal
-        eng.set_option('METRPO_VAL_TILES_PER_WAVE', str(ntw))
+        eng.set_option('VAL_PLAN', str(ntw))
         np.testing.assert_allclose(cpu(eng.validation_cost(s0, T, gamma)), got, rtol=1e-6, atol=1e-6)
-    eng.set_option('METRPO_VAL_TILES_PER_WAVE', None)
     for nb in (2, 3, 5):                                                  # the batch in chunks (one launch each; the last one ragged)
         if Bv >= nb:
-            eng.set_option('METRPO_VAL_CHUNKS', str(nb))
+            eng.set_option('VAL_PLAN', '0,%d' % nb)
             np.testing.assert_allclose(cpu(eng.validation_cost(s0, T, gamma)), got, rtol=1e-6, atol=1e-6)
     eng.comm_check()
 

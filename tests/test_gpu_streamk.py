@@ -132,7 +132,7 @@ def test_streamk_xcd_aware_ranges_are_bitwise_the_plain_split(monkeypatch):
     xcd = eng.rollout(B, T, H, 'step_rand', pool, seed=3)
     assert eng.last_rollout_kernel() == 'gemm-streamk'
     keep = [x.clone() for x in (xcd.obs, xcd.rew, xcd.mean, xcd.done)]
-    eng.set_option('METRPO_STREAMK_NO_XCD', '1')
+    eng.set_option('STREAMK_PLACE', 'flat')
     plain = eng.rollout(B, T, H, 'step_rand', pool, seed=3)
     for a, b in zip(keep, (plain.obs, plain.rew, plain.mean, plain.done)):
         assert torch.equal(a, b)
@@ -244,14 +244,14 @@ def test_step_closed_in_the_next_launch_is_bitwise_the_two_launch_sequence(env, 
     dr = Hh.draws(np.random.RandomState(8), K, B, T, dm.ns, dm.na, len(pool))
     dr32 = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in dr.items()}
     merged = eng.rollout(B, T, H, sam_mode, pool, **dr32)
-    eng.set_option('METRPO_NO_STEP_MERGE', '1')
+    eng.set_option('METRPO_STEP_MERGE', '0')
     two = eng.rollout(B, T, H, sam_mode, pool, **dr32)
     for name in ('obs', 'act', 'rew', 'mean', 'done', 'tpath', 'last_obs'):
         assert torch.equal(getattr(merged, name), getattr(two, name)), name
     # and with the library's own draws (Philox): same streams in both forms
-    eng.set_option('METRPO_NO_STEP_MERGE', None)
+    eng.set_option('METRPO_STEP_MERGE', '1')
     m2 = eng.rollout(B, T, H, sam_mode, pool, seed=5)
-    eng.set_option('METRPO_NO_STEP_MERGE', '1')
+    eng.set_option('METRPO_STEP_MERGE', '0')
     t2 = eng.rollout(B, T, H, sam_mode, pool, seed=5)
     for name in ('obs', 'act', 'rew', 'mean', 'done', 'tpath', 'last_obs'):
         assert torch.equal(getattr(m2, name), getattr(t2, name)), name
@@ -266,7 +266,7 @@ def test_streamk_xcd_teams_are_bitwise_the_consecutive_ranges():
     team = eng.rollout(B, T, H, 'step_rand', pool, seed=3)
     assert eng.last_rollout_kernel() == 'gemm-streamk'
     keep = [x.clone() for x in (team.obs, team.rew, team.mean, team.done)]
-    eng.set_option('STREAMK_NO_TEAM', '1')
+    eng.set_option('STREAMK_PLACE', 'xcd')
     plain = eng.rollout(B, T, H, 'step_rand', pool, seed=3)
     for a, b in zip(keep, (plain.obs, plain.rew, plain.mean, plain.done)):
         assert torch.equal(a, b)

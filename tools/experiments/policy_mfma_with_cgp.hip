@@ -39,6 +39,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // gradient kernel keeps 7 : 6, 71.5 vs 72.0).
 #define POL_SPLIT_R_FVP 7
 #endif
+#ifndef POL_DEFER_S7
+// 1: the sample-contracted weight-gradient products of a tile (S7: 24 matrix instructions at 2 x 32, na <= 2) are issued ONE TILE LATER, in four groups placed
+// inside the next tile's vector-ALU stretch (output layer, tanh' factors, deltas: ~95 instructions with no matrix instruction of their own) -- their operands
+// wait in 28 registers.  Same products in the same order: the same sums bit for bit.
+#define POL_DEFER_S7 0      // measured (round 5): Fisher-vector product 59.8 -> 60.5 us at C1 -- the stretch is already covered by the SIMD's other wave; off
+#endif
 #ifndef NWAVES
 #define NWAVES 8                // waves per block: one block per CU (2 waves per SIMD), the weight image is shared by all 8
 #endif
@@ -52,6 +58,15 @@ __device__ unsigned long long g_pol_phase[16][8];
 extern "C" int32_t metrpo_debug_pol_phases(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pol_phase), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -1; }
 #else
 #define PT_MARK(i)
+#endif
+// CGP_TIMING (developer build: SRC=policy_mfma.hip tools/build_variant.sh cgptiming -DCGP_TIMING; tools/cgp_phases.py): s_memrealtime (100 MHz) of thread 0 of
+// workgroups 0 and gridDim-1 at the phase boundaries of every iteration of the persistent CG solve
+#ifdef CGP_TIMING
+__device__ unsigned long long g_cgp_phase[2][16][8];
+#define CT_MARK(i) { if (tid == 0 && it < 16 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) g_cgp_phase[blockIdx.x == 0 ? 0 : 1][it][i] = __builtin_amdgcn_s_memrealtime(); }
+extern "C" int32_t metrpo_debug_cgp_phases(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cgp_phase), sizeof(unsigned long long) * 256) == hipSuccess ? 0 : -1; }
+#else
+#define CT_MARK(i)
 #endif
 
 
@@ -81,9 +96,18 @@ __device__ __forceinline__ float xsum_c(float v) {
     return v;
 }
 
-enum { MODE_GRAD = 0, MODE_FVP = 1, MODE_LOSSKL = 2, MODE_FVPC = 3 };
-// (Measured and parked, tools/experiments/policy_mfma_with_cgp.hip + profiles/r05_update_levers.txt: issue priorities per SIMD wave pair (POL_PRIO), h0 recomputed instead of
-// cached (POL_H0R, +4.8 us per product), weight-gradient products deferred into the next tile's vector stretch (POL_DEFER_S7, 60.5 vs 59.8 us), the CG solve as one launch.)
+enum { MODE_GRAD = 0, MODE_FVP = 1, MODE_LOSSKL = 2, MODE_FVPC = 3, MODE_CGP = 4 };
+// POL_PRIO (experiment, round 4): issue priorities of the two waves of a SIMD.  1: the younger wave of every SIMD (waves 4 .. 7) runs at priority 1 for the whole
+// kernel; 2: a wave raises its priority for the vector-ALU stretch of a tile (S4 / S5: output layer, tanh' factors, deltas) and drops it for the matrix runs.
+#ifndef POL_PRIO
+#define POL_PRIO 0
+#endif
+// POL_H0R = 1 (experiment, round 4): MODE_FVPC reads only h1 from the cache and recomputes h0 (one layer: NS_KS x HB MFMAs + 4 HB tanh per lane): -128 of
+// 302 B per sample from HBM, +8 % MFMAs.  Measured SLOWER at C1 (tools/variant_update.py h0r, twice: update 0.846 vs 0.798 ms = +4.8 us per
+// product): the product is bound by its dependent issue chain, not by HBM; the extra layer + tanh at the head of every tile's chain costs more than the bytes.
+#ifndef POL_H0R
+#define POL_H0R 0
+#endif
 // MODE_FVPC: Fisher-vector product with the hidden activations h0, h1 = tanh(.) read from the cache the gradient kernel of the
 // same (theta, batch) wrote (PolK::hcache) instead of being recomputed: all 10 products of a CG solve share theta and the
 // observations, so the forward pass (22 of the 100 MFMAs of a tile and all 16 tanh per lane) is done once per update, not 11 times.
@@ -101,11 +125,40 @@ struct PolImg {
                          O_V2F = O_W2F + KK * 64, TOTAL = O_V2F + KK * 64;
 };
 
+// MODE_CGP: ALL Fisher-vector products of a CG solve and the vector steps between them in ONE launch (one block per CU, all co-resident).  Per
+// iteration: the cached-activation product exactly as MODE_FVPC runs it (same tile deal, same partial rows) -> grid barrier -> the float64 column
+// sums in k_finalize's order, spread over the blocks -> the last block to arrive runs the krylov.cg step (cg_device.h: cgv_step_body, bit for bit the
+// fused tail's) and releases the others, which then copy the new tangent tables.  What a launch-per-product solve spends on ten kernel starts /
+// drains, ten reductions' launches and their tails' ticket waits stays inside: see DESIGN.md section 4d.
+constexpr int CGP_RMAX = 3;         // MODE_CGP: P <= 3 * 1024 (Ant's 2 x 32 policy: 2 288)
+struct CgpArgs {
+    CgTail tail;                    // op 1 fields: x r p z step scal gout pf vpos imgval, P, reg, tol, max_kl, implicit_hd
+    int n_it, n_params;
+    unsigned int* bar;              // [0] arrivals behind the products, [1] arrivals behind the column sums, [2] CG steps released; zero at launch
+    const float* theta_ls;          // raw log_std parameters (theta + n_params)
+    float* partials;                // the launch's partial rows (no __restrict__: read across workgroups)
+    unsigned long long timeout;     // s_memrealtime ticks (100 MHz) a block waits at a barrier before it gives up (scal[S_COMMERR] = 2)
+};
+#define LDA(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+__device__ __forceinline__ bool cgp_wait(const unsigned int* ctr, unsigned int target, unsigned long long timeout) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(2);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > timeout) return false;
+    }
+    return true;
+}
 
 template <int NS, int NA, int PH, int MODE_>
-__device__ __forceinline__ void pol_body(const PolK& k, const float* __restrict__ theta, const float* __restrict__ v, float* __restrict__ partials) {
+__device__ __forceinline__ void pol_body(const PolK& k, const float* __restrict__ theta, const float* __restrict__ v_in, float* __restrict__ partials_in,
+                                         const CgpArgs* cgp) {
+    // MODE_CGP: the tangent vector and the other blocks' partial rows CHANGE during the launch (written by other workgroups between the grid barriers):
+    // no __restrict__ on these two, or their loads may legally be hoisted out of the iteration loop
+    const float* v = v_in; float* partials = partials_in;
+    if constexpr (MODE_ == MODE_CGP) { v = cgp->tail.pf; partials = cgp->partials; }
     using I = PolImg<NS, NA, PH>;
-    constexpr bool CACHED = (MODE_ == MODE_FVPC);
+    constexpr bool PERSIST = (MODE_ == MODE_CGP);
+    constexpr bool CACHED = (MODE_ == MODE_FVPC || PERSIST);
     constexpr int MODE = CACHED ? MODE_FVP : MODE_;
     constexpr int NS_KS = I::NS_KS, NSI = cdiv_(NS, 16), HB = I::HB, KK = I::KK;
     constexpr int pW0 = 0, pb0 = NS * PH, pW1 = pb0 + PH, pb1 = pW1 + PH * PH, pW2 = pb1 + PH, pb2 = pW2 + PH * NA,
@@ -119,6 +172,8 @@ __device__ __forceinline__ void pol_body(const PolK& k, const float* __restrict_
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index in an SGPR: tile indices and base pointers stay scalar
     const int c = lane & 15, q = lane >> 4;
+    if (POL_PRIO == 1 && wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(1);
+    if (POL_PRIO == 3 && wave < NWAVES / 2) __builtin_amdgcn_s_setprio(1);
     if (MODE_ == MODE_LOSSKL && k.skip != nullptr && k.skip[0] >= 0.0) return;      // speculative line-search trial after the search stopped
     float* IMG = lds;
     float* TL = lds + I::TOTAL + wave * WTL;
@@ -173,7 +228,7 @@ __device__ __forceinline__ void pol_body(const PolK& k, const float* __restrict_
         if (CACHED) {
             const f32x4* __restrict__ hb_ = hc + tile * (2 * HB) * 64;
 #pragma unroll
-            for (int j = 0; j < 2 * HB; ++j) in.h[j] = hb_[j * 64 + lane];
+            for (int j = (POL_H0R ? HB : 0); j < 2 * HB; ++j) in.h[j] = hb_[j * 64 + lane];
         }
     };
     auto mask_tile = [&](TileIn& in) {
@@ -217,6 +272,9 @@ __device__ __forceinline__ void pol_body(const PolK& k, const float* __restrict_
         for (int r = 0; r < 4; ++r)
             if (4 * q + r < NA) { ols_c[r] = k.old_ls[4 * q + r]; eo_c[r] = expf(-ols_c[r]); os2_c[r] = expf(2.f * ols_c[r]); }
     }
+    const int n_it = PERSIST ? cgp->n_it : 1;
+    for (int it = 0; it < n_it; ++it) {                     // PERSIST: one pass per CG iteration; everything that depends on the tangent vector is (re)loaded inside
+    if constexpr (PERSIST) { CT_MARK(0) }
     f32x4 vb0f[HB], vb1f[HB], vb2f;
     if (MODE == MODE_FVP) {
 #pragma unroll
@@ -281,7 +339,7 @@ __device__ __forceinline__ void pol_body(const PolK& k, const float* __restrict_
                 bool use = m[u] >= 0;
                 if (MODE != MODE_FVP && (m[u] & 0x40000000)) use = false;                       // tangent tables: FVP only
                 if (MODE == MODE_LOSSKL && i >= I::O_W2B && i < I::O_W2F) use = false;          // back-prop tables unused
-                if (CACHED && i < I::O_W1F) use = false;                            // W0 forward table unused
+                if (CACHED && !POL_H0R && i < I::O_W1F) use = false;                            // W0 forward table unused
                 w[u] = 0.f;
                 if (use) w[u] = (m[u] & 0x40000000) ? v[m[u] & 0x3FFFFFFF] : theta[m[u]];
             }
@@ -293,6 +351,7 @@ __device__ __forceinline__ void pol_body(const PolK& k, const float* __restrict_
         }
     }
     __syncthreads();
+    if constexpr (PERSIST) { CT_MARK(1) }
     if (MODE_ == MODE_GRAD && k.imgval != nullptr && blockIdx.x == 0) {      // publish the image of this theta for the CG products that follow (tangent entries: zero here, the CG tails fill them)
         for (int i = tid; i < I::TOTAL; i += NWAVES * 64) k.imgval[i] = IMG[i];
     }
@@ -312,6 +371,28 @@ __device__ __forceinline__ void pol_body(const PolK& k, const float* __restrict_
     float dls[4] = {0.f, 0.f, 0.f, 0.f};
     float acc0 = 0.f, acc1 = 0.f, accw = 0.f;               // loss, kl, valid weight (per-lane partials)
 
+    constexpr bool DEFER = POL_DEFER_S7 && (NA <= 2) && MODE != MODE_LOSSKL;
+    f32x4 qa0[HB], qb1[HB], qd0[HB]; float qxT[4][NSI];     // DEFER: S7 operands of the previous tile (zeros in front of the first: its run adds nothing)
+#pragma unroll
+    for (int cb = 0; cb < HB; ++cb) { qa0[cb] = Z4; qb1[cb] = Z4; qd0[cb] = Z4; }
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+        for (int ci = 0; ci < NSI; ++ci) qxT[s_][ci] = 0.f;
+    auto s7_step = [&](auto sc) {                           // k-step s of the pending tile's products (samples 4q + s)
+        constexpr int s_ = decltype(sc)::value;
+        if constexpr (DEFER) {
+#pragma unroll
+            for (int ci = 0; ci < HB; ++ci)
+#pragma unroll
+                for (int cj = 0; cj < HB; ++cj) gW1[ci][cj] = MFMA16(qa0[ci][s_], qb1[cj][s_], gW1[ci][cj]);
+#pragma unroll
+            for (int ci = 0; ci < NSI; ++ci)
+#pragma unroll
+                for (int cj = 0; cj < HB; ++cj) gW0[ci][cj] = MFMA16(qxT[s_][ci], qd0[cj][s_], gW0[ci][cj]);
+        }
+    };
+#define S7_STEP(n) s7_step(std::integral_constant<int, (n)>{})
     // vmcnt(0) HERE: otherwise the wait for these first loads is placed inside the loop, at the top of every iteration, right
     // behind the prefetch of the next tile -- which it then waits for as well
     __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -324,6 +405,7 @@ __device__ __forceinline__ void pol_body(const PolK& k, const float* __restrict_
     for (long long m = (SPL && wave >= 4) ? 1 : 0, tile = sp_base + m * sp_stride; tile < ntiles; m = sp_next(m), tile = sp_base + m * sp_stride) {
         const long long n0 = tile * 16, n = n0 + c;
         const bool inr = n < k.N;
+        if (POL_PRIO == 2) __builtin_amdgcn_s_setprio(0);
         TileIn in = nxt;
         fetch(sp_base + sp_next(m) * sp_stride, nxt);
         asm volatile("" ::: "memory");                      // the loads are issued HERE (left alone, the compiler sinks them to the end of the iteration)
@@ -338,7 +420,7 @@ __device__ __forceinline__ void pol_body(const PolK& k, const float* __restrict_
         float* T_H0 = TL, *T_H1 = TL + HB * TILE, *T_D1 = TL + 2 * HB * TILE, *T_UM = TL + 3 * HB * TILE;
         // ---- S1: layer 0, forward and (FVP) tangent  ------------------------------------------------------
         f32x4 h0[HB], h1[HB], t0[HB], t1[HB];
-        constexpr bool H0C = CACHED;            // h0 comes from the cache
+        constexpr bool H0C = CACHED && !POL_H0R;            // h0 comes from the cache
         if (CACHED) {
 #pragma unroll
             for (int cb = 0; cb < HB; ++cb) { if (H0C) h0[cb] = in.h[cb]; h1[cb] = in.h[HB + cb]; }
@@ -404,6 +486,8 @@ __device__ __forceinline__ void pol_body(const PolK& k, const float* __restrict_
             for (int cb = 0; cb < HB; ++cb) { hw[cb * 64] = h0[cb]; hw[(HB + cb) * 64] = h1[cb]; }
         }
 
+        S7_STEP(0);
+        if (POL_PRIO == 2) __builtin_amdgcn_s_setprio(2);
         f32x4 um = Z4;                                      // d(objective)/d(mean) in D layout [d = 4q+r][sample c]
         float ual[NAV];                                     // FVP with the VALU output layer: the sample's mean-adjoint, already in all of its lanes
 #pragma unroll
@@ -514,6 +598,7 @@ __device__ __forceinline__ void pol_body(const PolK& k, const float* __restrict_
                 um[r] = (ok && 4 * q + r < NA) ? (m0[r] + m1[r]) * fisher_w[r] * k.inv_n : 0.f;
             if (ok && q == 0) accw += k.inv_n;
         }
+        S7_STEP(1);
         // ---- S5/S6: back-prop (transposed chain); deltas go straight into their transpose tiles ---------------------
         f32x4 d1[HB], d0n[HB];                              // d0n: layer-0 deltas in the OTHER orientation, [sample 4q+r][unit c] (see S6)
 #pragma unroll
@@ -547,12 +632,15 @@ __device__ __forceinline__ void pol_body(const PolK& k, const float* __restrict_
                 for (int cb = 0; cb < HB; ++cb) d1[cb] = MFMA16(FRAG2(I::O_W2B, r, cb), um[r], d1[cb]);
             }
         }
+        S7_STEP(2);
 #pragma unroll
         for (int cb = 0; cb < HB; ++cb) {
             d0n[cb] = Z4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { d1[cb][r] *= fmaf(-h1[cb][r], h1[cb][r], 1.f); T_D1[cb * TILE + (4 * q + r) * TS + wpos] = d1[cb][r]; }
         }
+        S7_STEP(3);
+        if (POL_PRIO == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
@@ -579,8 +667,16 @@ __device__ __forceinline__ void pol_body(const PolK& k, const float* __restrict_
             gb0[cb] += d0n[cb];
         }
         if (!L2V) buv = *(const f32x4*)&T_UM[c * TS + 4 * q];
+        if constexpr (DEFER) {                              // this tile's products run inside the next tile (or behind the loop)
 #pragma unroll
-        for (int s = 0; s < ((POL_SKIP & 2) ? 0 : 4); ++s) {
+            for (int cb = 0; cb < HB; ++cb) { qa0[cb] = a0v[cb]; qb1[cb] = b1v[cb]; qd0[cb] = d0n[cb]; }
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                for (int ci = 0; ci < NSI; ++ci) qxT[s_][ci] = xTs[s_][ci];
+        }
+#pragma unroll
+        for (int s = 0; s < ((DEFER || (POL_SKIP & 2)) ? 0 : 4); ++s) {
             const float bu = buv[s];
             float a1_[HB], a0_[HB], b1_[HB], b0_[HB], xT[NSI];
 #pragma unroll
@@ -603,6 +699,8 @@ __device__ __forceinline__ void pol_body(const PolK& k, const float* __restrict_
         }
         wave_sync_lds();
     }
+    S7_STEP(0); S7_STEP(1); S7_STEP(2); S7_STEP(3);       // the last tile's products
+#undef S7_STEP
 #undef FRAG2
 #undef FRAG1
 
@@ -671,15 +769,126 @@ __device__ __forceinline__ void pol_body(const PolK& k, const float* __restrict_
         float a = 0.f;
 #pragma unroll
         for (int w = 0; w < NWAVES; w += 4) a += (RB[w * ROW + i] + RB[(w + 1) * ROW + i]) + (RB[(w + 2) * ROW + i] + RB[(w + 3) * ROW + i]);
-        out[i] = a;
+        if constexpr (PERSIST) __hip_atomic_store(out + i, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through (sc1): summed by other workgroups, behind other L2s
+        else out[i] = a;
     }
     PT_MARK(6)
+    if constexpr (PERSIST) {
+        CT_MARK(2)
+        const CgpArgs& A = *cgp;
+        const unsigned int nblk = gridDim.x;
+        __shared__ unsigned int s_flag;
+        // ---- barrier: every block's partial row is in memory
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // Data that crosses workgroups inside the launch travels by agent-scope (sc1) stores and loads -- write-through, and never served from a line another
+        // XCD's L2 still holds -- so the barriers carry no cache-wide release / acquire (256 workgroups x 3 of those per iteration cost more than the products:
+        // measured 122 vs 66 us per iteration at C1).  The exception is the closing workgroup's CG step (plain stores: ONE release) and what every workgroup
+        // reads of it afterwards (tangent tables, float copy of p: ONE acquire per workgroup and iteration, issued by one wave).
+        if (tid == 0) {
+            __hip_atomic_fetch_add(A.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_flag = cgp_wait(A.bar, (unsigned int)(it + 1) * nblk, A.timeout) ? 1u : 0u;
+        }
+        __syncthreads();
+        if (!s_flag) { if (tid == 0) A.tail.scal[S_COMMERR] = 2.0; return; }
+        CT_MARK(3)
+        // ---- column sums, float64, k_finalize's order (slice s adds rows s, s + 32, ..; the slice sums are added in slice order); 16 columns per block
+        {
+            constexpr int NSL = 32, FC = NWAVES * 64 / NSL;
+            double* shd = (double*)lds;                     // [FC][NSL + 1]
+            const int Pn = A.tail.P, sl = tid & 31;
+            for (int o0 = (int)blockIdx.x * FC; o0 < Pn; o0 += (int)nblk * FC) {      // (block-uniform trip count: barriers inside)
+            const int o = o0 + (tid >> 5);
+            const bool lsrow = (o >= A.n_params && o < Pn);
+            const int col = lsrow ? Pn + 2 : o;
+            const int nrows = (int)nblk;
+            double a = 0.0;
+            if (o < Pn) {
+                int b = sl;
+                for (; b + 3 * NSL < nrows; b += 4 * NSL) {
+                    const float v0 = LDA(partials + (size_t)b * ROW + col), v1 = LDA(partials + (size_t)(b + NSL) * ROW + col);
+                    const float v2 = LDA(partials + (size_t)(b + 2 * NSL) * ROW + col), v3 = LDA(partials + (size_t)(b + 3 * NSL) * ROW + col);
+                    a += (double)v0; a += (double)v1; a += (double)v2; a += (double)v3;
+                }
+                for (; b < nrows; b += NSL) a += (double)LDA(partials + (size_t)b * ROW + col);
+            }
+            shd[(tid >> 5) * (NSL + 1) + sl] = a;
+            __syncthreads();
+            if (sl == 0 && o < Pn) {
+                double t = 0.0;
+                for (int w = 0; w < NSL; ++w) t += shd[(tid >> 5) * (NSL + 1) + w];
+                if (lsrow) {
+                    const double raw = (double)A.theta_ls[o - A.n_params];
+                    const double s2 = exp(2.0 * fmax(raw, (double)LOG_MIN_STD));
+                    const double cc = 4.0 * s2 * (2.0 * s2 - 1e-8) / ((2.0 * s2 + 1e-8) * (2.0 * s2 + 1e-8));
+                    t = (raw > (double)LOG_MIN_STD) ? cc * LDA(A.tail.p + o) * t : 0.0;
+                }
+                __hip_atomic_store(A.tail.z + o, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            }
+        }
+        CT_MARK(4)
+        // ---- second barrier; the last block to arrive owns the complete product and runs the CG step, the others wait for its release
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned int tk = __hip_atomic_fetch_add(A.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_flag = (tk == (unsigned int)(it + 1) * nblk - 1u) ? 1u : 0u;
+        }
+        __syncthreads();
+        const bool closes = (s_flag != 0u);
+        CT_MARK(5)
+        __syncthreads();                                    // s_flag is written again below
+        if (closes) {
+            if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // z (sc1 stores of this iteration) and the previous closer's vectors, whatever this L2 held of them
+            __syncthreads();
+            double* cgsh = (double*)lds;
+            const int last = (it == n_it - 1) ? 1 : 0;
+            if (A.tail.P <= CG_R * 1024)
+                cgv_step_body<1024 / (NWAVES * 64), CG_R>(A.tail.P, A.tail.reg, A.tail.tol, last, A.tail.x, A.tail.r, A.tail.p, A.tail.z,
+                                                          PfOut{A.tail.pf, A.tail.vpos, A.tail.imgval}, A.tail.scal, cgsh);
+            else
+                cgv_step_body<1024 / (NWAVES * 64), CGP_RMAX>(A.tail.P, A.tail.reg, A.tail.tol, last, A.tail.x, A.tail.r, A.tail.p, A.tail.z,
+                                                             PfOut{A.tail.pf, A.tail.vpos, A.tail.imgval}, A.tail.scal, cgsh);
+            if (last && A.tail.implicit_hd) {
+                __syncthreads();
+                cgv_finish_implicit<1024 / (NWAVES * 64)>(A.tail.P, A.tail.max_kl, A.tail.x, A.tail.r, A.tail.gout + 1, A.tail.step, A.tail.scal, cgsh);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (last) {                                 // nobody reads the counters any more: leave them at zero for the next solve
+                    __hip_atomic_store(A.bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(A.bar + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(A.bar + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else __hip_atomic_store(A.bar + 2, (unsigned int)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (it + 1 < n_it) {
+            if (tid == 0) s_flag = cgp_wait(A.bar + 2, (unsigned int)(it + 1), A.timeout) ? 2u : 3u;
+            __syncthreads();
+            if (s_flag == 3u) { if (tid == 0) A.tail.scal[S_COMMERR] = 2.0; return; }
+        }
+        __syncthreads();
+        CT_MARK(6)
+        if (it + 1 < n_it) {
+            if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // the closer's tangent tables / float copy of p
+            __syncthreads();
+        }
+        CT_MARK(7)
+    }
+    }                                                       // iterations
 }
 
 template <int NS, int NA, int PH, int MODE_>
 __global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_mfma(PolK k, const float* __restrict__ theta, const float* __restrict__ v,
                                                         float* __restrict__ partials) {
-    pol_body<NS, NA, PH, MODE_>(k, theta, v, partials);
+    pol_body<NS, NA, PH, MODE_>(k, theta, v, partials, nullptr);
+}
+template <int NS, int NA, int PH>
+__global__ void __launch_bounds__(NWAVES * 64, 1) k_policy_cgp(PolK k, const float* __restrict__ theta, const float* __restrict__ v,
+                                                       float* __restrict__ partials, CgpArgs cgp) {
+    pol_body<NS, NA, PH, MODE_CGP>(k, theta, v, partials, &cgp);
 }
 
 
@@ -716,7 +925,8 @@ static void pol_image_map(std::vector<int>& map) {
 
 // -------------------------------------------------------------------------------------------------
 typedef void (*pol_kernel_t)(PolK, const float*, const float*, float*);
-struct PolEntry { int ns, na, ph; pol_kernel_t kern[4]; int lds_floats, lds_floats_eval; void (*build_map)(std::vector<int>&); };
+typedef void (*pol_cgp_t)(PolK, const float*, const float*, float*, CgpArgs);
+struct PolEntry { int ns, na, ph; pol_kernel_t kern[4]; pol_cgp_t cgp; int lds_floats, lds_floats_eval; void (*build_map)(std::vector<int>&); };
 template <int NS, int NA, int PH> constexpr int pol_lds() {
     constexpr int HB = cdiv_(PH, 16);
     constexpr int a = PolImg<NS, NA, PH>::TOTAL + NWAVES * (3 * HB + (NA <= 2 ? 0 : 1)) * 16 * 20;      // 20 = TS of the kernel's transpose tiles
@@ -729,7 +939,7 @@ template <int NS, int NA, int PH> constexpr int pol_lds_eval() {       // MODE_L
     constexpr int a = PolImg<NS, NA, PH>::TOTAL, b = NWAVES * (P + PART_EXTRA);
     return a > b ? a : b;
 }
-#define PENTRY(NS, NA, PH) {NS, NA, PH, {k_policy_mfma<NS, NA, PH, 0>, k_policy_mfma<NS, NA, PH, 1>, k_policy_mfma<NS, NA, PH, 2>, k_policy_mfma<NS, NA, PH, 3>}, pol_lds<NS, NA, PH>(), pol_lds_eval<NS, NA, PH>(), pol_image_map<NS, NA, PH>}
+#define PENTRY(NS, NA, PH) {NS, NA, PH, {k_policy_mfma<NS, NA, PH, 0>, k_policy_mfma<NS, NA, PH, 1>, k_policy_mfma<NS, NA, PH, 2>, k_policy_mfma<NS, NA, PH, 3>}, k_policy_cgp<NS, NA, PH>, pol_lds<NS, NA, PH>(), pol_lds_eval<NS, NA, PH>(), pol_image_map<NS, NA, PH>}
 static const PolEntry kPol[] = {
     PENTRY(10, 2, 32),    // swimmer
     PENTRY(18, 6, 32),    // half-cheetah
@@ -806,3 +1016,29 @@ int policy_mfma_launch(metrpo_ctx* c, int idx, int mode, const metrpo_batch* b, 
     return METRPO_OK;
 }
 
+// Whole CG solve in one launch (MODE_CGP): n_it Fisher-vector products on the cached activations + the vector steps between them.  Requires what the
+// fused launch-per-product solve has set up (run_trpo_update: hcache_on, img_live: the gradient kernel of this theta has written the activation cache
+// and published the weight image, its tail the first tangent entries) and a grid the device holds at once.  METRPO_EUNSUPPORTED: take the per-launch path.
+int policy_mfma_cg_persist(metrpo_ctx* c, int idx, const metrpo_batch* b, const float* theta, const CgTail& tl, int n_it, float* partials, int nblocks,
+                           hipStream_t st) {
+    const PolEntry& en = kPol[idx];
+    if (!c->img_live || !c->hcache_on || c->d_hcache == nullptr || c->d_pol_imgval == nullptr || tl.vpos == nullptr) return METRPO_EUNSUPPORTED;
+    if (tl.P > CGP_RMAX * 1024 || n_it < 1 || c->cgp_failed) return METRPO_EUNSUPPORTED;
+    const size_t sh = sizeof(float) * (size_t)en.lds_floats;
+    if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)en.cgp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    if (!grid_is_coresident(c, (const void*)en.cgp, NWAVES * 64, sh, nblocks, st)) return METRPO_EUNSUPPORTED;
+    if (!c->d_cgp_bar) {
+        HIP_TRY(c, ws_alloc(c, (void**)&c->d_cgp_bar, 64));
+        HIP_TRY(c, hipMemsetAsync(c->d_cgp_bar, 0, 64, st));      // the closing block of a solve leaves the counters at zero again
+    }
+    PolK k;
+    k.obs = b->d_obs; k.act = b->d_act; k.adv = b->d_adv; k.old_mean = b->d_old_mean; k.old_ls = b->d_old_log_std;
+    k.ls_stride = b->old_log_std_stride; k.valid = b->d_valid; k.N = b->N; k.inv_n = (float)b->inv_n_global;
+    k.img_map = (const int*)c->d_pol_img; k.gm = nullptr; k.skip = nullptr; k.hcache = c->d_hcache; k.imgval = c->d_pol_imgval;
+    CgpArgs a;
+    a.tail = tl; a.n_it = n_it; a.n_params = c->pd.pol.n_params; a.bar = c->d_cgp_bar; a.theta_ls = theta + c->pd.pol.n_params; a.partials = partials;
+    a.timeout = 200000000ull;                                 // 2 s
+    hipLaunchKernelGGL(en.cgp, dim3(nblocks), dim3(NWAVES * 64), sh, st, k, theta, (const float*)tl.pf, partials, a);
+    HIP_TRY(c, hipGetLastError());
+    return METRPO_OK;
+}

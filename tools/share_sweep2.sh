@@ -1,0 +1,8 @@
+#!/bin/bash
+# crossover of the persistent stream-K rollout against per-step stream-K launches (tiles per step = K x ceil(B / 128) x (hidden / 256) against the CU count)
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+show='import json,sys;d=json.loads(sys.stdin.read().strip().split(chr(10))[-1]);print("%-4s B=%-5s %-28s iter %8.3f ms  rollout %8.3f ms  %-20s frac %.3f" % (sys.argv[1],sys.argv[2],sys.argv[3],d["ms_per_step"],d["rollout"]["ms"],d["rollout"]["kernel"],d["roofline"]["frac"]))'
+for cfg in C2 C3; do for B in ${BS:-1536 1792 2048 2304}; do
+  for v in "" "METRPO_NO_PERSIST=1"; do
+    env $v python bench.py --config $cfg --B $B --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "$show" $cfg $B "${v:-default}"
+  done; done; done
