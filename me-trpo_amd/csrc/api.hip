@@ -341,20 +341,29 @@ extern "C" int32_t metrpo_rollout(metrpo_ctx* c, const metrpo_rollout_args* a, v
         return set_err(c, METRPO_EINVAL, "rollout: d_init_obs, d_init_ts and d_init_model must be given together");
     if (a->B == 0 || a->T == 0) return METRPO_OK;
     c->rollout_note.clear();
-    if (c->mfma_cfg >= 0) {
-        const int rc = launch_rollout_mfma(c, a, (hipStream_t)stream);
+    if (c->mfma_cfg >= 0 || c->coop_cfg >= 0) {
+        int coop = 0;
+        const int rc = launch_rollout_mfma(c, a, (hipStream_t)stream, &coop);
         if (rc != METRPO_EUNSUPPORTED) {
-            c->last_rollout_kernel = (c->coop_cfg >= 0 && c->rollout_variant != 1) ? 2 : 1;
-            if (c->coop_cfg < 0 && c->rollout_variant == 0)
-                note_off_table(c, "the cooperative fused kernel (rollout_coop.hip) is instantiated for K = 1 ... 5 heads, 2 x 64 dynamics, 2 x 32 policy of the six envs; this shape (K = " +
-                                  std::to_string(c->pd.K) + ") runs on the head-per-wave fused kernel (rollout_mfma.hip), ~2.9x the cooperative kernel's time at B = 5000");
+            c->last_rollout_kernel = coop ? 2 : 1;
+            if (!coop && c->rollout_variant == 0)
+                note_off_table(c, c->coop_cfg < 0 ? "the cooperative fused kernel (rollout_coop.hip) holds 2 x 64 dynamics + 2 x 32 policy with K = 1 ... 10 heads (Ant: 8, half-cheetah: 9 -- LDS); this shape (K = " +
+                                  std::to_string(c->pd.K) + ") runs on the head-per-wave fused kernel (rollout_mfma.hip), ~2.5x the cooperative kernel's time per head"
+                                  : "the cooperative fused kernel holds K = " + std::to_string(c->pd.K) + " > 5 heads only with a CU to itself per workgroup; more 16-env tiles than CUs on a device that "
+                                    "is not exclusive (metrpo_set_exclusive / NO_RESIDENT): head-per-wave fused kernel (rollout_mfma.hip)");
             return rc;
         }
+        if (c->coop_cfg >= 0 && c->rollout_variant == 0)
+            note_off_table(c, "the cooperative fused kernel holds K = " + std::to_string(c->pd.K) + " > 8 heads only with a CU to itself per workgroup; more 16-env tiles than CUs on a device that "
+                              "is not exclusive: step-wise tile GEMMs (rollout_gemm.hip), ~8x the fused kernel's time");
     }
     if (gemm_path_applicable(c)) {                                                           // large dynamics nets
         const int rc = launch_rollout_resident(c, a, (hipStream_t)stream);                   // ... at small batch: the whole time loop in one launch
         if (rc != METRPO_EUNSUPPORTED) return rc;
         c->last_rollout_kernel = 3;
+        if (c->coop_cfg < 0 && c->mfma_cfg < 0 && mfma_shape_config(c) >= 0 && c->rollout_variant == 0)
+            note_off_table(c, "K = " + std::to_string(c->pd.K) + " heads of this 2 x 64-class shape are beyond the fused kernels (cooperative: K <= 10, half-cheetah 9, Ant 8 -- "
+                              "LDS; head-per-wave: K <= 8): step-wise tile GEMMs (rollout_gemm.hip), ~3x the fused kernels' time per head (profiles/r06_coop_heads.txt)");
         return launch_rollout_gemm(c, a, (hipStream_t)stream);
     }
     c->last_rollout_kernel = 0;

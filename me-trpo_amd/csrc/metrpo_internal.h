@@ -253,10 +253,11 @@ int launch_policy_vjp(metrpo_ctx*, const float* obs, const float* gm, long long 
 int launch_dyn_train_step(metrpo_ctx*, const float*, const float*, const metrpo_train_params*, double*, hipStream_t);
 int launch_dyn_eval_losses(metrpo_ctx*, const float*, const float*, long long, double, double*, hipStream_t);
 int launch_rms_accumulate(metrpo_ctx*, const float*, long long, int, double*, double*, hipStream_t);
-int launch_rollout_mfma(metrpo_ctx*, const metrpo_rollout_args*, hipStream_t);   // returns METRPO_EUNSUPPORTED if no instantiation fits
+int launch_rollout_mfma(metrpo_ctx*, const metrpo_rollout_args*, hipStream_t, int* coop = nullptr);   // returns METRPO_EUNSUPPORTED if no instantiation fits; *coop = 1: the cooperative kernel ran
 int mfma_prepare_dynamics(metrpo_ctx*, hipStream_t);
 int mfma_prepare_policy(metrpo_ctx*, hipStream_t);
 int mfma_select_config(metrpo_ctx*);
+int mfma_shape_config(const metrpo_ctx*);
 int coop_select_config(metrpo_ctx*);
 int launch_rollout_coop(metrpo_ctx*, int idx, const RolloutK&, hipStream_t);
 int launch_validation_cost(metrpo_ctx*, const float*, int, int, double, double*, hipStream_t);

@@ -373,9 +373,10 @@ static const MfmaEntry kTable[] = {
     ENTRY(METRPO_ENV_SWIMMER, 32, 32),
 };
 
-int mfma_select_config(metrpo_ctx* c) {
+// index into kTable of the fused kernels' shape class (env dims, hidden widths, activations), whatever K is; -1: none
+int mfma_shape_config(const metrpo_ctx* c) {
     const ProblemDesc& pd = c->pd;
-    if (pd.dyn.n_layers != 3 || pd.pol.n_layers != 3 || pd.K > 8) return -1;
+    if (pd.dyn.n_layers != 3 || pd.pol.n_layers != 3) return -1;
     if (pd.dyn.act[0] != METRPO_ACT_RELU || pd.dyn.act[1] != METRPO_ACT_RELU) return -1;
     if (pd.dyn.dims[1] != pd.dyn.dims[2] || pd.pol.dims[1] != pd.pol.dims[2]) return -1;
     const int n = (int)(sizeof(kTable) / sizeof(kTable[0]));
@@ -395,17 +396,24 @@ int mfma_select_config(metrpo_ctx* c) {
     }
     return -1;
 }
+// the head-per-wave kernel: a wave per head, at most 8 (its workgroup is <= 512 threads)
+int mfma_select_config(metrpo_ctx* c) { return c->pd.K > 8 ? -1 : mfma_shape_config(c); }
 
 // weights are read straight from the flat parameter buffers at kernel start: nothing to prepare
 int mfma_prepare_dynamics(metrpo_ctx*, hipStream_t) { return METRPO_OK; }
 int mfma_prepare_policy(metrpo_ctx*, hipStream_t) { return METRPO_OK; }
 
-int launch_rollout_mfma(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t st) {
+// *coop (out, optional): 1 when the cooperative kernel took the launch
+int launch_rollout_mfma(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t st, int* coop) {
+    if (coop) *coop = 0;
+    RolloutK r = make_rollout_k(a);
+    if (c->coop_cfg >= 0 && c->rollout_variant != 1) {
+        const int rc = launch_rollout_coop(c, c->coop_cfg, r, st);           // METRPO_EUNSUPPORTED: more than 5 heads without a CU of their own per workgroup (below)
+        if (rc != METRPO_EUNSUPPORTED) { if (coop) *coop = 1; return rc; }
+    }
     if (c->mfma_cfg < 0) return METRPO_EUNSUPPORTED;
     const MfmaEntry& en = kTable[c->mfma_cfg];
     const int K = c->pd.K;
-    RolloutK r = make_rollout_k(a);
-    if (c->coop_cfg >= 0 && c->rollout_variant != 1) return launch_rollout_coop(c, c->coop_cfg, r, st);
     size_t sh = sizeof(float) * ((size_t)K * en.w_total + 2 * (size_t)K * 16 * en.nsp);
     const int grid = (a->B + 15) / 16;
     hipLaunchKernelGGL(en.kern, dim3(grid), dim3(K * 64), sh, st, r, K, c->d_dyn, c->d_theta, c->d_norm);

@@ -118,6 +118,43 @@ def test_cooperative_rollout_with_one_to_four_heads(env, sam_mode, K, variant):
     _rollout_parity_teacher_forced(env, sam_mode, False, variant, K)
 
 
+@pytest.mark.parametrize('env,sam_mode,K', [('swimmer', 'step_rand', 10), ('swimmer', 'model_med', 7), ('half_cheetah', 'step_rand', 8), ('hopper', 'model_mean_std', 6),
+                                            ('ant', 'step_rand', 8), ('snake', 'eps_rand', 9), ('ant', 'model_mean', 6), ('half_cheetah', 'model_mean_std', 9), ('hopper', 'step_rand', 10)])
+def test_cooperative_rollout_with_six_to_ten_heads(env, sam_mode, K):
+    """Round 6 (verdict r5 item 6a): K = 6 ... 10 heads at 2 x 64 on the cooperative kernel's one-workgroup-per-CU instantiation (rollout_coop_k<K>.hip; until then the
+    head-per-wave kernel for K <= 8 and step-wise tile GEMMs for 9 / 10).  The same teacher-forced comparison against the oracle, selection modes that read all heads included."""
+    _rollout_parity_teacher_forced(env, sam_mode, False, 'coop', K)
+
+
+def test_heads_beyond_the_cooperative_kernels_lds_say_so():
+    """Ant holds 8 heads in a CU's LDS, half-cheetah 9: one more lands on the step-wise tile GEMMs and metrpo_rollout_note names the table."""
+    for env, K in (('ant', 9), ('half_cheetah', 10)):
+        eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (64, 64), (32, 32), seed=9)
+        eng.rollout(64, 3, 3, 'step_rand', pool, seed=1)
+        assert eng.last_rollout_kernel() == 'gemm-stepwise' and 'beyond the fused kernels' in eng.rollout_note(), (eng.last_rollout_kernel(), eng.rollout_note())
+
+
+def test_cooperative_rollout_more_than_five_heads_needs_a_cu_per_workgroup():
+    """K > 5 exists only as one workgroup per CU.  More tiles than CUs: the migrating schedule on an exclusive device (bitwise the trajectories of a launch that has a
+    CU per tile ... the same draws, tile by tile); on a shared device the dispatcher leaves the kernel (head-per-wave for K <= 8) and says so."""
+    env, K, T, H = 'swimmer', 7, 6, 4
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (64, 64), (32, 32), seed=9)
+    n_cu = torch.cuda.get_device_properties(eng.device).multi_processor_count
+    B = 16 * (n_cu + 9)
+    pool_t = torch.tensor(pool, dtype=torch.float32, device=eng.device)
+    a = eng.rollout(B, T, H, 'step_rand', pool_t, seed=4)
+    assert eng.last_rollout_kernel() == 'mfma-cooperative' and eng.rollout_note() == ''
+    keep = [x.clone() for x in (a.obs, a.act, a.rew, a.done)]
+    # the first n_cu tiles alone (a CU per tile, no migration): Philox streams are per env index -> the same rows
+    b = eng.rollout(16 * n_cu, T, H, 'step_rand', pool_t, seed=4)
+    for x, y in zip(keep, (b.obs, b.act, b.rew, b.done)):
+        assert torch.equal(x[:, :16 * n_cu], y)
+    eng.set_exclusive(False)
+    c = eng.rollout(B, T, H, 'step_rand', pool_t, seed=4)
+    assert eng.last_rollout_kernel() == 'mfma-head-per-wave' and 'CU to itself' in eng.rollout_note()
+    np.testing.assert_allclose(cpu(c.obs), cpu(keep[0]), **TOL.CROSS_KERNEL)
+
+
 def _rollout_parity_teacher_forced(env, sam_mode, determ, variant, K):
     B, T, H = 200, 12, 5
     eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (64, 64), (32, 32), seed=7)
