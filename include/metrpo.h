@@ -16,6 +16,10 @@
  *    without synchronising unless documented.  One ctx per GPU, one host thread per ctx, and the
  *    calls of a ctx on ONE stream at a time (they share ctx-owned workspaces: work of the same ctx
  *    enqueued on two streams is not ordered against itself).
+ *  - no launch entry point frees device memory or synchronises the device: a ctx-owned workspace
+ *    that has to grow (a B / N larger than any call before) is allocated with hipMalloc and the
+ *    outgrown buffer is kept until metrpo_destroy (one synchronising sweep only once 4 GB of
+ *    outgrown buffers have piled up in a context that keeps growing its shapes).
  *  - all functions return 0 (METRPO_OK) or a negative metrpo_status; no exception or abort
  *    crosses the ABI; metrpo_last_error() gives the message for the last failure on a ctx.
  *  - arithmetic is float32 on device (TF graph dtype of the reference); CG vectors, reductions
