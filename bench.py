@@ -405,7 +405,24 @@ def main():
                              "note": "config B = %d over %d rank(s) is the weak-scaling share: the timed region above IS the strong-scaling point" % (cfg['B'], comm.world)}
         elif B_s < 16:
             out["strong"] = {"ms_per_step": None, "value": None, "unit": "env-steps/s", "B_per_gpu": B_s, "note": "fewer than one 16-env tile per rank: not run"}
+        elif B_s * H * max(ns, 1) >= 2 ** 31:                   # [T, B, ns] tensors of more than 2^31 elements (C4's whole batch on ONE GPU: 2.75e9) are beyond what any parity test has exercised
+            out["strong"] = {"ms_per_step": None, "value": None, "unit": "env-steps/s", "B_per_gpu": B_s,
+                             "note": "config B = %d on %d rank(s): %d x %d x %d trajectory elements (> 2^31): a share no parity test covers, not run on one GPU (profiles/r06_scaling_model.json extrapolates it from B = 25 000 / 12 500)" % (cfg['B'], comm.world, H, B_s, ns)}
         else:
+            # The weak-scaling result above must never be lost to the second region: if the strong leg has not finished within a generous multiple of the first
+            # region's time (a hang in a collective cannot be caught as an exception), every rank leaves through the watchdog and rank 0 prints the line without it.
+            import threading
+            limit_s = max(180.0, 6.0 * dt * (args.steps + args.warmup) / max(args.steps, 1) + 120.0)
+
+            def give_up():
+                if comm.rank == 0:
+                    out["strong"] = {"ms_per_step": None, "value": None, "unit": "env-steps/s", "B_per_gpu": B_s,
+                                     "note": "strong-scaling region did not finish within %.0f s: abandoned, the line carries the weak-scaling region only" % limit_s}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+            watchdog = threading.Timer(limit_s, give_up)
+            watchdog.daemon = True
+            watchdog.start()
             try:
                 if transport == 'one-shot':
                     eng.comm_ipc_detach()
@@ -446,6 +463,7 @@ def main():
                                          "weak-scaling region, %d envs per rank)" % (cfg['B'], comm.world, B)}
             except Exception as e:                              # the second region must not cost the run its line
                 out["strong"] = {"ms_per_step": None, "value": None, "unit": "env-steps/s", "B_per_gpu": B_s, "note": "strong-scaling region failed: %r" % (e,)}
+            watchdog.cancel()
     if comm.rank == 0 and comm.world == 1 and not args.no_cpu_baseline:
         try:
             # bounded sample: ~10-30 s of 1-thread CPU work (about 0.4 TFLOP of dynamics forwards), same per-step structure

@@ -33,7 +33,7 @@ E_STEP_US = 1.0        # assumed growth per doubling of N (not measurable on one
 # (steps, warmup) per config: iterations of tens of ms and more need few
 RUNS = {'C1': (40, 10), 'C2': (4, 1), 'C3': (4, 1), 'C4': (2, 1)}
 # largest share timed per config (beyond it: linear extrapolation from the two largest timed shares, flagged).  C4: [T, B, ns] float32 trajectories of
-# B = 50 000 are 2.75e9 elements -- past the int32 element indices of the trajectory kernels; a rank never sees more than B / N
+# B = 50 000 are 2.75e9 elements -- beyond anything the parity tests exercise (their largest share: 6 250); a rank of the quoted 8-GPU job never sees more than B / 8
 MAX_B = {'C4': 25000}
 
 
