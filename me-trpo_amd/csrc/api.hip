@@ -364,6 +364,13 @@ extern "C" int32_t metrpo_rollout(metrpo_ctx* c, const metrpo_rollout_args* a, v
         if (c->coop_cfg < 0 && c->mfma_cfg < 0 && mfma_shape_config(c) >= 0 && c->rollout_variant == 0)
             note_off_table(c, "K = " + std::to_string(c->pd.K) + " heads of this 2 x 64-class shape are beyond the fused kernels (cooperative: K <= 10, half-cheetah 9, Ant 8 -- "
                               "LDS; head-per-wave: K <= 8): step-wise tile GEMMs (rollout_gemm.hip), ~3x the fused kernels' time per head (profiles/r06_coop_heads.txt)");
+        {
+            bool m256 = true; std::string w;
+            for (int l = 1; l < c->pd.dyn.n_layers; ++l) { m256 = m256 && (c->pd.dyn.dims[l] % 256 == 0); w += (l > 1 ? "x" : "") + std::to_string(c->pd.dyn.dims[l]); }
+            if (!m256 && c->rollout_note.empty() && c->rollout_variant == 0)
+                note_off_table(c, "dynamics hidden widths " + w + " are neither the fused kernels' 64x64 nor multiples of 256 (stream-K / persistent / resident kernels): step-wise tile "
+                                  "GEMMs (rollout_gemm.hip), 3-4 launches per step -- at B = 5000 hidden 96 takes 3.8 ms where 64 takes 0.43 (INTEGRATION.md section 9)");
+        }
         return launch_rollout_gemm(c, a, (hipStream_t)stream);
     }
     c->last_rollout_kernel = 0;
