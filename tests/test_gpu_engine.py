@@ -126,6 +126,36 @@ def test_cooperative_rollout_with_six_to_ten_heads(env, sam_mode, K):
     _rollout_parity_teacher_forced(env, sam_mode, False, 'coop', K)
 
 
+def test_cooperative_launch_rule_does_not_pick_the_slow_form():
+    """The launch rule of rollout_coop.hip chooses between one workgroup per CU (tiles migrate) and two co-resident workgroups from constants MEASURED at K = 5
+    (1.50 / 1.58 / 1.65 per pair-step).  If the kernel changes and the constants do not, the rule goes silently wrong -- so its pick is timed against the forced
+    two-per-CU form here (K = 5 and K = 3, below and above two tiles per CU): never more than 15 % behind it (profiles/r05_e_coop_heads.txt: within 4 %)."""
+    import metrpo_amd
+    from metrpo_amd import synthetic
+    for K, B in ((5, 5000), (5, 8192), (3, 5000)):
+        ms = {}
+        for var in (0, 2):
+            eng = metrpo_amd.Engine('swimmer', K, (64, 64), (32, 32))
+            Ws, bs, norm = synthetic.make_dynamics('swimmer', K, (64, 64), seed=0)
+            eng.set_dynamics_layers(Ws, bs, norm['in_mean'], norm['in_std'], norm['diff_mean'], norm['diff_std'])
+            eng.set_policy(metrpo_amd.xavier_policy_theta(eng.ns, (32, 32), eng.na))
+            eng.set_rollout_variant(var)
+            pool = torch.as_tensor(synthetic.make_pool('swimmer'), device='cuda')
+            out = eng.alloc_trajectory(B, 100, 100)
+            for i in range(3):
+                eng.rollout(B, 100, 100, 'step_rand', pool, seed=i, out=out)
+            best = 1e9
+            for rep in range(3):                                   # best of three 10-launch means: a timing assertion must not trip over a noisy neighbour
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for i in range(10):
+                    eng.rollout(B, 100, 100, 'step_rand', pool, seed=10 + i, out=out)
+                e1.record(); torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1) / 10)
+            ms[var] = best
+        assert ms[0] <= 1.15 * ms[2], (K, B, ms)
+
+
 def test_heads_beyond_the_cooperative_kernels_lds_say_so():
     """Ant holds 8 heads in a CU's LDS, half-cheetah 9: one more lands on the step-wise tile GEMMs and metrpo_rollout_note names the table."""
     for env, K in (('ant', 9), ('half_cheetah', 10)):
