@@ -195,8 +195,9 @@ typedef struct {
 } metrpo_rollout_args;
 int32_t metrpo_rollout(metrpo_ctx* ctx, const metrpo_rollout_args* args, void* stream);
 /* Which kernel family the last metrpo_rollout of this context ran on (-1 none yet; 0 thread-per-env, 1 head-per-wave fused, 2 cooperative fused, 3 step-wise
- * GEMM, 4 resident, 5 step-wise stream-K, 6 persistent stream-K), and -- when the shape fell off the fast dispatch table (K != 5 at 2 x 64; hidden widths
- * 65..127) -- why ("" otherwise; also printed once per context on stderr unless option QUIET is set).  The reference has one code path for every shape
+ * GEMM, 4 resident, 5 step-wise stream-K, 6 persistent stream-K), and -- when the shape fell off the fast dispatch table (2 x 64 nets with more heads than the
+ * fused kernels hold: K > 10, Ant > 8, half-cheetah > 9, or K > 5 on a shared device; hidden widths that are neither 64 nor multiples of 256; INTEGRATION.md
+ * section 9 has the table and the measured cost) -- why ("" otherwise; also printed once per context on stderr unless option QUIET is set).  The reference has one code path for every shape
  * (env_helpers.py:609-635); these two calls are how a caller learns which of this library's it got. */
 int32_t metrpo_last_rollout_kernel(const metrpo_ctx* ctx);
 const char* metrpo_rollout_note(const metrpo_ctx* ctx);

@@ -119,7 +119,7 @@ struct metrpo_ctx {
     hipStream_t side_stream[METRPO_MAX_PAR_ROUNDS - 1]; hipEvent_t ev_fork, ev_join[METRPO_MAX_PAR_ROUNDS - 1]; int side_ready;   // rollout_gemm.hip: independent rounds of a small-batch rollout run concurrently
     double* h_pinned;    // pinned host scratch for the per-trial read-back
     int n_sm;            // CU count (device property)
-    int upd_tiles_per_wave;   // MFMA update kernels: at least this many 16-sample tiles per wave before another block is added (METRPO_UPD_TILES_PER_WAVE)
+    int upd_tiles_per_wave;   // MFMA update kernels: at least this many 16-sample tiles per wave before another block is added (1; the option that set it was retired in round 6: experiments/upd_small.py)
     int n_cu_sched;      // CUs that actually ran this process's waves (probe.hip: census; 0 = not measured yet)
     int exclusive;       // the caller's metrpo_set_exclusive value (1 at metrpo_create); 0: the GPU is shared with other compute processes.  Read through ctx_exclusive(), which also honours option NO_RESIDENT
     std::string opt_val[OPT_COUNT]; bool opt_set[OPT_COUNT];   // METRPO_OPT_LIST: set by metrpo_create from the environment, then only by metrpo_set_option
