@@ -220,6 +220,21 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     c->pol_mfma = policy_mfma_select(pd);
     c->pol_f3 = policy_f3_select(pd);
     c->coop_cfg = coop_select_config(c);
+    c->coop_pad_cfg = -1; c->d_dyn_pad = nullptr;
+    if (c->coop_cfg < 0 && pd.dyn.n_layers == 3 && pd.dyn.dims[1] == pd.dyn.dims[2] && pd.dyn.dims[1] < 64) {      // narrow nets: zero-padded to the fused kernel's 64 x 64
+        const int32_t hid64[2] = {64, 64}, acts[2] = {pd.dyn.act[0], pd.dyn.act[1]};
+        if (build_net(&c->dyn_pad, pd.nin, hid64, acts, 2, pd.ns, METRPO_ACT_RELU, true)) {
+            const NetDesc real = pd.dyn;
+            pd.dyn = c->dyn_pad;
+            const int cfg = coop_select_config(c);                         // the table's view of the padded shape (env dims, activations, policy, K, LDS)
+            pd.dyn = real;
+            if (cfg >= 0) {
+                const size_t bytes = sizeof(float) * (size_t)pd.K * c->dyn_pad.n_params;
+                if (hipMalloc(&c->d_dyn_pad, bytes) != hipSuccess || hipMemset(c->d_dyn_pad, 0, bytes) != hipSuccess) { c->err = "hipMalloc failed (padded dynamics)"; return METRPO_EHIP; }
+                c->coop_pad_cfg = cfg;
+            }
+        }
+    }
     c->det_cfg = det_mfma_select(c);
     c->det_gemm = det_gemm_applicable(c) ? 1 : 0;
     c->rollout_variant = 0;
@@ -241,6 +256,7 @@ extern "C" int32_t metrpo_destroy(metrpo_ctx* c) {
     }
     for (int i = 0; i < c->fvp_ev_made; ++i) (void)hipEventDestroy(c->fvp_ev[i]);
     ws_sweep(c);
+    if (c->d_dyn_pad) (void)hipFree(c->d_dyn_pad);
     if (c->d_skp_tab) (void)hipFree(c->d_skp_tab);
     if (c->d_skp_stats) (void)hipFree(c->d_skp_stats);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -341,7 +357,7 @@ extern "C" int32_t metrpo_rollout(metrpo_ctx* c, const metrpo_rollout_args* a, v
         return set_err(c, METRPO_EINVAL, "rollout: d_init_obs, d_init_ts and d_init_model must be given together");
     if (a->B == 0 || a->T == 0) return METRPO_OK;
     c->rollout_note.clear();
-    if (c->mfma_cfg >= 0 || c->coop_cfg >= 0) {
+    if (c->mfma_cfg >= 0 || c->coop_cfg >= 0 || c->coop_pad_cfg >= 0) {
         int coop = 0;
         const int rc = launch_rollout_mfma(c, a, (hipStream_t)stream, &coop);
         if (rc != METRPO_EUNSUPPORTED) {
@@ -414,7 +430,7 @@ extern "C" int32_t metrpo_has_mfma_path(const metrpo_ctx* c) { return (c && c->m
 extern "C" int32_t metrpo_set_rollout_variant(metrpo_ctx* c, int32_t v) {
     if (!c) return METRPO_ENULL;
     c->rollout_variant = v;
-    return (v != 1 && c->coop_cfg >= 0) ? 2 : (c->mfma_cfg >= 0 ? 1 : (gemm_path_applicable(c) ? 3 : 0));
+    return (v != 1 && (c->coop_cfg >= 0 || (v == 0 && c->coop_pad_cfg >= 0))) ? 2 : (c->mfma_cfg >= 0 ? 1 : (gemm_path_applicable(c) ? 3 : 0));
 }
 // which policy-update kernels a batch of N samples would run on: 1 fused MFMA (policy_mfma.hip), 2 GEMM path (policy_gemm.hip), 0 generic
 extern "C" int32_t metrpo_update_path(const metrpo_ctx* c, int64_t N) {

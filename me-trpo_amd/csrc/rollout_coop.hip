@@ -40,7 +40,27 @@ int coop_select_config(metrpo_ctx* c) {
 // setting the wall time while 199 idle half of it), co-residency at 2 or 4 tiles per CU, the migrating schedule again at 2.4.  Envs with more
 // than 16 state dims (half-cheetah, Ant) always run one workgroup per CU: their two-per-CU instantiation spills 100+ registers and is
 // 1.6-2 x slower per tile-step.
-int launch_rollout_coop(metrpo_ctx* c, int idx, const RolloutK& r_in, hipStream_t st) {
+// Zero-padded copy of a narrow ensemble in the 64 x 64 layout (metrpo_internal.h: coop_pad_cfg).  One thread per element of the padded layout.
+__global__ void __launch_bounds__(256) k_pad_dyn(NetDesc src, NetDesc dst, int K, const float* __restrict__ s, float* __restrict__ d) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)K * dst.n_params) return;
+    const int k = (int)(idx / dst.n_params), o = (int)(idx % dst.n_params);
+    const float* sk = s + (size_t)k * src.n_params;
+    float v = 0.0f;
+    for (int l = 0; l < dst.n_layers; ++l) {
+        const int din = dst.dims[l], dout = dst.dims[l + 1];
+        if (o >= dst.w_off[l] && o < dst.w_off[l] + din * dout) {
+            const int i = (o - dst.w_off[l]) / dout, j = (o - dst.w_off[l]) % dout;
+            if (i < src.dims[l] && j < src.dims[l + 1]) v = sk[src.w_off[l] + i * src.dims[l + 1] + j];
+        } else if (o >= dst.b_off[l] && o < dst.b_off[l] + dout) {
+            const int j = o - dst.b_off[l];
+            if (j < src.dims[l + 1]) v = sk[src.b_off[l] + j];
+        }
+    }
+    d[idx] = v;
+}
+
+int launch_rollout_coop(metrpo_ctx* c, int idx, const RolloutK& r_in, hipStream_t st, bool padded) {
     const CoopEntry& en = coop_entry(idx);
     const size_t sh = sizeof(float) * (size_t)en.lds_floats;
     const int tiles = (r_in.B + 15) / 16;
@@ -79,7 +99,13 @@ int launch_rollout_coop(metrpo_ctx* c, int idx, const RolloutK& r_in, hipStream_
     const bool draws = r.eps || r.model_idx || r.sel_noise || r.reset_idx || r.reset_model;
     const coop_kernel_t kern = en.kern[one ? 1 : 0][draws ? 1 : 0];
     if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), sh, st, r, c->d_dyn, c->d_theta, c->d_norm);
+    const float* dyn = c->d_dyn;
+    if (padded) {
+        const long long n = (long long)c->pd.K * c->dyn_pad.n_params;
+        hipLaunchKernelGGL(k_pad_dyn, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->pd.dyn, c->dyn_pad, c->pd.K, c->d_dyn, c->d_dyn_pad);
+        dyn = c->d_dyn_pad;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), sh, st, r, dyn, c->d_theta, c->d_norm);
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;
 }

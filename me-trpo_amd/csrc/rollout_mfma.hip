@@ -410,6 +410,9 @@ int launch_rollout_mfma(metrpo_ctx* c, const metrpo_rollout_args* a, hipStream_t
     if (c->coop_cfg >= 0 && c->rollout_variant != 1) {
         const int rc = launch_rollout_coop(c, c->coop_cfg, r, st);           // METRPO_EUNSUPPORTED: more than 5 heads without a CU of their own per workgroup (below)
         if (rc != METRPO_EUNSUPPORTED) { if (coop) *coop = 1; return rc; }
+    } else if (c->coop_pad_cfg >= 0 && c->rollout_variant == 0) {            // two hidden layers narrower than 64: the same kernel on the zero-padded weights
+        const int rc = launch_rollout_coop(c, c->coop_pad_cfg, r, st, true);
+        if (rc != METRPO_EUNSUPPORTED) { if (coop) *coop = 1; return rc; }
     }
     if (c->mfma_cfg < 0) return METRPO_EUNSUPPORTED;
     const MfmaEntry& en = kTable[c->mfma_cfg];

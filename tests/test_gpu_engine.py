@@ -126,6 +126,34 @@ def test_cooperative_rollout_with_six_to_ten_heads(env, sam_mode, K):
     _rollout_parity_teacher_forced(env, sam_mode, False, 'coop', K)
 
 
+@pytest.mark.parametrize('env,sam_mode,K,w', [('swimmer', 'step_rand', 5, 48), ('hopper', 'model_mean_std', 3, 32), ('ant', 'step_rand', 5, 20), ('half_cheetah', 'model_med', 4, 50),
+                                              ('snake', 'eps_rand', 7, 63), ('swimmer', 'one_model', 5, 1)])
+def test_narrow_dynamics_nets_run_zero_padded_on_the_cooperative_kernel(env, sam_mode, K, w):
+    """Round 6: two hidden layers of equal width below 64 run on the fused cooperative kernel over a zero-padded copy of the weights in its 64 x 64 layout (the padded
+    units add exact zeros; until then: step-wise tile GEMMs, 2.7 ms where 64 x 64 takes 0.47 -- tools/width_table.py).  Same teacher-forced comparison against the oracle."""
+    _rollout_parity_teacher_forced(env, sam_mode, False, 'coop', K, hidden=(w, w))
+
+
+def test_padded_weights_follow_every_writer_of_the_dynamics():
+    """The padded copy is rebuilt in front of every rollout launch: set_dynamics_model (one head replaced) must show in the next rollout -- compared with a fresh context
+    that was given the final weights at once (bitwise)."""
+    env, K, w, B, T, H = 'swimmer', 4, 40, 96, 5, 5
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (w, w), (32, 32), seed=21)
+    pool_t = torch.tensor(pool, dtype=torch.float32, device=eng.device)
+    eng.rollout(B, T, H, 'step_rand', pool_t, seed=2)
+    assert eng.last_rollout_kernel() == 'mfma-cooperative' and eng.rollout_note() == ''
+    other = Hh.make_engine(env, K, (w, w), (32, 32), seed=22)[1]
+    eng.set_dynamics_model(2, np.concatenate([np.concatenate([other.Ws[l][2].ravel(), other.bs[l][2].ravel()]) for l in range(3)]).astype(np.float32))
+    a = eng.rollout(B, T, H, 'step_rand', pool_t, seed=3)
+    Ws = [W.copy() for W in dm.Ws]; bs = [b.copy() for b in dm.bs]
+    for l in range(3):
+        Ws[l][2] = other.Ws[l][2]; bs[l][2] = other.bs[l][2]
+    fresh = Hh.make_engine(env, K, (w, w), (32, 32), seed=21)[0]
+    fresh.set_dynamics_layers(Ws, bs, dm.in_mean, dm.in_std, dm.diff_mean, dm.diff_std)
+    b = fresh.rollout(B, T, H, 'step_rand', pool_t, seed=3)
+    assert torch.equal(a.obs, b.obs) and torch.equal(a.rew, b.rew)
+
+
 def test_cooperative_launch_rule_does_not_pick_the_slow_form():
     """The launch rule of rollout_coop.hip chooses between one workgroup per CU (tiles migrate) and two co-resident workgroups from constants MEASURED at K = 5
     (1.50 / 1.58 / 1.65 per pair-step).  If the kernel changes and the constants do not, the rule goes silently wrong -- so its pick is timed against the forced
@@ -185,9 +213,9 @@ def test_cooperative_rollout_more_than_five_heads_needs_a_cu_per_workgroup():
     np.testing.assert_allclose(cpu(c.obs), cpu(keep[0]), **TOL.CROSS_KERNEL)
 
 
-def _rollout_parity_teacher_forced(env, sam_mode, determ, variant, K):
+def _rollout_parity_teacher_forced(env, sam_mode, determ, variant, K, hidden=(64, 64)):
     B, T, H = 200, 12, 5
-    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, (64, 64), (32, 32), seed=7)
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, K, hidden, (32, 32), seed=7)
     force_generic = variant == 'generic'
     running = eng.set_rollout_variant({'head_per_wave': 1, 'coop_two_per_cu': 2}.get(variant, 0))
     if not force_generic:
