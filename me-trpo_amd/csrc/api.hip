@@ -221,7 +221,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
     c->pol_f3 = policy_f3_select(pd);
     c->coop_cfg = coop_select_config(c);
     c->coop_pad_cfg = -1; c->d_dyn_pad = nullptr;
-    if (c->coop_cfg < 0 && pd.dyn.n_layers == 3 && pd.dyn.dims[1] == pd.dyn.dims[2] && pd.dyn.dims[1] < 64) {      // narrow nets: zero-padded to the fused kernel's 64 x 64
+    if (c->coop_cfg < 0 && pd.dyn.n_layers == 3 && pd.dyn.dims[1] <= 64 && pd.dyn.dims[2] <= 64) {      // narrow nets (either width below 64): zero-padded to the fused kernel's 64 x 64
         const int32_t hid64[2] = {64, 64}, acts[2] = {pd.dyn.act[0], pd.dyn.act[1]};
         if (build_net(&c->dyn_pad, pd.nin, hid64, acts, 2, pd.ns, METRPO_ACT_RELU, true)) {
             const NetDesc real = pd.dyn;

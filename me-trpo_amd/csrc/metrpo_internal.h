@@ -72,7 +72,7 @@ struct metrpo_ctx {
     int mfma_cfg;        // index into the instantiation table, -1 = generic path only
     int pol_mfma;        // index into policy_mfma.hip's table, -1 = generic update kernels
     int coop_cfg;        // index into rollout_coop.hip's table, -1 = head-per-wave kernel (rollout_mfma.hip)
-    // two hidden layers of EQUAL width below 64 (round 6): the cooperative kernel on a zero-padded copy of the weights in the 64 x 64 layout (padded units: zero weights and
+    // two hidden layers of at most 64 units each, not both 64 (round 6): the cooperative kernel on a zero-padded copy of the weights in the 64 x 64 layout (padded units: zero weights and
     // bias -> relu(0) = 0 -> they add exact zeros); the copy is rebuilt from d_dyn in front of every rollout launch (one small kernel: no tracking of who wrote d_dyn)
     int coop_pad_cfg; float* d_dyn_pad; NetDesc dyn_pad;
     int rollout_variant; // test hook: 0 = fastest available, 1 = head-per-wave MFMA kernel

@@ -394,7 +394,7 @@ def test_from_params_builds_the_loop_of_a_params_file():
 def test_rollout_note_names_shapes_off_the_fast_table():
     """metrpo_rollout reports the kernel family it chose, and says why when a shape falls off the fast dispatch table (once per context on stderr)."""
     for K, hid, family, needle in ((5, (64, 64), 'mfma-cooperative', ''), (3, (64, 64), 'mfma-cooperative', ''), (7, (64, 64), 'mfma-cooperative', ''), (12, (64, 64), 'gemm-stepwise', 'K = 12'), (5, (96, 96), 'gemm-stepwise', '96x96'),       # round 5: widths below 128 take the tile GEMMs, not the thread-per-env kernel
-                                    (5, (8, 8), 'mfma-cooperative', ''), (5, (8, 12), 'generic', '8x12')):       # round 6: equal widths below 64 run zero-padded on the fused kernel
+                                    (5, (8, 8), 'mfma-cooperative', ''), (5, (8, 12), 'mfma-cooperative', ''), (5, (8, 12, 8), 'generic', '8x12x8')):       # round 6: two hidden layers of at most 64 units run zero-padded on the fused kernel
         eng, dm, theta, pdims, pool = Hh.make_engine('swimmer', K, hid, (32, 32), seed=3)
         eng.set_option('QUIET', '1')
         assert eng.get_option('quiet') == '1' and eng.get_option('STREAMK') is None and 'STREAMK' in eng.option_names()

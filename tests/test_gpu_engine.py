@@ -127,11 +127,11 @@ def test_cooperative_rollout_with_six_to_ten_heads(env, sam_mode, K):
 
 
 @pytest.mark.parametrize('env,sam_mode,K,w', [('swimmer', 'step_rand', 5, 48), ('hopper', 'model_mean_std', 3, 32), ('ant', 'step_rand', 5, 20), ('half_cheetah', 'model_med', 4, 50),
-                                              ('snake', 'eps_rand', 7, 63), ('swimmer', 'one_model', 5, 1)])
+                                              ('snake', 'eps_rand', 7, 63), ('swimmer', 'one_model', 5, 1), ('hopper', 'step_rand', 5, (24, 64)), ('swimmer', 'model_mean', 2, (64, 17))])
 def test_narrow_dynamics_nets_run_zero_padded_on_the_cooperative_kernel(env, sam_mode, K, w):
-    """Round 6: two hidden layers of equal width below 64 run on the fused cooperative kernel over a zero-padded copy of the weights in its 64 x 64 layout (the padded
+    """Round 6: two hidden layers of at most 64 units (not both 64; unequal widths included) run on the fused cooperative kernel over a zero-padded copy of the weights in its 64 x 64 layout (the padded
     units add exact zeros; until then: step-wise tile GEMMs, 2.7 ms where 64 x 64 takes 0.47 -- tools/width_table.py).  Same teacher-forced comparison against the oracle."""
-    _rollout_parity_teacher_forced(env, sam_mode, False, 'coop', K, hidden=(w, w))
+    _rollout_parity_teacher_forced(env, sam_mode, False, 'coop', K, hidden=w if isinstance(w, tuple) else (w, w))
 
 
 def test_padded_weights_follow_every_writer_of_the_dynamics():
