@@ -236,6 +236,7 @@ extern "C" int32_t metrpo_create(metrpo_ctx** out, int32_t device, const metrpo_
         }
     }
     c->det_cfg = det_mfma_select(c);
+    c->det_padded = (c->coop_cfg < 0 && c->coop_pad_cfg >= 0) ? 1 : 0;
     c->det_gemm = det_gemm_applicable(c) ? 1 : 0;
     c->rollout_variant = 0;
     (void)sched_cus(c, nullptr);                              // CU census here, not inside the first resident / cooperative launch (probe.hip)

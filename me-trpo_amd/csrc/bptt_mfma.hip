@@ -408,8 +408,9 @@ static const DetEntry kDet[] = {DENTRY(METRPO_ENV_SWIMMER), DENTRY(METRPO_ENV_HA
 // table index or -1: same shape conditions as the MFMA rollouts (dynamics 2x64 relu, policy 2x32 tanh, known env dims)
 int det_mfma_select(const metrpo_ctx* c) {
     const ProblemDesc& pd = c->pd;
-    if (c->mfma_cfg < 0 || pd.dyn.n_layers != 3 || pd.dyn.dims[1] != 64 || pd.dyn.dims[2] != 64 || pd.pol.n_layers != 3 ||
-        pd.pol.dims[1] != 32 || pd.pol.dims[2] != 32)
+    const bool exact = c->mfma_cfg >= 0 && pd.dyn.n_layers == 3 && pd.dyn.dims[1] == 64 && pd.dyn.dims[2] == 64;
+    const bool padded = c->coop_cfg < 0 && c->coop_pad_cfg >= 0;            // two hidden layers of at most 64 units: the zero-padded copy in the 64 x 64 layout (api.hip)
+    if ((!exact && !padded) || pd.pol.n_layers != 3 || pd.pol.dims[1] != 32 || pd.pol.dims[2] != 32)
         return -1;
     for (int i = 0; i < (int)(sizeof(kDet) / sizeof(kDet[0])); ++i)
         if (kDet[i].env == pd.env) return i;
@@ -423,7 +424,9 @@ int launch_det_forward(metrpo_ctx* c, int idx, const float* s0, int B, int T, do
     const size_t sh = sizeof(float) * (size_t)en.lds_floats;
     if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)en.fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     const int gx = (B + 63) / 64;
-    hipLaunchKernelGGL(en.fwd, dim3(gx, c->pd.K), dim3(256), sh, st, c->pd.K, B, T, gamma, c->d_dyn, c->d_theta, c->d_norm, s0, XS, WT,
+    const float* dyn = c->d_dyn;
+    if (c->det_padded) { const int rc = launch_pad_dyn(c, st); if (rc) return rc; dyn = c->d_dyn_pad; }
+    hipLaunchKernelGGL(en.fwd, dim3(gx, c->pd.K), dim3(256), sh, st, c->pd.K, B, T, gamma, dyn, c->d_theta, c->d_norm, s0, XS, WT,
                        (float*)nullptr, part);
     hipLaunchKernelGGL(k_det_cost_reduce, dim3(c->pd.K), dim3(64), 0, st, gx * 4, part, costs, (const double*)nullptr);
     HIP_TRY(c, hipGetLastError());
@@ -434,7 +437,9 @@ int launch_det_backward(metrpo_ctx* c, int idx, int B, int T, const float* XS, c
     const DetEntry& en = kDet[idx];
     const size_t sh = sizeof(float) * (size_t)en.lds_floats;
     if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)en.bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    hipLaunchKernelGGL(en.bwd, dim3((B + 63) / 64, c->pd.K), dim3(256), sh, st, c->pd.K, B, T, 1.0, c->d_dyn, c->d_theta, c->d_norm,
+    const float* dyn = c->d_dyn;
+    if (c->det_padded) { const int rc = launch_pad_dyn(c, st); if (rc) return rc; dyn = c->d_dyn_pad; }
+    hipLaunchKernelGGL(en.bwd, dim3((B + 63) / 64, c->pd.K), dim3(256), sh, st, c->pd.K, B, T, 1.0, dyn, c->d_theta, c->d_norm,
                        (const float*)nullptr, const_cast<float*>(XS), const_cast<float*>(WT), GM, (double*)nullptr);
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;

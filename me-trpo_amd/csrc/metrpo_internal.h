@@ -75,6 +75,7 @@ struct metrpo_ctx {
     // two hidden layers of at most 64 units each, not both 64 (round 6): the cooperative kernel on a zero-padded copy of the weights in the 64 x 64 layout (padded units: zero weights and
     // bias -> relu(0) = 0 -> they add exact zeros); the copy is rebuilt from d_dyn in front of every rollout launch (one small kernel: no tracking of who wrote d_dyn)
     int coop_pad_cfg; float* d_dyn_pad; NetDesc dyn_pad;
+    int det_padded;      // the validation-cost / BPTT sweeps of bptt_mfma.hip run on the same padded copy
     int rollout_variant; // test hook: 0 = fastest available, 1 = head-per-wave MFMA kernel
     // --- workspaces for the update path (lazily sized) ---
     float* d_partials;   // [n_blocks][P+2] per-block partial sums
@@ -263,6 +264,7 @@ int mfma_select_config(metrpo_ctx*);
 int mfma_shape_config(const metrpo_ctx*);
 int coop_select_config(metrpo_ctx*);
 int launch_rollout_coop(metrpo_ctx*, int idx, const RolloutK&, hipStream_t, bool padded = false);
+int launch_pad_dyn(metrpo_ctx*, hipStream_t);      // d_dyn -> d_dyn_pad (zero-padded 64 x 64 layout)
 int launch_validation_cost(metrpo_ctx*, const float*, int, int, double, double*, hipStream_t);
 int launch_gae(metrpo_ctx*, const float*, const float*, const uint8_t*, const int32_t*, int, int, const double*,
                double, double, float*, float*, uint8_t*, double*, hipStream_t);

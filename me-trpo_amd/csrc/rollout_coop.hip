@@ -60,6 +60,13 @@ __global__ void __launch_bounds__(256) k_pad_dyn(NetDesc src, NetDesc dst, int K
     d[idx] = v;
 }
 
+int launch_pad_dyn(metrpo_ctx* c, hipStream_t st) {
+    const long long n = (long long)c->pd.K * c->dyn_pad.n_params;
+    hipLaunchKernelGGL(k_pad_dyn, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->pd.dyn, c->dyn_pad, c->pd.K, c->d_dyn, c->d_dyn_pad);
+    HIP_TRY(c, hipGetLastError());
+    return METRPO_OK;
+}
+
 int launch_rollout_coop(metrpo_ctx* c, int idx, const RolloutK& r_in, hipStream_t st, bool padded) {
     const CoopEntry& en = coop_entry(idx);
     const size_t sh = sizeof(float) * (size_t)en.lds_floats;
@@ -100,11 +107,7 @@ int launch_rollout_coop(metrpo_ctx* c, int idx, const RolloutK& r_in, hipStream_
     const coop_kernel_t kern = en.kern[one ? 1 : 0][draws ? 1 : 0];
     if (sh > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     const float* dyn = c->d_dyn;
-    if (padded) {
-        const long long n = (long long)c->pd.K * c->dyn_pad.n_params;
-        hipLaunchKernelGGL(k_pad_dyn, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->pd.dyn, c->dyn_pad, c->pd.K, c->d_dyn, c->d_dyn_pad);
-        dyn = c->d_dyn_pad;
-    }
+    if (padded) { const int rc = launch_pad_dyn(c, st); if (rc) return rc; dyn = c->d_dyn_pad; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), sh, st, r, dyn, c->d_theta, c->d_norm);
     HIP_TRY(c, hipGetLastError());
     return METRPO_OK;

@@ -27,6 +27,8 @@ def rel_l2(a, b):
     ('ant', 3, (64, 64), (32, 32), 130, 14, 0.95),             # running `dones` mask
     ('snake', 2, (64, 64), (32, 32), 64, 9, 1.0),
     ('humanoid', 2, (48, 48, 32), (20, 10, 5), 40, 6, 1.0),    # three hidden layers on both nets
+    ('swimmer', 4, (48, 20), (32, 32), 150, 12, 0.98),         # round 6: narrow nets on the MFMA sweeps over the zero-padded weights
+    ('ant', 3, (40, 40), (32, 32), 100, 10, 0.95),
 ])
 def test_bptt_gradient_matches_oracle(env, K, dh, ph, B, T, gamma):
     eng, dm, theta, pdims, pool = Hh.make_engine(env, K, dh, ph, seed=91)
@@ -56,10 +58,12 @@ def test_bptt_gradient_matches_oracle(env, K, dh, ph, B, T, gamma):
     assert cosine > 1.0 - 1e-7
 
 
-@pytest.mark.parametrize('env', ['swimmer', 'half_cheetah', 'hopper', 'snake', 'ant'])
-def test_mfma_and_generic_sweeps_agree(env):
-    """every env of the MFMA table: MFMA sweeps (default) vs the generic sweep kernels vs the oracle, incl. ragged batch sizes."""
-    eng, dm, theta, pdims, pool = Hh.make_engine(env, 3, (64, 64), (32, 32), seed=95)
+@pytest.mark.parametrize('env,dh', [('swimmer', (64, 64)), ('half_cheetah', (64, 64)), ('hopper', (64, 64)), ('snake', (64, 64)), ('ant', (64, 64)),
+                                    ('swimmer', (32, 50)), ('ant', (16, 16))])
+def test_mfma_and_generic_sweeps_agree(env, dh):
+    """every env of the MFMA table: MFMA sweeps (default) vs the generic sweep kernels vs the oracle, incl. ragged batch sizes; round 6: also narrow nets,
+    whose MFMA sweeps read the zero-padded copy of the weights."""
+    eng, dm, theta, pdims, pool = Hh.make_engine(env, 3, dh, (32, 32), seed=95)
     rng = np.random.RandomState(6)
     theta = theta + 0.2 * rng.randn(theta.size); theta[-dm.na:] = 0.0
     eng.set_policy(theta)
