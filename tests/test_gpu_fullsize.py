@@ -17,7 +17,17 @@ CONFIGS = {
     'C2-2x64': ('half_cheetah', 5, (64, 64), (32, 32), 2500, 200),
     'C3': ('ant', 10, (512, 512), (32, 32), 2500, 500),
     'C4': ('humanoid', 20, (1024, 1024, 1024), (100, 50, 25), 6250, 1000),
+    # round 6: shapes that moved to another kernel family
+    'C1-K10': ('swimmer', 10, (64, 64), (32, 32), 5000, 100),            # ten heads on the cooperative kernel (one workgroup per CU, tiles migrate)
+    'C1-48x40': ('swimmer', 5, (48, 40), (32, 32), 5000, 100),           # narrow nets on the cooperative kernel over zero-padded weights
+    'C2-strong8': ('half_cheetah', 5, (1024, 1024), (32, 32), 1250, 200),  # C2's share of an 8-GPU strong-scaling run: per-step stream-K launches instead of the persistent one
+    'C3-strong16': ('ant', 10, (512, 512), (32, 32), 1250, 500),
 }
+
+
+# the kernel family each shape is expected on (an exclusive 256-CU device): a silent change of the dispatch rules shows here
+FAMILY = {'C1': 'mfma-cooperative', 'C2': 'streamk-persistent', 'C2-2x64': 'mfma-cooperative', 'C3': 'streamk-persistent', 'C4': 'gemm-streamk',
+          'C1-K10': 'mfma-cooperative', 'C1-48x40': 'mfma-cooperative', 'C2-strong8': 'gemm-streamk', 'C3-strong16': 'gemm-streamk'}
 
 
 def build(name, seed=0):
@@ -44,6 +54,8 @@ def test_full_size_iteration_properties(name):
     tr = paths.traj
     T = tr.T
     done, tpath = tr.done.bool(), tr.tpath.long()
+    if torch.cuda.get_device_properties(eng.device).multi_processor_count == 256:
+        assert eng.last_rollout_kernel() == FAMILY[name], (name, eng.last_rollout_kernel(), eng.rollout_note())
     # --- step indices and done structure
     assert int(tpath.min()) == 0 and int(tpath.max()) <= H - 1
     assert bool((tpath[0] == 0).all())
