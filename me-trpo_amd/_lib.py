@@ -128,6 +128,7 @@ EXTRA_SYMBOLS = {
     'metrpo_schedulable_cus': (_I, [_P, _P]),
     'metrpo_debug_fvp_us': (_I, [_P, _P, _P]),
     'metrpo_debug_persist_stats': (_I, [_P, _P, _I, _P]),
+    'metrpo_debug_ws_retired': (_I, [_P, _P, _I]),
 }
 
 

@@ -109,6 +109,15 @@ extern "C" int32_t metrpo_debug_fvp_us(metrpo_ctx* c, double* mean_us, int32_t* 
 }
 
 
+// Diagnostics hook (tests/test_gpu_api.py): outgrown workspaces this context holds back instead of freeing them inside a launch entry point (metrpo_internal.h: ws_retire);
+// sweep != 0 frees them now (a synchronising call, like the sweep the library runs by itself past WS_RETIRED_MAX).  Returns the count in front of the sweep.
+extern "C" int32_t metrpo_debug_ws_retired(metrpo_ctx* c, unsigned long long* bytes, int32_t sweep) {
+    if (!c) return METRPO_ENULL;
+    const int32_t n = (int32_t)c->ws_retired.size();
+    if (bytes) *bytes = (unsigned long long)c->ws_retired_bytes;
+    if (sweep) ws_sweep(c);
+    return n;
+}
 // Diagnostics hook (tools/persist_stats.py): per-workgroup statistics of the last persistent stream-K launch made with option PERSIST_STATS set
 // (mlp_persist.h: SkpArgs::stats), 8 values per workgroup; returns the number of workgroups (0: none recorded).
 extern "C" int32_t metrpo_debug_persist_stats(metrpo_ctx* c, unsigned long long* out, int32_t cap_wgs, void* stream) {

@@ -209,6 +209,13 @@ class Engine(object):
         self._chk(lib.metrpo_debug_fvp_us(self._ctx, C.byref(us), C.byref(n)))
         return float(us.value), int(n.value)
 
+    def retired_workspaces(self, sweep=False):
+        """Diagnostics: (count, bytes) of outgrown workspaces the context keeps until destroy (a launch entry point never frees: hipFree waits for every stream);
+        sweep=True frees them now (synchronising)."""
+        b = C.c_ulonglong(0)
+        n = int(lib.metrpo_debug_ws_retired(self._ctx, C.byref(b), int(bool(sweep))))
+        return n, int(b.value)
+
     def update_path(self, N):
         """Kernel family the policy update of an N-sample batch runs on: 'mfma' (fused), 'gemm' or 'generic'."""
         return {1: 'mfma', 2: 'gemm', 0: 'generic'}[int(lib.metrpo_update_path(self._ctx, int(N)))]
