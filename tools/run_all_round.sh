@@ -21,4 +21,4 @@ for c in C2 C3 C0an C0hu C0p; do
 done
 (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace -d /tmp/prof_C4 -o t -- python $OLDPWD/bench.py --config C4 --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2>&1)
 python tools/rocpd_stats.py /tmp/prof_C4/t_results.db > $out/${tag}_bench_C4.kernel_stats.txt; rm -rf /tmp/prof_C4
-head -8 $out/${tag}_bench_C1.kernel_stats.txt
+head -8 $out/${tag}_C1_drv.kernel_stats.txt
