@@ -458,7 +458,7 @@ def main():
                     gc.enable()
                 out["strong"] = {"ms_per_step": dt_s / args.steps * 1e3, "value": K * B_s * float(np.mean(T_s)) * comm.world / (dt_s / args.steps),
                                  "unit": "env-steps/s", "B_per_gpu": B_s, "B_total": B_s * comm.world, "steps": args.steps, "warmup": args.warmup,
-                                 "rollout_kernel": eng_s.last_rollout_kernel(), "transport": transport_s or ("torch.distributed %s via host callback" % backend),
+                                 "rollout_kernel": eng_s.last_rollout_kernel(), "transport": ("single rank: no exchange" if comm.world == 1 else (transport_s or ("torch.distributed %s via host callback" % backend))),
                                  "note": "second timed region of this command: config B = %d divided over %d ranks (strong scaling; `value` / `ms_per_step` of the line are the "
                                          "weak-scaling region, %d envs per rank)" % (cfg['B'], comm.world, B)}
             except Exception as e:                              # the second region must not cost the run its line
